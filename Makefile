@@ -1,0 +1,41 @@
+# Build recipes.  `make` builds the gfx950 shared library (hipcc cross-compiles without a GPU);
+# `make emu` builds the CPU emulation of the same kernel sources (TEST INFRASTRUCTURE ONLY, see
+# tests/emu/README.md).
+HIPCC ?= /opt/rocm/bin/hipcc
+CSRC := pace_amd/csrc
+SRCS := $(CSRC)/capi.hip $(CSRC)/k_fxadv.hip $(CSRC)/k_fvtp2d.hip $(CSRC)/k_delnflux.hip $(CSRC)/k_dsw.hip $(CSRC)/k_riem3.hip
+HDRS := $(CSRC)/common.h $(CSRC)/kernels.h include/pace_hip.h
+# -ffp-contract=off: no FMA contraction, so horizontal stencils are bit-comparable with the numpy oracle.
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+OBJS := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
+
+all: pace_amd/libpace_hip.so
+
+build/hip/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/hip
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+pace_amd/libpace_hip.so: $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OBJS) -o $@
+
+EMU_TI ?= 64
+EMU_TJ ?= 16
+EMUFLAGS := -O2 -g -std=c++17 -fPIC -ffp-contract=off -DPACE_EMU -Itests/emu -x c++ $(EMU_EXTRA)
+EMUOBJS := $(patsubst $(CSRC)/%.hip,build/emu/%.o,$(SRCS))
+
+build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	g++ $(EMUFLAGS) -c $< -o $@
+
+build/emu/hip_emu.o: tests/emu/hip_emu.cpp tests/emu/hip_emu.h
+	@mkdir -p build/emu
+	g++ -O2 -g -std=c++17 -fPIC -Itests/emu -c $< -o $@
+
+emu: tests/emu/libpace_emu.so
+tests/emu/libpace_emu.so: $(EMUOBJS) build/emu/hip_emu.o
+	g++ -shared -fPIC $(EMUOBJS) build/emu/hip_emu.o -o $@
+
+clean:
+	rm -rf build pace_amd/libpace_hip.so tests/emu/libpace_emu.so
+
+.PHONY: all emu clean

@@ -1,0 +1,134 @@
+/* pace_hip.h -- C ABI of libpace_hip.so: MI355X (gfx950) kernels for the FV3 acoustic substep.
+ *
+ * This is the drop-in boundary: each entry point replaces what the reference executes *under*
+ * one of its Python classes (a chain of GT4Py FrozenStencil launches, dsl/pace/dsl/stencil.py:395-434).
+ * Plain pointers and sizes only; no allocation, no global state, re-entrant per stream.  All
+ * `double*` arguments are DEVICE pointers unless stated otherwise.  Every function returns
+ * PACE_OK (0) or a negative PACE_ERR_* code; nothing is written on error.
+ *
+ * Field layout: 3-D fields are [k][j][i], i fastest, logical shape (N+7, N+7, nz+1) with origin
+ * (3,3,0) exactly as the reference allocates them (util/pace/util/initialization/sizer.py:132-155);
+ * row stride `sj` (>= N+7) and level stride `sk` (>= sj*(N+7)) are given in pace_geom_t.  2-D metric
+ * fields share the row stride.  K-fields are dense arrays of nk (or nk+1) doubles.
+ */
+#ifndef PACE_HIP_H
+#define PACE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PACE_OK 0
+#define PACE_ERR_ARG (-1)
+#define PACE_ERR_LAUNCH (-2)
+#define PACE_ERR_UNSUPPORTED (-3)
+
+typedef struct {
+  int32_t n;   /* cells per tile edge (C<n>) */
+  int32_t nk;  /* number of layers nz */
+  int32_t sj;  /* row stride in doubles */
+  int32_t pad_;
+  int64_t sk;  /* level stride in doubles */
+} pace_geom_t;
+
+/* Read-only grid metrics, i.e. pace.util.grid.GridData / DampingCoefficients
+ * (util/pace/util/grid/helper.py:21-45,306-530).  2-D device arrays with row stride sj. */
+typedef struct {
+  const double *area, *rarea, *rarea_c;
+  const double *dx, *dy, *dxa, *dya, *dxc, *dyc;
+  const double *rdx, *rdy, *rdxa, *rdya, *rdxc, *rdyc;
+  const double *cosa, *rsina, *cosa_u, *cosa_v, *cosa_s;
+  const double *sina_u, *sina_v, *rsin_u, *rsin_v, *rsin2;
+  const double *sin_sg1, *sin_sg2, *sin_sg3, *sin_sg4;
+  const double *cos_sg1, *cos_sg2, *cos_sg3, *cos_sg4;
+  const double *del6_u, *del6_v, *divg_u, *divg_v;
+  const double *fC, *fC_agrid;
+  const double *edge_w, *edge_e; /* length nj, indexed by j */
+  const double *edge_s, *edge_n; /* length ni, indexed by i */
+  /* a2b_ord4 corner extrapolation weights x1/(x2-x1) (a2b_ord4.py:43-56) for the corner
+   * points sw(is,js), nw-stencil(ie+1,js), ne(ie+1,je+1), se-stencil(is,je+1), three diagonals
+   * each, precomputed on the host from lon/lat (HOST values, copied by value). */
+  double a2b_corner_w[4][3];
+  double da_min, da_min_c;
+} pace_metrics_t;
+
+/* Column namelist (d_sw.get_column_namelist, fv3core/pace/fv3core/stencils/d_sw.py:633-683)
+ * expanded to one value per level; HOST arrays of length nk. */
+typedef struct {
+  const double *nord, *nord_v, *nord_w, *nord_t;
+  const double *damp_vt, *damp_w, *damp_t;
+  const double *d2_divg, *d_con, *ke_bg;
+  /* calc_damp (delnflux.py:21-38) = (damp_c * da)^(nord+1), evaluated by the host exactly where the
+   * reference evaluates it: fac_vt = (damp_vt, da_min, nord_v), fac_t = (damp_t, da_min, nord_t) in
+   * DelnFlux.__init__ (delnflux.py:1001-1003); fac_vt_c = (damp_vt, da_min_c, nord_v),
+   * fac_w_c = (damp_w, da_min_c, nord_w) in d_sw.py:924-933. */
+  const double *fac_vt, *fac_t, *fac_vt_c, *fac_w_c;
+} pace_column_t;
+
+typedef struct {
+  int32_t hord_dp, hord_tm, hord_vt, hord_mt;
+  int32_t nord;
+  int32_t do_skeb;
+  double dddmp, d4_bg, d_con;
+} pace_dsw_config_t;
+
+/* ---- FiniteVolumeFluxPrep.__call__ (fv3core/pace/fv3core/stencils/fxadv.py:565-661) ---- */
+int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const double* uc, const double* vc,
+               double* crx, double* cry, double* x_area_flux, double* y_area_flux, double* uc_contra,
+               double* vc_contra, double dt, void* stream);
+
+/* ---- FiniteVolumeTransport.__call__ without damping (fvtp2d.py:262-345).  x/y_mass_flux may be
+ * NULL (area fluxes are used as unit fluxes).  hord in {5, 6}.  nlev = number of levels
+ * processed (nk, or nk+1 for interface fields).  q's corner halos are NOT rewritten: corner reads
+ * go through the copy_corners index map, which yields identical fluxes. */
+int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
+                const double* cry, const double* x_area_flux, const double* y_area_flux, double* q_x_flux,
+                double* q_y_flux, const double* x_mass_flux, const double* y_mass_flux, int hord, int nlev,
+                void* stream);
+
+/* ---- DelnFluxNoSG.__call__ (delnflux.py:1050-1261): damping fluxes fx2, fy2 of q.
+ * nord_k, damp_k: DEVICE arrays, one entry per level (see DESIGN.md for how the reference's
+ * nord0..nord3 externals map to per-level values).  If mass_given != 0, d2 starts from q
+ * (copy_stencil_interval) instead of damp*q.  nmax = max(nord_k). */
+int pace_delnflux_nosg(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, double* fx2,
+                       double* fy2, const double* damp_k, const double* nord_k, int nmax, int mass_given,
+                       int nlev, void* stream);
+
+/* ---- DelnFlux.__call__ (delnflux.py:945-1047): fx, fy += damping flux (mass-weighted if
+ * mass != NULL).  damp_k = (damp_c*da_min)^(nord+1) per level (calc_damp, delnflux.py:21-38). */
+int pace_delnflux(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, double* fx, double* fy,
+                  const double* mass, const double* damp_k, const double* nord_k, int nmax, int nlev,
+                  void* stream);
+
+/* ---- AGrid2BGridFourthOrder.__call__ (a2b_ord4.py:668-761) on levels [k0, k1). ---- */
+int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, double* qin, double* qout, int k0, int k1,
+                  int replace, void* stream);
+
+/* ---- DGridShallowWaterLagrangianDynamics.__call__ (d_sw.py:935-1237).
+ * workspace: DEVICE scratch of pace_d_sw_workspace_bytes() bytes, owned by the caller for the
+ * object's lifetime (the reference allocates its temporaries in __init__, d_sw.py:765-784);
+ * it also carries uc_contra / vc_contra between calls.  col holds HOST arrays. */
+int64_t pace_d_sw_workspace_bytes(const pace_geom_t* geom);
+/* Once per object, after zero-filling the workspace: uploads the column namelist (synchronises). */
+int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream);
+int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
+              const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
+              double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
+              double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx, double* yfx,
+              double* q_con, const double* zh, double* heat_source, double* diss_est, double dt, void* stream);
+
+/* ---- NonhydrostaticVerticalSolver.__call__ (riem_solver3.py:208-321), compute domain.
+ * zs, ws: 2-D.  workspace: pace_riem_solver3_workspace_bytes() bytes of DEVICE scratch. */
+int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom);
+int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, double dt, const double* cappa,
+                      double ptop, const double* zs, const double* ws, double* delz, const double* q_con,
+                      const double* delp, const double* pt, double* zh, double* pe, double* ppe, double* pk3,
+                      double* pk, double* peln, double* w, double p_fac, void* stream);
+
+const char* pace_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI in include/pace_hip.h.
+
+The product path is ``load()``: it loads ``pace_amd/libpace_hip.so`` (built in-tree by
+``make`` / ``__graft_entry__.build()``) and raises if it is missing -- there is no CPU fallback.
+``Library(path)`` with an explicit path exists so the test-suite can also bind
+``tests/emu/libpace_emu.so`` (the same kernel sources compiled for the CPU; test infrastructure).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libpace_hip.so")
+
+c_dp = C.c_void_p  # device pointer to double
+
+
+class Geom(C.Structure):
+    _fields_ = [("n", C.c_int32), ("nk", C.c_int32), ("sj", C.c_int32), ("pad_", C.c_int32), ("sk", C.c_int64)]
+
+
+METRIC_2D = (
+    "area rarea rarea_c dx dy dxa dya dxc dyc rdx rdy rdxa rdya rdxc rdyc cosa rsina cosa_u cosa_v cosa_s "
+    "sina_u sina_v rsin_u rsin_v rsin2 sin_sg1 sin_sg2 sin_sg3 sin_sg4 cos_sg1 cos_sg2 cos_sg3 cos_sg4 "
+    "del6_u del6_v divg_u divg_v fC fC_agrid"
+).split()
+METRIC_1D = ["edge_w", "edge_e", "edge_s", "edge_n"]
+
+
+class Metrics(C.Structure):
+    _fields_ = (
+        [(n, c_dp) for n in METRIC_2D]
+        + [(n, c_dp) for n in METRIC_1D]
+        + [("a2b_corner_w", (C.c_double * 3) * 4), ("da_min", C.c_double), ("da_min_c", C.c_double)]
+    )
+
+
+COLUMN_FIELDS = "nord nord_v nord_w nord_t damp_vt damp_w damp_t d2_divg d_con ke_bg fac_vt fac_t fac_vt_c fac_w_c".split()
+
+
+class Column(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in COLUMN_FIELDS]
+
+
+class DswConfig(C.Structure):
+    _fields_ = [
+        ("hord_dp", C.c_int32), ("hord_tm", C.c_int32), ("hord_vt", C.c_int32), ("hord_mt", C.c_int32),
+        ("nord", C.c_int32), ("do_skeb", C.c_int32), ("dddmp", C.c_double), ("d4_bg", C.c_double), ("d_con", C.c_double),
+    ]
+
+
+class PaceError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported configuration"}
+
+_P = C.POINTER
+_PROTOS = {
+    "pace_version": (C.c_char_p, []),
+    "pace_fxadv": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 8 + [C.c_double, C.c_void_p]),
+    "pace_fvtp2d": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 9 + [C.c_int, C.c_int, C.c_void_p]),
+    "pace_delnflux_nosg": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pace_delnflux": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    "pace_a2b_ord4": (C.c_int, [_P(Geom), _P(Metrics), c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pace_d_sw_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_d_sw_prepare": (C.c_int, [_P(Geom), _P(Column), c_dp, C.c_void_p]),
+    "pace_d_sw": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
+    "pace_riem_solver3_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_riem_solver3": (
+        C.c_int,
+        [_P(Geom), c_dp, C.c_int, C.c_double, c_dp, C.c_double] + [c_dp] * 13 + [C.c_double, C.c_void_p],
+    ),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class Library:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise PaceError(
+                f"{path} not found: build it with `make` (or __graft_entry__.build()). "
+                "pace_amd has no CPU fallback -- the HIP library is required."
+            )
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise PaceError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+    def version(self):
+        return self.cdll.pace_version().decode()
+
+
+_default = None
+
+
+def load():
+    """The product library (gfx950).  Raises PaceError if it has not been built."""
+    global _default
+    if _default is None:
+        _default = Library(DEFAULT_LIB)
+    return _default

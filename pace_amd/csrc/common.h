@@ -1,0 +1,137 @@
+// Shared device-side definitions for the FV3 acoustic-step kernels (gfx950 / CDNA4).
+//
+// Data layout (DESIGN.md "HBM layout"): every 3-D field is [k][j][i] with i fastest, row stride
+// sj >= ni = N+7 doubles (padded to a multiple of 16 = 128 B so each 64-lane wave issues aligned,
+// fully coalesced 512 B rows), level stride sk = sj*nj.  Index space is the reference's
+// (dsl/pace/dsl/stencil.py:629-667): halo 3, compute domain is..ie = 3..N+2 in both directions,
+// one tile per device so the tile edges coincide with is/ie/js/je.
+#pragma once
+#ifdef PACE_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+#include "../../include/pace_hip.h"
+
+struct Geo {
+  int n, nk, ni, nj, sj;
+  long sk;
+  int is, ie, js, je;
+};
+
+static inline Geo make_geo(const pace_geom_t* g) {
+  Geo o;
+  o.n = g->n;
+  o.nk = g->nk;
+  o.ni = g->n + 7;
+  o.nj = g->n + 7;
+  o.sj = g->sj;
+  o.sk = g->sk;
+  o.is = 3;
+  o.ie = g->n + 2;
+  o.js = 3;
+  o.je = g->n + 2;
+  return o;
+}
+
+typedef pace_metrics_t Met;
+
+#define IDX2(g, i, j) ((long)(i) + (long)(j) * (g).sj)
+#define IDX3(g, i, j, k) ((long)(i) + (long)(j) * (g).sj + (long)(k) * (g).sk)
+
+// ppm.py:6-19
+#define PPM_C1 (-2.0 / 14.0)
+#define PPM_C2 (11.0 / 14.0)
+#define PPM_C3 (5.0 / 14.0)
+#define PPM_P1 (7.0 / 12.0)
+#define PPM_P2 (-1.0 / 12.0)
+
+// ---------------------------------------------------------------------------------------------
+// Corner index maps (stencils/pace/stencils/corners.py:307-425; closed forms derived in
+// oracle/corner_ops.py).  A read of an A-grid field "with corners copied in x (or y)" is a read
+// of the raw field at the mapped index, so no kernel ever rewrites the corner halos.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void remap_agrid_x(const Geo& g, int& i, int& j) {
+  const bool w = i < g.is, e = i > g.ie, s = j < g.js, n = j > g.je;
+  if (!((w || e) && (s || n))) return;
+  const int a = w ? g.is - 1 - i : i - g.ie - 1;  // cells away from the tile edge in i
+  const int b = s ? g.js - 1 - j : j - g.je - 1;  // ... in j
+  if (a > 2 || b > 2) return;                     // the storage has one spare row/column past the halo
+  i = w ? g.is - 1 - b : g.ie + 1 + b;
+  j = s ? g.js + a : g.je - a;
+}
+
+__device__ __forceinline__ void remap_agrid_y(const Geo& g, int& i, int& j) {
+  const bool w = i < g.is, e = i > g.ie, s = j < g.js, n = j > g.je;
+  if (!((w || e) && (s || n))) return;
+  const int a = w ? g.is - 1 - i : i - g.ie - 1;
+  const int b = s ? g.js - 1 - j : j - g.je - 1;
+  if (a > 2 || b > 2) return;
+  i = w ? g.is + b : g.ie - b;
+  j = s ? g.js - 1 - a : g.je + 1 + a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PPM interface value / flux for ord < 8 (xppm.py:19-72,148-181; yppm.py is the transpose).
+// q[] holds the six cell values at positions pos-3 .. pos+2 along the sweep axis, d[] the matching
+// A-grid spacings (only read next to a tile edge).  s/e are the tile start/end along the axis.
+// ---------------------------------------------------------------------------------------------
+template <class DX>
+__device__ __forceinline__ double ppm_al(const double* q, int off, int pos, int s, int e, DX dxa) {
+  // q[off + m] is the cell value at position pos + m
+  const double qm2 = q[off - 2], qm1 = q[off - 1], q0 = q[off], qp1 = q[off + 1];
+  if (pos == s - 1 || pos == e) return PPM_C1 * qm2 + PPM_C2 * qm1 + PPM_C3 * q0;
+  if (pos == s || pos == e + 1) {
+    const double dm2 = dxa(pos - 2), dm1 = dxa(pos - 1), d0 = dxa(pos), dp1 = dxa(pos + 1);
+    return 0.5 * (((2.0 * dm1 + dm2) * qm1 - dm1 * qm2) / (dm2 + dm1) + ((2.0 * d0 + dp1) * q0 - d0 * qp1) / (d0 + dp1));
+  }
+  if (pos == s + 1 || pos == e + 2) return PPM_C3 * qm1 + PPM_C2 * q0 + PPM_C1 * qp1;
+  return PPM_P1 * (qm1 + q0) + PPM_P2 * (qm2 + qp1);
+}
+
+// Mean value advected through the interface at position pos (between cells pos-1 and pos).
+// q6[m] = cell value at pos-3+m, m = 0..5.
+template <int MORD, class DX>
+__device__ __forceinline__ double ppm_flux6(const double* q6, double c, int pos, int s, int e, DX dxa) {
+  const double al_m = ppm_al(q6, 2, pos - 1, s, e, dxa);
+  const double al_0 = ppm_al(q6, 3, pos, s, e, dxa);
+  const double al_p = ppm_al(q6, 4, pos + 1, s, e, dxa);
+  const double qm = q6[2], q0 = q6[3];
+  const double bl_m = al_m - qm, br_m = al_0 - qm, b0_m = bl_m + br_m;
+  const double bl_0 = al_0 - q0, br_0 = al_p - q0, b0_0 = bl_0 + br_0;
+  bool s_m, s_0;
+  if (MORD == 5) {
+    s_m = bl_m * br_m < 0;
+    s_0 = bl_0 * br_0 < 0;
+  } else {
+    s_m = (3.0 * fabs(b0_m)) < fabs(bl_m - br_m);
+    s_0 = (3.0 * fabs(b0_0)) < fabs(bl_0 - br_0);
+  }
+  const double mask = (s_m || s_0) ? 1.0 : 0.0;
+  if (c > 0.0) {
+    const double fx1 = (1.0 - c) * (br_m - c * b0_m);
+    return qm + fx1 * mask;
+  } else {
+    const double fx1 = (1.0 + c) * (bl_0 + c * b0_0);
+    return q0 + fx1 * mask;
+  }
+}
+
+#define PACE_CHECK_LAUNCH()                               \
+  do {                                                    \
+    hipError_t err__ = hipGetLastError();                 \
+    if (err__ != hipSuccess) return PACE_ERR_LAUNCH;      \
+  } while (0)
+
+static inline dim3 plane_grid(const Geo& g, int nlev) {
+  return dim3((unsigned)(((long)g.sj * g.nj + 255) / 256), (unsigned)nlev, 1);
+}
+// flattened plane index -> (i, j); returns false for pad lanes / out of plane
+#define PLANE_IJK(g)                                                  \
+  const long p__ = (long)blockIdx.x * 256 + threadIdx.x;             \
+  const int j = (int)(p__ / (g).sj);                                  \
+  const int i = (int)(p__ - (long)j * (g).sj);                        \
+  const int k = (int)blockIdx.y;                                      \
+  if (j >= (g).nj || i >= (g).ni) return;

@@ -1,0 +1,695 @@
+// D-grid shallow-water step (Fortran d_sw) -- everything in
+// fv3core/pace/fv3core/stencils/d_sw.py:33-608 and divergence_damping.py:23-632 / a2b_ord4.py that is
+// not transport (k_fvtp2d.hip), del-n damping (k_delnflux.hip) or flux preparation (k_fxadv.hip).
+// All kernels are one thread per (i, j, k) point with i fastest (coalesced rows); neighbour values are
+// re-read through L1/L2 and multi-stage reference temporaries (u_contra_dyc, v_contra_dxc, uc/vc of the
+// divergence iteration, qx/qy of a2b_ord4, ubt/vbt ...) are recomputed in registers instead of being
+// stored, so each kernel is a pure streaming pass.  HBM-bound.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+#define DCON_THRESHOLD 1e-5
+
+// ------------------------------------------------------------------------------------------------
+// flux_capacitor (d_sw.py:33-60) + heat_diss (:63-103)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_fluxcap_heatdiss(Geo g, Met m, double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ mfx,
+                   double* __restrict__ mfy, const double* __restrict__ crx, const double* __restrict__ cry,
+                   const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fx2,
+                   const double* __restrict__ fy2, const double* __restrict__ w, double* __restrict__ heat_s,
+                   double* __restrict__ diss_est, double* __restrict__ dw, const double* __restrict__ damp_w,
+                   const double* __restrict__ ke_bg, double dt) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  if (i >= g.is && i <= g.ie + 1) cx[c] = cx[c] + crx[c];
+  if (j >= g.js && j <= g.je + 1) cy[c] = cy[c] + cry[c];
+  const bool ci = (i >= g.is && i <= g.ie), cj = (j >= g.js && j <= g.je);
+  if (cj && i >= g.is && i <= g.ie + 1) mfx[c] = mfx[c] + fx[c];
+  if (ci && j >= g.js && j <= g.je + 1) mfy[c] = mfy[c] + fy[c];
+  if (ci && cj) {
+    double hs = 0.0;
+    if (damp_w[k] > 1e-5) {
+      const double dd8 = ke_bg[k] * fabs(dt);
+      const double d = (fx2[c] - fx2[c + 1] + fy2[c] - fy2[c + g.sj]) * m.rarea[IDX2(g, i, j)];
+      dw[c] = d;
+      hs = dd8 - d * (w[c] + 0.5 * d);
+    }
+    heat_s[c] = hs;
+    diss_est[c] = hs;
+  }
+}
+
+// apply_fluxes (d_sw.py:122-145): q = q*delp + flux_increment(gx, gy)
+__global__ void __launch_bounds__(256)
+k_apply_fluxes(Geo g, Met m, double* __restrict__ q, const double* __restrict__ delp,
+               const double* __restrict__ gx, const double* __restrict__ gy) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
+  const long c = IDX3(g, i, j, k);
+  q[c] = q[c] * delp[c] + (gx[c] - gx[c + 1] + gy[c] - gy[c + g.sj]) * m.rarea[IDX2(g, i, j)];
+}
+
+// apply_pt_delp_fluxes (d_sw.py:148-201) + adjust_w_and_qcon (:331-350)
+__global__ void __launch_bounds__(256)
+k_pt_delp_w_qcon(Geo g, Met m, double* __restrict__ pt, double* __restrict__ delp, double* __restrict__ w,
+                 double* __restrict__ q_con, const double* __restrict__ gx, const double* __restrict__ gy,
+                 const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ dw,
+                 const double* __restrict__ damp_w) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
+  const long c = IDX3(g, i, j, k);
+  const double ra = m.rarea[IDX2(g, i, j)];
+  const double ptn = pt[c] * delp[c] + (gx[c] - gx[c + 1] + gy[c] - gy[c + g.sj]) * ra;
+  const double dn = delp[c] + (fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) * ra;
+  pt[c] = ptn / dn;
+  delp[c] = dn;
+  double wn = w[c] / dn;
+  if (damp_w[k] > 1e-5) wn = wn + dw[c];
+  w[c] = wn;
+  q_con[c] = q_con[c] / dn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_kinetic_energy (d_sw.py:204-298) with xtp_u / ytp_v (xtp_u.py:9-91, ytp_v.py:9-91), ord < 8
+// ------------------------------------------------------------------------------------------------
+template <int MORD, class DX>
+__device__ __forceinline__ double wind_flux6(const double* q6, double csign, double cfl, int pos, int s, int e,
+                                             DX dxa, bool zero_m, bool zero_0) {
+  const double al_m = ppm_al(q6, 2, pos - 1, s, e, dxa);
+  const double al_0 = ppm_al(q6, 3, pos, s, e, dxa);
+  const double al_p = ppm_al(q6, 4, pos + 1, s, e, dxa);
+  const double qm = q6[2], q0 = q6[3];
+  double bl_m = al_m - qm, br_m = al_0 - qm;
+  double bl_0 = al_0 - q0, br_0 = al_p - q0;
+  if (zero_m) { bl_m = 0.0; br_m = 0.0; }
+  if (zero_0) { bl_0 = 0.0; br_0 = 0.0; }
+  const double b0_m = bl_m + br_m, b0_0 = bl_0 + br_0;
+  bool s_m, s_0;
+  if (MORD == 5) {
+    s_m = bl_m * br_m < 0;
+    s_0 = bl_0 * br_0 < 0;
+  } else {
+    s_m = (3.0 * fabs(b0_m)) < fabs(bl_m - br_m);
+    s_0 = (3.0 * fabs(b0_0)) < fabs(bl_0 - br_0);
+  }
+  const double mask = (s_m || s_0) ? 1.0 : 0.0;
+  const double fx0 = (cfl > 0.0) ? (1.0 - cfl) * (br_m - cfl * b0_m) : (1.0 + cfl) * (bl_0 + cfl * b0_0);
+  return (csign > 0.0) ? (qm + fx0 * mask) : (q0 + fx0 * mask);
+}
+
+template <int MORD>
+__global__ void __launch_bounds__(256)
+k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __restrict__ vc,
+                 const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ ut,
+                 const double* __restrict__ vt, double* __restrict__ ke, double dt) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  const bool jedge = (j == g.js || j == g.je + 1), iedge = (i == g.is || i == g.ie + 1);
+  double kev;
+  if (iedge && jedge) {
+    // all_corners_ke / corner_ke (d_sw.py:259-298)
+    int io1, jo1, io2;
+    double vs;
+    if (i == g.is && j == g.js) { io1 = 0; jo1 = 0; io2 = -1; vs = 1.0; }
+    else if (i == g.ie + 1 && j == g.js) { io1 = -1; jo1 = 0; io2 = 0; vs = -1.0; }
+    else if (i == g.ie + 1 && j == g.je + 1) { io1 = -1; jo1 = -1; io2 = 0; vs = 1.0; }
+    else { io1 = 0; jo1 = -1; io2 = -1; vs = -1.0; }
+    const double dt6 = dt / 6.0;
+    const double ut0 = ut[c], utm = ut[c - sj], vt0 = vt[c], vtm = vt[c - 1];
+    const double u0 = u[c], um = u[c - 1], v0 = v[c], vm = v[c - sj];
+    kev = dt6 * ((ut0 + utm) * ((io1 + 1) * u0 - (io1 * um)) + (vt0 + vtm) * ((jo1 + 1) * v0 - (jo1 * vm)) +
+                 (((jo1 + 1) * ut0 - (jo1 * utm)) + vs * ((io1 + 1) * vt0 - (io1 * vtm))) *
+                     ((io2 + 1) * u0 - (io2 * um)));
+  } else {
+    const double ub_cov = 0.5 * (uc[c - sj] + uc[c]);
+    const double vb_cov = 0.5 * (vc[c - 1] + vc[c]);
+    double ub = (ub_cov - vb_cov * m.cosa[c2]) * m.rsina[c2];
+    double vb = (vb_cov - ub_cov * m.cosa[c2]) * m.rsina[c2];
+    if (jedge) ub = 0.25 * (-ut[c - 2 * sj] + 3.0 * (ut[c - sj] + ut[c]) - ut[c + sj]);
+    if (iedge) ub = 0.5 * (ut[c - sj] + ut[c]);
+    if (iedge) vb = 0.25 * (-vt[c - 2] + 3.0 * (vt[c - 1] + vt[c]) - vt[c + 1]);
+    if (jedge) vb = 0.5 * (vt[c - 1] + vt[c]);
+    double q6[6];
+    // advect_v_along_y: cells (i, j-3 .. j+2); spacing passed to compute_al is dy (ytp_v.py:22)
+#pragma unroll
+    for (int t = 0; t < 6; ++t) q6[t] = v[c + (long)(t - 3) * sj];
+    const double* dy = m.dy;
+    const long col = i;
+    const bool zi = (i == g.is || i == g.ie + 1);
+    auto zrow = [&](int jj) { return zi && (jj == g.js - 1 || jj == g.js || jj == g.je || jj == g.je + 1); };
+    double cfl = (vb > 0.0) ? vb * dt * m.rdy[c2 - sj] : vb * dt * m.rdy[c2];
+    const double adv_v = wind_flux6<MORD>(q6, vb, cfl, j, g.js, g.je,
+                                          [=](int p) { return dy[col + (long)p * sj]; }, zrow(j - 1), zrow(j));
+#pragma unroll
+    for (int t = 0; t < 6; ++t) q6[t] = u[c + (t - 3)];
+    const double* dx = m.dx + (long)j * sj;
+    const bool zj = (j == g.js || j == g.je + 1);
+    auto zcol = [&](int ii) { return zj && (ii == g.is - 1 || ii == g.is || ii == g.ie || ii == g.ie + 1); };
+    cfl = (ub > 0.0) ? ub * dt * m.rdx[c2 - 1] : ub * dt * m.rdx[c2];
+    const double adv_u = wind_flux6<MORD>(q6, ub, cfl, i, g.is, g.ie, [=](int p) { return dx[p]; }, zcol(i - 1), zcol(i));
+    kev = 0.5 * dt * (ub * adv_u + vb * adv_v);
+  }
+  ke[c] = kev;
+}
+
+// compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
+__global__ void __launch_bounds__(256)
+k_vorticity(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ vort,
+            double* __restrict__ abs_vort) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const double ra = m.rarea[c2], dx = m.dx[c2], dy = m.dy[c2];
+  const double val = (u[c] - u[c + g.sj] * m.dx[c2 + g.sj] / dx) * (ra * dx) + (v[c + 1] * m.dy[c2 + 1] / dy - v[c]) * (ra * dy);
+  vort[c] = val;
+  abs_vort[c] = val + m.fC_agrid[c2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// DivergenceDamping, sponge levels (nord_col == 0): divergence_damping.py:30-158
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dd_u_contra_dyc(const Geo& g, const Met& m, const double* u, const double* va,
+                                                  const double* vc, long c, long c2, int j) {
+  double uc_;
+  if (j == g.js || j == g.je + 1) {
+    uc_ = (vc[c] > 0.0) ? u[c] * m.sin_sg4[c2 - g.sj] : u[c] * m.sin_sg2[c2];
+  } else {
+    const double vfa = 0.5 * (va[c - g.sj] + va[c]);
+    uc_ = (u[c] - vfa * m.cosa_v[c2]) * m.sina_v[c2];
+  }
+  return uc_ * m.dyc[c2];
+}
+
+__device__ __forceinline__ double dd_v_contra_dxc(const Geo& g, const Met& m, const double* v, const double* ua,
+                                                  const double* uc, long c, long c2, int i) {
+  double vc_;
+  if (i == g.is || i == g.ie + 1) {
+    vc_ = (uc[c] > 0.0) ? v[c] * m.sin_sg3[c2 - 1] : v[c] * m.sin_sg1[c2];
+  } else {
+    const double ufa = 0.5 * (ua[c - 1] + ua[c]);
+    vc_ = (v[c] - ufa * m.cosa_u[c2]) * m.sina_u[c2];
+  }
+  return vc_ * m.dxc[c2];
+}
+
+__global__ void __launch_bounds__(256)
+k_divdamp_low(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
+              const double* __restrict__ ua, const double* __restrict__ va, const double* __restrict__ uc,
+              const double* __restrict__ vc, double* __restrict__ delpc, double* __restrict__ vort_b,
+              double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dt) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  // a = u_contra_dyc, b = v_contra_dxc (argument order at divergence_damping.py:561-566)
+  const double a0 = dd_u_contra_dyc(g, m, u, va, vc, c, c2, j);
+  const double am = dd_u_contra_dyc(g, m, u, va, vc, c - 1, c2 - 1, j);
+  const double b0 = dd_v_contra_dxc(g, m, v, ua, uc, c, c2, i);
+  const double bm = dd_v_contra_dxc(g, m, v, ua, uc, c - sj, c2 - sj, i);
+  double d = bm - b0 + am - a0;
+  const bool ic = (i == g.is || i == g.ie + 1);
+  if (ic && j == g.js) d = d - bm;
+  if (ic && j == g.je + 1) d = d + b0;
+  d = m.rarea_c[c2] * d;
+  delpc[c] = d;
+  const double delpcdt = d * dt;
+  const double damp = m.da_min_c * fmax(d2_bg[k], fmin(0.2, dddmp * fabs(delpcdt)));
+  const double vort = damp * d;
+  vort_b[c] = vort;
+  ke[c] = ke[c] + vort;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DivergenceDamping, nord > 0 levels: one pass of
+//   fill_corners_bgrid_x -> vc_from_divg -> fill_corners_bgrid_y -> uc_from_divg -> fill_corners_dgrid
+//   -> redo_divg_d                                   (divergence_damping.py:579-600)
+// as a 5-point update of the divergence itself; uc/vc are recomputed, never stored (they are dead
+// after d_sw: d_sw.py:1032-1033, dyn_core.py:851-852).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void remap_bgrid_x(const Geo& g, int& i, int& j) {
+  // corners.py:591-650; closed form in oracle/corner_ops.py.  B-grid points: tile spans is .. ie+1.
+  const bool w = i < g.is, e = i > g.ie + 1, s = j < g.js, n = j > g.je + 1;
+  if (!((w || e) && (s || n))) return;
+  const int a = w ? g.is - i : i - g.ie - 1;
+  const int b = s ? g.js - j : j - g.je - 1;
+  if (a > 3 || b > 3) return;
+  i = w ? g.is - b : g.ie + 1 + b;
+  j = s ? g.js + a : g.je + 1 - a;
+}
+__device__ __forceinline__ void remap_bgrid_y(const Geo& g, int& i, int& j) {
+  const bool w = i < g.is, e = i > g.ie + 1, s = j < g.js, n = j > g.je + 1;
+  if (!((w || e) && (s || n))) return;
+  const int a = w ? g.is - i : i - g.ie - 1;
+  const int b = s ? g.js - j : j - g.je - 1;
+  if (a > 3 || b > 3) return;
+  i = w ? g.is + b : g.ie + 1 - b;
+  j = s ? g.js - a : g.je + 1 + a;
+}
+
+struct DivIter {
+  const Geo& g;
+  const Met& m;
+  const double* d;  // divergence of the previous iterate, level base applied
+  bool fill;
+  __device__ __forceinline__ double dx_(int i, int j) const {  // divg with corners filled in x
+    if (fill) remap_bgrid_x(g, i, j);
+    return d[IDX2(g, i, j)];
+  }
+  __device__ __forceinline__ double dy_(int i, int j) const {
+    if (fill) remap_bgrid_y(g, i, j);
+    return d[IDX2(g, i, j)];
+  }
+  __device__ __forceinline__ double vc_raw(int i, int j) const {  // vc_from_divg :188-197
+    return (dx_(i + 1, j) - dx_(i, j)) * m.divg_u[IDX2(g, i, j)];
+  }
+  __device__ __forceinline__ double uc_raw(int i, int j) const {  // uc_from_divg :200-209
+    return (dy_(i, j + 1) - dy_(i, j)) * m.divg_v[IDX2(g, i, j)];
+  }
+  // fill_corners_dgrid(vc as x, uc as y, mysign = -1) (corners.py:987-1151)
+  __device__ __forceinline__ double vc(int i, int j) const {
+    if (fill) {
+      if (i < g.is && j < g.js) { int a = g.is - i, b = g.js - j; return -uc_raw(g.is - b, g.js + a - 1); }
+      if (i > g.ie && j > g.je + 1) { int a = i - g.ie, b = j - g.je - 1; return -uc_raw(g.ie + 1 + b, g.je + 1 - a); }
+      if (i < g.is && j > g.je + 1) { int a = g.is - i, b = j - g.je - 1; return uc_raw(g.is - b, g.je + 1 - a); }
+      if (i > g.ie && j < g.js) { int a = i - g.ie, b = g.js - j; return uc_raw(g.ie + 1 + b, g.js + a - 1); }
+    }
+    return vc_raw(i, j);
+  }
+  __device__ __forceinline__ double uc(int i, int j) const {
+    if (fill) {
+      if (i < g.is && j < g.js) { int a = g.is - i, b = g.js - j; return -vc_raw(g.is + b - 1, g.js - a); }
+      if (i > g.ie + 1 && j > g.je) { int a = i - g.ie - 1, b = j - g.je; return -vc_raw(g.ie + 1 - b, g.je + 1 + a); }
+      if (i < g.is && j > g.je) { int a = g.is - i, b = j - g.je; return vc_raw(g.is + b - 1, g.je + 1 + a); }
+      if (i > g.ie + 1 && j < g.js) { int a = i - g.ie - 1, b = g.js - j; return vc_raw(g.ie + 1 - b, g.js - a); }
+    }
+    return uc_raw(i, j);
+  }
+};
+
+__global__ void __launch_bounds__(256)
+k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int nt, int fill,
+               int adjust) {
+  PLANE_IJK(g);
+  const int kk = k + k0;
+  if (i < g.is - nt || i > g.ie + nt + 1 || j < g.js - nt || j > g.je + nt + 1) return;
+  DivIter it{g, m, din + (long)kk * g.sk, fill != 0};
+  const double ucm = it.uc(i, j - 1), uc0 = it.uc(i, j), vcm = it.vc(i - 1, j), vc0 = it.vc(i, j);
+  double d = ucm - uc0 + vcm - vc0;  // redo_divg_d :212-240
+  const bool ic = (i == g.is || i == g.ie + 1);
+  if (ic && j == g.js) d = d - ucm;
+  if (ic && j == g.je + 1) d = d + uc0;
+  if (adjust) d = d * m.rarea_c[IDX2(g, i, j)];
+  dout[IDX3(g, i, j, kk)] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2b_ord4 (a2b_ord4.py:59-506) as a point function, + the tail of DivergenceDamping.__call__
+// (smagorinsky_diffusion_approx :243-251, damping_nord_highorder_stencil :161-185)
+// ------------------------------------------------------------------------------------------------
+struct A2B {
+  const Geo& g;
+  const Met& m;
+  const double* q;  // level base applied
+  __device__ __forceinline__ double Q(int i, int j) const { return q[IDX2(g, i, j)]; }
+  __device__ __forceinline__ double DXA(int i, int j) const { return m.dxa[IDX2(g, i, j)]; }
+  __device__ __forceinline__ double DYA(int i, int j) const { return m.dya[IDX2(g, i, j)]; }
+  __device__ double qx(int i, int j) const {  // ppm_volume_mean_x :429-450
+    const double b1 = 7.0 / 12.0, b2 = -1.0 / 12.0;
+    if (i == g.is) {
+      const double g_in = DXA(i + 1, j) / DXA(i, j), g_ou = DXA(i - 2, j) / DXA(i - 1, j);
+      return 0.5 * (((2.0 + g_in) * Q(i, j) - Q(i + 1, j)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i - 1, j) - Q(i - 2, j)) / (1.0 + g_ou));
+    }
+    if (i == g.is + 1) {
+      const double g_in = DXA(i, j) / DXA(i - 1, j), g_ou = DXA(i - 3, j) / DXA(i - 2, j);
+      const double left = 0.5 * (((2.0 + g_in) * Q(i - 1, j) - Q(i, j)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i - 2, j) - Q(i - 3, j)) / (1.0 + g_ou));
+      const double right = b2 * (Q(i - 1, j) + Q(i + 2, j)) + b1 * (Q(i, j) + Q(i + 1, j));
+      return (3.0 * (g_in * Q(i - 1, j) + Q(i, j)) - (g_in * left + right)) / (2.0 + 2.0 * g_in);
+    }
+    if (i == g.ie + 1) {
+      const double g_in = DXA(i - 2, j) / DXA(i - 1, j), g_ou = DXA(i + 1, j) / DXA(i, j);
+      return 0.5 * (((2.0 + g_in) * Q(i - 1, j) - Q(i - 2, j)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i, j) - Q(i + 1, j)) / (1.0 + g_ou));
+    }
+    if (i == g.ie) {
+      const double g_in = DXA(i - 1, j) / DXA(i, j), g_ou = DXA(i + 2, j) / DXA(i + 1, j);
+      const double right = 0.5 * (((2.0 + g_in) * Q(i, j) - Q(i - 1, j)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i + 1, j) - Q(i + 2, j)) / (1.0 + g_ou));
+      const double left = b2 * (Q(i - 3, j) + Q(i, j)) + b1 * (Q(i - 2, j) + Q(i - 1, j));
+      return (3.0 * (Q(i - 1, j) + g_in * Q(i, j)) - (g_in * right + left)) / (2.0 + 2.0 * g_in);
+    }
+    return b2 * (Q(i - 2, j) + Q(i + 1, j)) + b1 * (Q(i - 1, j) + Q(i, j));
+  }
+  __device__ double qy(int i, int j) const {  // ppm_volume_mean_y :453-473
+    const double b1 = 7.0 / 12.0, b2 = -1.0 / 12.0;
+    if (j == g.js) {
+      const double g_in = DYA(i, j + 1) / DYA(i, j), g_ou = DYA(i, j - 2) / DYA(i, j - 1);
+      return 0.5 * (((2.0 + g_in) * Q(i, j) - Q(i, j + 1)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i, j - 1) - Q(i, j - 2)) / (1.0 + g_ou));
+    }
+    if (j == g.js + 1) {
+      const double g_in = DYA(i, j) / DYA(i, j - 1), g_ou = DYA(i, j - 3) / DYA(i, j - 2);
+      const double lower = 0.5 * (((2.0 + g_in) * Q(i, j - 1) - Q(i, j)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i, j - 2) - Q(i, j - 3)) / (1.0 + g_ou));
+      const double upper = b2 * (Q(i, j - 1) + Q(i, j + 2)) + b1 * (Q(i, j) + Q(i, j + 1));
+      return (3.0 * (g_in * Q(i, j - 1) + Q(i, j)) - (g_in * lower + upper)) / (2.0 + 2.0 * g_in);
+    }
+    if (j == g.je + 1) {
+      const double g_in = DYA(i, j - 2) / DYA(i, j - 1), g_ou = DYA(i, j + 1) / DYA(i, j);
+      return 0.5 * (((2.0 + g_in) * Q(i, j - 1) - Q(i, j - 2)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i, j) - Q(i, j + 1)) / (1.0 + g_ou));
+    }
+    if (j == g.je) {
+      const double g_in = DYA(i, j - 1) / DYA(i, j), g_ou = DYA(i, j + 2) / DYA(i, j + 1);
+      const double lower = b2 * (Q(i, j - 3) + Q(i, j)) + b1 * (Q(i, j - 2) + Q(i, j - 1));
+      const double upper = 0.5 * (((2.0 + g_in) * Q(i, j) - Q(i, j - 1)) / (1.0 + g_in) + ((2.0 + g_ou) * Q(i, j + 1) - Q(i, j + 2)) / (1.0 + g_ou));
+      return (3.0 * (Q(i, j - 1) + g_in * Q(i, j)) - (g_in * upper + lower)) / (2.0 + 2.0 * g_in);
+    }
+    return b2 * (Q(i, j - 2) + Q(i, j + 1)) + b1 * (Q(i, j - 1) + Q(i, j));
+  }
+  // qout_x_edge :286-304 (west/east columns), qout_y_edge :307-325 (south/north rows)
+  __device__ __forceinline__ double q2(int i, int j) const {
+    return (Q(i - 1, j) * DXA(i, j) + Q(i, j) * DXA(i - 1, j)) / (DXA(i - 1, j) + DXA(i, j));
+  }
+  __device__ __forceinline__ double q1(int i, int j) const {
+    return (Q(i, j - 1) * DYA(i, j) + Q(i, j) * DYA(i, j - 1)) / (DYA(i, j - 1) + DYA(i, j));
+  }
+  __device__ __forceinline__ double edge_x(int i, int j) const {
+    const double e = (i == g.is) ? m.edge_w[j] : m.edge_e[j];
+    return e * q2(i, j - 1) + (1.0 - e) * q2(i, j);
+  }
+  __device__ __forceinline__ double edge_y(int i, int j) const {
+    const double e = (j == g.js) ? m.edge_s[i] : m.edge_n[i];
+    return e * q1(i - 1, j) + (1.0 - e) * q1(i, j);
+  }
+  __device__ double corner(int which, int i, int j) const {  // a2b_ord4.py:43-273
+    // diagonals: 0 = (0,0)/(1,1), 1 = (-1,0)/(-2,1), 2 = (0,-1)/(1,-2), 3 = (-1,-1)/(-2,-2)
+    const int set[4][3] = {{0, 1, 2}, {1, 3, 0}, {3, 2, 1}, {2, 3, 0}};
+    const int o1[4][2] = {{0, 0}, {-1, 0}, {0, -1}, {-1, -1}};
+    const int o2[4][2] = {{1, 1}, {-2, 1}, {1, -2}, {-2, -2}};
+    double ec[3];
+    for (int t = 0; t < 3; ++t) {
+      const int d = set[which][t];
+      const double qa = Q(i + o1[d][0], j + o1[d][1]), qb = Q(i + o2[d][0], j + o2[d][1]);
+      ec[t] = qa + m.a2b_corner_w[which][t] * (qa - qb);
+    }
+    return (ec[0] + ec[1] + ec[2]) * (1.0 / 3.0);
+  }
+  __device__ double point(int i, int j) const {  // value of qout at B-grid point (i, j), is <= i,j <= ie+1
+    const double a1 = 9.0 / 16.0, a2 = -1.0 / 16.0, c1 = 2.0 / 3.0, c2 = -1.0 / 6.0;
+    const bool iw = (i == g.is), ie_ = (i == g.ie + 1), js_ = (j == g.js), jn = (j == g.je + 1);
+    if (iw && js_) return corner(0, i, j);
+    if (ie_ && js_) return corner(1, i, j);
+    if (ie_ && jn) return corner(2, i, j);
+    if (iw && jn) return corner(3, i, j);
+    if (iw || ie_) return edge_x(i, j);
+    if (js_ || jn) return edge_y(i, j);
+    double qxx, qyy;
+    if (j == g.js + 1) {
+      const double up = a2 * (qx(i, j - 1) + qx(i, j + 2)) + a1 * (qx(i, j) + qx(i, j + 1));
+      qxx = c1 * (qx(i, j - 1) + qx(i, j)) + c2 * (edge_y(i, j - 1) + up);
+    } else if (j == g.je) {
+      const double lo = a2 * (qx(i, j - 3) + qx(i, j)) + a1 * (qx(i, j - 2) + qx(i, j - 1));
+      qxx = c1 * (qx(i, j - 1) + qx(i, j)) + c2 * (edge_y(i, j + 1) + lo);
+    } else {
+      qxx = a2 * (qx(i, j - 2) + qx(i, j + 1)) + a1 * (qx(i, j - 1) + qx(i, j));
+    }
+    if (i == g.is + 1) {
+      const double rt = a2 * (qy(i - 1, j) + qy(i + 2, j)) + a1 * (qy(i, j) + qy(i + 1, j));
+      qyy = c1 * (qy(i - 1, j) + qy(i, j)) + c2 * (edge_x(i - 1, j) + rt);
+    } else if (i == g.ie) {
+      const double lf = a2 * (qy(i - 3, j) + qy(i, j)) + a1 * (qy(i - 2, j) + qy(i - 1, j));
+      qyy = c1 * (qy(i - 1, j) + qy(i, j)) + c2 * (edge_x(i + 1, j) + lf);
+    } else {
+      qyy = a2 * (qy(i - 2, j) + qy(i + 1, j)) + a1 * (qy(i - 1, j) + qy(i, j));
+    }
+    return 0.5 * (qxx + qyy);
+  }
+};
+
+__global__ void __launch_bounds__(256) k_a2b_ord4(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, int k0) {
+  PLANE_IJK(g);
+  const int kk = k + k0;
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  A2B a{g, m, qin + (long)kk * g.sk};
+  qout[IDX3(g, i, j, kk)] = a.point(i, j);
+}
+
+__global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __restrict__ src, double* __restrict__ dst, int k0, int i1, int j1) {
+  PLANE_IJK(g);
+  const int kk = k + k0;
+  if (i < g.is || i > i1 || j < g.js || j > j1) return;
+  const long c = IDX3(g, i, j, kk);
+  dst[c] = src[c];
+}
+
+// tail of DivergenceDamping for nord > 0 levels: a2b_ord4(wk) -> smagorinsky -> damping
+__global__ void __launch_bounds__(256)
+k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* __restrict__ delpc_src,
+                     double* __restrict__ delpc, const double* __restrict__ divg_d, double* __restrict__ vort_b,
+                     double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt,
+                     int k0) {
+  PLANE_IJK(g);
+  const int kk = k + k0;
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, kk);
+  const double dpc = delpc_src[c];  // copy_computeplus :578
+  delpc[c] = dpc;
+  double vb;
+  if (dddmp < 1e-5) {
+    vb = 0.0;
+  } else {
+    A2B a{g, m, wk + (long)kk * g.sk};
+    const double qb = a.point(i, j);
+    vb = absdt * sqrt(dpc * dpc + qb * qb);
+  }
+  const double damp = m.da_min_c * fmax(d2_bg[kk], fmin(0.2, dddmp * fabs(vb)));
+  const double vort = damp * dpc + dd8 * divg_d[c];
+  vort_b[c] = vort;
+  ke[c] = ke[c] + vort;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tail of d_sw: u_and_v_from_ke (:439-477), vort_differencing (:353-380) +
+// heat_source_from_vorticity_damping (:493-577), update_u_and_v (:582-608)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_uv_from_ke(Geo g, Met m, double* __restrict__ u, double* __restrict__ v, const double* __restrict__ ke,
+             const double* __restrict__ fx, const double* __restrict__ fy) {
+  PLANE_IJK(g);
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je + 1) u[c] = u[c] * m.dx[c2] + ke[c] - ke[c + 1] + fy[c];
+  if (i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je) v[c] = v[c] * m.dy[c2] + ke[c] - ke[c + g.sj] - fx[c];
+}
+
+struct HeatPt {
+  double ubt, vbt, fy, fx, gy, gx;
+};
+
+__device__ __forceinline__ HeatPt heat_point(const Geo& g, const Met& m, const double* u, const double* v,
+                                             const double* vort_b, const double* ut2, const double* vt2, bool don,
+                                             long c, long c2, int i, int j) {
+  // vort_x_delta / vort_y_delta are only written where d_con > threshold and inside their regions
+  // (d_sw.py:373-380); elsewhere the reference reads its zero-initialised persistent temporaries.
+  double vxd = 0.0, vyd = 0.0;
+  if (don) {
+    if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je + 1) vxd = vort_b[c] - vort_b[c + 1];
+    if (i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je) vyd = vort_b[c] - vort_b[c + g.sj];
+  }
+  HeatPt h;
+  h.ubt = (vxd + vt2[c]) * m.rdx[c2];
+  h.fy = u[c] * m.rdx[c2];
+  h.gy = h.fy * h.ubt;
+  h.vbt = (vyd - ut2[c]) * m.rdy[c2];
+  h.fx = v[c] * m.rdy[c2];
+  h.gx = h.fx * h.vbt;
+  return h;
+}
+
+__global__ void __launch_bounds__(256)
+k_heat_source(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
+              const double* __restrict__ vort_b, const double* __restrict__ ut2, const double* __restrict__ vt2,
+              const double* __restrict__ delp, double* __restrict__ heat_s, double* __restrict__ heat_source,
+              double* __restrict__ diss_est, const double* __restrict__ d_con_k, double d_con, int do_skeb) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const double dck = d_con_k[k];
+  const bool don = dck > DCON_THRESHOLD;
+  const HeatPt p0 = heat_point(g, m, u, v, vort_b, ut2, vt2, don, c, c2, i, j);
+  if ((dck > DCON_THRESHOLD) || do_skeb) {
+    const HeatPt pj = heat_point(g, m, u, v, vort_b, ut2, vt2, don, c + g.sj, c2 + g.sj, i, j + 1);
+    const HeatPt pi = heat_point(g, m, u, v, vort_b, ut2, vt2, don, c + 1, c2 + 1, i + 1, j);
+    const double u2 = p0.fy + pj.fy, du2 = p0.ubt + pj.ubt, v2 = p0.fx + pi.fx, dv2 = p0.vbt + pi.vbt;
+    const double dampterm = m.rsin2[c2] * 0.25 *
+                            ((p0.ubt * p0.ubt + pj.ubt * pj.ubt + p0.vbt * p0.vbt + pi.vbt * pi.vbt) +
+                             2.0 * (p0.gy + pj.gy + p0.gx + pi.gx) - m.cosa_s[c2] * (u2 * dv2 + v2 * du2 + du2 * dv2));
+    const double hs = delp[c] * (heat_s[c] - dck * dampterm);
+    heat_s[c] = hs;
+    if ((d_con > DCON_THRESHOLD || do_skeb) && i <= g.ie && j <= g.je) {
+      heat_source[c] = heat_source[c] + hs;
+      if (do_skeb) diss_est[c] = diss_est[c] - dampterm;
+    }
+  } else if ((d_con > DCON_THRESHOLD || do_skeb) && i <= g.ie && j <= g.je) {
+    heat_source[c] = heat_source[c] + heat_s[c];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_update_uv(Geo g, double* __restrict__ u, double* __restrict__ v, const double* __restrict__ ut2,
+            const double* __restrict__ vt2, const double* __restrict__ damp_vt) {
+  PLANE_IJK(g);
+  if (!(damp_vt[k] > 1e-5)) return;
+  const long c = IDX3(g, i, j, k);
+  if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je + 1) u[c] = u[c] + vt2[c];
+  if (i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je) v[c] = v[c] - ut2[c];
+}
+
+// =================================================================================================
+int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k0, int k1, int replace, hipStream_t st) {
+  const dim3 grid = plane_grid(g, k1 - k0), block(256);
+  hipLaunchKernelGGL(k_a2b_ord4, grid, block, 0, st, g, m, qin, qout, k0);
+  if (replace) hipLaunchKernelGGL(k_copy_window, grid, block, 0, st, g, qout, qin, k0, g.ie + 1, g.je + 1);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+struct DswWork {
+  double *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db;
+  double* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
+};
+#define DSW_NFIELDS 18
+
+int64_t dsw_workspace_bytes(const Geo& g) {
+  const int64_t field = (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double);
+  return field * DSW_NFIELDS + 16 * (int64_t)(g.nk + 1) * (int64_t)sizeof(double) + 256;
+}
+
+static DswWork carve(const Geo& g, void* ws) {
+  DswWork w;
+  double* p = (double*)ws;
+  const long field = g.sk * (g.nk + 1);
+  double** f = &w.ut;
+  for (int n = 0; n < DSW_NFIELDS; ++n) f[n] = p + (long)n * field;
+  w.kcol = p + (long)DSW_NFIELDS * field;
+  return w;
+}
+
+#ifdef PACE_EMU
+#include <cstring>
+static void upload(double* dst, const double* src, size_t n, hipStream_t) { memcpy(dst, src, n * sizeof(double)); }
+#else
+static void upload(double* dst, const double* src, size_t n, hipStream_t st) {
+  hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, st);
+  hipStreamSynchronize(st);
+}
+#endif
+
+#define NCOL 13
+// Upload the column namelist once per object (the reference derives these in __init__, d_sw.py:785,924-933).
+int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st) {
+  DswWork W = carve(g, ws);
+  const int K = g.nk + 1;
+  std::vector<double> h((size_t)NCOL * K, 0.0);
+  const double* src[NCOL] = {col->nord_v, col->nord_w, col->nord_t, col->damp_vt, col->damp_w, col->damp_t, col->d2_divg,
+                             col->d_con,  col->ke_bg,  col->fac_vt, col->fac_t,   col->fac_vt_c, col->fac_w_c};
+  for (int a = 0; a < NCOL; ++a)
+    for (int k = 0; k < g.nk; ++k) h[(size_t)a * K + k] = src[a][k];
+  upload(W.kcol, h.data(), h.size(), st);
+  return PACE_OK;
+}
+
+int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace_dsw_config_t* cfg, void* ws,
+                double* delpc, double* delp, double* pt, double* u, double* v, double* w, double* uc, double* vc,
+                const double* ua, const double* va, double* divgd, double* mfx, double* mfy, double* cx, double* cy,
+                double* crx, double* cry, double* xfx, double* yfx, double* q_con, const double* zh,
+                double* heat_source, double* diss_est, double dt, hipStream_t st) {
+  (void)zh;
+  const int nk = g.nk;
+  DswWork W = carve(g, ws);
+  const int K = nk + 1;
+  double* kc = W.kcol;  // filled by dsw_prepare
+  double *d_nord_v = kc, *d_nord_w = kc + K, *d_nord_t = kc + 2 * K, *d_damp_vt_c = kc + 3 * K, *d_damp_w_c = kc + 4 * K,
+         *d_d2 = kc + 6 * K, *d_dcon = kc + 7 * K, *d_kebg = kc + 8 * K, *d_dampfac_vt = kc + 9 * K,
+         *d_dampfac_t = kc + 10 * K, *d_dampfac_vt_c = kc + 11 * K, *d_dampfac_w_c = kc + 12 * K;
+  int nmax_v = 0, nmax_w = 0, nmax_t = 0, kstart = 0, nonzero_nord = cfg->nord;
+  bool found = false;
+  for (int k = 0; k < nk; ++k) {
+    nmax_v = std::max(nmax_v, (int)col->nord_v[k]);
+    nmax_w = std::max(nmax_w, (int)col->nord_w[k]);
+    nmax_t = std::max(nmax_t, (int)col->nord_t[k]);
+    if (!found && col->nord[k] > 0) {
+      found = true;
+      kstart = k;
+      nonzero_nord = (int)col->nord[k];
+    }
+  }
+  int rc;
+  const dim3 block(256);
+  const dim3 gk = plane_grid(g, nk);
+  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, st))) return rc;
+  // delp
+  if ((rc = launch_fvtp2d(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, st))) return rc;
+  if ((rc = launch_delnflux(g, m, 1, delp, W.fx, W.fy, nullptr, d_dampfac_vt, d_nord_v, nmax_v, 0, nk, st))) return rc;
+  // w damping fluxes
+  if ((rc = launch_delnflux(g, m, 0, w, W.fx2, W.fy2, nullptr, d_dampfac_w_c, d_nord_w, nmax_w, 0, nk, st))) return rc;
+  hipLaunchKernelGGL(k_fluxcap_heatdiss, gk, block, 0, st, g, m, cx, cy, mfx, mfy, crx, cry, W.fx, W.fy, W.fx2, W.fy2, w,
+                     W.heat_s, diss_est, W.dw, d_damp_w_c, d_kebg, dt);
+  // w
+  if ((rc = launch_fvtp2d(g, m, w, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_vt, nk, st))) return rc;
+  hipLaunchKernelGGL(k_apply_fluxes, gk, block, 0, st, g, m, w, delp, W.gx, W.gy);
+  // q_con
+  if ((rc = launch_fvtp2d(g, m, q_con, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_dp, nk, st))) return rc;
+  if ((rc = launch_delnflux(g, m, 2, q_con, W.gx, W.gy, delp, d_dampfac_t, d_nord_t, nmax_t, 1, nk, st))) return rc;
+  hipLaunchKernelGGL(k_apply_fluxes, gk, block, 0, st, g, m, q_con, delp, W.gx, W.gy);
+  // pt
+  if ((rc = launch_fvtp2d(g, m, pt, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_tm, nk, st))) return rc;
+  if ((rc = launch_delnflux(g, m, 2, pt, W.gx, W.gy, delp, d_dampfac_vt, d_nord_v, nmax_v, 1, nk, st))) return rc;
+  hipLaunchKernelGGL(k_pt_delp_w_qcon, gk, block, 0, st, g, m, pt, delp, w, q_con, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
+  // winds
+  if (cfg->hord_mt == 5) {
+    hipLaunchKernelGGL(k_kinetic_energy<5>, gk, block, 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt);
+  } else if (cfg->hord_mt == 6) {
+    hipLaunchKernelGGL(k_kinetic_energy<6>, gk, block, 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt);
+  } else {
+    return PACE_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(k_vorticity, gk, block, 0, st, g, m, u, v, W.wk, W.abs_vort);
+  // divergence damping
+  if (kstart > 0) {
+    hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), block, 0, st, g, m, u, v, ua, va, uc, vc, delpc, W.vort_b, W.ke,
+                       d_d2, cfg->dddmp, dt);
+  }
+  {
+    const int nhigh = nk - kstart;
+    const dim3 gh = plane_grid(g, nhigh);
+    const double* src = divgd;
+    double* bufs[2] = {W.da, W.db};
+    for (int n = 0; n < nonzero_nord; ++n) {
+      const int nt = nonzero_nord - (n + 1);
+      const int fill = (n + 1 != nonzero_nord) ? 1 : 0;
+      double* dst = bufs[n & 1];
+      hipLaunchKernelGGL(k_divdamp_iter, gh, block, 0, st, g, m, src, dst, kstart, nt, fill, 1);
+      src = dst;
+    }
+    const double dd8 = pow(m.da_min_c * cfg->d4_bg, (double)(nonzero_nord + 1));
+    hipLaunchKernelGGL(k_divdamp_high_final, gh, block, 0, st, g, m, W.wk, divgd, delpc, src, W.vort_b, W.ke, d_d2, cfg->dddmp,
+                       dd8, fabs(dt), kstart);
+  }
+  // vorticity transport
+  if ((rc = launch_fvtp2d(g, m, W.abs_vort, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_vt, nk, st))) return rc;
+  hipLaunchKernelGGL(k_uv_from_ke, gk, block, 0, st, g, m, u, v, W.ke, W.fx, W.fy);
+  if ((rc = launch_delnflux(g, m, 0, W.wk, W.ut2, W.vt2, nullptr, d_dampfac_vt_c, d_nord_v, nmax_v, 0, nk, st))) return rc;
+  hipLaunchKernelGGL(k_heat_source, gk, block, 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,
+                     d_dcon, cfg->d_con, cfg->do_skeb);
+  hipLaunchKernelGGL(k_update_uv, gk, block, 0, st, g, u, v, W.ut2, W.vt2, d_damp_vt_c);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}

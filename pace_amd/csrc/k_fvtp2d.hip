@@ -1,0 +1,172 @@
+// FiniteVolumeTransport (Fortran fv_tp_2d): Putman-Lin 2-D transport fluxes of one scalar.
+// Reference: fv3core/pace/fv3core/stencils/fvtp2d.py:262-345 -- 9 stencil launches (copy_corners_y,
+// yppm inner, q_i, xppm outer, copy_corners_x, xppm inner, q_j, yppm outer, final_fluxes) through 6
+// full 3-D temporaries.  Here: ONE kernel.  A workgroup owns a TI x TJ tile of one level, stages the
+// (TI+6) x (TJ+6) footprint of q in LDS, runs the five sweeps tile-locally and writes only the two
+// flux fields.  HBM-bound: algorithmic traffic = 5-7 reads + 2 writes of 3-D fields.
+#include "common.h"
+#include "kernels.h"
+
+#ifndef FV_TI
+#define FV_TI 64
+#define FV_TJ 16
+#endif
+#define TI FV_TI
+#define TJ FV_TJ
+#define QW (TI + 6)
+#define QH (TJ + 6)
+
+template <int MORD>
+__global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
+                                                const double* __restrict__ crx, const double* __restrict__ cry,
+                                                const double* __restrict__ xfx, const double* __restrict__ yfx,
+                                                double* __restrict__ fx, double* __restrict__ fy,
+                                                const double* __restrict__ xunit, const double* __restrict__ yunit) {
+  __shared__ double sq[QH][QW + 1];    // q on [i0-3, i0+TI+3) x [j0-3, j0+TJ+3)
+  __shared__ double syin[TJ + 1][QW + 1];  // inner y sweep: mean advected value on y-interfaces
+  __shared__ double sqi[TJ][QW + 1];       // q advected in y (fvtp2d.py:34-56)
+  __shared__ double sxin[QH][TI + 2];      // inner x sweep on x-interfaces
+  __shared__ double sqj[QH][TI + 1];       // q advected in x (fvtp2d.py:59-77)
+
+  const int tid = threadIdx.x;
+  const int i0 = g.is + blockIdx.x * TI;
+  const int j0 = g.js + blockIdx.y * TJ;
+  const int k = blockIdx.z;
+  const long kb = (long)k * g.sk;
+  const int ilo = i0 - 3, jlo = j0 - 3;
+
+  // stage 0: q with corners copied in the y direction (copy_corners_y, corners.py:367-425)
+  for (int e = tid; e < QW * QH; e += 256) {
+    const int jj = e / QW, ii = e - jj * QW;
+    int gi = ilo + ii, gj = jlo + jj;
+    double v = 0.0;
+    if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj) {
+      remap_agrid_y(g, gi, gj);
+      v = q[kb + IDX2(g, gi, gj)];
+    }
+    sq[jj][ii] = v;
+  }
+  __syncthreads();
+
+  // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1))
+  for (int e = tid; e < QW * (TJ + 1); e += 256) {
+    const int jj = e / QW, ii = e - jj * QW;
+    const int gi = ilo + ii, gj = j0 + jj;
+    double val = 0.0;
+    if (gi >= 0 && gi <= g.ni - 1 && gj >= g.js && gj <= g.je + 1) {
+      double q6[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) q6[t] = sq[jj + t][ii];  // rows gj-3 .. gj+2
+      const double* dya = m.dya;
+      const long col = gi;
+      const int sj = g.sj;
+      val = ppm_flux6<MORD>(q6, cry[kb + IDX2(g, gi, gj)], gj, g.js, g.je,
+                            [=](int p) { return dya[col + (long)p * sj]; });
+    }
+    syin[jj][ii] = val;
+  }
+  __syncthreads();
+
+  // stage 2: q_i; and re-stage the corner cells of q for the x direction (copy_corners_x)
+  for (int e = tid; e < QW * TJ; e += 256) {
+    const int jj = e / QW, ii = e - jj * QW;
+    const int gi = ilo + ii, gj = j0 + jj;
+    double val = 0.0;
+    if (gi >= 0 && gi <= g.ni - 1 && gj >= g.js && gj <= g.je) {
+      const long c2 = IDX2(g, gi, gj);
+      const double y0 = yfx[kb + c2], y1 = yfx[kb + c2 + g.sj];
+      const double a = m.area[c2];
+      val = (sq[jj + 3][ii] * a + y0 * syin[jj][ii] - y1 * syin[jj + 1][ii]) / (a + y0 - y1);
+    }
+    sqi[jj][ii] = val;
+  }
+  {
+    const bool icorner_tile = (i0 == g.is) || (i0 + TI + 3 > g.ie + 1);
+    const bool jcorner_tile = (j0 == g.js) || (j0 + TJ + 3 > g.je + 1);
+    if (icorner_tile && jcorner_tile) {
+      for (int e = tid; e < QW * QH; e += 256) {
+        const int jj = e / QW, ii = e - jj * QW;
+        int gi = ilo + ii, gj = jlo + jj;
+        if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj && (gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) {
+          remap_agrid_x(g, gi, gj);
+          sq[jj][ii] = q[kb + IDX2(g, gi, gj)];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // stage 3: inner x sweep (XPiecewiseParabolic, origin (is, js-3), domain (N+1, N+7))
+  for (int e = tid; e < (TI + 1) * QH; e += 256) {
+    const int jj = e / (TI + 1), ii = e - jj * (TI + 1);
+    const int gi = i0 + ii, gj = jlo + jj;
+    double val = 0.0;
+    if (gj >= 0 && gj <= g.nj - 1 && gi >= g.is && gi <= g.ie + 1) {
+      double q6[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) q6[t] = sq[jj][ii + t];  // columns gi-3 .. gi+2
+      const double* dxa = m.dxa + (long)gj * g.sj;
+      val = ppm_flux6<MORD>(q6, crx[kb + IDX2(g, gi, gj)], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
+    }
+    sxin[jj][ii] = val;
+  }
+  __syncthreads();
+
+  // stage 4: q_j
+  for (int e = tid; e < TI * QH; e += 256) {
+    const int jj = e / TI, ii = e - jj * TI;
+    const int gi = i0 + ii, gj = jlo + jj;
+    double val = 0.0;
+    if (gj >= 0 && gj <= g.nj - 1 && gi >= g.is && gi <= g.ie) {
+      const long c2 = IDX2(g, gi, gj);
+      const double x0 = xfx[kb + c2], x1 = xfx[kb + c2 + 1];
+      const double a = m.area[c2];
+      val = (sq[jj][ii + 3] * a + x0 * sxin[jj][ii] - x1 * sxin[jj][ii + 1]) / (a + x0 - x1);
+    }
+    sqj[jj][ii] = val;
+  }
+  __syncthreads();
+
+  // stage 5: outer sweeps + final_fluxes (fvtp2d.py:80-119)
+  for (int e = tid; e < TI * TJ; e += 256) {
+    const int jj = e / TI, ii = e - jj * TI;
+    const int gi = i0 + ii, gj = j0 + jj;
+    if (gi > g.ie + 1 || gj > g.je + 1) continue;
+    const long c = kb + IDX2(g, gi, gj);
+    if (gj <= g.je) {
+      double q6[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) q6[t] = sqi[jj][ii + t];  // q_i at gi-3 .. gi+2
+      const double* dxa = m.dxa + (long)gj * g.sj;
+      const double xo = ppm_flux6<MORD>(q6, crx[c], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
+      fx[c] = 0.5 * (xo + sxin[jj + 3][ii]) * xunit[c];
+    }
+    if (gi <= g.ie) {
+      double q6[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) q6[t] = sqj[jj + t][ii];  // q_j at gj-3 .. gj+2
+      const double* dya = m.dya;
+      const long col = gi;
+      const int sj = g.sj;
+      const double yo = ppm_flux6<MORD>(q6, cry[c], gj, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; });
+      fy[c] = 0.5 * (yo + syin[jj][ii + 3]) * yunit[c];
+    }
+  }
+}
+
+int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
+                  const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
+                  const double* ymf, int hord, int nlev, hipStream_t st) {
+  const dim3 grid((g.n + 1 + TI - 1) / TI, (g.n + 1 + TJ - 1) / TJ, nlev), block(256);
+  const double* xu = xmf ? xmf : xfx;
+  const double* yu = ymf ? ymf : yfx;
+  if (hord == 5) {
+    hipLaunchKernelGGL(k_fvtp2d<5>, grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu);
+  } else if (hord == 6) {
+    hipLaunchKernelGGL(k_fvtp2d<6>, grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu);
+  } else {
+    return PACE_ERR_UNSUPPORTED;
+  }
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}

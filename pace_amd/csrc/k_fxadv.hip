@@ -1,0 +1,176 @@
+// FiniteVolumeFluxPrep (Fortran fxadv) -- contravariant C-grid winds, Courant numbers and area
+// fluxes.  Reference: fv3core/pace/fv3core/stencils/fxadv.py:10-661 (8 stencils, each a full
+// pass over two to four 3-D fields).  Here: one streaming pass for the interior formula and the
+// west/east edge rule, three thin passes that only touch the O(N) edge/corner points, and one
+// streaming pass for the fluxes.  HBM-bound: 2 reads + 6 writes of 3-D fields are algorithmic.
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ double contra(double v1, double v2, double cosa, double rsin2) {
+  return (v1 - v2 * cosa) * rsin2;  // d2a2c_vect.py:225-281
+}
+
+// stage A: main_uc_vc_contra (fxadv.py:10-48) + uc_contra_y_edge (:51-77)
+__global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const double* __restrict__ uc,
+                                                    const double* __restrict__ vc, double* __restrict__ ut,
+                                                    double* __restrict__ vt) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;  // domain_full = N+6 points
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  if (i == g.is || i == g.ie + 1) {
+    const double u = uc[c];
+    ut[c] = (u > 0.0) ? (u / m.sin_sg3[c2 - 1]) : (u / m.sin_sg1[c2]);
+  } else if (i >= g.is - 1 && i <= g.ie + 2 && !(j == g.js - 1 || j == g.js || j == g.je || j == g.je + 1)) {
+    const double vb = 0.25 * (vc[c - 1] + vc[c] + vc[c - 1 + g.sj] + vc[c + g.sj]);
+    ut[c] = contra(uc[c], vb, m.cosa_u[c2], m.rsin_u[c2]);
+  }
+  if (j >= g.js - 1 && j <= g.je + 2) {
+    const double ub = 0.25 * (uc[c - g.sj] + uc[c + 1 - g.sj] + uc[c] + uc[c + 1]);
+    vt[c] = contra(vc[c], ub, m.cosa_v[c2], m.rsin_v[c2]);
+  }
+}
+
+// stage B: vc_contra_y_edge (:80-125) then vc_contra_x_edge (:128-145); touches edge strips only
+__global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const double* __restrict__ vc,
+                                                        const double* __restrict__ ut, double* __restrict__ vt) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  if (j == g.js || j == g.je + 1) {
+    const double v = vc[c];
+    vt[c] = (v > 0.0) ? (v / m.sin_sg4[c2 - g.sj]) : (v / m.sin_sg2[c2]);
+    return;
+  }
+  const bool strip = (i == g.is - 1 || i == g.is || i == g.ie || i == g.ie + 1);
+  if (strip && j >= g.js + 2 && j <= g.je - 1) {
+    const double ub = 0.25 * (ut[c - g.sj] + ut[c + 1 - g.sj] + ut[c] + ut[c + 1]);
+    vt[c] = contra(vc[c], ub, m.cosa_v[c2], 1.0);
+  }
+}
+
+// stage C: uc_contra_x_edge (:148-180), uc_contra_corners (:183-300), vc_contra_corners (:303-404)
+__global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, const double* __restrict__ uc,
+                                                                const double* __restrict__ vc, double* ut,
+                                                                double* vt) {
+  PLANE_IJK(g);
+  if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  const bool rows = (j == g.js - 1 || j == g.js || j == g.je || j == g.je + 1);
+  if (rows && i >= g.is + 2 && i <= g.ie - 1) {
+    const double vb = 0.25 * (vt[c - 1] + vt[c] + vt[c - 1 + sj] + vt[c + sj]);
+    ut[c] = contra(uc[c], vb, m.cosa_u[c2], 1.0);
+    return;
+  }
+  // The corner formulas read ut/vt only at points no corner formula writes, so
+  // the in-place update equals the reference's aliased uc_contra/uc_contra_copy call.
+  if (rows && (i == g.is + 1 || i == g.ie)) {
+    const double cu = m.cosa_u[c2];
+    double damp, val;
+    if (i == g.is + 1 && (j == g.js - 1 || j == g.je)) {
+      const double cv = m.cosa_v[c2 - 1];
+      damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      val = (uc[c] - 0.25 * cu * (vt[c - 1 + sj] + vt[c + sj] + vt[c] + vc[c - 1] -
+                                  0.25 * cv * (ut[c - 1] + ut[c - 1 - sj] + ut[c - sj]))) * damp;
+    } else if (i == g.is + 1) {
+      const double cv = m.cosa_v[c2 - 1 + sj];
+      damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      val = (uc[c] - 0.25 * cu * (vt[c - 1] + vt[c] + vt[c + sj] + vc[c - 1 + sj] -
+                                  0.25 * cv * (ut[c - 1] + ut[c - 1 + sj] + ut[c + sj]))) * damp;
+    } else if (j == g.js - 1 || j == g.je) {
+      const double cv = m.cosa_v[c2];
+      damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      val = (uc[c] - 0.25 * cu * (vt[c + sj] + vt[c - 1 + sj] + vt[c - 1] + vc[c] -
+                                  0.25 * cv * (ut[c + 1] + ut[c + 1 - sj] + ut[c - sj]))) * damp;
+    } else {
+      const double cv = m.cosa_v[c2 + sj];
+      damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      val = (uc[c] - 0.25 * cu * (vt[c] + vt[c - 1] + vt[c - 1 + sj] + vc[c + sj] -
+                                  0.25 * cv * (ut[c + 1] + ut[c + 1 + sj] + ut[c + sj]))) * damp;
+    }
+    ut[c] = val;
+    return;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fxadv_vt_corners(Geo g, Met m, const double* __restrict__ uc,
+                                                          const double* __restrict__ vc, const double* ut,
+                                                          double* vt) {
+  PLANE_IJK(g);
+  if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
+  const bool cols = (i == g.is - 1 || i == g.is || i == g.ie || i == g.ie + 1);
+  if (!cols || !(j == g.js + 1 || j == g.je)) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  const double cv = m.cosa_v[c2];
+  double damp, val;
+  if (j == g.js + 1 && (i == g.is - 1 || i == g.ie)) {
+    const double cu = m.cosa_u[c2 - sj];
+    damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+    val = (vc[c] - 0.25 * cv * (ut[c + 1 - sj] + ut[c + 1] + ut[c] + uc[c - sj] -
+                                0.25 * cu * (vt[c - sj] + vt[c - 1 - sj] + vt[c - 1]))) * damp;
+  } else if (j == g.js + 1) {
+    const double cu = m.cosa_u[c2 + 1 - sj];
+    damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+    val = (vc[c] - 0.25 * cv * (ut[c - sj] + ut[c] + ut[c + 1] + uc[c + 1 - sj] -
+                                0.25 * cu * (vt[c - sj] + vt[c + 1 - sj] + vt[c + 1]))) * damp;
+  } else if (i == g.ie + 1 || i == g.is) {
+    const double cu = m.cosa_u[c2 + 1];
+    damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+    val = (vc[c] - 0.25 * cv * (ut[c] + ut[c - sj] + ut[c + 1 - sj] + uc[c + 1] -
+                                0.25 * cu * (vt[c + sj] + vt[c + 1 + sj] + vt[c + 1]))) * damp;
+  } else {
+    const double cu = m.cosa_u[c2];
+    damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+    val = (vc[c] - 0.25 * cv * (ut[c + 1] + ut[c + 1 - sj] + ut[c - sj] + uc[c] -
+                                0.25 * cu * (vt[c + sj] + vt[c - 1 + sj] + vt[c - 1]))) * damp;
+  }
+  vt[c] = val;
+}
+
+// fxadv_fluxes_stencil (:436-486)
+__global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const double* __restrict__ ut,
+                                                      const double* __restrict__ vt, double* __restrict__ crx,
+                                                      double* __restrict__ cry, double* __restrict__ xfx,
+                                                      double* __restrict__ yfx, double dt) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  if (i >= g.is && i <= g.ie + 1) {
+    const double u = ut[c];
+    if (u > 0.0) {
+      crx[c] = dt * u * m.rdxa[c2 - 1];
+      xfx[c] = m.dy[c2] * dt * u * m.sin_sg3[c2 - 1];
+    } else {
+      crx[c] = dt * u * m.rdxa[c2];
+      xfx[c] = m.dy[c2] * dt * u * m.sin_sg1[c2];
+    }
+  }
+  if (j >= g.js && j <= g.je + 1) {
+    const double v = vt[c];
+    if (v > 0.0) {
+      cry[c] = dt * v * m.rdya[c2 - g.sj];
+      yfx[c] = m.dx[c2] * dt * v * m.sin_sg4[c2 - g.sj];
+    } else {
+      cry[c] = dt * v * m.rdya[c2];
+      yfx[c] = m.dx[c2] * dt * v * m.sin_sg2[c2];
+    }
+  }
+}
+
+int launch_fxadv(const Geo& g, const Met& m, const double* uc, const double* vc, double* crx, double* cry,
+                 double* xfx, double* yfx, double* ut, double* vt, double dt, hipStream_t st) {
+  const dim3 grid = plane_grid(g, g.nk), block(256);
+  hipLaunchKernelGGL(k_fxadv_main, grid, block, 0, st, g, m, uc, vc, ut, vt);
+  hipLaunchKernelGGL(k_fxadv_vt_edges, grid, block, 0, st, g, m, vc, ut, vt);
+  hipLaunchKernelGGL(k_fxadv_ut_edges_corners, grid, block, 0, st, g, m, uc, vc, ut, vt);
+  hipLaunchKernelGGL(k_fxadv_vt_corners, grid, block, 0, st, g, m, uc, vc, ut, vt);
+  hipLaunchKernelGGL(k_fxadv_fluxes, grid, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}

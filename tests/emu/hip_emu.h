@@ -1,0 +1,51 @@
+// CPU emulation of the small slice of the HIP programming model our kernels use.
+//
+// TEST INFRASTRUCTURE ONLY.  It lets the *same kernel sources* (pace_amd/csrc/*.hip) be compiled
+// by g++ (optionally with -fsanitize=address,undefined -- GPU sanitizers are unavailable on the
+// MI355X pool) and run inside the CPU-only container, so index logic, LDS tiling and barrier
+// structure can be checked against the oracle before a kernel ever reaches a GPU.  The product
+// loader (pace_amd/_lib.py) never loads the emulation library; see tests/emu/README.md.
+//
+// Model: blocks run one after another; the threads of a block are ucontext fibers that switch at
+// __syncthreads(); __shared__ variables become function-local statics (shared by all fibers).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <ucontext.h>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+
+extern uint3_emu threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __restrict__
+#define __launch_bounds__(...)
+#define PACE_EMU 1
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+void __syncthreads();
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+using std::exp; using std::log; using std::sqrt; using std::fabs; using std::fmin; using std::fmax;
+using std::sin; using std::cos; using std::asin; using std::pow;
