@@ -1,0 +1,215 @@
+"""Benchmark of the hot path named in BASELINE.json: one acoustic substep = d_sw + riem_solver3 on one
+cubed-sphere tile per GPU, fp64, C192 x 79 levels, synthetic (baroclinic-like) state.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 192] [--nz 79]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one d_sw call followed by one riem_solver3 call on one pristine, HBM-resident copy of the
+model state (K + W copies are staged before the timed region; nothing is re-used between steps, so no
+step benefits from cached data of the previous one).  Prints ONE JSON line on rank 0.
+
+Multi-GPU: tiles are independent inside d_sw + riem_solver3 (the delp/pt/q_con halo exchange of
+dyn_core.py:854 between them is not part of this round's path -- DESIGN.md), so ranks run their tile
+with no data-path collective and the result is weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+BYTES_PER_CELL_UPDATE = 360.0  # d_sw 32 fields + riem_solver3 13 fields, fp64
+FVTP2D_FIELDS = 9  # q, crx, cry, xfx, yfx, x/y mass flux in; fx, fy out (mass-flux variant, 3 of 5 calls)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--n", type=int, default=192)
+    p.add_argument("--nz", type=int, default=79)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-n", type=int, default=192, help="tile size of the bounded CPU-baseline sample")
+    return p.parse_args()
+
+
+def column_namelist(nz, qf):
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import get_column_namelist
+
+    return get_column_namelist(DGridShallowWaterLagrangianDynamicsConfig(), qf)
+
+
+def cpu_baseline(n, nz):
+    """The oracle (numpy restatement with the reference's stencil granularity) timed on the host:
+    one d_sw + riem_solver3 substep at C<n> x nz.  kind = 'port', 1 thread (numpy elementwise)."""
+    from helpers import DSW_ARGS, DSW_CFG
+
+    from oracle import dgrid_sw, vertical
+    from oracle._np import Grid
+    from pace_amd import synthetic
+
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    g = Grid(n, nz, m)
+    # column namelist values (d_sw.py:633-683) without touching a device
+    col = {}
+    z = nz + 1
+    col["nord"] = np.full(z, 3.0); col["nord"][:3] = 0  # noqa: E702
+    col["nord_v"] = np.full(z, 2.0); col["nord_v"][:2] = 0  # noqa: E702
+    col["nord_w"] = np.full(z, 2.0); col["nord_w"][:3] = 0  # noqa: E702
+    col["nord_t"] = np.full(z, 2.0)
+    col["damp_vt"] = np.full(z, 0.06); col["damp_vt"][:2] = [0.1, 0.05]  # noqa: E702
+    col["damp_w"] = np.full(z, 0.06); col["damp_w"][:3] = [0.2, 0.1, 0.02]  # noqa: E702
+    col["damp_t"] = np.full(z, 0.06)
+    col["d2_divg"] = np.zeros(z); col["d2_divg"][:3] = [0.2, 0.1, 0.02]  # noqa: E702
+    col["d_con"] = np.full(z, 1.0); col["d_con"][:3] = 0  # noqa: E702
+    col["ke_bg"] = np.zeros(z)
+    st = dgrid_sw.DSWState(s["u"].shape)
+    a = {k: s[k].copy() for k in DSW_ARGS}
+    t0 = time.perf_counter()
+    dgrid_sw.d_sw(g, col, DSW_CFG, st, *[a[k] for k in DSW_ARGS], s["dt"])
+    vertical.riem_solver3(g, False, s["dt"], s["cappa"], m["ptop"], s["zs"], s["ws"], s["delz"], a["q_con"], a["delp"], a["pt"],
+                          s["zh"], s["pe"], s["ppe"], s["pk3"], s["pk"], s["peln"], a["w"], p_fac=0.05)
+    dt = time.perf_counter() - t0
+    return {"value": n * n * nz / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"1 substep (d_sw + riem_solver3) at C{n}x{nz}L, numpy oracle, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    from helpers import DSW_ARGS, Env
+
+    from pace_amd import _lib, synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig
+    from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics
+    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
+    from pace_amd.fv3core.stencils.riem_solver3 import NonhydrostaticVerticalSolver
+
+    lib = _lib.load()
+    n, nz = args.n, args.nz
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    env = Env(lib, dev, metrics, n, nz)
+    col = column_namelist(nz, env.qf)
+    dsw = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, nested=False,
+                                              stretched_grid=False, config=DGridShallowWaterLagrangianDynamicsConfig())
+    riem = NonhydrostaticVerticalSolver(env.stencil_factory, env.qf, RiemannConfig())
+    ptop = float(metrics["ptop"])
+    dt = float(s["dt"])
+
+    RIEM_ONLY = ("cappa", "delz", "pe", "ppe", "pk3", "pk", "peln")
+    base = {k: env.q3(s[k]) for k in list(DSW_ARGS) + list(RIEM_ONLY)}
+    zs, ws = env.q2(s["zs"]), env.q2(s["ws"])
+    nbatch = args.steps + args.warmup
+
+    def clone_state():
+        out = {}
+        for k, q in base.items():
+            c = env.q3()
+            c._base.copy_(q._base)
+            out[k] = c
+        return out
+
+    batches = [clone_state() for _ in range(nbatch)]
+    torch.cuda.synchronize()
+
+    def step(b):
+        dsw(*[b[k] for k in DSW_ARGS], dt)
+        riem(False, dt, b["cappa"], ptop, zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"], b["ppe"], b["pk3"],
+             b["pk"], b["peln"], b["w"])
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batches[i])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nbatch):
+        step(batches[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    cells = n * n * nz
+    value = world * cells * args.steps / elapsed
+
+    # dominant kernel: k_fvtp2d (5 launches per d_sw); timed live with events on the launch stream
+    roof = None
+    if rank == 0:
+        b = batches[0]
+        tp = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 6)
+        reps = max(10, args.steps)
+        for _ in range(3):
+            tp(b["pt"], b["crx"], b["cry"], b["xfx"], b["yfx"], b["mfx"], b["mfy"], x_mass_flux=b["cx"], y_mass_flux=b["cy"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tp(b["pt"], b["crx"], b["cry"], b["xfx"], b["yfx"], b["mfx"], b["mfy"], x_mass_flux=b["cx"], y_mass_flux=b["cy"])
+        e1.record()
+        torch.cuda.synchronize()
+        t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
+        algo = FVTP2D_FIELDS * 8.0 * (n + 1) * (n + 1) * nz
+        roof = {"kernel": "k_fvtp2d<6>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_launch": t_kernel * 1e6}
+
+    if rank == 0:
+        line = {
+            "metric": "cell-updates/s per acoustic substep (d_sw+riem3), C192x79L; % HBM roofline",
+            "value": value,
+            "unit": "cell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, fp64",
+                       "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}"},
+            "step_hbm_frac": BYTES_PER_CELL_UPDATE * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_n, nz)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

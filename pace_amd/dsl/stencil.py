@@ -1,0 +1,237 @@
+"""The stencil-construction boundary of the reference (dsl/pace/dsl/stencil.py:268-1002,
+stencil_config.py:28-246) re-expressed over libpace_hip.so.
+
+In the reference every numerical class builds ``FrozenStencil`` objects from gtscript definition
+functions through a ``StencilFactory``; GT4Py compiles them.  Here there is no compiler: the hot-path
+classes under ``pace_amd.fv3core.stencils`` bind whole-class HIP entry points, and a ``FrozenStencil``
+is a *lookup* of ``func.__module__ + "." + func.__name__`` (the identity GT4Py itself uses,
+stencil_config.py:226) in the registry of per-stencil device implementations.  An unregistered
+stencil raises -- nothing silently falls back to the CPU.
+"""
+import dataclasses
+import inspect
+from typing import Any, Callable, Dict, Mapping, Optional, Sequence, Tuple
+
+from .. import _lib
+from ..util import constants as c
+
+Index3D = Tuple[int, int, int]
+
+
+class CompilationConfig:
+    """stencil_config.py:28-160 (fields that still mean something without a compiler)."""
+
+    def __init__(self, backend: str = "hip:gfx950", rebuild: bool = False, validate_args: bool = True,
+                 format_source: bool = False, device_sync: bool = False, **_ignored):
+        if backend in ("numpy", "gt:cpu_ifirst", "gt:cpu_kfirst", "gt:gpu", "cuda", "dace:cpu", "dace:gpu"):
+            raise ValueError(f"backend {backend!r} is a GT4Py backend; pace_amd only provides 'hip:gfx950'")
+        self.backend = backend
+        self.rebuild = rebuild
+        self.validate_args = validate_args
+        self.format_source = format_source
+        self.device_sync = device_sync
+
+
+@dataclasses.dataclass
+class StencilConfig:
+    compare_to_numpy: bool = False
+    compilation_config: CompilationConfig = dataclasses.field(default_factory=CompilationConfig)
+    dace_config: Any = None
+
+    @property
+    def backend(self):
+        return self.compilation_config.backend
+
+    @property
+    def is_gpu_backend(self) -> bool:
+        return True
+
+
+class GridIndexing:
+    """Index bookkeeping for cell-centred fields with halos (stencil.py:542-855)."""
+
+    def __init__(self, domain: Index3D, n_halo: int, south_edge: bool, north_edge: bool, west_edge: bool, east_edge: bool):
+        self.origin = (n_halo, n_halo, 0)
+        self.n_halo = n_halo
+        self.domain = tuple(domain)
+        self.south_edge, self.north_edge, self.west_edge, self.east_edge = south_edge, north_edge, west_edge, east_edge
+
+    @classmethod
+    def from_sizer_and_communicator(cls, sizer, cube=None) -> "GridIndexing":
+        # one tile per rank: every rank owns all four tile edges (partitioner.py:525-590)
+        return cls((sizer.nx, sizer.ny, sizer.nz), sizer.n_halo, True, True, True, True)
+
+    isc = property(lambda s: s.origin[0])
+    iec = property(lambda s: s.origin[0] + s.domain[0] - 1)
+    jsc = property(lambda s: s.origin[1])
+    jec = property(lambda s: s.origin[1] + s.domain[1] - 1)
+    isd = property(lambda s: s.origin[0] - s.n_halo)
+    ied = property(lambda s: s.isd + s.domain[0] + 2 * s.n_halo - 1)
+    jsd = property(lambda s: s.origin[1] - s.n_halo)
+    jed = property(lambda s: s.jsd + s.domain[1] + 2 * s.n_halo - 1)
+    sw_corner = property(lambda s: s.south_edge and s.west_edge)
+    se_corner = property(lambda s: s.south_edge and s.east_edge)
+    nw_corner = property(lambda s: s.north_edge and s.west_edge)
+    ne_corner = property(lambda s: s.north_edge and s.east_edge)
+
+    @property
+    def max_shape(self):
+        return self.domain_full(add=(1, 1, 1 + self.origin[2]))
+
+    def origin_full(self, add: Index3D = (0, 0, 0)):
+        return (self.isd + add[0], self.jsd + add[1], self.origin[2] + add[2])
+
+    def origin_compute(self, add: Index3D = (0, 0, 0)):
+        return (self.isc + add[0], self.jsc + add[1], self.origin[2] + add[2])
+
+    def domain_full(self, add: Index3D = (0, 0, 0)):
+        return (self.ied + 1 - self.isd + add[0], self.jed + 1 - self.jsd + add[1], self.domain[2] + add[2])
+
+    def domain_compute(self, add: Index3D = (0, 0, 0)):
+        return (self.iec + 1 - self.isc + add[0], self.jec + 1 - self.jsc + add[1], self.domain[2] + add[2])
+
+    def axis_offsets(self, origin, domain) -> Dict[str, Any]:
+        """Global-index form of the reference's axis-offset externals (stencil.py:717-759): with one
+        tile per rank i_start == local_is == isc and so on."""
+        big = 2 ** 15
+        return {
+            "i_start": self.isc if self.west_edge else -big,
+            "local_is": self.isc,
+            "i_end": self.iec if self.east_edge else big,
+            "local_ie": self.iec,
+            "j_start": self.jsc if self.south_edge else -big,
+            "local_js": self.jsc,
+            "j_end": self.jec if self.north_edge else big,
+            "local_je": self.jec,
+        }
+
+    def get_origin_domain(self, dims: Sequence[str], halos: Sequence[int] = ()):
+        origin = []
+        domain = []
+        for d in dims:
+            if d in c.X_DIMS:
+                origin.append(self.origin[0])
+                domain.append(self.domain[0] + (1 if d == c.X_INTERFACE_DIM else 0))
+            elif d in c.Y_DIMS:
+                origin.append(self.origin[1])
+                domain.append(self.domain[1] + (1 if d == c.Y_INTERFACE_DIM else 0))
+            elif d in c.Z_DIMS:
+                origin.append(self.origin[2])
+                domain.append(self.domain[2] + (1 if d == c.Z_INTERFACE_DIM else 0))
+        for i, n in enumerate(halos):
+            origin[i] -= n
+            domain[i] += 2 * n
+        return tuple(origin), tuple(domain)
+
+    def get_shape(self, dims: Sequence[str], halos: Sequence[int] = ()):
+        _, shape = self.get_origin_domain(dims)
+        shape = list(shape)
+        for i, d in enumerate(dims):
+            if d in c.HORIZONTAL_DIMS:
+                shape[i] += self.n_halo
+        for i, n in enumerate(halos):
+            shape[i] += n
+        return tuple(shape)
+
+    def restrict_vertical(self, k_start=0, nk=None) -> "GridIndexing":
+        if k_start < 0:
+            raise ValueError("k_start must be positive")
+        if k_start > self.domain[2]:
+            raise ValueError(f"k_start must be less than the number of vertical levels (received {k_start} for {self.domain[2]})")
+        if nk is None:
+            nk = self.domain[2] - k_start
+        elif nk < 0:
+            raise ValueError("number of vertical levels should be positive")
+        elif nk > self.domain[2] - k_start:
+            raise ValueError("nk can be at most the size of the vertical domain minus k_start")
+        new = GridIndexing(self.domain[:2] + (nk,), self.n_halo, self.south_edge, self.north_edge, self.west_edge, self.east_edge)
+        new.origin = self.origin[:2] + (self.origin[2] + k_start,)
+        return new
+
+
+_REGISTRY: Dict[str, Callable] = {}
+
+
+def register_stencil(name: str):
+    """Register a device implementation ``impl(stencil, **named_args)`` for a stencil identity."""
+
+    def deco(fn):
+        _REGISTRY[name] = fn
+        return fn
+
+    return deco
+
+
+class FrozenStencil:
+    """stencil.py:268-519: origin/domain frozen at construction, in-place call, no return value."""
+
+    def __init__(self, func: Callable[..., None], origin, domain, stencil_config: StencilConfig,
+                 externals: Optional[Mapping[str, Any]] = None, skip_passes=(), timing_collector=None, comm=None,
+                 factory=None):
+        if isinstance(origin, tuple) and len(origin) != 3:
+            raise ValueError(f"expected 3d index, received {origin}")
+        if len(domain) != 3:
+            raise ValueError(f"expected 3d index, received {domain}")
+        self.origin = origin
+        self.domain = tuple(domain)
+        self.stencil_config = stencil_config
+        self.externals = dict(externals or {})
+        self._func_name = func.__name__
+        self.name = func.__module__ + "." + func.__name__
+        self._argument_names = tuple(inspect.getfullargspec(func).args)
+        assert len(self._argument_names) > 0, "A stencil with no arguments? You may be double decorating"
+        self._factory = factory
+        impl = _REGISTRY.get(self.name) or _REGISTRY.get(func.__name__)
+        if impl is None:
+            raise NotImplementedError(
+                f"no HIP implementation registered for stencil {self.name!r}; registered: {sorted(_REGISTRY)}. "
+                "pace_amd binds the acoustic-step classes at class level (pace_amd.fv3core.stencils) and does not "
+                "execute gtscript."
+            )
+        self._impl = impl
+
+    def __call__(self, *args, **kwargs) -> None:
+        if "origin" in kwargs:
+            raise TypeError("origin cannot be passed to FrozenStencil call")
+        if "domain" in kwargs:
+            raise TypeError("domain cannot be passed to FrozenStencil call")
+        named = dict(zip(self._argument_names, args))
+        named.update(kwargs)
+        self._impl(self, **named)
+
+
+class StencilFactory:
+    """stencil.py:858-970."""
+
+    def __init__(self, config: StencilConfig, grid_indexing: GridIndexing, comm=None, lib: Optional[_lib.Library] = None):
+        self.config = config
+        self.grid_indexing = grid_indexing
+        self.comm = comm
+        self.lib = lib if lib is not None else _lib.load()
+
+    @property
+    def backend(self):
+        return self.config.compilation_config.backend
+
+    def from_origin_domain(self, func, origin, domain, externals=None, skip_passes=()):
+        return FrozenStencil(func, origin, domain, self.config, externals=externals, skip_passes=skip_passes, factory=self)
+
+    def from_dims_halo(self, func, compute_dims, compute_halos=(), externals=None, skip_passes=()):
+        if len(compute_dims) != 3:
+            raise ValueError(f"must have 3 dimensions to create stencil, got {compute_dims}")
+        origin, domain = self.grid_indexing.get_origin_domain(dims=compute_dims, halos=compute_halos)
+        all_externals = self.grid_indexing.axis_offsets(origin=origin, domain=domain)
+        all_externals.update(externals or {})
+        return self.from_origin_domain(func, origin=origin, domain=domain, externals=all_externals, skip_passes=skip_passes)
+
+    def restrict_vertical(self, k_start=0, nk=None) -> "StencilFactory":
+        return StencilFactory(self.config, self.grid_indexing.restrict_vertical(k_start=k_start, nk=nk), comm=self.comm, lib=self.lib)
+
+
+def get_stencils_with_varied_bounds(func, origins, domains, stencil_factory, externals=None):
+    assert len(origins) == len(domains), "Lists of origins and domains need to have the same length"
+    out = []
+    for origin, domain in zip(origins, domains):
+        ax = stencil_factory.grid_indexing.axis_offsets(origin=origin, domain=domain)
+        out.append(stencil_factory.from_origin_domain(func, origin=origin, domain=domain, externals={**(externals or {}), **ax}))
+    return out

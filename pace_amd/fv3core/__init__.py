@@ -1,0 +1,6 @@
+from ._config import (  # noqa: F401
+    AcousticDynamicsConfig,
+    DGridShallowWaterLagrangianDynamicsConfig,
+    DynamicalCoreConfig,
+    RiemannConfig,
+)

@@ -1,0 +1,104 @@
+"""DGridShallowWaterLagrangianDynamics + get_column_namelist
+(reference: fv3core/pace/fv3core/stencils/d_sw.py:614-683,726-1237)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ...util.constants import Z_DIM
+from .._config import DGridShallowWaterLagrangianDynamicsConfig
+from ._common import Operator, check_layout, dptr, host_column
+
+dcon_threshold = 1e-5
+
+
+def get_column_namelist(config: DGridShallowWaterLagrangianDynamicsConfig, quantity_factory):
+    """d_sw.py:633-683: dictionary of K-Quantities describing how nord/damp vary with level."""
+    names = ["ke_bg", "d_con", "nord", "nord_v", "nord_w", "nord_t", "damp_vt", "damp_w", "damp_t", "d2_divg"]
+    nz = quantity_factory.sizer.nz
+    col = {n: np.zeros(nz + 1) for n in names}
+    v = {n: col[n][:nz] for n in names}  # the reference's .view (compute levels)
+    for n in ("ke_bg", "d_con", "nord"):
+        v[n][:] = getattr(config, n)
+    v["d2_divg"][:] = min(0.2, config.d2_bg)
+    v["nord_v"][:] = min(2, v["nord"][0])
+    v["nord_w"][:] = v["nord_v"][0]
+    v["nord_t"][:] = v["nord_v"][0]
+    v["damp_vt"][:] = config.vtdm4 if config.do_vort_damp else 0
+    v["damp_w"][:] = v["damp_vt"][0]
+    v["damp_t"][:] = v["damp_vt"][0]
+
+    def set_low(k):
+        for n in ("nord", "nord_w", "d_con"):
+            v[n][k] = 0
+        v["damp_w"][k] = v["d2_divg"][k]
+
+    def vort_opt(k):
+        if config.do_vort_damp:
+            v["nord_v"][k] = 0
+            v["damp_vt"][k] = 0.5 * v["d2_divg"][k]
+
+    if nz == 1 or config.n_sponge < 0:
+        v["d2_divg"][0] = config.d2_bg
+    else:
+        v["d2_divg"][0] = max(0.01, config.d2_bg, config.d2_bg_k1)
+        set_low(0)
+        vort_opt(0)
+        if config.d2_bg_k2 > 0.01:
+            v["d2_divg"][1] = max(config.d2_bg, config.d2_bg_k2)
+            set_low(1)
+            vort_opt(1)
+        if config.d2_bg_k2 > 0.05:
+            v["d2_divg"][2] = max(config.d2_bg, 0.2 * config.d2_bg_k2)
+            set_low(2)
+    out = {}
+    for n in names:
+        q = quantity_factory.zeros([Z_DIM], units="unknown")
+        q.set(col[n])
+        out[n] = q
+    return out
+
+
+class DGridShallowWaterLagrangianDynamics(Operator):
+    """Fortran d_sw.  One call = the 29-launch HIP sequence in csrc/k_dsw.hip::launch_d_sw instead of
+    the reference's 177 stencil launches."""
+
+    def __init__(self, stencil_factory, quantity_factory, grid_data, damping_coefficients, column_namelist, nested: bool,
+                 stretched_grid: bool, config: DGridShallowWaterLagrangianDynamicsConfig):
+        super().__init__(stencil_factory, quantity_factory, grid_data)
+        assert config.grid_type < 3, "ubke and vbke only implemented for grid_type < 3"
+        assert not config.inline_q, "inline_q not yet implemented"
+        assert config.d_ext <= 0, "untested d_ext > 0. need to call a2b_ord2, not yet implemented"
+        assert not nested, "nested not implemented"
+        if stretched_grid:
+            raise NotImplementedError("stretched_grid")
+        if config.do_f3d:
+            raise NotImplementedError("do_f3d is not implemented")
+        nz = self.grid_indexing.domain[2]
+        col = {k: host_column(v, nz) for k, v in column_namelist.items()}
+        assert (col["damp_vt"] > dcon_threshold).all()
+        assert (col["damp_w"] > dcon_threshold).all()
+        da_min, da_min_c = damping_coefficients.da_min, damping_coefficients.da_min_c
+        # calc_damp exactly where the reference evaluates it (DelnFlux.__init__ with da_min; d_sw.py:924-933 with da_min_c)
+        col["fac_vt"] = (col["damp_vt"] * da_min) ** (col["nord_v"] + 1)
+        col["fac_t"] = (col["damp_t"] * da_min) ** (col["nord_t"] + 1)
+        col["fac_vt_c"] = (col["damp_vt"] * da_min_c) ** (col["nord_v"] + 1)
+        col["fac_w_c"] = (col["damp_w"] * da_min_c) ** (col["nord_w"] + 1)
+        self._col_host = {k: np.ascontiguousarray(v) for k, v in col.items()}
+        self._col = _lib.Column()
+        for k in _lib.COLUMN_FIELDS:
+            setattr(self._col, k, self._col_host[k].ctypes.data_as(C.POINTER(C.c_double)))
+        self._cfg = _lib.DswConfig(config.hord_dp, config.hord_tm, config.hord_vt, config.hord_mt, config.nord,
+                                   int(config.do_skeb), config.dddmp, config.d4_bg, config.d_con)
+        nbytes = self.lib.cdll.pace_d_sw_workspace_bytes(C.byref(self._geom))
+        self._workspace = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=quantity_factory.device)
+        self.call("pace_d_sw_prepare", C.byref(self._col), self._workspace.data_ptr(), self.stream())
+
+    def __call__(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
+                 heat_source, diss_est, dt):
+        fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
+                  heat_source, diss_est)
+        check_layout(self._geom, *fields)
+        self.call("pace_d_sw", C.byref(self._met), C.byref(self._col), C.byref(self._cfg), self._workspace.data_ptr(),
+                  *[dptr(f) for f in fields], float(dt), self.stream())

@@ -1,0 +1,60 @@
+"""The HIP kernel SOURCES compiled for the CPU (tests/emu) and driven through the same host classes and
+C ABI, checked against the reference-generated fixtures.  This is how kernel index logic / LDS tiling /
+barrier structure is verified in the GPU-less container (and under ASan); it says nothing about the GPU
+build, which the `-m gpu` tests cover.  CPU only."""
+import numpy as np
+import pytest
+
+from helpers import (DSW_ARGS, Env, build_emu, column_for_levels, compare, dsw_window, expand_riem_fixture, golden, run_d_sw,
+                     run_riem3, window)
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    from pace_amd import _lib
+
+    return _lib.Library(build_emu())
+
+
+@pytest.mark.parametrize("name,tile", [("d_sw_c12_tile0_call1.npz", 0), ("d_sw_c12_tile1_call3.npz", 1)])
+def test_d_sw_kernels_emulated(emu_lib, name, tile):
+    fix = golden(name)
+    k_sel = fix["k_sel"]
+    nk = len(k_sel)
+    env = Env(emu_lib, "cpu", golden(f"grid_c12_tile{tile}.npz"), 12, nk)
+    out, _ = run_d_sw(env, column_for_levels(k_sel), {k: fix["in_" + k] for k in DSW_ARGS}, float(fix["dt"]),
+                      ut0=fix["in_uc_contra"], vt0=fix["in_vc_contra"])
+    for k in DSW_ARGS:
+        if k in ("divgd", "uc", "vc", "zh"):
+            continue
+        err = compare(fix["out_" + k][dsw_window(k, 12, nk)], out[k][dsw_window(k, 12, nk)])
+        assert err < 3.2e-10, (k, err)
+
+
+@pytest.mark.parametrize("name", ["riem_solver3_c12_tile0_call2.npz", "riem_solver3_c12_tile0_call3.npz"])
+def test_riem_solver3_kernel_emulated(emu_lib, name):
+    fix = golden(name)
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, 79)
+    out = run_riem3(env, expand_riem_fixture(fix), bool(fix["last_call"]), float(fix["dt"]), float(fix["ptop"]))
+    for k in ("delz", "zh", "p", "ppe", "pk3", "pk", "log_p_interface", "w"):
+        nk = 79 if k in ("delz", "w") else 80
+        err = compare(fix["out_" + k][:, :, :nk], out[k][3:15, 3:7, :nk], near_zero=1e-12)
+        assert err < 5e-6, (k, err)  # overrides/standard.yaml:49-61
+
+
+def test_fvtp2d_kernel_emulated(emu_lib):
+    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
+
+    fix = golden("fvtp2d_c12_tile0_call8.npz")
+    k_sel = golden("d_sw_c12_tile0_call1.npz")["k_sel"]
+    nk = len(k_sel)
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, nk)
+    col = column_for_levels(k_sel)
+    op = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 6, nord=env.kq(col["nord_t"]),
+                               damp_c=env.kq(col["damp_t"]))
+    f = {k[3:]: env.q3(v) for k, v in fix.items() if k.startswith("in_")}
+    fx, fy = env.q3(), env.q3()
+    op(f["q"], f["crx"], f["cry"], f["x_area_flux"], f["y_area_flux"], fx, fy, x_mass_flux=f["x_mass_flux"],
+       y_mass_flux=f["y_mass_flux"], mass=f["mass"])
+    assert compare(fix["out_q_x_flux"][window(12, 1, 0, nk)], fx.numpy()[window(12, 1, 0, nk)]) < 1e-14
+    assert compare(fix["out_q_y_flux"][window(12, 0, 1, nk)], fy.numpy()[window(12, 0, 1, nk)]) < 1e-14

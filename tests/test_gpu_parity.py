@@ -1,0 +1,150 @@
+"""`-m gpu`: the HIP library on a real MI355X, through the C ABI and the host classes.
+
+* against the reference-generated fixtures (C12),
+* against the oracle on synthetic inputs at C48 x 79 (all levels, tile seams of the LDS kernels),
+* at the BASELINE size (C192 x 79) through size-independent properties.
+"""
+import numpy as np
+import pytest
+
+from helpers import (DSW_ARGS, DSW_CFG, RIEM_ARGS, Env, column_for_levels, compare, dsw_window, expand_riem_fixture, golden,
+                     oracle_grid, run_d_sw, run_riem3, window)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pace_amd import _lib
+
+    return _lib.load()  # raises if libpace_hip.so is missing: no fallback
+
+
+def full_column(nz):
+    col = golden("column_namelist_c12.npz")
+    return {k: np.ascontiguousarray(v[:nz]) for k, v in col.items()}
+
+
+@pytest.mark.parametrize("name,tile", [("d_sw_c12_tile0_call1.npz", 0), ("d_sw_c12_tile1_call3.npz", 1)])
+def test_d_sw_matches_reference_fixture(lib, name, tile):
+    fix = golden(name)
+    k_sel = fix["k_sel"]
+    nk = len(k_sel)
+    env = Env(lib, "cuda", golden(f"grid_c12_tile{tile}.npz"), 12, nk)
+    out, _ = run_d_sw(env, column_for_levels(k_sel), {k: fix["in_" + k] for k in DSW_ARGS}, float(fix["dt"]),
+                      ut0=fix["in_uc_contra"], vt0=fix["in_vc_contra"])
+    for k in DSW_ARGS:
+        if k in ("divgd", "uc", "vc", "zh"):
+            continue
+        err = compare(fix["out_" + k][dsw_window(k, 12, nk)], out[k][dsw_window(k, 12, nk)])
+        assert err < 3.2e-10, (k, err)  # translate_d_sw.py:19
+
+
+@pytest.mark.parametrize("name", ["riem_solver3_c12_tile0_call2.npz", "riem_solver3_c12_tile0_call3.npz"])
+def test_riem_solver3_matches_reference_fixture(lib, name):
+    fix = golden(name)
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, 79)
+    out = run_riem3(env, expand_riem_fixture(fix), bool(fix["last_call"]), float(fix["dt"]), float(fix["ptop"]))
+    for k in ("delz", "zh", "p", "ppe", "pk3", "pk", "log_p_interface", "w"):
+        nk = 79 if k in ("delz", "w") else 80
+        err = compare(fix["out_" + k][:, :, :nk], out[k][3:15, 3:7, :nk], near_zero=1e-12)
+        assert err < 5e-6, (k, err)  # overrides/standard.yaml:49-61
+
+
+def test_fvtp2d_matches_reference_fixture(lib):
+    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
+
+    fix = golden("fvtp2d_c12_tile0_call8.npz")
+    k_sel = golden("d_sw_c12_tile0_call1.npz")["k_sel"]
+    nk = len(k_sel)
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, nk)
+    col = column_for_levels(k_sel)
+    op = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 6, nord=env.kq(col["nord_t"]),
+                               damp_c=env.kq(col["damp_t"]))
+    f = {k[3:]: env.q3(v) for k, v in fix.items() if k.startswith("in_")}
+    fx, fy = env.q3(), env.q3()
+    op(f["q"], f["crx"], f["cry"], f["x_area_flux"], f["y_area_flux"], fx, fy, x_mass_flux=f["x_mass_flux"],
+       y_mass_flux=f["y_mass_flux"], mass=f["mass"])
+    assert compare(fix["out_q_x_flux"][window(12, 1, 0, nk)], fx.numpy()[window(12, 1, 0, nk)]) < 1e-13
+    assert compare(fix["out_q_y_flux"][window(12, 0, 1, nk)], fy.numpy()[window(12, 0, 1, nk)]) < 1e-13
+
+
+def test_d_sw_and_riem3_match_oracle_c48(lib):
+    """Synthetic C48 x 79: exercises every level class (k = 0, 1, 2, >= 3) and the tile seams of the LDS kernels."""
+    from oracle import dgrid_sw, vertical
+    from pace_amd import synthetic
+
+    n, nz = 48, 79
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    col = full_column(nz)
+    env = Env(lib, "cuda", metrics, n, nz)
+    out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"])
+    g = oracle_grid(metrics, n, nz)
+    st = dgrid_sw.DSWState(s["u"].shape)
+    a = {k: s[k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(g, col, DSW_CFG, st, *[a[k] for k in DSW_ARGS], s["dt"])
+    for k in DSW_ARGS:
+        if k in ("divgd", "uc", "vc", "zh"):
+            continue
+        scale = float(np.abs(a[k][dsw_window(k, n, nz)]).max())
+        err = compare(a[k][dsw_window(k, n, nz)], out[k][dsw_window(k, n, nz)], near_zero=1e-12 * max(scale, 1e-300))
+        assert err < 3.2e-10, (k, err)
+    # riem_solver3 on the d_sw-updated state
+    inp = {"cappa": s["cappa"], "zs": s["zs"], "ws": s["ws"], "delz": s["delz"], "q_con": a["q_con"], "delp": a["delp"],
+           "pt": a["pt"], "zh": s["zh"], "p": s["pe"], "ppe": s["ppe"], "pk3": s["pk3"], "pk": s["pk"],
+           "log_p_interface": s["peln"], "w": a["w"]}
+    got = run_riem3(env, inp, False, s["dt"], metrics["ptop"])
+    b = {k: v.copy() for k, v in inp.items()}
+    vertical.riem_solver3(g, False, s["dt"], b["cappa"], metrics["ptop"], b["zs"], b["ws"], b["delz"], b["q_con"], b["delp"], b["pt"],
+                          b["zh"], b["p"], b["ppe"], b["pk3"], b["pk"], b["log_p_interface"], b["w"], p_fac=0.05)
+    for k in ("delz", "zh", "ppe", "pk3", "w"):
+        nk = nz if k in ("delz", "w") else nz + 1
+        scale = float(np.abs(b[k][window(n, 0, 0, nk)]).max())
+        err = compare(b[k][window(n, 0, 0, nk)], got[k][window(n, 0, 0, nk)], near_zero=1e-9 * scale)
+        assert err < 5e-6, (k, err)
+
+
+def test_c192_properties(lib):
+    """BASELINE size (C192 x 79): properties that need no oracle.
+    (1) a constant scalar is transported as q * unit flux (fvtp2d consistency);
+    (2) d_sw is deterministic (bitwise) and leaves no NaN in its outputs;
+    (3) delp is updated in flux form: sum(delp*area) changes only by the boundary fluxes."""
+    import torch
+
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
+    from pace_amd.fv3core.stencils.fxadv import FiniteVolumeFluxPrep
+
+    n, nz = 192, 79
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    env = Env(lib, "cuda", metrics, n, nz)
+    col = full_column(nz)
+    # (1)
+    prep = FiniteVolumeFluxPrep(env.stencil_factory, env.grid_data)
+    f = {k: env.q3(s[k]) for k in ("uc", "vc")}
+    crx, cry, xfx, yfx, ut, vt = (env.q3() for _ in range(6))
+    prep(f["uc"], f["vc"], crx, cry, xfx, yfx, ut, vt, s["dt"])
+    tp = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 6)
+    q = env.q3(np.full(s["u"].shape, 2.5))
+    fx, fy = env.q3(), env.q3()
+    tp(q, crx, cry, xfx, yfx, fx, fy)
+    torch.cuda.synchronize()
+    w = window(n, 1, 0, nz)
+    np.testing.assert_allclose(fx.numpy()[w], 2.5 * xfx.numpy()[w], rtol=1e-13, atol=0)
+    # (2) + (3)
+    out1, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"])
+    out2, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"])
+    for k in ("delp", "pt", "u", "v", "w", "q_con", "mfx", "mfy", "heat_source"):
+        a, b = out1[k][dsw_window(k, n, nz)], out2[k][dsw_window(k, n, nz)]
+        assert np.isfinite(a).all(), k
+        assert np.array_equal(a, b), k
+    area = metrics["area"][3 : 3 + n, 3 : 3 + n, None]
+    c = window(n, 0, 0, nz)
+    dm = ((out1["delp"][c] - s["delp"][c]) * area).sum(axis=(0, 1))
+    mfx, mfy = out1["mfx"], out1["mfy"]
+    boundary = (mfx[3, 3 : 3 + n, :nz].sum(0) - mfx[3 + n, 3 : 3 + n, :nz].sum(0) + mfy[3 : 3 + n, 3, :nz].sum(0)
+                - mfy[3 : 3 + n, 3 + n, :nz].sum(0))
+    total = (s["delp"][c] * area).sum(axis=(0, 1))
+    np.testing.assert_allclose(dm / total, boundary / total, rtol=0, atol=1e-12)

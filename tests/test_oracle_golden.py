@@ -1,0 +1,122 @@
+"""The oracle (oracle/*.py) against fixtures produced by running the reference's own source
+(tools/make_golden.py).  CPU only.  Tolerances are the reference's translate-test tolerances
+ or tighter."""
+import numpy as np
+import pytest
+
+from helpers import DSW_ARGS, DSW_CFG, RIEM_ARGS, column_for_levels, compare, dsw_window, expand_riem_fixture, golden, oracle_grid, window
+
+
+@pytest.mark.parametrize("name,tile", [("d_sw_c12_tile0_call1.npz", 0), ("d_sw_c12_tile1_call3.npz", 1)])
+def test_d_sw_oracle_matches_reference(name, tile):
+    from oracle import dgrid_sw
+
+    fix = golden(name)
+    k_sel = fix["k_sel"]
+    nk = len(k_sel)
+    g = oracle_grid(golden(f"grid_c12_tile{tile}.npz"), 12, nk)
+    col = column_for_levels(k_sel)
+    st = dgrid_sw.DSWState(fix["in_u"].shape)
+    st.uc_contra[...] = fix["in_uc_contra"]
+    st.vc_contra[...] = fix["in_vc_contra"]
+    a = {k: fix["in_" + k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(g, col, DSW_CFG, st, *[a[k] for k in DSW_ARGS], float(fix["dt"]))
+    for k in DSW_ARGS:
+        if k in ("divgd", "uc", "vc", "zh"):
+            continue  # scratch after d_sw (d_sw.py:1032-1033) / untouched input
+        err = compare(fix["out_" + k][dsw_window(k, 12, nk)], a[k][dsw_window(k, 12, nk)])
+        assert err < 3.2e-10, (k, err)  # translate_d_sw.py:19
+
+
+@pytest.mark.parametrize("name", ["riem_solver3_c12_tile0_call2.npz", "riem_solver3_c12_tile0_call3.npz"])
+def test_riem_solver3_oracle_matches_reference(name):
+    from oracle import vertical
+
+    fix = golden(name)
+    g = oracle_grid(golden("grid_c12_tile0.npz"), 12, 79)
+    a = expand_riem_fixture(fix)
+    vertical.riem_solver3(g, bool(fix["last_call"]), float(fix["dt"]), a["cappa"], float(fix["ptop"]), a["zs"], a["ws"], a["delz"],
+                          a["q_con"], a["delp"], a["pt"], a["zh"], a["p"], a["ppe"], a["pk3"], a["pk"], a["log_p_interface"], a["w"],
+                          p_fac=0.05)
+    for k in ("delz", "zh", "p", "ppe", "pk3", "pk", "log_p_interface", "w"):
+        nk = 79 if k in ("delz", "w") else 80
+        got = a[k][3:15, 3:7, :nk]
+        err = compare(fix["out_" + k][:, :, :nk], got)
+        assert err < 1e-12, (k, err)  # reference tolerance is 5e-6 (overrides/standard.yaml:49-61)
+
+
+@pytest.mark.parametrize("name,nord,damp,mass", [("fvtp2d_c12_tile0_call6.npz", "nord_v", "damp_vt", False),
+                                                ("fvtp2d_c12_tile0_call8.npz", "nord_t", "damp_t", True)])
+def test_fvtp2d_oracle_matches_reference(name, nord, damp, mass):
+    from oracle import ppm_transport
+
+    fix = golden(name)
+    k_sel = golden("d_sw_c12_tile0_call1.npz")["k_sel"]
+    nk = len(k_sel)
+    g = oracle_grid(golden("grid_c12_tile0.npz"), 12, nk)
+    col = column_for_levels(k_sel)
+    q = fix["in_q"].copy()
+    fx, fy = np.zeros_like(q), np.zeros_like(q)
+    kw = dict(x_mass_flux=fix["in_x_mass_flux"], y_mass_flux=fix["in_y_mass_flux"], mass=fix["in_mass"]) if mass else {}
+    ppm_transport.fvtp2d(g, q, fix["in_crx"], fix["in_cry"], fix["in_x_area_flux"], fix["in_y_area_flux"], fx, fy, 6,
+                         nord_k=col[nord], damp_c_k=col[damp], **kw)
+    assert compare(fix["out_q_x_flux"][window(12, 1, 0, nk)], fx[window(12, 1, 0, nk)]) < 1e-14
+    assert compare(fix["out_q_y_flux"][window(12, 0, 1, nk)], fy[window(12, 0, 1, nk)]) < 1e-14
+
+
+def test_ppm_known_answers():
+    """Hand-derivable properties of the PPM operator (xppm.py:148-181): a constant field is transported
+    unchanged, and the interior interface formula is exact for cubics' cell means only up to its
+    4th-order truncation -- for a linear field the interface value is the exact midpoint."""
+    from oracle import ppm_transport
+    from oracle._np import Grid
+
+    n = 12
+    rng = np.random.default_rng(0)
+    metrics = dict(golden("grid_c12_tile0.npz"))
+    g = Grid(n, 4, metrics)
+    shape = (n + 7, n + 7, 5)
+    c = rng.random(shape) - 0.5
+    out = np.zeros(shape)
+    ppm_transport.ppm_flux(np.full(shape, 3.25), c, g.dxa, g, 0, 6, out, (3, 3), (n + 1, n))
+    assert np.all(out[3 : 3 + n + 1, 3 : 3 + n, :4] == 3.25)
+    lin = np.arange(n + 7, dtype=float).reshape(-1, 1, 1) * np.ones(shape)
+    al = ppm_transport.compute_al(lin, np.ones((n + 7, n + 7, 1)), g, 0)
+    np.testing.assert_allclose(al[5 : n, 3 : 3 + n, 0], lin[5:n, 3 : 3 + n, 0] - 0.5, rtol=0, atol=1e-13)
+
+
+def test_tridiagonal_solver_against_scipy():
+    """sim1_solver's first system (sim1_solver.py:60-88) is the tridiagonal system
+    [1+.. g_rat] pp = dd; check our restatement against scipy.linalg.solve_banded on one column."""
+    import scipy.linalg
+
+    from oracle import vertical
+
+    fix = golden("riem_solver3_c12_tile0_call2.npz")
+    g = oracle_grid(golden("grid_c12_tile0.npz"), 12, 79)
+    a = expand_riem_fixture(fix)
+    before_w = a["w"].copy()
+    vertical.riem_solver3(g, False, float(fix["dt"]), a["cappa"], float(fix["ptop"]), a["zs"], a["ws"], a["delz"], a["q_con"],
+                          a["delp"], a["pt"], a["zh"], a["p"], a["ppe"], a["pk3"], a["pk"], a["log_p_interface"], a["w"], p_fac=0.05)
+    # independent check of the w system: rebuild it from the solver's own outputs is circular, so check
+    # instead the discrete identity pe[k] - pe[k-1] = dm[k-1] (w - w_old)[k-1] / dt  (sim1_solver.py:118-126)
+    dm = fix["in_delp"][:, :, :79] / 9.80665
+    dpe = np.diff(a["ppe"][3:15, 3:7, :80], axis=2)
+    rhs = dm * (a["w"][3:15, 3:7, :79] - before_w[3:15, 3:7, :79]) / float(fix["dt"])
+    np.testing.assert_allclose(dpe, rhs, rtol=1e-9, atol=1e-9)
+    # and the banded-solve sanity on a synthetic diagonally dominant system of the same shape
+    n = 79
+    lo, di, up = np.full(n, 1.0), np.full(n, 4.0), np.full(n, 1.0)
+    rhs1 = np.arange(n, dtype=float)
+    ab = np.zeros((3, n))
+    ab[0, 1:], ab[1], ab[2, :-1] = up[:-1], di, lo[1:]
+    x = scipy.linalg.solve_banded((1, 1), ab, rhs1)
+    bet, gam, y = di[0], np.zeros(n), np.zeros(n)
+    y[0] = rhs1[0] / bet
+    for k in range(1, n):
+        gam[k] = up[k - 1] / bet
+        bet = di[k] - lo[k] * gam[k]
+        y[k] = (rhs1[k] - lo[k] * y[k - 1]) / bet
+    for k in range(n - 2, -1, -1):
+        y[k] -= gam[k + 1] * y[k + 1]
+    np.testing.assert_allclose(x, y, rtol=1e-12)
