@@ -127,6 +127,8 @@ int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, d
                       double* pk, double* peln, double* w, double p_fac, void* stream);
 
 const char* pace_version(void);
+/* Text of the last HIP error this library saw on the calling thread ("" if none). */
+const char* pace_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,7 @@ _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported con
 _P = C.POINTER
 _PROTOS = {
     "pace_version": (C.c_char_p, []),
+    "pace_last_error": (C.c_char_p, []),
     "pace_fxadv": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 8 + [C.c_double, C.c_void_p]),
     "pace_fvtp2d": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 9 + [C.c_int, C.c_int, C.c_void_p]),
     "pace_delnflux_nosg": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -83,6 +84,11 @@ class Library:
                 "pace_amd has no CPU fallback -- the HIP library is required."
             )
         self.path = path
+        if "emu" not in os.path.basename(path):
+            # One HIP runtime per process: PyTorch bundles its own libamdhip64/libhsa-runtime64 and owns the
+            # device memory and streams we are handed, so it must be loaded first; our DT_NEEDED
+            # libamdhip64.so.7 then binds to that same runtime instead of a second copy under /opt/rocm.
+            import torch  # noqa: F401
         self.cdll = C.CDLL(path)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
@@ -92,7 +98,8 @@ class Library:
     def call(self, name, *args):
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
-            raise PaceError(f"{name} failed: {_ERR.get(rc, rc)}")
+            detail = self.cdll.pace_last_error().decode() if rc == -2 else ""
+            raise PaceError(f"{name} failed: {_ERR.get(rc, rc)} {detail}".rstrip())
 
     def version(self):
         return self.cdll.pace_version().decode()

@@ -3,11 +3,24 @@
 #include "common.h"
 #include "kernels.h"
 
-#define NEED(p) if (!(p)) return PACE_ERR_ARG
+#include <cstdio>
+
+thread_local char g_pace_err[256] = "";
+void pace_set_err(const char* where, hipError_t e) {
+  snprintf(g_pace_err, sizeof(g_pace_err), "%s: %s", where, hipGetErrorString(e));
+}
+
+// Entry prologue: argument check, then drop any stale "last error" another library (e.g. the caching
+// allocator's event queries) left on this thread, so PACE_CHECK_LAUNCH only reports our own launches.
+#define NEED(p)                      \
+  if (!(p)) return PACE_ERR_ARG;     \
+  (void)hipGetLastError()
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 extern "C" {
+
+const char* pace_last_error(void) { return g_pace_err; }
 
 const char* pace_version(void) {
 #ifdef PACE_EMU

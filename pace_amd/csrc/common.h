@@ -119,10 +119,17 @@ __device__ __forceinline__ double ppm_flux6(const double* q6, double c, int pos,
   }
 }
 
+// Last HIP error text seen by this library on the calling thread (pace_last_error()).
+extern thread_local char g_pace_err[256];
+void pace_set_err(const char* where, hipError_t e);
+
 #define PACE_CHECK_LAUNCH()                               \
   do {                                                    \
     hipError_t err__ = hipGetLastError();                 \
-    if (err__ != hipSuccess) return PACE_ERR_LAUNCH;      \
+    if (err__ != hipSuccess) {                            \
+      pace_set_err(__func__, err__);                      \
+      return PACE_ERR_LAUNCH;                             \
+    }                                                     \
   } while (0)
 
 static inline dim3 plane_grid(const Geo& g, int nlev) {
