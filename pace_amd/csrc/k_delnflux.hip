@@ -11,7 +11,7 @@
 #include "kernels.h"
 
 #ifndef DN_TI
-#define DN_TI 64
+#define DN_TI 32
 #define DN_TJ 16
 #endif
 #define DW (DN_TI + 6)

@@ -587,8 +587,8 @@ static DswWork carve(const Geo& g, void* ws) {
 static void upload(double* dst, const double* src, size_t n, hipStream_t) { memcpy(dst, src, n * sizeof(double)); }
 #else
 static void upload(double* dst, const double* src, size_t n, hipStream_t st) {
-  hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, st);
-  hipStreamSynchronize(st);
+  (void)hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, st);
+  (void)hipStreamSynchronize(st);
 }
 #endif
 

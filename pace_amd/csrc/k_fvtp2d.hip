@@ -8,7 +8,7 @@
 #include "kernels.h"
 
 #ifndef FV_TI
-#define FV_TI 64
+#define FV_TI 32
 #define FV_TJ 16
 #endif
 #define TI FV_TI
