@@ -321,7 +321,93 @@ def check_riem3():
     return ok
 
 
-GROUPS = {"riem3": check_riem3, "corners": check_corners, "transport": check_transport, "damping": check_damping, "dsw": check_dsw}
+CSW_ARGS = "delp pt u v w uc vc ua va ut vt divgd omga".split()
+
+
+def check_csw():
+    from oracle import cgrid_sw as oc
+
+    cap = captured()
+    ok = True
+    for rank in (0, 1):
+        g = grid_from_capture(cap, rank)
+        recs = cap["records"][(f"rank{rank}", "DGrid2AGrid2CGridVectors")]
+        st = oc.D2A2CState(recs[0]["in"]["u"].shape)
+        names = ["uc", "vc", "u", "v", "ua", "va", "utc", "vtc"]
+        for n_, r in enumerate(recs[:2]):
+            a = {k: r["in"][k].copy() for k in names}
+            oc.d2a2c_vect(g, st, *[a[k] for k in names])
+            for k in ("uc", "vc", "ua", "va", "utc", "vtc"):
+                ok &= report(f"rank{rank} d2a2c[{n_}] {k}", r["out"][k][:, :, :NZ], a[k][:, :, :NZ], tol=1e-12)
+        recs = cap["records"][(f"rank{rank}", "CGridShallowWaterDynamics")]
+        st = oc.CSWState(recs[0]["in"]["u"].shape)
+        for n_, r in enumerate(recs):
+            a = {k: r["in"][k].copy() for k in CSW_ARGS}
+            oc.c_sw(g, st, *[a[k] for k in CSW_ARGS], r["in"]["dt2"])
+            for k in CSW_ARGS:
+                ok &= report(f"rank{rank} c_sw[{n_}] {k}", r["out"][k][:, :, :NZ], a[k][:, :, :NZ], tol=1e-11)
+    return ok
+
+
+def _rec(cap, rank, name):
+    return cap["records"][(f"rank{rank}", name)]
+
+
+def check_parts():
+    from oracle import acoustic_parts as oa
+    from oracle import vertical as ov
+
+    cap = captured()
+    ok = True
+    col = column_namelist()
+    for rank in (0, 1):
+        g = grid_from_capture(cap, rank)
+        gm = cap[f"grid{rank}"]
+        full = (slice(None), slice(None), slice(0, NZ + 1))
+        for n_, r in enumerate(_rec(cap, rank, "NonhydrostaticVerticalSolverCGrid")):
+            i_ = r["in"]
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in i_.items()}
+            ov.riem_solver_c(g, a["dt2"], a["cappa"], a["ptop"], a["hs"], a["ws"], a["ptc"], a["q_con"], a["delpc"], a["gz"], a["pef"],
+                             a["w3"], p_fac=0.05)
+            w = (slice(2, N + 5), slice(2, N + 5), slice(0, NZ + 1))
+            for k in ("gz", "pef"):
+                ok &= report(f"rank{rank} riem_solver_c[{n_}] {k}", r["out"][k], a[k], w, tol=1e-12)
+        for n_, r in enumerate(_rec(cap, rank, "UpdateGeopotentialHeightOnCGrid")):
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r["in"].items()}
+            ov.update_dz_c(g, gm["dp_ref"], a["zs"], a["ut"], a["vt"], a["gz"], a["ws"], a["dt"])
+            w = (slice(2, N + 5), slice(2, N + 5), slice(0, NZ + 1))
+            ok &= report(f"rank{rank} updatedzc[{n_}] gz", r["out"]["gz"], a["gz"], w, tol=1e-13)
+            ok &= report(f"rank{rank} updatedzc[{n_}] ws", r["out"]["ws"], a["ws"], w[:2], tol=1e-13)
+        for n_, r in enumerate(_rec(cap, rank, "UpdateHeightOnDGrid")):
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r["in"].items()}
+            ov.update_dz_d(g, col, gm["dp_ref"], a["surface_height"], a["height"], a["courant_number_x"], a["courant_number_y"],
+                           a["x_area_flux"], a["y_area_flux"], a["ws"], a["dt"])
+            ok &= report(f"rank{rank} updatedzd[{n_}] zh", r["out"]["height"], a["height"], _W(g, 0, 0, NZ + 1), tol=1e-13)
+            ok &= report(f"rank{rank} updatedzd[{n_}] ws", r["out"]["ws"], a["ws"], _W(g)[:2], tol=1e-13)
+        for n_, r in enumerate(_rec(cap, rank, "NonHydrostaticPressureGradient")):
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r["in"].items()}
+            oa.nh_p_grad(g, a["u"], a["v"], a["pp"], a["gz"], a["pk3"], a["delp"], a["dt"], a["ptop"], a["akap"])
+            ok &= report(f"rank{rank} nh_p_grad[{n_}] u", r["out"]["u"], a["u"], _W(g, 0, 1), tol=1e-12)
+            ok &= report(f"rank{rank} nh_p_grad[{n_}] v", r["out"]["v"], a["v"], _W(g, 1, 0), tol=1e-12)
+            for k in ("pp", "gz", "pk3"):
+                ok &= report(f"rank{rank} nh_p_grad[{n_}] {k}", r["out"][k], a[k], _W(g, 1, 1, NZ + 1), tol=1e-12)
+        for n_, r in enumerate(_rec(cap, rank, "PK3Halo")):
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r["in"].items()}
+            oa.pk3_halo(g, a["pk3"], a["delp"], a["ptop"], a["akap"])
+            ok &= report(f"rank{rank} pk3_halo[{n_}]", r["out"]["pk3"][full], a["pk3"][full], tol=1e-13)
+        for n_, r in enumerate(_rec(cap, rank, "RayleighDamping")):
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r["in"].items()}
+            oa.ray_fast(g, a["u"], a["v"], a["w"], a["dp"], a["pfull"], a["dt"], a["ptop"], rf_cutoff=3000.0, tau=10.0)
+            for k in ("u", "v", "w"):
+                ok &= report(f"rank{rank} ray_fast[{n_}] {k}", r["out"][k][:, :, :NZ], a[k][:, :, :NZ], tol=1e-13)
+        for n_, r in enumerate(_rec(cap, rank, "HyperdiffusionDamping")):
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r["in"].items()}
+            oa.del2_cubed(g, a["qdel"], a["cd"], 3)
+            ok &= report(f"rank{rank} del2cubed[{n_}]", r["out"]["qdel"][:, :, :NZ], a["qdel"][:, :, :NZ], tol=1e-13)
+    return ok
+
+
+GROUPS = {"parts": check_parts, "csw": check_csw, "riem3": check_riem3, "corners": check_corners, "transport": check_transport, "damping": check_damping, "dsw": check_dsw}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
