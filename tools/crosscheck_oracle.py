@@ -407,7 +407,59 @@ def check_parts():
     return ok
 
 
-GROUPS = {"parts": check_parts, "csw": check_csw, "riem3": check_riem3, "corners": check_corners, "transport": check_transport, "damping": check_damping, "dsw": check_dsw}
+def check_halo():
+    """Reference CubedSphereCommunicator (6 ranks on threads) vs oracle/halo.py on random fields."""
+    import pace.util
+    from threadcomm import run_ranks
+
+    from oracle import halo as oh
+
+    n, nz = 12, 4
+    rng = np.random.default_rng(5)
+    dims = {"c": ["x", "y", "z"], "xi": ["x_interface", "y", "z"], "yi": ["x", "y_interface", "z"],
+            "b": ["x_interface", "y_interface", "z"], "zi": ["x", "y", "z_interface"]}
+    base = {k: [rng.random((n + 7, n + 7, nz + 1)) for _ in range(6)] for k in dims}
+
+    def rank(comm):
+        part = pace.util.CubedSpherePartitioner(pace.util.TilePartitioner((1, 1)))
+        cube = pace.util.CubedSphereCommunicator(comm, part)
+        sizer = pace.util.SubtileGridSizer.from_tile_params(nx_tile=n, ny_tile=n, nz=nz, n_halo=3, extra_dim_lengths={},
+                                                            layout=(1, 1), tile_partitioner=part.tile, tile_rank=0)
+        qf = pace.util.QuantityFactory.from_backend(sizer, "numpy")
+        r = comm.Get_rank()
+        out = {}
+
+        def q(key, dd):
+            x = qf.zeros(dd, "")
+            x.data[:] = base[key][r]
+            return x
+
+        s = q("c", dims["c"]); cube.halo_update(s, n_points=3); out["c"] = s.data.copy()
+        s = q("b", dims["b"]); cube.halo_update(s, n_points=3); out["b"] = s.data.copy()
+        s = q("zi", dims["zi"]); cube.halo_update(s, n_points=2); out["zi"] = s.data.copy()
+        u, v = q("yi", dims["yi"]), q("xi", dims["xi"])
+        cube.vector_halo_update(u, v, n_points=3); out["du"], out["dv"] = u.data.copy(), v.data.copy()
+        uc, vc = q("xi", dims["xi"]), q("yi", dims["yi"])
+        cube.vector_halo_update(uc, vc, n_points=3); out["cu"], out["cv"] = uc.data.copy(), vc.data.copy()
+        u, v = q("yi", dims["yi"]), q("xi", dims["xi"])
+        cube.synchronize_vector_interfaces(u, v); out["su"], out["sv"] = u.data.copy(), v.data.copy()
+        return out
+
+    ref = run_ranks(6, rank)
+    ok = True
+    f = [a.copy() for a in base["c"]]; oh.halo_update(f, n, nk=nz)
+    g_ = [a.copy() for a in base["b"]]; oh.halo_update(g_, n, xi=1, yi=1, nk=nz)
+    z = [a.copy() for a in base["zi"]]; oh.halo_update(z, n, n_pts=2)
+    du, dv = [a.copy() for a in base["yi"]], [a.copy() for a in base["xi"]]; oh.vector_halo_update(du, dv, n, grid="d", nk=nz)
+    cu, cv = [a.copy() for a in base["xi"]], [a.copy() for a in base["yi"]]; oh.vector_halo_update(cu, cv, n, grid="c", nk=nz)
+    su, sv = [a.copy() for a in base["yi"]], [a.copy() for a in base["xi"]]; oh.synchronize_vector_interfaces(su, sv, n, nk=nz)
+    for t in range(6):
+        for name, mine in (("c", f), ("b", g_), ("zi", z), ("du", du), ("dv", dv), ("cu", cu), ("cv", cv), ("su", su), ("sv", sv)):
+            ok &= report(f"tile{t} halo {name}", ref[t][name], mine[t])
+    return ok
+
+
+GROUPS = {"halo": check_halo, "parts": check_parts, "csw": check_csw, "riem3": check_riem3, "corners": check_corners, "transport": check_transport, "damping": check_damping, "dsw": check_dsw}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)
