@@ -126,6 +126,79 @@ int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, d
                       const double* delp, const double* pt, double* zh, double* pe, double* ppe, double* pk3,
                       double* pk, double* peln, double* w, double p_fac, void* stream);
 
+/* ---- CGridShallowWaterDynamics.__call__ (fv3core/pace/fv3core/stencils/c_sw.py:599-766), including
+ * DGrid2AGrid2CGridVectors (d2a2c_vect.py:529-655).  delpc / ptc are the class attributes the reference
+ * exposes (c_sw.py:497-502, read by dyn_core.py:795-800).  workspace: pace_c_sw_workspace_bytes(). */
+int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom);
+int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* delpc, double* ptc,
+              const double* delp, const double* pt, const double* u, const double* v, const double* w, double* uc,
+              double* vc, double* ua, double* va, double* ut, double* vt, double* divgd, double* omga, double dt2,
+              int nord, void* stream);
+/* ---- DGrid2AGrid2CGridVectors.__call__ alone (d2a2c_vect.py:529-655), dord4 = True; same workspace. */
+int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* uc, double* vc,
+                    const double* u, const double* v, double* ua, double* va, double* utc, double* vtc, void* stream);
+
+/* ---- NonhydrostaticVerticalSolverCGrid.__call__ (riem_solver_c.py:160-250), compute domain +- 1. */
+int64_t pace_riem_solver_c_workspace_bytes(const pace_geom_t* geom);
+int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const double* cappa, double ptop,
+                       const double* hs, const double* ws, const double* ptc, const double* q_con,
+                       const double* delpc, double* gz, double* pef, const double* w3, double p_fac, void* stream);
+
+/* ---- UpdateGeopotentialHeightOnCGrid.__call__ (updatedzc.py:172-207).  dp_ref: DEVICE K-array (nk). */
+int64_t pace_updatedzc_workspace_bytes(const pace_geom_t* geom);
+int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* dp_ref,
+                   const double* zs, const double* ut, const double* vt, double* gz, double* ws, double dt,
+                   void* stream);
+
+/* ---- UpdateHeightOnDGrid.__call__ (updatedzd.py:281-356).  K-dependent constants: gk/beta/gamma from
+ * cubic_spline_interpolation_constants (updatedzd.py:129-154) as DEVICE arrays of nk, the four scalars the
+ * interpolation stencil derives from them (:180-192), and the DelnFluxNoSG column arguments on nk+1 levels
+ * (damp = column_namelist["damp_vt"], nord = nord_v expanded per level), DEVICE arrays. */
+typedef struct {
+  const double *gk, *beta, *gamma;
+  double xt1_top, a_bot, xt1_bot, xt2_bot;
+  const double *damp, *nord;
+  int32_t nmax, pad_;
+} pace_updatedzd_k_t;
+int64_t pace_updatedzd_workspace_bytes(const pace_geom_t* geom);
+int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_updatedzd_k_t* kc,
+                   const double* surface_height, double* height, const double* courant_number_x,
+                   const double* courant_number_y, const double* x_area_flux, const double* y_area_flux, double* ws,
+                   double dt, int hord_tm, void* stream);
+
+/* ---- dyn_core.py stencils: gz_from_surface_height_and_thicknesses (:83-96, compute domain),
+ * compute_geopotential (:115-117, halo 2, nk+1 levels), basic.copy_defn as used at dyn_core.py:773-781
+ * (full domain, nk+1 levels), p_grad_c_stencil (:120-171, hydrostatic = False). */
+int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const double* zs, const double* delz,
+                                                double* gz, void* stream);
+int pace_compute_geopotential(const pace_geom_t* geom, const double* zh, double* gz, void* stream);
+int pace_copy(const pace_geom_t* geom, const double* src, double* dst, void* stream);
+int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, double* uc, double* vc, const double* delpc,
+                  const double* pkc, const double* gz, double dt2, void* stream);
+
+/* ---- NonHydrostaticPressureGradient.__call__ (nh_p_grad.py:187-255). */
+int64_t pace_nh_p_grad_workspace_bytes(const pace_geom_t* geom);
+int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* u, double* v,
+                   double* pp, double* gz, double* pk3, double* delp, double dt, double ptop, double akap,
+                   void* stream);
+
+/* ---- pe_halo.edge_pe (pe_halo.py:6-34) and PK3Halo.__call__ (pk3_halo.py:55-69). */
+int pace_edge_pe(const pace_geom_t* geom, double* pe, const double* delp, double ptop, void* stream);
+int pace_pk3_halo(const pace_geom_t* geom, double* pk3, const double* delp, double ptop, double akap, void* stream);
+
+/* ---- RayleighDamping.__call__ (ray_fast.py:186-206).  dp, pfull: HOST K-arrays (nk). */
+int pace_ray_fast(const pace_geom_t* geom, double* u, double* v, double* w, const double* dp, const double* pfull,
+                  double dt, double ptop, double rf_cutoff, double tau, int hydrostatic, void* stream);
+
+/* ---- HyperdiffusionDamping.__call__ (del2cubed.py:168-194) and apply_diffusive_heating
+ * (temperature_adjust.py:8-43, first nlev levels of the compute domain). */
+int64_t pace_del2cubed_workspace_bytes(const pace_geom_t* geom);
+int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* qdel, double cd,
+                   int nmax, void* stream);
+int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, const double* delz, const double* cappa,
+                                 const double* heat_source, double* pt, double delt_time_factor, int nlev,
+                                 void* stream);
+
 const char* pace_version(void);
 /* Text of the last HIP error this library saw on the calling thread ("" if none). */
 const char* pace_last_error(void);

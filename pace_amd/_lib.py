@@ -48,6 +48,14 @@ class DswConfig(C.Structure):
     ]
 
 
+class UpdatedzdK(C.Structure):
+    _fields_ = [
+        ("gk", c_dp), ("beta", c_dp), ("gamma", c_dp),
+        ("xt1_top", C.c_double), ("a_bot", C.c_double), ("xt1_bot", C.c_double), ("xt2_bot", C.c_double),
+        ("damp", c_dp), ("nord", c_dp), ("nmax", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
 class PaceError(RuntimeError):
     pass
 
@@ -71,6 +79,27 @@ _PROTOS = {
         C.c_int,
         [_P(Geom), c_dp, C.c_int, C.c_double, c_dp, C.c_double] + [c_dp] * 13 + [C.c_double, C.c_void_p],
     ),
+    "pace_c_sw_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_c_sw": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 16 + [C.c_double, C.c_int, C.c_void_p]),
+    "pace_d2a2c_vect": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 9 + [C.c_void_p]),
+    "pace_riem_solver_c_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_riem_solver_c": (C.c_int, [_P(Geom), c_dp, C.c_double, c_dp, C.c_double] + [c_dp] * 8 + [C.c_double, C.c_void_p]),
+    "pace_updatedzc_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_updatedzc": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 7 + [C.c_double, C.c_void_p]),
+    "pace_updatedzd_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_updatedzd": (C.c_int, [_P(Geom), _P(Metrics), c_dp, _P(UpdatedzdK)] + [c_dp] * 7 + [C.c_double, C.c_int, C.c_void_p]),
+    "pace_gz_from_surface_height_and_thicknesses": (C.c_int, [_P(Geom), c_dp, c_dp, c_dp, C.c_void_p]),
+    "pace_compute_geopotential": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_void_p]),
+    "pace_copy": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_void_p]),
+    "pace_p_grad_c": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 5 + [C.c_double, C.c_void_p]),
+    "pace_nh_p_grad_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_nh_p_grad": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 7 + [C.c_double] * 3 + [C.c_void_p]),
+    "pace_edge_pe": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_double, C.c_void_p]),
+    "pace_pk3_halo": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_double, C.c_double, C.c_void_p]),
+    "pace_ray_fast": (C.c_int, [_P(Geom), c_dp, c_dp, c_dp, _P(C.c_double), _P(C.c_double)] + [C.c_double] * 4 + [C.c_int, C.c_void_p]),
+    "pace_del2cubed_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_del2cubed": (C.c_int, [_P(Geom), _P(Metrics), c_dp, c_dp, C.c_double, C.c_int, C.c_void_p]),
+    "pace_apply_diffusive_heating": (C.c_int, [_P(Geom)] + [c_dp] * 5 + [C.c_double, C.c_int, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

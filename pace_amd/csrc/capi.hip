@@ -99,4 +99,126 @@ int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, d
                              ppe, pk3, pk, peln, w, p_fac, S(stream));
 }
 
+int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom) { return geom ? csw_workspace_bytes(make_geo(geom)) : 0; }
+
+int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* delpc, double* ptc,
+              const double* delp, const double* pt, const double* u, const double* v, const double* w, double* uc,
+              double* vc, double* ua, double* va, double* ut, double* vt, double* divgd, double* omga, double dt2,
+              int nord, void* stream) {
+  NEED(geom && met && workspace && delpc && ptc && delp && pt && u && v && w && uc && vc && ua && va && ut && vt && divgd && omga);
+  return launch_c_sw(make_geo(geom), *met, workspace, delpc, ptc, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2,
+                     nord, S(stream));
+}
+
+int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* uc, double* vc,
+                    const double* u, const double* v, double* ua, double* va, double* utc, double* vtc, void* stream) {
+  NEED(geom && met && workspace && uc && vc && u && v && ua && va && utc && vtc);
+  return launch_d2a2c_vect(make_geo(geom), *met, workspace, uc, vc, u, v, ua, va, utc, vtc, S(stream));
+}
+
+int64_t pace_riem_solver_c_workspace_bytes(const pace_geom_t* geom) {
+  return geom ? riemc_workspace_bytes(make_geo(geom)) : 0;
+}
+
+int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const double* cappa, double ptop,
+                       const double* hs, const double* ws, const double* ptc, const double* q_con,
+                       const double* delpc, double* gz, double* pef, const double* w3, double p_fac, void* stream) {
+  NEED(geom && workspace && cappa && hs && ws && ptc && q_con && delpc && gz && pef && w3);
+  return launch_riem_solver_c(make_geo(geom), workspace, dt2, cappa, ptop, hs, ws, ptc, q_con, delpc, gz, pef, w3, p_fac,
+                              S(stream));
+}
+
+int64_t pace_updatedzc_workspace_bytes(const pace_geom_t* geom) {
+  return geom ? updatedzc_workspace_bytes(make_geo(geom)) : 0;
+}
+
+int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* dp_ref,
+                   const double* zs, const double* ut, const double* vt, double* gz, double* ws, double dt,
+                   void* stream) {
+  NEED(geom && met && workspace && dp_ref && zs && ut && vt && gz && ws);
+  return launch_updatedzc(make_geo(geom), *met, workspace, dp_ref, zs, ut, vt, gz, ws, dt, S(stream));
+}
+
+int64_t pace_updatedzd_workspace_bytes(const pace_geom_t* geom) {
+  return geom ? updatedzd_workspace_bytes(make_geo(geom)) : 0;
+}
+
+int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_updatedzd_k_t* kc,
+                   const double* surface_height, double* height, const double* courant_number_x,
+                   const double* courant_number_y, const double* x_area_flux, const double* y_area_flux, double* ws,
+                   double dt, int hord_tm, void* stream) {
+  NEED(geom && met && workspace && kc && surface_height && height && courant_number_x && courant_number_y && x_area_flux &&
+       y_area_flux && ws);
+  NEED(kc->gk && kc->beta && kc->gamma && kc->damp && kc->nord);
+  return launch_updatedzd(make_geo(geom), *met, workspace, kc, surface_height, height, courant_number_x, courant_number_y,
+                          x_area_flux, y_area_flux, ws, dt, hord_tm, S(stream));
+}
+
+int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const double* zs, const double* delz,
+                                                double* gz, void* stream) {
+  NEED(geom && zs && delz && gz);
+  return launch_gz_from_surface(make_geo(geom), zs, delz, gz, S(stream));
+}
+
+int pace_compute_geopotential(const pace_geom_t* geom, const double* zh, double* gz, void* stream) {
+  NEED(geom && zh && gz);
+  return launch_scale_copy(make_geo(geom), zh, gz, 9.80665, 1, 2, geom->nk + 1, S(stream));
+}
+
+int pace_copy(const pace_geom_t* geom, const double* src, double* dst, void* stream) {
+  NEED(geom && src && dst);
+  return launch_scale_copy(make_geo(geom), src, dst, 1.0, 0, 3, geom->nk + 1, S(stream));
+}
+
+int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, double* uc, double* vc, const double* delpc,
+                  const double* pkc, const double* gz, double dt2, void* stream) {
+  NEED(geom && met && uc && vc && delpc && pkc && gz);
+  return launch_p_grad_c(make_geo(geom), *met, uc, vc, delpc, pkc, gz, dt2, S(stream));
+}
+
+int64_t pace_nh_p_grad_workspace_bytes(const pace_geom_t* geom) {
+  return geom ? nh_p_grad_workspace_bytes(make_geo(geom)) : 0;
+}
+
+int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* u, double* v,
+                   double* pp, double* gz, double* pk3, double* delp, double dt, double ptop, double akap,
+                   void* stream) {
+  NEED(geom && met && workspace && u && v && pp && gz && pk3 && delp);
+  return launch_nh_p_grad(make_geo(geom), *met, workspace, u, v, pp, gz, pk3, delp, dt, ptop, akap, S(stream));
+}
+
+int pace_edge_pe(const pace_geom_t* geom, double* pe, const double* delp, double ptop, void* stream) {
+  NEED(geom && pe && delp);
+  return launch_edge_pe(make_geo(geom), pe, delp, ptop, S(stream));
+}
+
+int pace_pk3_halo(const pace_geom_t* geom, double* pk3, const double* delp, double ptop, double akap, void* stream) {
+  NEED(geom && pk3 && delp);
+  return launch_pk3_halo(make_geo(geom), pk3, delp, ptop, akap, S(stream));
+}
+
+int pace_ray_fast(const pace_geom_t* geom, double* u, double* v, double* w, const double* dp, const double* pfull,
+                  double dt, double ptop, double rf_cutoff, double tau, int hydrostatic, void* stream) {
+  NEED(geom && u && v && w && dp && pfull);
+  return launch_ray_fast(make_geo(geom), u, v, w, dp, pfull, dt, ptop, rf_cutoff, tau, hydrostatic, S(stream));
+}
+
+int64_t pace_del2cubed_workspace_bytes(const pace_geom_t* geom) {
+  return geom ? del2cubed_workspace_bytes(make_geo(geom)) : 0;
+}
+
+int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* qdel, double cd,
+                   int nmax, void* stream) {
+  NEED(geom && met && workspace && qdel);
+  return launch_del2cubed(make_geo(geom), *met, workspace, qdel, cd, nmax, S(stream));
+}
+
+int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, const double* delz, const double* cappa,
+                                 const double* heat_source, double* pt, double delt_time_factor, int nlev,
+                                 void* stream) {
+  NEED(geom && delp && delz && cappa && heat_source && pt);
+  if (nlev < 0 || nlev > geom->nk) return PACE_ERR_ARG;
+  return launch_diffusive_heating(make_geo(geom), delp, delz, cappa, heat_source, pt, delt_time_factor, nlev, S(stream));
+}
+
 }  // extern "C"

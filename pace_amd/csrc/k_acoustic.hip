@@ -1,0 +1,580 @@
+// The remaining operators of the acoustic substep (everything in dyn_core.py's loop that is not c_sw, d_sw or a
+// Riemann solver).  All are HBM-bound streaming passes or column sweeps with lanes along i.
+//   updatedzc.py:15-207      UpdateGeopotentialHeightOnCGrid   (4 launches -> 2)
+//   updatedzd.py:70-356      UpdateHeightOnDGrid               (29 launches -> 4: spline, fvtp2d, delnflux, apply)
+//   dyn_core.py:83-171       gz_from_surface_height_and_thicknesses, compute_geopotential, p_grad_c_stencil
+//   nh_p_grad.py:11-255      NonHydrostaticPressureGradient    (51 launches -> 9)
+//   pe_halo.py:6-34, pk3_halo.py:11-69                          ring column scans
+//   ray_fast.py:48-206       RayleighDamping
+//   del2cubed.py:16-194      HyperdiffusionDamping             (18 launches -> 3)
+//   temperature_adjust.py:8-43 apply_diffusive_heating
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "kernels.h"
+
+#define GRAV 9.80665
+#define RDGAS 287.05
+#define CP_AIR 1004.6
+#define CV_AIR (CP_AIR - RDGAS)
+#define RDG (-RDGAS / GRAV)
+#define DZ_MIN 2.0
+
+// fill_corners_2cells_{x,y} with unit multipliers as read-side maps (corners.py:129-305); same maps as k_csw.hip
+__device__ __forceinline__ long zc_xfill(const Geo& g, int i, int j) {
+  if (j == g.js - 1) {
+    if (i < g.is && i >= g.is - 2) return IDX2(g, g.is - 1, g.js + (g.is - i) - 1);
+    if (i > g.ie && i <= g.ie + 2) return IDX2(g, g.ie + 1, g.js + (i - g.ie) - 1);
+  } else if (j == g.je + 1) {
+    if (i < g.is && i >= g.is - 2) return IDX2(g, g.is - 1, g.je + 1 - (g.is - i));
+    if (i > g.ie && i <= g.ie + 2) return IDX2(g, g.ie + 1, g.je + 1 - (i - g.ie));
+  }
+  return IDX2(g, i, j);
+}
+__device__ __forceinline__ long zc_yfill(const Geo& g, int i, int j) {
+  if (i == g.is - 1) {
+    if (j < g.js && j >= g.js - 2) return IDX2(g, g.is + (g.js - j) - 1, g.js - 1);
+    if (j > g.je && j <= g.je + 2) return IDX2(g, g.is + (j - g.je) - 1, g.je + 1);
+  } else if (i == g.ie + 1) {
+    if (j < g.js && j >= g.js - 2) return IDX2(g, g.ie + 1 - (g.js - j), g.js - 1);
+    if (j > g.je && j <= g.je + 2) return IDX2(g, g.ie + 1 - (j - g.je), g.je + 1);
+  }
+  return IDX2(g, i, j);
+}
+
+// ------------------------------------------------------------------------------------------------
+// updatedzc: interface winds by dp_ref-weighted averages (p_weighted_average_*, updatedzc.py:15-31), first-order
+// upwind advection of gz (xy_flux :34-52, update_dz_c :61-117) on compute +- 1, interface levels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pavg(const double* __restrict__ f, long c, long sk, int k, int km,
+                                       const double* __restrict__ dp) {
+  if (k == 0) {
+    const double ratio = dp[0] / (dp[0] + dp[1]);
+    return f[c] + (f[c] - f[c + sk]) * ratio;
+  }
+  if (k == km) {
+    const double ratio = dp[km - 1] / (dp[km - 2] + dp[km - 1]);
+    return f[c - sk] + (f[c - sk] - f[c - 2 * sk]) * ratio;
+  }
+  const double int_ratio = 1.0 / (dp[k - 1] + dp[k]);
+  return (dp[k] * f[c - sk] + dp[k - 1] * f[c]) * int_ratio;
+}
+
+__global__ void __launch_bounds__(256)
+k_updatedzc_advect(Geo g, Met m, const double* __restrict__ dp_ref, const double* __restrict__ ut,
+                   const double* __restrict__ vt, const double* __restrict__ gz, double* __restrict__ gz_new) {
+  PLANE_IJK(g);
+  if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1) return;
+  const long kb = (long)k * g.sk;
+  const long c2 = IDX2(g, i, j);
+  const long c = c2 + kb;
+  const int km = g.nk;
+  double xfx[2], yfx[2], fx[2], fy[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    xfx[t] = pavg(ut, c + t, g.sk, k, km, dp_ref);
+    fx[t] = xfx[t] * ((xfx[t] > 0.0) ? gz[kb + zc_xfill(g, i + t - 1, j)] : gz[kb + zc_xfill(g, i + t, j)]);
+    yfx[t] = pavg(vt, c + (long)t * g.sj, g.sk, k, km, dp_ref);
+    fy[t] = yfx[t] * ((yfx[t] > 0.0) ? gz[kb + zc_yfill(g, i, j + t - 1)] : gz[kb + zc_yfill(g, i, j + t)]);
+  }
+  const double area = m.area[c2];
+  gz_new[c] = (gz[c] * area + fx[0] - fx[1] + fy[0] - fy[1]) / (area + xfx[0] - xfx[1] + yfx[0] - yfx[1]);
+}
+
+// ws and the monotonicity sweep (updatedzc.py:108-117), columns of compute +- 1
+__global__ void __launch_bounds__(64)
+k_updatedzc_column(Geo g, const double* __restrict__ zs, const double* __restrict__ gz_new, double* __restrict__ gz,
+                   double* __restrict__ ws, double rdt) {
+  const int i = g.is - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.js - 1 + blockIdx.y;
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const long c0 = IDX2(g, i, j);
+  const int km = g.nk;
+  double below = gz_new[c0 + (long)km * g.sk];
+  gz[c0 + (long)km * g.sk] = below;
+  ws[c0] = (zs[c0] - below) * rdt;
+  for (int k = km - 1; k >= 0; --k) {
+    const double v = gz_new[c0 + (long)k * g.sk];
+    const double lim = below + DZ_MIN;
+    below = (v > lim) ? v : lim;
+    gz[c0 + (long)k * g.sk] = below;
+  }
+}
+
+int64_t updatedzc_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double); }
+
+int launch_updatedzc(const Geo& g, const Met& m, void* ws_, const double* dp_ref, const double* zs, const double* ut,
+                     const double* vt, double* gz, double* ws, double dt, hipStream_t st) {
+  if (g.nk < 3) return PACE_ERR_UNSUPPORTED;
+  double* gz_new = (double*)ws_;
+  hipLaunchKernelGGL(k_updatedzc_advect, plane_grid(g, g.nk + 1), dim3(256), 0, st, g, m, dp_ref, ut, vt, gz, gz_new);
+  hipLaunchKernelGGL(k_updatedzc_column, dim3((g.n + 2 + 63) / 64, g.n + 2), dim3(64), 0, st, g, zs, gz_new, gz, ws, 1.0 / dt);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// updatedzd
+// ------------------------------------------------------------------------------------------------
+struct SplineK {
+  const double *gk, *beta, *gamma;  // device K-arrays (updatedzd.py:129-154)
+  double xt1_top, a_bot, xt1_bot, xt2_bot;
+};
+
+// cubic_spline_interpolation_from_layer_center_to_interfaces (updatedzd.py:157-196), full domain; blockIdx.z picks
+// one of the four fields
+__global__ void __launch_bounds__(64)
+k_spline_to_interfaces(Geo g, SplineK s, const double* __restrict__ q0, const double* __restrict__ q1,
+                       const double* __restrict__ q2, const double* __restrict__ q3, double* __restrict__ o0,
+                       double* __restrict__ o1, double* __restrict__ o2, double* __restrict__ o3) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const double* qc = (blockIdx.z == 0) ? q0 : (blockIdx.z == 1) ? q1 : (blockIdx.z == 2) ? q2 : q3;
+  double* qi = (blockIdx.z == 0) ? o0 : (blockIdx.z == 1) ? o1 : (blockIdx.z == 2) ? o2 : o3;
+  const long c0 = IDX2(g, i, j);
+  const long sk = g.sk;
+  const int km = g.nk;
+  double prev_c = qc[c0];
+  double v = (s.xt1_top * prev_c + qc[c0 + sk]) / s.beta[0];
+  qi[c0] = v;
+  for (int k = 1; k < km; ++k) {
+    const double cur = qc[c0 + (long)k * sk];
+    v = (3.0 * (prev_c + s.gk[k] * cur) - v) / s.beta[k];
+    qi[c0 + (long)k * sk] = v;
+    prev_c = cur;
+  }
+  v = (s.xt1_bot * qc[c0 + (long)(km - 1) * sk] + qc[c0 + (long)(km - 2) * sk] - s.a_bot * v) / s.xt2_bot;
+  qi[c0 + (long)km * sk] = v;
+  for (int k = km - 1; k >= 0; --k) {
+    v = qi[c0 + (long)k * sk] - s.gamma[k] * v;
+    qi[c0 + (long)k * sk] = v;
+  }
+}
+
+// apply_height_fluxes (updatedzd.py:70-126): advective + diffusive update, ws, monotonicity sweep; one column
+// per thread walking up from the surface (a cell's update reads only its own zh)
+__global__ void __launch_bounds__(64)
+k_apply_height_fluxes(Geo g, Met m, const double* __restrict__ zs, double* __restrict__ zh,
+                      const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ xfx,
+                      const double* __restrict__ yfx, const double* __restrict__ fx2, const double* __restrict__ fy2,
+                      double* __restrict__ ws, double dt) {
+  const int i = g.is + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.js + blockIdx.y;
+  if (i > g.ie || j > g.je) return;
+  const long c0 = IDX2(g, i, j);
+  const int km = g.nk;
+  const double area = m.area[c0];
+  double below = 0.0;
+  for (int k = km; k >= 0; --k) {
+    const long c = c0 + (long)k * g.sk;
+    const double area_after = (area + xfx[c] - xfx[c + 1]) + (area + yfx[c] - yfx[c + g.sj]) - area;
+    const double adv = (zh[c] * area + fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) / area_after;
+    double v = adv + (fx2[c] - fx2[c + 1] + fy2[c] - fy2[c + g.sj]) / area;
+    if (k == km) {
+      ws[c0] = (zs[c0] - v) / dt;
+    } else {
+      const double other = below + DZ_MIN;
+      v = (v > other) ? v : other;
+    }
+    zh[c] = v;
+    below = v;
+  }
+}
+
+#define UZD_NFIELDS 8
+int64_t updatedzd_workspace_bytes(const Geo& g) {
+  return (int64_t)g.sk * (g.nk + 1) * UZD_NFIELDS * (int64_t)sizeof(double);
+}
+
+int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd_k_t* kc, const double* zs, double* zh,
+                     const double* crx, const double* cry, const double* xfx, const double* yfx, double* wsd, double dt,
+                     int hord_tm, hipStream_t st) {
+  if (g.nk < 3) return PACE_ERR_UNSUPPORTED;
+  const long field = g.sk * (g.nk + 1);
+  double* p = (double*)ws_;
+  double *crx_i = p, *cry_i = p + field, *xfx_i = p + 2 * field, *yfx_i = p + 3 * field, *fx = p + 4 * field,
+         *fy = p + 5 * field, *fx2 = p + 6 * field, *fy2 = p + 7 * field;
+  SplineK s{kc->gk, kc->beta, kc->gamma, kc->xt1_top, kc->a_bot, kc->xt1_bot, kc->xt2_bot};
+  hipLaunchKernelGGL(k_spline_to_interfaces, dim3((g.ni - 1 + 63) / 64, g.nj - 1, 4), dim3(64), 0, st, g, s, crx, cry, xfx, yfx,
+                     crx_i, cry_i, xfx_i, yfx_i);
+  int rc;
+  if ((rc = launch_fvtp2d(g, m, zh, crx_i, cry_i, xfx_i, yfx_i, fx, fy, nullptr, nullptr, hord_tm, g.nk + 1, st))) return rc;
+  if ((rc = launch_delnflux(g, m, 0, zh, fx2, fy2, nullptr, kc->damp, kc->nord, kc->nmax, 0, g.nk + 1, st))) return rc;
+  hipLaunchKernelGGL(k_apply_height_fluxes, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, m, zs, zh, fx, fy, xfx_i, yfx_i, fx2,
+                     fy2, wsd, dt);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dyn_core.py small stencils
+// ------------------------------------------------------------------------------------------------
+// gz_from_surface_height_and_thicknesses (dyn_core.py:83-96), compute domain
+__global__ void __launch_bounds__(64)
+k_gz_from_surface(Geo g, const double* __restrict__ zs, const double* __restrict__ delz, double* __restrict__ gz) {
+  const int i = g.is + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.js + blockIdx.y;
+  if (i > g.ie || j > g.je) return;
+  const long c0 = IDX2(g, i, j);
+  double z = zs[c0];
+  gz[c0 + (long)g.nk * g.sk] = z;
+  for (int k = g.nk - 1; k >= 0; --k) {
+    z = z - delz[c0 + (long)k * g.sk];
+    gz[c0 + (long)k * g.sk] = z;
+  }
+}
+
+// dst = src * factor on the window [i0, i1] x [j0, j1], nlev levels: copy_defn (basic_operations.py:7, factor 1)
+// and compute_geopotential (dyn_core.py:115-117, factor GRAV)
+__global__ void __launch_bounds__(256)
+k_scale_copy(Geo g, const double* __restrict__ src, double* __restrict__ dst, double factor, int scale, int i0, int i1,
+             int j0, int j1) {
+  PLANE_IJK(g);
+  if (i < i0 || i > i1 || j < j0 || j > j1) return;
+  const long c = IDX3(g, i, j, k);
+  dst[c] = scale ? src[c] * factor : src[c];
+}
+
+// p_grad_c_stencil (dyn_core.py:120-171), non-hydrostatic; compute + 1
+__global__ void __launch_bounds__(256)
+k_p_grad_c(Geo g, Met m, double* __restrict__ uc, double* __restrict__ vc, const double* __restrict__ delpc,
+           const double* __restrict__ pkc, const double* __restrict__ gz, double dt2) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const long sk = g.sk;
+  const int sj = g.sj;
+  uc[c] = uc[c] + dt2 * m.rdxc[c2] / (delpc[c - 1] + delpc[c]) *
+                      ((gz[c - 1 + sk] - gz[c]) * (pkc[c + sk] - pkc[c - 1]) + (gz[c - 1] - gz[c + sk]) * (pkc[c - 1 + sk] - pkc[c]));
+  vc[c] = vc[c] + dt2 * m.rdyc[c2] / (delpc[c - sj] + delpc[c]) *
+                      ((gz[c - sj + sk] - gz[c]) * (pkc[c + sk] - pkc[c - sj]) + (gz[c - sj] - gz[c + sk]) * (pkc[c - sj + sk] - pkc[c]));
+}
+
+int launch_gz_from_surface(const Geo& g, const double* zs, const double* delz, double* gz, hipStream_t st) {
+  hipLaunchKernelGGL(k_gz_from_surface, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, zs, delz, gz);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+int launch_scale_copy(const Geo& g, const double* src, double* dst, double factor, int scale, int halo, int nlev,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(k_scale_copy, plane_grid(g, nlev), dim3(256), 0, st, g, src, dst, factor, scale, g.is - halo, g.ie + halo,
+                     g.js - halo, g.je + halo);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+int launch_p_grad_c(const Geo& g, const Met& m, double* uc, double* vc, const double* delpc, const double* pkc,
+                    const double* gz, double dt2, hipStream_t st) {
+  hipLaunchKernelGGL(k_p_grad_c, plane_grid(g, g.nk), dim3(256), 0, st, g, m, uc, vc, delpc, pkc, gz, dt2);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// nh_p_grad
+// ------------------------------------------------------------------------------------------------
+// set_k0_and_calc_wk (nh_p_grad.py:11-26), level 0 only; wk itself is recomputed where it is used
+__global__ void __launch_bounds__(256)
+k_nh_set_top(Geo g, double* __restrict__ pp, double* __restrict__ pk3, double top_value) {
+  PLANE_IJK(g);
+  (void)k;
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX2(g, i, j);
+  pp[c] = 0.0;
+  pk3[c] = top_value;
+}
+
+// calc_u (nh_p_grad.py:29-69), calc_v (:72-112)
+__global__ void __launch_bounds__(256)
+k_nh_uv(Geo g, Met m, double* __restrict__ u, double* __restrict__ v, const double* __restrict__ wk1,
+        const double* __restrict__ gz, const double* __restrict__ pk3, const double* __restrict__ pp, double dt) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const long sk = g.sk;
+  const int sj = g.sj;
+  const double wk0 = pk3[c + sk] - pk3[c];
+  if (i <= g.ie) {
+    const double wkx = pk3[c + 1 + sk] - pk3[c + 1];
+    const double du = dt / (wk0 + wkx) *
+                      ((gz[c + sk] - gz[c + 1]) * (pk3[c + 1 + sk] - pk3[c]) + (gz[c] - gz[c + 1 + sk]) * (pk3[c + sk] - pk3[c + 1]));
+    u[c] = (u[c] + du +
+            dt / (wk1[c] + wk1[c + 1]) *
+                ((gz[c + sk] - gz[c + 1]) * (pp[c + 1 + sk] - pp[c]) + (gz[c] - gz[c + 1 + sk]) * (pp[c + sk] - pp[c + 1]))) *
+           m.rdx[c2];
+  }
+  if (j <= g.je) {
+    const double wky = pk3[c + sj + sk] - pk3[c + sj];
+    const double dv = dt / (wk0 + wky) *
+                      ((gz[c + sk] - gz[c + sj]) * (pk3[c + sj + sk] - pk3[c]) + (gz[c] - gz[c + sj + sk]) * (pk3[c + sk] - pk3[c + sj]));
+    v[c] = (v[c] + dv +
+            dt / (wk1[c] + wk1[c + sj]) *
+                ((gz[c + sk] - gz[c + sj]) * (pp[c + sj + sk] - pp[c]) + (gz[c] - gz[c + sj + sk]) * (pp[c + sk] - pp[c + sj]))) *
+           m.rdy[c2];
+  }
+}
+
+int64_t nh_p_grad_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double); }
+
+int launch_nh_p_grad(const Geo& g, const Met& m, void* ws_, double* u, double* v, double* pp, double* gz, double* pk3,
+                     double* delp, double dt, double ptop, double akap, hipStream_t st) {
+  double* wk1 = (double*)ws_;
+  const int K = g.nk + 1;
+  int rc;
+  if ((rc = launch_a2b_ord4(g, m, pp, wk1, 1, K, 1, st))) return rc;
+  if ((rc = launch_a2b_ord4(g, m, pk3, wk1, 1, K, 1, st))) return rc;
+  if ((rc = launch_a2b_ord4(g, m, gz, wk1, 0, K, 1, st))) return rc;
+  if ((rc = launch_a2b_ord4(g, m, delp, wk1, 0, g.nk, 0, st))) return rc;
+  const double top_value = pow(ptop, akap);
+  hipLaunchKernelGGL(k_nh_set_top, plane_grid(g, 1), dim3(256), 0, st, g, pp, pk3, top_value);
+  hipLaunchKernelGGL(k_nh_uv, plane_grid(g, g.nk), dim3(256), 0, st, g, m, u, v, wk1, gz, pk3, pp, dt);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pe_halo.edge_pe (pe_halo.py:6-34) and PK3Halo (pk3_halo.py:11-69): forward k scans in the ring of width
+// `width` around the compute domain.  One thread per ring column.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ring_cell(const Geo& g, int width, int t, int& i, int& j) {
+  // enumerate the (n + 2 width)^2 - n^2 ring cells: `width` full rows south, `width` north, then west/east strips
+  const int span = g.n + 2 * width;
+  const int nrow = span * width;
+  if (t < nrow) { j = g.js - width + t / span; i = g.is - width + t % span; return true; }
+  t -= nrow;
+  if (t < nrow) { j = g.je + 1 + t / span; i = g.is - width + t % span; return true; }
+  t -= nrow;
+  const int ncol = g.n * width;
+  if (t < ncol) { j = g.js + t / width; i = g.is - width + t % width; return true; }
+  t -= ncol;
+  if (t < ncol) { j = g.js + t / width; i = g.ie + 1 + t % width; return true; }
+  return false;
+}
+
+__global__ void __launch_bounds__(64)
+k_edge_pe(Geo g, double* __restrict__ pe, const double* __restrict__ delp, double ptop) {
+  int i, j;
+  if (!ring_cell(g, 1, blockIdx.x * 64 + threadIdx.x, i, j)) return;
+  const long c0 = IDX2(g, i, j);
+  double p = ptop;
+  pe[c0] = p;
+  for (int k = 1; k <= g.nk; ++k) {
+    p = p + delp[c0 + (long)(k - 1) * g.sk];
+    pe[c0 + (long)k * g.sk] = p;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_pk3_halo(Geo g, double* __restrict__ pk3, const double* __restrict__ delp, double ptop, double akap) {
+  int i, j;
+  if (!ring_cell(g, 2, blockIdx.x * 64 + threadIdx.x, i, j)) return;
+  const long c0 = IDX2(g, i, j);
+  double p = ptop;
+  for (int k = 1; k <= g.nk; ++k) {
+    p = p + delp[c0 + (long)(k - 1) * g.sk];
+    pk3[c0 + (long)k * g.sk] = pow(p, akap);
+  }
+}
+
+int launch_edge_pe(const Geo& g, double* pe, const double* delp, double ptop, hipStream_t st) {
+  const int cells = 4 * (g.n + 1);
+  hipLaunchKernelGGL(k_edge_pe, dim3((cells + 63) / 64), dim3(64), 0, st, g, pe, delp, ptop);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+int launch_pk3_halo(const Geo& g, double* pk3, const double* delp, double ptop, double akap, hipStream_t st) {
+  const int cells = (g.n + 4) * (g.n + 4) - g.n * g.n;
+  hipLaunchKernelGGL(k_pk3_halo, dim3((cells + 63) / 64), dim3(64), 0, st, g, pk3, delp, ptop, akap);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RayleighDamping (ray_fast.py:48-141).  Everything that depends on the level only (rf, p_ref, which level's
+// running momentum sum a level finally sees) is evaluated on the host, literally following the stencil's
+// FORWARD/BACKWARD passes; the kernel does the per-column sums.  Only the top `kmax` levels are touched.
+// ------------------------------------------------------------------------------------------------
+#define RAY_MAXK 48
+struct RayK {
+  double rf[RAY_MAXK], dp[RAY_MAXK], p_ref[RAY_MAXK];
+  signed char act[RAY_MAXK], nudge[RAY_MAXK], msrc[RAY_MAXK];
+  int kmax;
+};
+
+__device__ __forceinline__ void ray_wind(const RayK& r, double* __restrict__ wind, long c0, long sk) {
+  double s_[RAY_MAXK];
+  double s = 0.0;
+  for (int k = 0; k < r.kmax; ++k) {
+    if (r.act[k]) {
+      const double wv = wind[c0 + (long)k * sk];
+      const double layer = (1.0 - r.rf[k]) * r.dp[k] * wv;
+      s = (k == 0) ? layer : s + layer;
+      wind[c0 + (long)k * sk] = wv * r.rf[k];
+    }
+    s_[k] = s;
+  }
+  for (int k = 0; k < r.kmax; ++k) {
+    if (r.nudge[k]) wind[c0 + (long)k * sk] = wind[c0 + (long)k * sk] + s_[r.msrc[k]] / r.p_ref[k];
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_ray_fast(Geo g, RayK r, double* __restrict__ u, double* __restrict__ v, double* __restrict__ w, int hydrostatic) {
+  const int i = g.is + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.js + blockIdx.y;
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const long c0 = IDX2(g, i, j);
+  if (i <= g.ie) ray_wind(r, u, c0, g.sk);
+  if (j <= g.je) ray_wind(r, v, c0, g.sk);
+  if (!hydrostatic && i <= g.ie && j <= g.je) {
+    for (int k = 0; k < r.kmax; ++k)
+      if (r.act[k]) w[c0 + (long)k * g.sk] = w[c0 + (long)k * g.sk] * r.rf[k];
+  }
+}
+
+int launch_ray_fast(const Geo& g, double* u, double* v, double* w, const double* dp, const double* pfull, double dt,
+                    double ptop, double rf_cutoff, double tau, int hydrostatic, hipStream_t st) {
+  const int nk = g.nk;
+  const double SDAY = 86400.0, PI = 3.14159265358979323846;
+  const double nudge = rf_cutoff + fmin(100.0, 10.0 * ptop);
+  RayK r;
+  memset(&r, 0, sizeof(r));
+  int kmax = 0;
+  for (int k = 0; k < nk; ++k)
+    if (pfull[k] < rf_cutoff || pfull[k] < nudge) kmax = k + 1;
+  if (kmax > RAY_MAXK) return PACE_ERR_UNSUPPORTED;
+  if (kmax == 0) return PACE_OK;
+  if (!(pfull[0] < rf_cutoff)) return PACE_ERR_UNSUPPORTED;  // the reference reads an undefined temporary then
+  r.kmax = kmax;
+  // p_ref: FORWARD accumulate over nudged levels, then BACKWARD copy (ray_fast.py:79-89) -- over all nk levels
+  {
+    double* pr = new double[nk];
+    double run = 0.0;
+    for (int k = 0; k < nk; ++k) {
+      const bool nz = pfull[k] < nudge;
+      if (k == 0) run = nz ? dp[0] : NAN;
+      else if (nz) run = run + dp[k];
+      pr[k] = run;
+    }
+    for (int k = nk - 2; k >= 0; --k)
+      if (pfull[k] < nudge) pr[k] = pr[k + 1];
+    for (int k = 0; k < kmax; ++k) r.p_ref[k] = pr[k];
+    delete[] pr;
+  }
+  // msrc: after the BACKWARD pass "if active: dmdir = dmdir[k+1]" level k holds the forward sum of level msrc[k]
+  {
+    int* ms = new int[nk];
+    ms[nk - 1] = nk - 1;
+    for (int k = nk - 2; k >= 0; --k) ms[k] = (pfull[k] < rf_cutoff) ? ms[k + 1] : k;
+    for (int k = 0; k < kmax; ++k) r.msrc[k] = (signed char)(ms[k] < kmax ? ms[k] : kmax - 1);
+    delete[] ms;
+  }
+  for (int k = 0; k < kmax; ++k) {
+    r.act[k] = pfull[k] < rf_cutoff;
+    r.nudge[k] = pfull[k] < nudge;
+    r.dp[k] = dp[k];
+    if (r.act[k]) {
+      // compute_rff_vals (ray_fast.py:24-40)
+      const double s = sin(0.5 * PI * log(rf_cutoff / pfull[k]) / log(rf_cutoff / ptop));
+      const double rffvals = dt / (tau * SDAY) * (s * s);
+      r.rf[k] = 1.0 / (1.0 + rffvals);
+    }
+  }
+  hipLaunchKernelGGL(k_ray_fast, dim3((g.n + 1 + 63) / 64, g.n + 1), dim3(64), 0, st, g, r, u, v, w, hydrostatic);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HyperdiffusionDamping (del2cubed.py:16-194): one launch per iteration, ping-pong between qdel and a
+// scratch field.  corner_fill is a function of the input; copy_corners_{x,y} are read-side maps.
+// ------------------------------------------------------------------------------------------------
+struct Del2 {
+  const Geo& g;
+  const double* q;  // level base applied
+  // corner_fill (del2cubed.py:31-68): the inner corner cell and its two out-of-tile neighbours all become
+  // the mean of the three
+  __device__ __forceinline__ double filled(int i, int j) const {
+    const int ci = (i <= g.is) ? g.is : g.ie, cj = (j <= g.js) ? g.js : g.je;
+    const int xo = (ci == g.is) ? g.is - 1 : g.ie + 1, yo = (cj == g.js) ? g.js - 1 : g.je + 1;
+    const bool hit = (i == ci && j == cj) || (i == xo && j == cj) || (i == ci && j == yo);
+    if (hit && (i <= g.is || i >= g.ie) && (j <= g.js || j >= g.je))
+      return (q[IDX2(g, ci, cj)] + q[IDX2(g, xo, cj)] + q[IDX2(g, ci, yo)]) * (1.0 / 3.0);
+    return q[IDX2(g, i, j)];
+  }
+  __device__ __forceinline__ double qx(int i, int j, bool cc) const {
+    if (cc) remap_agrid_x(g, i, j);
+    return filled(i, j);
+  }
+  __device__ __forceinline__ double qy(int i, int j, bool cc) const {
+    if (cc) remap_agrid_y(g, i, j);
+    return filled(i, j);
+  }
+};
+
+__global__ void __launch_bounds__(256)
+k_del2cubed_iter(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, double cd, int nt) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long kb = (long)k * g.sk;
+  const long c2 = IDX2(g, i, j);
+  Del2 d{g, qin + kb};
+  double val = d.filled(i, j);
+  if (i >= g.is - nt && i <= g.ie + nt && j >= g.js - nt && j <= g.je + nt) {
+    const bool cc = nt > 0;
+    const double fx0 = m.del6_v[c2] * (d.qx(i - 1, j, cc) - d.qx(i, j, cc));
+    const double fx1 = m.del6_v[c2 + 1] * (d.qx(i, j, cc) - d.qx(i + 1, j, cc));
+    const double fy0 = m.del6_u[c2] * (d.qy(i, j - 1, cc) - d.qy(i, j, cc));
+    const double fy1 = m.del6_u[c2 + g.sj] * (d.qy(i, j, cc) - d.qy(i, j + 1, cc));
+    val = val + cd * m.rarea[c2] * (fx0 - fx1 + fy0 - fy1);
+  }
+  qout[kb + c2] = val;
+}
+
+int64_t del2cubed_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double); }
+
+int launch_del2cubed(const Geo& g, const Met& m, void* ws_, double* qdel, double cd, int nmax, hipStream_t st) {
+  const int ntimes = nmax < 3 ? nmax : 3;
+  double* scratch = (double*)ws_;
+  double* src = qdel;
+  double* dst = scratch;
+  const dim3 grid = plane_grid(g, g.nk), block(256);
+  for (int n = 0; n < ntimes; ++n) {
+    hipLaunchKernelGGL(k_del2cubed_iter, grid, block, 0, st, g, m, src, dst, cd, ntimes - (n + 1));
+    double* t = src;
+    src = dst;
+    dst = t;
+  }
+  if (src != qdel) hipLaunchKernelGGL(k_scale_copy, grid, block, 0, st, g, src, qdel, 1.0, 0, 0, g.ni - 2, 0, g.nj - 2);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// apply_diffusive_heating (temperature_adjust.py:8-43), compute domain, first nlev levels
+__global__ void __launch_bounds__(256)
+k_diffusive_heating(Geo g, const double* __restrict__ delp, const double* __restrict__ delz,
+                    const double* __restrict__ cappa, const double* __restrict__ heat_source, double* __restrict__ pt,
+                    double delt_time_factor) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
+  const long c = IDX3(g, i, j, k);
+  const double pkz = pow(RDG * delp[c] / delz[c] * pt[c], cappa[c] / (1.0 - cappa[c]));
+  const double dtmp = heat_source[c] / (CV_AIR * delp[c]);
+  const double fac = (k == 0) ? 0.1 : (k == 1) ? 0.5 : 1.0;
+  const double lim = delt_time_factor * fac;
+  const double mag = fmin(lim, fabs(dtmp));
+  const double deltmin = (dtmp > 0.0) ? fabs(mag) : -fabs(mag);  // basic_operations.sign
+  pt[c] = pt[c] + deltmin / pkz;
+}
+
+int launch_diffusive_heating(const Geo& g, const double* delp, const double* delz, const double* cappa,
+                             const double* heat_source, double* pt, double delt_time_factor, int nlev, hipStream_t st) {
+  if (nlev < 1) return PACE_OK;
+  hipLaunchKernelGGL(k_diffusive_heating, plane_grid(g, nlev), dim3(256), 0, st, g, delp, delz, cappa, heat_source, pt,
+                     delt_time_factor);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}

@@ -1,0 +1,317 @@
+// C-grid half step (Fortran c_sw) and the D->A->C wind interpolation (d2a2c_vect).
+// Reference: fv3core/pace/fv3core/stencils/c_sw.py:31-766 (12 launches + 5 temporaries) and
+// d2a2c_vect.py:27-655 (12 launches), stencils/pace/stencils/corners.py:129-305 (multiplier fills).
+//
+// Four streaming passes instead of 24 launches; every pass is one thread per (i, j, k) with i fastest:
+//   A  utmp, vtmp (4-point Lagrange / 2-point average of the D-grid winds), ua, va; the corner
+//      fills of all four are produced by the writer itself (the value a fill would copy is recomputed
+//      from its source point), so nothing ever rewrites a corner afterwards
+//   B  uc, vc (+ contravariant ut, vt with the geoadjust factor folded in) and divgd
+//   C  upwind transport of delp / pt / w (corner fills of the *inputs* become read-side index maps,
+//      the x/y fluxes are recomputed at both faces instead of stored), kinetic energy, C-grid
+//      absolute vorticity
+//   D  uc, vc update
+// HBM-bound; algorithmic traffic 5 reads (delp, pt, u, v, w) + 11 writes = 128 B/cell.
+#include "common.h"
+#include "kernels.h"
+
+#define A1 (9.0 / 16.0)
+#define A2 (-1.0 / 16.0)
+
+__device__ __forceinline__ double contra2(double v1, double v2, double cosa, double rsin2) {
+  return (v1 - v2 * cosa) * rsin2;  // d2a2c_vect.py:225-281
+}
+
+struct D2A {
+  const Geo& g;
+  const double* u;  // level base applied
+  const double* v;
+  // d2a2c_vect.py:283-360 (lagrange_interpolation_{y,x}_p1 inside the tile, avg_box within 3 of an edge)
+  __device__ __forceinline__ bool boxed(int i, int j) const {
+    return (j < g.js + 3) || (j >= g.je - 2) || (i < g.is + 3) || (i >= g.ie - 2);
+  }
+  __device__ __forceinline__ double utmp(int i, int j) const {
+    const long c = IDX2(g, i, j);
+    if (boxed(i, j)) return 0.5 * (u[c] + u[c + g.sj]);
+    return A2 * (u[c - g.sj] + u[c + 2 * g.sj]) + A1 * (u[c] + u[c + g.sj]);
+  }
+  __device__ __forceinline__ double vtmp(int i, int j) const {
+    const long c = IDX2(g, i, j);
+    if (boxed(i, j)) return 0.5 * (v[c] + v[c + 1]);
+    return A2 * (v[c - 1] + v[c + 2]) + A1 * (v[c] + v[c + 1]);
+  }
+};
+
+// fill_corners_{2,3}cells_mult_x(q, qc, sw=-1, se=1, ne=-1, nw=1): destination (i, j) of the x fill ->
+// source point in qc and multiplier; returns false if (i, j) is not a destination.  (corners.py:129-217)
+__device__ __forceinline__ bool fill_x_src(const Geo& g, int ncells, int i, int j, int& si, int& sj_, double& mult) {
+  if (j == g.js - 1) {
+    if (i < g.is && i >= g.is - ncells) { const int a = g.is - i; si = g.is - 1; sj_ = g.js + a - 1; mult = -1.0; return true; }
+    if (i > g.ie && i <= g.ie + ncells) { const int a = i - g.ie; si = g.ie + 1; sj_ = g.js + a - 1; mult = 1.0; return true; }
+  } else if (j == g.je + 1) {
+    if (i < g.is && i >= g.is - ncells) { const int a = g.is - i; si = g.is - 1; sj_ = g.je + 1 - a; mult = 1.0; return true; }
+    if (i > g.ie && i <= g.ie + ncells) { const int a = i - g.ie; si = g.ie + 1; sj_ = g.je + 1 - a; mult = -1.0; return true; }
+  }
+  return false;
+}
+// ... and of the y fill (corners.py:219-305)
+__device__ __forceinline__ bool fill_y_src(const Geo& g, int ncells, int i, int j, int& si, int& sj_, double& mult) {
+  if (i == g.is - 1) {
+    if (j < g.js && j >= g.js - ncells) { const int a = g.js - j; si = g.is + a - 1; sj_ = g.js - 1; mult = -1.0; return true; }
+    if (j > g.je && j <= g.je + ncells) { const int a = j - g.je; si = g.is + a - 1; sj_ = g.je + 1; mult = 1.0; return true; }
+  } else if (i == g.ie + 1) {
+    if (j < g.js && j >= g.js - ncells) { const int a = g.js - j; si = g.ie + 1 - a; sj_ = g.js - 1; mult = 1.0; return true; }
+    if (j > g.je && j <= g.je + ncells) { const int a = j - g.je; si = g.ie + 1 - a; sj_ = g.je + 1; mult = -1.0; return true; }
+  }
+  return false;
+}
+
+// pass A
+__global__ void __launch_bounds__(256)
+k_d2a2c_a(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ utmp,
+          double* __restrict__ vtmp, double* __restrict__ ua, double* __restrict__ va) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  const long kb = (long)k * g.sk;
+  D2A d{g, u + kb, v + kb};
+  int si, sj_;
+  double mult;
+  const double ut_raw = d.utmp(i, j), vt_raw = d.vtmp(i, j);
+  double ut_ = ut_raw, vt_ = vt_raw;
+  if (fill_x_src(g, 3, i, j, si, sj_, mult)) ut_ = mult * d.vtmp(si, sj_);
+  if (fill_y_src(g, 3, i, j, si, sj_, mult)) vt_ = mult * d.utmp(si, sj_);
+  utmp[c] = ut_;
+  vtmp[c] = vt_;
+  if (i >= g.is - 2 && i <= g.ie + 2 && j >= g.js - 2 && j <= g.je + 2) {
+    const long c2 = IDX2(g, i, j);
+    double ua_ = contra2(ut_raw, vt_raw, m.cosa_s[c2], m.rsin2[c2]);
+    double va_ = contra2(vt_raw, ut_raw, m.cosa_s[c2], m.rsin2[c2]);
+    if (fill_x_src(g, 2, i, j, si, sj_, mult)) {
+      const long s2 = IDX2(g, si, sj_);
+      ua_ = mult * contra2(d.vtmp(si, sj_), d.utmp(si, sj_), m.cosa_s[s2], m.rsin2[s2]);
+    }
+    if (fill_y_src(g, 2, i, j, si, sj_, mult)) {
+      const long s2 = IDX2(g, si, sj_);
+      va_ = mult * contra2(d.utmp(si, sj_), d.vtmp(si, sj_), m.cosa_s[s2], m.rsin2[s2]);
+    }
+    ua[c] = ua_;
+    va[c] = va_;
+  }
+}
+
+// pass B: d2a2c_vect.py:362-527 (ut_main / east_west_edges / north_south_edges / vt_main), geoadjust_ut/vt
+// (c_sw.py:159-203) and divergence_corner (c_sw.py:31-156)
+__global__ void __launch_bounds__(256)
+k_d2a2c_b(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
+          const double* __restrict__ utmp, const double* __restrict__ vtmp, const double* __restrict__ ua,
+          const double* __restrict__ va, double* __restrict__ uc, double* __restrict__ vc, double* __restrict__ ut,
+          double* __restrict__ vt, double* __restrict__ divgd, double dt2, int do_divg, int geoadjust) {
+  PLANE_IJK(g);
+  if (i < g.is - 1 || i > g.ie + 2 || j < g.js - 1 || j > g.je + 2) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  if (j <= g.je + 1) {  // uc, ut on i = is-1 .. ie+2, j = js-1 .. je+1
+    double ucv, utv;
+    if (i == g.is || i == g.ie + 1) {
+      const double* dxa = m.dxa;
+      const double t1 = dxa[c2 - 2] + dxa[c2 - 1];
+      const double t2 = dxa[c2] + dxa[c2 + 1];
+      const double n1 = (t1 + dxa[c2 - 1]) * ua[c - 1] - dxa[c2 - 1] * ua[c - 2];
+      const double n2 = (t1 + dxa[c2]) * ua[c] - dxa[c2] * ua[c + 1];
+      utv = 0.5 * (n1 / t1 + n2 / t2);
+      ucv = (utv > 0.0) ? utv * m.sin_sg3[c2 - 1] : utv * m.sin_sg1[c2];
+    } else {
+      if (i == g.is - 1 || i == g.ie) {
+        ucv = PPM_C1 * utmp[c - 2] + PPM_C2 * utmp[c - 1] + PPM_C3 * utmp[c];
+      } else if (i == g.is + 1 || i == g.ie + 2) {
+        ucv = PPM_C1 * utmp[c + 1] + PPM_C2 * utmp[c] + PPM_C3 * utmp[c - 1];
+      } else {
+        ucv = A2 * (utmp[c - 2] + utmp[c + 1]) + A1 * (utmp[c - 1] + utmp[c]);
+      }
+      utv = contra2(ucv, v[c], m.cosa_u[c2], m.rsin_u[c2]);
+    }
+    uc[c] = ucv;
+    if (geoadjust) utv = (utv > 0.0) ? dt2 * utv * m.dy[c2] * m.sin_sg3[c2 - 1] : dt2 * utv * m.dy[c2] * m.sin_sg1[c2];
+    ut[c] = utv;
+  }
+  if (i <= g.ie + 1) {  // vc, vt on i = is-1 .. ie+1, j = js-1 .. je+2
+    double vcv, vtv;
+    if (j == g.js || j == g.je + 1) {
+      const double* dya = m.dya;
+      const double t1 = dya[c2 - 2 * sj] + dya[c2 - sj];
+      const double t2 = dya[c2] + dya[c2 + sj];
+      const double n1 = (t1 + dya[c2 - sj]) * va[c - sj] - dya[c2 - sj] * va[c - 2 * sj];
+      const double n2 = (t1 + dya[c2]) * va[c] - dya[c2] * va[c + sj];
+      vtv = 0.5 * (n1 / t1 + n2 / t2);
+      vcv = (vtv > 0.0) ? vtv * m.sin_sg4[c2 - sj] : vtv * m.sin_sg2[c2];
+    } else {
+      if (j == g.js - 1 || j == g.je) {
+        vcv = PPM_C1 * vtmp[c - 2 * sj] + PPM_C2 * vtmp[c - sj] + PPM_C3 * vtmp[c];
+      } else if (j == g.js + 1 || j == g.je + 2) {
+        vcv = PPM_C1 * vtmp[c + sj] + PPM_C2 * vtmp[c] + PPM_C3 * vtmp[c - sj];
+      } else {
+        vcv = A2 * (vtmp[c - 2 * sj] + vtmp[c + sj]) + A1 * (vtmp[c - sj] + vtmp[c]);
+      }
+      vtv = contra2(vcv, u[c], m.cosa_v[c2], m.rsin_v[c2]);
+    }
+    vc[c] = vcv;
+    if (geoadjust) vtv = (vtv > 0.0) ? dt2 * vtv * m.dx[c2] * m.sin_sg4[c2 - sj] : dt2 * vtv * m.dx[c2] * m.sin_sg2[c2];
+    vt[c] = vtv;
+  }
+  if (do_divg && i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1) {
+    const bool iedge = (i == g.is || i == g.ie + 1), jedge = (j == g.js || j == g.je + 1);
+    const double* sg1 = m.sin_sg1; const double* sg2 = m.sin_sg2; const double* sg3 = m.sin_sg3; const double* sg4 = m.sin_sg4;
+    const double* cg1 = m.cos_sg1; const double* cg2 = m.cos_sg2; const double* cg3 = m.cos_sg3; const double* cg4 = m.cos_sg4;
+    // uf at (i, j) and (i-1, j); vf at (i, j) and (i, j-1), interior or edge form (c_sw.py:60-156)
+    const double uf = jedge ? u[c] * m.dyc[c2] * 0.5 * (sg4[c2 - sj] + sg2[c2])
+                            : (u[c] - 0.25 * (va[c - sj] + va[c]) * (cg4[c2 - sj] + cg2[c2])) * m.dyc[c2] * 0.5 * (sg4[c2 - sj] + sg2[c2]);
+    const double uf1 = jedge ? u[c - 1] * m.dyc[c2 - 1] * 0.5 * (sg4[c2 - 1 - sj] + sg2[c2 - 1])
+                             : (u[c - 1] - 0.25 * (va[c - 1 - sj] + va[c - 1]) * (cg4[c2 - 1 - sj] + cg2[c2 - 1])) * m.dyc[c2 - 1] * 0.5 * (sg4[c2 - 1 - sj] + sg2[c2 - 1]);
+    const double vf = iedge ? v[c] * m.dxc[c2] * 0.5 * (sg3[c2 - 1] + sg1[c2])
+                            : (v[c] - 0.25 * (ua[c - 1] + ua[c]) * (cg3[c2 - 1] + cg1[c2])) * m.dxc[c2] * 0.5 * (sg3[c2 - 1] + sg1[c2]);
+    const double vf1 = iedge ? v[c - sj] * m.dxc[c2 - sj] * 0.5 * (sg3[c2 - 1 - sj] + sg1[c2 - sj])
+                             : (v[c - sj] - 0.25 * (ua[c - 1 - sj] + ua[c - sj]) * (cg3[c2 - 1 - sj] + cg1[c2 - sj])) * m.dxc[c2 - sj] * 0.5 * (sg3[c2 - 1 - sj] + sg1[c2 - sj]);
+    double d;
+    if (iedge && j == g.js) d = (-vf + uf1 - uf) * m.rarea_c[c2];
+    else if (iedge && j == g.je + 1) d = (vf1 + uf1 - uf) * m.rarea_c[c2];
+    else d = (vf1 - vf + uf1 - uf) * m.rarea_c[c2];
+    divgd[c] = d;
+  }
+}
+
+// read-side forms of fill_corners_2cells_x / _y with unit multipliers on the transported scalars
+// (c_sw.py:206-228,699,724; corners.py:129-305)
+__device__ __forceinline__ long cell_xfill(const Geo& g, int i, int j) {
+  int si, sj_;
+  double mult;
+  if (fill_x_src(g, 2, i, j, si, sj_, mult)) return IDX2(g, si, sj_);
+  return IDX2(g, i, j);
+}
+__device__ __forceinline__ long cell_yfill(const Geo& g, int i, int j) {
+  int si, sj_;
+  double mult;
+  if (fill_y_src(g, 2, i, j, si, sj_, mult)) return IDX2(g, si, sj_);
+  return IDX2(g, i, j);
+}
+
+// pass C: compute_nonhydrostatic_fluxes_x (c_sw.py:231-259), transportdelp_update_vorticity_and_kineticenergy
+// (:262-364), circulation_cgrid (:367-397), absolute_vorticity (:400-408)
+__global__ void __launch_bounds__(256)
+k_csw_transport(Geo g, Met m, const double* __restrict__ delp, const double* __restrict__ pt,
+                const double* __restrict__ w, const double* __restrict__ u, const double* __restrict__ v,
+                const double* __restrict__ ua, const double* __restrict__ va, const double* __restrict__ uc,
+                const double* __restrict__ vc, const double* __restrict__ ut, const double* __restrict__ vt,
+                double* __restrict__ delpc, double* __restrict__ ptc, double* __restrict__ omga,
+                double* __restrict__ ke, double* __restrict__ vort, double dt2) {
+  PLANE_IJK(g);
+  if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1) return;
+  const long kb = (long)k * g.sk;
+  const long c2 = IDX2(g, i, j);
+  const long c = c2 + kb;
+  const int sj = g.sj;
+  {
+    // x faces i and i+1 (corner-filled in x), y faces j and j+1 (corner-filled in y)
+    double fx1[2], fx[2], fx2[2], fy1[2], fy[2], fy2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const double utv = ut[c + t];
+      const long s = kb + ((utv > 0.0) ? cell_xfill(g, i + t - 1, j) : cell_xfill(g, i + t, j));
+      fx1[t] = utv * delp[s];
+      fx[t] = fx1[t] * pt[s];
+      fx2[t] = fx1[t] * w[s];
+      const double vtv = vt[c + (long)t * sj];
+      const long s2 = kb + ((vtv > 0.0) ? cell_yfill(g, i, j + t - 1) : cell_yfill(g, i, j + t));
+      fy1[t] = vtv * delp[s2];
+      fy[t] = fy1[t] * pt[s2];
+      fy2[t] = fy1[t] * w[s2];
+    }
+    // the cell's own delp/pt/w are read after both fills: the y fill is the last writer of a corner cell
+    const long s0 = kb + cell_yfill(g, i, j);
+    const double ra = m.rarea[c2];
+    const double dp = delp[s0];
+    const double dpc = dp + (fx1[0] - fx1[1] + fy1[0] - fy1[1]) * ra;
+    delpc[c] = dpc;
+    ptc[c] = (pt[s0] * dp + (fx[0] - fx[1] + fy[0] - fy[1]) * ra) / dpc;
+    omga[c] = (w[s0] * dp + (fx2[0] - fx2[1] + fy2[0] - fy2[1]) * ra) / dpc;
+  }
+  {
+    const double uav = ua[c], vav = va[c];
+    double kev = (uav > 0.0) ? uc[c] : uc[c + 1];
+    double vov = (vav > 0.0) ? vc[c] : vc[c + sj];
+    if ((j == g.js - 1 || j == g.je) && !(vav > 0.0)) vov = vov * m.sin_sg4[c2] + u[c + sj] * m.cos_sg4[c2];
+    if ((j == g.js || j == g.je + 1) && (vav > 0.0)) vov = vov * m.sin_sg2[c2] + u[c] * m.cos_sg2[c2];
+    if ((i == g.ie || i == g.is - 1) && !(uav > 0.0)) kev = kev * m.sin_sg3[c2] + v[c + 1] * m.cos_sg3[c2];
+    if ((i == g.ie + 1 || i == g.is) && (uav > 0.0)) kev = kev * m.sin_sg1[c2] + v[c] * m.cos_sg1[c2];
+    ke[c] = 0.5 * dt2 * (uav * kev + vav * vov);
+  }
+  if (i >= g.is && j >= g.js) {
+    const double fxc = m.dxc[c2] * uc[c];
+    const double fyc = m.dyc[c2] * vc[c];
+    const double fx1c = m.dxc[c2 - sj] * uc[c - sj];
+    const double fy1c = m.dyc[c2 - 1] * vc[c - 1];
+    double vcirc = fx1c - fxc - fy1c + fyc;
+    const bool jc = (j == g.js || j == g.je + 1);
+    if (i == g.is && jc) vcirc = fx1c - fxc + fyc;
+    if (i == g.ie + 1 && jc) vcirc = fx1c - fxc - fy1c;
+    vort[c] = m.fC[c2] + m.rarea_c[c2] * vcirc;
+  }
+}
+
+// pass D: update_y_velocity (c_sw.py:445-480), update_x_velocity (:411-442)
+__global__ void __launch_bounds__(256)
+k_csw_update_uc_vc(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
+                   const double* __restrict__ ke, const double* __restrict__ vort, double* __restrict__ uc,
+                   double* __restrict__ vc, double dt2) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  if (i <= g.ie) {
+    const double tmp = (j == g.js || j == g.je + 1) ? dt2 * u[c] : dt2 * (u[c] - vc[c] * m.cosa_v[c2]) / m.sina_v[c2];
+    const double flux = (tmp > 0.0) ? vort[c] : vort[c + 1];
+    vc[c] = vc[c] - tmp * flux + m.rdyc[c2] * (ke[c - sj] - ke[c]);
+  }
+  if (j <= g.je) {
+    const double tmp = (i == g.is || i == g.ie + 1) ? dt2 * v[c] : dt2 * (v[c] - uc[c] * m.cosa_u[c2]) / m.sina_u[c2];
+    const double flux = (tmp > 0.0) ? vort[c] : vort[c + sj];
+    uc[c] = uc[c] + tmp * flux + m.rdxc[c2] * (ke[c - 1] - ke[c]);
+  }
+}
+
+#define CSW_NFIELDS 4
+int64_t csw_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * CSW_NFIELDS * (int64_t)sizeof(double); }
+
+int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, double* uc, double* vc, const double* u, const double* v,
+                      double* ua, double* va, double* utc, double* vtc, hipStream_t st) {
+  if (g.n < 8) return PACE_ERR_UNSUPPORTED;  // npt = 4 branch of d2a2c_vect.py:421-424 only
+  const long field = g.sk * (g.nk + 1);
+  double* utmp = (double*)ws;
+  double* vtmp = utmp + field;
+  const dim3 grid = plane_grid(g, g.nk), block(256);
+  hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
+  hipLaunchKernelGGL(k_d2a2c_b, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, utc, vtc, (double*)nullptr, 0.0, 0, 0);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+int launch_c_sw(const Geo& g, const Met& m, void* ws, double* delpc, double* ptc, const double* delp, const double* pt,
+                const double* u, const double* v, const double* w, double* uc, double* vc, double* ua, double* va,
+                double* ut, double* vt, double* divgd, double* omga, double dt2, int nord, hipStream_t st) {
+  if (g.n < 8) return PACE_ERR_UNSUPPORTED;
+  const long field = g.sk * (g.nk + 1);
+  double* utmp = (double*)ws;
+  double* vtmp = utmp + field;
+  double* ke = utmp + 2 * field;
+  double* vort = utmp + 3 * field;
+  const dim3 grid = plane_grid(g, g.nk), block(256);
+  hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
+  hipLaunchKernelGGL(k_d2a2c_b, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2, nord > 0 ? 1 : 0, 1);
+  hipLaunchKernelGGL(k_csw_transport, grid, block, 0, st, g, m, delp, pt, w, u, v, ua, va, uc, vc, ut, vt, delpc, ptc, omga, ke,
+                     vort, dt2);
+  hipLaunchKernelGGL(k_csw_update_uc_vc, grid, block, 0, st, g, m, u, v, ke, vort, uc, vc, dt2);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}

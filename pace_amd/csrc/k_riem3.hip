@@ -31,10 +31,11 @@ int64_t riem3_workspace_bytes(const Geo& g) {
   return (int64_t)g.sk * (g.nk + 1) * RIEM3_NFIELDS * (int64_t)sizeof(double);
 }
 
-#define COLUMN_IJ(g)                                        \
-  const int i = (g).is + blockIdx.x * 64 + threadIdx.x;     \
-  const int j = (g).js + blockIdx.y;                        \
-  if (i > (g).ie || j > (g).je) return;                     \
+#define COLUMN_IJ(g) COLUMN_IJH(g, 0)
+#define COLUMN_IJH(g, h)                                        \
+  const int i = (g).is - (h) + blockIdx.x * 64 + threadIdx.x;   \
+  const int j = (g).js - (h) + blockIdx.y;                      \
+  if (i > (g).ie + (h) || j > (g).je + (h)) return;             \
   const long sk = (g).sk;                                   \
   const long c0 = IDX2(g, i, j);                            \
   const int km = (g).nk;                                    \
@@ -43,9 +44,10 @@ int64_t riem3_workspace_bytes(const Geo& g) {
 
 // A: p_interface (-> pem) and the gas-only interface pressure (-> aa, reused later) by prefix sums
 //    (riem_solver3.py:63-81 without the logs)
+template <int CG>
 __global__ void __launch_bounds__(64)
 k_riem3_prefix(Geo g, Riem3Work W, double ptop, const double* __restrict__ delp, const double* __restrict__ q_con) {
-  COLUMN_IJ(g);
+  COLUMN_IJH(g, CG);
   double p_int = ptop, pg = ptop;
   W.pem[AT(0)] = ptop;
   W.aa[AT(0)] = ptop;
@@ -104,13 +106,16 @@ k_riem3_parallel_pre(Geo g, Riem3Work W, int last_call, double peln1, double ptk
 }
 
 // C: the two tridiagonal systems of sim1_solver (sim1_solver.py:76-132); pe0 arrives in ppe
+// CG = 0: D-grid solver on the compute domain, delta_mass = delp * RGRAV (riem_solver3.py:86);
+// CG = 1: C-grid solver on compute +- 1, delta_mass = delpc / GRAV (riem_solver_c.py:84)
+template <int CG>
 __global__ void __launch_bounds__(64)
 k_riem3_tridiag(Geo g, Riem3Work W, double dt, const double* __restrict__ cappa, const double* __restrict__ ws,
                 const double* __restrict__ delz, const double* __restrict__ delp, double* __restrict__ ppe,
                 double* __restrict__ w) {
-  COLUMN_IJ(g);
+  COLUMN_IJH(g, CG);
   const double t1g = 2.0 * dt * dt, rdt = 1.0 / dt;
-#define DM(x) ((x)*RGRAV)
+#define DM(x) (CG ? (x) / GRAV : (x)*RGRAV)
   // ---- sweep 1 (forward): gam, pp of the first system
   {
     double dm_k = DM(delp[AT(0)]), dm_n = DM(delp[AT(1)]);
@@ -384,12 +389,109 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
   const double ptk = exp(KAPPA * peln1);
   const dim3 cgrid((g.n + 63) / 64, g.n, 1), cblock(64);
   const dim3 pgrid = plane_grid(g, g.nk + 1), pblock(256);
-  hipLaunchKernelGGL(k_riem3_prefix, cgrid, cblock, 0, st, g, W, ptop, delp, q_con);
+  hipLaunchKernelGGL(k_riem3_prefix<0>, cgrid, cblock, 0, st, g, W, ptop, delp, q_con);
   hipLaunchKernelGGL(k_riem3_parallel_pre, pgrid, pblock, 0, st, g, W, last_call, peln1, ptk, cappa, delp, pt, zh, delz, ppe,
                      pk3, peln);
-  hipLaunchKernelGGL(k_riem3_tridiag, cgrid, cblock, 0, st, g, W, dt, cappa, wsd, delz, delp, ppe, w);
+  hipLaunchKernelGGL(k_riem3_tridiag<0>, cgrid, cblock, 0, st, g, W, dt, cappa, wsd, delz, delp, ppe, w);
   hipLaunchKernelGGL(k_riem3_parallel_post, pgrid, pblock, 0, st, g, W, last_call, cappa, delp, pt, delz, pk3, pk, pe, p_fac);
   hipLaunchKernelGGL(k_riem3_zh, cgrid, cblock, 0, st, g, zs, delz, zh);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// =================================================================================================
+// NonhydrostaticVerticalSolverCGrid (Fortran Riem_Solver_c), riem_solver_c.py:21-250, on compute +- 1.
+// Same five-stage structure; w3 is not updated (the solver works on a copy), outputs are gz and pef.
+// =================================================================================================
+struct RiemCWork {
+  Riem3Work r;
+  double *dz, *pe, *w;
+};
+#define RIEMC_NFIELDS 9
+
+int64_t riemc_workspace_bytes(const Geo& g) {
+  return (int64_t)g.sk * (g.nk + 1) * RIEMC_NFIELDS * (int64_t)sizeof(double);
+}
+
+// precompute (riem_solver_c.py:21-88) without the prefix sums + first statement of sim1_solver
+__global__ void __launch_bounds__(256)
+k_riemc_parallel_pre(Geo g, RiemCWork W, const double* __restrict__ cappa, const double* __restrict__ delpc,
+                     const double* __restrict__ ptc, const double* __restrict__ gz, const double* __restrict__ w3) {
+  PLANE_IJK(g);
+  if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1 || k >= g.nk) return;
+  const long c = IDX3(g, i, j, k);
+  const double* peg = W.r.aa;
+  const double pmk = (peg[c + g.sk] - peg[c]) / log(peg[c + g.sk] / peg[c]);
+  W.r.pm[c] = pmk;
+  const double dz = gz[c + g.sk] - gz[c];
+  W.dz[c] = dz;
+  const double dm = delpc[c] / GRAV;
+  const double gm = 1.0 / (1.0 - cappa[c]);
+  W.pe[c] = exp(gm * log(-dm / dz * RDGAS * ptc[c])) - pmk;
+  W.w[c] = w3[c];
+}
+
+// sim1_solver.py:133-141 (dz) + finalize (riem_solver_c.py:91-123): pef
+__global__ void __launch_bounds__(256)
+k_riemc_parallel_post(Geo g, RiemCWork W, double ptop, const double* __restrict__ cappa, const double* __restrict__ delpc,
+                      const double* __restrict__ ptc, double* __restrict__ pef, double p_fac) {
+  PLANE_IJK(g);
+  if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  if (k < g.nk) {
+    const double dm = delpc[c] / GRAV;
+    const double p1 = W.r.pp[c], pmk = W.r.pm[c];
+    const double maxp = (p_fac * dm > p1 + pmk) ? p_fac * pmk : p1 + pmk;
+    W.dz[c] = -dm * RDGAS * ptc[c] * exp((cappa[c] - 1.0) * log(maxp));
+  }
+  pef[c] = (k == 0) ? ptop : W.pe[c] + W.r.pem[c];
+}
+
+__global__ void __launch_bounds__(64)
+k_riemc_gz(Geo g, const double* __restrict__ hs, const double* __restrict__ dz, double* __restrict__ gz) {
+  COLUMN_IJH(g, 1);
+  double z = hs[c0];
+  gz[AT(km)] = z;
+  for (int k0 = km - 1; k0 >= 0; k0 -= CH) {
+    double d_[CH];
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int k = (k0 - t >= 0) ? k0 - t : 0;
+      d_[t] = dz[AT(k)];
+    }
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int k = k0 - t;
+      if (k >= 0) {
+        z = z - d_[t] * GRAV;
+        gz[AT(k)] = z;
+      }
+    }
+  }
+}
+
+int launch_riem_solver_c(const Geo& g, void* ws, double dt2, const double* cappa, double ptop, const double* hs,
+                         const double* ws3, const double* ptc, const double* q_con, const double* delpc, double* gz,
+                         double* pef, const double* w3, double p_fac, hipStream_t st) {
+  RiemCWork W;
+  double* p = (double*)ws;
+  const long field = g.sk * (g.nk + 1);
+  W.r.pem = p;
+  W.r.pm = p + field;
+  W.r.w1 = p + 2 * field;
+  W.r.gam = p + 3 * field;
+  W.r.pp = p + 4 * field;
+  W.r.aa = p + 5 * field;
+  W.dz = p + 6 * field;
+  W.pe = p + 7 * field;
+  W.w = p + 8 * field;
+  const dim3 cgrid((g.n + 2 + 63) / 64, g.n + 2, 1), cblock(64);
+  const dim3 pgrid = plane_grid(g, g.nk + 1), pblock(256);
+  hipLaunchKernelGGL(k_riem3_prefix<1>, cgrid, cblock, 0, st, g, W.r, ptop, delpc, q_con);
+  hipLaunchKernelGGL(k_riemc_parallel_pre, pgrid, pblock, 0, st, g, W, cappa, delpc, ptc, gz, w3);
+  hipLaunchKernelGGL(k_riem3_tridiag<1>, cgrid, cblock, 0, st, g, W.r, dt2, cappa, ws3, W.dz, delpc, W.pe, W.w);
+  hipLaunchKernelGGL(k_riemc_parallel_post, pgrid, pblock, 0, st, g, W, ptop, cappa, delpc, ptc, pef, p_fac);
+  hipLaunchKernelGGL(k_riemc_gz, cgrid, cblock, 0, st, g, hs, W.dz, gz);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

@@ -23,3 +23,39 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
                         const double* zs, const double* wsd, double* delz, const double* q_con, const double* delp,
                         const double* pt, double* zh, double* pe, double* ppe, double* pk3, double* pk, double* peln,
                         double* w, double p_fac, hipStream_t st);
+// k_csw.hip
+int64_t csw_workspace_bytes(const Geo& g);
+int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, double* uc, double* vc, const double* u, const double* v,
+                      double* ua, double* va, double* utc, double* vtc, hipStream_t st);
+int launch_c_sw(const Geo& g, const Met& m, void* ws, double* delpc, double* ptc, const double* delp, const double* pt,
+                const double* u, const double* v, const double* w, double* uc, double* vc, double* ua, double* va,
+                double* ut, double* vt, double* divgd, double* omga, double dt2, int nord, hipStream_t st);
+// k_riem3.hip (C-grid solver)
+int64_t riemc_workspace_bytes(const Geo& g);
+int launch_riem_solver_c(const Geo& g, void* ws, double dt2, const double* cappa, double ptop, const double* hs,
+                         const double* ws3, const double* ptc, const double* q_con, const double* delpc, double* gz,
+                         double* pef, const double* w3, double p_fac, hipStream_t st);
+// k_acoustic.hip
+int64_t updatedzc_workspace_bytes(const Geo& g);
+int launch_updatedzc(const Geo& g, const Met& m, void* ws_, const double* dp_ref, const double* zs, const double* ut,
+                     const double* vt, double* gz, double* ws, double dt, hipStream_t st);
+int64_t updatedzd_workspace_bytes(const Geo& g);
+int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd_k_t* kc, const double* zs, double* zh,
+                     const double* crx, const double* cry, const double* xfx, const double* yfx, double* wsd, double dt,
+                     int hord_tm, hipStream_t st);
+int launch_gz_from_surface(const Geo& g, const double* zs, const double* delz, double* gz, hipStream_t st);
+int launch_scale_copy(const Geo& g, const double* src, double* dst, double factor, int scale, int halo, int nlev,
+                      hipStream_t st);
+int launch_p_grad_c(const Geo& g, const Met& m, double* uc, double* vc, const double* delpc, const double* pkc,
+                    const double* gz, double dt2, hipStream_t st);
+int64_t nh_p_grad_workspace_bytes(const Geo& g);
+int launch_nh_p_grad(const Geo& g, const Met& m, void* ws_, double* u, double* v, double* pp, double* gz, double* pk3,
+                     double* delp, double dt, double ptop, double akap, hipStream_t st);
+int launch_edge_pe(const Geo& g, double* pe, const double* delp, double ptop, hipStream_t st);
+int launch_pk3_halo(const Geo& g, double* pk3, const double* delp, double ptop, double akap, hipStream_t st);
+int launch_ray_fast(const Geo& g, double* u, double* v, double* w, const double* dp, const double* pfull, double dt,
+                    double ptop, double rf_cutoff, double tau, int hydrostatic, hipStream_t st);
+int64_t del2cubed_workspace_bytes(const Geo& g);
+int launch_del2cubed(const Geo& g, const Met& m, void* ws_, double* qdel, double cd, int nmax, hipStream_t st);
+int launch_diffusive_heating(const Geo& g, const double* delp, const double* delz, const double* cappa,
+                             const double* heat_source, double* pt, double delt_time_factor, int nlev, hipStream_t st);

@@ -70,6 +70,7 @@ class GridData:
                     continue
                 q = quantity_factory.zeros([c.X_DIM, c.Y_DIM], units="")
                 q.set(a)
+                q._grid_data = self  # lets operators that are handed one metric (updatedzc's `area`) find the table
                 setattr(self, name, q)
                 self._names.append(name)
         if all(hasattr(self, k) for k in _HOST_ONLY):
