@@ -199,6 +199,22 @@ int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, co
                                  const double* heat_source, double* pt, double delt_time_factor, int nlev,
                                  void* stream);
 
+/* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
+ * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation
+ * (rotate.py:4-50) and boundary slicing (_boundary_utils.py:58-95) folded into an affine index map.
+ * Strip element (a, b, k), 0 <= a < na, 0 <= b < nb, 0 <= k < nk, lives at message offset (k*nb + b)*na + a
+ * and at field index (i0 + a*di_a + b*di_b, j0 + a*dj_a + b*dj_b, k).  pack: buf = sign * field;
+ * unpack: field = buf.  descs is a HOST array; field / buf are DEVICE pointers. */
+typedef struct {
+  double* field;
+  double* buf;
+  int32_t i0, j0, di_a, dj_a, di_b, dj_b;
+  int32_t na, nb, nk, pad_;
+  double sign;
+} pace_halo_desc_t;
+int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream);
+int pace_halo_unpack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream);
+
 const char* pace_version(void);
 /* Text of the last HIP error this library saw on the calling thread ("" if none). */
 const char* pace_last_error(void);

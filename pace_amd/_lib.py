@@ -56,6 +56,14 @@ class UpdatedzdK(C.Structure):
     ]
 
 
+class HaloDesc(C.Structure):
+    _fields_ = [
+        ("field", c_dp), ("buf", c_dp),
+        ("i0", C.c_int32), ("j0", C.c_int32), ("di_a", C.c_int32), ("dj_a", C.c_int32), ("di_b", C.c_int32), ("dj_b", C.c_int32),
+        ("na", C.c_int32), ("nb", C.c_int32), ("nk", C.c_int32), ("pad_", C.c_int32), ("sign", C.c_double),
+    ]
+
+
 class PaceError(RuntimeError):
     pass
 
@@ -100,6 +108,8 @@ _PROTOS = {
     "pace_del2cubed_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_del2cubed": (C.c_int, [_P(Geom), _P(Metrics), c_dp, c_dp, C.c_double, C.c_int, C.c_void_p]),
     "pace_apply_diffusive_heating": (C.c_int, [_P(Geom)] + [c_dp] * 5 + [C.c_double, C.c_int, C.c_void_p]),
+    "pace_halo_pack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
+    "pace_halo_unpack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

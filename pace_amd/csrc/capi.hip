@@ -221,4 +221,30 @@ int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, co
   return launch_diffusive_heating(make_geo(geom), delp, delz, cappa, heat_source, pt, delt_time_factor, nlev, S(stream));
 }
 
+static int halo_check(const pace_geom_t* geom, const pace_halo_desc_t* d, int n) {
+  const int ni = geom->n + 7;
+  for (int t = 0; t < n; ++t) {
+    if (!d[t].field || !d[t].buf || d[t].na < 1 || d[t].nb < 1 || d[t].nk < 1 || d[t].nk > geom->nk + 1) return PACE_ERR_ARG;
+    for (int ca = 0; ca < 2; ++ca)
+      for (int cb = 0; cb < 2; ++cb) {
+        const int a = ca ? d[t].na - 1 : 0, b = cb ? d[t].nb - 1 : 0;
+        const int i = d[t].i0 + a * d[t].di_a + b * d[t].di_b, j = d[t].j0 + a * d[t].dj_a + b * d[t].dj_b;
+        if (i < 0 || i >= ni || j < 0 || j >= ni) return PACE_ERR_ARG;
+      }
+  }
+  return PACE_OK;
+}
+
+int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {
+  NEED(geom && descs && ndesc > 0);
+  if (halo_check(geom, descs, ndesc)) return PACE_ERR_ARG;
+  return launch_halo_copy(make_geo(geom), descs, ndesc, 0, S(stream));
+}
+
+int pace_halo_unpack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {
+  NEED(geom && descs && ndesc > 0);
+  if (halo_check(geom, descs, ndesc)) return PACE_ERR_ARG;
+  return launch_halo_copy(make_geo(geom), descs, ndesc, 1, S(stream));
+}
+
 }  // extern "C"

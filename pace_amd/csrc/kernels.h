@@ -59,3 +59,5 @@ int64_t del2cubed_workspace_bytes(const Geo& g);
 int launch_del2cubed(const Geo& g, const Met& m, void* ws_, double* qdel, double cd, int nmax, hipStream_t st);
 int launch_diffusive_heating(const Geo& g, const double* delp, const double* delz, const double* cappa,
                              const double* heat_source, double* pt, double delt_time_factor, int nlev, hipStream_t st);
+// k_halo.hip
+int launch_halo_copy(const Geo& g, const pace_halo_desc_t* descs, int ndesc, int unpack, hipStream_t st);

@@ -1,0 +1,130 @@
+"""Point-to-point transports for the halo exchange.
+
+The reference's ``HaloUpdater`` needs exactly ``Isend`` / ``Irecv`` of contiguous 1-D buffers plus
+``Get_rank`` / ``Get_size`` (util/pace/util/comm.py:14-73, halo_updater.py:241-267).  Two transports provide that
+over device tensors:
+
+* ``TorchDistComm``  -- one process per GPU, ``torch.distributed`` (backend "nccl" is RCCL over xGMI; "gloo" is used by
+  the CPU tests).  ``exchange`` posts all sends and receives of one halo update as ONE ``batch_isend_irecv`` group,
+  so RCCL sees a single grouped launch per update and the transfers run on RCCL's stream while the compute stream
+  keeps launching kernels until ``wait``.
+* ``ThreadComm``     -- several tiles inside one process (one Python thread per tile, e.g. all six tiles of a small
+  cubed sphere on a single 288 GB device).  A send enqueues a device-side copy; a receive copies it out.
+"""
+import threading
+from collections import defaultdict, deque
+
+import torch
+
+
+class Request:
+    def __init__(self, fn=None):
+        self._fn = fn
+
+    def wait(self):
+        if self._fn is not None:
+            self._fn()
+            self._fn = None
+
+
+class TorchDistComm:
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
+        self._dist = dist
+        self._group = group
+
+    def Get_rank(self):
+        return self._dist.get_rank(self._group)
+
+    def Get_size(self):
+        return self._dist.get_world_size(self._group)
+
+    def barrier(self):
+        self._dist.barrier(self._group)
+
+    def exchange(self, sends, recvs, tag=0):
+        """sends / recvs: lists of (1-D tensor, peer rank).  Returns a Request."""
+        dist = self._dist
+        ops = [dist.P2POp(dist.irecv, buf, peer, self._group, tag) for buf, peer in recvs]
+        ops += [dist.P2POp(dist.isend, buf, peer, self._group, tag) for buf, peer in sends]
+        works = dist.batch_isend_irecv(ops)
+
+        def fin():
+            for w in works:
+                w.wait()
+
+        return Request(fin)
+
+    def allreduce_min(self, value: float) -> float:
+        t = torch.tensor([value], dtype=torch.float64, device="cuda" if self._dist.get_backend(self._group) == "nccl" else "cpu")
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self._group)
+        return float(t.item())
+
+
+class _World:
+    def __init__(self, n):
+        self.n = n
+        self.cond = threading.Condition()
+        self.mail = defaultdict(deque)
+        self.barrier = threading.Barrier(n)
+
+
+class ThreadComm:
+    def __init__(self, world: _World, rank: int):
+        self._world = world
+        self._rank = rank
+
+    def Get_rank(self):
+        return self._rank
+
+    def Get_size(self):
+        return self._world.n
+
+    def barrier(self):
+        self._world.barrier.wait()
+
+    def exchange(self, sends, recvs, tag=0):
+        w = self._world
+        with w.cond:
+            for buf, peer in sends:
+                w.mail[(self._rank, peer, tag)].append(buf.clone())
+            w.cond.notify_all()
+
+        def fin():
+            for buf, peer in recvs:
+                key = (peer, self._rank, tag)
+                with w.cond:
+                    if not w.cond.wait_for(lambda: len(w.mail[key]) > 0, timeout=300):
+                        raise TimeoutError(f"tile {self._rank} waiting for message {key}")
+                    data = w.mail[key].popleft()
+                buf.copy_(data)
+
+        return Request(fin)
+
+
+def run_tiles(n, fn):
+    """Run ``fn(comm)`` for n tiles on n threads of this process; returns their results in tile order."""
+    world = _World(n)
+    results, errors = [None] * n, []
+
+    def target(r):
+        try:
+            results[r] = fn(ThreadComm(world, r))
+        except BaseException as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((r, e, traceback.format_exc()))
+            world.barrier.abort()
+
+    threads = [threading.Thread(target=target, args=(r,), daemon=True, name=f"tile{r}") for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        r, e, tb = errors[0]
+        raise RuntimeError(f"tile {r} failed: {e!r}\n{tb}") from e
+    return results

@@ -153,6 +153,14 @@ class QuantityFactory:
         q.set(data)
         return q
 
+    def get_quantity_halo_spec(self, dims, n_halo=None, dtype=float):
+        """allocator.py:132-155: the memory description a HaloUpdater is built from."""
+        from .halo import QuantityHaloSpec
+
+        return QuantityHaloSpec(self.sizer.n_halo if n_halo is None else n_halo, (1, self.row_stride, self.level_stride), 8,
+                                self.sizer.get_shape(dims), self.sizer.get_origin(dims), self.sizer.get_extent(dims), tuple(dims),
+                                None, torch.float64)
+
     @property
     def row_stride(self):
         return row_stride(self.sizer.nx + 1 + 2 * self.sizer.n_halo)

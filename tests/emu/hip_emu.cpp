@@ -1,6 +1,8 @@
 // Fiber scheduler for tests/emu/hip_emu.h (test infrastructure only).
 #include "hip_emu.h"
 
+#include <mutex>
+
 uint3_emu threadIdx, blockIdx;
 dim3 blockDim, gridDim;
 
@@ -25,6 +27,9 @@ void trampoline() {
 void __syncthreads() { swapcontext(&g_cur->ctx, &g_main); }
 
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  // one launch at a time: the scheduler state is global (several tile threads may call into the library)
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   gridDim = grid;
   blockDim = block;
   g_body = &body;

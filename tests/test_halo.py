@@ -1,0 +1,125 @@
+"""Halo exchange: the product path (HIP pack/unpack kernel sources under emulation + ThreadComm / gloo transports)
+against oracle/halo.py, which is bit-exact against the reference's CubedSphereCommunicator
+(tools/crosscheck_oracle.py halo) and its own halo tests.  CPU only."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, build_emu
+
+N, NZ = 12, 5
+DIMS = {"c": ["x", "y", "z"], "xi": ["x_interface", "y", "z"], "yi": ["x", "y_interface", "z"],
+        "b": ["x_interface", "y_interface", "z"], "zi": ["x", "y", "z_interface"]}
+
+
+def _base(seed=5):
+    rng = np.random.default_rng(seed)
+    return {k: [rng.random((N + 7, N + 7, NZ + 1)) for _ in range(6)] for k in DIMS}
+
+
+def _expected(base):
+    from oracle import halo as oh
+
+    out = {}
+    f = [a.copy() for a in base["c"]]; oh.halo_update(f, N, nk=NZ); out["c"] = f
+    f = [a.copy() for a in base["b"]]; oh.halo_update(f, N, xi=1, yi=1, nk=NZ); out["b"] = f
+    f = [a.copy() for a in base["zi"]]; oh.halo_update(f, N, n_pts=2); out["zi"] = f
+    u, v = [a.copy() for a in base["yi"]], [a.copy() for a in base["xi"]]; oh.vector_halo_update(u, v, N, grid="d", nk=NZ)
+    out["du"], out["dv"] = u, v
+    u, v = [a.copy() for a in base["xi"]], [a.copy() for a in base["yi"]]; oh.vector_halo_update(u, v, N, grid="c", nk=NZ)
+    out["cu"], out["cv"] = u, v
+    u, v = [a.copy() for a in base["yi"]], [a.copy() for a in base["xi"]]; oh.synchronize_vector_interfaces(u, v, N, nk=NZ)
+    out["su"], out["sv"] = u, v
+    return out
+
+
+def tile_program(comm, lib, base):
+    """What every tile runs (shared by the thread and the gloo tests)."""
+    from pace_amd.util import CubedSphereCommunicator, QuantityFactory, SubtileGridSizer
+
+    sizer = SubtileGridSizer.from_tile_params(nx_tile=N, ny_tile=N, nz=NZ, n_halo=3, extra_dim_lengths={}, layout=(1, 1))
+    qf = QuantityFactory(sizer, device="cpu")
+    cube = CubedSphereCommunicator(comm, device="cpu", lib=lib)
+    r = cube.rank
+
+    def q(key):
+        x = qf.zeros(DIMS[key], "")
+        x.set(base[key][r])
+        return x
+
+    out = {}
+    s = q("c"); cube.halo_update(s, n_points=3); out["c"] = s.numpy()
+    s = q("b"); cube.halo_update(s, n_points=3); out["b"] = s.numpy()
+    s = q("zi"); cube.halo_update(s, n_points=2); out["zi"] = s.numpy()
+    u, v = q("yi"), q("xi"); cube.vector_halo_update(u, v, n_points=3); out["du"], out["dv"] = u.numpy(), v.numpy()
+    u, v = q("xi"), q("yi"); cube.vector_halo_update(u, v, n_points=3); out["cu"], out["cv"] = u.numpy(), v.numpy()
+    u, v = q("yi"), q("xi"); cube.synchronize_vector_interfaces(u, v); out["su"], out["sv"] = u.numpy(), v.numpy()
+    # a reusable multi-field updater with two exchanges in flight, waited out of order (dyn_core.py:686-699)
+    a, b, cc = q("c"), q("c"), q("c")
+    b.data[:] = b.data * 2.0
+    cc.data[:] = cc.data + 1.0
+    up3 = cube.get_scalar_halo_updater([qf.get_quantity_halo_spec(DIMS["c"])] * 2)
+    up1 = cube.get_scalar_halo_updater([qf.get_quantity_halo_spec(DIMS["c"])])
+    up3.start([a, b])
+    up1.start([cc])
+    up1.wait()
+    up3.wait()
+    out["m_a"], out["m_b"], out["m_c"] = a.numpy(), b.numpy(), cc.numpy()
+    return out
+
+
+def _check(results, base):
+    exp = _expected(base)
+    for t in range(6):
+        for k, e in exp.items():
+            assert np.array_equal(results[t][k], e[t]), (t, k)
+        assert np.array_equal(results[t]["m_a"], exp["c"][t])
+        # compute domain + edge halos (corners are never exchanged): b = 2 * field, c = field + 1 elementwise
+        m = np.zeros((N + 7, N + 7), dtype=bool)
+        m[3 : 3 + N, 0 : N + 6] = True
+        m[0 : N + 6, 3 : 3 + N] = True
+        assert np.array_equal(results[t]["m_b"][m][:, :NZ], 2.0 * exp["c"][t][m][:, :NZ])
+        assert np.array_equal(results[t]["m_c"][m][:, :NZ], exp["c"][t][m][:, :NZ] + 1.0)
+
+
+def test_halo_updates_six_tiles_on_threads():
+    from pace_amd import _lib
+    from pace_amd.util import run_tiles
+
+    lib = _lib.Library(build_emu())
+    base = _base()
+    results = run_tiles(6, lambda comm: tile_program(comm, lib, base))
+    _check(results, base)
+
+
+_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=6)
+from pace_amd import _lib
+from pace_amd.util import TorchDistComm
+import test_halo
+lib = _lib.Library(os.path.join({root!r}, "tests", "emu", "libpace_emu.so"))
+out = test_halo.tile_program(TorchDistComm(), lib, test_halo._base())
+pickle.dump(out, open(sys.argv[2], "wb"))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_halo_updates_six_processes_gloo(tmp_path):
+    """One process per tile over torch.distributed (gloo here; the same code path runs RCCL on the GPUs)."""
+    import pickle
+
+    build_emu()
+    port = 29500 + os.getpid() % 2000
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / f"out{r}.pkl")]) for r in range(6)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    results = [pickle.load(open(tmp_path / f"out{r}.pkl", "rb")) for r in range(6)]
+    _check(results, _base())
