@@ -24,15 +24,45 @@ void trampoline() {
 }
 }  // namespace
 
-void __syncthreads() { swapcontext(&g_cur->ctx, &g_main); }
+namespace {
+bool g_plain = false;
+struct NeedsFibers {};
+}  // namespace
 
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+void __syncthreads() {
+  if (g_plain) throw NeedsFibers();
+  swapcontext(&g_cur->ctx, &g_main);
+}
+
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode) {
   // one launch at a time: the scheduler state is global (several tile threads may call into the library)
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   gridDim = grid;
   blockDim = block;
   g_body = &body;
+  if (*mode != 2) {
+    g_plain = true;
+    try {
+      for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+          for (unsigned bx = 0; bx < grid.x; ++bx) {
+            blockIdx = {bx, by, bz};
+            for (unsigned tz = 0; tz < block.z; ++tz)
+              for (unsigned ty = 0; ty < block.y; ++ty)
+                for (unsigned tx = 0; tx < block.x; ++tx) {
+                  threadIdx = {tx, ty, tz};
+                  body();
+                }
+          }
+      g_plain = false;
+      *mode = 1;
+      return;
+    } catch (const NeedsFibers&) {
+      g_plain = false;
+      *mode = 2;
+    }
+  }
   const size_t nthreads = (size_t)block.x * block.y * block.z;
   const size_t stack_bytes = 256 * 1024;
   std::vector<Fiber> fibers(nthreads);

@@ -42,10 +42,16 @@ inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 
 void __syncthreads();
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
+// `mode` is per launch site: 0 = not known yet, 1 = the kernel never synchronises (threads run as plain calls),
+// 2 = it does (threads run as fibers).  A kernel that hits __syncthreads() in plain mode is restarted with fibers;
+// that is safe because nothing but LDS is written before a kernel's first barrier.
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode);
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)            \
+  do {                                                                          \
+    static int emu_mode__ = 0;                                                  \
+    emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); }, &emu_mode__);   \
+  } while (0)
 
 using std::exp; using std::log; using std::sqrt; using std::fabs; using std::fmin; using std::fmax;
 using std::sin; using std::cos; using std::asin; using std::pow;

@@ -7,7 +7,7 @@
 import numpy as np
 import pytest
 
-from helpers import (DSW_ARGS, DSW_CFG, RIEM_ARGS, Env, column_for_levels, compare, dsw_window, expand_riem_fixture, golden,
+from helpers import (acoustic_errors, run_acoustic_six_tiles, DSW_ARGS, DSW_CFG, RIEM_ARGS, Env, column_for_levels, compare, dsw_window, expand_riem_fixture, golden,
                      oracle_grid, run_d_sw, run_riem3, window)
 
 pytestmark = pytest.mark.gpu
@@ -148,3 +148,13 @@ def test_c192_properties(lib):
                 - mfy[3 : 3 + n, 3 + n, :nz].sum(0))
     total = (s["delp"][c] * area).sum(axis=(0, 1))
     np.testing.assert_allclose(dm / total, boundary / total, rtol=0, atol=1e-12)
+
+
+def test_acoustic_dynamics_six_tiles_matches_reference_run(lib):
+    """One whole AcousticDynamics call (n_split = 2, every operator of the loop and all halo-update groups) for the six C12
+    tiles resident on one device, against the reference run's output.  Tolerance: see
+    test_emu_kernels.test_acoustic_dynamics_six_tiles_emulated."""
+    fixes, outs = run_acoustic_six_tiles(lib, "cuda")
+    for t in range(6):
+        for k, e in acoustic_errors(fixes[t], outs[t]).items():
+            assert e < 1e-7, (t, k, e)

@@ -36,13 +36,13 @@ def _expected(base):
     return out
 
 
-def tile_program(comm, lib, base):
+def tile_program(comm, lib, base, device="cpu"):
     """What every tile runs (shared by the thread and the gloo tests)."""
     from pace_amd.util import CubedSphereCommunicator, QuantityFactory, SubtileGridSizer
 
     sizer = SubtileGridSizer.from_tile_params(nx_tile=N, ny_tile=N, nz=NZ, n_halo=3, extra_dim_lengths={}, layout=(1, 1))
-    qf = QuantityFactory(sizer, device="cpu")
-    cube = CubedSphereCommunicator(comm, device="cpu", lib=lib)
+    qf = QuantityFactory(sizer, device=device)
+    cube = CubedSphereCommunicator(comm, device=device, lib=lib)
     r = cube.rank
 
     def q(key):
@@ -92,6 +92,18 @@ def test_halo_updates_six_tiles_on_threads():
     lib = _lib.Library(build_emu())
     base = _base()
     results = run_tiles(6, lambda comm: tile_program(comm, lib, base))
+    _check(results, base)
+
+
+@pytest.mark.gpu
+def test_halo_updates_six_tiles_on_one_gpu():
+    """The gfx950 pack/unpack kernels: six tiles resident on one device, one host thread per tile."""
+    from pace_amd import _lib
+    from pace_amd.util import run_tiles
+
+    lib = _lib.load()
+    base = _base()
+    results = run_tiles(6, lambda comm: tile_program(comm, lib, base, device="cuda"))
     _check(results, base)
 
 

@@ -1,0 +1,84 @@
+"""Generate tests/golden/acoustic_c12_*.npz by RUNNING THE REFERENCE's AcousticDynamics in this container: 6 tile ranks on
+threads (tools/threadcomm.py), real halo exchanges, every gtscript stencil executed by tools/gtinterp.py (see
+make_golden.py for what that means).  One call of n_split = 2 substeps at C12 x 79L, k_split = 1 (so the call is the
+last one: remap_step / end_step paths are exercised).
+
+Per tile the fixture holds the grid metrics, the full state going in (+ cappa, which DynamicalCore's preamble computes),
+and the state coming out on a level subset plus a few full columns.  Data only.
+"""
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+warnings.filterwarnings("ignore")
+
+import numpy as np  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+K_SEL = [0, 1, 2, 3, 4, 40, 77, 78, 79]
+COLS = [(3, 3), (8, 9), (14, 14), (3, 14)]
+N, NZ, N_SPLIT = 12, 79, 2
+STATE_IN = "u v w delz delp pt pe pk peln q_con omga ua va uc vc mfxd mfyd cxd cyd diss_estd phis".split()
+STATE_OUT = "u v w delz delp pt pe pk peln q_con omga ua va mfxd mfyd cxd cyd diss_estd".split()
+
+
+def main():
+    import capture
+    import datetime
+    import pace.fv3core as fv3core
+    import refenv
+    from threadcomm import run_ranks
+
+    config = capture.dycore_config(n_split=N_SPLIT, npx=N + 1, npz=NZ)
+
+    def rank(comm):
+        env = refenv.build_rank(comm, N, NZ)
+        dycore = fv3core.DynamicalCore(
+            comm=env.cube, grid_data=env.grid_data, stencil_factory=env.stencil_factory, quantity_factory=env.qf,
+            damping_coefficients=env.damping, config=config, timestep=datetime.timedelta(seconds=config.dt_atmos),
+            phis=env.state.phis, state=env.state)
+        state = env.state
+        dycore.compute_preamble(state, is_root_rank=comm.Get_rank() == 0)
+        dycore._copy_stencil(state.delp, dycore._dp_initial)
+        snap = capture._snap
+        before = {k: snap(getattr(state, k)) for k in STATE_IN}
+        before["cappa"] = snap(dycore.acoustic_dynamics.cappa)
+        dycore.acoustic_dynamics(state, timestep=dycore._timestep / dycore._k_split, n_map=1)
+        after = {k: snap(getattr(state, k)) for k in STATE_OUT}
+        after["heat_source"] = snap(dycore.acoustic_dynamics._heat_source)
+        grid = {}
+        for name in dir(env.grid_data):
+            if name.startswith("_"):
+                continue
+            try:
+                v = getattr(env.grid_data, name)
+            except Exception:  # noqa: BLE001
+                continue
+            s = snap(v)
+            if s is not None and not isinstance(s, str):
+                grid[name] = s
+        for name in ["del6_u", "del6_v", "divg_u", "divg_v", "da_min", "da_min_c"]:
+            grid[name] = snap(getattr(env.damping, name))
+        return grid, before, after, float(dycore._timestep / dycore._k_split)
+
+    out = run_ranks(6, rank)
+    os.makedirs(GOLDEN, exist_ok=True)
+    for t, (grid, before, after, timestep) in enumerate(out):
+        g = {k: v for k, v in grid.items() if isinstance(v, (float, int)) or (isinstance(v, np.ndarray) and v.ndim <= 2)}
+        for k in ("edge_w", "edge_e"):
+            g[k] = np.ascontiguousarray(g[k][0, :]) if g[k].ndim == 2 else g[k]
+        data = {"grid_" + k: v for k, v in g.items()}
+        data.update({"in_" + k: v for k, v in before.items()})
+        for k, v in after.items():
+            data["out_" + k] = np.ascontiguousarray(v[3 : 3 + N + 1, 3 : 3 + N + 1][:, :, K_SEL])
+            data["col_" + k] = np.stack([v[i, j, :] for (i, j) in COLS])
+        data["k_sel"], data["cols"] = np.array(K_SEL), np.array(COLS)
+        data["timestep"], data["n_split"] = timestep, N_SPLIT
+        np.savez_compressed(os.path.join(GOLDEN, f"acoustic_c12_tile{t}.npz"), **data)
+    for f in sorted(os.listdir(GOLDEN)):
+        print(f, os.path.getsize(os.path.join(GOLDEN, f)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()
