@@ -135,9 +135,11 @@ def main():
     torch.cuda.synchronize()
 
     def step(b):
-        dsw(*[b[k] for k in DSW_ARGS], dt)
+        # the wind half of d_sw runs on a side stream, concurrently with the (latency-bound) column solver
+        dsw(*[b[k] for k in DSW_ARGS], dt, overlap_winds=True)
         riem(False, dt, b["cappa"], ptop, zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"], b["ppe"], b["pk3"],
              b["pk"], b["peln"], b["w"])
+        dsw.join()
 
     def barrier():
         if world > 1:

@@ -118,6 +118,23 @@ int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_col
               double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx, double* yfx,
               double* q_con, const double* zh, double* heat_source, double* diss_est, double dt, void* stream);
 
+/* The two halves of pace_d_sw, same arguments.  pace_d_sw_transport: flux preparation and the transport of delp, w,
+ * q_con, pt (d_sw.py:935-1117) -- everything updatedzd / riem_solver3 read.  pace_d_sw_winds: the rest
+ * (d_sw.py:1119-1237); it reads only what the first half left behind, so it may be launched on a second stream
+ * and run concurrently with the vertical solver.  pace_d_sw == transport followed by winds on one stream. */
+int pace_d_sw_transport(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
+                        const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt,
+                        double* u, double* v, double* w, double* uc, double* vc, const double* ua, const double* va,
+                        double* divgd, double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry,
+                        double* xfx, double* yfx, double* q_con, const double* zh, double* heat_source,
+                        double* diss_est, double dt, void* stream);
+int pace_d_sw_winds(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
+                    const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
+                    double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
+                    double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx,
+                    double* yfx, double* q_con, const double* zh, double* heat_source, double* diss_est, double dt,
+                    void* stream);
+
 /* ---- NonhydrostaticVerticalSolver.__call__ (riem_solver3.py:208-321), compute domain.
  * zs, ws: 2-D.  workspace: pace_riem_solver3_workspace_bytes() bytes of DEVICE scratch. */
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom);

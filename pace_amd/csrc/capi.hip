@@ -74,17 +74,31 @@ int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* w
   return dsw_prepare(make_geo(geom), col, workspace, S(stream));
 }
 
-int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-              const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
-              double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
-              double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx, double* yfx,
-              double* q_con, const double* zh, double* heat_source, double* diss_est, double dt, void* stream) {
+static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
+                      const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
+                      double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
+                      double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx, double* yfx,
+                      double* q_con, const double* zh, double* heat_source, double* diss_est, double dt, void* stream) {
   NEED(geom && met && col && cfg && workspace);
   NEED(delpc && delp && pt && u && v && w && uc && vc && ua && va && divgd && mfx && mfy && cx && cy);
   NEED(crx && cry && xfx && yfx && q_con && heat_source && diss_est);
   return launch_d_sw(make_geo(geom), *met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy,
-                     cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est, dt, S(stream));
+                     cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est, dt, phases, S(stream));
 }
+
+#define DSW_PARAMS                                                                                                        \
+  const pace_geom_t *geom, const pace_metrics_t *met, const pace_column_t *col, const pace_dsw_config_t *cfg,            \
+      void *workspace, double *delpc, double *delp, double *pt, double *u, double *v, double *w, double *uc, double *vc,  \
+      const double *ua, const double *va, double *divgd, double *mfx, double *mfy, double *cx, double *cy, double *crx,   \
+      double *cry, double *xfx, double *yfx, double *q_con, const double *zh, double *heat_source, double *diss_est,       \
+      double dt, void *stream
+#define DSW_ARGS_                                                                                                          \
+  geom, met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx,  \
+      q_con, zh, heat_source, diss_est, dt, stream
+
+int pace_d_sw(DSW_PARAMS) { return d_sw_entry(3, DSW_ARGS_); }
+int pace_d_sw_transport(DSW_PARAMS) { return d_sw_entry(1, DSW_ARGS_); }
+int pace_d_sw_winds(DSW_PARAMS) { return d_sw_entry(2, DSW_ARGS_); }
 
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom) {
   return geom ? riem3_workspace_bytes(make_geo(geom)) : 0;

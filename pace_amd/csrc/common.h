@@ -91,13 +91,18 @@ __device__ __forceinline__ double ppm_al(const double* q, int off, int pos, int 
   return PPM_P1 * (qm1 + q0) + PPM_P2 * (qm2 + qp1);
 }
 
+// Interior form: valid when no interface of the stencil lies within 2 of a tile edge (block-uniform test in the callers).
+__device__ __forceinline__ double ppm_al_interior(const double* q, int off) {
+  return PPM_P1 * (q[off - 1] + q[off]) + PPM_P2 * (q[off - 2] + q[off + 1]);
+}
+
 // Mean value advected through the interface at position pos (between cells pos-1 and pos).
 // q6[m] = cell value at pos-3+m, m = 0..5.
-template <int MORD, class DX>
+template <int MORD, bool EDGE = true, class DX>
 __device__ __forceinline__ double ppm_flux6(const double* q6, double c, int pos, int s, int e, DX dxa) {
-  const double al_m = ppm_al(q6, 2, pos - 1, s, e, dxa);
-  const double al_0 = ppm_al(q6, 3, pos, s, e, dxa);
-  const double al_p = ppm_al(q6, 4, pos + 1, s, e, dxa);
+  const double al_m = EDGE ? ppm_al(q6, 2, pos - 1, s, e, dxa) : ppm_al_interior(q6, 2);
+  const double al_0 = EDGE ? ppm_al(q6, 3, pos, s, e, dxa) : ppm_al_interior(q6, 3);
+  const double al_p = EDGE ? ppm_al(q6, 4, pos + 1, s, e, dxa) : ppm_al_interior(q6, 4);
   const double qm = q6[2], q0 = q6[3];
   const double bl_m = al_m - qm, br_m = al_0 - qm, b0_m = bl_m + br_m;
   const double bl_0 = al_0 - q0, br_0 = al_p - q0, b0_0 = bl_0 + br_0;

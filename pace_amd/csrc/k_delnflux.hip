@@ -33,6 +33,8 @@ __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __
   const long kb = (long)k * g.sk;
   const int ilo = i0 - 3, jlo = j0 - 3;
   const bool hi_order = nord_k[k] > 0.0;
+  // the corner-copy index maps only matter to workgroups whose footprint reaches a corner of the halo (block-uniform)
+  const bool rc = hi_order && (ilo < g.is || ilo + DW - 1 > g.ie) && (jlo < g.js || jlo + DH - 1 > g.je);
   const int iters = hi_order ? nmax : 0;
   const double damp = damp_k[k];
   const double d0 = mass_given ? 1.0 : damp;
@@ -58,31 +60,35 @@ __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __
       if (gi >= 1 && gi < g.ni && gj >= 1 && gj < g.nj && ii >= 1 && jj >= 1) {
         const long c2 = IDX2(g, gi, gj);
         // x flux: d2 with corners copied in x
-        {
-          int ai = gi - 1, aj = gj, bi = gi, bj = gj;
-          if (hi_order) {
+        if (rc) {
+          {
+            int ai = gi - 1, aj = gj, bi = gi, bj = gj;
             remap_agrid_x(g, ai, aj);
             remap_agrid_x(g, bi, bj);
+            const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
+            double da = 0.0, db = 0.0;
+            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb][la];
+            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld][lc];
+            const double t = m.del6_v[c2] * (da - db);
+            vx = (it == 0) ? t : -t;
           }
-          const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
-          double da = 0.0, db = 0.0;
-          if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb][la];
-          if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld][lc];
-          const double t = m.del6_v[c2] * (da - db);
-          vx = (it == 0) ? t : -t;
-        }
-        {
-          int ai = gi, aj = gj - 1, bi = gi, bj = gj;
-          if (hi_order) {
+          {
+            int ai = gi, aj = gj - 1, bi = gi, bj = gj;
             remap_agrid_y(g, ai, aj);
             remap_agrid_y(g, bi, bj);
+            const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
+            double da = 0.0, db = 0.0;
+            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb][la];
+            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld][lc];
+            const double t = m.del6_u[c2] * (da - db);
+            vy = (it == 0) ? t : -t;
           }
-          const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
-          double da = 0.0, db = 0.0;
-          if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb][la];
-          if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld][lc];
-          const double t = m.del6_u[c2] * (da - db);
-          vy = (it == 0) ? t : -t;
+        } else {
+          const double d0v = sd[jj][ii];
+          const double tx = m.del6_v[c2] * (sd[jj][ii - 1] - d0v);
+          const double ty = m.del6_u[c2] * (sd[jj - 1][ii] - d0v);
+          vx = (it == 0) ? tx : -tx;
+          vy = (it == 0) ? ty : -ty;
         }
       }
       (void)sgn;

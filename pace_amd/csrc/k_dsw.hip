@@ -606,11 +606,15 @@ int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st
   return PACE_OK;
 }
 
+// phases: 1 = flux preparation + transport of delp, w, q_con, pt (everything riem_solver3 / updatedzd depend on),
+//         2 = winds (kinetic energy, vorticity, divergence damping, vorticity transport, heating), 3 = both.
+// Phase 2 only reads what phase 1 produced (ut/vt, crx..yfx, the new delp, heat_s), so a caller may run it on a second
+// stream concurrently with the vertical solver (pace_amd/fv3core/stencils/d_sw.py).
 int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace_dsw_config_t* cfg, void* ws,
                 double* delpc, double* delp, double* pt, double* u, double* v, double* w, double* uc, double* vc,
                 const double* ua, const double* va, double* divgd, double* mfx, double* mfy, double* cx, double* cy,
                 double* crx, double* cry, double* xfx, double* yfx, double* q_con, const double* zh,
-                double* heat_source, double* diss_est, double dt, hipStream_t st) {
+                double* heat_source, double* diss_est, double dt, int phases, hipStream_t st) {
   (void)zh;
   const int nk = g.nk;
   DswWork W = carve(g, ws);
@@ -634,6 +638,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   int rc;
   const dim3 block(256);
   const dim3 gk = plane_grid(g, nk);
+  if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, st))) return rc;
   // delp
   if ((rc = launch_fvtp2d(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, st))) return rc;
@@ -653,6 +658,11 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   if ((rc = launch_fvtp2d(g, m, pt, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_tm, nk, st))) return rc;
   if ((rc = launch_delnflux(g, m, 2, pt, W.gx, W.gy, delp, d_dampfac_vt, d_nord_v, nmax_v, 1, nk, st))) return rc;
   hipLaunchKernelGGL(k_pt_delp_w_qcon, gk, block, 0, st, g, m, pt, delp, w, q_con, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
+  }
+  if (!(phases & 2)) {
+    PACE_CHECK_LAUNCH();
+    return PACE_OK;
+  }
   // winds
   if (cfg->hord_mt == 5) {
     hipLaunchKernelGGL(k_kinetic_energy<5>, gk, block, 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt);

@@ -16,17 +16,28 @@
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
-template <int MORD>
-__global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
+// EX / EY: whether any x- (y-) interface this workgroup evaluates lies within two cells of a tile edge, where the
+// PPM interface values switch to the one-sided forms (xppm.py:148-181).  Block-uniform, so interior workgroups
+// (25 of 35 at C192) run straight-line code without the per-interface position tests.
+struct FvLds {
+  double sq[QH][QW + 1];        // q on [i0-3, i0+TI+3) x [j0-3, j0+TJ+3)
+  double syin[TJ + 1][QW + 1];  // inner y sweep: mean advected value on y-interfaces
+  double sqi[TJ][QW + 1];       // q advected in y (fvtp2d.py:34-56)
+  double sxin[QH][TI + 2];      // inner x sweep on x-interfaces
+  double sqj[QH][TI + 1];       // q advected in x (fvtp2d.py:59-77)
+};
+
+template <int MORD, bool EX, bool EY>
+__device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m, const double* __restrict__ q,
                                                 const double* __restrict__ crx, const double* __restrict__ cry,
                                                 const double* __restrict__ xfx, const double* __restrict__ yfx,
                                                 double* __restrict__ fx, double* __restrict__ fy,
                                                 const double* __restrict__ xunit, const double* __restrict__ yunit) {
-  __shared__ double sq[QH][QW + 1];    // q on [i0-3, i0+TI+3) x [j0-3, j0+TJ+3)
-  __shared__ double syin[TJ + 1][QW + 1];  // inner y sweep: mean advected value on y-interfaces
-  __shared__ double sqi[TJ][QW + 1];       // q advected in y (fvtp2d.py:34-56)
-  __shared__ double sxin[QH][TI + 2];      // inner x sweep on x-interfaces
-  __shared__ double sqj[QH][TI + 1];       // q advected in x (fvtp2d.py:59-77)
+  auto& sq = L.sq;
+  auto& syin = L.syin;
+  auto& sqi = L.sqi;
+  auto& sxin = L.sxin;
+  auto& sqj = L.sqj;
 
   const int tid = threadIdx.x;
   const int i0 = g.is + blockIdx.x * TI;
@@ -60,8 +71,8 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
       const double* dya = m.dya;
       const long col = gi;
       const int sj = g.sj;
-      val = ppm_flux6<MORD>(q6, cry[kb + IDX2(g, gi, gj)], gj, g.js, g.je,
-                            [=](int p) { return dya[col + (long)p * sj]; });
+      val = ppm_flux6<MORD, EY>(q6, cry[kb + IDX2(g, gi, gj)], gj, g.js, g.je,
+                                [=](int p) { return dya[col + (long)p * sj]; });
     }
     syin[jj][ii] = val;
   }
@@ -106,7 +117,7 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
 #pragma unroll
       for (int t = 0; t < 6; ++t) q6[t] = sq[jj][ii + t];  // columns gi-3 .. gi+2
       const double* dxa = m.dxa + (long)gj * g.sj;
-      val = ppm_flux6<MORD>(q6, crx[kb + IDX2(g, gi, gj)], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
+      val = ppm_flux6<MORD, EX>(q6, crx[kb + IDX2(g, gi, gj)], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
     }
     sxin[jj][ii] = val;
   }
@@ -138,7 +149,7 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
 #pragma unroll
       for (int t = 0; t < 6; ++t) q6[t] = sqi[jj][ii + t];  // q_i at gi-3 .. gi+2
       const double* dxa = m.dxa + (long)gj * g.sj;
-      const double xo = ppm_flux6<MORD>(q6, crx[c], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
+      const double xo = ppm_flux6<MORD, EX>(q6, crx[c], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
       fx[c] = 0.5 * (xo + sxin[jj + 3][ii]) * xunit[c];
     }
     if (gi <= g.ie) {
@@ -148,10 +159,28 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
       const double* dya = m.dya;
       const long col = gi;
       const int sj = g.sj;
-      const double yo = ppm_flux6<MORD>(q6, cry[c], gj, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; });
+      const double yo = ppm_flux6<MORD, EY>(q6, cry[c], gj, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; });
       fy[c] = 0.5 * (yo + syin[jj][ii + 3]) * yunit[c];
     }
   }
+}
+
+template <int MORD>
+__global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
+                                                const double* __restrict__ crx, const double* __restrict__ cry,
+                                                const double* __restrict__ xfx, const double* __restrict__ yfx,
+                                                double* __restrict__ fx, double* __restrict__ fy,
+                                                const double* __restrict__ xunit, const double* __restrict__ yunit) {
+  // x-interfaces evaluated: i0 .. i0+TI (their al's reach one further each way); special forms at is-1 .. is+1 and
+  // ie .. ie+2
+  __shared__ FvLds L;
+  const int i0 = g.is + blockIdx.x * TI, j0 = g.js + blockIdx.y * TJ;
+  const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
+  const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
+  if (ex && ey) fvtp2d_tile<MORD, true, true>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
+  else if (ex) fvtp2d_tile<MORD, true, false>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
+  else if (ey) fvtp2d_tile<MORD, false, true>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
+  else fvtp2d_tile<MORD, false, false>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
 }
 
 int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,

@@ -20,7 +20,10 @@
 #define RGRAV (1.0 / GRAV)
 #define CP_AIR 1004.6
 #define KAPPA (RDGAS / CP_AIR)
-#define CH 8
+#ifndef RIEM_CH
+#define RIEM_CH 8
+#endif
+#define CH RIEM_CH
 
 struct Riem3Work {
   double *pem, *pm, *w1, *gam, *pp, *aa;

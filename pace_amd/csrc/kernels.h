@@ -17,7 +17,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
                 double* delpc, double* delp, double* pt, double* u, double* v, double* w, double* uc, double* vc,
                 const double* ua, const double* va, double* divgd, double* mfx, double* mfy, double* cx, double* cy,
                 double* crx, double* cry, double* xfx, double* yfx, double* q_con, const double* zh,
-                double* heat_source, double* diss_est, double dt, hipStream_t st);
+                double* heat_source, double* diss_est, double dt, int phases, hipStream_t st);
 int64_t riem3_workspace_bytes(const Geo& g);
 int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const double* cappa, double ptop,
                         const double* zs, const double* wsd, double* delz, const double* q_con, const double* delp,

@@ -96,9 +96,36 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         self.call("pace_d_sw_prepare", C.byref(self._col), self._workspace.data_ptr(), self.stream())
 
     def __call__(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
-                 heat_source, diss_est, dt):
+                 heat_source, diss_est, dt, overlap_winds: bool = False):
+        """overlap_winds=True (an extension; the default is the reference's behaviour): the second half of d_sw -- the
+        wind update, which nothing before nh_p_grad reads -- is launched on this object's side stream, so that on
+        return the calling stream only carries the transport of delp / w / q_con / pt and the caller's next launches
+        (halo exchange, updatedzd, riem_solver3: few, latency-bound columns) overlap with it.  The caller MUST call
+        ``join()`` before touching u, v, uc, vc, heat_source, diss_est, delpc or divgd again."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                   heat_source, diss_est)
         check_layout(self._geom, *fields)
-        self.call("pace_d_sw", C.byref(self._met), C.byref(self._col), C.byref(self._cfg), self._workspace.data_ptr(),
-                  *[dptr(f) for f in fields], float(dt), self.stream())
+        args = (C.byref(self._met), C.byref(self._col), C.byref(self._cfg), self._workspace.data_ptr(), *[dptr(f) for f in fields],
+                float(dt))
+        if not overlap_winds or self._emu:
+            self.call("pace_d_sw", *args, self.stream())
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self._workspace.device)
+            self._fork, self._done = torch.cuda.Event(), torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        self.call("pace_d_sw_transport", *args, self.stream())
+        self._fork.record(main)
+        self._side.wait_event(self._fork)
+        self.call("pace_d_sw_winds", *args, C.c_void_p(self._side.cuda_stream))
+        self._done.record(self._side)
+        self._pending = True
+
+    _side = None
+    _pending = False
+
+    def join(self):
+        """Make the calling stream wait for an overlapped wind update (no-op otherwise)."""
+        if self._pending:
+            torch.cuda.current_stream().wait_event(self._done)
+            self._pending = False

@@ -227,7 +227,7 @@ class AcousticDynamics(Operator):
             self.dgrid_shallow_water_lagrangian_dynamics(
                 self._vt, state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._divgd,
                 state.mfxd, state.mfyd, state.cxd, state.cyd, self._crx, self._cry, self._xfx, self._yfx, state.q_con, self._zh,
-                self._heat_source, state.diss_estd, dt_acoustic_substep)
+                self._heat_source, state.diss_estd, dt_acoustic_substep, overlap_winds=True)
             halo.delp__pt__q_con.update()
             self.update_height_on_d_grid(surface_height=self._zs, height=self._zh, courant_number_x=self._crx,
                                          courant_number_y=self._cry, x_area_flux=self._xfx, y_area_flux=self._yfx, ws=self._wsd,
@@ -243,6 +243,7 @@ class AcousticDynamics(Operator):
             halo.zh.wait()
             self._compute_geopotential_stencil(self._zh, self._gz)
             halo.pkc.wait()
+            self.dgrid_shallow_water_lagrangian_dynamics.join()  # the overlapped wind half of d_sw
             self.nonhydrostatic_pressure_gradient(state.u, state.v, self._pkc, self._gz, self._pk3, state.delp, dt_acoustic_substep,
                                                   self._ptop, akap)
             if cfg.rf_fast:
