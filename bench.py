@@ -8,9 +8,10 @@ A "step" is one d_sw call followed by one riem_solver3 call on one pristine, HBM
 model state (K + W copies are staged before the timed region; nothing is re-used between steps, so no
 step benefits from cached data of the previous one).  Prints ONE JSON line on rank 0.
 
-Multi-GPU: tiles are independent inside d_sw + riem_solver3 (the delp/pt/q_con halo exchange of
-dyn_core.py:854 between them is not part of this round's path -- DESIGN.md), so ranks run their tile
-with no data-path collective and the result is weak scaling.
+Multi-GPU: one tile per GPU, weak scaling.  With exactly 6 ranks the ranks ARE the six faces of the cube and the
+delp / pt / q_con halo exchange that sits between d_sw and riem_solver3 in the acoustic loop (dyn_core.py:854) runs
+inside the timed region: HIP pack -> one grouped RCCL send/recv per rank -> HIP unpack.  With any other rank count
+there is no cubed-sphere topology to exchange over; the tiles are independent replicas (no data-path collective).
 """
 import argparse
 import json
@@ -134,9 +135,19 @@ def main():
     batches = [clone_state() for _ in range(nbatch)]
     torch.cuda.synchronize()
 
+    exchange = None
+    if world == 6:
+        from pace_amd.util import CubedSphereCommunicator, TorchDistComm
+        from pace_amd.util.constants import X_DIM, Y_DIM, Z_DIM
+
+        cube = CubedSphereCommunicator(TorchDistComm(), device=dev, lib=lib)
+        exchange = cube.get_scalar_halo_updater([env.qf.get_quantity_halo_spec([X_DIM, Y_DIM, Z_DIM])] * 3)
+
     def step(b):
         # the wind half of d_sw runs on a side stream, concurrently with the (latency-bound) column solver
         dsw(*[b[k] for k in DSW_ARGS], dt, overlap_winds=True)
+        if exchange is not None:
+            exchange.update([b["delp"], b["pt"], b["q_con"]])
         riem(False, dt, b["cappa"], ptop, zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"], b["ppe"], b["pk3"],
              b["pk"], b["peln"], b["w"])
         dsw.join()
@@ -182,8 +193,17 @@ def main():
         torch.cuda.synchronize()
         t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
         algo = FVTP2D_FIELDS * 8.0 * (n + 1) * (n + 1) * nz
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
+        # separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/r01_pmc_traffic.json
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc["k_fvtp2d<6>"]["hbm_bytes_per_launch"] if n == 192 and nz == 79 else None
+        except (OSError, KeyError):
+            pass
         roof = {"kernel": "k_fvtp2d<6>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_launch": t_kernel * 1e6}
+                "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "us_per_launch": t_kernel * 1e6,
+                "algorithmic_bytes_per_launch": algo}
 
     if rank == 0:
         line = {
@@ -200,7 +220,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, fp64",
-                       "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}"},
+                       "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}",
+                       "halo_exchange": "delp,pt,q_con over RCCL (cubed sphere)" if exchange is not None else "none"},
             "step_hbm_frac": BYTES_PER_CELL_UPDATE * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,
         }

@@ -69,12 +69,14 @@ def test_fvtp2d_matches_reference_fixture(lib):
     assert compare(fix["out_q_y_flux"][window(12, 0, 1, nk)], fy.numpy()[window(12, 0, 1, nk)]) < 1e-13
 
 
-def test_d_sw_and_riem3_match_oracle_c48(lib):
-    """Synthetic C48 x 79: exercises every level class (k = 0, 1, 2, >= 3) and the tile seams of the LDS kernels."""
+@pytest.mark.parametrize("n", [48, 96])
+def test_d_sw_and_riem3_match_oracle(lib, n):
+    """Synthetic C48 / C96 x 79: exercises every level class (k = 0, 1, 2, >= 3), the tile seams of the LDS kernels and
+    (C96) workgroups that touch no tile edge, which run the straight-line interior PPM / delnflux paths."""
     from oracle import dgrid_sw, vertical
     from pace_amd import synthetic
 
-    n, nz = 48, 79
+    nz = 79
     metrics = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(metrics, n, nz)
     col = full_column(nz)
