@@ -18,14 +18,19 @@
 #define DH (DN_TJ + 6)
 
 // MODE 0: write fx2, fy2.  MODE 1: fx += fx2, fy += fy2.  MODE 2: mass-weighted add (delnflux.py:318-328).
+//
+// Each thread owns NE fixed points of the footprint for the whole kernel: their LDS slot, validity flags and the three
+// metric values (del6_v, del6_u, rarea) are worked out once, so an iteration is LDS reads and a handful of flops.
+#define DWP (DW + 1)
+#define NE ((DW * DH + 255) / 256)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __restrict__ q, double* fxo,
                                                   double* fyo, const double* __restrict__ mass,
                                                   const double* __restrict__ damp_k,
                                                   const double* __restrict__ nord_k, int nmax, int mass_given) {
-  __shared__ double sd[DH][DW + 1];
-  __shared__ double sfx[DH][DW + 1];
-  __shared__ double sfy[DH][DW + 1];
+  __shared__ double sd[DH * DWP];
+  __shared__ double sfx[DH * DWP];
+  __shared__ double sfy[DH * DWP];
   const int tid = threadIdx.x;
   const int i0 = g.is + blockIdx.x * DN_TI;
   const int j0 = g.js + blockIdx.y * DN_TJ;
@@ -39,38 +44,55 @@ __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __
   const double damp = damp_k[k];
   const double d0 = mass_given ? 1.0 : damp;
 
-  for (int e = tid; e < DW * DH; e += 256) {
+  int lidx[NE], pgi[NE], pgj[NE];
+  bool own[NE], flx[NE], cel[NE];
+  double dv[NE], du[NE], ra[NE];
+#pragma unroll
+  for (int t = 0; t < NE; ++t) {
+    const int e = tid + 256 * t;
     const int jj = e / DW, ii = e - jj * DW;
     const int gi = ilo + ii, gj = jlo + jj;
-    double v = 0.0;
-    if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj) {
-      v = q[kb + IDX2(g, gi, gj)];
-      if (!mass_given) v = d0 * v;
+    own[t] = e < DW * DH;
+    const bool stored = own[t] && gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj;
+    flx[t] = stored && gi >= 1 && gj >= 1 && ii >= 1 && jj >= 1;
+    cel[t] = stored && ii < DW - 1 && jj < DH - 1;
+    lidx[t] = jj * DWP + ii;
+    pgi[t] = gi;
+    pgj[t] = gj;
+    const long c2 = IDX2(g, gi, gj);
+    dv[t] = flx[t] ? m.del6_v[c2] : 0.0;
+    du[t] = flx[t] ? m.del6_u[c2] : 0.0;
+    ra[t] = cel[t] ? m.rarea[c2] : 0.0;
+    if (own[t]) {
+      double v = 0.0;
+      if (stored) {
+        v = q[kb + c2];
+        if (!mass_given) v = d0 * v;
+      }
+      sd[lidx[t]] = v;
     }
-    sd[jj][ii] = v;
   }
   __syncthreads();
 
   for (int it = 0;; ++it) {
-    const double sgn = (it == 0) ? 1.0 : -1.0;
-    for (int e = tid; e < DW * DH; e += 256) {
-      const int jj = e / DW, ii = e - jj * DW;
-      const int gi = ilo + ii, gj = jlo + jj;
+#pragma unroll
+    for (int t = 0; t < NE; ++t) {
+      if (!own[t]) continue;
+      const int l = lidx[t];
       double vx = 0.0, vy = 0.0;
-      if (gi >= 1 && gi < g.ni && gj >= 1 && gj < g.nj && ii >= 1 && jj >= 1) {
-        const long c2 = IDX2(g, gi, gj);
-        // x flux: d2 with corners copied in x
+      if (flx[t]) {
         if (rc) {
+          const int gi = pgi[t], gj = pgj[t];
           {
             int ai = gi - 1, aj = gj, bi = gi, bj = gj;
             remap_agrid_x(g, ai, aj);
             remap_agrid_x(g, bi, bj);
             const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
             double da = 0.0, db = 0.0;
-            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb][la];
-            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld][lc];
-            const double t = m.del6_v[c2] * (da - db);
-            vx = (it == 0) ? t : -t;
+            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb * DWP + la];
+            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld * DWP + lc];
+            const double tt = dv[t] * (da - db);
+            vx = (it == 0) ? tt : -tt;
           }
           {
             int ai = gi, aj = gj - 1, bi = gi, bj = gj;
@@ -78,50 +100,50 @@ __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __
             remap_agrid_y(g, bi, bj);
             const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
             double da = 0.0, db = 0.0;
-            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb][la];
-            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld][lc];
-            const double t = m.del6_u[c2] * (da - db);
-            vy = (it == 0) ? t : -t;
+            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb * DWP + la];
+            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld * DWP + lc];
+            const double tt = du[t] * (da - db);
+            vy = (it == 0) ? tt : -tt;
           }
         } else {
-          const double d0v = sd[jj][ii];
-          const double tx = m.del6_v[c2] * (sd[jj][ii - 1] - d0v);
-          const double ty = m.del6_u[c2] * (sd[jj - 1][ii] - d0v);
+          const double d0v = sd[l];
+          const double tx = dv[t] * (sd[l - 1] - d0v);
+          const double ty = du[t] * (sd[l - DWP] - d0v);
           vx = (it == 0) ? tx : -tx;
           vy = (it == 0) ? ty : -ty;
         }
       }
-      (void)sgn;
-      sfx[jj][ii] = vx;
-      sfy[jj][ii] = vy;
+      sfx[l] = vx;
+      sfy[l] = vy;
     }
     __syncthreads();
     if (it == iters) break;
     // d2_highorder (delnflux.py:183-205)
-    for (int e = tid; e < DW * DH; e += 256) {
-      const int jj = e / DW, ii = e - jj * DW;
-      const int gi = ilo + ii, gj = jlo + jj;
+#pragma unroll
+    for (int t = 0; t < NE; ++t) {
+      if (!own[t]) continue;
+      const int l = lidx[t];
       double v = 0.0;
-      if (ii < DW - 1 && jj < DH - 1 && gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj) {
-        v = (sfx[jj][ii] - sfx[jj][ii + 1] + sfy[jj][ii] - sfy[jj + 1][ii]) * m.rarea[IDX2(g, gi, gj)];
-      }
-      sd[jj][ii] = v;
+      if (cel[t]) v = (sfx[l] - sfx[l + 1] + sfy[l] - sfy[l + DWP]) * ra[t];
+      sd[l] = v;
     }
     __syncthreads();
   }
 
-  for (int e = tid; e < DN_TI * DN_TJ; e += 256) {
-    const int jj = e / DN_TI, ii = e - jj * DN_TI;
+  // ceil(N / TI) x ceil(N / TJ) workgroups: the faces ie+1 / je+1 are written by the workgroup owning cell ie / je
+  for (int e = tid; e < (DN_TI + 1) * (DN_TJ + 1); e += 256) {
+    const int jj = e / (DN_TI + 1), ii = e - jj * (DN_TI + 1);
     const int gi = i0 + ii, gj = j0 + jj;
     if (gi > g.ie + 1 || gj > g.je + 1) continue;
+    if ((ii == DN_TI && gi != g.ie + 1) || (jj == DN_TJ && gj != g.je + 1)) continue;
     const long c = kb + IDX2(g, gi, gj);
-    const double vx = sfx[jj + 3][ii + 3], vy = sfy[jj + 3][ii + 3];
-    if (gj <= g.je) {
+    const double vx = sfx[(jj + 3) * DWP + ii + 3], vy = sfy[(jj + 3) * DWP + ii + 3];
+    if (gj <= g.je && jj < DN_TJ) {
       if (MODE == 0) fxo[c] = vx;
       else if (MODE == 1) fxo[c] = fxo[c] + vx;
       else fxo[c] = fxo[c] + 0.5 * damp * (mass[c - 1] + mass[c]) * vx;
     }
-    if (gi <= g.ie) {
+    if (gi <= g.ie && ii < DN_TI) {
       if (MODE == 0) fyo[c] = vy;
       else if (MODE == 1) fyo[c] = fyo[c] + vy;
       else fyo[c] = fyo[c] + 0.5 * damp * (mass[c - g.sj] + mass[c]) * vy;
@@ -133,7 +155,7 @@ int launch_delnflux(const Geo& g, const Met& m, int mode, const double* q, doubl
                     const double* mass, const double* damp_k, const double* nord_k, int nmax, int mass_given,
                     int nlev, hipStream_t st) {
   if (nmax > 2) return PACE_ERR_UNSUPPORTED;  // 3-cell halo (the reference would index out of range too)
-  const dim3 grid((g.n + 1 + DN_TI - 1) / DN_TI, (g.n + 1 + DN_TJ - 1) / DN_TJ, nlev), block(256);
+  const dim3 grid((g.n + DN_TI - 1) / DN_TI, (g.n + DN_TJ - 1) / DN_TJ, nlev), block(256);
   if (mode == 0) {
     hipLaunchKernelGGL(k_delnflux<0>, grid, block, 0, st, g, m, q, fx, fy, mass, damp_k, nord_k, nmax, mass_given);
   } else if (mode == 1) {

@@ -27,12 +27,17 @@ struct FvLds {
   double sqj[QH][TI + 1];       // q advected in x (fvtp2d.py:59-77)
 };
 
+#define RF 4                              // interfaces per thread in a PPM run
+#define GY ((TJ + 1 + RF - 1) / RF)       // runs per column for the TJ+1 y-interfaces
+#define GX ((TI + 1 + RF - 1) / RF)       // runs per row for the TI+1 x-interfaces
+static_assert(QW * GY <= 256 && QH * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
+
 template <int MORD, bool EX, bool EY>
 __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m, const double* __restrict__ q,
-                                                const double* __restrict__ crx, const double* __restrict__ cry,
-                                                const double* __restrict__ xfx, const double* __restrict__ yfx,
-                                                double* __restrict__ fx, double* __restrict__ fy,
-                                                const double* __restrict__ xunit, const double* __restrict__ yunit) {
+                                            const double* __restrict__ crx, const double* __restrict__ cry,
+                                            const double* __restrict__ xfx, const double* __restrict__ yfx,
+                                            double* __restrict__ fx, double* __restrict__ fy,
+                                            const double* __restrict__ xunit, const double* __restrict__ yunit) {
   auto& sq = L.sq;
   auto& syin = L.syin;
   auto& sqi = L.sqi;
@@ -45,6 +50,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
   const int k = blockIdx.z;
   const long kb = (long)k * g.sk;
   const int ilo = i0 - 3, jlo = j0 - 3;
+  const int sj = g.sj;
 
   // stage 0: q with corners copied in the y direction (copy_corners_y, corners.py:367-425)
   for (int e = tid; e < QW * QH; e += 256) {
@@ -59,22 +65,29 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
   }
   __syncthreads();
 
-  // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1))
-  for (int e = tid; e < QW * (TJ + 1); e += 256) {
-    const int jj = e / QW, ii = e - jj * QW;
-    const int gi = ilo + ii, gj = j0 + jj;
-    double val = 0.0;
-    if (gi >= 0 && gi <= g.ni - 1 && gj >= g.js && gj <= g.je + 1) {
-      double q6[6];
+  // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1)): one run of RF interfaces of one
+  // column per thread, lanes along i
+  if (tid < QW * GY) {
+    const int grp = tid / QW, ii = tid - grp * QW;
+    const int jj0 = grp * RF;
+    const int gi = ilo + ii, gj0 = j0 + jj0;
+    const bool col_ok = gi >= 0 && gi <= g.ni - 1;
+    double Q[RF + 5], cc[RF], out[RF];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) q6[t] = sq[jj + t][ii];  // rows gj-3 .. gj+2
-      const double* dya = m.dya;
-      const long col = gi;
-      const int sj = g.sj;
-      val = ppm_flux6<MORD, EY>(q6, cry[kb + IDX2(g, gi, gj)], gj, g.js, g.je,
-                                [=](int p) { return dya[col + (long)p * sj]; });
+    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[(jj0 + u < QH) ? jj0 + u : QH - 1][ii];  // rows gj0-3 ..
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      const int gj = gj0 + f;
+      cc[f] = (col_ok && jj0 + f <= TJ && gj >= g.js && gj <= g.je + 1) ? cry[kb + IDX2(g, gi, gj)] : 0.0;
     }
-    syin[jj][ii] = val;
+    const double* dya = m.dya;
+    const long col = gi;
+    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; }, out);
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      const int gj = gj0 + f;
+      if (jj0 + f <= TJ) syin[jj0 + f][ii] = (col_ok && gj >= g.js && gj <= g.je + 1) ? out[f] : 0.0;
+    }
   }
   __syncthreads();
 
@@ -107,19 +120,28 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
   }
   __syncthreads();
 
-  // stage 3: inner x sweep (XPiecewiseParabolic, origin (is, js-3), domain (N+1, N+7))
-  for (int e = tid; e < (TI + 1) * QH; e += 256) {
-    const int jj = e / (TI + 1), ii = e - jj * (TI + 1);
-    const int gi = i0 + ii, gj = jlo + jj;
-    double val = 0.0;
-    if (gj >= 0 && gj <= g.nj - 1 && gi >= g.is && gi <= g.ie + 1) {
-      double q6[6];
+  // stage 3: inner x sweep (XPiecewiseParabolic, origin (is, js-3), domain (N+1, N+7)): one run of RF interfaces of one
+  // row per thread
+  if (tid < QH * GX) {
+    const int jj = tid / GX, grp = tid - jj * GX;
+    const int ii0 = grp * RF;
+    const int gi0 = i0 + ii0, gj = jlo + jj;
+    const bool row_ok = gj >= 0 && gj <= g.nj - 1;
+    double Q[RF + 5], cc[RF], out[RF];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) q6[t] = sq[jj][ii + t];  // columns gi-3 .. gi+2
-      const double* dxa = m.dxa + (long)gj * g.sj;
-      val = ppm_flux6<MORD, EX>(q6, crx[kb + IDX2(g, gi, gj)], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
+    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[jj][(ii0 + u < QW) ? ii0 + u : QW - 1];  // columns gi0-3 ..
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      const int gi = gi0 + f;
+      cc[f] = (row_ok && ii0 + f <= TI && gi >= g.is && gi <= g.ie + 1) ? crx[kb + IDX2(g, gi, gj)] : 0.0;
     }
-    sxin[jj][ii] = val;
+    const double* dxa = m.dxa + (long)gj * sj;
+    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return dxa[p]; }, out);
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      const int gi = gi0 + f;
+      if (ii0 + f <= TI) sxin[jj][ii0 + f] = (row_ok && gi >= g.is && gi <= g.ie + 1) ? out[f] : 0.0;
+    }
   }
   __syncthreads();
 
@@ -138,29 +160,54 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
   }
   __syncthreads();
 
-  // stage 5: outer sweeps + final_fluxes (fvtp2d.py:80-119)
-  for (int e = tid; e < TI * TJ; e += 256) {
-    const int jj = e / TI, ii = e - jj * TI;
-    const int gi = i0 + ii, gj = j0 + jj;
-    if (gi > g.ie + 1 || gj > g.je + 1) continue;
-    const long c = kb + IDX2(g, gi, gj);
-    if (gj <= g.je) {
-      double q6[6];
+  // stage 5: outer sweeps + final_fluxes (fvtp2d.py:80-119).  The grid has ceil(N / TI) x ceil(N / TJ) workgroups; the
+  // N+1-th face row / column (ie+1, je+1) is produced by the workgroup that owns cell ie / je, not by an extra,
+  // almost empty row of workgroups.
+  if (tid < TJ * GX) {  // outer x on q_i: rows of the tile, runs of x-interfaces
+    const int jj = tid / GX, grp = tid - jj * GX;
+    const int ii0 = grp * RF;
+    const int gi0 = i0 + ii0, gj = j0 + jj;
+    double Q[RF + 5], cc[RF], xu[RF], out[RF];
+    bool ok[RF];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) q6[t] = sqi[jj][ii + t];  // q_i at gi-3 .. gi+2
-      const double* dxa = m.dxa + (long)gj * g.sj;
-      const double xo = ppm_flux6<MORD, EX>(q6, crx[c], gi, g.is, g.ie, [=](int p) { return dxa[p]; });
-      fx[c] = 0.5 * (xo + sxin[jj + 3][ii]) * xunit[c];
+    for (int u = 0; u < RF + 5; ++u) Q[u] = sqi[jj][(ii0 + u < QW) ? ii0 + u : QW - 1];  // q_i at gi0-3 ..
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      const int ii = ii0 + f, gi = gi0 + f;
+      ok[f] = gj <= g.je && gi <= g.ie + 1 && (ii < TI || (ii == TI && gi == g.ie + 1));
+      const long c = kb + IDX2(g, gi, gj);
+      cc[f] = ok[f] ? crx[c] : 0.0;
+      xu[f] = ok[f] ? xunit[c] : 0.0;
     }
-    if (gi <= g.ie) {
-      double q6[6];
+    const double* dxa = m.dxa + (long)gj * sj;
+    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return dxa[p]; }, out);
 #pragma unroll
-      for (int t = 0; t < 6; ++t) q6[t] = sqj[jj + t][ii];  // q_j at gj-3 .. gj+2
-      const double* dya = m.dya;
-      const long col = gi;
-      const int sj = g.sj;
-      const double yo = ppm_flux6<MORD, EY>(q6, cry[c], gj, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; });
-      fy[c] = 0.5 * (yo + syin[jj][ii + 3]) * yunit[c];
+    for (int f = 0; f < RF; ++f) {
+      if (ok[f]) fx[kb + IDX2(g, gi0 + f, gj)] = 0.5 * (out[f] + sxin[jj + 3][ii0 + f]) * xu[f];
+    }
+  }
+  if (tid < TI * GY) {  // outer y on q_j: columns of the tile, runs of y-interfaces, lanes along i
+    const int grp = tid / TI, ii = tid - grp * TI;
+    const int jj0 = grp * RF;
+    const int gi = i0 + ii, gj0 = j0 + jj0;
+    double Q[RF + 5], cc[RF], yu[RF], out[RF];
+    bool ok[RF];
+#pragma unroll
+    for (int u = 0; u < RF + 5; ++u) Q[u] = sqj[(jj0 + u < QH) ? jj0 + u : QH - 1][ii];  // q_j at gj0-3 ..
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      const int jj = jj0 + f, gj = gj0 + f;
+      ok[f] = gi <= g.ie && gj <= g.je + 1 && (jj < TJ || (jj == TJ && gj == g.je + 1));
+      const long c = kb + IDX2(g, gi, gj);
+      cc[f] = ok[f] ? cry[c] : 0.0;
+      yu[f] = ok[f] ? yunit[c] : 0.0;
+    }
+    const double* dya = m.dya;
+    const long col = gi;
+    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; }, out);
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      if (ok[f]) fy[kb + IDX2(g, gi, gj0 + f)] = 0.5 * (out[f] + syin[jj0 + f][ii + 3]) * yu[f];
     }
   }
 }
@@ -186,7 +233,7 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
 int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
                   const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
                   const double* ymf, int hord, int nlev, hipStream_t st) {
-  const dim3 grid((g.n + 1 + TI - 1) / TI, (g.n + 1 + TJ - 1) / TJ, nlev), block(256);
+  const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev), block(256);
   const double* xu = xmf ? xmf : xfx;
   const double* yu = ymf ? ymf : yfx;
   if (hord == 5) {
