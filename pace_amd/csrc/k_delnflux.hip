@@ -10,24 +10,15 @@
 #include "common.h"
 #include "kernels.h"
 
-#ifndef DN_TI
-#define DN_TI 32
-#define DN_TJ 16
-#endif
-#define DW (DN_TI + 6)
-#define DH (DN_TJ + 6)
+#include "delnflux_core.h"
 
 // MODE 0: write fx2, fy2.  MODE 1: fx += fx2, fy += fy2.  MODE 2: mass-weighted add (delnflux.py:318-328).
-//
-// Each thread owns NE fixed points of the footprint for the whole kernel: their LDS slot, validity flags and the three
-// metric values (del6_v, del6_u, rarea) are worked out once, so an iteration is LDS reads and a handful of flops.
-#define DWP (DW + 1)
-#define NE ((DW * DH + 255) / 256)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __restrict__ q, double* fxo,
                                                   double* fyo, const double* __restrict__ mass,
                                                   const double* __restrict__ damp_k,
                                                   const double* __restrict__ nord_k, int nmax, int mass_given) {
+  __shared__ double sraw[DH * DWP];
   __shared__ double sd[DH * DWP];
   __shared__ double sfx[DH * DWP];
   __shared__ double sfy[DH * DWP];
@@ -36,99 +27,14 @@ __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __
   const int j0 = g.js + blockIdx.y * DN_TJ;
   const int k = blockIdx.z;
   const long kb = (long)k * g.sk;
-  const int ilo = i0 - 3, jlo = j0 - 3;
-  const bool hi_order = nord_k[k] > 0.0;
-  // the corner-copy index maps only matter to workgroups whose footprint reaches a corner of the halo (block-uniform)
-  const bool rc = hi_order && (ilo < g.is || ilo + DW - 1 > g.ie) && (jlo < g.js || jlo + DH - 1 > g.je);
-  const int iters = hi_order ? nmax : 0;
   const double damp = damp_k[k];
-  const double d0 = mass_given ? 1.0 : damp;
-
-  int lidx[NE], pgi[NE], pgj[NE];
-  bool own[NE], flx[NE], cel[NE];
-  double dv[NE], du[NE], ra[NE];
-#pragma unroll
-  for (int t = 0; t < NE; ++t) {
-    const int e = tid + 256 * t;
+  for (int e = tid; e < DW * DH; e += 256) {
     const int jj = e / DW, ii = e - jj * DW;
-    const int gi = ilo + ii, gj = jlo + jj;
-    own[t] = e < DW * DH;
-    const bool stored = own[t] && gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj;
-    flx[t] = stored && gi >= 1 && gj >= 1 && ii >= 1 && jj >= 1;
-    cel[t] = stored && ii < DW - 1 && jj < DH - 1;
-    lidx[t] = jj * DWP + ii;
-    pgi[t] = gi;
-    pgj[t] = gj;
-    const long c2 = IDX2(g, gi, gj);
-    dv[t] = flx[t] ? m.del6_v[c2] : 0.0;
-    du[t] = flx[t] ? m.del6_u[c2] : 0.0;
-    ra[t] = cel[t] ? m.rarea[c2] : 0.0;
-    if (own[t]) {
-      double v = 0.0;
-      if (stored) {
-        v = q[kb + c2];
-        if (!mass_given) v = d0 * v;
-      }
-      sd[lidx[t]] = v;
-    }
+    const int gi = i0 - 3 + ii, gj = j0 - 3 + jj;
+    sraw[jj * DWP + ii] = (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj) ? q[kb + IDX2(g, gi, gj)] : 0.0;
   }
   __syncthreads();
-
-  for (int it = 0;; ++it) {
-#pragma unroll
-    for (int t = 0; t < NE; ++t) {
-      if (!own[t]) continue;
-      const int l = lidx[t];
-      double vx = 0.0, vy = 0.0;
-      if (flx[t]) {
-        if (rc) {
-          const int gi = pgi[t], gj = pgj[t];
-          {
-            int ai = gi - 1, aj = gj, bi = gi, bj = gj;
-            remap_agrid_x(g, ai, aj);
-            remap_agrid_x(g, bi, bj);
-            const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
-            double da = 0.0, db = 0.0;
-            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb * DWP + la];
-            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld * DWP + lc];
-            const double tt = dv[t] * (da - db);
-            vx = (it == 0) ? tt : -tt;
-          }
-          {
-            int ai = gi, aj = gj - 1, bi = gi, bj = gj;
-            remap_agrid_y(g, ai, aj);
-            remap_agrid_y(g, bi, bj);
-            const int la = ai - ilo, lb = aj - jlo, lc = bi - ilo, ld = bj - jlo;
-            double da = 0.0, db = 0.0;
-            if (la >= 0 && la < DW && lb >= 0 && lb < DH) da = sd[lb * DWP + la];
-            if (lc >= 0 && lc < DW && ld >= 0 && ld < DH) db = sd[ld * DWP + lc];
-            const double tt = du[t] * (da - db);
-            vy = (it == 0) ? tt : -tt;
-          }
-        } else {
-          const double d0v = sd[l];
-          const double tx = dv[t] * (sd[l - 1] - d0v);
-          const double ty = du[t] * (sd[l - DWP] - d0v);
-          vx = (it == 0) ? tx : -tx;
-          vy = (it == 0) ? ty : -ty;
-        }
-      }
-      sfx[l] = vx;
-      sfy[l] = vy;
-    }
-    __syncthreads();
-    if (it == iters) break;
-    // d2_highorder (delnflux.py:183-205)
-#pragma unroll
-    for (int t = 0; t < NE; ++t) {
-      if (!own[t]) continue;
-      const int l = lidx[t];
-      double v = 0.0;
-      if (cel[t]) v = (sfx[l] - sfx[l + 1] + sfy[l] - sfy[l + DWP]) * ra[t];
-      sd[l] = v;
-    }
-    __syncthreads();
-  }
+  delnflux_core(g, m, sraw, sd, sfx, sfy, i0, j0, mass_given ? 1.0 : damp, nord_k[k] > 0.0, nmax);
 
   // ceil(N / TI) x ceil(N / TJ) workgroups: the faces ie+1 / je+1 are written by the workgroup owning cell ie / je
   for (int e = tid; e < (DN_TI + 1) * (DN_TJ + 1); e += 256) {

@@ -640,23 +640,22 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   const dim3 gk = plane_grid(g, nk);
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, st))) return rc;
-  // delp
-  if ((rc = launch_fvtp2d(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, st))) return rc;
-  if ((rc = launch_delnflux(g, m, 1, delp, W.fx, W.fy, nullptr, d_dampfac_vt, d_nord_v, nmax_v, 0, nk, st))) return rc;
-  // w damping fluxes
-  if ((rc = launch_delnflux(g, m, 0, w, W.fx2, W.fy2, nullptr, d_dampfac_w_c, d_nord_w, nmax_w, 0, nk, st))) return rc;
+  // delp: transport + del-n damping of the mass fluxes in one kernel
+  if ((rc = launch_fvtp2d_damped(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, 1, d_dampfac_vt,
+                                 d_nord_v, nmax_v, 0, nullptr, nullptr, nullptr, st))) return rc;
+  // w: transport with the mass fluxes (-> gx, gy) + the damping fluxes fx2, fy2 that heat_diss needs, one kernel
+  if ((rc = launch_fvtp2d_damped(g, m, w, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_vt, nk, 0, d_dampfac_w_c,
+                                 d_nord_w, nmax_w, 0, nullptr, W.fx2, W.fy2, st))) return rc;
   hipLaunchKernelGGL(k_fluxcap_heatdiss, gk, block, 0, st, g, m, cx, cy, mfx, mfy, crx, cry, W.fx, W.fy, W.fx2, W.fy2, w,
                      W.heat_s, diss_est, W.dw, d_damp_w_c, d_kebg, dt);
-  // w
-  if ((rc = launch_fvtp2d(g, m, w, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_vt, nk, st))) return rc;
   hipLaunchKernelGGL(k_apply_fluxes, gk, block, 0, st, g, m, w, delp, W.gx, W.gy);
   // q_con
-  if ((rc = launch_fvtp2d(g, m, q_con, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_dp, nk, st))) return rc;
-  if ((rc = launch_delnflux(g, m, 2, q_con, W.gx, W.gy, delp, d_dampfac_t, d_nord_t, nmax_t, 1, nk, st))) return rc;
+  if ((rc = launch_fvtp2d_damped(g, m, q_con, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_dp, nk, 2, d_dampfac_t,
+                                 d_nord_t, nmax_t, 1, delp, nullptr, nullptr, st))) return rc;
   hipLaunchKernelGGL(k_apply_fluxes, gk, block, 0, st, g, m, q_con, delp, W.gx, W.gy);
   // pt
-  if ((rc = launch_fvtp2d(g, m, pt, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_tm, nk, st))) return rc;
-  if ((rc = launch_delnflux(g, m, 2, pt, W.gx, W.gy, delp, d_dampfac_vt, d_nord_v, nmax_v, 1, nk, st))) return rc;
+  if ((rc = launch_fvtp2d_damped(g, m, pt, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_tm, nk, 2, d_dampfac_vt,
+                                 d_nord_v, nmax_v, 1, delp, nullptr, nullptr, st))) return rc;
   hipLaunchKernelGGL(k_pt_delp_w_qcon, gk, block, 0, st, g, m, pt, delp, w, q_con, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   if (!(phases & 2)) {

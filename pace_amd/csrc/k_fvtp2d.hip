@@ -13,6 +13,12 @@
 #endif
 #define TI FV_TI
 #define TJ FV_TJ
+#ifndef DN_TI
+#define DN_TI FV_TI
+#define DN_TJ FV_TJ
+#endif
+#include "delnflux_core.h"
+static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the transport tile");
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
@@ -25,6 +31,11 @@ struct FvLds {
   double sqi[TJ][QW + 1];       // q advected in y (fvtp2d.py:34-56)
   double sxin[QH][TI + 2];      // inner x sweep on x-interfaces
   double sqj[QH][TI + 1];       // q advected in x (fvtp2d.py:59-77)
+  // the four sweep arrays double as the three scratch planes of the fused damping; pad only if a (test-sized) tile
+  // makes them too small
+  static constexpr int kSweep = (TJ + 1) * (QW + 1) + TJ * (QW + 1) + QH * (TI + 2) + QH * (TI + 1);
+  static constexpr int kNeed = 3 * (TJ + 6) * (TI + 7);
+  double pad[kNeed > kSweep ? kNeed - kSweep : 1];
 };
 
 #define RF 4                              // interfaces per thread in a PPM run
@@ -32,12 +43,25 @@ struct FvLds {
 #define GX ((TI + 1 + RF - 1) / RF)       // runs per row for the TI+1 x-interfaces
 static_assert(QW * GY <= 256 && QH * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
-template <int MORD, bool EX, bool EY>
+// Optional fused del-n damping of the same scalar (FiniteVolumeTransport calls DelnFlux on q right after the transport,
+// fvtp2d.py:338-345; d_sw also needs DelnFluxNoSG(w) next to the transport of w).  DMODE -1: none; 0: damping fluxes
+// written to fx2o / fy2o; 1: added to fx / fy; 2: added mass-weighted (delnflux.py:318-328).
+struct FvDamp {
+  const double* damp_k;
+  const double* nord_k;
+  const double* mass;
+  double* fx2o;
+  double* fy2o;
+  int nmax, mass_given;
+};
+
+template <int MORD, bool EX, bool EY, int DMODE>
 __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m, const double* __restrict__ q,
                                             const double* __restrict__ crx, const double* __restrict__ cry,
                                             const double* __restrict__ xfx, const double* __restrict__ yfx,
                                             double* __restrict__ fx, double* __restrict__ fy,
-                                            const double* __restrict__ xunit, const double* __restrict__ yunit) {
+                                            const double* __restrict__ xunit, const double* __restrict__ yunit,
+                                            const FvDamp& dp) {
   auto& sq = L.sq;
   auto& syin = L.syin;
   auto& sqi = L.sqi;
@@ -64,6 +88,30 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
     sq[jj][ii] = v;
   }
   __syncthreads();
+
+  // fused damping: iterate in the LDS space the sweeps will use afterwards, keep this thread's face values in registers
+  double dvx[RF], dvy[RF];
+  double damp = 0.0;
+  if (DMODE >= 0) {
+    static_assert(sizeof(L.syin) + sizeof(L.sqi) + sizeof(L.sxin) + sizeof(L.sqj) + sizeof(L.pad) >= 3 * DH * DWP * sizeof(double),
+                  "scratch");
+    double* sd = &L.syin[0][0];
+    double* sfx = sd + DH * DWP;
+    double* sfy = sfx + DH * DWP;
+    damp = dp.damp_k[k];
+    delnflux_core(g, m, &sq[0][0], sd, sfx, sfy, i0, j0, dp.mass_given ? 1.0 : damp, dp.nord_k[k] > 0.0, dp.nmax);
+    if (tid < TJ * GX) {
+      const int jj = tid / GX, grp = tid - jj * GX;
+#pragma unroll
+      for (int f = 0; f < RF; ++f) dvx[f] = (grp * RF + f <= TI) ? sfx[(jj + 3) * DWP + grp * RF + f + 3] : 0.0;
+    }
+    if (tid < TI * GY) {
+      const int grp = tid / TI, ii = tid - grp * TI;
+#pragma unroll
+      for (int f = 0; f < RF; ++f) dvy[f] = (grp * RF + f <= TJ) ? sfy[(grp * RF + f + 3) * DWP + ii + 3] : 0.0;
+    }
+    __syncthreads();
+  }
 
   // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1)): one run of RF interfaces of one
   // column per thread, lanes along i
@@ -183,7 +231,14 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
     ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return dxa[p]; }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-      if (ok[f]) fx[kb + IDX2(g, gi0 + f, gj)] = 0.5 * (out[f] + sxin[jj + 3][ii0 + f]) * xu[f];
+      if (ok[f]) {
+        const long c = kb + IDX2(g, gi0 + f, gj);
+        double v = 0.5 * (out[f] + sxin[jj + 3][ii0 + f]) * xu[f];
+        if (DMODE == 0) dp.fx2o[c] = dvx[f];
+        if (DMODE == 1) v = v + dvx[f];
+        if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - 1] + dp.mass[c]) * dvx[f];
+        fx[c] = v;
+      }
     }
   }
   if (tid < TI * GY) {  // outer y on q_j: columns of the tile, runs of y-interfaces, lanes along i
@@ -207,42 +262,70 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
     ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-      if (ok[f]) fy[kb + IDX2(g, gi, gj0 + f)] = 0.5 * (out[f] + syin[jj0 + f][ii + 3]) * yu[f];
+      if (ok[f]) {
+        const long c = kb + IDX2(g, gi, gj0 + f);
+        double v = 0.5 * (out[f] + syin[jj0 + f][ii + 3]) * yu[f];
+        if (DMODE == 0) dp.fy2o[c] = dvy[f];
+        if (DMODE == 1) v = v + dvy[f];
+        if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - sj] + dp.mass[c]) * dvy[f];
+        fy[c] = v;
+      }
     }
   }
 }
 
-template <int MORD>
+template <int MORD, int DMODE>
 __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
                                                 const double* __restrict__ crx, const double* __restrict__ cry,
                                                 const double* __restrict__ xfx, const double* __restrict__ yfx,
                                                 double* __restrict__ fx, double* __restrict__ fy,
-                                                const double* __restrict__ xunit, const double* __restrict__ yunit) {
+                                                const double* __restrict__ xunit, const double* __restrict__ yunit,
+                                                FvDamp dp) {
   // x-interfaces evaluated: i0 .. i0+TI (their al's reach one further each way); special forms at is-1 .. is+1 and
   // ie .. ie+2
   __shared__ FvLds L;
   const int i0 = g.is + blockIdx.x * TI, j0 = g.js + blockIdx.y * TJ;
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
-  if (ex && ey) fvtp2d_tile<MORD, true, true>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
-  else if (ex) fvtp2d_tile<MORD, true, false>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
-  else if (ey) fvtp2d_tile<MORD, false, true>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
-  else fvtp2d_tile<MORD, false, false>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit);
+  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else if (ex) fvtp2d_tile<MORD, true, false, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else if (ey) fvtp2d_tile<MORD, false, true, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else fvtp2d_tile<MORD, false, false, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+}
+
+template <int MORD>
+static void launch_mode(int dmode, dim3 grid, hipStream_t st, const Geo& g, const Met& m, const double* q, const double* crx,
+                        const double* cry, const double* xfx, const double* yfx, double* fx, double* fy, const double* xu,
+                        const double* yu, const FvDamp& dp) {
+  const dim3 block(256);
+  switch (dmode) {
+    case 0: hipLaunchKernelGGL((k_fvtp2d<MORD, 0>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
+    case 1: hipLaunchKernelGGL((k_fvtp2d<MORD, 1>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
+    case 2: hipLaunchKernelGGL((k_fvtp2d<MORD, 2>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
+    default: hipLaunchKernelGGL((k_fvtp2d<MORD, -1>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
+  }
+}
+
+// dmode -1: transport only.  Otherwise the del-n damping of q is fused (see FvDamp).
+int launch_fvtp2d_damped(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
+                         const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf, const double* ymf,
+                         int hord, int nlev, int dmode, const double* damp_k, const double* nord_k, int nmax,
+                         int mass_given, const double* mass, double* fx2o, double* fy2o, hipStream_t st) {
+  if (dmode >= 0 && nmax > 2) return PACE_ERR_UNSUPPORTED;
+  const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
+  const double* xu = xmf ? xmf : xfx;
+  const double* yu = ymf ? ymf : yfx;
+  const FvDamp dp{damp_k, nord_k, mass, fx2o, fy2o, nmax, mass_given};
+  if (hord == 5) launch_mode<5>(dmode, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+  else if (hord == 6) launch_mode<6>(dmode, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+  else return PACE_ERR_UNSUPPORTED;
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
 }
 
 int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
                   const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
                   const double* ymf, int hord, int nlev, hipStream_t st) {
-  const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev), block(256);
-  const double* xu = xmf ? xmf : xfx;
-  const double* yu = ymf ? ymf : yfx;
-  if (hord == 5) {
-    hipLaunchKernelGGL(k_fvtp2d<5>, grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu);
-  } else if (hord == 6) {
-    hipLaunchKernelGGL(k_fvtp2d<6>, grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu);
-  } else {
-    return PACE_ERR_UNSUPPORTED;
-  }
-  PACE_CHECK_LAUNCH();
-  return PACE_OK;
+  return launch_fvtp2d_damped(g, m, q, crx, cry, xfx, yfx, fx, fy, xmf, ymf, hord, nlev, -1, nullptr, nullptr, 0, 0, nullptr,
+                              nullptr, nullptr, st);
 }

@@ -7,6 +7,10 @@ int launch_fxadv(const Geo& g, const Met& m, const double* uc, const double* vc,
 int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
                   const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
                   const double* ymf, int hord, int nlev, hipStream_t st);
+int launch_fvtp2d_damped(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
+                         const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf, const double* ymf,
+                         int hord, int nlev, int dmode, const double* damp_k, const double* nord_k, int nmax,
+                         int mass_given, const double* mass, double* fx2o, double* fy2o, hipStream_t st);
 int launch_delnflux(const Geo& g, const Met& m, int mode, const double* q, double* fx, double* fy,
                     const double* mass, const double* damp_k, const double* nord_k, int nmax, int mass_given,
                     int nlev, hipStream_t st);
