@@ -45,6 +45,40 @@ k_fluxcap_heatdiss(Geo g, Met m, double* __restrict__ cx, double* __restrict__ c
   }
 }
 
+// flux_capacitor alone (d_sw.py:33-60); heat_diss lives in the epilogue of the w transport kernel
+__global__ void __launch_bounds__(256)
+k_fluxcap(Geo g, double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ mfx, double* __restrict__ mfy,
+          const double* __restrict__ crx, const double* __restrict__ cry, const double* __restrict__ fx,
+          const double* __restrict__ fy) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  if (i >= g.is && i <= g.ie + 1) cx[c] = cx[c] + crx[c];
+  if (j >= g.js && j <= g.je + 1) cy[c] = cy[c] + cry[c];
+  const bool ci = (i >= g.is && i <= g.ie), cj = (j >= g.js && j <= g.je);
+  if (cj && i >= g.is && i <= g.ie + 1) mfx[c] = mfx[c] + fx[c];
+  if (ci && j >= g.js && j <= g.je + 1) mfy[c] = mfy[c] + fy[c];
+}
+
+// apply_pt_delp_fluxes (d_sw.py:148-201) + adjust_w_and_qcon (:331-350), given the flux-form updates
+// pt*delp + F(pt), w*delp + F(w), q_con*delp + F(q_con) that the transport kernels' epilogues produced
+__global__ void __launch_bounds__(256)
+k_finish_scalars(Geo g, Met m, double* __restrict__ pt, double* __restrict__ delp, double* __restrict__ w,
+                 double* __restrict__ q_con, const double* __restrict__ ptn, const double* __restrict__ wn,
+                 const double* __restrict__ qn, const double* __restrict__ fx, const double* __restrict__ fy,
+                 const double* __restrict__ dw, const double* __restrict__ damp_w) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
+  const long c = IDX3(g, i, j, k);
+  const double dn = delp[c] + (fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) * m.rarea[IDX2(g, i, j)];
+  pt[c] = ptn[c] / dn;
+  delp[c] = dn;
+  double wv = wn[c] / dn;
+  if (damp_w[k] > 1e-5) wv = wv + dw[c];
+  w[c] = wv;
+  q_con[c] = qn[c] / dn;
+}
+
 // apply_fluxes (d_sw.py:122-145): q = q*delp + flux_increment(gx, gy)
 __global__ void __launch_bounds__(256)
 k_apply_fluxes(Geo g, Met m, double* __restrict__ q, const double* __restrict__ delp,
@@ -640,23 +674,28 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   const dim3 gk = plane_grid(g, nk);
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, st))) return rc;
-  // delp: transport + del-n damping of the mass fluxes in one kernel
-  if ((rc = launch_fvtp2d_damped(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, 1, d_dampfac_vt,
-                                 d_nord_v, nmax_v, 0, nullptr, nullptr, nullptr, st))) return rc;
-  // w: transport with the mass fluxes (-> gx, gy) + the damping fluxes fx2, fy2 that heat_diss needs, one kernel
-  if ((rc = launch_fvtp2d_damped(g, m, w, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_vt, nk, 0, d_dampfac_w_c,
-                                 d_nord_w, nmax_w, 0, nullptr, W.fx2, W.fy2, st))) return rc;
-  hipLaunchKernelGGL(k_fluxcap_heatdiss, gk, block, 0, st, g, m, cx, cy, mfx, mfy, crx, cry, W.fx, W.fy, W.fx2, W.fy2, w,
-                     W.heat_s, diss_est, W.dw, d_damp_w_c, d_kebg, dt);
-  hipLaunchKernelGGL(k_apply_fluxes, gk, block, 0, st, g, m, w, delp, W.gx, W.gy);
-  // q_con
-  if ((rc = launch_fvtp2d_damped(g, m, q_con, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_dp, nk, 2, d_dampfac_t,
-                                 d_nord_t, nmax_t, 1, delp, nullptr, nullptr, st))) return rc;
-  hipLaunchKernelGGL(k_apply_fluxes, gk, block, 0, st, g, m, q_con, delp, W.gx, W.gy);
-  // pt
-  if ((rc = launch_fvtp2d_damped(g, m, pt, crx, cry, xfx, yfx, W.gx, W.gy, W.fx, W.fy, cfg->hord_tm, nk, 2, d_dampfac_vt,
-                                 d_nord_v, nmax_v, 1, delp, nullptr, nullptr, st))) return rc;
-  hipLaunchKernelGGL(k_pt_delp_w_qcon, gk, block, 0, st, g, m, pt, delp, w, q_con, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
+  {
+    FvDamp dp{};
+    // delp: transport + del-n damping of the mass fluxes -> fx, fy
+    dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
+    if ((rc = launch_transport(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, 1, 0, dp, st))) return rc;
+    hipLaunchKernelGGL(k_fluxcap, gk, block, 0, st, g, cx, cy, mfx, mfy, crx, cry, W.fx, W.fy);
+    // w: transport with the mass fluxes, del-n damping fluxes -> heat_diss, flux-form update -> W.gx (= w*delp + F(w))
+    dp = FvDamp{};
+    dp.damp_k = d_dampfac_w_c; dp.nord_k = d_nord_w; dp.nmax = nmax_w; dp.mass_given = 0;
+    dp.qout = W.gx; dp.amass = delp; dp.dw = W.dw; dp.heat_s = W.heat_s; dp.diss_est = diss_est;
+    dp.damp_w_k = d_damp_w_c; dp.ke_bg_k = d_kebg; dp.dt = dt;
+    if ((rc = launch_transport(g, m, w, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_vt, nk, 0, 2, dp, st))) return rc;
+    // q_con -> W.gy
+    dp = FvDamp{};
+    dp.damp_k = d_dampfac_t; dp.nord_k = d_nord_t; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp;
+    dp.qout = W.gy; dp.amass = delp;
+    if ((rc = launch_transport(g, m, q_con, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_dp, nk, 2, 1, dp, st))) return rc;
+    // pt -> W.fx2
+    dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.qout = W.fx2;
+    if ((rc = launch_transport(g, m, pt, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_tm, nk, 2, 1, dp, st))) return rc;
+    hipLaunchKernelGGL(k_finish_scalars, gk, block, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
+  }
   }
   if (!(phases & 2)) {
     PACE_CHECK_LAUNCH();

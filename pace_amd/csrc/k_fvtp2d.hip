@@ -43,19 +43,7 @@ struct FvLds {
 #define GX ((TI + 1 + RF - 1) / RF)       // runs per row for the TI+1 x-interfaces
 static_assert(QW * GY <= 256 && QH * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
-// Optional fused del-n damping of the same scalar (FiniteVolumeTransport calls DelnFlux on q right after the transport,
-// fvtp2d.py:338-345; d_sw also needs DelnFluxNoSG(w) next to the transport of w).  DMODE -1: none; 0: damping fluxes
-// written to fx2o / fy2o; 1: added to fx / fy; 2: added mass-weighted (delnflux.py:318-328).
-struct FvDamp {
-  const double* damp_k;
-  const double* nord_k;
-  const double* mass;
-  double* fx2o;
-  double* fy2o;
-  int nmax, mass_given;
-};
-
-template <int MORD, bool EX, bool EY, int DMODE>
+template <int MORD, bool EX, bool EY, int DMODE, int EPI>
 __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m, const double* __restrict__ q,
                                             const double* __restrict__ crx, const double* __restrict__ cry,
                                             const double* __restrict__ xfx, const double* __restrict__ yfx,
@@ -211,33 +199,37 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
   // stage 5: outer sweeps + final_fluxes (fvtp2d.py:80-119).  The grid has ceil(N / TI) x ceil(N / TJ) workgroups; the
   // N+1-th face row / column (ie+1, je+1) is produced by the workgroup that owns cell ie / je, not by an extra,
   // almost empty row of workgroups.
+  double vxf[RF], vyf[RF];  // this thread's final face fluxes (kept for the epilogue)
   if (tid < TJ * GX) {  // outer x on q_i: rows of the tile, runs of x-interfaces
     const int jj = tid / GX, grp = tid - jj * GX;
     const int ii0 = grp * RF;
     const int gi0 = i0 + ii0, gj = j0 + jj;
     double Q[RF + 5], cc[RF], xu[RF], out[RF];
-    bool ok[RF];
+    bool calc[RF];
 #pragma unroll
     for (int u = 0; u < RF + 5; ++u) Q[u] = sqi[jj][(ii0 + u < QW) ? ii0 + u : QW - 1];  // q_i at gi0-3 ..
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int ii = ii0 + f, gi = gi0 + f;
-      ok[f] = gj <= g.je && gi <= g.ie + 1 && (ii < TI || (ii == TI && gi == g.ie + 1));
+      calc[f] = gj <= g.je && gi <= g.ie + 1 && ii <= TI;
+      if (EPI == 0) calc[f] = calc[f] && (ii < TI || gi == g.ie + 1);  // a neighbour stores its own west face
       const long c = kb + IDX2(g, gi, gj);
-      cc[f] = ok[f] ? crx[c] : 0.0;
-      xu[f] = ok[f] ? xunit[c] : 0.0;
+      cc[f] = calc[f] ? crx[c] : 0.0;
+      xu[f] = calc[f] ? xunit[c] : 0.0;
     }
     const double* dxa = m.dxa + (long)gj * sj;
     ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return dxa[p]; }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-      if (ok[f]) {
+      vxf[f] = 0.0;
+      if (calc[f]) {
         const long c = kb + IDX2(g, gi0 + f, gj);
         double v = 0.5 * (out[f] + sxin[jj + 3][ii0 + f]) * xu[f];
-        if (DMODE == 0) dp.fx2o[c] = dvx[f];
+        if (DMODE == 0 && EPI == 0) dp.fx2o[c] = dvx[f];
         if (DMODE == 1) v = v + dvx[f];
         if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - 1] + dp.mass[c]) * dvx[f];
-        fx[c] = v;
+        if (EPI == 0) fx[c] = v;
+        vxf[f] = v;
       }
     }
   }
@@ -246,35 +238,91 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
     const int jj0 = grp * RF;
     const int gi = i0 + ii, gj0 = j0 + jj0;
     double Q[RF + 5], cc[RF], yu[RF], out[RF];
-    bool ok[RF];
+    bool calc[RF];
 #pragma unroll
     for (int u = 0; u < RF + 5; ++u) Q[u] = sqj[(jj0 + u < QH) ? jj0 + u : QH - 1][ii];  // q_j at gj0-3 ..
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int jj = jj0 + f, gj = gj0 + f;
-      ok[f] = gi <= g.ie && gj <= g.je + 1 && (jj < TJ || (jj == TJ && gj == g.je + 1));
+      calc[f] = gi <= g.ie && gj <= g.je + 1 && jj <= TJ;
+      if (EPI == 0) calc[f] = calc[f] && (jj < TJ || gj == g.je + 1);
       const long c = kb + IDX2(g, gi, gj);
-      cc[f] = ok[f] ? cry[c] : 0.0;
-      yu[f] = ok[f] ? yunit[c] : 0.0;
+      cc[f] = calc[f] ? cry[c] : 0.0;
+      yu[f] = calc[f] ? yunit[c] : 0.0;
     }
     const double* dya = m.dya;
     const long col = gi;
     ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-      if (ok[f]) {
+      vyf[f] = 0.0;
+      if (calc[f]) {
         const long c = kb + IDX2(g, gi, gj0 + f);
         double v = 0.5 * (out[f] + syin[jj0 + f][ii + 3]) * yu[f];
-        if (DMODE == 0) dp.fy2o[c] = dvy[f];
+        if (DMODE == 0 && EPI == 0) dp.fy2o[c] = dvy[f];
         if (DMODE == 1) v = v + dvy[f];
         if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - sj] + dp.mass[c]) * dvy[f];
-        fy[c] = v;
+        if (EPI == 0) fy[c] = v;
+        vyf[f] = v;
+      }
+    }
+  }
+  if (EPI > 0) {
+    // epilogue: put the face fluxes of the tile (both sides of every cell) into LDS, then update the cells
+    constexpr int AXP = TI + 2, AYP = TI + 1;
+    double* ax = &L.syin[0][0];          // [TJ][AXP]
+    double* ay = ax + TJ * AXP;          // [TJ + 1][AYP]
+    double* ax2 = ay + (TJ + 1) * AYP;   // damping fluxes (EPI == 2)
+    double* ay2 = ax2 + TJ * AXP;
+    static_assert(2 * (TJ * AXP + (TJ + 1) * AYP) <= FvLds::kSweep + (FvLds::kNeed > FvLds::kSweep ? FvLds::kNeed - FvLds::kSweep : 1),
+                  "epilogue scratch");
+    __syncthreads();
+    if (tid < TJ * GX) {
+      const int jj = tid / GX, grp = tid - jj * GX;
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        if (grp * RF + f <= TI) {
+          ax[jj * AXP + grp * RF + f] = vxf[f];
+          if (EPI == 2) ax2[jj * AXP + grp * RF + f] = dvx[f];
+        }
+      }
+    }
+    if (tid < TI * GY) {
+      const int grp = tid / TI, ii = tid - grp * TI;
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        if (grp * RF + f <= TJ) {
+          ay[(grp * RF + f) * AYP + ii] = vyf[f];
+          if (EPI == 2) ay2[(grp * RF + f) * AYP + ii] = dvy[f];
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < TI * TJ; e += 256) {
+      const int jj = e / TI, ii = e - jj * TI;
+      const int gi = i0 + ii, gj = j0 + jj;
+      if (gi > g.ie || gj > g.je) continue;
+      const long c2 = IDX2(g, gi, gj);
+      const long c = kb + c2;
+      const double ra = m.rarea[c2];
+      const double qv = sq[jj + 3][ii + 3];
+      dp.qout[c] = qv * dp.amass[c] + (ax[jj * AXP + ii] - ax[jj * AXP + ii + 1] + ay[jj * AYP + ii] - ay[(jj + 1) * AYP + ii]) * ra;
+      if (EPI == 2) {
+        double hs = 0.0;
+        if (dp.damp_w_k[k] > 1e-5) {
+          const double dd8 = dp.ke_bg_k[k] * fabs(dp.dt);
+          const double d = (ax2[jj * AXP + ii] - ax2[jj * AXP + ii + 1] + ay2[jj * AYP + ii] - ay2[(jj + 1) * AYP + ii]) * ra;
+          dp.dw[c] = d;
+          hs = dd8 - d * (qv + 0.5 * d);
+        }
+        dp.heat_s[c] = hs;
+        dp.diss_est[c] = hs;
       }
     }
   }
 }
 
-template <int MORD, int DMODE>
+template <int MORD, int DMODE, int EPI>
 __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
                                                 const double* __restrict__ crx, const double* __restrict__ cry,
                                                 const double* __restrict__ xfx, const double* __restrict__ yfx,
@@ -287,38 +335,55 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
   const int i0 = g.is + blockIdx.x * TI, j0 = g.js + blockIdx.y * TJ;
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
-  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else if (ex) fvtp2d_tile<MORD, true, false, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else if (ey) fvtp2d_tile<MORD, false, true, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else fvtp2d_tile<MORD, false, false, DMODE>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else fvtp2d_tile<MORD, false, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
 }
+
+#define FV_LAUNCH(D, E) \
+  hipLaunchKernelGGL((k_fvtp2d<MORD, D, E>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp)
 
 template <int MORD>
-static void launch_mode(int dmode, dim3 grid, hipStream_t st, const Geo& g, const Met& m, const double* q, const double* crx,
-                        const double* cry, const double* xfx, const double* yfx, double* fx, double* fy, const double* xu,
-                        const double* yu, const FvDamp& dp) {
+static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g, const Met& m, const double* q,
+                       const double* crx, const double* cry, const double* xfx, const double* yfx, double* fx, double* fy,
+                       const double* xu, const double* yu, const FvDamp& dp) {
   const dim3 block(256);
-  switch (dmode) {
-    case 0: hipLaunchKernelGGL((k_fvtp2d<MORD, 0>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
-    case 1: hipLaunchKernelGGL((k_fvtp2d<MORD, 1>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
-    case 2: hipLaunchKernelGGL((k_fvtp2d<MORD, 2>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
-    default: hipLaunchKernelGGL((k_fvtp2d<MORD, -1>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp); break;
+  if (epi == 0) {
+    switch (dmode) {
+      case 0: FV_LAUNCH(0, 0); break;
+      case 1: FV_LAUNCH(1, 0); break;
+      case 2: FV_LAUNCH(2, 0); break;
+      default: FV_LAUNCH(-1, 0); break;
+    }
+  } else if (epi == 1) {
+    switch (dmode) {
+      case 1: FV_LAUNCH(1, 1); break;
+      case 2: FV_LAUNCH(2, 1); break;
+      case -1: FV_LAUNCH(-1, 1); break;
+      default: return PACE_ERR_UNSUPPORTED;
+    }
+  } else {
+    if (dmode != 0) return PACE_ERR_UNSUPPORTED;
+    FV_LAUNCH(0, 2);
   }
+  return PACE_OK;
 }
 
-// dmode -1: transport only.  Otherwise the del-n damping of q is fused (see FvDamp).
-int launch_fvtp2d_damped(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
-                         const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf, const double* ymf,
-                         int hord, int nlev, int dmode, const double* damp_k, const double* nord_k, int nmax,
-                         int mass_given, const double* mass, double* fx2o, double* fy2o, hipStream_t st) {
-  if (dmode >= 0 && nmax > 2) return PACE_ERR_UNSUPPORTED;
+// The general launcher.  dmode -1: transport only; otherwise the del-n damping of q is fused (see FvDamp).  epi 0:
+// fluxes are written; 1 / 2: the flux-form update of the cell (and heat_diss) is written instead.
+int launch_transport(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
+                     const double* yfx, double* fx, double* fy, const double* xmf, const double* ymf, int hord, int nlev,
+                     int dmode, int epi, const FvDamp& dp, hipStream_t st) {
+  if (dmode >= 0 && dp.nmax > 2) return PACE_ERR_UNSUPPORTED;
   const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
   const double* xu = xmf ? xmf : xfx;
   const double* yu = ymf ? ymf : yfx;
-  const FvDamp dp{damp_k, nord_k, mass, fx2o, fy2o, nmax, mass_given};
-  if (hord == 5) launch_mode<5>(dmode, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
-  else if (hord == 6) launch_mode<6>(dmode, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+  int rc;
+  if (hord == 5) rc = launch_mode<5>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+  else if (hord == 6) rc = launch_mode<6>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
   else return PACE_ERR_UNSUPPORTED;
+  if (rc) return rc;
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
@@ -326,6 +391,6 @@ int launch_fvtp2d_damped(const Geo& g, const Met& m, const double* q, const doub
 int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
                   const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
                   const double* ymf, int hord, int nlev, hipStream_t st) {
-  return launch_fvtp2d_damped(g, m, q, crx, cry, xfx, yfx, fx, fy, xmf, ymf, hord, nlev, -1, nullptr, nullptr, 0, 0, nullptr,
-                              nullptr, nullptr, st);
+  FvDamp dp{};
+  return launch_transport(g, m, q, crx, cry, xfx, yfx, fx, fy, xmf, ymf, hord, nlev, -1, 0, dp, st);
 }

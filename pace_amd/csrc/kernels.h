@@ -7,10 +7,31 @@ int launch_fxadv(const Geo& g, const Met& m, const double* uc, const double* vc,
 int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
                   const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
                   const double* ymf, int hord, int nlev, hipStream_t st);
-int launch_fvtp2d_damped(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
-                         const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf, const double* ymf,
-                         int hord, int nlev, int dmode, const double* damp_k, const double* nord_k, int nmax,
-                         int mass_given, const double* mass, double* fx2o, double* fy2o, hipStream_t st);
+// Optional fused del-n damping of the same scalar (FiniteVolumeTransport calls DelnFlux on q right after the transport,
+// fvtp2d.py:338-345; d_sw also needs DelnFluxNoSG(w) next to the transport of w).  DMODE -1: none; 0: damping fluxes
+// written to fx2o / fy2o; 1: added to fx / fy; 2: added mass-weighted (delnflux.py:318-328).
+struct FvDamp {
+  const double* damp_k;
+  const double* nord_k;
+  const double* mass;
+  double* fx2o;
+  double* fy2o;
+  int nmax, mass_given;
+  // epilogue (EPI > 0): qout = q * amass + flux_increment(fx, fy) (apply_fluxes, d_sw.py:122-145) is written instead of
+  // the fluxes; EPI == 2 additionally turns the damping fluxes into dw / heat_s / diss_est (heat_diss, d_sw.py:63-103)
+  double* qout;
+  const double* amass;
+  double* dw;
+  double* heat_s;
+  double* diss_est;
+  const double* damp_w_k;
+  const double* ke_bg_k;
+  double dt;
+};
+
+int launch_transport(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
+                     const double* yfx, double* fx, double* fy, const double* xmf, const double* ymf, int hord, int nlev,
+                     int dmode, int epi, const FvDamp& dp, hipStream_t st);
 int launch_delnflux(const Geo& g, const Met& m, int mode, const double* q, double* fx, double* fy,
                     const double* mass, const double* damp_k, const double* nord_k, int nmax, int mass_given,
                     int nlev, hipStream_t st);
