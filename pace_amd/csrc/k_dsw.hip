@@ -331,20 +331,58 @@ struct DivIter {
   }
 };
 
+// Box launch helpers: a 64 x 4 thread block per (i, j) patch of the box [ib, ie_] x [jb, je_]; used to split a
+// stencil into a straight-line INTERIOR launch (no edge / corner logic at all, ~95 % of the points) and thin frame
+// launches that run the general code.
+#define BOX_IJK(ib, ie_, jb, je_)                       \
+  const int i = (ib) + blockIdx.x * 64 + threadIdx.x;   \
+  const int j = (jb) + blockIdx.y * 4 + threadIdx.y;    \
+  const int k = (int)blockIdx.z;                        \
+  if (i > (ie_) || j > (je_)) return;
+static inline dim3 box_grid(int ib, int ie_, int jb, int je_, int nlev) {
+  return dim3((unsigned)((ie_ - ib + 64) / 64), (unsigned)((je_ - jb + 4) / 4), (unsigned)nlev);
+}
+
+template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
-k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int nt, int fill,
-               int adjust) {
-  PLANE_IJK(g);
+k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int fill, int adjust, int ib,
+               int ie_, int jb, int je_) {
+  BOX_IJK(ib, ie_, jb, je_);
   const int kk = k + k0;
-  if (i < g.is - nt || i > g.ie + nt + 1 || j < g.js - nt || j > g.je + nt + 1) return;
-  DivIter it{g, m, din + (long)kk * g.sk, fill != 0};
-  const double ucm = it.uc(i, j - 1), uc0 = it.uc(i, j), vcm = it.vc(i - 1, j), vc0 = it.vc(i, j);
-  double d = ucm - uc0 + vcm - vc0;  // redo_divg_d :212-240
-  const bool ic = (i == g.is || i == g.ie + 1);
-  if (ic && j == g.js) d = d - ucm;
-  if (ic && j == g.je + 1) d = d + uc0;
-  if (adjust) d = d * m.rarea_c[IDX2(g, i, j)];
-  dout[IDX3(g, i, j, kk)] = d;
+  const long c2 = IDX2(g, i, j);
+  const long c = c2 + (long)kk * g.sk;
+  double d;
+  if (INTERIOR) {
+    // columns is+1 .. ie: no operand lies in a corner region and no corner adjustment applies
+    const int sj = g.sj;
+    const double d0 = din[c];
+    const double ucm = (d0 - din[c - sj]) * m.divg_v[c2 - sj];
+    const double uc0 = (din[c + sj] - d0) * m.divg_v[c2];
+    const double vcm = (d0 - din[c - 1]) * m.divg_u[c2 - 1];
+    const double vc0 = (din[c + 1] - d0) * m.divg_u[c2];
+    d = ucm - uc0 + vcm - vc0;
+  } else {
+    DivIter it{g, m, din + (long)kk * g.sk, fill != 0};
+    const double ucm = it.uc(i, j - 1), uc0 = it.uc(i, j), vcm = it.vc(i - 1, j), vc0 = it.vc(i, j);
+    d = ucm - uc0 + vcm - vc0;  // redo_divg_d :212-240
+    const bool ic = (i == g.is || i == g.ie + 1);
+    if (ic && j == g.js) d = d - ucm;
+    if (ic && j == g.je + 1) d = d + uc0;
+  }
+  if (adjust) d = d * m.rarea_c[c2];
+  dout[c] = d;
+}
+
+static void launch_divdamp_iter(const Geo& g, const Met& m, const double* din, double* dout, int k0, int nlev, int nt, int fill,
+                                hipStream_t st) {
+  const dim3 block(64, 4);
+  const int jb = g.js - nt, je_ = g.je + nt + 1;
+  hipLaunchKernelGGL(k_divdamp_iter<true>, box_grid(g.is + 1, g.ie, jb, je_, nlev), block, 0, st, g, m, din, dout, k0, fill, 1,
+                     g.is + 1, g.ie, jb, je_);
+  hipLaunchKernelGGL(k_divdamp_iter<false>, box_grid(g.is - nt, g.is, jb, je_, nlev), block, 0, st, g, m, din, dout, k0, fill, 1,
+                     g.is - nt, g.is, jb, je_);
+  hipLaunchKernelGGL(k_divdamp_iter<false>, box_grid(g.ie + 1, g.ie + nt + 1, jb, je_, nlev), block, 0, st, g, m, din, dout, k0,
+                     fill, 1, g.ie + 1, g.ie + nt + 1, jb, je_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -434,6 +472,24 @@ struct A2B {
     }
     return (ec[0] + ec[1] + ec[2]) * (1.0 / 3.0);
   }
+  // is+2 <= i <= ie-1 and js+2 <= j <= je-1: every qx / qy involved is the plain 4-point mean (a2b_ord4.py:329-506)
+  __device__ __forceinline__ double point_interior(int i, int j) const {
+    const double a1 = 9.0 / 16.0, a2 = -1.0 / 16.0, b1 = 7.0 / 12.0, b2 = -1.0 / 12.0;
+    double v[4][4];  // v[b][a] = Q(i-2+a, j-2+b)
+    const double* p = q + IDX2(g, i - 2, j - 2);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) v[b][a] = p[a + (long)b * g.sj];
+    double qx_[4], qy_[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) qx_[b] = b2 * (v[b][0] + v[b][3]) + b1 * (v[b][1] + v[b][2]);  // qx(i, j-2+b)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) qy_[a] = b2 * (v[0][a] + v[3][a]) + b1 * (v[1][a] + v[2][a]);  // qy(i-2+a, j)
+    const double qxx = a2 * (qx_[0] + qx_[3]) + a1 * (qx_[1] + qx_[2]);
+    const double qyy = a2 * (qy_[0] + qy_[3]) + a1 * (qy_[1] + qy_[2]);
+    return 0.5 * (qxx + qyy);
+  }
   __device__ double point(int i, int j) const {  // value of qout at B-grid point (i, j), is <= i,j <= ie+1
     const double a1 = 9.0 / 16.0, a2 = -1.0 / 16.0, c1 = 2.0 / 3.0, c2 = -1.0 / 6.0;
     const bool iw = (i == g.is), ie_ = (i == g.ie + 1), js_ = (j == g.js), jn = (j == g.je + 1);
@@ -466,13 +522,22 @@ struct A2B {
   }
 };
 
-__global__ void __launch_bounds__(256) k_a2b_ord4(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, int k0) {
-  PLANE_IJK(g);
+template <bool INTERIOR>
+__global__ void __launch_bounds__(256)
+k_a2b_ord4(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, int k0, int ib, int ie_, int jb, int je_) {
+  BOX_IJK(ib, ie_, jb, je_);
   const int kk = k + k0;
-  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   A2B a{g, m, qin + (long)kk * g.sk};
-  qout[IDX3(g, i, j, kk)] = a.point(i, j);
+  qout[IDX3(g, i, j, kk)] = INTERIOR ? a.point_interior(i, j) : a.point(i, j);
 }
+
+// the interior box and the four frame strips of the B-grid domain is .. ie+1
+#define A2B_BOXES(LAUNCH)                                    \
+  LAUNCH(true, g.is + 2, g.ie - 1, g.js + 2, g.je - 1);      \
+  LAUNCH(false, g.is, g.is + 1, g.js, g.je + 1);             \
+  LAUNCH(false, g.ie, g.ie + 1, g.js, g.je + 1);             \
+  LAUNCH(false, g.is + 2, g.ie - 1, g.js, g.js + 1);         \
+  LAUNCH(false, g.is + 2, g.ie - 1, g.je, g.je + 1)
 
 __global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __restrict__ src, double* __restrict__ dst, int k0, int i1, int j1) {
   PLANE_IJK(g);
@@ -483,14 +548,14 @@ __global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __rest
 }
 
 // tail of DivergenceDamping for nord > 0 levels: a2b_ord4(wk) -> smagorinsky -> damping
+template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
 k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* __restrict__ delpc_src,
                      double* __restrict__ delpc, const double* __restrict__ divg_d, double* __restrict__ vort_b,
                      double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt,
-                     int k0) {
-  PLANE_IJK(g);
+                     int k0, int ib, int ie_, int jb, int je_) {
+  BOX_IJK(ib, ie_, jb, je_);
   const int kk = k + k0;
-  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, kk);
   const double dpc = delpc_src[c];  // copy_computeplus :578
   delpc[c] = dpc;
@@ -499,7 +564,7 @@ k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* 
     vb = 0.0;
   } else {
     A2B a{g, m, wk + (long)kk * g.sk};
-    const double qb = a.point(i, j);
+    const double qb = INTERIOR ? a.point_interior(i, j) : a.point(i, j);
     vb = absdt * sqrt(dpc * dpc + qb * qb);
   }
   const double damp = m.da_min_c * fmax(d2_bg[kk], fmin(0.2, dddmp * fabs(vb)));
@@ -588,9 +653,17 @@ k_update_uv(Geo g, double* __restrict__ u, double* __restrict__ v, const double*
 
 // =================================================================================================
 int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k0, int k1, int replace, hipStream_t st) {
-  const dim3 grid = plane_grid(g, k1 - k0), block(256);
-  hipLaunchKernelGGL(k_a2b_ord4, grid, block, 0, st, g, m, qin, qout, k0);
-  if (replace) hipLaunchKernelGGL(k_copy_window, grid, block, 0, st, g, qout, qin, k0, g.ie + 1, g.je + 1);
+  const dim3 bblock(64, 4);
+  const int nlev = k1 - k0;
+#define A2B_LAUNCH(INT, ib, ie_, jb, je_)                                                                                  \
+  hipLaunchKernelGGL(k_a2b_ord4<INT>, box_grid(ib, ie_, jb, je_, nlev), bblock, 0, st, g, m, qin, qout, k0, ib, ie_, jb, je_)
+  if (g.n < 8) {
+    A2B_LAUNCH(false, g.is, g.ie + 1, g.js, g.je + 1);
+  } else {
+    A2B_BOXES(A2B_LAUNCH);
+  }
+#undef A2B_LAUNCH
+  if (replace) hipLaunchKernelGGL(k_copy_window, plane_grid(g, nlev), dim3(256), 0, st, g, qout, qin, k0, g.ie + 1, g.je + 1);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
@@ -717,19 +790,26 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   {
     const int nhigh = nk - kstart;
-    const dim3 gh = plane_grid(g, nhigh);
     const double* src = divgd;
     double* bufs[2] = {W.da, W.db};
     for (int n = 0; n < nonzero_nord; ++n) {
       const int nt = nonzero_nord - (n + 1);
       const int fill = (n + 1 != nonzero_nord) ? 1 : 0;
       double* dst = bufs[n & 1];
-      hipLaunchKernelGGL(k_divdamp_iter, gh, block, 0, st, g, m, src, dst, kstart, nt, fill, 1);
+      launch_divdamp_iter(g, m, src, dst, kstart, nhigh, nt, fill, st);
       src = dst;
     }
     const double dd8 = pow(m.da_min_c * cfg->d4_bg, (double)(nonzero_nord + 1));
-    hipLaunchKernelGGL(k_divdamp_high_final, gh, block, 0, st, g, m, W.wk, divgd, delpc, src, W.vort_b, W.ke, d_d2, cfg->dddmp,
-                       dd8, fabs(dt), kstart);
+    const dim3 bblock(64, 4);
+#define DDF_LAUNCH(INT, ib, ie_, jb, je_)                                                                                     \
+  hipLaunchKernelGGL(k_divdamp_high_final<INT>, box_grid(ib, ie_, jb, je_, nhigh), bblock, 0, st, g, m, W.wk, divgd, delpc, src, \
+                     W.vort_b, W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, ib, ie_, jb, je_)
+    if (g.n < 8) {
+      DDF_LAUNCH(false, g.is, g.ie + 1, g.js, g.je + 1);
+    } else {
+      A2B_BOXES(DDF_LAUNCH);
+    }
+#undef DDF_LAUNCH
   }
   // vorticity transport
   if ((rc = launch_fvtp2d(g, m, W.abs_vort, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_vt, nk, st))) return rc;
