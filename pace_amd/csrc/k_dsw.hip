@@ -342,12 +342,38 @@ struct DivIter {
 static inline dim3 box_grid(int ib, int ie_, int jb, int je_, int nlev) {
   return dim3((unsigned)((ie_ - ib + 64) / 64), (unsigned)((je_ - jb + 4) / 4), (unsigned)nlev);
 }
+// Frame strips are a few points wide: their points are flattened over the 256 threads of a block so that lanes stay
+// busy whatever the strip's orientation (same 64 x 4 block shape, different index map).
+#define STRIP_IJK(ib, ie_, jb, je_)                                                \
+  const int w__ = (ie_) - (ib) + 1;                                                \
+  const int p__ = (int)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x; \
+  const int j = (jb) + p__ / w__;                                                  \
+  const int i = (ib) + p__ % w__;                                                  \
+  const int k = (int)blockIdx.z;                                                   \
+  if (j > (je_)) return;
+static inline dim3 strip_grid(int ib, int ie_, int jb, int je_, int nlev) {
+  return dim3((unsigned)(((ie_ - ib + 1) * (je_ - jb + 1) + 255) / 256), 1, (unsigned)nlev);
+}
+#define REGION_IJK(INTERIOR, ib, ie_, jb, je_)                                                                            \
+  int i, j, k;                                                                                                            \
+  if (INTERIOR) {                                                                                                         \
+    i = (ib) + blockIdx.x * 64 + threadIdx.x; j = (jb) + blockIdx.y * 4 + threadIdx.y; k = (int)blockIdx.z;                \
+    if (i > (ie_) || j > (je_)) return;                                                                                   \
+  } else {                                                                                                                \
+    const int w__ = (ie_) - (ib) + 1;                                                                                     \
+    const int p__ = (int)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;                                     \
+    j = (jb) + p__ / w__; i = (ib) + p__ % w__; k = (int)blockIdx.z;                                                       \
+    if (j > (je_)) return;                                                                                                \
+  }
+static inline dim3 region_grid(bool interior, int ib, int ie_, int jb, int je_, int nlev) {
+  return interior ? box_grid(ib, ie_, jb, je_, nlev) : strip_grid(ib, ie_, jb, je_, nlev);
+}
 
 template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
 k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int fill, int adjust, int ib,
                int ie_, int jb, int je_) {
-  BOX_IJK(ib, ie_, jb, je_);
+  REGION_IJK(INTERIOR, ib, ie_, jb, je_);
   const int kk = k + k0;
   const long c2 = IDX2(g, i, j);
   const long c = c2 + (long)kk * g.sk;
@@ -379,9 +405,9 @@ static void launch_divdamp_iter(const Geo& g, const Met& m, const double* din, d
   const int jb = g.js - nt, je_ = g.je + nt + 1;
   hipLaunchKernelGGL(k_divdamp_iter<true>, box_grid(g.is + 1, g.ie, jb, je_, nlev), block, 0, st, g, m, din, dout, k0, fill, 1,
                      g.is + 1, g.ie, jb, je_);
-  hipLaunchKernelGGL(k_divdamp_iter<false>, box_grid(g.is - nt, g.is, jb, je_, nlev), block, 0, st, g, m, din, dout, k0, fill, 1,
+  hipLaunchKernelGGL(k_divdamp_iter<false>, strip_grid(g.is - nt, g.is, jb, je_, nlev), block, 0, st, g, m, din, dout, k0, fill, 1,
                      g.is - nt, g.is, jb, je_);
-  hipLaunchKernelGGL(k_divdamp_iter<false>, box_grid(g.ie + 1, g.ie + nt + 1, jb, je_, nlev), block, 0, st, g, m, din, dout, k0,
+  hipLaunchKernelGGL(k_divdamp_iter<false>, strip_grid(g.ie + 1, g.ie + nt + 1, jb, je_, nlev), block, 0, st, g, m, din, dout, k0,
                      fill, 1, g.ie + 1, g.ie + nt + 1, jb, je_);
 }
 
@@ -525,7 +551,7 @@ struct A2B {
 template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
 k_a2b_ord4(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, int k0, int ib, int ie_, int jb, int je_) {
-  BOX_IJK(ib, ie_, jb, je_);
+  REGION_IJK(INTERIOR, ib, ie_, jb, je_);
   const int kk = k + k0;
   A2B a{g, m, qin + (long)kk * g.sk};
   qout[IDX3(g, i, j, kk)] = INTERIOR ? a.point_interior(i, j) : a.point(i, j);
@@ -554,7 +580,7 @@ k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* 
                      double* __restrict__ delpc, const double* __restrict__ divg_d, double* __restrict__ vort_b,
                      double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt,
                      int k0, int ib, int ie_, int jb, int je_) {
-  BOX_IJK(ib, ie_, jb, je_);
+  REGION_IJK(INTERIOR, ib, ie_, jb, je_);
   const int kk = k + k0;
   const long c = IDX3(g, i, j, kk);
   const double dpc = delpc_src[c];  // copy_computeplus :578
@@ -656,7 +682,7 @@ int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k
   const dim3 bblock(64, 4);
   const int nlev = k1 - k0;
 #define A2B_LAUNCH(INT, ib, ie_, jb, je_)                                                                                  \
-  hipLaunchKernelGGL(k_a2b_ord4<INT>, box_grid(ib, ie_, jb, je_, nlev), bblock, 0, st, g, m, qin, qout, k0, ib, ie_, jb, je_)
+  hipLaunchKernelGGL(k_a2b_ord4<INT>, region_grid(INT, ib, ie_, jb, je_, nlev), bblock, 0, st, g, m, qin, qout, k0, ib, ie_, jb, je_)
   if (g.n < 8) {
     A2B_LAUNCH(false, g.is, g.ie + 1, g.js, g.je + 1);
   } else {
@@ -802,7 +828,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     const double dd8 = pow(m.da_min_c * cfg->d4_bg, (double)(nonzero_nord + 1));
     const dim3 bblock(64, 4);
 #define DDF_LAUNCH(INT, ib, ie_, jb, je_)                                                                                     \
-  hipLaunchKernelGGL(k_divdamp_high_final<INT>, box_grid(ib, ie_, jb, je_, nhigh), bblock, 0, st, g, m, W.wk, divgd, delpc, src, \
+  hipLaunchKernelGGL(k_divdamp_high_final<INT>, region_grid(INT, ib, ie_, jb, je_, nhigh), bblock, 0, st, g, m, W.wk, divgd, delpc, src, \
                      W.vort_b, W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, ib, ie_, jb, je_)
     if (g.n < 8) {
       DDF_LAUNCH(false, g.is, g.ie + 1, g.js, g.je + 1);
