@@ -331,54 +331,71 @@ struct DivIter {
   }
 };
 
-// Box launch helpers: a 64 x 4 thread block per (i, j) patch of the box [ib, ie_] x [jb, je_]; used to split a
-// stencil into a straight-line INTERIOR launch (no edge / corner logic at all, ~95 % of the points) and thin frame
-// launches that run the general code.
-#define BOX_IJK(ib, ie_, jb, je_)                       \
-  const int i = (ib) + blockIdx.x * 64 + threadIdx.x;   \
-  const int j = (jb) + blockIdx.y * 4 + threadIdx.y;    \
-  const int k = (int)blockIdx.z;                        \
-  if (i > (ie_) || j > (je_)) return;
-static inline dim3 box_grid(int ib, int ie_, int jb, int je_, int nlev) {
-  return dim3((unsigned)((ie_ - ib + 64) / 64), (unsigned)((je_ - jb + 4) / 4), (unsigned)nlev);
-}
-// Frame strips are a few points wide: their points are flattened over the 256 threads of a block so that lanes stay
-// busy whatever the strip's orientation (same 64 x 4 block shape, different index map).
-#define STRIP_IJK(ib, ie_, jb, je_)                                                \
-  const int w__ = (ie_) - (ib) + 1;                                                \
-  const int p__ = (int)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x; \
-  const int j = (jb) + p__ / w__;                                                  \
-  const int i = (ib) + p__ % w__;                                                  \
-  const int k = (int)blockIdx.z;                                                   \
-  if (j > (je_)) return;
-static inline dim3 strip_grid(int ib, int ie_, int jb, int je_, int nlev) {
-  return dim3((unsigned)(((ie_ - ib + 1) * (je_ - jb + 1) + 255) / 256), 1, (unsigned)nlev);
-}
-#define REGION_IJK(INTERIOR, ib, ie_, jb, je_)                                                                            \
-  int i, j, k;                                                                                                            \
-  if (INTERIOR) {                                                                                                         \
-    i = (ib) + blockIdx.x * 64 + threadIdx.x; j = (jb) + blockIdx.y * 4 + threadIdx.y; k = (int)blockIdx.z;                \
-    if (i > (ie_) || j > (je_)) return;                                                                                   \
-  } else {                                                                                                                \
-    const int w__ = (ie_) - (ib) + 1;                                                                                     \
-    const int p__ = (int)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;                                     \
-    j = (jb) + p__ / w__; i = (ib) + p__ % w__; k = (int)blockIdx.z;                                                       \
-    if (j > (je_)) return;                                                                                                \
+// Region launches.  A stencil with edge / corner logic is split into an INTERIOR box (straight-line code, ~95 % of
+// the points; 64 x 4 patches so rows stay coalesced) and up to four thin frame strips that run the general code (their
+// points are flattened over the 256 threads of a block so lanes stay busy whatever the strip's orientation) -- all in
+// ONE launch: blockIdx.x is split into per-region ranges, the branch on the region is block-uniform.
+#define MAX_REGIONS 5
+struct Regions {
+  int n;
+  int ib[MAX_REGIONS], ie[MAX_REGIONS], jb[MAX_REGIONS], je[MAX_REGIONS];
+  int first[MAX_REGIONS + 1];  // first block of each region; first[n] = total
+  int nbx0;                    // 64-wide patches per row of region 0
+};
+static inline void add_region(Regions& r, int ib, int ie, int jb, int je) {
+  if (ie < ib || je < jb) return;
+  const int q = r.n++;
+  r.ib[q] = ib; r.ie[q] = ie; r.jb[q] = jb; r.je[q] = je;
+  int nb;
+  if (q == 0) {
+    r.nbx0 = (ie - ib + 64) / 64;
+    nb = r.nbx0 * ((je - jb + 4) / 4);
+  } else {
+    nb = ((ie - ib + 1) * (je - jb + 1) + 255) / 256;
   }
-static inline dim3 region_grid(bool interior, int ib, int ie_, int jb, int je_, int nlev) {
-  return interior ? box_grid(ib, ie_, jb, je_, nlev) : strip_grid(ib, ie_, jb, je_, nlev);
+  r.first[q + 1] = r.first[q] + nb;
 }
+// region 0 = interior box [is+di, ie+1-di] x [js+dj, je+1-dj] of the B-grid domain is..ie+1, the rest = frame strips
+static inline Regions bgrid_regions(const Geo& g, int d) {
+  Regions r{};
+  add_region(r, g.is + d, g.ie + 1 - d, g.js + d, g.je + 1 - d);
+  add_region(r, g.is, g.is + d - 1, g.js, g.je + 1);
+  add_region(r, g.ie + 2 - d, g.ie + 1, g.js, g.je + 1);
+  add_region(r, g.is + d, g.ie + 1 - d, g.js, g.js + d - 1);
+  add_region(r, g.is + d, g.ie + 1 - d, g.je + 2 - d, g.je + 1);
+  return r;
+}
+// sets i, j, k and `interior`; returns from the kernel for padding threads
+#define REGION_POINT(R)                                                                        \
+  int reg__ = 0;                                                                               \
+  while (reg__ + 1 < (R).n && (int)blockIdx.x >= (R).first[reg__ + 1]) ++reg__;               \
+  const int b__ = (int)blockIdx.x - (R).first[reg__];                                          \
+  const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
+  const bool interior = reg__ == 0;                                                            \
+  int i, j;                                                                                    \
+  const int k = (int)blockIdx.z;                                                               \
+  if (interior) {                                                                              \
+    i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
+    j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
+    if (i > (R).ie[0] || j > (R).je[0]) return;                                                \
+  } else {                                                                                     \
+    const int w__ = (R).ie[reg__] - (R).ib[reg__] + 1;                                         \
+    const int p__ = b__ * 256 + t__;                                                           \
+    j = (R).jb[reg__] + p__ / w__;                                                             \
+    i = (R).ib[reg__] + p__ % w__;                                                             \
+    if (j > (R).je[reg__]) return;                                                             \
+  }
+static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsigned)r.first[r.n], 1, (unsigned)nlev); }
 
-template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
-k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int fill, int adjust, int ib,
-               int ie_, int jb, int je_) {
-  REGION_IJK(INTERIOR, ib, ie_, jb, je_);
+k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int fill, int adjust,
+               Regions R) {
+  REGION_POINT(R);
   const int kk = k + k0;
   const long c2 = IDX2(g, i, j);
   const long c = c2 + (long)kk * g.sk;
   double d;
-  if (INTERIOR) {
+  if (interior) {
     // columns is+1 .. ie: no operand lies in a corner region and no corner adjustment applies
     const int sj = g.sj;
     const double d0 = din[c];
@@ -401,14 +418,12 @@ k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict_
 
 static void launch_divdamp_iter(const Geo& g, const Met& m, const double* din, double* dout, int k0, int nlev, int nt, int fill,
                                 hipStream_t st) {
-  const dim3 block(64, 4);
   const int jb = g.js - nt, je_ = g.je + nt + 1;
-  hipLaunchKernelGGL(k_divdamp_iter<true>, box_grid(g.is + 1, g.ie, jb, je_, nlev), block, 0, st, g, m, din, dout, k0, fill, 1,
-                     g.is + 1, g.ie, jb, je_);
-  hipLaunchKernelGGL(k_divdamp_iter<false>, strip_grid(g.is - nt, g.is, jb, je_, nlev), block, 0, st, g, m, din, dout, k0, fill, 1,
-                     g.is - nt, g.is, jb, je_);
-  hipLaunchKernelGGL(k_divdamp_iter<false>, strip_grid(g.ie + 1, g.ie + nt + 1, jb, je_, nlev), block, 0, st, g, m, din, dout, k0,
-                     fill, 1, g.ie + 1, g.ie + nt + 1, jb, je_);
+  Regions r{};
+  add_region(r, g.is + 1, g.ie, jb, je_);
+  add_region(r, g.is - nt, g.is, jb, je_);
+  add_region(r, g.ie + 1, g.ie + nt + 1, jb, je_);
+  hipLaunchKernelGGL(k_divdamp_iter, regions_grid(r, nlev), dim3(64, 4), 0, st, g, m, din, dout, k0, fill, 1, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,22 +563,13 @@ struct A2B {
   }
 };
 
-template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
-k_a2b_ord4(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, int k0, int ib, int ie_, int jb, int je_) {
-  REGION_IJK(INTERIOR, ib, ie_, jb, je_);
+k_a2b_ord4(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, int k0, Regions R) {
+  REGION_POINT(R);
   const int kk = k + k0;
   A2B a{g, m, qin + (long)kk * g.sk};
-  qout[IDX3(g, i, j, kk)] = INTERIOR ? a.point_interior(i, j) : a.point(i, j);
+  qout[IDX3(g, i, j, kk)] = interior ? a.point_interior(i, j) : a.point(i, j);
 }
-
-// the interior box and the four frame strips of the B-grid domain is .. ie+1
-#define A2B_BOXES(LAUNCH)                                    \
-  LAUNCH(true, g.is + 2, g.ie - 1, g.js + 2, g.je - 1);      \
-  LAUNCH(false, g.is, g.is + 1, g.js, g.je + 1);             \
-  LAUNCH(false, g.ie, g.ie + 1, g.js, g.je + 1);             \
-  LAUNCH(false, g.is + 2, g.ie - 1, g.js, g.js + 1);         \
-  LAUNCH(false, g.is + 2, g.ie - 1, g.je, g.je + 1)
 
 __global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __restrict__ src, double* __restrict__ dst, int k0, int i1, int j1) {
   PLANE_IJK(g);
@@ -574,13 +580,12 @@ __global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __rest
 }
 
 // tail of DivergenceDamping for nord > 0 levels: a2b_ord4(wk) -> smagorinsky -> damping
-template <bool INTERIOR>
 __global__ void __launch_bounds__(256)
 k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* __restrict__ delpc_src,
                      double* __restrict__ delpc, const double* __restrict__ divg_d, double* __restrict__ vort_b,
                      double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt,
-                     int k0, int ib, int ie_, int jb, int je_) {
-  REGION_IJK(INTERIOR, ib, ie_, jb, je_);
+                     int k0, Regions R) {
+  REGION_POINT(R);
   const int kk = k + k0;
   const long c = IDX3(g, i, j, kk);
   const double dpc = delpc_src[c];  // copy_computeplus :578
@@ -590,7 +595,7 @@ k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* 
     vb = 0.0;
   } else {
     A2B a{g, m, wk + (long)kk * g.sk};
-    const double qb = INTERIOR ? a.point_interior(i, j) : a.point(i, j);
+    const double qb = interior ? a.point_interior(i, j) : a.point(i, j);
     vb = absdt * sqrt(dpc * dpc + qb * qb);
   }
   const double damp = m.da_min_c * fmax(d2_bg[kk], fmin(0.2, dddmp * fabs(vb)));
@@ -678,17 +683,18 @@ k_update_uv(Geo g, double* __restrict__ u, double* __restrict__ v, const double*
 }
 
 // =================================================================================================
+static Regions a2b_regions(const Geo& g) {
+  if (g.n >= 8) return bgrid_regions(g, 2);
+  Regions r{};  // tiny tiles: no interior; one (empty-interior) strip covering everything
+  r.n = 1; r.ib[0] = 0; r.ie[0] = -1; r.jb[0] = 0; r.je[0] = -1; r.nbx0 = 1; r.first[1] = 0;
+  add_region(r, g.is, g.ie + 1, g.js, g.je + 1);
+  return r;
+}
+
 int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k0, int k1, int replace, hipStream_t st) {
-  const dim3 bblock(64, 4);
   const int nlev = k1 - k0;
-#define A2B_LAUNCH(INT, ib, ie_, jb, je_)                                                                                  \
-  hipLaunchKernelGGL(k_a2b_ord4<INT>, region_grid(INT, ib, ie_, jb, je_, nlev), bblock, 0, st, g, m, qin, qout, k0, ib, ie_, jb, je_)
-  if (g.n < 8) {
-    A2B_LAUNCH(false, g.is, g.ie + 1, g.js, g.je + 1);
-  } else {
-    A2B_BOXES(A2B_LAUNCH);
-  }
-#undef A2B_LAUNCH
+  const Regions r = a2b_regions(g);
+  hipLaunchKernelGGL(k_a2b_ord4, regions_grid(r, nlev), dim3(64, 4), 0, st, g, m, qin, qout, k0, r);
   if (replace) hipLaunchKernelGGL(k_copy_window, plane_grid(g, nlev), dim3(256), 0, st, g, qout, qin, k0, g.ie + 1, g.je + 1);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
@@ -826,16 +832,9 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
       src = dst;
     }
     const double dd8 = pow(m.da_min_c * cfg->d4_bg, (double)(nonzero_nord + 1));
-    const dim3 bblock(64, 4);
-#define DDF_LAUNCH(INT, ib, ie_, jb, je_)                                                                                     \
-  hipLaunchKernelGGL(k_divdamp_high_final<INT>, region_grid(INT, ib, ie_, jb, je_, nhigh), bblock, 0, st, g, m, W.wk, divgd, delpc, src, \
-                     W.vort_b, W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, ib, ie_, jb, je_)
-    if (g.n < 8) {
-      DDF_LAUNCH(false, g.is, g.ie + 1, g.js, g.je + 1);
-    } else {
-      A2B_BOXES(DDF_LAUNCH);
-    }
-#undef DDF_LAUNCH
+    const Regions r = a2b_regions(g);
+    hipLaunchKernelGGL(k_divdamp_high_final, regions_grid(r, nhigh), dim3(64, 4), 0, st, g, m, W.wk, divgd, delpc, src, W.vort_b,
+                       W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, r);
   }
   // vorticity transport
   if ((rc = launch_fvtp2d(g, m, W.abs_vort, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_vt, nk, st))) return rc;
