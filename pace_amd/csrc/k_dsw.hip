@@ -14,6 +14,63 @@
 
 #define DCON_THRESHOLD 1e-5
 
+// Region launches.  A stencil with edge / corner logic is split into an INTERIOR box (straight-line code, ~95 % of
+// the points; 64 x 4 patches so rows stay coalesced) and up to four thin frame strips that run the general code (their
+// points are flattened over the 256 threads of a block so lanes stay busy whatever the strip's orientation) -- all in
+// ONE launch: blockIdx.x is split into per-region ranges, the branch on the region is block-uniform.
+#define MAX_REGIONS 5
+struct Regions {
+  int n;
+  int ib[MAX_REGIONS], ie[MAX_REGIONS], jb[MAX_REGIONS], je[MAX_REGIONS];
+  int first[MAX_REGIONS + 1];  // first block of each region; first[n] = total
+  int nbx0;                    // 64-wide patches per row of region 0
+};
+static inline void add_region(Regions& r, int ib, int ie, int jb, int je) {
+  if (ie < ib || je < jb) return;
+  const int q = r.n++;
+  r.ib[q] = ib; r.ie[q] = ie; r.jb[q] = jb; r.je[q] = je;
+  int nb;
+  if (q == 0) {
+    r.nbx0 = (ie - ib + 64) / 64;
+    nb = r.nbx0 * ((je - jb + 4) / 4);
+  } else {
+    nb = ((ie - ib + 1) * (je - jb + 1) + 255) / 256;
+  }
+  r.first[q + 1] = r.first[q] + nb;
+}
+// region 0 = interior box [is+di, ie+1-di] x [js+dj, je+1-dj] of the B-grid domain is..ie+1, the rest = frame strips
+static inline Regions bgrid_regions(const Geo& g, int d) {
+  Regions r{};
+  add_region(r, g.is + d, g.ie + 1 - d, g.js + d, g.je + 1 - d);
+  add_region(r, g.is, g.is + d - 1, g.js, g.je + 1);
+  add_region(r, g.ie + 2 - d, g.ie + 1, g.js, g.je + 1);
+  add_region(r, g.is + d, g.ie + 1 - d, g.js, g.js + d - 1);
+  add_region(r, g.is + d, g.ie + 1 - d, g.je + 2 - d, g.je + 1);
+  return r;
+}
+// sets i, j, k and `interior`; returns from the kernel for padding threads
+#define REGION_POINT(R)                                                                        \
+  int reg__ = 0;                                                                               \
+  while (reg__ + 1 < (R).n && (int)blockIdx.x >= (R).first[reg__ + 1]) ++reg__;               \
+  const int b__ = (int)blockIdx.x - (R).first[reg__];                                          \
+  const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
+  const bool interior = reg__ == 0;                                                            \
+  int i, j;                                                                                    \
+  const int k = (int)blockIdx.z;                                                               \
+  if (interior) {                                                                              \
+    i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
+    j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
+    if (i > (R).ie[0] || j > (R).je[0]) return;                                                \
+  } else {                                                                                     \
+    const int w__ = (R).ie[reg__] - (R).ib[reg__] + 1;                                         \
+    const int p__ = b__ * 256 + t__;                                                           \
+    j = (R).jb[reg__] + p__ / w__;                                                             \
+    i = (R).ib[reg__] + p__ % w__;                                                             \
+    if (j > (R).je[reg__]) return;                                                             \
+  }
+static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsigned)r.first[r.n], 1, (unsigned)nlev); }
+
+
 // ------------------------------------------------------------------------------------------------
 // flux_capacitor (d_sw.py:33-60) + heat_diss (:63-103)
 // ------------------------------------------------------------------------------------------------
@@ -112,12 +169,12 @@ k_pt_delp_w_qcon(Geo g, Met m, double* __restrict__ pt, double* __restrict__ del
 // ------------------------------------------------------------------------------------------------
 // compute_kinetic_energy (d_sw.py:204-298) with xtp_u / ytp_v (xtp_u.py:9-91, ytp_v.py:9-91), ord < 8
 // ------------------------------------------------------------------------------------------------
-template <int MORD, class DX>
+template <int MORD, bool EDGE = true, class DX>
 __device__ __forceinline__ double wind_flux6(const double* q6, double csign, double cfl, int pos, int s, int e,
                                              DX dxa, bool zero_m, bool zero_0) {
-  const double al_m = ppm_al(q6, 2, pos - 1, s, e, dxa);
-  const double al_0 = ppm_al(q6, 3, pos, s, e, dxa);
-  const double al_p = ppm_al(q6, 4, pos + 1, s, e, dxa);
+  const double al_m = EDGE ? ppm_al(q6, 2, pos - 1, s, e, dxa) : ppm_al_interior(q6, 2);
+  const double al_0 = EDGE ? ppm_al(q6, 3, pos, s, e, dxa) : ppm_al_interior(q6, 3);
+  const double al_p = EDGE ? ppm_al(q6, 4, pos + 1, s, e, dxa) : ppm_al_interior(q6, 4);
   const double qm = q6[2], q0 = q6[3];
   double bl_m = al_m - qm, br_m = al_0 - qm;
   double bl_0 = al_0 - q0, br_0 = al_p - q0;
@@ -141,12 +198,29 @@ template <int MORD>
 __global__ void __launch_bounds__(256)
 k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __restrict__ vc,
                  const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ ut,
-                 const double* __restrict__ vt, double* __restrict__ ke, double dt) {
-  PLANE_IJK(g);
-  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+                 const double* __restrict__ vt, double* __restrict__ ke, double dt, Regions R) {
+  REGION_POINT(R);
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;
+  if (interior) {
+    // is+3 <= i <= ie-2 and the same in j: no edge wind, no one-sided PPM interface, no zeroed reconstruction
+    const double ub_cov = 0.5 * (uc[c - sj] + uc[c]);
+    const double vb_cov = 0.5 * (vc[c - 1] + vc[c]);
+    const double ub = (ub_cov - vb_cov * m.cosa[c2]) * m.rsina[c2];
+    const double vb = (vb_cov - ub_cov * m.cosa[c2]) * m.rsina[c2];
+    double q6[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) q6[t] = v[c + (long)(t - 3) * sj];
+    double cfl = (vb > 0.0) ? vb * dt * m.rdy[c2 - sj] : vb * dt * m.rdy[c2];
+    const double adv_v = wind_flux6<MORD, false>(q6, vb, cfl, j, g.js, g.je, [](int) { return 0.0; }, false, false);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) q6[t] = u[c + (t - 3)];
+    cfl = (ub > 0.0) ? ub * dt * m.rdx[c2 - 1] : ub * dt * m.rdx[c2];
+    const double adv_u = wind_flux6<MORD, false>(q6, ub, cfl, i, g.is, g.ie, [](int) { return 0.0; }, false, false);
+    ke[c] = 0.5 * dt * (ub * adv_u + vb * adv_v);
+    return;
+  }
   const bool jedge = (j == g.js || j == g.je + 1), iedge = (i == g.is || i == g.ie + 1);
   double kev;
   if (iedge && jedge) {
@@ -330,62 +404,6 @@ struct DivIter {
     return uc_raw(i, j);
   }
 };
-
-// Region launches.  A stencil with edge / corner logic is split into an INTERIOR box (straight-line code, ~95 % of
-// the points; 64 x 4 patches so rows stay coalesced) and up to four thin frame strips that run the general code (their
-// points are flattened over the 256 threads of a block so lanes stay busy whatever the strip's orientation) -- all in
-// ONE launch: blockIdx.x is split into per-region ranges, the branch on the region is block-uniform.
-#define MAX_REGIONS 5
-struct Regions {
-  int n;
-  int ib[MAX_REGIONS], ie[MAX_REGIONS], jb[MAX_REGIONS], je[MAX_REGIONS];
-  int first[MAX_REGIONS + 1];  // first block of each region; first[n] = total
-  int nbx0;                    // 64-wide patches per row of region 0
-};
-static inline void add_region(Regions& r, int ib, int ie, int jb, int je) {
-  if (ie < ib || je < jb) return;
-  const int q = r.n++;
-  r.ib[q] = ib; r.ie[q] = ie; r.jb[q] = jb; r.je[q] = je;
-  int nb;
-  if (q == 0) {
-    r.nbx0 = (ie - ib + 64) / 64;
-    nb = r.nbx0 * ((je - jb + 4) / 4);
-  } else {
-    nb = ((ie - ib + 1) * (je - jb + 1) + 255) / 256;
-  }
-  r.first[q + 1] = r.first[q] + nb;
-}
-// region 0 = interior box [is+di, ie+1-di] x [js+dj, je+1-dj] of the B-grid domain is..ie+1, the rest = frame strips
-static inline Regions bgrid_regions(const Geo& g, int d) {
-  Regions r{};
-  add_region(r, g.is + d, g.ie + 1 - d, g.js + d, g.je + 1 - d);
-  add_region(r, g.is, g.is + d - 1, g.js, g.je + 1);
-  add_region(r, g.ie + 2 - d, g.ie + 1, g.js, g.je + 1);
-  add_region(r, g.is + d, g.ie + 1 - d, g.js, g.js + d - 1);
-  add_region(r, g.is + d, g.ie + 1 - d, g.je + 2 - d, g.je + 1);
-  return r;
-}
-// sets i, j, k and `interior`; returns from the kernel for padding threads
-#define REGION_POINT(R)                                                                        \
-  int reg__ = 0;                                                                               \
-  while (reg__ + 1 < (R).n && (int)blockIdx.x >= (R).first[reg__ + 1]) ++reg__;               \
-  const int b__ = (int)blockIdx.x - (R).first[reg__];                                          \
-  const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
-  const bool interior = reg__ == 0;                                                            \
-  int i, j;                                                                                    \
-  const int k = (int)blockIdx.z;                                                               \
-  if (interior) {                                                                              \
-    i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
-    j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
-    if (i > (R).ie[0] || j > (R).je[0]) return;                                                \
-  } else {                                                                                     \
-    const int w__ = (R).ie[reg__] - (R).ib[reg__] + 1;                                         \
-    const int p__ = b__ * 256 + t__;                                                           \
-    j = (R).jb[reg__] + p__ / w__;                                                             \
-    i = (R).ib[reg__] + p__ % w__;                                                             \
-    if (j > (R).je[reg__]) return;                                                             \
-  }
-static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsigned)r.first[r.n], 1, (unsigned)nlev); }
 
 __global__ void __launch_bounds__(256)
 k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int fill, int adjust,
@@ -807,10 +825,11 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     return PACE_OK;
   }
   // winds
+  const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
   if (cfg->hord_mt == 5) {
-    hipLaunchKernelGGL(k_kinetic_energy<5>, gk, block, 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt);
+    hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke);
   } else if (cfg->hord_mt == 6) {
-    hipLaunchKernelGGL(k_kinetic_energy<6>, gk, block, 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt);
+    hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke);
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
