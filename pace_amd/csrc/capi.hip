@@ -33,7 +33,7 @@ const char* pace_version(void) {
 int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const double* uc, const double* vc, double* crx,
                double* cry, double* xfx, double* yfx, double* ut, double* vt, double dt, void* stream) {
   NEED(geom && met && uc && vc && crx && cry && xfx && yfx && ut && vt);
-  return launch_fxadv(make_geo(geom), *met, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, S(stream));
+  return launch_fxadv(make_geo(geom), *met, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, nullptr, nullptr, S(stream));
 }
 
 int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,

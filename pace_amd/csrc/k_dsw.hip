@@ -796,13 +796,13 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   const dim3 block(256);
   const dim3 gk = plane_grid(g, nk);
   if (phases & 1) {
-  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, st))) return rc;
+  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
   {
     FvDamp dp{};
     // delp: transport + del-n damping of the mass fluxes -> fx, fy
     dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
+    dp.accx = mfx; dp.accy = mfy;  // flux_capacitor (d_sw.py:33-60); its Courant-number half sits in fxadv
     if ((rc = launch_transport(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, 1, 0, dp, st))) return rc;
-    hipLaunchKernelGGL(k_fluxcap, gk, block, 0, st, g, cx, cy, mfx, mfy, crx, cry, W.fx, W.fy);
     // w: transport with the mass fluxes, del-n damping fluxes -> heat_diss, flux-form update -> W.gx (= w*delp + F(w))
     dp = FvDamp{};
     dp.damp_k = d_dampfac_w_c; dp.nord_k = d_nord_w; dp.nmax = nmax_w; dp.mass_given = 0;

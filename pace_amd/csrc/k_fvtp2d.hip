@@ -228,7 +228,10 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
         if (DMODE == 0 && EPI == 0) dp.fx2o[c] = dvx[f];
         if (DMODE == 1) v = v + dvx[f];
         if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - 1] + dp.mass[c]) * dvx[f];
-        if (EPI == 0) fx[c] = v;
+        if (EPI == 0) {
+          fx[c] = v;
+          if (dp.accx && (ii0 + f < TI || gi0 + f == g.ie + 1)) dp.accx[c] = dp.accx[c] + v;
+        }
         vxf[f] = v;
       }
     }
@@ -262,7 +265,10 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
         if (DMODE == 0 && EPI == 0) dp.fy2o[c] = dvy[f];
         if (DMODE == 1) v = v + dvy[f];
         if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - sj] + dp.mass[c]) * dvy[f];
-        if (EPI == 0) fy[c] = v;
+        if (EPI == 0) {
+          fy[c] = v;
+          if (dp.accy) dp.accy[c] = dp.accy[c] + v;
+        }
         vyf[f] = v;
       }
     }

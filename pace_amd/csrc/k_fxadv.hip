@@ -136,41 +136,51 @@ __global__ void __launch_bounds__(256) k_fxadv_vt_corners(Geo g, Met m, const do
 __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const double* __restrict__ ut,
                                                       const double* __restrict__ vt, double* __restrict__ crx,
                                                       double* __restrict__ cry, double* __restrict__ xfx,
-                                                      double* __restrict__ yfx, double dt) {
+                                                      double* __restrict__ yfx, double dt,
+                                                      double* __restrict__ cx_acc, double* __restrict__ cy_acc) {
+  // cx_acc / cy_acc (optional): the Courant-number half of d_sw's flux_capacitor (d_sw.py:33-60), cx += crx, cy += cry,
+  // done where crx / cry are produced
   PLANE_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   if (i >= g.is && i <= g.ie + 1) {
     const double u = ut[c];
+    double cr;
     if (u > 0.0) {
-      crx[c] = dt * u * m.rdxa[c2 - 1];
+      cr = dt * u * m.rdxa[c2 - 1];
       xfx[c] = m.dy[c2] * dt * u * m.sin_sg3[c2 - 1];
     } else {
-      crx[c] = dt * u * m.rdxa[c2];
+      cr = dt * u * m.rdxa[c2];
       xfx[c] = m.dy[c2] * dt * u * m.sin_sg1[c2];
     }
+    crx[c] = cr;
+    if (cx_acc) cx_acc[c] = cx_acc[c] + cr;
   }
   if (j >= g.js && j <= g.je + 1) {
     const double v = vt[c];
+    double cr;
     if (v > 0.0) {
-      cry[c] = dt * v * m.rdya[c2 - g.sj];
+      cr = dt * v * m.rdya[c2 - g.sj];
       yfx[c] = m.dx[c2] * dt * v * m.sin_sg4[c2 - g.sj];
     } else {
-      cry[c] = dt * v * m.rdya[c2];
+      cr = dt * v * m.rdya[c2];
       yfx[c] = m.dx[c2] * dt * v * m.sin_sg2[c2];
     }
+    cry[c] = cr;
+    if (cy_acc) cy_acc[c] = cy_acc[c] + cr;
   }
 }
 
 int launch_fxadv(const Geo& g, const Met& m, const double* uc, const double* vc, double* crx, double* cry,
-                 double* xfx, double* yfx, double* ut, double* vt, double dt, hipStream_t st) {
+                 double* xfx, double* yfx, double* ut, double* vt, double dt, double* cx_acc, double* cy_acc,
+                 hipStream_t st) {
   const dim3 grid = plane_grid(g, g.nk), block(256);
   hipLaunchKernelGGL(k_fxadv_main, grid, block, 0, st, g, m, uc, vc, ut, vt);
   hipLaunchKernelGGL(k_fxadv_vt_edges, grid, block, 0, st, g, m, vc, ut, vt);
   hipLaunchKernelGGL(k_fxadv_ut_edges_corners, grid, block, 0, st, g, m, uc, vc, ut, vt);
   hipLaunchKernelGGL(k_fxadv_vt_corners, grid, block, 0, st, g, m, uc, vc, ut, vt);
-  hipLaunchKernelGGL(k_fxadv_fluxes, grid, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt);
+  hipLaunchKernelGGL(k_fxadv_fluxes, grid, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

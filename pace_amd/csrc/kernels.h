@@ -3,7 +3,8 @@
 #include "common.h"
 
 int launch_fxadv(const Geo& g, const Met& m, const double* uc, const double* vc, double* crx, double* cry,
-                 double* xfx, double* yfx, double* ut, double* vt, double dt, hipStream_t st);
+                 double* xfx, double* yfx, double* ut, double* vt, double dt, double* cx_acc, double* cy_acc,
+                 hipStream_t st);
 int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
                   const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
                   const double* ymf, int hord, int nlev, hipStream_t st);
@@ -27,6 +28,9 @@ struct FvDamp {
   const double* damp_w_k;
   const double* ke_bg_k;
   double dt;
+  // optional accumulators of the final fluxes (EPI == 0): the mass-flux half of flux_capacitor, mfx += fx, mfy += fy
+  double* accx;
+  double* accy;
 };
 
 int launch_transport(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
