@@ -87,6 +87,15 @@ int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const double
                 double* q_y_flux, const double* x_mass_flux, const double* y_mass_flux, int hord, int nlev,
                 void* stream);
 
+/* ---- The fused form d_sw uses for q_con and pt (d_sw.py:1075-1117): FiniteVolumeTransport with mass fluxes AND its
+ * DelnFlux(mass = delp) (fvtp2d.py:262-345), followed by apply_fluxes (d_sw.py:122-145):
+ *   qout = q * delp + flux_increment(q_x_flux, q_y_flux) * rarea      on the compute domain,
+ * in ONE kernel; the flux fields never reach memory.  damp_k / nord_k as for pace_delnflux.  qout must not alias q. */
+int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
+                       const double* cry, const double* x_area_flux, const double* y_area_flux,
+                       const double* x_mass_flux, const double* y_mass_flux, const double* delp, const double* damp_k,
+                       const double* nord_k, int nmax, double* qout, int hord, int nlev, void* stream);
+
 /* ---- DelnFluxNoSG.__call__ (delnflux.py:1050-1261): damping fluxes fx2, fy2 of q.
  * nord_k, damp_k: DEVICE arrays, one entry per level (see DESIGN.md for how the reference's
  * nord0..nord3 externals map to per-level values).  If mass_given != 0, d2 starts from q

@@ -76,6 +76,7 @@ _PROTOS = {
     "pace_last_error": (C.c_char_p, []),
     "pace_fxadv": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 8 + [C.c_double, C.c_void_p]),
     "pace_fvtp2d": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 9 + [C.c_int, C.c_int, C.c_void_p]),
+    "pace_fvtp2d_update": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 10 + [C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p]),
     "pace_delnflux_nosg": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pace_delnflux": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "pace_a2b_ord4": (C.c_int, [_P(Geom), _P(Metrics), c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -45,6 +45,19 @@ int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const double
   return launch_fvtp2d(make_geo(geom), *met, q, crx, cry, xfx, yfx, fx, fy, xmf, ymf, hord, nlev, S(stream));
 }
 
+int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
+                       const double* cry, const double* x_area_flux, const double* y_area_flux,
+                       const double* x_mass_flux, const double* y_mass_flux, const double* delp, const double* damp_k,
+                       const double* nord_k, int nmax, double* qout, int hord, int nlev, void* stream) {
+  NEED(geom && met && q && crx && cry && x_area_flux && y_area_flux && x_mass_flux && y_mass_flux && delp && damp_k && nord_k && qout);
+  if (nlev < 1 || nlev > geom->nk + 1 || qout == q) return PACE_ERR_ARG;
+  FvDamp dp{};
+  dp.damp_k = damp_k; dp.nord_k = nord_k; dp.nmax = nmax; dp.mass_given = 1; dp.mass = delp;
+  dp.qout = qout; dp.amass = delp;
+  return launch_transport(make_geo(geom), *met, q, crx, cry, x_area_flux, y_area_flux, nullptr, nullptr, x_mass_flux, y_mass_flux,
+                          hord, nlev, 2, 1, dp, S(stream));
+}
+
 int pace_delnflux_nosg(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, double* fx2, double* fy2,
                        const double* damp_k, const double* nord_k, int nmax, int mass_given, int nlev, void* stream) {
   NEED(geom && met && q && fx2 && fy2 && damp_k && nord_k);

@@ -71,52 +71,6 @@ static inline Regions bgrid_regions(const Geo& g, int d) {
 static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsigned)r.first[r.n], 1, (unsigned)nlev); }
 
 
-// ------------------------------------------------------------------------------------------------
-// flux_capacitor (d_sw.py:33-60) + heat_diss (:63-103)
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_fluxcap_heatdiss(Geo g, Met m, double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ mfx,
-                   double* __restrict__ mfy, const double* __restrict__ crx, const double* __restrict__ cry,
-                   const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fx2,
-                   const double* __restrict__ fy2, const double* __restrict__ w, double* __restrict__ heat_s,
-                   double* __restrict__ diss_est, double* __restrict__ dw, const double* __restrict__ damp_w,
-                   const double* __restrict__ ke_bg, double dt) {
-  PLANE_IJK(g);
-  if (i > g.ni - 2 || j > g.nj - 2) return;
-  const long c = IDX3(g, i, j, k);
-  if (i >= g.is && i <= g.ie + 1) cx[c] = cx[c] + crx[c];
-  if (j >= g.js && j <= g.je + 1) cy[c] = cy[c] + cry[c];
-  const bool ci = (i >= g.is && i <= g.ie), cj = (j >= g.js && j <= g.je);
-  if (cj && i >= g.is && i <= g.ie + 1) mfx[c] = mfx[c] + fx[c];
-  if (ci && j >= g.js && j <= g.je + 1) mfy[c] = mfy[c] + fy[c];
-  if (ci && cj) {
-    double hs = 0.0;
-    if (damp_w[k] > 1e-5) {
-      const double dd8 = ke_bg[k] * fabs(dt);
-      const double d = (fx2[c] - fx2[c + 1] + fy2[c] - fy2[c + g.sj]) * m.rarea[IDX2(g, i, j)];
-      dw[c] = d;
-      hs = dd8 - d * (w[c] + 0.5 * d);
-    }
-    heat_s[c] = hs;
-    diss_est[c] = hs;
-  }
-}
-
-// flux_capacitor alone (d_sw.py:33-60); heat_diss lives in the epilogue of the w transport kernel
-__global__ void __launch_bounds__(256)
-k_fluxcap(Geo g, double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ mfx, double* __restrict__ mfy,
-          const double* __restrict__ crx, const double* __restrict__ cry, const double* __restrict__ fx,
-          const double* __restrict__ fy) {
-  PLANE_IJK(g);
-  if (i > g.ni - 2 || j > g.nj - 2) return;
-  const long c = IDX3(g, i, j, k);
-  if (i >= g.is && i <= g.ie + 1) cx[c] = cx[c] + crx[c];
-  if (j >= g.js && j <= g.je + 1) cy[c] = cy[c] + cry[c];
-  const bool ci = (i >= g.is && i <= g.ie), cj = (j >= g.js && j <= g.je);
-  if (cj && i >= g.is && i <= g.ie + 1) mfx[c] = mfx[c] + fx[c];
-  if (ci && j >= g.js && j <= g.je + 1) mfy[c] = mfy[c] + fy[c];
-}
-
 // apply_pt_delp_fluxes (d_sw.py:148-201) + adjust_w_and_qcon (:331-350), given the flux-form updates
 // pt*delp + F(pt), w*delp + F(w), q_con*delp + F(q_con) that the transport kernels' epilogues produced
 __global__ void __launch_bounds__(256)
@@ -134,36 +88,6 @@ k_finish_scalars(Geo g, Met m, double* __restrict__ pt, double* __restrict__ del
   if (damp_w[k] > 1e-5) wv = wv + dw[c];
   w[c] = wv;
   q_con[c] = qn[c] / dn;
-}
-
-// apply_fluxes (d_sw.py:122-145): q = q*delp + flux_increment(gx, gy)
-__global__ void __launch_bounds__(256)
-k_apply_fluxes(Geo g, Met m, double* __restrict__ q, const double* __restrict__ delp,
-               const double* __restrict__ gx, const double* __restrict__ gy) {
-  PLANE_IJK(g);
-  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
-  const long c = IDX3(g, i, j, k);
-  q[c] = q[c] * delp[c] + (gx[c] - gx[c + 1] + gy[c] - gy[c + g.sj]) * m.rarea[IDX2(g, i, j)];
-}
-
-// apply_pt_delp_fluxes (d_sw.py:148-201) + adjust_w_and_qcon (:331-350)
-__global__ void __launch_bounds__(256)
-k_pt_delp_w_qcon(Geo g, Met m, double* __restrict__ pt, double* __restrict__ delp, double* __restrict__ w,
-                 double* __restrict__ q_con, const double* __restrict__ gx, const double* __restrict__ gy,
-                 const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ dw,
-                 const double* __restrict__ damp_w) {
-  PLANE_IJK(g);
-  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
-  const long c = IDX3(g, i, j, k);
-  const double ra = m.rarea[IDX2(g, i, j)];
-  const double ptn = pt[c] * delp[c] + (gx[c] - gx[c + 1] + gy[c] - gy[c + g.sj]) * ra;
-  const double dn = delp[c] + (fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) * ra;
-  pt[c] = ptn / dn;
-  delp[c] = dn;
-  double wn = w[c] / dn;
-  if (damp_w[k] > 1e-5) wn = wn + dw[c];
-  w[c] = wn;
-  q_con[c] = q_con[c] / dn;
 }
 
 // ------------------------------------------------------------------------------------------------
