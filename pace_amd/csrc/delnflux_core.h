@@ -5,7 +5,7 @@
 
 #ifndef DN_TI
 #define DN_TI 32
-#define DN_TJ 16
+#define DN_TJ 24
 #endif
 #define DW (DN_TI + 6)
 #define DH (DN_TJ + 6)

@@ -9,7 +9,7 @@
 
 #ifndef FV_TI
 #define FV_TI 32
-#define FV_TJ 16
+#define FV_TJ 24  // 32 x 24 cells, runs of 5 interfaces: best of the tile shapes measured at C192
 #endif
 #define TI FV_TI
 #define TJ FV_TJ
@@ -38,7 +38,10 @@ struct FvLds {
   double pad[kNeed > kSweep ? kNeed - kSweep : 1];
 };
 
-#define RF 4                              // interfaces per thread in a PPM run
+#ifndef FV_RF
+#define FV_RF 5
+#endif
+#define RF FV_RF                          // interfaces per thread in a PPM run
 #define GY ((TJ + 1 + RF - 1) / RF)       // runs per column for the TJ+1 y-interfaces
 #define GX ((TI + 1 + RF - 1) / RF)       // runs per row for the TI+1 x-interfaces
 static_assert(QW * GY <= 256 && QH * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
