@@ -25,17 +25,22 @@ static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the tr
 // EX / EY: whether any x- (y-) interface this workgroup evaluates lies within two cells of a tile edge, where the
 // PPM interface values switch to the one-sided forms (xppm.py:148-181).  Block-uniform, so interior workgroups
 // (25 of 35 at C192) run straight-line code without the per-interface position tests.
+// LDS of one workgroup.  Occupancy is what this kernel lives on (a workgroup's time is set by its ~15 barrier-separated,
+// latency-bound stages; measured: throughput is proportional to resident workgroups per CU), so the arrays are kept
+// to a minimum: q advected in x (q_j) overwrites q in place, and the three scratch planes of the fused damping alias
+// the sweep arrays (padded only as far as needed).  32 x 24 tile: 32.6 KB (5 workgroups / CU) plain, 37.4 KB (4) fused.
+template <int DMODE, int EPI>
 struct FvLds {
-  double sq[QH][QW + 1];        // q on [i0-3, i0+TI+3) x [j0-3, j0+TJ+3)
+  double sq[QH][QW + 1];        // q on [i0-3, i0+TI+3) x [j0-3, j0+TJ+3); columns 3 .. TI+2 become q_j in stage 4
   double syin[TJ + 1][QW + 1];  // inner y sweep: mean advected value on y-interfaces
   double sqi[TJ][QW + 1];       // q advected in y (fvtp2d.py:34-56)
-  double sxin[QH][TI + 2];      // inner x sweep on x-interfaces
-  double sqj[QH][TI + 1];       // q advected in x (fvtp2d.py:59-77)
-  // the four sweep arrays double as the three scratch planes of the fused damping; pad only if a (test-sized) tile
-  // makes them too small
-  static constexpr int kSweep = (TJ + 1) * (QW + 1) + TJ * (QW + 1) + QH * (TI + 2) + QH * (TI + 1);
-  static constexpr int kNeed = 3 * (TJ + 6) * (TI + 7);
-  double pad[kNeed > kSweep ? kNeed - kSweep : 1];
+  double sxin[QH][TI + 1];      // inner x sweep on x-interfaces
+  static constexpr int kSweep = (TJ + 1) * (QW + 1) + TJ * (QW + 1) + QH * (TI + 1);
+  static constexpr int kDamp = DMODE >= 0 ? 3 * (TJ + 6) * (TI + 7) : 0;
+  static constexpr int kEpi = EPI > 0 ? 2 * (TJ * (TI + 2) + (TJ + 1) * (TI + 1)) : 0;
+  static constexpr int kNeed = kDamp > kEpi ? kDamp : kEpi;
+  static constexpr int kPad = kNeed > kSweep ? kNeed - kSweep : 1;
+  double pad[kPad];
 };
 
 #ifndef FV_RF
@@ -47,7 +52,7 @@ struct FvLds {
 static_assert(QW * GY <= 256 && QH * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
 template <int MORD, bool EX, bool EY, int DMODE, int EPI>
-__device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m, const double* __restrict__ q,
+__device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, const Met& m, const double* __restrict__ q,
                                             const double* __restrict__ crx, const double* __restrict__ cry,
                                             const double* __restrict__ xfx, const double* __restrict__ yfx,
                                             double* __restrict__ fx, double* __restrict__ fy,
@@ -57,7 +62,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
   auto& syin = L.syin;
   auto& sqi = L.sqi;
   auto& sxin = L.sxin;
-  auto& sqj = L.sqj;
 
   const int tid = threadIdx.x;
   const int i0 = g.is + blockIdx.x * TI;
@@ -84,7 +88,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
   double dvx[RF], dvy[RF];
   double damp = 0.0;
   if (DMODE >= 0) {
-    static_assert(sizeof(L.syin) + sizeof(L.sqi) + sizeof(L.sxin) + sizeof(L.sqj) + sizeof(L.pad) >= 3 * DH * DWP * sizeof(double),
+    static_assert(DMODE < 0 || sizeof(L.syin) + sizeof(L.sqi) + sizeof(L.sxin) + sizeof(L.pad) >= 3 * DH * DWP * sizeof(double),
                   "scratch");
     double* sd = &L.syin[0][0];
     double* sfx = sd + DH * DWP;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
       const double a = m.area[c2];
       val = (sq[jj][ii + 3] * a + x0 * sxin[jj][ii] - x1 * sxin[jj][ii + 1]) / (a + x0 - x1);
     }
-    sqj[jj][ii] = val;
+    sq[jj][ii + 3] = val;  // q_j in place: this thread is the only one that reads or writes this cell in this stage
   }
   __syncthreads();
 
@@ -246,7 +250,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
     double Q[RF + 5], cc[RF], yu[RF], out[RF];
     bool calc[RF];
 #pragma unroll
-    for (int u = 0; u < RF + 5; ++u) Q[u] = sqj[(jj0 + u < QH) ? jj0 + u : QH - 1][ii];  // q_j at gj0-3 ..
+    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[(jj0 + u < QH) ? jj0 + u : QH - 1][ii + 3];  // q_j at gj0-3 ..
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int jj = jj0 + f, gj = gj0 + f;
@@ -283,8 +287,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
     double* ay = ax + TJ * AXP;          // [TJ + 1][AYP]
     double* ax2 = ay + (TJ + 1) * AYP;   // damping fluxes (EPI == 2)
     double* ay2 = ax2 + TJ * AXP;
-    static_assert(2 * (TJ * AXP + (TJ + 1) * AYP) <= FvLds::kSweep + (FvLds::kNeed > FvLds::kSweep ? FvLds::kNeed - FvLds::kSweep : 1),
-                  "epilogue scratch");
+    static_assert(EPI == 0 || 2 * (TJ * AXP + (TJ + 1) * AYP) <= FvLds<DMODE, EPI>::kSweep + FvLds<DMODE, EPI>::kPad, "epilogue scratch");
     __syncthreads();
     if (tid < TJ * GX) {
       const int jj = tid / GX, grp = tid - jj * GX;
@@ -314,7 +317,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds& L, const Geo& g, const Met& m
       const long c2 = IDX2(g, gi, gj);
       const long c = kb + c2;
       const double ra = m.rarea[c2];
-      const double qv = sq[jj + 3][ii + 3];
+      const double qv = q[c];  // (the LDS copy of q has become q_j)
       dp.qout[c] = qv * dp.amass[c] + (ax[jj * AXP + ii] - ax[jj * AXP + ii + 1] + ay[jj * AYP + ii] - ay[(jj + 1) * AYP + ii]) * ra;
       if (EPI == 2) {
         double hs = 0.0;
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
                                                 FvDamp dp) {
   // x-interfaces evaluated: i0 .. i0+TI (their al's reach one further each way); special forms at is-1 .. is+1 and
   // ie .. ie+2
-  __shared__ FvLds L;
+  __shared__ FvLds<DMODE, EPI> L;
   const int i0 = g.is + blockIdx.x * TI, j0 = g.js + blockIdx.y * TJ;
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);

@@ -65,11 +65,18 @@ class TorchDistComm:
 
 
 class _World:
+    """Shared state of the tile threads.  The condition's lock doubles as a run token: a tile thread holds it whenever it
+    executes and gives it up only while it waits for a message (``Condition.wait_for`` releases and re-acquires it), so the
+    tiles run as coroutines -- one at a time, in message-driven order -- and nothing below (PyTorch, the HIP runtime, the
+    library) is ever entered from two threads at once."""
+
     def __init__(self, n):
         self.n = n
-        self.cond = threading.Condition()
+        self.cond = threading.Condition()  # RLock inside: re-entrant
         self.mail = defaultdict(deque)
-        self.barrier = threading.Barrier(n)
+        self.arrived = 0
+        self.generation = 0
+        self.failed = False
 
 
 class ThreadComm:
@@ -83,8 +90,24 @@ class ThreadComm:
     def Get_size(self):
         return self._world.n
 
+    def _wait(self, predicate, what):
+        w = self._world
+        if not w.cond.wait_for(lambda: predicate() or w.failed, timeout=600):
+            raise TimeoutError(f"tile {self._rank} waiting for {what}")
+        if w.failed and not predicate():
+            raise RuntimeError(f"tile {self._rank}: another tile failed while this one waited for {what}")
+
     def barrier(self):
-        self._world.barrier.wait()
+        w = self._world
+        with w.cond:
+            gen = w.generation
+            w.arrived += 1
+            if w.arrived == w.n:
+                w.arrived = 0
+                w.generation += 1
+                w.cond.notify_all()
+            else:
+                self._wait(lambda: w.generation != gen, "barrier")
 
     def exchange(self, sends, recvs, tag=0):
         w = self._world
@@ -97,8 +120,7 @@ class ThreadComm:
             for buf, peer in recvs:
                 key = (peer, self._rank, tag)
                 with w.cond:
-                    if not w.cond.wait_for(lambda: len(w.mail[key]) > 0, timeout=300):
-                        raise TimeoutError(f"tile {self._rank} waiting for message {key}")
+                    self._wait(lambda: len(w.mail[key]) > 0, f"message {key}")
                     data = w.mail[key].popleft()
                 buf.copy_(data)
 
@@ -111,13 +133,15 @@ def run_tiles(n, fn):
     results, errors = [None] * n, []
 
     def target(r):
-        try:
-            results[r] = fn(ThreadComm(world, r))
-        except BaseException as e:  # noqa: BLE001
-            import traceback
+        with world.cond:  # the run token (see _World)
+            try:
+                results[r] = fn(ThreadComm(world, r))
+            except BaseException as e:  # noqa: BLE001
+                import traceback
 
-            errors.append((r, e, traceback.format_exc()))
-            world.barrier.abort()
+                errors.append((r, e, traceback.format_exc()))
+                world.failed = True
+                world.cond.notify_all()
 
     threads = [threading.Thread(target=target, args=(r,), daemon=True, name=f"tile{r}") for r in range(n)]
     for t in threads:
