@@ -144,6 +144,17 @@ int pace_d_sw_winds(const pace_geom_t* geom, const pace_metrics_t* met, const pa
                     double* yfx, double* q_con, const double* zh, double* heat_source, double* diss_est, double dt,
                     void* stream);
 
+/* Finer split for callers that overlap on two streams (same arguments after `phases`).  Bit mask: 1 = flux preparation
+ * (fxadv), 2 = transport of delp, w, q_con, pt, 4 = winds A (kinetic energy ... vorticity damping fluxes), 8 = winds B
+ * (dissipative heating, final u/v update).  2 and 4 depend only on 1 and use disjoint workspace fields; 8 needs 2 and
+ * 4.  pace_d_sw_transport == phases 3, pace_d_sw_winds == phases 12, pace_d_sw == 15. */
+int pace_d_sw_phases(int phases, const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
+                     const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
+                     double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
+                     double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx,
+                     double* yfx, double* q_con, const double* zh, double* heat_source, double* diss_est, double dt,
+                     void* stream);
+
 /* ---- NonhydrostaticVerticalSolver.__call__ (riem_solver3.py:208-321), compute domain.
  * zs, ws: 2-D.  workspace: pace_riem_solver3_workspace_bytes() bytes of DEVICE scratch. */
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom);

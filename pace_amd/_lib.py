@@ -85,6 +85,7 @@ _PROTOS = {
     "pace_d_sw": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_transport": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_winds": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
+    "pace_d_sw_phases": (C.c_int, [C.c_int, _P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_riem_solver3_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_riem_solver3": (
         C.c_int,

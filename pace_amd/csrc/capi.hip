@@ -109,9 +109,13 @@ static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t*
   geom, met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx,  \
       q_con, zh, heat_source, diss_est, dt, stream
 
-int pace_d_sw(DSW_PARAMS) { return d_sw_entry(3, DSW_ARGS_); }
-int pace_d_sw_transport(DSW_PARAMS) { return d_sw_entry(1, DSW_ARGS_); }
-int pace_d_sw_winds(DSW_PARAMS) { return d_sw_entry(2, DSW_ARGS_); }
+int pace_d_sw(DSW_PARAMS) { return d_sw_entry(15, DSW_ARGS_); }
+int pace_d_sw_transport(DSW_PARAMS) { return d_sw_entry(3, DSW_ARGS_); }
+int pace_d_sw_winds(DSW_PARAMS) { return d_sw_entry(12, DSW_ARGS_); }
+int pace_d_sw_phases(int phases, DSW_PARAMS) {
+  if (phases < 1 || phases > 15) return PACE_ERR_ARG;
+  return d_sw_entry(phases, DSW_ARGS_);
+}
 
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom) {
   return geom ? riem3_workspace_bytes(make_geo(geom)) : 0;

@@ -643,10 +643,10 @@ int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k
 }
 
 struct DswWork {
-  double *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db;
+  double *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv;
   double* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
 };
-#define DSW_NFIELDS 18
+#define DSW_NFIELDS 19
 
 int64_t dsw_workspace_bytes(const Geo& g) {
   const int64_t field = (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double);
@@ -687,10 +687,12 @@ int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st
   return PACE_OK;
 }
 
-// phases: 1 = flux preparation + transport of delp, w, q_con, pt (everything riem_solver3 / updatedzd depend on),
-//         2 = winds (kinetic energy, vorticity, divergence damping, vorticity transport, heating), 3 = both.
-// Phase 2 only reads what phase 1 produced (ut/vt, crx..yfx, the new delp, heat_s), so a caller may run it on a second
-// stream concurrently with the vertical solver (pace_amd/fv3core/stencils/d_sw.py).
+// phases (bit mask): 1 = flux preparation (fxadv), 2 = transport of delp, w, q_con, pt (everything riem_solver3 /
+// updatedzd depend on), 4 = winds A (kinetic energy, vorticity, divergence damping, vorticity transport, u/v from ke,
+// vorticity damping fluxes), 8 = winds B (dissipative heating, final u/v update).  15 = the whole of d_sw.
+// Dependencies: 2 and 4 need only 1 (and use disjoint workspace fields); 8 needs 2 and 4.  A caller may therefore run
+// 4 (then 8) on a second stream concurrently with 2 and with whatever follows d_sw on the first stream -- the vertical
+// solver -- see pace_amd/fv3core/stencils/d_sw.py.
 int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace_dsw_config_t* cfg, void* ws,
                 double* delpc, double* delp, double* pt, double* u, double* v, double* w, double* uc, double* vc,
                 const double* ua, const double* va, double* divgd, double* mfx, double* mfy, double* cx, double* cy,
@@ -721,6 +723,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   const dim3 gk = plane_grid(g, nk);
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
+  }
+  if (phases & 2) {
   {
     FvDamp dp{};
     // delp: transport + del-n damping of the mass fluxes -> fx, fy
@@ -744,10 +748,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     hipLaunchKernelGGL(k_finish_scalars, gk, block, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   }
-  if (!(phases & 2)) {
-    PACE_CHECK_LAUNCH();
-    return PACE_OK;
-  }
+  if (phases & 4) {
   // winds
   const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
   if (cfg->hord_mt == 5) {
@@ -780,12 +781,16 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
                        W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, r);
   }
   // vorticity transport
-  if ((rc = launch_fvtp2d(g, m, W.abs_vort, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_vt, nk, st))) return rc;
-  hipLaunchKernelGGL(k_uv_from_ke, gk, block, 0, st, g, m, u, v, W.ke, W.fx, W.fy);
+  // (own flux buffers: the mass fluxes in W.fx / W.fy may still be in use by phase 2 on another stream)
+  if ((rc = launch_fvtp2d(g, m, W.abs_vort, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, st))) return rc;
+  hipLaunchKernelGGL(k_uv_from_ke, gk, block, 0, st, g, m, u, v, W.ke, W.fy2, W.fyv);
   if ((rc = launch_delnflux(g, m, 0, W.wk, W.ut2, W.vt2, nullptr, d_dampfac_vt_c, d_nord_v, nmax_v, 0, nk, st))) return rc;
+  }
+  if (phases & 8) {
   hipLaunchKernelGGL(k_heat_source, gk, block, 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,
                      d_dcon, cfg->d_con, cfg->do_skeb);
   hipLaunchKernelGGL(k_update_uv, gk, block, 0, st, g, u, v, W.ut2, W.vt2, d_damp_vt_c);
+  }
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

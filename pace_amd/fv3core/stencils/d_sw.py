@@ -97,10 +97,9 @@ class DGridShallowWaterLagrangianDynamics(Operator):
 
     def __call__(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                  heat_source, diss_est, dt, overlap_winds: bool = False):
-        """overlap_winds=True (an extension; the default is the reference's behaviour): the second half of d_sw -- the
-        wind update, which nothing before nh_p_grad reads -- is launched on this object's side stream, so that on
-        return the calling stream only carries the transport of delp / w / q_con / pt and the caller's next launches
-        (halo exchange, updatedzd, riem_solver3: few, latency-bound columns) overlap with it.  The caller MUST call
+        """overlap_winds=True (an extension; the default is the reference's behaviour): the wind update of d_sw, which
+        nothing before nh_p_grad reads, is launched on this object's side stream: after return it runs concurrently with the caller's next
+        launches (halo exchange, updatedzd, riem_solver3).  The caller MUST call
         ``join()`` before touching u, v, uc, vc, heat_source, diss_est, delpc or divgd again."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                   heat_source, diss_est)
@@ -112,13 +111,20 @@ class DGridShallowWaterLagrangianDynamics(Operator):
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self._workspace.device)
-            self._fork, self._done = torch.cuda.Event(), torch.cuda.Event()
-        main = torch.cuda.current_stream()
-        self.call("pace_d_sw_transport", *args, self.stream())
-        self._fork.record(main)
-        self._side.wait_event(self._fork)
-        self.call("pace_d_sw_winds", *args, C.c_void_p(self._side.cuda_stream))
-        self._done.record(self._side)
+            self._ev_prep, self._ev_scalars, self._done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        main, side = torch.cuda.current_stream(), self._side
+        side_ptr = C.c_void_p(side.cuda_stream)
+
+        def phases(mask, stream_ptr):
+            self.lib.call("pace_d_sw_phases", mask, C.byref(self._geom), *args, stream_ptr)
+
+        # Measured at C192 x 79: running winds A (mask 4) concurrently with the scalar transport (mask 2) gains nothing -- both
+        # saturate the SIMDs -- while the winds next to the bandwidth-shaped column solver do (-10 % per substep).
+        phases(3, self.stream())        # flux preparation + scalar transport on the calling stream
+        self._ev_scalars.record(main)
+        side.wait_event(self._ev_scalars)
+        phases(12, side_ptr)            # the whole wind update on the side stream
+        self._done.record(side)
         self._pending = True
 
     _side = None
