@@ -195,16 +195,14 @@ k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __re
 
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
 __global__ void __launch_bounds__(256)
-k_vorticity(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ vort,
-            double* __restrict__ abs_vort) {
+k_vorticity(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ vort) {
   PLANE_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const double ra = m.rarea[c2], dx = m.dx[c2], dy = m.dy[c2];
   const double val = (u[c] - u[c + g.sj] * m.dx[c2 + g.sj] / dx) * (ra * dx) + (v[c + 1] * m.dy[c2 + 1] / dy - v[c]) * (ra * dy);
-  vort[c] = val;
-  abs_vort[c] = val + m.fC_agrid[c2];
+  vort[c] = val;  // the absolute vorticity (+ fC_agrid) is formed where it is transported (launch_d_sw)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -758,7 +756,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_vorticity, gk, block, 0, st, g, m, u, v, W.wk, W.abs_vort);
+  hipLaunchKernelGGL(k_vorticity, gk, block, 0, st, g, m, u, v, W.wk);
   // divergence damping
   if (kstart > 0) {
     hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), block, 0, st, g, m, u, v, ua, va, uc, vc, delpc, W.vort_b, W.ke,
@@ -781,10 +779,16 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
                        W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, r);
   }
   // vorticity transport
-  // (own flux buffers: the mass fluxes in W.fx / W.fy may still be in use by phase 2 on another stream)
-  if ((rc = launch_fvtp2d(g, m, W.abs_vort, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, st))) return rc;
+  // vorticity: transport of the absolute vorticity (wk + fC_agrid) -> W.fy2, W.fyv (own flux buffers: the mass fluxes
+  // in W.fx / W.fy may still be in use by phase 2 on another stream) and the del-n damping fluxes of the relative
+  // vorticity -> ut2, vt2 (DelnFluxNoSG, d_sw.py:1187-1195), one kernel
+  {
+    FvDamp dp{};
+    dp.damp_k = d_dampfac_vt_c; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
+    dp.fx2o = W.ut2; dp.fy2o = W.vt2; dp.add2d = m.fC_agrid;
+    if ((rc = launch_transport(g, m, W.wk, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, 0, 0, dp, st))) return rc;
+  }
   hipLaunchKernelGGL(k_uv_from_ke, gk, block, 0, st, g, m, u, v, W.ke, W.fy2, W.fyv);
-  if ((rc = launch_delnflux(g, m, 0, W.wk, W.ut2, W.vt2, nullptr, d_dampfac_vt_c, d_nord_v, nmax_v, 0, nk, st))) return rc;
   }
   if (phases & 8) {
   hipLaunchKernelGGL(k_heat_source, gk, block, 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,

@@ -107,6 +107,17 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     }
     __syncthreads();
   }
+  if (dp.add2d) {  // block-uniform
+    for (int e = tid; e < QW * QH; e += 256) {
+      const int jj = e / QW, ii = e - jj * QW;
+      int gi = ilo + ii, gj = jlo + jj;
+      if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj) {
+        remap_agrid_y(g, gi, gj);
+        sq[jj][ii] = sq[jj][ii] + dp.add2d[IDX2(g, gi, gj)];
+      }
+    }
+    __syncthreads();
+  }
 
   // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1)): one run of RF interfaces of one
   // column per thread, lanes along i
@@ -156,7 +167,9 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
         int gi = ilo + ii, gj = jlo + jj;
         if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj && (gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) {
           remap_agrid_x(g, gi, gj);
-          sq[jj][ii] = q[kb + IDX2(g, gi, gj)];
+          double v = q[kb + IDX2(g, gi, gj)];
+          if (dp.add2d) v = v + dp.add2d[IDX2(g, gi, gj)];
+          sq[jj][ii] = v;
         }
       }
     }

@@ -31,6 +31,9 @@ struct FvDamp {
   // optional accumulators of the final fluxes (EPI == 0): the mass-flux half of flux_capacitor, mfx += fx, mfy += fy
   double* accx;
   double* accy;
+  // optional 2-D field added to q AFTER the fused damping has read it: the transported scalar is q + add2d while the damped
+  // one is q (d_sw: absolute vorticity = relative vorticity + fC_agrid, d_sw.py:389-402, damping acts on the relative one)
+  const double* add2d;
 };
 
 int launch_transport(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
