@@ -367,16 +367,26 @@ k_edge_pe(Geo g, double* __restrict__ pe, const double* __restrict__ delp, doubl
   }
 }
 
+// PK3Halo in two steps: the pressure scan is sequential per ring column (cheap), the power is not -- ~1600 threads
+// doing 79 dependent pow() each was 68 us; all (column, level) pairs in parallel is a few.
 __global__ void __launch_bounds__(64)
-k_pk3_halo(Geo g, double* __restrict__ pk3, const double* __restrict__ delp, double ptop, double akap) {
+k_pk3_halo_scan(Geo g, double* __restrict__ pk3, const double* __restrict__ delp, double ptop) {
   int i, j;
   if (!ring_cell(g, 2, blockIdx.x * 64 + threadIdx.x, i, j)) return;
   const long c0 = IDX2(g, i, j);
   double p = ptop;
   for (int k = 1; k <= g.nk; ++k) {
     p = p + delp[c0 + (long)(k - 1) * g.sk];
-    pk3[c0 + (long)k * g.sk] = pow(p, akap);
+    pk3[c0 + (long)k * g.sk] = p;  // pe for now
   }
+}
+
+__global__ void __launch_bounds__(64)
+k_pk3_halo_pow(Geo g, double* __restrict__ pk3, double akap) {
+  int i, j;
+  if (!ring_cell(g, 2, blockIdx.x * 64 + threadIdx.x, i, j)) return;
+  const long c = IDX2(g, i, j) + (long)(blockIdx.y + 1) * g.sk;
+  pk3[c] = pow(pk3[c], akap);
 }
 
 int launch_edge_pe(const Geo& g, double* pe, const double* delp, double ptop, hipStream_t st) {
@@ -387,7 +397,8 @@ int launch_edge_pe(const Geo& g, double* pe, const double* delp, double ptop, hi
 }
 int launch_pk3_halo(const Geo& g, double* pk3, const double* delp, double ptop, double akap, hipStream_t st) {
   const int cells = (g.n + 4) * (g.n + 4) - g.n * g.n;
-  hipLaunchKernelGGL(k_pk3_halo, dim3((cells + 63) / 64), dim3(64), 0, st, g, pk3, delp, ptop, akap);
+  hipLaunchKernelGGL(k_pk3_halo_scan, dim3((cells + 63) / 64), dim3(64), 0, st, g, pk3, delp, ptop);
+  hipLaunchKernelGGL(k_pk3_halo_pow, dim3((cells + 63) / 64, g.nk), dim3(64), 0, st, g, pk3, akap);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

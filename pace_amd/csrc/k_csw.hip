@@ -106,12 +106,34 @@ __global__ void __launch_bounds__(256)
 k_d2a2c_b(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
           const double* __restrict__ utmp, const double* __restrict__ vtmp, const double* __restrict__ ua,
           const double* __restrict__ va, double* __restrict__ uc, double* __restrict__ vc, double* __restrict__ ut,
-          double* __restrict__ vt, double* __restrict__ divgd, double dt2, int do_divg, int geoadjust) {
-  PLANE_IJK(g);
-  if (i < g.is - 1 || i > g.ie + 2 || j < g.js - 1 || j > g.je + 2) return;
+          double* __restrict__ vt, double* __restrict__ divgd, double dt2, int do_divg, int geoadjust, Regions R) {
+  REGION_POINT(R);
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;
+  if (interior) {
+    // is+2 <= i <= ie-1, js+2 <= j <= je-1: 4-point Lagrange everywhere, no edge wind, interior divergence
+    const double ucv = A2 * (utmp[c - 2] + utmp[c + 1]) + A1 * (utmp[c - 1] + utmp[c]);
+    double utv = contra2(ucv, v[c], m.cosa_u[c2], m.rsin_u[c2]);
+    uc[c] = ucv;
+    if (geoadjust) utv = (utv > 0.0) ? dt2 * utv * m.dy[c2] * m.sin_sg3[c2 - 1] : dt2 * utv * m.dy[c2] * m.sin_sg1[c2];
+    ut[c] = utv;
+    const double vcv = A2 * (vtmp[c - 2 * sj] + vtmp[c + sj]) + A1 * (vtmp[c - sj] + vtmp[c]);
+    double vtv = contra2(vcv, u[c], m.cosa_v[c2], m.rsin_v[c2]);
+    vc[c] = vcv;
+    if (geoadjust) vtv = (vtv > 0.0) ? dt2 * vtv * m.dx[c2] * m.sin_sg4[c2 - sj] : dt2 * vtv * m.dx[c2] * m.sin_sg2[c2];
+    vt[c] = vtv;
+    if (do_divg) {
+      const double* sg1 = m.sin_sg1; const double* sg2 = m.sin_sg2; const double* sg3 = m.sin_sg3; const double* sg4 = m.sin_sg4;
+      const double* cg1 = m.cos_sg1; const double* cg2 = m.cos_sg2; const double* cg3 = m.cos_sg3; const double* cg4 = m.cos_sg4;
+      const double uf = (u[c] - 0.25 * (va[c - sj] + va[c]) * (cg4[c2 - sj] + cg2[c2])) * m.dyc[c2] * 0.5 * (sg4[c2 - sj] + sg2[c2]);
+      const double uf1 = (u[c - 1] - 0.25 * (va[c - 1 - sj] + va[c - 1]) * (cg4[c2 - 1 - sj] + cg2[c2 - 1])) * m.dyc[c2 - 1] * 0.5 * (sg4[c2 - 1 - sj] + sg2[c2 - 1]);
+      const double vf = (v[c] - 0.25 * (ua[c - 1] + ua[c]) * (cg3[c2 - 1] + cg1[c2])) * m.dxc[c2] * 0.5 * (sg3[c2 - 1] + sg1[c2]);
+      const double vf1 = (v[c - sj] - 0.25 * (ua[c - 1 - sj] + ua[c - sj]) * (cg3[c2 - 1 - sj] + cg1[c2 - sj])) * m.dxc[c2 - sj] * 0.5 * (sg3[c2 - 1 - sj] + sg1[c2 - sj]);
+      divgd[c] = (vf1 - vf + uf1 - uf) * m.rarea_c[c2];
+    }
+    return;
+  }
   if (j <= g.je + 1) {  // uc, ut on i = is-1 .. ie+2, j = js-1 .. je+1
     double ucv, utv;
     if (i == g.is || i == g.ie + 1) {
@@ -281,6 +303,18 @@ k_csw_update_uc_vc(Geo g, Met m, const double* __restrict__ u, const double* __r
   }
 }
 
+// interior box (every output point uses the plain 4-point formulas) + the four frame strips of the domain
+// [is-1, ie+2] x [js-1, je+2] of pass B
+static Regions d2a2c_regions(const Geo& g) {
+  Regions r{};
+  add_region(r, g.is + 2, g.ie - 1, g.js + 2, g.je - 1);
+  add_region(r, g.is - 1, g.is + 1, g.js - 1, g.je + 2);
+  add_region(r, g.ie, g.ie + 2, g.js - 1, g.je + 2);
+  add_region(r, g.is + 2, g.ie - 1, g.js - 1, g.js + 1);
+  add_region(r, g.is + 2, g.ie - 1, g.je, g.je + 2);
+  return r;
+}
+
 #define CSW_NFIELDS 4
 int64_t csw_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * CSW_NFIELDS * (int64_t)sizeof(double); }
 
@@ -292,7 +326,9 @@ int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, double* uc, double* 
   double* vtmp = utmp + field;
   const dim3 grid = plane_grid(g, g.nk), block(256);
   hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
-  hipLaunchKernelGGL(k_d2a2c_b, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, utc, vtc, (double*)nullptr, 0.0, 0, 0);
+  const Regions rb = d2a2c_regions(g);
+  hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, utc, vtc,
+                     (double*)nullptr, 0.0, 0, 0, rb);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
@@ -308,7 +344,9 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, double* delpc, double* ptc
   double* vort = utmp + 3 * field;
   const dim3 grid = plane_grid(g, g.nk), block(256);
   hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
-  hipLaunchKernelGGL(k_d2a2c_b, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2, nord > 0 ? 1 : 0, 1);
+  const Regions rb = d2a2c_regions(g);
+  hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2,
+                     nord > 0 ? 1 : 0, 1, rb);
   hipLaunchKernelGGL(k_csw_transport, grid, block, 0, st, g, m, delp, pt, w, u, v, ua, va, uc, vc, ut, vt, delpc, ptc, omga, ke,
                      vort, dt2);
   hipLaunchKernelGGL(k_csw_update_uc_vc, grid, block, 0, st, g, m, u, v, ke, vort, uc, vc, dt2);
