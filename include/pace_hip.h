@@ -79,7 +79,7 @@ int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const double*
                double* vc_contra, double dt, void* stream);
 
 /* ---- FiniteVolumeTransport.__call__ without damping (fvtp2d.py:262-345).  x/y_mass_flux may be
- * NULL (area fluxes are used as unit fluxes).  hord in {5, 6}.  nlev = number of levels
+ * NULL (area fluxes are used as unit fluxes).  hord in {5, 6, 8}.  nlev = number of levels
  * processed (nk, or nk+1 for interface fields).  q's corner halos are NOT rewritten: corner reads
  * go through the copy_corners index map, which yields identical fluxes. */
 int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
@@ -235,6 +235,20 @@ int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* wor
 int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, const double* delz, const double* cappa,
                                  const double* heat_source, double* pt, double delt_time_factor, int nlev,
                                  void* stream);
+
+/* ---- TracerAdvection (Fortran tracer_2d_1l): the stencils around FiniteVolumeTransport(hord = 8) in
+ * fv3core/pace/fv3core/stencils/tracer_2d_1l.py -- flux_compute (:19-77), divide_fluxes_by_n_substeps (:80-106),
+ * apply_mass_flux (:115-135), apply_tracer_flux (:138-158), swap_dp (:166-170).  The transport itself is pace_fvtp2d
+ * with hord = 8 (monotone PPM, xppm.py:76-145,185-287). */
+int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const double* cx, const double* cy,
+                             double* xfx, double* yfx, void* stream);
+int pace_tracer_divide_fluxes(const pace_geom_t* geom, double* cxd, double* xfx, double* mfxd, double* cyd, double* yfx,
+                              double* mfyd, int n_split, void* stream);
+int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const double* dp1, const double* x_mass_flux,
+                         const double* y_mass_flux, double* dp2, void* stream);
+int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, double* q, const double* dp1,
+                           const double* fx, const double* fy, const double* dp2, void* stream);
+int pace_swap_dp(const pace_geom_t* geom, double* dp1, double* dp2, void* stream);
 
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation

@@ -252,6 +252,36 @@ int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, co
   return launch_diffusive_heating(make_geo(geom), delp, delz, cappa, heat_source, pt, delt_time_factor, nlev, S(stream));
 }
 
+int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const double* cx, const double* cy,
+                             double* xfx, double* yfx, void* stream) {
+  NEED(geom && met && cx && cy && xfx && yfx);
+  return launch_tracer_flux_compute(make_geo(geom), *met, cx, cy, xfx, yfx, S(stream));
+}
+
+int pace_tracer_divide_fluxes(const pace_geom_t* geom, double* cxd, double* xfx, double* mfxd, double* cyd, double* yfx,
+                              double* mfyd, int n_split, void* stream) {
+  NEED(geom && cxd && xfx && mfxd && cyd && yfx && mfyd);
+  if (n_split < 1) return PACE_ERR_ARG;
+  return launch_tracer_divide(make_geo(geom), cxd, xfx, mfxd, cyd, yfx, mfyd, n_split, S(stream));
+}
+
+int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const double* dp1, const double* x_mass_flux,
+                         const double* y_mass_flux, double* dp2, void* stream) {
+  NEED(geom && met && dp1 && x_mass_flux && y_mass_flux && dp2);
+  return launch_apply_mass_flux(make_geo(geom), *met, dp1, x_mass_flux, y_mass_flux, dp2, S(stream));
+}
+
+int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, double* q, const double* dp1,
+                           const double* fx, const double* fy, const double* dp2, void* stream) {
+  NEED(geom && met && q && dp1 && fx && fy && dp2);
+  return launch_apply_tracer_flux(make_geo(geom), *met, q, dp1, fx, fy, dp2, S(stream));
+}
+
+int pace_swap_dp(const pace_geom_t* geom, double* dp1, double* dp2, void* stream) {
+  NEED(geom && dp1 && dp2);
+  return launch_swap_dp(make_geo(geom), dp1, dp2, S(stream));
+}
+
 static int halo_check(const pace_geom_t* geom, const pace_halo_desc_t* d, int n) {
   const int ni = geom->n + 7;
   for (int t = 0; t < n; ++t) {

@@ -124,11 +124,106 @@ __device__ __forceinline__ double ppm_flux6(const double* q6, double c, int pos,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Monotone PPM, ord 8 (xppm.py:76-145,185-287 with xt_minmax = True; ppm.py:22-35) for a run of F interfaces.
+// The cell at position x needs q[x-2 .. x+2]; the six-cell window of an interface covers both of its cells.
+// ---------------------------------------------------------------------------------------------
+#define PPM_S11 (11.0 / 14.0)
+#define PPM_S14 (4.0 / 7.0)
+#define PPM_S15 (3.0 / 14.0)
+__device__ __forceinline__ double sign_like(double a, double b) { return (b > 0.0) ? fabs(a) : -fabs(a); }  // basic_operations.sign
+
+__device__ __forceinline__ double dm_ord8(double qm1, double q0, double qp1) {  // dm_iord8plus
+  const double xt = 0.25 * (qp1 - qm1);
+  const double dqr = fmax(fmax(q0, qm1), qp1) - q0;
+  const double dql = q0 - fmin(fmin(q0, qm1), qp1);
+  return sign_like(fmin(fmin(fabs(xt), dqr), dql), xt);
+}
+
+__device__ __forceinline__ void pert_ppm_standard_constraint(double& al, double& ar) {  // ppm.py:22-35
+  if (al * ar < 0.0) {
+    const double da1 = al - ar;
+    const double da2 = da1 * da1;
+    const double a6da = 3.0 * (al + ar) * da1;
+    if (a6da < -da2) ar = -2.0 * al;
+    else if (a6da > da2) al = -2.0 * ar;
+  } else {
+    al = 0.0;
+    ar = 0.0;
+  }
+}
+
+template <bool EDGE, int F, class DX>
+__device__ __forceinline__ void ppm_run8(const double* Q, const double* c, int pos0, int s, int e, DX dxa, double* out) {
+  // Q[u] = cell pos0-3+u.  dm at u = 1 .. F+3, al (interface between u-1 and u) at u = 2 .. F+3, cells u = 2 .. F+2
+  double dm[F + 5], al[F + 5];
+#pragma unroll
+  for (int u = 1; u <= F + 3; ++u) dm[u] = dm_ord8(Q[u - 1], Q[u], Q[u + 1]);
+#pragma unroll
+  for (int u = 2; u <= F + 3; ++u) al[u] = 0.5 * (Q[u - 1] + Q[u]) + 1.0 / 3.0 * (dm[u - 1] - dm[u]);
+  double bl[F + 3], br[F + 3], b0[F + 3];
+#pragma unroll
+  for (int u = 2; u <= F + 2; ++u) {
+    const double q0 = Q[u];
+    const double xt2 = 2.0 * dm[u];
+    double l = -1.0 * sign_like(fmin(fabs(xt2), fabs(al[u] - q0)), xt2);
+    double r = sign_like(fmin(fabs(xt2), fabs(al[u + 1] - q0)), xt2);
+    if (EDGE) {
+      const int x = pos0 - 3 + u;
+      const bool near = (x >= s - 1 && x <= s + 1) || (x >= e - 1 && x <= e + 1);
+      if (near) {
+        const double qm2 = Q[u - 2], qm1 = Q[u - 1], qp1 = Q[u + 1], qp2 = Q[u + 2];
+        double xt_bl, xt_br;
+        if (x == s - 1 || x == e) {
+          const double d0 = dxa(x), dm1 = dxa(x - 1), dp1 = dxa(x + 1), dp2 = dxa(x + 2);
+          double e0 = 0.5 * (((2.0 * d0 + dm1) * q0 - d0 * qm1) / (dm1 + d0) + ((2.0 * dp1 + dp2) * qp1 - dp1 * qp2) / (dp1 + dp2));
+          e0 = fmin(fmax(e0, fmin(fmin(fmin(qm1, q0), qp1), qp2)), fmax(fmax(fmax(qm1, q0), qp1), qp2));
+          xt_bl = (x == s - 1) ? PPM_S14 * dm[u - 1] + PPM_S11 * (qm1 - q0) + q0 : PPM_S15 * q0 + PPM_S11 * qm1 + PPM_S14 * dm[u - 1];
+          xt_br = e0;
+        } else if (x == s || x == e + 1) {
+          const double d0 = dxa(x), dm1 = dxa(x - 1), dm2 = dxa(x - 2), dp1 = dxa(x + 1);
+          double e1 = 0.5 * (((2.0 * dm1 + dm2) * qm1 - dm1 * qm2) / (dm2 + dm1) + ((2.0 * d0 + dp1) * q0 - d0 * qp1) / (d0 + dp1));
+          e1 = fmin(fmax(e1, fmin(fmin(fmin(qm2, qm1), q0), qp1)), fmax(fmax(fmax(qm2, qm1), q0), qp1));
+          xt_bl = e1;
+          xt_br = (x == s) ? PPM_S15 * q0 + PPM_S11 * qp1 - PPM_S14 * dm[u + 1] : PPM_S11 * (qp1 - q0) - PPM_S14 * dm[u + 1] + q0;
+        } else if (x == s + 1) {
+          xt_bl = PPM_S15 * qm1 + PPM_S11 * q0 - PPM_S14 * dm[u];
+          xt_br = al[u + 1];
+        } else {  // x == e - 1
+          xt_bl = al[u];
+          xt_br = PPM_S15 * qp1 + PPM_S11 * q0 + PPM_S14 * dm[u];
+        }
+        l = xt_bl - q0;
+        r = xt_br - q0;
+        pert_ppm_standard_constraint(l, r);
+      }
+    }
+    bl[u] = l;
+    br[u] = r;
+    b0[u] = l + r;
+  }
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const double cc = c[f];
+    if (cc > 0.0) {
+      const double fx1 = (1.0 - cc) * (br[f + 2] - cc * b0[f + 2]);
+      out[f] = Q[f + 2] + fx1 * 1.0;
+    } else {
+      const double fx1 = (1.0 + cc) * (bl[f + 3] + cc * b0[f + 3]);
+      out[f] = Q[f + 3] + fx1 * 1.0;
+    }
+  }
+}
+
 // A run of F consecutive interfaces pos0 .. pos0+F-1 evaluated by one thread: the F+2 interface values and the F+1
 // cell reconstructions (bl, br, b0, steepness flag) are computed once and shared, instead of three interface values
 // and two reconstructions per flux.  Q[u] = cell pos0-3+u, u = 0 .. F+4.  Same expressions as ppm_flux6 -> same bits.
 template <int MORD, bool EDGE, int F, class DX>
 __device__ __forceinline__ void ppm_run(const double* Q, const double* c, int pos0, int s, int e, DX dxa, double* out) {
+  if (MORD == 8) {
+    ppm_run8<EDGE, F>(Q, c, pos0, s, e, dxa, out);
+    return;
+  }
   double al[F + 2];
 #pragma unroll
   for (int a = 0; a < F + 2; ++a) al[a] = EDGE ? ppm_al(Q, a + 2, pos0 - 1 + a, s, e, dxa) : ppm_al_interior(Q, a + 2);

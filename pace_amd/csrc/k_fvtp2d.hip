@@ -358,6 +358,7 @@ __global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __re
   // ie .. ie+2
   __shared__ FvLds<DMODE, EPI> L;
   const int i0 = g.is + blockIdx.x * TI, j0 = g.js + blockIdx.y * TJ;
+  // (ord 8: the special CELLS are s-1 .. s+1 and e-1 .. e+1; the cells evaluated are i0-1 .. i0+TI -- the same test)
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
   if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
@@ -407,6 +408,10 @@ int launch_transport(const Geo& g, const Met& m, const double* q, const double* 
   int rc;
   if (hord == 5) rc = launch_mode<5>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
   else if (hord == 6) rc = launch_mode<6>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+  else if (hord == 8 && dmode == -1 && epi == 0) {  // monotone PPM: tracer advection (plain transport only)
+    hipLaunchKernelGGL((k_fvtp2d<8, -1, 0>), grid, dim3(256), 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+    rc = PACE_OK;
+  }
   else return PACE_ERR_UNSUPPORTED;
   if (rc) return rc;
   PACE_CHECK_LAUNCH();

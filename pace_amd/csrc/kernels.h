@@ -93,3 +93,13 @@ int launch_diffusive_heating(const Geo& g, const double* delp, const double* del
                              const double* heat_source, double* pt, double delt_time_factor, int nlev, hipStream_t st);
 // k_halo.hip
 int launch_halo_copy(const Geo& g, const pace_halo_desc_t* descs, int ndesc, int unpack, hipStream_t st);
+// k_tracer.hip
+int launch_tracer_flux_compute(const Geo& g, const Met& m, const double* cx, const double* cy, double* xfx, double* yfx,
+                               hipStream_t st);
+int launch_tracer_divide(const Geo& g, double* cxd, double* xfx, double* mfxd, double* cyd, double* yfx, double* mfyd,
+                         int n_split, hipStream_t st);
+int launch_apply_mass_flux(const Geo& g, const Met& m, const double* dp1, const double* mfx, const double* mfy, double* dp2,
+                           hipStream_t st);
+int launch_apply_tracer_flux(const Geo& g, const Met& m, double* q, const double* dp1, const double* fx, const double* fy,
+                             const double* dp2, hipStream_t st);
+int launch_swap_dp(const Geo& g, double* dp1, double* dp2, hipStream_t st);

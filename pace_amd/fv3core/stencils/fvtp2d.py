@@ -10,8 +10,8 @@ class FiniteVolumeTransport(Operator):
                  nord=None, damp_c=None):
         super().__init__(stencil_factory, quantity_factory, grid_data)
         assert grid_type < 3
-        if hord not in (5, 6):
-            raise NotImplementedError(f"hord={hord}: only the ord<8 PPM branch (hord 5, 6) is implemented on device so far")
+        if hord not in (5, 6, 8):
+            raise NotImplementedError(f"hord={hord}: implemented on device are the unlimited PPM (5, 6) and the monotone one (8)")
         self._hord = int(hord)
         self._nlev = self.grid_indexing.domain[2]
         self._do_delnflux = (nord is not None) and (damp_c is not None)

@@ -229,3 +229,47 @@ def acoustic_errors(fix, out, n=12):
         e = max(e, compare(fix["col_" + k][:, :nk], cols, near_zero=near_zero))
         errs[k] = e
     return errs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# TracerAdvection on six tiles
+# ------------------------------------------------------------------------------------------------------------------
+def run_tracer_tile(comm, lib, device, fix, metrics, n):
+    import torch
+
+    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
+    from pace_amd.fv3core.stencils.tracer_2d_1l import TracerAdvection
+    from pace_amd.util import CubedSphereCommunicator
+
+    nk = len(fix["k_sel"])
+    env = Env(lib, device, metrics, n, nk)
+    cube = CubedSphereCommunicator(comm, device=device, lib=lib)
+    tracers = {"qvapor": env.q3(fix["in_qvapor"]), "q2": env.q3(fix["in_q2"])}
+    f = {k: env.q3(fix["in_" + k]) for k in ("dp1", "mfxd", "mfyd", "cxd", "cyd")}
+    transport = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 8)
+    adv = TracerAdvection(env.stencil_factory, env.qf, transport, env.grid_data, cube, tracers)
+    adv(tracers, f["dp1"], f["mfxd"], f["mfyd"], f["cxd"], f["cyd"])
+    if env.qf.device.type == "cuda":
+        torch.cuda.synchronize()
+    out = {k: v.numpy() for k, v in tracers.items()}
+    out.update({k: v.numpy() for k, v in f.items()})
+    return out
+
+
+def run_tracer_six_tiles(lib, device, n=12):
+    from pace_amd.util import run_tiles
+
+    fixes = [golden(f"tracer_c12_tile{t}.npz") for t in range(6)]
+    metrics = [{k[5:]: v for k, v in golden(f"acoustic_c12_tile{t}.npz").items() if k.startswith("grid_")} for t in range(6)]
+    outs = run_tiles(6, lambda comm: run_tracer_tile(comm, lib, device, fixes[comm.Get_rank()], metrics[comm.Get_rank()], n))
+    return fixes, outs
+
+
+def check_tracer_outputs(fixes, outs, n=12):
+    for t in range(6):
+        nk = len(fixes[t]["k_sel"])
+        W = (slice(3, 3 + n), slice(3, 3 + n), slice(0, nk))
+        for name in ("qvapor", "q2"):
+            assert np.array_equal(outs[t][name][W], fixes[t]["out_" + name][W]), (t, name)
+        assert np.array_equal(outs[t]["mfxd"][3 : 4 + n, 3 : 3 + n, :nk], fixes[t]["out_mfxd"][3 : 4 + n, 3 : 3 + n, :nk]), t
+        assert np.array_equal(outs[t]["cyd"][3 : 3 + n, 3 : 4 + n, :nk], fixes[t]["out_cyd"][3 : 3 + n, 3 : 4 + n, :nk]), t

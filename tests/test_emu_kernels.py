@@ -5,7 +5,7 @@ build, which the `-m gpu` tests cover.  CPU only."""
 import numpy as np
 import pytest
 
-from helpers import (DSW_ARGS, Env, acoustic_errors, run_acoustic_six_tiles, build_emu, column_for_levels, compare, dsw_window, expand_riem_fixture, golden, run_d_sw,
+from helpers import (DSW_ARGS, Env, acoustic_errors, check_tracer_outputs, run_acoustic_six_tiles, run_tracer_six_tiles, build_emu, column_for_levels, compare, dsw_window, expand_riem_fixture, golden, run_d_sw,
                      run_riem3, window)
 
 
@@ -71,3 +71,10 @@ def test_acoustic_dynamics_six_tiles_emulated(emu_lib):
     for t in range(6):
         for k, e in acoustic_errors(fixes[t], outs[t]).items():
             assert e < 1e-7, (t, k, e)
+
+
+def test_tracer_advection_six_tiles_emulated(emu_lib):
+    """TracerAdvection (monotone ord-8 PPM transport, sub-cycling, tracer halo updates) on the six C12 tiles against the
+    reference's own run (tools/make_golden_tracer.py): bit for bit -- no transcendental is involved."""
+    fixes, outs = run_tracer_six_tiles(emu_lib, "cpu")
+    check_tracer_outputs(fixes, outs)

@@ -143,3 +143,32 @@ def test_oracle_acoustic_dynamics_against_reference_run():
         out["heat_source"] = tmp[t].heat_source
         for k, e in acoustic_errors(fixes[t], out).items():
             assert e == 0.0, (t, k, e)  # bit-for-bit
+
+
+def _tracer_case():
+    from helpers import golden, oracle_grid
+
+    n = 12
+    fixes = [golden(f"tracer_c12_tile{t}.npz") for t in range(6)]
+    nk = len(fixes[0]["k_sel"])
+    grids = [oracle_grid({k[5:]: v for k, v in golden(f"acoustic_c12_tile{t}.npz").items() if k.startswith("grid_")}, n, nk)
+             for t in range(6)]
+    return n, nk, fixes, grids
+
+
+def test_oracle_tracer_advection_against_reference_run():
+    """oracle/tracer.py (flux_compute, sub-cycling, ord-8 monotone PPM transport, tracer halo updates) for all six tiles
+    against the reference's TracerAdvection run (tools/make_golden_tracer.py): bit for bit."""
+    from oracle import tracer
+
+    n, nk, fixes, grids = _tracer_case()
+    f = lambda k: [fx["in_" + k].copy() for fx in fixes]  # noqa: E731
+    tracers = {"qvapor": f("qvapor"), "q2": f("q2")}
+    dp1, mfx, mfy, cx, cy = f("dp1"), f("mfxd"), f("mfyd"), f("cxd"), f("cyd")
+    tracer.tracer_advection(grids, tracers, dp1, mfx, mfy, cx, cy, n, nk)
+    W = (slice(3, 3 + n), slice(3, 3 + n), slice(0, nk))
+    for t in range(6):
+        for name, q in tracers.items():
+            assert np.array_equal(q[t][W], fixes[t]["out_" + name][W]), (t, name)
+        assert np.array_equal(mfx[t][3 : 4 + n, 3 : 3 + n, :nk], fixes[t]["out_mfxd"][3 : 4 + n, 3 : 3 + n, :nk])
+        assert np.array_equal(cy[t][3 : 3 + n, 3 : 4 + n, :nk], fixes[t]["out_cyd"][3 : 3 + n, 3 : 4 + n, :nk])
