@@ -135,3 +135,38 @@ def test_halo_updates_six_processes_gloo(tmp_path):
         assert p.wait(timeout=300) == 0
     results = [pickle.load(open(tmp_path / f"out{r}.pkl", "rb")) for r in range(6)]
     _check(results, _base())
+
+
+def test_halo_updater_error_behaviour():
+    """The misuse errors of the reference's HaloUpdater / communicator (halo_updater.py:225-232,277-278;
+    communicator.py:521-553,700-709)."""
+    from pace_amd import _lib
+    from pace_amd.util import CubedSphereCommunicator, QuantityFactory, SubtileGridSizer, run_tiles
+    from pace_amd.util.comm import ThreadComm, _World
+
+    lib = _lib.Library(build_emu())
+    with pytest.raises(ValueError, match="ranks"):
+        CubedSphereCommunicator(ThreadComm(_World(4), 0), device="cpu", lib=lib)
+
+    def program(comm):
+        sizer = SubtileGridSizer.from_tile_params(nx_tile=N, ny_tile=N, nz=NZ, n_halo=3, extra_dim_lengths={}, layout=(1, 1))
+        qf = QuantityFactory(sizer, device="cpu")
+        cube = CubedSphereCommunicator(comm, device="cpu", lib=lib)
+        spec = qf.get_quantity_halo_spec(DIMS["c"])
+        with pytest.raises(RuntimeError):
+            cube.get_scalar_halo_updater([])
+        with pytest.raises(ValueError, match="zero halo points"):
+            cube.get_scalar_halo_updater([qf.get_quantity_halo_spec(DIMS["c"], n_halo=0)])
+        up = cube.get_scalar_halo_updater([spec])
+        with pytest.raises(RuntimeError, match="before"):
+            up.wait()
+        q = qf.zeros(DIMS["c"], "")
+        with pytest.raises(ValueError):
+            up.start([q, q])
+        up.start([q])
+        with pytest.raises(RuntimeError, match="finished"):
+            up.start([q])
+        up.wait()
+        return True
+
+    assert all(run_tiles(6, program))
