@@ -136,50 +136,82 @@ k_spline_to_interfaces(Geo g, SplineK s, const double* __restrict__ q0, const do
   const long c0 = IDX2(g, i, j);
   const long sk = g.sk;
   const int km = g.nk;
+  // both sweeps in register chunks: the loads of a chunk are issued together, the recurrence then runs out of registers
+  constexpr int CHS = 16;
   double prev_c = qc[c0];
   double v = (s.xt1_top * prev_c + qc[c0 + sk]) / s.beta[0];
   qi[c0] = v;
-  for (int k = 1; k < km; ++k) {
-    const double cur = qc[c0 + (long)k * sk];
-    v = (3.0 * (prev_c + s.gk[k] * cur) - v) / s.beta[k];
-    qi[c0 + (long)k * sk] = v;
-    prev_c = cur;
+  for (int k0 = 1; k0 < km; k0 += CHS) {
+    double c_[CHS];
+#pragma unroll
+    for (int t = 0; t < CHS; ++t) c_[t] = qc[c0 + (long)((k0 + t < km) ? k0 + t : km - 1) * sk];
+#pragma unroll
+    for (int t = 0; t < CHS; ++t) {
+      const int k = k0 + t;
+      if (k < km) {
+        v = (3.0 * (prev_c + s.gk[k] * c_[t]) - v) / s.beta[k];
+        qi[c0 + (long)k * sk] = v;
+        prev_c = c_[t];
+      }
+    }
   }
   v = (s.xt1_bot * qc[c0 + (long)(km - 1) * sk] + qc[c0 + (long)(km - 2) * sk] - s.a_bot * v) / s.xt2_bot;
   qi[c0 + (long)km * sk] = v;
-  for (int k = km - 1; k >= 0; --k) {
-    v = qi[c0 + (long)k * sk] - s.gamma[k] * v;
-    qi[c0 + (long)k * sk] = v;
+  for (int k0 = km - 1; k0 >= 0; k0 -= CHS) {
+    double i_[CHS];
+#pragma unroll
+    for (int t = 0; t < CHS; ++t) i_[t] = qi[c0 + (long)((k0 - t >= 0) ? k0 - t : 0) * sk];
+#pragma unroll
+    for (int t = 0; t < CHS; ++t) {
+      const int k = k0 - t;
+      if (k >= 0) {
+        v = i_[t] - s.gamma[k] * v;
+        qi[c0 + (long)k * sk] = v;
+      }
+    }
   }
 }
 
-// apply_height_fluxes (updatedzd.py:70-126): advective + diffusive update, ws, monotonicity sweep; one column
-// per thread walking up from the surface (a cell's update reads only its own zh)
+// apply_height_fluxes (updatedzd.py:70-126) in two steps: the advective + diffusive update is a point function (all
+// levels in parallel, in place: a cell reads only its own zh); ws and the bottom-up monotonicity sweep are the only
+// column-sequential part and touch one field.
+__global__ void __launch_bounds__(256)
+k_apply_height_fluxes(Geo g, Met m, double* __restrict__ zh, const double* __restrict__ fx, const double* __restrict__ fy,
+                      const double* __restrict__ xfx, const double* __restrict__ yfx, const double* __restrict__ fx2,
+                      const double* __restrict__ fy2) {
+  PLANE_IJK(g);
+  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
+  const long c = IDX3(g, i, j, k);
+  const double area = m.area[IDX2(g, i, j)];
+  const double area_after = (area + xfx[c] - xfx[c + 1]) + (area + yfx[c] - yfx[c + g.sj]) - area;
+  const double adv = (zh[c] * area + fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) / area_after;
+  zh[c] = adv + (fx2[c] - fx2[c + 1] + fy2[c] - fy2[c + g.sj]) / area;
+}
+
 __global__ void __launch_bounds__(64)
-k_apply_height_fluxes(Geo g, Met m, const double* __restrict__ zs, double* __restrict__ zh,
-                      const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ xfx,
-                      const double* __restrict__ yfx, const double* __restrict__ fx2, const double* __restrict__ fy2,
-                      double* __restrict__ ws, double dt) {
+k_height_column(Geo g, const double* __restrict__ zs, double* __restrict__ zh, double* __restrict__ ws, double dt) {
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y;
   if (i > g.ie || j > g.je) return;
   const long c0 = IDX2(g, i, j);
   const int km = g.nk;
-  const double area = m.area[c0];
-  double below = 0.0;
-  for (int k = km; k >= 0; --k) {
-    const long c = c0 + (long)k * g.sk;
-    const double area_after = (area + xfx[c] - xfx[c + 1]) + (area + yfx[c] - yfx[c + g.sj]) - area;
-    const double adv = (zh[c] * area + fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) / area_after;
-    double v = adv + (fx2[c] - fx2[c + 1] + fy2[c] - fy2[c + g.sj]) / area;
-    if (k == km) {
-      ws[c0] = (zs[c0] - v) / dt;
-    } else {
-      const double other = below + DZ_MIN;
-      v = (v > other) ? v : other;
+  constexpr int CHZ = 16;
+  double below = zh[c0 + (long)km * g.sk];
+  ws[c0] = (zs[c0] - below) / dt;
+  for (int k0 = km - 1; k0 >= 0; k0 -= CHZ) {
+    double z_[CHZ];
+#pragma unroll
+    for (int t = 0; t < CHZ; ++t) z_[t] = zh[c0 + (long)((k0 - t >= 0) ? k0 - t : 0) * g.sk];
+#pragma unroll
+    for (int t = 0; t < CHZ; ++t) {
+      const int k = k0 - t;
+      if (k >= 0) {
+        const double other = below + DZ_MIN;
+        const double v = (z_[t] > other) ? z_[t] : other;
+        if (v != z_[t]) zh[c0 + (long)k * g.sk] = v;
+        below = v;
+      }
     }
-    zh[c] = v;
-    below = v;
   }
 }
 
@@ -202,8 +234,8 @@ int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd
   int rc;
   if ((rc = launch_fvtp2d(g, m, zh, crx_i, cry_i, xfx_i, yfx_i, fx, fy, nullptr, nullptr, hord_tm, g.nk + 1, st))) return rc;
   if ((rc = launch_delnflux(g, m, 0, zh, fx2, fy2, nullptr, kc->damp, kc->nord, kc->nmax, 0, g.nk + 1, st))) return rc;
-  hipLaunchKernelGGL(k_apply_height_fluxes, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, m, zs, zh, fx, fy, xfx_i, yfx_i, fx2,
-                     fy2, wsd, dt);
+  hipLaunchKernelGGL(k_apply_height_fluxes, plane_grid(g, g.nk + 1), dim3(256), 0, st, g, m, zh, fx, fy, xfx_i, yfx_i, fx2, fy2);
+  hipLaunchKernelGGL(k_height_column, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, zs, zh, wsd, dt);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

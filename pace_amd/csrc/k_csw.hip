@@ -226,13 +226,45 @@ k_csw_transport(Geo g, Met m, const double* __restrict__ delp, const double* __r
                 const double* __restrict__ ua, const double* __restrict__ va, const double* __restrict__ uc,
                 const double* __restrict__ vc, const double* __restrict__ ut, const double* __restrict__ vt,
                 double* __restrict__ delpc, double* __restrict__ ptc, double* __restrict__ omga,
-                double* __restrict__ ke, double* __restrict__ vort, double dt2) {
-  PLANE_IJK(g);
-  if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1) return;
+                double* __restrict__ ke, double* __restrict__ vort, double dt2, Regions R) {
+  REGION_POINT(R);
   const long kb = (long)k * g.sk;
   const long c2 = IDX2(g, i, j);
   const long c = c2 + kb;
   const int sj = g.sj;
+  if (interior) {
+    // is+1 <= i <= ie-1, js+1 <= j <= je-1: no corner-filled operand, no edge form of ke / vorticity
+    double fx1[2], fx[2], fx2[2], fy1[2], fy[2], fy2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const double utv = ut[c + t];
+      const long s = (utv > 0.0) ? c + t - 1 : c + t;
+      fx1[t] = utv * delp[s];
+      fx[t] = fx1[t] * pt[s];
+      fx2[t] = fx1[t] * w[s];
+      const double vtv = vt[c + (long)t * sj];
+      const long s2 = (vtv > 0.0) ? c + (long)(t - 1) * sj : c + (long)t * sj;
+      fy1[t] = vtv * delp[s2];
+      fy[t] = fy1[t] * pt[s2];
+      fy2[t] = fy1[t] * w[s2];
+    }
+    const double ra = m.rarea[c2];
+    const double dp = delp[c];
+    const double dpc = dp + (fx1[0] - fx1[1] + fy1[0] - fy1[1]) * ra;
+    delpc[c] = dpc;
+    ptc[c] = (pt[c] * dp + (fx[0] - fx[1] + fy[0] - fy[1]) * ra) / dpc;
+    omga[c] = (w[c] * dp + (fx2[0] - fx2[1] + fy2[0] - fy2[1]) * ra) / dpc;
+    const double uav = ua[c], vav = va[c];
+    const double kev = (uav > 0.0) ? uc[c] : uc[c + 1];
+    const double vov = (vav > 0.0) ? vc[c] : vc[c + sj];
+    ke[c] = 0.5 * dt2 * (uav * kev + vav * vov);
+    const double fxc = m.dxc[c2] * uc[c];
+    const double fyc = m.dyc[c2] * vc[c];
+    const double fx1c = m.dxc[c2 - sj] * uc[c - sj];
+    const double fy1c = m.dyc[c2 - 1] * vc[c - 1];
+    vort[c] = m.fC[c2] + m.rarea_c[c2] * (fx1c - fxc - fy1c + fyc);
+    return;
+  }
   {
     // x faces i and i+1 (corner-filled in x), y faces j and j+1 (corner-filled in y)
     double fx1[2], fx[2], fx2[2], fy1[2], fy[2], fy2[2];
@@ -347,8 +379,14 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, double* delpc, double* ptc
   const Regions rb = d2a2c_regions(g);
   hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2,
                      nord > 0 ? 1 : 0, 1, rb);
-  hipLaunchKernelGGL(k_csw_transport, grid, block, 0, st, g, m, delp, pt, w, u, v, ua, va, uc, vc, ut, vt, delpc, ptc, omga, ke,
-                     vort, dt2);
+  Regions rt{};  // interior box + the width-2 frame of the domain [is-1, ie+1] x [js-1, je+1]
+  add_region(rt, g.is + 1, g.ie - 1, g.js + 1, g.je - 1);
+  add_region(rt, g.is - 1, g.is, g.js - 1, g.je + 1);
+  add_region(rt, g.ie, g.ie + 1, g.js - 1, g.je + 1);
+  add_region(rt, g.is + 1, g.ie - 1, g.js - 1, g.js);
+  add_region(rt, g.is + 1, g.ie - 1, g.je, g.je + 1);
+  hipLaunchKernelGGL(k_csw_transport, regions_grid(rt, g.nk), dim3(64, 4), 0, st, g, m, delp, pt, w, u, v, ua, va, uc, vc, ut, vt,
+                     delpc, ptc, omga, ke, vort, dt2, rt);
   hipLaunchKernelGGL(k_csw_update_uc_vc, grid, block, 0, st, g, m, u, v, ke, vort, uc, vc, dt2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
