@@ -35,7 +35,18 @@ emu: tests/emu/libpace_emu.so
 tests/emu/libpace_emu.so: $(EMUOBJS) build/emu/hip_emu.o
 	g++ -shared -fPIC $(EMUOBJS) build/emu/hip_emu.o -o $@
 
-clean:
-	rm -rf build pace_amd/libpace_hip.so tests/emu/libpace_emu.so
+# the same, with 4 x 4 transport / damping tiles and runs of 2 interfaces: at C12 this gives workgroups that touch no tile
+# edge, so the straight-line interior code paths and every tile seam are exercised by the CPU test-suite as well
+SMALLFLAGS := $(EMUFLAGS) -DFV_TI=4 -DFV_TJ=4 -DDN_TI=4 -DDN_TJ=4 -DFV_RF=2
+SMALLOBJS := $(patsubst $(CSRC)/%.hip,build/emu_small/%.o,$(SRCS))
+build/emu_small/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
+	@mkdir -p build/emu_small
+	g++ $(SMALLFLAGS) -c $< -o $@
+emu-small: tests/emu/libpace_emu_small.so
+tests/emu/libpace_emu_small.so: $(SMALLOBJS) build/emu/hip_emu.o
+	g++ -shared -fPIC $(SMALLOBJS) build/emu/hip_emu.o -o $@
 
-.PHONY: all emu clean
+clean:
+	rm -rf build pace_amd/libpace_hip.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so
+
+.PHONY: all emu emu-small clean

@@ -49,7 +49,7 @@ struct FvLds {
 #define RF FV_RF                          // interfaces per thread in a PPM run
 #define GY ((TJ + 1 + RF - 1) / RF)       // runs per column for the TJ+1 y-interfaces
 #define GX ((TI + 1 + RF - 1) / RF)       // runs per row for the TI+1 x-interfaces
-static_assert(QW * GY <= 256 && QH * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
+static_assert(QW * GY <= 256 && QH * GX <= 256 && (TJ + 3) * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
 template <int MORD, bool EX, bool EY, int DMODE, int EPI>
 __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, const Met& m, const double* __restrict__ q,
@@ -70,6 +70,14 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   const long kb = (long)k * g.sk;
   const int ilo = i0 - 3, jlo = j0 - 3;
   const int sj = g.sj;
+  // Thread maps of the outer sweeps (stage 5): the thread that ran the inner x-run of footprint row jj+3 / the inner y-run
+  // of footprint column ii+3 also runs the outer run of tile row jj / tile column ii, so the Courant numbers it loaded
+  // for the inner sweep are reused from registers instead of being fetched a second time (by then evicted from L2).
+  const int x5_row = tid / GX - 3, x5_grp = tid % GX;
+  const bool x5_on = x5_row >= 0 && x5_row < TJ;
+  const int y5_grp = tid / QW, y5_col = tid % QW - 3;
+  const bool y5_on = y5_grp < GY && y5_col >= 0 && y5_col < TI;
+  double cx_keep[RF], cy_keep[RF];
 
   // stage 0: q with corners copied in the y direction (copy_corners_y, corners.py:367-425)
   for (int e = tid; e < QW * QH; e += 256) {
@@ -95,13 +103,13 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     double* sfy = sfx + DH * DWP;
     damp = dp.damp_k[k];
     delnflux_core(g, m, &sq[0][0], sd, sfx, sfy, i0, j0, dp.mass_given ? 1.0 : damp, dp.nord_k[k] > 0.0, dp.nmax);
-    if (tid < TJ * GX) {
-      const int jj = tid / GX, grp = tid - jj * GX;
+    if (x5_on) {
+      const int jj = x5_row, grp = x5_grp;
 #pragma unroll
       for (int f = 0; f < RF; ++f) dvx[f] = (grp * RF + f <= TI) ? sfx[(jj + 3) * DWP + grp * RF + f + 3] : 0.0;
     }
-    if (tid < TI * GY) {
-      const int grp = tid / TI, ii = tid - grp * TI;
+    if (y5_on) {
+      const int grp = y5_grp, ii = y5_col;
 #pragma unroll
       for (int f = 0; f < RF; ++f) dvy[f] = (grp * RF + f <= TJ) ? sfy[(grp * RF + f + 3) * DWP + ii + 3] : 0.0;
     }
@@ -133,6 +141,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
       cc[f] = (col_ok && jj0 + f <= TJ && gj >= g.js && gj <= g.je + 1) ? cry[kb + IDX2(g, gi, gj)] : 0.0;
+      cy_keep[f] = cc[f];
     }
     const double* dya = m.dya;
     const long col = gi;
@@ -190,6 +199,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
       cc[f] = (row_ok && ii0 + f <= TI && gi >= g.is && gi <= g.ie + 1) ? crx[kb + IDX2(g, gi, gj)] : 0.0;
+      cx_keep[f] = cc[f];
     }
     const double* dxa = m.dxa + (long)gj * sj;
     ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return dxa[p]; }, out);
@@ -220,8 +230,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   // N+1-th face row / column (ie+1, je+1) is produced by the workgroup that owns cell ie / je, not by an extra,
   // almost empty row of workgroups.
   double vxf[RF], vyf[RF];  // this thread's final face fluxes (kept for the epilogue)
-  if (tid < TJ * GX) {  // outer x on q_i: rows of the tile, runs of x-interfaces
-    const int jj = tid / GX, grp = tid - jj * GX;
+  if (x5_on) {  // outer x on q_i: rows of the tile, runs of x-interfaces
+    const int jj = x5_row, grp = x5_grp;
     const int ii0 = grp * RF;
     const int gi0 = i0 + ii0, gj = j0 + jj;
     double Q[RF + 5], cc[RF], xu[RF], out[RF];
@@ -234,7 +244,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       calc[f] = gj <= g.je && gi <= g.ie + 1 && ii <= TI;
       if (EPI == 0) calc[f] = calc[f] && (ii < TI || gi == g.ie + 1);  // a neighbour stores its own west face
       const long c = kb + IDX2(g, gi, gj);
-      cc[f] = calc[f] ? crx[c] : 0.0;
+      cc[f] = calc[f] ? cx_keep[f] : 0.0;  // = crx[c], loaded by this thread for the inner sweep of the same row
       xu[f] = calc[f] ? xunit[c] : 0.0;
     }
     const double* dxa = m.dxa + (long)gj * sj;
@@ -256,8 +266,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       }
     }
   }
-  if (tid < TI * GY) {  // outer y on q_j: columns of the tile, runs of y-interfaces, lanes along i
-    const int grp = tid / TI, ii = tid - grp * TI;
+  if (y5_on) {  // outer y on q_j: columns of the tile, runs of y-interfaces, lanes along i
+    const int grp = y5_grp, ii = y5_col;
     const int jj0 = grp * RF;
     const int gi = i0 + ii, gj0 = j0 + jj0;
     double Q[RF + 5], cc[RF], yu[RF], out[RF];
@@ -270,7 +280,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       calc[f] = gi <= g.ie && gj <= g.je + 1 && jj <= TJ;
       if (EPI == 0) calc[f] = calc[f] && (jj < TJ || gj == g.je + 1);
       const long c = kb + IDX2(g, gi, gj);
-      cc[f] = calc[f] ? cry[c] : 0.0;
+      cc[f] = calc[f] ? cy_keep[f] : 0.0;  // = cry[c]
       yu[f] = calc[f] ? yunit[c] : 0.0;
     }
     const double* dya = m.dya;
@@ -302,8 +312,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     double* ay2 = ax2 + TJ * AXP;
     static_assert(EPI == 0 || 2 * (TJ * AXP + (TJ + 1) * AYP) <= FvLds<DMODE, EPI>::kSweep + FvLds<DMODE, EPI>::kPad, "epilogue scratch");
     __syncthreads();
-    if (tid < TJ * GX) {
-      const int jj = tid / GX, grp = tid - jj * GX;
+    if (x5_on) {
+      const int jj = x5_row, grp = x5_grp;
 #pragma unroll
       for (int f = 0; f < RF; ++f) {
         if (grp * RF + f <= TI) {
@@ -312,8 +322,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
         }
       }
     }
-    if (tid < TI * GY) {
-      const int grp = tid / TI, ii = tid - grp * TI;
+    if (y5_on) {
+      const int grp = y5_grp, ii = y5_col;
 #pragma unroll
       for (int f = 0; f < RF; ++f) {
         if (grp * RF + f <= TJ) {

@@ -61,6 +61,13 @@ def build_emu():
     return path
 
 
+def build_emu_small():
+    """tests/emu/libpace_emu_small.so: the emulation build with 4 x 4 LDS tiles (interior code paths at C12)."""
+    path = os.path.join(ROOT, "tests", "emu", "libpace_emu_small.so")
+    subprocess.run(["make", "-s", "-j4", "emu-small"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+    return path
+
+
 class Env:
     """Everything a test needs to call the host classes on one device."""
 

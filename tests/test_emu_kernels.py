@@ -5,7 +5,7 @@ build, which the `-m gpu` tests cover.  CPU only."""
 import numpy as np
 import pytest
 
-from helpers import (DSW_ARGS, Env, acoustic_errors, check_tracer_outputs, run_acoustic_six_tiles, run_tracer_six_tiles, build_emu, column_for_levels, compare, dsw_window, expand_riem_fixture, golden, run_d_sw,
+from helpers import (DSW_ARGS, Env, build_emu_small, oracle_grid, acoustic_errors, check_tracer_outputs, run_acoustic_six_tiles, run_tracer_six_tiles, build_emu, column_for_levels, compare, dsw_window, expand_riem_fixture, golden, run_d_sw,
                      run_riem3, window)
 
 
@@ -78,3 +78,50 @@ def test_tracer_advection_six_tiles_emulated(emu_lib):
     reference's own run (tools/make_golden_tracer.py): bit for bit -- no transcendental is involved."""
     fixes, outs = run_tracer_six_tiles(emu_lib, "cpu")
     check_tracer_outputs(fixes, outs)
+
+
+@pytest.fixture(scope="module")
+def emu_small_lib():
+    from pace_amd import _lib
+
+    return _lib.Library(build_emu_small())
+
+
+@pytest.mark.parametrize("name,tile", [("d_sw_c12_tile0_call1.npz", 0), ("d_sw_c12_tile1_call3.npz", 1)])
+def test_d_sw_small_tiles_bit_exact(emu_small_lib, name, tile):
+    """4 x 4 tiles: 3 x 3 workgroups per level at C12, the middle one runs the interior (no edge logic) variants of the
+    transport / damping kernels; every tile seam is crossed.  Must equal the reference run bit for bit like the big tiles."""
+    fix = golden(name)
+    k_sel = fix["k_sel"]
+    nk = len(k_sel)
+    env = Env(emu_small_lib, "cpu", golden(f"grid_c12_tile{tile}.npz"), 12, nk)
+    out, _ = run_d_sw(env, column_for_levels(k_sel), {k: fix["in_" + k] for k in DSW_ARGS}, float(fix["dt"]),
+                      ut0=fix["in_uc_contra"], vt0=fix["in_vc_contra"])
+    for k in DSW_ARGS:
+        if k in ("divgd", "uc", "vc", "zh"):
+            continue
+        err = compare(fix["out_" + k][dsw_window(k, 12, nk)], out[k][dsw_window(k, 12, nk)])
+        assert err < 3.2e-10, (k, err)
+
+
+@pytest.mark.parametrize("which", ["big", "small"])
+def test_ord8_transport_emulated_vs_oracle(emu_lib, emu_small_lib, which):
+    """Monotone (ord 8) PPM transport against the oracle, bit for bit, with both tilings."""
+    from oracle import ppm_transport as tr
+    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
+
+    lib = emu_lib if which == "big" else emu_small_lib
+    fix = golden("fvtp2d_c12_tile0_call8.npz")
+    nk = len(golden("d_sw_c12_tile0_call1.npz")["k_sel"])
+    metrics = golden("grid_c12_tile1.npz")
+    env = Env(lib, "cpu", metrics, 12, nk)
+    g = oracle_grid(metrics, 12, nk)
+    op = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 8)
+    f = {k[3:]: env.q3(v) for k, v in fix.items() if k.startswith("in_")}
+    fx, fy = env.q3(), env.q3()
+    op(f["q"], f["crx"], f["cry"], f["x_area_flux"], f["y_area_flux"], fx, fy, x_mass_flux=f["x_mass_flux"], y_mass_flux=f["y_mass_flux"])
+    ofx, ofy = np.zeros_like(fix["in_q"]), np.zeros_like(fix["in_q"])
+    tr.fvtp2d(g, fix["in_q"].copy(), fix["in_crx"], fix["in_cry"], fix["in_x_area_flux"], fix["in_y_area_flux"], ofx, ofy, 8,
+              x_mass_flux=fix["in_x_mass_flux"], y_mass_flux=fix["in_y_mass_flux"])
+    assert np.array_equal(ofx[window(12, 1, 0, nk)], fx.numpy()[window(12, 1, 0, nk)])
+    assert np.array_equal(ofy[window(12, 0, 1, nk)], fy.numpy()[window(12, 0, 1, nk)])
