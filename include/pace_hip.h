@@ -206,6 +206,10 @@ int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* wor
 /* ---- dyn_core.py stencils: gz_from_surface_height_and_thicknesses (:83-96, compute domain),
  * compute_geopotential (:115-117, halo 2, nk+1 levels), basic.copy_defn as used at dyn_core.py:773-781
  * (full domain, nk+1 levels), p_grad_c_stencil (:120-171, hydrostatic = False). */
+int pace_zero_data(const pace_geom_t* geom, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source,
+                   double* diss_estd, int first_timestep, void* stream);                           /* dyn_core.py:51-80 */
+int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const double* delp, double* pem,
+                                                            double ptop, void* stream);              /* :99-112 */
 int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const double* zs, const double* delz,
                                                 double* gz, void* stream);
 int pace_compute_geopotential(const pace_geom_t* geom, const double* zh, double* gz, void* stream);

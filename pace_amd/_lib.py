@@ -100,6 +100,8 @@ _PROTOS = {
     "pace_updatedzc": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 7 + [C.c_double, C.c_void_p]),
     "pace_updatedzd_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_updatedzd": (C.c_int, [_P(Geom), _P(Metrics), c_dp, _P(UpdatedzdK)] + [c_dp] * 7 + [C.c_double, C.c_int, C.c_void_p]),
+    "pace_zero_data": (C.c_int, [_P(Geom)] + [c_dp] * 6 + [C.c_int, C.c_void_p]),
+    "pace_interface_pressure_from_toa_pressure_and_thickness": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_double, C.c_void_p]),
     "pace_gz_from_surface_height_and_thicknesses": (C.c_int, [_P(Geom), c_dp, c_dp, c_dp, C.c_void_p]),
     "pace_compute_geopotential": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_void_p]),
     "pace_copy": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_void_p]),

@@ -185,6 +185,18 @@ int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* wor
                           x_area_flux, y_area_flux, ws, dt, hord_tm, S(stream));
 }
 
+int pace_zero_data(const pace_geom_t* geom, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source,
+                   double* diss_estd, int first_timestep, void* stream) {
+  NEED(geom && mfxd && mfyd && cxd && cyd && heat_source && diss_estd);
+  return launch_zero_data(make_geo(geom), mfxd, mfyd, cxd, cyd, heat_source, diss_estd, first_timestep, S(stream));
+}
+
+int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const double* delp, double* pem,
+                                                            double ptop, void* stream) {
+  NEED(geom && delp && pem);
+  return launch_interface_pressure(make_geo(geom), delp, pem, ptop, S(stream));
+}
+
 int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const double* zs, const double* delz,
                                                 double* gz, void* stream) {
   NEED(geom && zs && delz && gz);

@@ -323,6 +323,17 @@ void pace_set_err(const char* where, hipError_t e);
 static inline dim3 plane_grid(const Geo& g, int nlev) {
   return dim3((unsigned)(((long)g.sj * g.nj + 255) / 256), (unsigned)nlev, 1);
 }
+// 2-D patches for point kernels that read a (j+1) or (j-1) neighbour: a 64 x 4 patch per workgroup serves three of four
+// such reads from the same workgroup's cache lines; with the flattened map below every row is fetched twice (the
+// neighbouring row belongs to a workgroup on another XCD).  Launch with dim3(64, 4) threads.
+static inline dim3 patch_grid(const Geo& g, int nlev) {
+  return dim3((unsigned)((g.ni + 63) / 64), (unsigned)((g.nj + 3) / 4), (unsigned)nlev);
+}
+#define PATCH_IJK(g)                                              \
+  const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;          \
+  const int j = (int)blockIdx.y * 4 + (int)threadIdx.y;           \
+  const int k = (int)blockIdx.z;                                  \
+  if (j >= (g).nj || i >= (g).ni) return;
 // flattened plane index -> (i, j); returns false for pad lanes / out of plane
 #define PLANE_IJK(g)                                                  \
   const long p__ = (long)blockIdx.x * 256 + threadIdx.x;             \

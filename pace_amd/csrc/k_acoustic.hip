@@ -258,6 +258,51 @@ k_gz_from_surface(Geo g, const double* __restrict__ zs, const double* __restrict
   }
 }
 
+// zero_data (dyn_core.py:51-80): the flux accumulators on the full domain, the heat terms on the compute domain
+__global__ void __launch_bounds__(256)
+k_zero_data(Geo g, double* __restrict__ mfxd, double* __restrict__ mfyd, double* __restrict__ cxd, double* __restrict__ cyd,
+            double* __restrict__ heat_source, double* __restrict__ diss_estd, int first_timestep) {
+  PLANE_IJK(g);
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const long c = IDX3(g, i, j, k);
+  mfxd[c] = 0.0;
+  mfyd[c] = 0.0;
+  cxd[c] = 0.0;
+  cyd[c] = 0.0;
+  if (first_timestep && i >= g.is && i <= g.ie && j >= g.js && j <= g.je) {
+    heat_source[c] = 0.0;
+    diss_estd[c] = 0.0;
+  }
+}
+
+// interface_pressure_from_toa_pressure_and_thickness (dyn_core.py:99-112), compute domain +- 1
+__global__ void __launch_bounds__(64)
+k_interface_pressure(Geo g, const double* __restrict__ delp, double* __restrict__ pem, double ptop) {
+  const int i = g.is - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.js - 1 + blockIdx.y;
+  if (i > g.ie + 1 || j > g.je + 1) return;
+  const long c0 = IDX2(g, i, j);
+  double p = ptop;
+  pem[c0] = p;
+  for (int k = 1; k < g.nk; ++k) {
+    p = p + delp[c0 + (long)k * g.sk];
+    pem[c0 + (long)k * g.sk] = p;
+  }
+}
+
+int launch_zero_data(const Geo& g, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source, double* diss_estd,
+                     int first_timestep, hipStream_t st) {
+  hipLaunchKernelGGL(k_zero_data, plane_grid(g, g.nk), dim3(256), 0, st, g, mfxd, mfyd, cxd, cyd, heat_source, diss_estd,
+                     first_timestep);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+int launch_interface_pressure(const Geo& g, const double* delp, double* pem, double ptop, hipStream_t st) {
+  hipLaunchKernelGGL(k_interface_pressure, dim3((g.n + 2 + 63) / 64, g.n + 2), dim3(64), 0, st, g, delp, pem, ptop);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
 // dst = src * factor on the window [i0, i1] x [j0, j1], nlev levels: copy_defn (basic_operations.py:7, factor 1)
 // and compute_geopotential (dyn_core.py:115-117, factor GRAV)
 __global__ void __launch_bounds__(256)

@@ -23,7 +23,7 @@ k_finish_scalars(Geo g, Met m, double* __restrict__ pt, double* __restrict__ del
                  double* __restrict__ q_con, const double* __restrict__ ptn, const double* __restrict__ wn,
                  const double* __restrict__ qn, const double* __restrict__ fx, const double* __restrict__ fy,
                  const double* __restrict__ dw, const double* __restrict__ damp_w) {
-  PLANE_IJK(g);
+  PATCH_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
   const double dn = delp[c] + (fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) * m.rarea[IDX2(g, i, j)];
@@ -141,7 +141,7 @@ k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __re
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
 __global__ void __launch_bounds__(256)
 k_vorticity(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ vort) {
-  PLANE_IJK(g);
+  PATCH_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -496,7 +496,7 @@ k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* 
 __global__ void __launch_bounds__(256)
 k_uv_from_ke(Geo g, Met m, double* __restrict__ u, double* __restrict__ v, const double* __restrict__ ke,
              const double* __restrict__ fx, const double* __restrict__ fy) {
-  PLANE_IJK(g);
+  PATCH_IJK(g);
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je + 1) u[c] = u[c] * m.dx[c2] + ke[c] - ke[c + 1] + fy[c];
@@ -532,7 +532,7 @@ k_heat_source(Geo g, Met m, const double* __restrict__ u, const double* __restri
               const double* __restrict__ vort_b, const double* __restrict__ ut2, const double* __restrict__ vt2,
               const double* __restrict__ delp, double* __restrict__ heat_s, double* __restrict__ heat_source,
               double* __restrict__ diss_est, const double* __restrict__ d_con_k, double d_con, int do_skeb) {
-  PLANE_IJK(g);
+  PATCH_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -688,7 +688,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     // pt -> W.fx2
     dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.qout = W.fx2;
     if ((rc = launch_transport(g, m, pt, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_tm, nk, 2, 1, dp, st))) return rc;
-    hipLaunchKernelGGL(k_finish_scalars, gk, block, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
+    hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   }
   if (phases & 4) {
@@ -701,7 +701,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_vorticity, gk, block, 0, st, g, m, u, v, W.wk);
+  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, u, v, W.wk);
   // divergence damping
   if (kstart > 0) {
     hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), block, 0, st, g, m, u, v, ua, va, uc, vc, delpc, W.vort_b, W.ke,
@@ -733,10 +733,10 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     dp.fx2o = W.ut2; dp.fy2o = W.vt2; dp.add2d = m.fC_agrid;
     if ((rc = launch_transport(g, m, W.wk, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, 0, 0, dp, st))) return rc;
   }
-  hipLaunchKernelGGL(k_uv_from_ke, gk, block, 0, st, g, m, u, v, W.ke, W.fy2, W.fyv);
+  hipLaunchKernelGGL(k_uv_from_ke, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, u, v, W.ke, W.fy2, W.fyv);
   }
   if (phases & 8) {
-  hipLaunchKernelGGL(k_heat_source, gk, block, 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,
+  hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,
                      d_dcon, cfg->d_con, cfg->do_skeb);
   hipLaunchKernelGGL(k_update_uv, gk, block, 0, st, g, u, v, W.ut2, W.vt2, d_damp_vt_c);
   }

@@ -103,3 +103,6 @@ int launch_apply_mass_flux(const Geo& g, const Met& m, const double* dp1, const 
 int launch_apply_tracer_flux(const Geo& g, const Met& m, double* q, const double* dp1, const double* fx, const double* fy,
                              const double* dp2, hipStream_t st);
 int launch_swap_dp(const Geo& g, double* dp1, double* dp2, hipStream_t st);
+int launch_zero_data(const Geo& g, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source, double* diss_estd,
+                     int first_timestep, hipStream_t st);
+int launch_interface_pressure(const Geo& g, const double* delp, double* pem, double ptop, hipStream_t st);

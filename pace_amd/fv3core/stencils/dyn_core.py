@@ -143,12 +143,8 @@ class AcousticDynamics(Operator):
 
     # ---- the one-launch dyn_core stencils -------------------------------------------------------------
     def _zero_data(self, mfxd, mfyd, cxd, cyd, heat_source, diss_estd, first_timestep: bool):
-        """zero_data (dyn_core.py:51-80): full domain for the flux accumulators, compute domain for the heat terms."""
-        for q in (mfxd, mfyd, cxd, cyd):
-            q.data[:-1, :-1, :-1] = 0.0
-        if first_timestep:
-            for q in (heat_source, diss_estd):
-                q.data[3:-4, 3:-4, :-1] = 0.0
+        self.call("pace_zero_data", dptr(mfxd), dptr(mfyd), dptr(cxd), dptr(cyd), dptr(heat_source), dptr(diss_estd),
+                  int(bool(first_timestep)), self.stream())
 
     def _gz_from_surface_height_and_thickness(self, zs, delz, gz):
         self.call("pace_gz_from_surface_height_and_thicknesses", dptr(zs), dptr(delz), dptr(gz), self.stream())
@@ -167,9 +163,7 @@ class AcousticDynamics(Operator):
         self.call("pace_edge_pe", dptr(pe), dptr(delp), float(ptop), self.stream())
 
     def _interface_pressure_from_toa_pressure_and_thickness(self, delp, pem, ptop):
-        """dyn_core.py:99-112 on compute +- 1 (only its result `pem` is never read again on this path)."""
-        pem.data[2:-3, 2:-3, 0] = ptop
-        pem.data[2:-3, 2:-3, 1:-1] = ptop + delp.data[2:-3, 2:-3, 1:-1].cumsum(dim=2)
+        self.call("pace_interface_pressure_from_toa_pressure_and_thickness", dptr(delp), dptr(pem), float(ptop), self.stream())
 
     def _apply_diffusive_heating(self, delp, delz, cappa, heat_source, pt, delt_time_factor):
         self.call("pace_apply_diffusive_heating", dptr(delp), dptr(delz), dptr(cappa), dptr(heat_source), dptr(pt),

@@ -7,7 +7,7 @@
 import numpy as np
 import pytest
 
-from helpers import (acoustic_errors, check_tracer_outputs, run_acoustic_six_tiles, run_tracer_six_tiles, DSW_ARGS, DSW_CFG, RIEM_ARGS, Env, column_for_levels, compare, dsw_window, expand_riem_fixture, golden,
+from helpers import (acoustic_errors, check_tracer_outputs, run_in_child, DSW_ARGS, DSW_CFG, RIEM_ARGS, Env, column_for_levels, compare, dsw_window, expand_riem_fixture, golden,
                      oracle_grid, run_d_sw, run_riem3, window)
 
 pytestmark = pytest.mark.gpu
@@ -152,14 +152,14 @@ def test_c192_properties(lib):
     np.testing.assert_allclose(dm / total, boundary / total, rtol=0, atol=1e-12)
 
 
-def test_acoustic_dynamics_six_tiles_matches_reference_run(lib):
+def test_acoustic_dynamics_six_tiles_matches_reference_run(lib, tmp_path):
     """One whole AcousticDynamics call (n_split = 2, every operator of the loop and all halo-update groups) for the six C12
     tiles resident on one device, against the reference run's output.  Tolerance: see
     test_emu_kernels.test_acoustic_dynamics_six_tiles_emulated."""
     import json
     import os
 
-    fixes, outs = run_acoustic_six_tiles(lib, "cuda")
+    fixes, outs = run_in_child("acoustic", tmp_path)
     errs = [acoustic_errors(fixes[t], outs[t]) for t in range(6)]
     worst = {k: max(e[k] for e in errs) for k in errs[0]}
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -220,10 +220,10 @@ def test_fused_transport_update_matches_oracle_c96(lib):
     assert np.array_equal(expect[W], out.numpy()[W])
 
 
-def test_tracer_advection_six_tiles_matches_reference_run(lib):
+def test_tracer_advection_six_tiles_matches_reference_run(lib, tmp_path):
     """TracerAdvection (k_fvtp2d<8, -1, 0> + the tracer_2d_1l stencils + tracer halo updates), six tiles on one device,
     against the reference's own run: bit for bit."""
-    fixes, outs = run_tracer_six_tiles(lib, "cuda")
+    fixes, outs = run_in_child("tracer", tmp_path)
     check_tracer_outputs(fixes, outs)
 
 

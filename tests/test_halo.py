@@ -96,15 +96,25 @@ def test_halo_updates_six_tiles_on_threads():
 
 
 @pytest.mark.gpu
-def test_halo_updates_six_tiles_on_one_gpu():
-    """The gfx950 pack/unpack kernels: six tiles resident on one device, one host thread per tile."""
-    from pace_amd import _lib
-    from pace_amd.util import run_tiles
+def test_halo_updates_six_tiles_on_one_gpu(tmp_path):
+    """The gfx950 pack/unpack kernels: six tiles resident on one device, one host thread per tile (in a child process,
+    see helpers.run_in_child for why)."""
+    import pickle
 
-    lib = _lib.load()
-    base = _base()
-    results = run_tiles(6, lambda comm: tile_program(comm, lib, base, device="cuda"))
-    _check(results, base)
+    script = tmp_path / "halo_gpu.py"
+    out = tmp_path / "halo_gpu.pkl"
+    script.write_text(
+        f"import sys, pickle\nsys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import test_halo\nfrom pace_amd import _lib\nfrom pace_amd.util import run_tiles\n"
+        "lib = _lib.load(); base = test_halo._base()\n"
+        "res = run_tiles(6, lambda comm: test_halo.tile_program(comm, lib, base, device='cuda'))\n"
+        f"pickle.dump(res, open({str(out)!r}, 'wb'))\n")
+    for attempt in range(2):
+        p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+        if p.returncode == 0:
+            break
+        assert (p.returncode < 0 or p.returncode in (134, 139)) and attempt == 0, p.stderr[-3000:]
+    _check(pickle.load(open(out, "rb")), _base())
 
 
 _WORKER = r"""
