@@ -39,7 +39,7 @@ k_tracer_divide(Geo g, double* __restrict__ a0, double* __restrict__ a1, double*
 __global__ void __launch_bounds__(256)
 k_apply_mass_flux(Geo g, Met m, const double* __restrict__ dp1, const double* __restrict__ mfx, const double* __restrict__ mfy,
                   double* __restrict__ dp2) {
-  PLANE_IJK(g);
+  PATCH_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
   dp2[c] = dp1[c] + (mfx[c] - mfx[c + 1] + mfy[c] - mfy[c + g.sj]) * m.rarea[IDX2(g, i, j)];
@@ -49,7 +49,7 @@ k_apply_mass_flux(Geo g, Met m, const double* __restrict__ dp1, const double* __
 __global__ void __launch_bounds__(256)
 k_apply_tracer_flux(Geo g, Met m, double* __restrict__ q, const double* __restrict__ dp1, const double* __restrict__ fx,
                     const double* __restrict__ fy, const double* __restrict__ dp2) {
-  PLANE_IJK(g);
+  PATCH_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
   q[c] = (q[c] * dp1[c] + (fx[c] - fx[c + 1] + fy[c] - fy[c + g.sj]) * m.rarea[IDX2(g, i, j)]) / dp2[c];
@@ -79,13 +79,13 @@ int launch_tracer_divide(const Geo& g, double* cxd, double* xfx, double* mfxd, d
 }
 int launch_apply_mass_flux(const Geo& g, const Met& m, const double* dp1, const double* mfx, const double* mfy, double* dp2,
                            hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_mass_flux, plane_grid(g, g.nk), dim3(256), 0, st, g, m, dp1, mfx, mfy, dp2);
+  hipLaunchKernelGGL(k_apply_mass_flux, patch_grid(g, g.nk), dim3(64, 4), 0, st, g, m, dp1, mfx, mfy, dp2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
 int launch_apply_tracer_flux(const Geo& g, const Met& m, double* q, const double* dp1, const double* fx, const double* fy,
                              const double* dp2, hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_tracer_flux, plane_grid(g, g.nk), dim3(256), 0, st, g, m, q, dp1, fx, fy, dp2);
+  hipLaunchKernelGGL(k_apply_tracer_flux, patch_grid(g, g.nk), dim3(64, 4), 0, st, g, m, q, dp1, fx, fy, dp2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
