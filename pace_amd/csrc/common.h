@@ -326,12 +326,17 @@ static inline dim3 plane_grid(const Geo& g, int nlev) {
 // 2-D patches for point kernels that read a (j+1) or (j-1) neighbour: a 64 x 4 patch per workgroup serves three of four
 // such reads from the same workgroup's cache lines; with the flattened map below every row is fetched twice (the
 // neighbouring row belongs to a workgroup on another XCD).  Launch with dim3(64, 4) threads.
+#ifndef PATCH_W
+#define PATCH_W 64
+#endif
+#define PATCH_H (256 / PATCH_W)
+#define PATCH_BLOCK dim3(PATCH_W, PATCH_H)
 static inline dim3 patch_grid(const Geo& g, int nlev) {
-  return dim3((unsigned)((g.ni + 63) / 64), (unsigned)((g.nj + 3) / 4), (unsigned)nlev);
+  return dim3((unsigned)((g.ni + PATCH_W - 1) / PATCH_W), (unsigned)((g.nj + PATCH_H - 1) / PATCH_H), (unsigned)nlev);
 }
 #define PATCH_IJK(g)                                              \
-  const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;          \
-  const int j = (int)blockIdx.y * 4 + (int)threadIdx.y;           \
+  const int i = (int)blockIdx.x * PATCH_W + (int)threadIdx.x;     \
+  const int j = (int)blockIdx.y * PATCH_H + (int)threadIdx.y;     \
   const int k = (int)blockIdx.z;                                  \
   if (j >= (g).nj || i >= (g).ni) return;
 // flattened plane index -> (i, j); returns false for pad lanes / out of plane

@@ -108,7 +108,7 @@ int launch_updatedzc(const Geo& g, const Met& m, void* ws_, const double* dp_ref
                      const double* vt, double* gz, double* ws, double dt, hipStream_t st) {
   if (g.nk < 3) return PACE_ERR_UNSUPPORTED;
   double* gz_new = (double*)ws_;
-  hipLaunchKernelGGL(k_updatedzc_advect, patch_grid(g, g.nk + 1), dim3(64, 4), 0, st, g, m, dp_ref, ut, vt, gz, gz_new);
+  hipLaunchKernelGGL(k_updatedzc_advect, patch_grid(g, g.nk + 1), PATCH_BLOCK, 0, st, g, m, dp_ref, ut, vt, gz, gz_new);
   hipLaunchKernelGGL(k_updatedzc_column, dim3((g.n + 2 + 63) / 64, g.n + 2), dim3(64), 0, st, g, zs, gz_new, gz, ws, 1.0 / dt);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
@@ -234,7 +234,7 @@ int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd
   int rc;
   if ((rc = launch_fvtp2d(g, m, zh, crx_i, cry_i, xfx_i, yfx_i, fx, fy, nullptr, nullptr, hord_tm, g.nk + 1, st))) return rc;
   if ((rc = launch_delnflux(g, m, 0, zh, fx2, fy2, nullptr, kc->damp, kc->nord, kc->nmax, 0, g.nk + 1, st))) return rc;
-  hipLaunchKernelGGL(k_apply_height_fluxes, patch_grid(g, g.nk + 1), dim3(64, 4), 0, st, g, m, zh, fx, fy, xfx_i, yfx_i, fx2, fy2);
+  hipLaunchKernelGGL(k_apply_height_fluxes, patch_grid(g, g.nk + 1), PATCH_BLOCK, 0, st, g, m, zh, fx, fy, xfx_i, yfx_i, fx2, fy2);
   hipLaunchKernelGGL(k_height_column, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, zs, zh, wsd, dt);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
@@ -344,7 +344,7 @@ int launch_scale_copy(const Geo& g, const double* src, double* dst, double facto
 }
 int launch_p_grad_c(const Geo& g, const Met& m, double* uc, double* vc, const double* delpc, const double* pkc,
                     const double* gz, double dt2, hipStream_t st) {
-  hipLaunchKernelGGL(k_p_grad_c, patch_grid(g, g.nk), dim3(64, 4), 0, st, g, m, uc, vc, delpc, pkc, gz, dt2);
+  hipLaunchKernelGGL(k_p_grad_c, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, uc, vc, delpc, pkc, gz, dt2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
@@ -407,7 +407,7 @@ int launch_nh_p_grad(const Geo& g, const Met& m, void* ws_, double* u, double* v
   if ((rc = launch_a2b_ord4(g, m, delp, wk1, 0, g.nk, 0, st))) return rc;
   const double top_value = pow(ptop, akap);
   hipLaunchKernelGGL(k_nh_set_top, plane_grid(g, 1), dim3(256), 0, st, g, pp, pk3, top_value);
-  hipLaunchKernelGGL(k_nh_uv, patch_grid(g, g.nk), dim3(64, 4), 0, st, g, m, u, v, wk1, gz, pk3, pp, dt);
+  hipLaunchKernelGGL(k_nh_uv, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, u, v, wk1, gz, pk3, pp, dt);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
@@ -631,7 +631,7 @@ int launch_del2cubed(const Geo& g, const Met& m, void* ws_, double* qdel, double
   double* dst = scratch;
   const dim3 grid = plane_grid(g, g.nk), block(256);
   for (int n = 0; n < ntimes; ++n) {
-    hipLaunchKernelGGL(k_del2cubed_iter, patch_grid(g, g.nk), dim3(64, 4), 0, st, g, m, src, dst, cd, ntimes - (n + 1));
+    hipLaunchKernelGGL(k_del2cubed_iter, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, src, dst, cd, ntimes - (n + 1));
     double* t = src;
     src = dst;
     dst = t;

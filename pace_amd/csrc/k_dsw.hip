@@ -688,7 +688,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     // pt -> W.fx2
     dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.qout = W.fx2;
     if ((rc = launch_transport(g, m, pt, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_tm, nk, 2, 1, dp, st))) return rc;
-    hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
+    hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   }
   if (phases & 4) {
@@ -701,7 +701,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, u, v, W.wk);
+  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
   // divergence damping
   if (kstart > 0) {
     hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), block, 0, st, g, m, u, v, ua, va, uc, vc, delpc, W.vort_b, W.ke,
@@ -733,10 +733,10 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     dp.fx2o = W.ut2; dp.fy2o = W.vt2; dp.add2d = m.fC_agrid;
     if ((rc = launch_transport(g, m, W.wk, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, 0, 0, dp, st))) return rc;
   }
-  hipLaunchKernelGGL(k_uv_from_ke, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, u, v, W.ke, W.fy2, W.fyv);
+  hipLaunchKernelGGL(k_uv_from_ke, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.ke, W.fy2, W.fyv);
   }
   if (phases & 8) {
-  hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), dim3(64, 4), 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,
+  hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,
                      d_dcon, cfg->d_con, cfg->do_skeb);
   hipLaunchKernelGGL(k_update_uv, gk, block, 0, st, g, u, v, W.ut2, W.vt2, d_damp_vt_c);
   }

@@ -79,13 +79,13 @@ int launch_tracer_divide(const Geo& g, double* cxd, double* xfx, double* mfxd, d
 }
 int launch_apply_mass_flux(const Geo& g, const Met& m, const double* dp1, const double* mfx, const double* mfy, double* dp2,
                            hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_mass_flux, patch_grid(g, g.nk), dim3(64, 4), 0, st, g, m, dp1, mfx, mfy, dp2);
+  hipLaunchKernelGGL(k_apply_mass_flux, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, dp1, mfx, mfy, dp2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
 int launch_apply_tracer_flux(const Geo& g, const Met& m, double* q, const double* dp1, const double* fx, const double* fy,
                              const double* dp2, hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_tracer_flux, patch_grid(g, g.nk), dim3(64, 4), 0, st, g, m, q, dp1, fx, fy, dp2);
+  hipLaunchKernelGGL(k_apply_tracer_flux, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, q, dp1, fx, fy, dp2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
