@@ -49,6 +49,9 @@ struct FvLds {
 #define RF FV_RF                          // interfaces per thread in a PPM run
 #define GY ((TJ + 1 + RF - 1) / RF)       // runs per column for the TJ+1 y-interfaces
 #define GX ((TI + 1 + RF - 1) / RF)       // runs per row for the TI+1 x-interfaces
+// whether a y-run can reach past the last footprint row (then its row index is clamped); not at the production shape
+constexpr bool kClampY = (GY - 1) * RF + RF + 4 >= QH;
+static_assert((GX - 1) * RF + RF + 4 < 2 * (QW + 1), "an x-run may overrun its row by less than one row");
 static_assert(QW * GY <= 256 && QH * GX <= 256 && (TJ + 3) * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
 template <int MORD, bool EX, bool EY, int DMODE, int EPI>
@@ -84,8 +87,10 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int jj = e / QW, ii = e - jj * QW;
     int gi = ilo + ii, gj = jlo + jj;
     double v = 0.0;
-    if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj) {
-      remap_agrid_y(g, gi, gj);
+    // (a workgroup with EX false has its whole footprint inside the compute domain in x, likewise EY in y; corner cells
+    // -- outside in both -- exist only for EX && EY)
+    if ((!EX || (gi >= 0 && gi < g.ni)) && (!EY || (gj >= 0 && gj < g.nj))) {
+      if (EX && EY) remap_agrid_y(g, gi, gj);
       v = q[kb + IDX2(g, gi, gj)];
     }
     sq[jj][ii] = v;
@@ -119,8 +124,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     for (int e = tid; e < QW * QH; e += 256) {
       const int jj = e / QW, ii = e - jj * QW;
       int gi = ilo + ii, gj = jlo + jj;
-      if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj) {
-        remap_agrid_y(g, gi, gj);
+      if ((!EX || (gi >= 0 && gi < g.ni)) && (!EY || (gj >= 0 && gj < g.nj))) {
+        if (EX && EY) remap_agrid_y(g, gi, gj);
         sq[jj][ii] = sq[jj][ii] + dp.add2d[IDX2(g, gi, gj)];
       }
     }
@@ -133,14 +138,14 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int grp = tid / QW, ii = tid - grp * QW;
     const int jj0 = grp * RF;
     const int gi = ilo + ii, gj0 = j0 + jj0;
-    const bool col_ok = gi >= 0 && gi <= g.ni - 1;
+    const bool col_ok = !EX || (gi >= 0 && gi <= g.ni - 1);
     double Q[RF + 5], cc[RF], out[RF];
 #pragma unroll
-    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[(jj0 + u < QH) ? jj0 + u : QH - 1][ii];  // rows gj0-3 ..
+    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[kClampY ? ((jj0 + u < QH) ? jj0 + u : QH - 1) : jj0 + u][ii];  // rows gj0-3 ..
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
-      cc[f] = (col_ok && jj0 + f <= TJ && gj >= g.js && gj <= g.je + 1) ? cry[kb + IDX2(g, gi, gj)] : 0.0;
+      cc[f] = (col_ok && jj0 + f <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1))) ? cry[kb + IDX2(g, gi, gj)] : 0.0;
       cy_keep[f] = cc[f];
     }
     const double* dya = m.dya;
@@ -149,7 +154,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
-      if (jj0 + f <= TJ) syin[jj0 + f][ii] = (col_ok && gj >= g.js && gj <= g.je + 1) ? out[f] : 0.0;
+      if (jj0 + f <= TJ) syin[jj0 + f][ii] = (col_ok && (!EY || (gj >= g.js && gj <= g.je + 1))) ? out[f] : 0.0;
     }
   }
   __syncthreads();
@@ -159,7 +164,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int jj = e / QW, ii = e - jj * QW;
     const int gi = ilo + ii, gj = j0 + jj;
     double val = 0.0;
-    if (gi >= 0 && gi <= g.ni - 1 && gj >= g.js && gj <= g.je) {
+    if ((!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je))) {
       const long c2 = IDX2(g, gi, gj);
       const double y0 = yfx[kb + c2], y1 = yfx[kb + c2 + g.sj];
       const double a = m.area[c2];
@@ -191,14 +196,17 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int jj = tid / GX, grp = tid - jj * GX;
     const int ii0 = grp * RF;
     const int gi0 = i0 + ii0, gj = jlo + jj;
-    const bool row_ok = gj >= 0 && gj <= g.nj - 1;
+    const bool row_ok = !EY || (gj >= 0 && gj <= g.nj - 1);
     double Q[RF + 5], cc[RF], out[RF];
+    // (no clamp of the column index: a run that sticks out of the row reads the pad column / the first element of the next
+    // row -- LDS that exists -- and only interfaces that are masked below see it)
+    const double* qrow = &sq[0][0] + jj * (QW + 1) + ii0;
 #pragma unroll
-    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[jj][(ii0 + u < QW) ? ii0 + u : QW - 1];  // columns gi0-3 ..
+    for (int u = 0; u < RF + 5; ++u) Q[u] = qrow[u];  // columns gi0-3 ..
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
-      cc[f] = (row_ok && ii0 + f <= TI && gi >= g.is && gi <= g.ie + 1) ? crx[kb + IDX2(g, gi, gj)] : 0.0;
+      cc[f] = (row_ok && ii0 + f <= TI && (!EX || (gi >= g.is && gi <= g.ie + 1))) ? crx[kb + IDX2(g, gi, gj)] : 0.0;
       cx_keep[f] = cc[f];
     }
     const double* dxa = m.dxa + (long)gj * sj;
@@ -206,7 +214,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
-      if (ii0 + f <= TI) sxin[jj][ii0 + f] = (row_ok && gi >= g.is && gi <= g.ie + 1) ? out[f] : 0.0;
+      if (ii0 + f <= TI) sxin[jj][ii0 + f] = (row_ok && (!EX || (gi >= g.is && gi <= g.ie + 1))) ? out[f] : 0.0;
     }
   }
   __syncthreads();
@@ -216,7 +224,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int jj = e / TI, ii = e - jj * TI;
     const int gi = i0 + ii, gj = jlo + jj;
     double val = 0.0;
-    if (gj >= 0 && gj <= g.nj - 1 && gi >= g.is && gi <= g.ie) {
+    if ((!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie))) {
       const long c2 = IDX2(g, gi, gj);
       const double x0 = xfx[kb + c2], x1 = xfx[kb + c2 + 1];
       const double a = m.area[c2];
@@ -236,12 +244,13 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int gi0 = i0 + ii0, gj = j0 + jj;
     double Q[RF + 5], cc[RF], xu[RF], out[RF];
     bool calc[RF];
+    const double* qirow = &sqi[0][0] + jj * (QW + 1) + ii0;
 #pragma unroll
-    for (int u = 0; u < RF + 5; ++u) Q[u] = sqi[jj][(ii0 + u < QW) ? ii0 + u : QW - 1];  // q_i at gi0-3 ..
+    for (int u = 0; u < RF + 5; ++u) Q[u] = qirow[u];  // q_i at gi0-3 .. (unclamped, as in stage 3)
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int ii = ii0 + f, gi = gi0 + f;
-      calc[f] = gj <= g.je && gi <= g.ie + 1 && ii <= TI;
+      calc[f] = (!EY || gj <= g.je) && (!EX || gi <= g.ie + 1) && ii <= TI;
       if (EPI == 0) calc[f] = calc[f] && (ii < TI || gi == g.ie + 1);  // a neighbour stores its own west face
       const long c = kb + IDX2(g, gi, gj);
       cc[f] = calc[f] ? cx_keep[f] : 0.0;  // = crx[c], loaded by this thread for the inner sweep of the same row
@@ -273,11 +282,11 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     double Q[RF + 5], cc[RF], yu[RF], out[RF];
     bool calc[RF];
 #pragma unroll
-    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[(jj0 + u < QH) ? jj0 + u : QH - 1][ii + 3];  // q_j at gj0-3 ..
+    for (int u = 0; u < RF + 5; ++u) Q[u] = sq[kClampY ? ((jj0 + u < QH) ? jj0 + u : QH - 1) : jj0 + u][ii + 3];  // q_j at gj0-3 ..
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int jj = jj0 + f, gj = gj0 + f;
-      calc[f] = gi <= g.ie && gj <= g.je + 1 && jj <= TJ;
+      calc[f] = (!EX || gi <= g.ie) && (!EY || gj <= g.je + 1) && jj <= TJ;
       if (EPI == 0) calc[f] = calc[f] && (jj < TJ || gj == g.je + 1);
       const long c = kb + IDX2(g, gi, gj);
       cc[f] = calc[f] ? cy_keep[f] : 0.0;  // = cry[c]
@@ -336,7 +345,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     for (int e = tid; e < TI * TJ; e += 256) {
       const int jj = e / TI, ii = e - jj * TI;
       const int gi = i0 + ii, gj = j0 + jj;
-      if (gi > g.ie || gj > g.je) continue;
+      if ((EX && gi > g.ie) || (EY && gj > g.je)) continue;
       const long c2 = IDX2(g, gi, gj);
       const long c = kb + c2;
       const double ra = m.rarea[c2];

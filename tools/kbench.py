@@ -57,6 +57,15 @@ def main():
         for k in f:
             f[k].set(s[k])
 
+    import ctypes as C
+
+    from pace_amd.fv3core.stencils._common import dptr
+
+    def dsw_phase(mask):
+        fields = [f[k] for k in DSW_ARGS]
+        dsw.lib.call("pace_d_sw_phases", mask, C.byref(dsw._geom), C.byref(dsw._met), C.byref(dsw._col), C.byref(dsw._cfg),
+                     dsw._workspace.data_ptr(), *[dptr(x) for x in fields], float(s["dt"]), dsw.stream())
+
     cases = {
         "fxadv": (lambda: prep(f["uc"], f["vc"], f["crx"], f["cry"], f["xfx"], f["yfx"], ut, vt, s["dt"]), 8),
         "fvtp2d": (lambda: tp(f["pt"], f["crx"], f["cry"], f["xfx"], f["yfx"], fx, fy, x_mass_flux=f["mfx"], y_mass_flux=f["mfy"]), 9),
@@ -64,6 +73,8 @@ def main():
         "delnflux_mass": (lambda: dn2(f["pt"], fx, fy, mass=f["delp"]), 6),
         "riem3": (lambda: riem(False, s["dt"], f["cappa"], m["ptop"], zs, ws, f["delz"], f["q_con"], f["delp"], f["pt"], f["zh"],
                                f["pe"], f["ppe"], f["pk3"], f["pk"], f["peln"], f["w"]), 13),
+        "dsw_scalars": (lambda: dsw_phase(2), 18),
+        "dsw_winds": (lambda: dsw_phase(12), 20),
         "d_sw": (lambda: dsw(*[f[k] for k in DSW_ARGS], s["dt"]), 32),
     }
     only = [x for x in args.only.split(",") if x]
@@ -76,7 +87,7 @@ def main():
         torch.cuda.synchronize()
         ts = []
         for _ in range(args.reps):
-            if name in ("d_sw", "riem3"):
+            if name in ("d_sw", "riem3", "dsw_scalars", "dsw_winds"):
                 restore()
                 torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
