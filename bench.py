@@ -38,6 +38,8 @@ def parse():
     p.add_argument("--n", type=int, default=192)
     p.add_argument("--nz", type=int, default=79)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--exchange", choices=("on", "off"), default="on",
+                   help="multi-rank runs: keep the delp/pt/q_con halo exchange inside the measured step (default) or run the tiles independently")
     p.add_argument("--graph", choices=("on", "off"), default="off",
                    help="replay each step from a captured HIP graph (measured: no gain at C48 ... C192 -- the launches are "
                         "already queued ahead of the GPU; kept as an option)")
@@ -137,13 +139,20 @@ def main():
     batches = [clone_state() for _ in range(nbatch)]
     torch.cuda.synchronize()
 
-    exchange = None
-    if world == 6:
-        from pace_amd.util import CubedSphereCommunicator, TorchDistComm
+    # The halo exchange of the acoustic loop stays inside the measured step whenever there is more than one rank: on the
+    # cubed-sphere topology at 6 ranks, and at rank counts that cannot form a cube (the driver's 2 / 4 / 8) on a periodic
+    # ring of tiles with the same four edge strips per tile (same message sizes and pack / exchange / unpack path; a
+    # stand-in topology, named as such in the output).
+    exchange, topology = None, "none"
+    if world > 1 and args.exchange != "off":
+        from pace_amd.util import CubedSphereCommunicator, CubedSpherePartitioner, RingPartitioner, TorchDistComm
         from pace_amd.util.constants import X_DIM, Y_DIM, Z_DIM
 
-        cube = CubedSphereCommunicator(TorchDistComm(), device=dev, lib=lib)
+        part = CubedSpherePartitioner() if world == 6 else RingPartitioner(world)
+        cube = CubedSphereCommunicator(TorchDistComm(), part, device=dev, lib=lib)
         exchange = cube.get_scalar_halo_updater([env.qf.get_quantity_halo_spec([X_DIM, Y_DIM, Z_DIM])] * 3)
+        topology = "delp,pt,q_con over RCCL (cubed sphere)" if world == 6 else \
+            f"delp,pt,q_con over RCCL (ring of {world} tiles: stand-in topology, cubed-sphere strip sizes)"
 
     def step(b):
         # the wind half of d_sw runs on a side stream, concurrently with the (latency-bound) column solver
@@ -256,7 +265,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, fp64",
                        "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}",
-                       "halo_exchange": "delp,pt,q_con over RCCL (cubed sphere)" if exchange is not None else "none",
+                       "halo_exchange": topology,
                        "launch": "hip graph replay" if use_graph else "eager"},
             "step_hbm_frac": BYTES_PER_CELL_UPDATE * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,

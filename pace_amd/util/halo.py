@@ -209,17 +209,27 @@ class HaloUpdater:
         ni = first.shape[0]
         self._geom = _lib.Geom(n, first.shape[2] - 1, first.strides[1], 0, first.strides[2])
         tile = communicator.rank
-        nbrs = {e: tile_neighbour(tile, e) for e in EDGES}
+        topo = communicator.partitioner
+        nbrs = {e: topo.neighbour(tile, e) for e in EDGES}
         msgs = _Messages(communicator.device, [nbrs[e][0] for e in EDGES], [nbrs[e][0] for e in EDGES])
+        # One message per peer.  Its strips are ordered by the SENDER's edges, so the receiving side walks the peer's
+        # edges too (on the cubed sphere two tiles share one edge and the order is moot; in a two-tile ring they share four).
+        recv_edges = {}  # (peer, position in the peer's message) -> my edge
+        for peer in set(nb[0] for nb in nbrs.values()):
+            order = [topo.arrival_edge(peer, e2) for e2 in EDGES if topo.neighbour(peer, e2)[0] == tile]
+            recv_edges[peer] = order
+        sent = {peer: 0 for peer in recv_edges}
         for e in EDGES:
             to, rot = nbrs[e]
-            to_edge = facing_edge(to, tile)
+            to_edge = topo.arrival_edge(tile, e)
             k = (-rot) % 4
+            re = recv_edges[to][sent[to]]  # my edge whose halo the matching strip of the peer's message fills
+            sent[to] += 1
             for f, sx in enumerate(specs_x):
                 nk = _nk_of(sx)
                 if not vector:
                     msgs.send[to].append(_send_strip(n, n_halo, ni, e, rot, to_edge, sx.n_points, sx.dims, sx.dims, nk, f, 1.0))
-                    msgs.recv[to].append(_recv_strip(n, n_halo, e, sx.n_points, sx.dims, nk, f))
+                    msgs.recv[to].append(_recv_strip(n, n_halo, re, sx.n_points, sx.dims, nk, f))
                     continue
                 sy = specs_y[f]
                 fx, fy = f, self._n_x + f
@@ -229,8 +239,8 @@ class HaloUpdater:
                 dims_of = {fx: sx.dims, fy: sy.dims}
                 msgs.send[to].append(_send_strip(n, n_halo, ni, e, rot, to_edge, sx.n_points, dims_of[x_src], sx.dims, nk, x_src, x_sign))
                 msgs.send[to].append(_send_strip(n, n_halo, ni, e, rot, to_edge, sy.n_points, dims_of[y_src], sy.dims, nk, y_src, y_sign))
-                msgs.recv[to].append(_recv_strip(n, n_halo, e, sx.n_points, sx.dims, nk, fx))
-                msgs.recv[to].append(_recv_strip(n, n_halo, e, sy.n_points, sy.dims, nk, fy))
+                msgs.recv[to].append(_recv_strip(n, n_halo, re, sx.n_points, sx.dims, nk, fx))
+                msgs.recv[to].append(_recv_strip(n, n_halo, re, sy.n_points, sy.dims, nk, fy))
         msgs.finalize()
         self._msgs = msgs
 
@@ -278,6 +288,8 @@ class VectorInterfaceHaloUpdater:
         nk = _nk_of(spec_x)
         self._geom = _lib.Geom(n, spec_x.shape[2] - 1, spec_x.strides[1], 0, spec_x.strides[2])
         tile = communicator.rank
+        if not isinstance(communicator.partitioner, CubedSpherePartitioner):
+            raise NotImplementedError("synchronize_vector_interfaces is defined on the cubed sphere only")
         (to_s, rot_s), (to_w, rot_w) = tile_neighbour(tile, SOUTH), tile_neighbour(tile, WEST)
         (from_n, _), (from_e, _) = tile_neighbour(tile, NORTH), tile_neighbour(tile, EAST)
         msgs = _Messages(communicator.device, [to_s, to_w], [from_n, from_e])

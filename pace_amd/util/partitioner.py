@@ -44,8 +44,48 @@ class CubedSpherePartitioner:
     def tile_index(self, rank: int) -> int:
         return rank
 
+    def neighbour(self, rank: int, edge: int):
+        """(neighbour rank, n_clockwise_rotations) across ``edge``."""
+        return tile_neighbour(rank, edge)
+
+    def arrival_edge(self, rank: int, edge: int) -> int:
+        """The neighbour's edge at which what ``rank`` sends across ``edge`` arrives."""
+        return facing_edge(tile_neighbour(rank, edge)[0], rank)
+
     def boundary(self, boundary_type: int, rank: int):
         to, rot = tile_neighbour(rank, boundary_type)
+        return _Boundary(rank, to, rot, boundary_type)
+
+
+class RingPartitioner:
+    """NOT a reference topology: ``n`` tiles in a periodic ring, every tile exchanging its four edges without rotation
+    (west <-> east and south <-> north with the previous / next tile).  The strips, message sizes and the pack /
+    exchange / unpack path are exactly those of the cubed sphere; bench.py uses it to keep the halo exchange inside the
+    measured step at rank counts that cannot form a cube (2, 4, 8), and the tests use it for world-size-2 runs."""
+
+    _OPPOSITE = {WEST: EAST, EAST: WEST, SOUTH: NORTH, NORTH: SOUTH}
+
+    def __init__(self, n: int):
+        if n < 2:
+            raise ValueError("a ring needs at least two tiles")
+        self.n = n
+        self.layout = (1, 1)
+
+    @property
+    def total_ranks(self):
+        return self.n
+
+    def tile_index(self, rank: int) -> int:
+        return rank
+
+    def neighbour(self, rank: int, edge: int):
+        return ((rank - 1) % self.n if edge in (WEST, SOUTH) else (rank + 1) % self.n), 0
+
+    def arrival_edge(self, rank: int, edge: int) -> int:
+        return self._OPPOSITE[edge]
+
+    def boundary(self, boundary_type: int, rank: int):
+        to, rot = self.neighbour(rank, boundary_type)
         return _Boundary(rank, to, rot, boundary_type)
 
 

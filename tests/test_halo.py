@@ -180,3 +180,80 @@ def test_halo_updater_error_behaviour():
         return True
 
     assert all(run_tiles(6, program))
+
+
+# ---- the ring stand-in topology (bench.py at 2 / 4 / 8 ranks; world-size-2 coverage of the multi-process path) ----
+def ring_program(comm, lib, n_ranks, device="cpu"):
+    from pace_amd.util import CubedSphereCommunicator, QuantityFactory, RingPartitioner, SubtileGridSizer
+
+    sizer = SubtileGridSizer.from_tile_params(nx_tile=N, ny_tile=N, nz=NZ, n_halo=3, extra_dim_lengths={}, layout=(1, 1))
+    qf = QuantityFactory(sizer, device=device)
+    ring = CubedSphereCommunicator(comm, RingPartitioner(n_ranks), device=device, lib=lib)
+    base = _base(seed=11)
+    out = {}
+    for key in ("c", "b"):
+        qs = []
+        for scale in (1.0, 3.0):
+            x = qf.zeros(DIMS[key], "")
+            x.set(base[key][ring.rank] * scale)
+            qs.append(x)
+        up = ring.get_scalar_halo_updater([qf.get_quantity_halo_spec(DIMS[key])] * 2)
+        up.update(qs)
+        out[key] = [x.numpy() for x in qs]
+    return out
+
+
+def _check_ring(results, n_ranks):
+    """West halo = the previous tile's easternmost compute columns, etc.; corners and the compute domain untouched."""
+    base = _base(seed=11)
+    h = 3
+    for key, st in (("c", 0), ("b", 1)):
+        e = h + N + st  # end of the compute domain (staggered fields own one more point)
+        for r in range(n_ranks):
+            prev, nxt = base[key][(r - 1) % n_ranks], base[key][(r + 1) % n_ranks]
+            for f, scale in enumerate((1.0, 3.0)):
+                got = results[r][key][f]
+                exp = base[key][r] * scale
+                exp[0:h, h:e, :NZ] = prev[e - st - h:e - st, h:e, :NZ] * scale      # west  <- previous tile's east side
+                exp[e:e + h, h:e, :NZ] = nxt[h + st:h + st + h, h:e, :NZ] * scale    # east  <- next tile's west side
+                exp[h:e, 0:h, :NZ] = prev[h:e, e - st - h:e - st, :NZ] * scale      # south <- previous tile's north side
+                exp[h:e, e:e + h, :NZ] = nxt[h:e, h + st:h + st + h, :NZ] * scale    # north <- next tile's south side
+                assert np.array_equal(got, exp), (key, r, f)
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_ring_exchange_on_threads(n_ranks):
+    from pace_amd import _lib
+    from pace_amd.util import run_tiles
+
+    lib = _lib.Library(build_emu())
+    _check_ring(run_tiles(n_ranks, lambda comm: ring_program(comm, lib, n_ranks)), n_ranks)
+
+
+_RING_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+from pace_amd import _lib
+from pace_amd.util import TorchDistComm
+import test_halo
+lib = _lib.Library(os.path.join({root!r}, "tests", "emu", "libpace_emu.so"))
+out = test_halo.ring_program(TorchDistComm(), lib, 2)
+pickle.dump(out, open(sys.argv[2], "wb"))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_ring_exchange_two_processes_gloo(tmp_path):
+    """world_size 2 over torch.distributed: both ranks exchange all four edges with the same peer in one message."""
+    import pickle
+
+    build_emu()
+    port = 31500 + os.getpid() % 2000
+    script = tmp_path / "ring_worker.py"
+    script.write_text(_RING_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / f"ring{r}.pkl")]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    _check_ring([pickle.load(open(tmp_path / f"ring{r}.pkl", "rb")) for r in range(2)], 2)
