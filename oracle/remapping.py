@@ -1,0 +1,318 @@
+"""CPU oracle (TEST INFRASTRUCTURE, not product) for the vertical remapping operators of the reference:
+
+* ``remap_profile``  -- RemapProfile.__call__, fv3core/pace/fv3core/stencils/remap_profile.py:566-681 (Fortran cs_profile),
+  for |kord| in {9, 10} (the reference asserts kord <= 10; kord < 9 is not restated) and every ``iv``;
+* ``map_single``     -- MapSingle.__call__, fv3core/pace/fv3core/stencils/map_single.py:96-200 (Fortran map_single /
+  map1_ppm / map_scalar).
+
+Plain numpy, vectorised over the columns, sequential in k where the reference is.  Every expression keeps the
+reference's operand order.  Pinned bit for bit against a run of the reference itself (tools/make_golden_remap.py ->
+tests/golden/remap_c12.npz, tests/test_oracle_golden.py).
+
+Array convention: fields are (ni, nj, km + 1); ``km`` layers, level ``km`` is the extra (interface) level that the
+reference's storages carry too.  ``pe1`` / ``pe2`` hold the km + 1 interface pressures.
+"""
+import numpy as np
+
+
+def _w(c, a, b):
+    return np.where(c, a, b)
+
+
+def _min3(a, p, l):
+    # a if (a < p) and (a < l) else p if p < l else l   (remap_profile.py:417-423)
+    return _w((a < p) & (a < l), a, _w(p < l, p, l))
+
+
+def _max3(a, p, l):
+    return _w((a > p) & (a > l), a, _w(p > l, p, l))
+
+
+def _posdef_constraint_iv0(a1, a2, a3, a4):
+    """remap_profile.py:52-87"""
+    with np.errstate(all="ignore"):
+        c0 = a1 <= 0.0
+        c1 = (np.abs(a3 - a2) < -a4) & ((a1 + 0.25 * (a3 - a2) ** 2 / a4 + a4 * (1.0 / 12.0)) < 0.0)
+    c2 = (a1 < a3) & (a1 < a2)
+    c3 = a3 > a2
+    inner = ~c0 & c1
+    # branch A (c0, or inner & c2): a2 = a3 = a1, a4 = 0
+    A = c0 | (inner & c2)
+    B = inner & ~c2 & c3    # a4 = 3 (a2 - a1); a3 = a2 - a4
+    C = inner & ~c2 & ~c3   # a4 = 3 (a3 - a1); a2 = a3 - a4
+    a4B = 3.0 * (a2 - a1)
+    a3B = a2 - a4B
+    a4C = 3.0 * (a3 - a1)
+    a2C = a3 - a4C
+    n2 = _w(A, a1, _w(C, a2C, a2))
+    n3 = _w(A, a1, _w(B, a3B, a3))
+    n4 = _w(A, 0.0, _w(B, a4B, _w(C, a4C, a4)))
+    return a1, n2, n3, n4
+
+
+def _posdef_constraint_iv1(a1, a2, a3, a4):
+    """remap_profile.py:90-117"""
+    da1 = a3 - a2
+    da2 = da1 * da1
+    a6da = a4 * da1
+    A = ((a1 - a2) * (a1 - a3)) >= 0.0
+    B = ~A & (a6da < -1.0 * da2)
+    C = ~A & ~B & (a6da > da2)
+    a4B = 3.0 * (a2 - a1)
+    a3B = a2 - a4B
+    a4C = 3.0 * (a3 - a1)
+    a2C = a3 - a4C
+    n2 = _w(A, a1, _w(C, a2C, a2))
+    n3 = _w(A, a1, _w(B, a3B, a3))
+    n4 = _w(A, 0.0, _w(B, a4B, _w(C, a4C, a4)))
+    return a1, n2, n3, n4
+
+
+def _remap_constraint(a1, a2, a3, a4, extm):
+    """remap_profile.py:120-151"""
+    da1 = a3 - a2
+    da2 = da1 * da1
+    a6da = a4 * da1
+    A = extm
+    B = ~A & (a6da < -da2)
+    C = ~A & ~B & (a6da > da2)
+    a4B = 3.0 * (a2 - a1)
+    a3B = a2 - a4B
+    a4C = 3.0 * (a3 - a1)
+    a2C = a3 - a4C
+    n2 = _w(A, a1, _w(C, a2C, a2))
+    n3 = _w(A, a1, _w(B, a3B, a3))
+    n4 = _w(A, 0.0, _w(B, a4B, _w(C, a4C, a4)))
+    return a1, n2, n3, n4
+
+
+def remap_profile(qs, a1, a2, a3, a4, delp, km, kord, iv, qmin=0.0, gam=None):
+    """In place on a2, a3, a4 (and a1 where the reference writes it -- it never changes its value).  ``qs``: (ni, nj)
+    bottom boundary value (used for iv == -2 only).  ``gam``: the RemapProfile object's persistent work field (level 0
+    keeps whatever an earlier call left when iv == -2; zeros for a fresh object)."""
+    kord = abs(kord)
+    assert kord in (9, 10), "oracle restates kord 9 and 10"
+    shp = a1.shape
+    if gam is None:
+        gam = np.zeros(shp)
+    q = np.zeros(shp)
+    # ---- set_initial_vals (remap_profile.py:154-264); k-domain = km + 1 levels
+    with np.errstate(all="ignore"):
+        if iv == -2:
+            q[:, :, 0] = 1.5 * a1[:, :, 0]
+            gam[:, :, 1] = 0.5
+            gr = delp[:, :, 0] / delp[:, :, 1]
+            bet = 2.0 + gr + gr - gam[:, :, 1]
+            q[:, :, 1] = (3.0 * (a1[:, :, 0] + a1[:, :, 1]) - q[:, :, 0]) / bet
+            grid_ratio = np.zeros(shp)
+            for k in range(2, km):
+                old_gr = delp[:, :, k - 2] / delp[:, :, k - 1]
+                old_bet = 2.0 + old_gr + old_gr - gam[:, :, k - 1]
+                gam[:, :, k] = old_gr / old_bet
+                grid_ratio[:, :, k] = delp[:, :, k - 1] / delp[:, :, k]
+            for k in range(2, km - 1):
+                g = grid_ratio[:, :, k]
+                bet = 2.0 + g + g - gam[:, :, k]
+                q[:, :, k] = (3.0 * (a1[:, :, k - 1] + a1[:, :, k]) - q[:, :, k - 1]) / bet
+            k = km - 1
+            g = grid_ratio[:, :, k]
+            q[:, :, k] = (3.0 * (a1[:, :, k - 1] + a1[:, :, k]) - g * qs - q[:, :, k - 1]) / (2.0 + g + g - gam[:, :, k])
+            q[:, :, km] = qs
+            for k in range(km - 2, -1, -1):
+                q[:, :, k] = q[:, :, k] - gam[:, :, k + 1] * q[:, :, k + 1]
+        else:
+            gr = delp[:, :, 1] / delp[:, :, 0]
+            bet = gr * (gr + 0.5)
+            q[:, :, 0] = ((gr + gr) * (gr + 1.0) * a1[:, :, 0] + a1[:, :, 1]) / bet
+            gam[:, :, 0] = (1.0 + gr * (gr + 1.5)) / bet
+            for k in range(1, km):
+                d4 = delp[:, :, k - 1] / delp[:, :, k]
+                bet = 2.0 + d4 + d4 - gam[:, :, k - 1]
+                q[:, :, k] = (3.0 * (a1[:, :, k - 1] + d4 * a1[:, :, k]) - q[:, :, k - 1]) / bet
+                gam[:, :, k] = d4 / bet
+            d4 = delp[:, :, km - 2] / delp[:, :, km - 1]
+            a_bot = 1.0 + d4 * (d4 + 1.5)
+            q[:, :, km] = (2.0 * d4 * (d4 + 1.0) * a1[:, :, km - 1] + a1[:, :, km - 2] - a_bot * q[:, :, km - 1]) / (
+                d4 * (d4 + 0.5) - a_bot * gam[:, :, km - 1])
+            for k in range(km - 1, -1, -1):
+                q[:, :, k] = q[:, :, k] - gam[:, :, k] * q[:, :, k + 1]
+
+    # ---- apply_constraints (remap_profile.py:267-337); k-domain = km levels
+    tmp = np.zeros(shp)
+    tmp2 = np.zeros(shp)
+    a10 = a1[:, :, 0:km - 1]
+    a11 = a1[:, :, 1:km]
+    tmp[:, :, 1:km] = _w(a10 > a11, a10, a11)
+    tmp2[:, :, 1:km] = _w(a10 < a11, a10, a11)
+    gam[:, :, 1:km] = a11 - a10
+
+    def clamp_hi(k):
+        q[:, :, k] = _w(q[:, :, k] >= tmp[:, :, k], tmp[:, :, k], q[:, :, k])
+
+    def clamp_lo(k):
+        q[:, :, k] = _w(q[:, :, k] <= tmp2[:, :, k], tmp2[:, :, k], q[:, :, k])
+
+    clamp_hi(1)
+    clamp_lo(1)
+    for k in range(2, km - 1):
+        qk = q[:, :, k]
+        g = gam[:, :, k - 1] * gam[:, :, k + 1]
+        A = g > 0
+        B = ~A & (gam[:, :, k - 1] > 0)
+        C = ~A & ~B
+        hi = _w(qk >= tmp[:, :, k], tmp[:, :, k], qk)
+        both = _w(hi <= tmp2[:, :, k], tmp2[:, :, k], hi)
+        lo = _w(qk <= tmp2[:, :, k], tmp2[:, :, k], qk)
+        qc = hi
+        if iv == 0:
+            qc = _w(qc < 0.0, 0.0, qc)
+        q[:, :, k] = _w(A, both, _w(B, lo, qc))
+    clamp_hi(km - 1)
+    clamp_lo(km - 1)
+    a2[:, :, 0:km] = q[:, :, 0:km]
+    a3[:, :, 0:km] = q[:, :, 1:km + 1]
+    extm = np.zeros(shp, dtype=bool)
+    extm[:, :, 0] = (a2[:, :, 0] - a1[:, :, 0]) * (a3[:, :, 0] - a1[:, :, 0]) > 0.0
+    extm[:, :, 1:km - 1] = gam[:, :, 1:km - 1] * gam[:, :, 2:km] < 0.0
+    extm[:, :, km - 1] = (a2[:, :, km - 1] - a1[:, :, km - 1]) * (a3[:, :, km - 1] - a1[:, :, km - 1]) > 0.0
+    ext5 = np.zeros(shp, dtype=bool)
+    ext6 = np.zeros(shp, dtype=bool)
+    if kord > 9:
+        s = slice(0, km)
+        x0 = 2.0 * a1[:, :, s] - (a2[:, :, s] + a3[:, :, s])
+        x1 = np.abs(a2[:, :, s] - a3[:, :, s])
+        a4[:, :, s] = 3.0 * x0
+        ext5[:, :, s] = np.abs(x0) > x1
+        ext6[:, :, s] = np.abs(a4[:, :, s]) > x1
+
+    # ---- set_interpolation_coefficients (remap_profile.py:340-563); k-domain = km levels
+    def a4_std(k):
+        a4[:, :, k] = 3.0 * (2.0 * a1[:, :, k] - (a2[:, :, k] + a3[:, :, k]))
+
+    if iv == 0:
+        a2[:, :, 0] = _w(a2[:, :, 0] < 0.0, 0.0, a2[:, :, 0])
+        a4_std(0); a4_std(1)
+    if iv == -1:
+        a2[:, :, 0] = _w(a2[:, :, 0] * a1[:, :, 0] <= 0.0, 0.0, a2[:, :, 0])
+        a4_std(0); a4_std(1)
+    if iv == 2:
+        a2[:, :, 0] = a1[:, :, 0]
+        a3[:, :, 0] = a1[:, :, 0]
+        a4[:, :, 0] = 0.0
+        a4_std(1)
+    if iv < -1 or iv == 1 or iv > 2:
+        a4_std(0); a4_std(1)
+    if iv != 2:
+        _, a2[:, :, 0], a3[:, :, 0], a4[:, :, 0] = _posdef_constraint_iv1(a1[:, :, 0], a2[:, :, 0], a3[:, :, 0], a4[:, :, 0])
+    _, a2[:, :, 1], a3[:, :, 1], a4[:, :, 1] = _remap_constraint(a1[:, :, 1], a2[:, :, 1], a3[:, :, 1], a4[:, :, 1], extm[:, :, 1])
+
+    s = slice(2, km - 2)
+    if km - 2 > 2:
+        A1, A2, A3, A4 = a1[:, :, s], a2[:, :, s].copy(), a3[:, :, s].copy(), a4[:, :, s].copy()
+        g0, gm, gp, gpp = gam[:, :, s], gam[:, :, 1:km - 3], gam[:, :, 3:km - 1], gam[:, :, 4:km]
+        pmp_1 = A1 - 2.0 * gp
+        lac_1 = pmp_1 + 1.5 * gpp
+        pmp_2 = A1 + 2.0 * g0
+        lac_2 = pmp_2 - 1.5 * gm
+        if kord == 9:
+            em, e0, ep = extm[:, :, 1:km - 3], extm[:, :, s], extm[:, :, 3:km - 1]
+            cond = (e0 & em) | (e0 & ep) | (e0 & ((qmin > 0.0) & (A1 < qmin)))
+            a4e = 6.0 * A1 - 3.0 * (A2 + A3)
+            big = np.abs(a4e) > np.abs(A2 - A3)
+            tmin = _min3(A1, pmp_1, lac_1)
+            tmax0 = _w(A2 > tmin, A2, tmin)
+            tmax = _max3(A1, pmp_1, lac_1)
+            n2 = _w(tmax0 < tmax, tmax0, tmax)
+            tmin = _min3(A1, pmp_2, lac_2)
+            tmax0 = _w(A3 > tmin, A3, tmin)
+            tmax = _max3(A1, pmp_2, lac_2)
+            n3 = _w(tmax0 < tmax, tmax0, tmax)
+            n4 = 6.0 * A1 - 3.0 * (n2 + n3)
+            R2 = _w(cond, A1, _w(big, n2, A2))
+            R3 = _w(cond, A1, _w(big, n3, A3))
+            R4 = _w(cond, 0.0, _w(big, n4, a4e))
+            A2, A3, A4 = R2, R3, R4
+        else:  # kord == 10
+            tmin2 = _min3(A1, pmp_1, lac_1)
+            tmax2 = _max3(A1, pmp_1, lac_1)
+            t2 = _w(A2 > tmin2, A2, tmin2)
+            tmin3 = _w(A1 < pmp_2, A1, pmp_2)
+            tmin3 = _w(lac_2 < tmin3, lac_2, tmin3)
+            tmax3 = _w(A1 > pmp_2, A1, pmp_2)
+            tmax3 = _w(lac_2 > tmax3, lac_2, tmax3)
+            t3 = _w(A3 > tmin3, A3, tmin3)
+            lim2 = _w(t2 < tmax2, t2, tmax2)
+            lim3 = _w(t3 < tmax3, t3, tmax3)
+            e5, e5m, e5p = ext5[:, :, s], ext5[:, :, 1:km - 3], ext5[:, :, 3:km - 1]
+            e6, e6m, e6p = ext6[:, :, s], ext6[:, :, 1:km - 3], ext6[:, :, 3:km - 1]
+            n5 = e5m | e5p
+            n6 = e6m | e6p
+            flat = e5 & n5
+            limited = (e5 & ~n5 & n6) | (~e5 & e6 & n5)
+            A2 = _w(flat, A1, _w(limited, lim2, A2))
+            A3 = _w(flat, A1, _w(limited, lim3, A3))
+            A4 = 3.0 * (2.0 * A1 - (A2 + A3))
+        if iv == 0:
+            _, A2, A3, A4 = _posdef_constraint_iv0(A1, A2, A3, A4)
+        a2[:, :, s], a3[:, :, s], a4[:, :, s] = A2, A3, A4
+
+    kb = km - 1
+    if iv == 0:
+        a3[:, :, kb] = _w(a3[:, :, kb] < 0.0, 0.0, a3[:, :, kb])
+    if iv == -1:
+        a3[:, :, kb] = _w(a3[:, :, kb] * a1[:, :, kb] <= 0.0, 0.0, a3[:, :, kb])
+    a4_std(km - 2); a4_std(km - 1)
+    k = km - 2
+    _, a2[:, :, k], a3[:, :, k], a4[:, :, k] = _remap_constraint(a1[:, :, k], a2[:, :, k], a3[:, :, k], a4[:, :, k], extm[:, :, k])
+    k = km - 1
+    _, a2[:, :, k], a3[:, :, k], a4[:, :, k] = _posdef_constraint_iv1(a1[:, :, k], a2[:, :, k], a3[:, :, k], a4[:, :, k])
+    return gam
+
+
+def lagrangian_contributions(q, pe1, pe2, a1, a2, a3, a4, dp1, km):
+    """map_single.py:21-93: layer means of the piecewise-parabolic profile between the target interfaces pe2.  The
+    reference's per-column relative index ``lev`` is kept as the absolute source layer L."""
+    ni, nj = q.shape[0], q.shape[1]
+    L = np.zeros((ni, nj), dtype=np.int64)
+    I, J = np.meshgrid(np.arange(ni), np.arange(nj), indexing="ij")
+
+    def at(f, idx):
+        return f[I, J, np.minimum(idx, f.shape[2] - 1)]
+
+    with np.errstate(all="ignore"):
+        for k in range(km):
+            p2a, p2b = pe2[:, :, k], pe2[:, :, k + 1]
+            pl = (p2a - at(pe1, L)) / at(dp1, L)
+            inside = p2b <= at(pe1, L + 1)
+            pr = (p2b - at(pe1, L)) / at(dp1, L)
+            q_in = (at(a2, L) + 0.5 * (at(a4, L) + at(a3, L) - at(a2, L)) * (pr + pl)
+                    - at(a4, L) * 1.0 / 3.0 * (pr * (pr + pl) + pl * pl))
+            qsum = (at(pe1, L + 1) - p2a) * (at(a2, L) + 0.5 * (at(a4, L) + at(a3, L) - at(a2, L)) * (1.0 + pl)
+                                            - at(a4, L) * 1.0 / 3.0 * (1.0 + pl * (1.0 + pl)))
+            out = ~inside
+            L = np.where(out, L + 1, L)
+            while True:
+                go = out & (L + 1 <= km) & (at(pe1, L + 1) < p2b)
+                if not go.any():
+                    break
+                qsum = np.where(go, qsum + at(dp1, L) * at(a1, L), qsum)
+                L = np.where(go, L + 1, L)
+            dp = p2b - at(pe1, L)
+            esl = dp / at(dp1, L)
+            qsum = qsum + dp * (at(a2, L) + 0.5 * esl * (at(a3, L) - at(a2, L) + at(a4, L) * (1.0 - (2.0 / 3.0) * esl)))
+            q[:, :, k] = np.where(inside, q_in, qsum / (p2b - p2a))
+
+
+def map_single(q1, pe1, pe2, km, kord, iv, qs=None, qmin=0.0, gam=None):
+    """MapSingle.__call__ (map_single.py:154-200): q1 (ni, nj, >= km) is remapped in place from the layers bounded by pe1
+    to those bounded by pe2."""
+    shp = q1.shape
+    a1 = q1.copy()
+    a2, a3, a4 = np.zeros(shp), np.zeros(shp), np.zeros(shp)
+    dp1 = np.zeros(shp)
+    dp1[:, :, 0:km] = pe1[:, :, 1:km + 1] - pe1[:, :, 0:km]
+    if qs is None:
+        qs = np.zeros(shp[:2])
+    remap_profile(qs, a1, a2, a3, a4, dp1, km, kord, iv, qmin, gam)
+    lagrangian_contributions(q1, pe1, pe2, a1, a2, a3, a4, dp1, km)
+    return q1

@@ -319,3 +319,22 @@ def run_in_child(what, tmp_path, retries=1):
         if not died_from_signal or attempt == retries:
             raise RuntimeError(f"child run {what!r} failed (rc {p.returncode}):\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}")
     raise AssertionError("unreachable")
+
+
+# ---- vertical remapping (tests/golden/remap_c12.npz: a run of the reference's MapSingle, tools/make_golden_remap.py) ----
+# name -> (kord, iv, source interfaces, target interfaces, bottom value, qmin)
+REMAP_CASES = {
+    "pt_k9_iv1": (9, 1, "pn1", "pn2", None, 184.0),
+    "qv_k9_iv0": (9, 0, "pe1", "pe2", None, 0.0),
+    "w_k9_ivm2": (9, -2, "pe1", "pe2", "wsd", 0.0),
+    "delz_k9_iv1": (9, 1, "pe1", "pe2", None, 0.0),
+    "u_k9_ivm1": (9, -1, "pe1_u", "pe2_u", None, 0.0),
+    "pt_k9_iv1_s": (9, 1, "pn1s", "pn2", None, 184.0),
+    "qv_k9_iv0_s": (9, 0, "pe1s", "pe2", None, 0.0),
+    "w_k9_ivm2_s": (9, -2, "pe1s", "pe2", "wsd", 0.0),
+    "u_k9_ivm1_s": (9, -1, "pe1s_u", "pe2_u", None, 0.0),
+    "qv_k10_iv0_s": (10, 0, "pe1s", "pe2", None, 0.0),
+    "qv_k10_iv0": (10, 0, "pe1", "pe2", None, 0.0),
+    "pt_k10_iv1": (10, 1, "pn1", "pn2", None, 184.0),
+}
+REMAP_KM = 79

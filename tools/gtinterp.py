@@ -435,6 +435,23 @@ class Interp:
         idx = self.ev(sl, scope)
         if not isinstance(idx, tuple):
             idx = (idx,)
+        if isinstance(base, Ref) and base.axes == ("I", "J", "K") and len(idx) == 3 and not isinstance(
+                idx[2], (int, np.integer)):
+            # variable (per-column) k offset, relative to the current level: field[0, 0, lev]
+            assert int(idx[0]) == 0 and int(idx[1]) == 0, "variable k offset with a horizontal shift"
+            ctx = self.ctx
+            assert ctx.k1 - ctx.k0 == 1, "variable k offset outside a sequential computation"
+            kv = np.asarray(self._num(idx[2]), dtype=float)
+            kv = np.where(np.isfinite(kv), kv, 0.0).astype(np.int64)
+            arr = base.arr
+            NI, NJ, NK = arr.shape
+            kk = np.broadcast_to(kv, (NI, NJ, 1)) + (ctx.k0 + base.off[2])
+            bad = (kk < 0) | (kk >= NK)
+            got = np.take_along_axis(arr, np.clip(kk, 0, NK - 1), axis=2).astype(float)
+            got[bad] = np.nan
+            if base.off[0] or base.off[1]:
+                got = _shift_slab(got, base.off[0], base.off[1])
+            return got
         idx = tuple(int(x) for x in idx)
         if isinstance(base, Ref):
             return base.shifted(idx)
@@ -556,6 +573,19 @@ class Interp:
             self.exec_block(st.body, scope, mt)
             if st.orelse:
                 self.exec_block(st.orelse, scope, mf)
+            return
+        if isinstance(st, ast.While):
+            # per-column loop: columns leave the loop one by one; only columns of the compute domain take part (writes
+            # outside it are dropped, so a column out there could never change its own condition)
+            dom = self.ctx.dom_mask
+            for _ in range(100000):
+                c = np.asarray(self._num(self.ev(st.test, scope)), dtype=bool)
+                m = (c & dom) if mask is None else (mask & c & dom)
+                if not np.any(m):
+                    break
+                self.exec_block(st.body, scope, m)
+            else:
+                raise RuntimeError("while loop did not terminate")
             return
         if isinstance(st, ast.With):
             call = st.items[0].context_expr
