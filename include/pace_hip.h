@@ -254,6 +254,17 @@ int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, d
                            const double* fx, const double* fy, const double* dp2, void* stream);
 int pace_swap_dp(const pace_geom_t* geom, double* dp1, double* dp2, void* stream);
 
+/* ---- MapSingle (Fortran map_single / map1_ppm / map_scalar): fv3core/pace/fv3core/stencils/map_single.py:96-200 with
+ * RemapProfile (cs_profile), remap_profile.py:566-681.  q1 is remapped in place from the nk layers bounded by the
+ * interface values pe1 to those bounded by pe2 (both nk + 1 levels; pressure or log-pressure -- remapping.py:587-627).
+ * kord: 9 or 10 (sign ignored, as the reference takes abs); iv: the reference's `mode` (-2 vertical velocity -- needs the
+ * bottom value qs, a 2-D field --, -1 winds, 0 positive-definite tracers, 1 others, 2 as remap_profile.py:387-395).
+ * xstag / ystag: the field is staggered in x / y and owns one more column / row (`dims` of the reference's constructor).
+ * workspace: pace_map_single_workspace_bytes() of device memory (5 fields; the reference keeps 14). */
+int64_t pace_map_single_workspace_bytes(const pace_geom_t* geom);
+int pace_map_single(const pace_geom_t* geom, void* workspace, double* q1, const double* pe1, const double* pe2,
+                    const double* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream);
+
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation
  * (rotate.py:4-50) and boundary slicing (_boundary_utils.py:58-95) folded into an affine index map.

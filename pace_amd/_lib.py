@@ -119,6 +119,8 @@ _PROTOS = {
     "pace_apply_mass_flux": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 4 + [C.c_void_p]),
     "pace_apply_tracer_flux": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 5 + [C.c_void_p]),
     "pace_swap_dp": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_void_p]),
+    "pace_map_single_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_map_single": (C.c_int, [_P(Geom), c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double] + [C.c_int] * 4 + [C.c_void_p]),
     "pace_halo_pack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
     "pace_halo_unpack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
 }

@@ -308,6 +308,16 @@ static int halo_check(const pace_geom_t* geom, const pace_halo_desc_t* d, int n)
   return PACE_OK;
 }
 
+int64_t pace_map_single_workspace_bytes(const pace_geom_t* geom) {
+  return geom ? map_single_workspace_bytes(make_geo(geom)) : 0;
+}
+
+int pace_map_single(const pace_geom_t* geom, void* workspace, double* q1, const double* pe1, const double* pe2,
+                    const double* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream) {
+  NEED(geom && workspace && q1 && pe1 && pe2);
+  return launch_map_single(make_geo(geom), workspace, q1, pe1, pe2, qs, qmin, kord, iv, xstag, ystag, S(stream));
+}
+
 int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {
   NEED(geom && descs && ndesc > 0);
   if (halo_check(geom, descs, ndesc)) return PACE_ERR_ARG;

@@ -1,0 +1,419 @@
+// MapSingle (Fortran map_single / map1_ppm / map_scalar): conservative remapping of one field from the Lagrangian
+// layers bounded by pe1 to the layers bounded by pe2, with the cubic-spline / PPM sub-grid profile of RemapProfile
+// (cs_profile).  Reference: fv3core/pace/fv3core/stencils/map_single.py:14-200 (3 stencils + RemapProfile),
+// remap_profile.py:154-681 (3 stencils, 6 three-dimensional work fields + 3 boolean ones).
+//
+// Column-local work, [k][j][i] storage: lanes run along i, so every level access of a wave is one coalesced row.
+//   k_remap_interfaces   one thread per column: the tridiagonal solve for the interface values q (forward elimination
+//                        + back substitution, remap_profile.py:176-253), and the copy of the field (a4_1)
+//   k_remap_coefficients one thread per CELL: everything after the solve is local in k once gam is recognised as the
+//                        difference of a4_1 (remap_profile.py:295) -- the limited interface values of the four
+//                        neighbouring interfaces, the extremum flags of the three neighbouring layers and the layer's
+//                        own coefficients are evaluated in registers; a4_2, a4_3, a4_4 are the only fields written
+//                        (the reference's q, gam, tmp, tmp2, extm, ext5, ext6 never exist)
+//   k_remap_layers       one thread per column: the walk over the source layers (map_single.py:44-93); the
+//                        per-column search index is a register
+// kord 9 and 10 (the reference asserts |kord| <= 10; kord < 9 is not implemented), every iv.
+#include "common.h"
+#include "kernels.h"
+
+struct RemapWin {
+  int i0, i1, j0, j1;  // inclusive window of columns
+  int km;
+};
+
+// ---- the three constraint functions (remap_profile.py:52-151), on scalars ----
+__device__ __forceinline__ void posdef_constraint_iv0(double a1, double& a2, double& a3, double& a4) {
+  if (a1 <= 0.0) {
+    a2 = a1; a3 = a1; a4 = 0.0;
+  } else if (fabs(a3 - a2) < -a4 && (a1 + 0.25 * ((a3 - a2) * (a3 - a2)) / a4 + a4 * (1.0 / 12.0)) < 0.0) {
+    if (a1 < a3 && a1 < a2) {
+      a3 = a1; a2 = a1; a4 = 0.0;
+    } else if (a3 > a2) {
+      a4 = 3.0 * (a2 - a1);
+      a3 = a2 - a4;
+    } else {
+      a4 = 3.0 * (a3 - a1);
+      a2 = a3 - a4;
+    }
+  }
+}
+
+__device__ __forceinline__ void posdef_constraint_iv1(double a1, double& a2, double& a3, double& a4) {
+  const double da1 = a3 - a2;
+  const double da2 = da1 * da1;
+  const double a6da = a4 * da1;
+  if (((a1 - a2) * (a1 - a3)) >= 0.0) {
+    a2 = a1; a3 = a1; a4 = 0.0;
+  } else if (a6da < -1.0 * da2) {
+    a4 = 3.0 * (a2 - a1);
+    a3 = a2 - a4;
+  } else if (a6da > da2) {
+    a4 = 3.0 * (a3 - a1);
+    a2 = a3 - a4;
+  }
+}
+
+__device__ __forceinline__ void remap_constraint(double a1, double& a2, double& a3, double& a4, bool extm) {
+  const double da1 = a3 - a2;
+  const double da2 = da1 * da1;
+  const double a6da = a4 * da1;
+  if (extm) {
+    a2 = a1; a3 = a1; a4 = 0.0;
+  } else if (a6da < -da2) {
+    a4 = 3.0 * (a2 - a1);
+    a3 = a2 - a4;
+  } else if (a6da > da2) {
+    a4 = 3.0 * (a3 - a1);
+    a2 = a3 - a4;
+  }
+}
+
+__device__ __forceinline__ double min3(double a, double p, double l) { return (a < p && a < l) ? a : (p < l ? p : l); }
+__device__ __forceinline__ double max3(double a, double p, double l) { return (a > p && a > l) ? a : (p > l ? p : l); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// interface values: set_initial_vals.  qi gets km + 1 levels, gw (work) km; a1 = copy of q1 (km levels).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool IVM2>
+__global__ void __launch_bounds__(64)
+k_remap_interfaces(Geo g, RemapWin w, const double* __restrict__ q1, const double* __restrict__ pe1,
+                   const double* __restrict__ qs, double* __restrict__ a1, double* __restrict__ qi, double* __restrict__ gw) {
+  const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
+  const int j = w.j0 + blockIdx.y;
+  if (i > w.i1 || j > w.j1) return;
+  const long c0 = IDX2(g, i, j);
+  const long sk = g.sk;
+  const int km = w.km;
+#define Q1(k) q1[c0 + (long)(k) * sk]
+#define DP(k) (pe1[c0 + (long)((k) + 1) * sk] - pe1[c0 + (long)(k) * sk])  // set_dp, map_single.py:14-18
+#define QI(k) qi[c0 + (long)(k) * sk]
+#define GW(k) gw[c0 + (long)(k) * sk]
+  for (int k = 0; k < km; ++k) a1[c0 + (long)k * sk] = Q1(k);
+  if (IVM2) {
+    // remap_profile.py:183-239 for iv == -2: gw[k] = gam[k]
+    const double qsv = qs[c0];
+    double qp = 1.5 * Q1(0);
+    QI(0) = qp;
+    double gam = 0.5;
+    GW(1) = gam;
+    {
+      const double gr = DP(0) / DP(1);
+      const double bet = 2.0 + gr + gr - gam;
+      qp = (3.0 * (Q1(0) + Q1(1)) - qp) / bet;
+      QI(1) = qp;
+    }
+    for (int k = 2; k < km; ++k) {
+      const double old_gr = DP(k - 2) / DP(k - 1);
+      const double old_bet = 2.0 + old_gr + old_gr - gam;
+      gam = old_gr / old_bet;
+      GW(k) = gam;
+      const double gr = DP(k - 1) / DP(k);
+      if (k < km - 1) {
+        const double bet = 2.0 + gr + gr - gam;
+        qp = (3.0 * (Q1(k - 1) + Q1(k)) - qp) / bet;
+      } else {
+        qp = (3.0 * (Q1(k - 1) + Q1(k)) - gr * qsv - qp) / (2.0 + gr + gr - gam);
+      }
+      QI(k) = qp;
+    }
+    QI(km) = qsv;
+    double qn = QI(km - 1);
+    for (int k = km - 2; k >= 0; --k) {
+      qn = QI(k) - GW(k + 1) * qn;
+      QI(k) = qn;
+    }
+  } else {
+    // remap_profile.py:188-253 for iv != -2
+    double gam, qp;
+    {
+      const double gr = DP(1) / DP(0);
+      const double bet = gr * (gr + 0.5);
+      qp = ((gr + gr) * (gr + 1.0) * Q1(0) + Q1(1)) / bet;
+      gam = (1.0 + gr * (gr + 1.5)) / bet;
+      QI(0) = qp;
+      GW(0) = gam;
+    }
+    for (int k = 1; k < km; ++k) {
+      const double d4 = DP(k - 1) / DP(k);
+      const double bet = 2.0 + d4 + d4 - gam;
+      qp = (3.0 * (Q1(k - 1) + d4 * Q1(k)) - qp) / bet;
+      gam = d4 / bet;
+      QI(k) = qp;
+      GW(k) = gam;
+    }
+    {
+      const double d4 = DP(km - 2) / DP(km - 1);
+      const double a_bot = 1.0 + d4 * (d4 + 1.5);
+      qp = (2.0 * d4 * (d4 + 1.0) * Q1(km - 1) + Q1(km - 2) - a_bot * qp) / (d4 * (d4 + 0.5) - a_bot * gam);
+      QI(km) = qp;
+    }
+    double qn = qp;
+    for (int k = km - 1; k >= 0; --k) {
+      qn = QI(k) - GW(k) * qn;
+      QI(k) = qn;
+    }
+  }
+#undef Q1
+#undef DP
+#undef QI
+#undef GW
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// coefficients: apply_constraints + set_interpolation_coefficients, one thread per cell
+// ---------------------------------------------------------------------------------------------------------------
+struct RemapCol {
+  const double* a1;  // column base (level 0)
+  const double* qi;
+  long sk;
+  int km;
+  __device__ __forceinline__ double A1(int k) const { return a1[(long)k * sk]; }
+  // gam of apply_constraints (remap_profile.py:295), levels 1 .. km-1
+  __device__ __forceinline__ double gam(int k) const { return A1(k) - A1(k - 1); }
+  // the limited interface value q[k] that apply_constraints leaves (remap_profile.py:290-323), k = 0 .. km
+  template <int IV>
+  __device__ __forceinline__ double qcon(int k) const {
+    double q = qi[(long)k * sk];
+    if (k == 0 || k == km) return q;
+    const double am = A1(k - 1), a0 = A1(k);
+    const double tmp = am > a0 ? am : a0;
+    const double tmp2 = am < a0 ? am : a0;
+    if (k == 1 || k == km - 1) {
+      if (q >= tmp) q = tmp;
+      if (q <= tmp2) q = tmp2;
+      return q;
+    }
+    const double gm = gam(k - 1), gp = gam(k + 1);
+    if (gm * gp > 0) {
+      if (q >= tmp) q = tmp;
+      if (q <= tmp2) q = tmp2;
+    } else if (gm > 0) {
+      if (q <= tmp2) q = tmp2;
+    } else {
+      if (q >= tmp) q = tmp;
+      if (IV == 0) {
+        if (q < 0.0) q = 0.0;
+      }
+    }
+    return q;
+  }
+  __device__ __forceinline__ bool extm_inner(int k) const { return gam(k) * gam(k + 1) < 0.0; }  // k = 1 .. km-2
+};
+
+template <int KORD, int IV>
+__global__ void __launch_bounds__(256)
+k_remap_coefficients(Geo g, RemapWin w, const double* __restrict__ a1, const double* __restrict__ qi,
+                     double* __restrict__ a2o, double* __restrict__ a3o, double* __restrict__ a4o, double qmin) {
+  const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
+  const int j = w.j0 + blockIdx.y * 4 + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > w.i1 || j > w.j1) return;
+  const long c0 = IDX2(g, i, j);
+  const int km = w.km;
+  RemapCol C{a1 + c0, qi + c0, g.sk, km};
+  const double A1 = C.A1(k);
+  double a2 = C.template qcon<IV>(k), a3 = C.template qcon<IV>(k + 1), a4 = 0.0;
+  if (k <= 1) {
+    // the top two layers (remap_profile.py:370-405)
+    if (k == 0) {
+      if (IV == 0) {
+        if (a2 < 0.0) a2 = 0.0;
+      }
+      if (IV == -1) {
+        if (a2 * A1 <= 0.0) a2 = 0.0;
+      }
+      if (IV == 2) {
+        a2 = A1; a3 = A1; a4 = 0.0;
+      } else {
+        a4 = 3.0 * (2.0 * A1 - (a2 + a3));
+        posdef_constraint_iv1(A1, a2, a3, a4);
+      }
+    } else {
+      a4 = 3.0 * (2.0 * A1 - (a2 + a3));
+      remap_constraint(A1, a2, a3, a4, C.extm_inner(1));
+    }
+  } else if (k >= km - 2) {
+    // the bottom two layers (remap_profile.py:546-563)
+    if (k == km - 1) {
+      if (IV == 0) {
+        if (a3 < 0.0) a3 = 0.0;
+      }
+      if (IV == -1) {
+        if (a3 * A1 <= 0.0) a3 = 0.0;
+      }
+    }
+    a4 = 3.0 * (2.0 * A1 - (a2 + a3));
+    if (k == km - 2) remap_constraint(A1, a2, a3, a4, C.extm_inner(km - 2));
+    else posdef_constraint_iv1(A1, a2, a3, a4);
+  } else {
+    // inner layers, 2 .. km-3
+    const double g0 = C.gam(k), gm = C.gam(k - 1), gp = C.gam(k + 1), gpp = C.gam(k + 2);
+    const double pmp_1 = A1 - 2.0 * gp;
+    const double lac_1 = pmp_1 + 1.5 * gpp;
+    const double pmp_2 = A1 + 2.0 * g0;
+    const double lac_2 = pmp_2 - 1.5 * gm;
+    if (KORD == 9) {
+      // set_inner_as_kord9 (remap_profile.py:449-498)
+      const bool e0 = C.extm_inner(k), em = C.extm_inner(k - 1), ep = C.extm_inner(k + 1);
+      if ((e0 && em) || (e0 && ep) || (e0 && (qmin > 0.0 && A1 < qmin))) {
+        a2 = A1; a3 = A1; a4 = 0.0;
+      } else {
+        a4 = 6.0 * A1 - 3.0 * (a2 + a3);
+        if (fabs(a4) > fabs(a2 - a3)) {
+          double tmin = min3(A1, pmp_1, lac_1);
+          double tmax0 = a2 > tmin ? a2 : tmin;
+          double tmax = max3(A1, pmp_1, lac_1);
+          a2 = tmax0 < tmax ? tmax0 : tmax;
+          tmin = min3(A1, pmp_2, lac_2);
+          tmax0 = a3 > tmin ? a3 : tmin;
+          tmax = max3(A1, pmp_2, lac_2);
+          a3 = tmax0 < tmax ? tmax0 : tmax;
+          a4 = 6.0 * A1 - 3.0 * (a2 + a3);
+        }
+      }
+    } else {
+      // set_exts (remap_profile.py:331-338) of the three layers + set_inner_as_kord10 (:500-544)
+      bool e5[3], e6[3];
+#pragma unroll
+      for (int d = -1; d <= 1; ++d) {
+        const double b1 = C.A1(k + d);
+        const double b2 = d == 0 ? a2 : C.template qcon<IV>(k + d);
+        const double b3 = d == 0 ? a3 : (d == -1 ? a2 : C.template qcon<IV>(k + 2));
+        const double x0 = 2.0 * b1 - (b2 + b3);
+        const double x1 = fabs(b2 - b3);
+        e5[d + 1] = fabs(x0) > x1;
+        e6[d + 1] = fabs(3.0 * x0) > x1;
+      }
+      const double tmin2 = min3(A1, pmp_1, lac_1);
+      const double tmax2 = max3(A1, pmp_1, lac_1);
+      const double t2 = a2 > tmin2 ? a2 : tmin2;
+      double tmin3 = A1 < pmp_2 ? A1 : pmp_2;
+      tmin3 = lac_2 < tmin3 ? lac_2 : tmin3;
+      double tmax3 = A1 > pmp_2 ? A1 : pmp_2;
+      tmax3 = lac_2 > tmax3 ? lac_2 : tmax3;
+      const double t3 = a3 > tmin3 ? a3 : tmin3;
+      const bool n5 = e5[0] || e5[2], n6 = e6[0] || e6[2];
+      if (e5[1]) {
+        if (n5) {
+          a2 = A1; a3 = A1;
+        } else if (n6) {
+          a2 = t2 < tmax2 ? t2 : tmax2;
+          a3 = t3 < tmax3 ? t3 : tmax3;
+        }
+      } else if (e6[1]) {
+        if (n5) {
+          a2 = t2 < tmax2 ? t2 : tmax2;
+          a3 = t3 < tmax3 ? t3 : tmax3;
+        }
+      }
+      a4 = 3.0 * (2.0 * A1 - (a2 + a3));
+    }
+    if (IV == 0) posdef_constraint_iv0(A1, a2, a3, a4);
+  }
+  const long c = c0 + (long)k * g.sk;
+  a2o[c] = a2;
+  a3o[c] = a3;
+  a4o[c] = a4;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// lagrangian_contributions (map_single.py:21-93)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_remap_layers(Geo g, RemapWin w, double* __restrict__ q, const double* __restrict__ pe1, const double* __restrict__ pe2,
+               const double* __restrict__ a1, const double* __restrict__ a2, const double* __restrict__ a3,
+               const double* __restrict__ a4) {
+  const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
+  const int j = w.j0 + blockIdx.y;
+  if (i > w.i1 || j > w.j1) return;
+  const long c0 = IDX2(g, i, j);
+  const long sk = g.sk;
+  const int km = w.km;
+#define AT(f, l) f[c0 + (long)(l) * sk]
+  int L = 0;
+  double p1a = AT(pe1, 0), p1b = AT(pe1, 1);  // the source layer's bounds
+  double p2a = AT(pe2, 0);
+  for (int k = 0; k < km; ++k) {
+    const double p2b = AT(pe2, k + 1);
+    double dpl = p1b - p1a;
+    const double pl = (p2a - p1a) / dpl;
+    double out;
+    if (p2b <= p1b) {
+      const double pr = (p2b - p1a) / dpl;
+      const double b2 = AT(a2, L), b3 = AT(a3, L), b4 = AT(a4, L);
+      out = b2 + 0.5 * (b4 + b3 - b2) * (pr + pl) - b4 * 1.0 / 3.0 * (pr * (pr + pl) + pl * pl);
+    } else {
+      double qsum;
+      {
+        const double b2 = AT(a2, L), b3 = AT(a3, L), b4 = AT(a4, L);
+        qsum = (p1b - p2a) * (b2 + 0.5 * (b4 + b3 - b2) * (1.0 + pl) - b4 * 1.0 / 3.0 * (1.0 + pl * (1.0 + pl)));
+      }
+      L = L + 1;
+      p1a = p1b;
+      p1b = (L + 1 <= km) ? AT(pe1, L + 1) : NAN;
+      while (p1b < p2b) {
+        qsum += (p1b - p1a) * AT(a1, L);
+        L = L + 1;
+        p1a = p1b;
+        p1b = (L + 1 <= km) ? AT(pe1, L + 1) : NAN;
+      }
+      const double dp = p2b - p1a;
+      dpl = p1b - p1a;
+      const double esl = dp / dpl;
+      const double b2 = AT(a2, L), b3 = AT(a3, L), b4 = AT(a4, L);
+      qsum += dp * (b2 + 0.5 * esl * (b3 - b2 + b4 * (1.0 - (2.0 / 3.0) * esl)));
+      out = qsum / (p2b - p2a);
+    }
+    AT(q, k) = out;
+    p2a = p2b;
+  }
+#undef AT
+}
+
+#define REMAP_NFIELDS 5
+
+int64_t map_single_workspace_bytes(const Geo& g) {
+  return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double) * REMAP_NFIELDS;
+}
+
+template <int KORD>
+static int launch_coeffs(int iv, dim3 grid, hipStream_t st, const Geo& g, const RemapWin& w, const double* a1, const double* qi,
+                         double* a2, double* a3, double* a4, double qmin) {
+  const dim3 block(64, 4);
+#define RC(IV) hipLaunchKernelGGL((k_remap_coefficients<KORD, IV>), grid, block, 0, st, g, w, a1, qi, a2, a3, a4, qmin)
+  switch (iv) {
+    case 0: RC(0); break;
+    case -1: RC(-1); break;
+    case 2: RC(2); break;
+    default: RC(1); break;  // iv < -1, iv == 1, iv > 2 share one variant (remap_profile.py:398-400)
+  }
+#undef RC
+  return PACE_OK;
+}
+
+int launch_map_single(const Geo& g, void* ws, double* q1, const double* pe1, const double* pe2, const double* qs, double qmin,
+                      int kord, int iv, int xstag, int ystag, hipStream_t st) {
+  kord = kord < 0 ? -kord : kord;
+  if (kord != 9 && kord != 10) return PACE_ERR_UNSUPPORTED;
+  if (g.nk < 6) return PACE_ERR_UNSUPPORTED;
+  if (iv == -2 && !qs) return PACE_ERR_ARG;
+  const long field = g.sk * (g.nk + 1);
+  double* a1 = (double*)ws;
+  double* qi = a1 + field;
+  double* a2 = qi + field;
+  double* a3 = a2 + field;
+  double* a4 = a3 + field;
+  RemapWin w{g.is, g.ie + (xstag ? 1 : 0), g.js, g.je + (ystag ? 1 : 0), g.nk};
+  const int nx = w.i1 - w.i0 + 1, ny = w.j1 - w.j0 + 1;
+  const dim3 cgrid((nx + 63) / 64, ny);
+  // the back substitution's multipliers live in a2's storage until the coefficient kernel overwrites it
+  if (iv == -2) hipLaunchKernelGGL(k_remap_interfaces<true>, cgrid, dim3(64), 0, st, g, w, q1, pe1, qs, a1, qi, a2);
+  else hipLaunchKernelGGL(k_remap_interfaces<false>, cgrid, dim3(64), 0, st, g, w, q1, pe1, qs, a1, qi, a2);
+  const dim3 pgrid((nx + 63) / 64, (ny + 3) / 4, g.nk);
+  if (kord == 9) launch_coeffs<9>(iv, pgrid, st, g, w, a1, qi, a2, a3, a4, qmin);
+  else launch_coeffs<10>(iv, pgrid, st, g, w, a1, qi, a2, a3, a4, qmin);
+  hipLaunchKernelGGL(k_remap_layers, cgrid, dim3(64), 0, st, g, w, q1, pe1, pe2, a1, a2, a3, a4);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}

@@ -338,3 +338,34 @@ REMAP_CASES = {
     "pt_k10_iv1": (10, 1, "pn1", "pn2", None, 184.0),
 }
 REMAP_KM = 79
+
+
+def run_map_single(env, name, d, n=12):
+    """One REMAP_CASES entry through the host class MapSingle: the fixture's compute-window arrays are embedded in full
+    fields (halo 3; everything outside the window is NaN so that any read from there shows).  Returns the window of
+    the remapped field."""
+    import torch
+
+    from pace_amd.fv3core.stencils.map_single import MapSingle
+
+    kord, iv, src, dst, qs, qmin = REMAP_CASES[name]
+    ustag = name.startswith("u_")
+    dims = ["x", "y_interface" if ustag else "y", "z"]
+    nj = n + 1 if ustag else n
+
+    def embed(a):
+        full = np.full((n + 7, n + 7, REMAP_KM + 1), np.nan)
+        full[3:3 + n, 3:3 + nj, :] = a
+        return env.q3(full)
+
+    q, p1, p2 = embed(d[name + "_in"]), embed(d[src]), embed(d[dst])
+    qsq = None
+    if qs is not None:
+        full = np.full((n + 7, n + 7), np.nan)
+        full[3:3 + n, 3:3 + n] = d[qs]
+        qsq = env.q2(full)
+    op = MapSingle(env.stencil_factory, env.qf, kord, iv, dims)
+    op(q, p1, p2, qs=qsq, qmin=qmin)
+    if env.qf.device.type == "cuda":
+        torch.cuda.synchronize()
+    return q.numpy()[3:3 + n, 3:3 + nj, :REMAP_KM]

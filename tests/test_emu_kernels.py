@@ -125,3 +125,15 @@ def test_ord8_transport_emulated_vs_oracle(emu_lib, emu_small_lib, which):
               x_mass_flux=fix["in_x_mass_flux"], y_mass_flux=fix["in_y_mass_flux"])
     assert np.array_equal(ofx[window(12, 1, 0, nk)], fx.numpy()[window(12, 1, 0, nk)])
     assert np.array_equal(ofy[window(12, 0, 1, nk)], fy.numpy()[window(12, 0, 1, nk)])
+
+
+@pytest.mark.parametrize("name", sorted(__import__("helpers").REMAP_CASES))
+def test_map_single_kernels_emulated(emu_lib, name):
+    """k_remap.hip through the host class MapSingle against the run of the reference's MapSingle: bit for bit (the three
+    kernels contain no transcendental)."""
+    from helpers import REMAP_KM, run_map_single
+
+    d = golden("remap_c12.npz")
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, REMAP_KM)
+    out = run_map_single(env, name, d)
+    assert np.array_equal(out, d[name + "_out"][:, :, :REMAP_KM])

@@ -253,3 +253,87 @@ def test_ord8_transport_matches_oracle_c96(lib):
     tr.fvtp2d(g, s["pt"].copy(), s["crx"], s["cry"], s["xfx"], s["yfx"], ofx, ofy, 8)
     assert np.array_equal(ofx[window(n, 1, 0, nz)], fx.numpy()[window(n, 1, 0, nz)])
     assert np.array_equal(ofy[window(n, 0, 1, nz)], fy.numpy()[window(n, 0, 1, nz)])
+
+
+@pytest.mark.parametrize("name", sorted(__import__("helpers").REMAP_CASES))
+def test_map_single_matches_reference_run(lib, name):
+    """MapSingle on the GPU against the run of the reference's MapSingle (tests/golden/remap_c12.npz): bit for bit -- the
+    kernels contain only IEEE add / multiply / divide and are built without FMA contraction."""
+    from helpers import REMAP_KM, run_map_single
+
+    d = golden("remap_c12.npz")
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, REMAP_KM)
+    out = run_map_single(env, name, d)
+    assert np.array_equal(out, d[name + "_out"][:, :, :REMAP_KM])
+
+
+def _remap_columns(n, km, seed, deform):
+    """Synthetic columns: hybrid-like target interfaces, a source coordinate deformed by up to `deform` layers, a smooth field
+    plus noise (so the monotonicity constraints engage)."""
+    rng = np.random.default_rng(seed)
+    ni = n + 7
+    sig = np.linspace(0.0, 1.0, km + 1) ** 1.6
+    ps = 1.0e5 * (1.0 + 0.02 * rng.random((ni, ni)))
+    ptop = 300.0
+    pe2 = ptop + (ps - ptop)[:, :, None] * sig[None, None, :]
+    amp = deform / km * rng.random((ni, ni))
+    s1 = sig[None, None, :] + amp[:, :, None] * np.sin(2.0 * np.pi * sig)[None, None, :]
+    s1[:, :, 0], s1[:, :, km] = 0.0, 1.0
+    pe1 = ptop + (ps - ptop)[:, :, None] * s1
+    q = np.zeros((ni, ni, km + 1))
+    q[:, :, :km] = 250.0 + 40.0 * np.cos(3.0 * np.pi * sig[:km])[None, None, :] + 3.0 * rng.standard_normal((ni, ni, km))
+    return q, pe1, pe2
+
+
+@pytest.mark.parametrize("kord,iv", [(9, 1), (9, 0), (10, 1), (9, -1), (9, -2)])
+def test_map_single_matches_oracle_c48(lib, kord, iv):
+    """All levels, 48 x 48 columns, strongly deformed coordinate (up to 3 layers): bit-exact against the oracle."""
+    import torch
+
+    from oracle import remapping
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils.map_single import MapSingle
+
+    n, km = 48, 79
+    env = Env(lib, "cuda", synthetic.tile_metrics(n, km), n, km)
+    q, pe1, pe2 = _remap_columns(n, km, seed=3 + kord + iv, deform=3.0)
+    qs = 0.1 * q[:, :, km - 1]
+    fq, f1, f2, fs = env.q3(q), env.q3(pe1), env.q3(pe2), env.q2(qs)
+    MapSingle(env.stencil_factory, env.qf, kord, iv, ["x", "y", "z"])(fq, f1, f2, qs=fs if iv == -2 else None, qmin=200.0 if iv == 1 else 0.0)
+    torch.cuda.synchronize()
+    w = (slice(3, 3 + n), slice(3, 3 + n))
+    ref = q[w].copy()
+    remapping.map_single(ref, pe1[w], pe2[w], km, kord, iv, qs=qs[w] if iv == -2 else None, qmin=200.0 if iv == 1 else 0.0)
+    assert np.array_equal(fq.numpy()[w][:, :, :km], ref[:, :, :km])
+
+
+def test_map_single_c192_properties(lib):
+    """BASELINE size: (a) the remap conserves the column integral sum(q dp) (iv = 1, kord 9) to rounding; (b) remapping
+    onto the same coordinate returns the field to rounding; (c) a constant field stays constant to rounding."""
+    import torch
+
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils.map_single import MapSingle
+
+    n, km = 192, 79
+    env = Env(lib, "cuda", synthetic.tile_metrics(n, km), n, km)
+    q, pe1, pe2 = _remap_columns(n, km, seed=17, deform=2.5)
+    w = (slice(3, 3 + n), slice(3, 3 + n))
+    op = MapSingle(env.stencil_factory, env.qf, 9, 1, ["x", "y", "z"])
+    fq, f1, f2 = env.q3(q), env.q3(pe1), env.q3(pe2)
+    op(fq, f1, f2)
+    torch.cuda.synchronize()
+    out = fq.numpy()[w][:, :, :km]
+    before = (q[w][:, :, :km] * np.diff(pe1[w], axis=2)).sum(axis=2)
+    after = (out * np.diff(pe2[w], axis=2)).sum(axis=2)
+    assert np.max(np.abs(after - before) / np.abs(before)) < 1e-13
+    fq = env.q3(q)
+    op(fq, f1, f1)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(fq.numpy()[w][:, :, :km] - q[w][:, :, :km])) < 1e-11
+    c = np.zeros_like(q)
+    c[:, :, :km] = 7.25
+    fq = env.q3(c)
+    op(fq, f1, f2)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(fq.numpy()[w][:, :, :km] - 7.25)) < 1e-12
