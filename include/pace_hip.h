@@ -265,6 +265,18 @@ int64_t pace_map_single_workspace_bytes(const pace_geom_t* geom);
 int pace_map_single(const pace_geom_t* geom, void* workspace, double* q1, const double* pe1, const double* pe2,
                     const double* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream);
 
+/* MapNTracer (Fortran mapn_tracer): fv3core/pace/fv3core/stencils/mapn_tracer.py:13-82 -- nq (<= 16) tracers that share
+ * pe1 / pe2 are remapped (iv = 0, one kord) by ONE three-launch sequence instead of nq MapSingle calls.  tracers is a
+ * HOST array of nq device pointers.  workspace: pace_mapn_tracer_workspace_bytes(geom, nq). */
+int64_t pace_mapn_tracer_workspace_bytes(const pace_geom_t* geom, int nq);
+int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, double* const* tracers, int nq, const double* pe1,
+                     const double* pe2, int kord, void* stream);
+
+/* FillNegativeTracerValues (Fortran fillz): fv3core/pace/fv3core/stencils/fillz.py:120-163 -- negative tracer masses
+ * borrow from the layers above / below, then the column is rescaled; all nq tracers in one launch.  tracers: HOST array
+ * of nq device pointers; dp2: layer thicknesses. */
+int pace_fillz(const pace_geom_t* geom, double* const* tracers, int nq, const double* dp2, void* stream);
+
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation
  * (rotate.py:4-50) and boundary slicing (_boundary_utils.py:58-95) folded into an affine index map.

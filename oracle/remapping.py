@@ -316,3 +316,77 @@ def map_single(q1, pe1, pe2, km, kord, iv, qs=None, qmin=0.0, gam=None):
     remap_profile(qs, a1, a2, a3, a4, dp1, km, kord, iv, qmin, gam)
     lagrangian_contributions(q1, pe1, pe2, a1, a2, a3, a4, dp1, km)
     return q1
+
+
+def fillz(q, dp, km):
+    """fix_tracer (fv3core/pace/fv3core/stencils/fillz.py:15-117, Fortran fillz): negative tracer masses borrow from the
+    layers above / below, then the column is rescaled so that its mass (below the top layer) is unchanged.  In place on
+    q (ni, nj, >= km); dp: layer thicknesses."""
+    ni, nj = q.shape[:2]
+    zfix = np.zeros((ni, nj), dtype=np.int64)
+    lower = np.zeros((ni, nj, km))
+    upper = np.zeros((ni, nj, km))
+    dm = np.zeros((ni, nj, km))
+    dm_pos = np.zeros((ni, nj, km))
+    with np.errstate(all="ignore"):
+        # fix_top (BACKWARD: level 1, then level 0)
+        c = q[:, :, 0] < 0.0
+        q[:, :, 1] = _w(c, q[:, :, 1] + q[:, :, 0] * dp[:, :, 0] / dp[:, :, 1], q[:, :, 1])
+        q[:, :, 0] = _w(q[:, :, 0] < 0, 0.0, q[:, :, 0])
+        dm[:, :, 0] = q[:, :, 0] * dp[:, :, 0]
+        # fix_interior
+        for k in range(1, km - 1):
+            qk, dk = q[:, :, k], dp[:, :, k]
+            lf = lower[:, :, k - 1]
+            qk = _w(lf != 0.0, qk - (lf / dk), qk)
+            neg = qk < 0.0
+            zfix = zfix + neg
+            up = q[:, :, k - 1] * dp[:, :, k - 1]
+            need = -(qk * dk)
+            dq = _w(up < need, up, need)
+            b1 = neg & (q[:, :, k - 1] > 0.0)
+            qk = _w(b1, qk + dq / dk, qk)
+            upper[:, :, k] = _w(b1, dq, upper[:, :, k])
+            lo = q[:, :, k + 1] * dp[:, :, k + 1]
+            need = -(qk * dk)
+            dq = _w(lo < need, lo, need)
+            b2 = neg & (qk < 0.0) & (q[:, :, k + 1] > 0.0)
+            qk = _w(b2, qk + dq / dk, qk)
+            lower[:, :, k] = _w(b2, dq, lower[:, :, k])
+            q[:, :, k] = qk
+        s = slice(0, km - 1)
+        uf = upper[:, :, 1:km]
+        q[:, :, s] = _w(uf != 0.0, q[:, :, s] - uf / dp[:, :, s], q[:, :, s])
+        dm[:, :, s] = q[:, :, s] * dp[:, :, s]
+        dm_pos[:, :, s] = _w(dm[:, :, s] > 0.0, dm[:, :, s], 0.0)
+        # fix_bottom
+        k = km - 1
+        qk, dk = q[:, :, k], dp[:, :, k]
+        lf = lower[:, :, k - 1]
+        qk = _w(lf != 0.0, qk - (lf / dk), qk)
+        qup = q[:, :, k - 1] * dp[:, :, k - 1]
+        qly = -qk * dk
+        dup = _w(qup < qly, qup, qly)
+        b = (qk < 0.0) & (q[:, :, k - 1] > 0.0)
+        zfix = zfix + b
+        qk = _w(b, qk + (dup / dk), qk)
+        upper[:, :, k] = _w(b, dup, upper[:, :, k])
+        q[:, :, k] = qk
+        dm[:, :, k] = qk * dk
+        dm_pos[:, :, k] = _w(dm[:, :, k] > 0.0, dm[:, :, k], 0.0)
+        k = km - 2
+        uf = upper[:, :, km - 1]
+        q[:, :, k] = _w(uf != 0.0, q[:, :, k] - (uf / dp[:, :, k]), q[:, :, k])
+        dm[:, :, k] = _w(uf != 0.0, q[:, :, k] * dp[:, :, k], dm[:, :, k])
+        dm_pos[:, :, k] = _w(uf != 0.0, _w(dm[:, :, k] > 0.0, dm[:, :, k], 0.0), dm_pos[:, :, k])
+        sum0 = np.zeros((ni, nj))
+        sum1 = np.zeros((ni, nj))
+        for k in range(1, km):
+            sum0 = sum0 + dm[:, :, k]
+            sum1 = sum1 + dm_pos[:, :, k]
+        fac = _w(sum0 > 0.0, sum0 / sum1, 0.0)
+        act = (zfix > 0) & (fac > 0.0)
+        for k in range(1, km):
+            v = fac * dm[:, :, k] / dp[:, :, k]
+            q[:, :, k] = _w(act, _w(v > 0.0, v, 0.0), q[:, :, k])
+    return zfix

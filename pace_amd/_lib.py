@@ -121,6 +121,9 @@ _PROTOS = {
     "pace_swap_dp": (C.c_int, [_P(Geom), c_dp, c_dp, C.c_void_p]),
     "pace_map_single_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_map_single": (C.c_int, [_P(Geom), c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double] + [C.c_int] * 4 + [C.c_void_p]),
+    "pace_mapn_tracer_workspace_bytes": (C.c_int64, [_P(Geom), C.c_int]),
+    "pace_mapn_tracer": (C.c_int, [_P(Geom), c_dp, _P(C.c_void_p), C.c_int, c_dp, c_dp, C.c_int, C.c_void_p]),
+    "pace_fillz": (C.c_int, [_P(Geom), _P(C.c_void_p), C.c_int, c_dp, C.c_void_p]),
     "pace_halo_pack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
     "pace_halo_unpack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
 }

@@ -309,13 +309,28 @@ static int halo_check(const pace_geom_t* geom, const pace_halo_desc_t* d, int n)
 }
 
 int64_t pace_map_single_workspace_bytes(const pace_geom_t* geom) {
-  return geom ? map_single_workspace_bytes(make_geo(geom)) : 0;
+  return geom ? map_single_workspace_bytes(make_geo(geom), 1) : 0;
 }
 
 int pace_map_single(const pace_geom_t* geom, void* workspace, double* q1, const double* pe1, const double* pe2,
                     const double* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream) {
   NEED(geom && workspace && q1 && pe1 && pe2);
-  return launch_map_single(make_geo(geom), workspace, q1, pe1, pe2, qs, qmin, kord, iv, xstag, ystag, S(stream));
+  return launch_map_fields(make_geo(geom), workspace, &q1, 1, pe1, pe2, qs, qmin, kord, iv, xstag, ystag, S(stream));
+}
+
+int64_t pace_mapn_tracer_workspace_bytes(const pace_geom_t* geom, int nq) {
+  return (geom && nq > 0) ? map_single_workspace_bytes(make_geo(geom), nq) : 0;
+}
+
+int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, double* const* tracers, int nq, const double* pe1,
+                     const double* pe2, int kord, void* stream) {
+  NEED(geom && workspace && tracers && pe1 && pe2);
+  return launch_map_fields(make_geo(geom), workspace, tracers, nq, pe1, pe2, nullptr, 0.0, kord, 0, 0, 0, S(stream));
+}
+
+int pace_fillz(const pace_geom_t* geom, double* const* tracers, int nq, const double* dp2, void* stream) {
+  NEED(geom && tracers && dp2);
+  return launch_fillz(make_geo(geom), tracers, nq, dp2, S(stream));
 }
 
 int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {

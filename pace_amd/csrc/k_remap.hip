@@ -22,6 +22,15 @@ struct RemapWin {
   int km;
 };
 
+// Fields remapped by one launch sequence (MapNTracer: all tracers share pe1 / pe2; MapSingle: one).  Field f uses the
+// f-th group of five work fields.
+#define REMAP_MAXQ 16
+#define REMAP_NFIELDS 5
+struct RemapBatch {
+  double* q[REMAP_MAXQ];
+  int n;
+};
+
 // ---- the three constraint functions (remap_profile.py:52-151), on scalars ----
 __device__ __forceinline__ void posdef_constraint_iv0(double a1, double& a2, double& a3, double& a4) {
   if (a1 <= 0.0) {
@@ -77,14 +86,20 @@ __device__ __forceinline__ double max3(double a, double p, double l) { return (a
 // ---------------------------------------------------------------------------------------------------------------
 template <bool IVM2>
 __global__ void __launch_bounds__(64)
-k_remap_interfaces(Geo g, RemapWin w, const double* __restrict__ q1, const double* __restrict__ pe1,
-                   const double* __restrict__ qs, double* __restrict__ a1, double* __restrict__ qi, double* __restrict__ gw) {
+k_remap_interfaces(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, const double* __restrict__ qs,
+                   double* __restrict__ ws) {
   const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = w.j0 + blockIdx.y;
   if (i > w.i1 || j > w.j1) return;
   const long c0 = IDX2(g, i, j);
   const long sk = g.sk;
   const int km = w.km;
+  const long field = sk * (g.nk + 1);
+  const double* __restrict__ q1 = B.q[blockIdx.z];
+  double* __restrict__ a1 = ws + (long)blockIdx.z * REMAP_NFIELDS * field;
+  double* __restrict__ qi = a1 + field;
+  double* __restrict__ gw = qi + field;  // (a2's storage: the back substitution's multipliers live there until the
+                                         // coefficient kernel overwrites it)
 #define Q1(k) q1[c0 + (long)(k) * sk]
 #define DP(k) (pe1[c0 + (long)((k) + 1) * sk] - pe1[c0 + (long)(k) * sk])  // set_dp, map_single.py:14-18
 #define QI(k) qi[c0 + (long)(k) * sk]
@@ -203,14 +218,19 @@ struct RemapCol {
 
 template <int KORD, int IV>
 __global__ void __launch_bounds__(256)
-k_remap_coefficients(Geo g, RemapWin w, const double* __restrict__ a1, const double* __restrict__ qi,
-                     double* __restrict__ a2o, double* __restrict__ a3o, double* __restrict__ a4o, double qmin) {
+k_remap_coefficients(Geo g, RemapWin w, double* __restrict__ ws, double qmin) {
   const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = w.j0 + blockIdx.y * 4 + threadIdx.y;
-  const int k = blockIdx.z;
+  const int km = w.km;
+  const int f = blockIdx.z / km, k = blockIdx.z - f * km;
   if (i > w.i1 || j > w.j1) return;
   const long c0 = IDX2(g, i, j);
-  const int km = w.km;
+  const long field = g.sk * (g.nk + 1);
+  const double* __restrict__ a1 = ws + (long)f * REMAP_NFIELDS * field;
+  const double* __restrict__ qi = a1 + field;
+  double* __restrict__ a2o = ws + ((long)f * REMAP_NFIELDS + 2) * field;
+  double* __restrict__ a3o = a2o + field;
+  double* __restrict__ a4o = a3o + field;
   RemapCol C{a1 + c0, qi + c0, g.sk, km};
   const double A1 = C.A1(k);
   double a2 = C.template qcon<IV>(k), a3 = C.template qcon<IV>(k + 1), a4 = 0.0;
@@ -321,15 +341,20 @@ k_remap_coefficients(Geo g, RemapWin w, const double* __restrict__ a1, const dou
 // lagrangian_contributions (map_single.py:21-93)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_remap_layers(Geo g, RemapWin w, double* __restrict__ q, const double* __restrict__ pe1, const double* __restrict__ pe2,
-               const double* __restrict__ a1, const double* __restrict__ a2, const double* __restrict__ a3,
-               const double* __restrict__ a4) {
+k_remap_layers(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, const double* __restrict__ pe2,
+               const double* __restrict__ ws) {
   const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = w.j0 + blockIdx.y;
   if (i > w.i1 || j > w.j1) return;
   const long c0 = IDX2(g, i, j);
   const long sk = g.sk;
   const int km = w.km;
+  const long field = sk * (g.nk + 1);
+  double* __restrict__ q = B.q[blockIdx.z];
+  const double* __restrict__ a1 = ws + (long)blockIdx.z * REMAP_NFIELDS * field;
+  const double* __restrict__ a2 = a1 + 2 * field;
+  const double* __restrict__ a3 = a2 + field;
+  const double* __restrict__ a4 = a3 + field;
 #define AT(f, l) f[c0 + (long)(l) * sk]
   int L = 0;
   double p1a = AT(pe1, 0), p1b = AT(pe1, 1);  // the source layer's bounds
@@ -371,17 +396,122 @@ k_remap_layers(Geo g, RemapWin w, double* __restrict__ q, const double* __restri
 #undef AT
 }
 
-#define REMAP_NFIELDS 5
+// ---------------------------------------------------------------------------------------------------------------
+// FillNegativeTracerValues / fix_tracer (fillz.py:15-117, Fortran fillz).  The reference runs five sequential and four
+// parallel computations over the column with five work fields; here one forward sweep carries the two levels in flight
+// in registers (a level is final once the level below has decided how much it borrows from it), and a second sweep
+// rescales the column only where something was fixed.  One thread per (column, tracer).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_fillz(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ dpf) {
+  const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
+  const int j = w.j0 + blockIdx.y;
+  if (i > w.i1 || j > w.j1) return;
+  const long c0 = IDX2(g, i, j);
+  const long sk = g.sk;
+  const int km = w.km;
+  double* __restrict__ q = B.q[blockIdx.z];
+#define Q(k) q[c0 + (long)(k) * sk]
+#define DPK(k) dpf[c0 + (long)(k) * sk]
+  int zfix = 0;
+  double sum0 = 0.0, sum1 = 0.0;
+  // fix_top (fillz.py:41-52)
+  double dpm = DPK(0), dpk = DPK(1);
+  double qm = Q(0), qk = Q(1);
+  if (qm < 0.0) qk = qk + qm * dpm / dpk;
+  if (qm < 0) qm = 0;
+  double lower_prev = 0.0;
+  double qn = Q(2), dpn = DPK(2);
+  for (int k = 1; k < km; ++k) {
+    // here: qm = q[k-1] as the reference's fix_interior leaves it, qk = q[k] not yet treated, qn = q[k+1] (original)
+    double upper = 0.0, lower = 0.0;
+    if (lower_prev != 0.0) qk = qk - (lower_prev / dpk);
+    if (k < km - 1) {
+      // fix_interior (fillz.py:54-79)
+      if (qk < 0.0) {
+        zfix += 1;
+        if (qm > 0.0) {
+          const double dq = (qm * dpm < -(qk * dpk)) ? qm * dpm : -(qk * dpk);
+          qk = qk + dq / dpk;
+          upper = dq;
+        }
+        if (qk < 0.0 && qn > 0.0) {
+          const double dq = (qn * dpn < -(qk * dpk)) ? qn * dpn : -(qk * dpk);
+          qk = qk + dq / dpk;
+          lower = dq;
+        }
+      }
+    } else {
+      // fix_bottom (fillz.py:87-100)
+      const double qup = qm * dpm;
+      const double qly = -qk * dpk;
+      const double dup = qup < qly ? qup : qly;
+      if (qk < 0.0 && qm > 0.0) {
+        zfix += 1;
+        qk = qk + (dup / dpk);
+        upper = dup;
+      }
+    }
+    // level k-1 is final now (fillz.py:80-85, 101-106)
+    if (upper != 0.0) qm = qm - upper / dpm;
+    Q(k - 1) = qm;
+    if (k - 1 >= 1) {
+      const double dm = qm * dpm;
+      sum0 += dm;
+      sum1 += dm > 0.0 ? dm : 0.0;
+    }
+    qm = qk; dpm = dpk;
+    qk = qn; dpk = dpn;
+    lower_prev = lower;
+    if (k + 2 < km) {
+      qn = Q(k + 2);
+      dpn = DPK(k + 2);
+    }
+  }
+  // qm / dpm hold the bottom level
+  Q(km - 1) = qm;
+  {
+    const double dm = qm * dpm;
+    sum0 += dm;
+    sum1 += dm > 0.0 ? dm : 0.0;
+  }
+  // final_check (fillz.py:111-117)
+  const double fac = sum0 > 0.0 ? sum0 / sum1 : 0.0;
+  if (zfix > 0 && fac > 0.0) {
+    for (int k = 1; k < km; ++k) {
+      const double d = DPK(k);
+      const double dm = Q(k) * d;
+      const double v = fac * dm / d;
+      Q(k) = v > 0.0 ? v : 0.0;
+    }
+  }
+#undef Q
+#undef DPK
+}
 
-int64_t map_single_workspace_bytes(const Geo& g) {
-  return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double) * REMAP_NFIELDS;
+int launch_fillz(const Geo& g, double* const* q, int nq, const double* dp, hipStream_t st) {
+  if (nq < 1 || nq > REMAP_MAXQ) return PACE_ERR_ARG;
+  if (g.nk < 4) return PACE_ERR_UNSUPPORTED;
+  RemapBatch B{};
+  B.n = nq;
+  for (int f = 0; f < nq; ++f) {
+    if (!q[f]) return PACE_ERR_ARG;
+    B.q[f] = q[f];
+  }
+  RemapWin w{g.is, g.ie, g.js, g.je, g.nk};
+  hipLaunchKernelGGL(k_fillz, dim3((g.n + 63) / 64, g.n, nq), dim3(64), 0, st, g, w, B, dp);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+int64_t map_single_workspace_bytes(const Geo& g, int nq) {
+  return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double) * REMAP_NFIELDS * nq;
 }
 
 template <int KORD>
-static int launch_coeffs(int iv, dim3 grid, hipStream_t st, const Geo& g, const RemapWin& w, const double* a1, const double* qi,
-                         double* a2, double* a3, double* a4, double qmin) {
+static int launch_coeffs(int iv, dim3 grid, hipStream_t st, const Geo& g, const RemapWin& w, double* ws, double qmin) {
   const dim3 block(64, 4);
-#define RC(IV) hipLaunchKernelGGL((k_remap_coefficients<KORD, IV>), grid, block, 0, st, g, w, a1, qi, a2, a3, a4, qmin)
+#define RC(IV) hipLaunchKernelGGL((k_remap_coefficients<KORD, IV>), grid, block, 0, st, g, w, ws, qmin)
   switch (iv) {
     case 0: RC(0); break;
     case -1: RC(-1); break;
@@ -392,28 +522,30 @@ static int launch_coeffs(int iv, dim3 grid, hipStream_t st, const Geo& g, const 
   return PACE_OK;
 }
 
-int launch_map_single(const Geo& g, void* ws, double* q1, const double* pe1, const double* pe2, const double* qs, double qmin,
-                      int kord, int iv, int xstag, int ystag, hipStream_t st) {
+// nq fields that share pe1 / pe2, kord, iv, qs and qmin, in one three-launch sequence
+int launch_map_fields(const Geo& g, void* ws_, double* const* q, int nq, const double* pe1, const double* pe2, const double* qs,
+                      double qmin, int kord, int iv, int xstag, int ystag, hipStream_t st) {
   kord = kord < 0 ? -kord : kord;
   if (kord != 9 && kord != 10) return PACE_ERR_UNSUPPORTED;
   if (g.nk < 6) return PACE_ERR_UNSUPPORTED;
+  if (nq < 1 || nq > REMAP_MAXQ) return PACE_ERR_ARG;
   if (iv == -2 && !qs) return PACE_ERR_ARG;
-  const long field = g.sk * (g.nk + 1);
-  double* a1 = (double*)ws;
-  double* qi = a1 + field;
-  double* a2 = qi + field;
-  double* a3 = a2 + field;
-  double* a4 = a3 + field;
+  double* ws = (double*)ws_;
+  RemapBatch B{};
+  B.n = nq;
+  for (int f = 0; f < nq; ++f) {
+    if (!q[f]) return PACE_ERR_ARG;
+    B.q[f] = q[f];
+  }
   RemapWin w{g.is, g.ie + (xstag ? 1 : 0), g.js, g.je + (ystag ? 1 : 0), g.nk};
   const int nx = w.i1 - w.i0 + 1, ny = w.j1 - w.j0 + 1;
-  const dim3 cgrid((nx + 63) / 64, ny);
-  // the back substitution's multipliers live in a2's storage until the coefficient kernel overwrites it
-  if (iv == -2) hipLaunchKernelGGL(k_remap_interfaces<true>, cgrid, dim3(64), 0, st, g, w, q1, pe1, qs, a1, qi, a2);
-  else hipLaunchKernelGGL(k_remap_interfaces<false>, cgrid, dim3(64), 0, st, g, w, q1, pe1, qs, a1, qi, a2);
-  const dim3 pgrid((nx + 63) / 64, (ny + 3) / 4, g.nk);
-  if (kord == 9) launch_coeffs<9>(iv, pgrid, st, g, w, a1, qi, a2, a3, a4, qmin);
-  else launch_coeffs<10>(iv, pgrid, st, g, w, a1, qi, a2, a3, a4, qmin);
-  hipLaunchKernelGGL(k_remap_layers, cgrid, dim3(64), 0, st, g, w, q1, pe1, pe2, a1, a2, a3, a4);
+  const dim3 cgrid((nx + 63) / 64, ny, nq);
+  if (iv == -2) hipLaunchKernelGGL(k_remap_interfaces<true>, cgrid, dim3(64), 0, st, g, w, B, pe1, qs, ws);
+  else hipLaunchKernelGGL(k_remap_interfaces<false>, cgrid, dim3(64), 0, st, g, w, B, pe1, qs, ws);
+  const dim3 pgrid((nx + 63) / 64, (ny + 3) / 4, g.nk * nq);
+  if (kord == 9) launch_coeffs<9>(iv, pgrid, st, g, w, ws, qmin);
+  else launch_coeffs<10>(iv, pgrid, st, g, w, ws, qmin);
+  hipLaunchKernelGGL(k_remap_layers, cgrid, dim3(64), 0, st, g, w, B, pe1, pe2, ws);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

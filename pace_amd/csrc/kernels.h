@@ -102,9 +102,10 @@ int launch_apply_mass_flux(const Geo& g, const Met& m, const double* dp1, const 
                            hipStream_t st);
 int launch_apply_tracer_flux(const Geo& g, const Met& m, double* q, const double* dp1, const double* fx, const double* fy,
                              const double* dp2, hipStream_t st);
-int64_t map_single_workspace_bytes(const Geo& g);
-int launch_map_single(const Geo& g, void* ws, double* q1, const double* pe1, const double* pe2, const double* qs, double qmin,
-                      int kord, int iv, int xstag, int ystag, hipStream_t st);
+int64_t map_single_workspace_bytes(const Geo& g, int nq);
+int launch_map_fields(const Geo& g, void* ws, double* const* q, int nq, const double* pe1, const double* pe2, const double* qs,
+                      double qmin, int kord, int iv, int xstag, int ystag, hipStream_t st);
+int launch_fillz(const Geo& g, double* const* q, int nq, const double* dp, hipStream_t st);
 int launch_swap_dp(const Geo& g, double* dp1, double* dp2, hipStream_t st);
 int launch_zero_data(const Geo& g, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source, double* diss_estd,
                      int first_timestep, hipStream_t st);

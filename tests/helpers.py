@@ -369,3 +369,41 @@ def run_map_single(env, name, d, n=12):
     if env.qf.device.type == "cuda":
         torch.cuda.synchronize()
     return q.numpy()[3:3 + n, 3:3 + nj, :REMAP_KM]
+
+
+def run_mapn_tracer(env, d, kord, nq=7, fill=True, n=12):
+    """MapNTracer (+ fillz) through the host classes on tracers made from the fixture's fields (one of them with negative
+    values so that fillz acts), and the same through the oracle.  Returns (got, expected): lists of window arrays."""
+    import torch
+
+    from oracle import remapping
+    from pace_amd.fv3core.stencils.fillz import tracer_variables
+    from pace_amd.fv3core.stencils.mapn_tracer import MapNTracer
+
+    km = REMAP_KM
+
+    def embed(a):
+        full = np.full((n + 7, n + 7, km + 1), np.nan)
+        full[3:3 + n, 3:3 + n, :] = a
+        return env.q3(full)
+
+    base = [d["qv_k9_iv0_in"], d["fillz0_in"], d["fillz1_in"], d["pt_k9_iv1_in"] * 1e-3, d["qv_k9_iv0_in"] * 0.5 + 1e-4,
+            d["fillz2_in"] * 0.1, d["w_k9_ivm2_in"], d["qv_k9_iv0_in"] * 2.0][:nq]
+    names = tracer_variables[:nq]
+    tracers = {nm: embed(a) for nm, a in zip(names, base)}
+    pe1, pe2 = d["pe1s"], d["pe2"]
+    dp2 = np.zeros_like(pe2)
+    dp2[:, :, :km] = pe2[:, :, 1:] - pe2[:, :, :-1]
+    op = MapNTracer(env.stencil_factory, env.qf, kord, nq, fill, tracers)
+    op(embed(pe1), embed(pe2), embed(dp2), tracers)
+    if env.qf.device.type == "cuda":
+        torch.cuda.synchronize()
+    got = [tracers[nm].numpy()[3:3 + n, 3:3 + n, :km] for nm in names]
+    exp = []
+    for t, a in enumerate(base):
+        q = a.copy()
+        remapping.map_single(q, pe1, pe2, km, 9 if t == 5 else kord, 0)
+        if fill:
+            remapping.fillz(q, dp2, km)
+        exp.append(q[:, :, :km])
+    return got, exp

@@ -137,3 +137,38 @@ def test_map_single_kernels_emulated(emu_lib, name):
     env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, REMAP_KM)
     out = run_map_single(env, name, d)
     assert np.array_equal(out, d[name + "_out"][:, :, :REMAP_KM])
+
+
+def test_fillz_kernel_emulated(emu_lib):
+    """k_fillz through FillNegativeTracerValues against the reference run (three tracers in one launch): bit for bit."""
+    from helpers import REMAP_KM
+
+    from pace_amd.fv3core.stencils.fillz import FillNegativeTracerValues
+
+    d = golden("remap_c12.npz")
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, REMAP_KM)
+
+    def embed(a):
+        full = np.full((19, 19, REMAP_KM + 1), np.nan)
+        full[3:15, 3:15, :] = a
+        return env.q3(full)
+
+    names = ["qvapor", "qliquid", "qrain"]
+    trs = {nm: embed(d[f"fillz{t}_in"]) for t, nm in enumerate(names)}
+    FillNegativeTracerValues(env.stencil_factory, env.qf, 3, trs)(embed(d["fillz_dp"]), trs)
+    for t, nm in enumerate(names):
+        assert np.array_equal(trs[nm].numpy()[3:15, 3:15, :REMAP_KM], d[f"fillz{t}_out"][:, :, :REMAP_KM]), nm
+    with pytest.raises(KeyError):
+        FillNegativeTracerValues(env.stencil_factory, env.qf, 4, trs)
+
+
+@pytest.mark.parametrize("kord", [9, 10])
+def test_mapn_tracer_emulated_vs_oracle(emu_lib, kord):
+    """MapNTracer: seven tracers through the batched remap kernels (kord 10: two groups, tracer 5 stays kord 9) + fillz,
+    against the oracle's per-tracer map_single + fillz: bit for bit."""
+    from helpers import REMAP_KM, run_mapn_tracer
+
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, REMAP_KM)
+    got, exp = run_mapn_tracer(env, golden("remap_c12.npz"), kord)
+    for t, (g, e) in enumerate(zip(got, exp)):
+        assert np.array_equal(g, e), t

@@ -337,3 +337,14 @@ def test_map_single_c192_properties(lib):
     op(fq, f1, f2)
     torch.cuda.synchronize()
     assert np.max(np.abs(fq.numpy()[w][:, :, :km] - 7.25)) < 1e-12
+
+
+@pytest.mark.parametrize("kord", [9, 10])
+def test_mapn_tracer_and_fillz_match_oracle(lib, kord):
+    """MapNTracer (batched remap of seven tracers + fillz) on the GPU against the oracle: bit for bit."""
+    from helpers import REMAP_KM, run_mapn_tracer
+
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, REMAP_KM)
+    got, exp = run_mapn_tracer(env, golden("remap_c12.npz"), kord)
+    for t, (g, e) in enumerate(zip(got, exp)):
+        assert np.array_equal(g, e), t

@@ -190,3 +190,17 @@ def test_map_single_oracle_against_reference_run(name):
     ref = d[name + "_out"]
     assert np.array_equal(q[:, :, :REMAP_KM], ref[:, :, :REMAP_KM])
     assert np.abs(ref[:, :, :REMAP_KM] - d[name + "_in"][:, :, :REMAP_KM]).max() > 0  # the fixture does remap something
+
+
+@pytest.mark.parametrize("t", [0, 1, 2])
+def test_fillz_oracle_against_reference_run(t):
+    """oracle fillz == the reference's FillNegativeTracerValues on tracers with sprinkled / dense negative masses."""
+    from helpers import REMAP_KM
+
+    from oracle import remapping
+
+    d = golden("remap_c12.npz")
+    q = d[f"fillz{t}_in"].copy()
+    remapping.fillz(q, d["fillz_dp"], REMAP_KM)
+    assert np.array_equal(q[:, :, :REMAP_KM], d[f"fillz{t}_out"][:, :, :REMAP_KM])
+    assert (d[f"fillz{t}_in"][:, :, :REMAP_KM] != q[:, :, :REMAP_KM]).mean() > 0.3

@@ -66,6 +66,18 @@ def main():
         dsw.lib.call("pace_d_sw_phases", mask, C.byref(dsw._geom), C.byref(dsw._met), C.byref(dsw._col), C.byref(dsw._cfg),
                      dsw._workspace.data_ptr(), *[dptr(x) for x in fields], float(s["dt"]), dsw.stream())
 
+    from pace_amd.fv3core.stencils.map_single import MapSingle
+
+    rng = np.random.default_rng(1)
+    sig = np.linspace(0.0, 1.0, nz + 1) ** 1.6
+    ps = 1.0e5 * (1.0 + 0.02 * rng.random((n + 7, n + 7)))
+    pe2_h = 300.0 + (ps - 300.0)[:, :, None] * sig[None, None, :]
+    s1 = sig[None, None, :] + (1.5 / nz * rng.random((n + 7, n + 7)))[:, :, None] * np.sin(2.0 * np.pi * sig)[None, None, :]
+    s1[:, :, 0], s1[:, :, nz] = 0.0, 1.0
+    pe1_h = 300.0 + (ps - 300.0)[:, :, None] * s1
+    rq, rp1, rp2 = env.q3(s["pt"]), env.q3(pe1_h), env.q3(pe2_h)
+    remap = MapSingle(env.stencil_factory, env.qf, 9, 1, ["x", "y", "z"])
+
     cases = {
         "fxadv": (lambda: prep(f["uc"], f["vc"], f["crx"], f["cry"], f["xfx"], f["yfx"], ut, vt, s["dt"]), 8),
         "fvtp2d": (lambda: tp(f["pt"], f["crx"], f["cry"], f["xfx"], f["yfx"], fx, fy, x_mass_flux=f["mfx"], y_mass_flux=f["mfy"]), 9),
@@ -73,6 +85,7 @@ def main():
         "delnflux_mass": (lambda: dn2(f["pt"], fx, fy, mass=f["delp"]), 6),
         "riem3": (lambda: riem(False, s["dt"], f["cappa"], m["ptop"], zs, ws, f["delz"], f["q_con"], f["delp"], f["pt"], f["zh"],
                                f["pe"], f["ppe"], f["pk3"], f["pk"], f["peln"], f["w"]), 13),
+        "map_single": (lambda: remap(rq, rp1, rp2), 4),
         "dsw_scalars": (lambda: dsw_phase(2), 18),
         "dsw_winds": (lambda: dsw_phase(12), 20),
         "d_sw": (lambda: dsw(*[f[k] for k in DSW_ARGS], s["dt"]), 32),

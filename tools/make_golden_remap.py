@@ -103,6 +103,29 @@ def main():
         run("qv_k10_iv0_s", np.asarray(state.qvapor.data), 10, 0, c3, pe1s, pe2)
         run("qv_k10_iv0", np.asarray(state.qvapor.data), 10, 0, c3, pe1, pe2)
         run("pt_k10_iv1", np.asarray(state.pt.data), 10, 1, c3, pn1, pn2, qmin=184.0)
+        # FillNegativeTracerValues (fillz.py:120-163) on tracers with negative masses sprinkled in: isolated ones, runs,
+        # at the top and at the bottom, small and large against the neighbours
+        from pace.fv3core.stencils.fillz import FillNegativeTracerValues
+
+        rng = np.random.default_rng(7)
+        dp2 = qf.zeros(c3, units="Pa")
+        dp2.data[:, :, :NZ] = pe2.data[:, :, 1:] - pe2.data[:, :, :-1]
+        names = ["qvapor", "qliquid", "qrain"]
+        trs = {n: qf.zeros(c3, units="kg/kg") for n in names}
+        shp = trs["qvapor"].data.shape
+        base = np.abs(np.asarray(state.qvapor.data)) + 1.0e-6
+        for t, (n, frac, scale) in enumerate(zip(names, (0.08, 0.3, 0.6), (0.5, 2.0, 5.0))):
+            f = base * (0.5 + rng.random(shp))
+            neg = rng.random(shp) < frac
+            f = np.where(neg, -scale * f * rng.random(shp), f)
+            f[:, :, 0] = np.where(rng.random(shp[:2]) < 0.5, -np.abs(f[:, :, 0]), f[:, :, 0])
+            f[:, :, NZ - 1] = np.where(rng.random(shp[:2]) < 0.5, -np.abs(f[:, :, NZ - 1]), f[:, :, NZ - 1])
+            trs[n].data[:] = f
+            out[f"fillz{t}_in"] = np.array(trs[n].data)
+        out["fillz_dp"] = np.array(dp2.data)
+        FillNegativeTracerValues(sf, qf, len(names), trs)(dp2, trs)
+        for t, n in enumerate(names):
+            out[f"fillz{t}_out"] = np.array(trs[n].data)
         return out
 
     res = run_ranks(6, rank)[0]
