@@ -390,3 +390,126 @@ def fillz(q, dp, km):
             v = fac * dm[:, :, k] / dp[:, :, k]
             q[:, :, k] = _w(act, _w(v > 0.0, v, 0.0), q[:, :, k])
     return zfix
+
+
+# =====================================================================================================================
+# LagrangianToEulerian (fv3core/pace/fv3core/stencils/remapping.py:286-695), do_sat_adj = False, non-hydrostatic,
+# kord_tm < 0 (the only modes the reference implements besides the saturation adjustment)
+# =====================================================================================================================
+def _moist_cvm_gz(t):
+    """moist_cv_nwat6_fn + moist_cvm (moist_cv.py:22-46); t: dict of the six water species."""
+    from . import constants as c
+
+    ql = t["qliquid"] + t["qrain"]
+    qs = t["qice"] + t["qsnow"] + t["qgraupel"]
+    gz = ql + qs
+    cvm = (1.0 - (t["qvapor"] + gz)) * c.CV_AIR + t["qvapor"] * c.CV_VAP + ql * c.C_LIQ + qs * c.C_ICE
+    return cvm, gz
+
+
+TRACER_ORDER = ["qvapor", "qliquid", "qrain", "qice", "qsnow", "qgraupel", "qo3mr", "qsgs_tke", "qcld"]
+
+
+def lagrangian_to_eulerian(f, tracers, ak, bk, ptop, akap, zvir, last_step, n, km, o=3, kord_tm=-9, kord_tr=9, kord_wz=9,
+                           kord_mt=9, fill=True, nq=8, work=None):
+    """In place on the dict ``f`` of arrays (ni, nj, km + 1): pt, delp, delz, peln, u, v, w, cappa, q_con, pkz, pk, pe and
+    the 2-D ps, wsd; ``tracers``: dict name -> array.  ``o``: index of the first compute cell in both horizontal
+    directions, ``n``: cells per direction.  ``work``: the operator's persistent pe2 (level values of the extra row
+    je+1 survive from call to call in the reference; zeros for a fresh object)."""
+    from . import constants as c
+
+    C = (slice(o, o + n), slice(o, o + n))          # compute columns
+    CJ = (slice(o, o + n), slice(o, o + n + 1))     # + the extra row (domain_jextra)
+    CI = (slice(o, o + n + 1), slice(o, o + n))     # + the extra column
+    pt, delp, delz, peln, pe = f["pt"], f["delp"], f["delz"], f["peln"], f["pe"]
+    shp = pe.shape
+    pe1, pe2 = np.zeros(shp), (np.zeros(shp) if work is None else work)
+    # init_pe (remapping.py:42-56), domain_jextra
+    pe2[CJ + (0,)] = ptop
+    pe2[CJ + (km,)] = pe[CJ + (km,)]
+    pe1[CJ] = pe[CJ]
+    # moist_cv_pt_pressure (remapping.py:85-171)
+    K = slice(0, km)
+    t = {k: v[C + (K,)] for k, v in tracers.items()}
+    cvm, gz = _moist_cvm_gz(t)
+    f["q_con"][C + (K,)] = gz
+    cappa = c.RDGAS / (c.RDGAS + cvm / (1.0 + zvir * t["qvapor"]))
+    f["cappa"][C + (K,)] = cappa
+    p = pt[C + (K,)]
+    pt[C + (K,)] = p * np.exp(cappa / (1.0 - cappa) * np.log(c.RDG * delp[C + (K,)] / delz[C + (K,)] * p))
+    delz[C + (K,)] = -delz[C + (K,)] / delp[C + (K,)]
+    ps = pe[C + (km,)].copy()
+    f["ps"][C] = ps
+    pn2 = np.zeros(shp)
+    pn2[C + (0,)] = peln[C + (0,)]
+    for k in range(1, km):
+        pe2[C + (k,)] = ak[k] + bk[k] * ps
+    pn2[C + (km,)] = peln[C + (km,)]
+    dp2 = np.zeros(shp)
+    dp2[C + (K,)] = pe2[C + (slice(1, km + 1),)] - pe2[C + (K,)]
+    delp[C + (K,)] = dp2[C + (K,)]
+    # pn2_pk_delp (remapping.py:174-193)
+    pn2[C + (K,)] = np.log(pe2[C + (K,)])
+    f["pk"][C + (K,)] = np.exp(akap * pn2[C + (K,)])
+
+    def remap(field, a, b, kord, iv, win, qs=None, qmin=0.0):
+        q = field[win].copy()
+        map_single(q, a[win], b[win], km, kord, iv, qs=qs, qmin=qmin)
+        field[win + (K,)] = q[:, :, :km]
+
+    # the remaps (remapping.py:587-592)
+    remap(pt, peln, pn2, abs(kord_tm), 1, C, qmin=184.0)
+    for t_index, name in enumerate(TRACER_ORDER[:nq]):
+        remap(tracers[name], pe1, pe2, 9 if t_index == 5 else abs(kord_tr), 0, C)
+    if fill:
+        for name in TRACER_ORDER[:nq]:
+            q = tracers[name][C].copy()
+            fillz(q, dp2[C], km)
+            tracers[name][C + (K,)] = q[:, :, :km]
+    remap(f["w"], pe1, pe2, kord_wz, -2, C, qs=f["wsd"][C])
+    remap(delz, pe1, pe2, kord_wz, 1, C)
+    # undo_delz_adjust_and_copy_peln (remapping.py:59-80)
+    delz[C + (K,)] = -delz[C + (K,)] * delp[C + (K,)]
+    pe0 = np.zeros(shp)
+    pe0[C] = peln[C]
+    peln[C] = pn2[C]
+    # moist_pkz (moist_cv.py:130-172)
+    t = {k: v[C + (K,)] for k, v in tracers.items()}
+    cvm, gz = _moist_cvm_gz(t)
+    f["q_con"][C + (K,)] = gz
+    cappa = c.RDGAS / (c.RDGAS + cvm / (1.0 + zvir * t["qvapor"]))
+    f["cappa"][C + (K,)] = cappa
+    f["pkz"][C + (K,)] = np.exp(cappa * np.log(c.RDG * delp[C + (K,)] / delz[C + (K,)] * pt[C + (K,)]))
+    # pressures_mapu + u (remapping.py:196-227, 624)
+    pe3 = np.zeros(shp)
+    js = slice(o - 1, o + n)  # the row to the south of every row of CJ
+    bot = pe[:, :, km]
+    pe0[CJ + (0,)] = pe[CJ + (0,)]
+    for k in range(1, km + 1):
+        pe0[CJ + (k,)] = 0.5 * (pe[C[0], js, k] + pe1[CJ + (k,)])
+    for k in range(km + 1):
+        bkh = 0.5 * bk[k]
+        pe3[CJ + (k,)] = ak[k] + bkh * (bot[C[0], js] + bot[CJ])
+    remap(f["u"], pe0, pe3, kord_mt, -1, CJ)
+    # pressures_mapv + v (remapping.py:230-254, 627)
+    iw = slice(o - 1, o + n)
+    pe3[CI + (0,)] = ak[0]
+    pe0[CI + (0,)] = pe[CI + (0,)]
+    for k in range(1, km + 1):
+        bkh = 0.5 * bk[k]
+        pe0[CI + (k,)] = 0.5 * (pe[iw, C[1], k] + pe[CI + (k,)])
+        pe3[CI + (k,)] = ak[k] + bkh * (bot[iw, C[1]] + bot[CI])
+    remap(f["v"], pe0, pe3, kord_mt, -1, CI)
+    # update_ua (remapping.py:257-273) + copy_from_below (:276-283): pe = the Eulerian interfaces
+    for k in range(1, km):
+        pe[C + (k,)] = pe2[C + (k,)]
+    # last step / not (remapping.py:675-695)
+    if last_step:
+        KK = slice(0, km + 1)
+        tt = {k: v[C + (KK,)] for k, v in tracers.items()}
+        gz = tt["qliquid"] + tt["qrain"] + tt["qice"] + tt["qsnow"] + tt["qgraupel"]
+        with np.errstate(all="ignore"):
+            pt[C + (KK,)] = (pt[C + (KK,)] + 0.0 * f["pkz"][C + (KK,)]) / ((1.0 + zvir * tt["qvapor"]) * (1.0 - gz))
+    else:
+        pt[C + (K,)] = pt[C + (K,)] / f["pkz"][C + (K,)]
+    return pe2

@@ -204,3 +204,37 @@ def test_fillz_oracle_against_reference_run(t):
     remapping.fillz(q, d["fillz_dp"], REMAP_KM)
     assert np.array_equal(q[:, :, :REMAP_KM], d[f"fillz{t}_out"][:, :, :REMAP_KM])
     assert (d[f"fillz{t}_in"][:, :, :REMAP_KM] != q[:, :, :REMAP_KM]).mean() > 0.3
+
+
+def _l2e_inputs():
+    d = golden("l2e_c12.npz")
+    f = {k[3:]: d[k].copy() for k in d if k.startswith("in_") and not k.startswith("in_tr_")}
+    tr = {k[6:]: d[k].copy() for k in d if k.startswith("in_tr_")}
+    return d, f, tr
+
+
+@pytest.mark.parametrize("last_step", [False, True])
+def test_lagrangian_to_eulerian_oracle_against_reference_run(last_step):
+    """oracle.remapping.lagrangian_to_eulerian == the reference's LagrangianToEulerian (do_sat_adj = False) on tile 0 after
+    an acoustic call, every output, bit for bit (fixture window: compute domain + 1 halo cell, origin 1)."""
+    from oracle import constants as c
+    from oracle import remapping
+
+    d, f, tr = _l2e_inputs()
+    km, n = 79, 12
+    remapping.lagrangian_to_eulerian(f, tr, d["ak"], d["bk"], float(d["ptop"]), c.KAPPA, c.ZVIR, last_step, n, km, o=1, nq=8)
+    cw = (slice(1, 13), slice(1, 13))
+    if last_step:
+        assert np.array_equal(f["pt"][cw][:, :, :km], d["out_last_pt"][cw][:, :, :km])
+        return
+    for key in d:
+        if not key.startswith("out_") or key == "out_last_pt":
+            continue
+        name = key[4:]
+        got = tr[name[3:]] if name.startswith("tr_") else f[name]
+        win = {"u": (slice(1, 13), slice(1, 14)), "v": (slice(1, 14), slice(1, 13))}.get(name, cw)
+        if d[key].ndim == 2:
+            assert np.array_equal(got[cw], d[key][cw]), name
+        else:
+            kk = km + 1 if name in ("pe", "peln", "pk") else km
+            assert np.array_equal(got[win][:, :, :kk], d[key][win][:, :, :kk]), name
