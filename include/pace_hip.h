@@ -277,6 +277,27 @@ int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, double* const* tr
  * of nq device pointers; dp2: layer thicknesses. */
 int pace_fillz(const pace_geom_t* geom, double* const* tracers, int nq, const double* dp2, void* stream);
 
+/* ---- LagrangianToEulerian: the stencils around the remaps (fv3core/pace/fv3core/stencils/remapping.py:286-695 calls them
+ * in this order; pace_amd/fv3core/stencils/remapping.py is the host sequence).  Non-hydrostatic, kord_tm < 0, no saturation
+ * adjustment.  water: HOST array of the six device pointers qvapor, qliquid, qrain, qsnow, qice, qgraupel; ak / bk: device
+ * arrays of nk + 1 hybrid coefficients; ps: 2-D field.
+ *   pace_l2e_prepare   = init_pe (:42-56) + moist_cv_pt_pressure (:85-171) + pn2_pk_delp (:174-193)
+ *   pace_l2e_post      = undo_delz_adjust_and_copy_peln (:59-80) + moist_cv.moist_pkz (moist_cv.py:130-172)
+ *   pace_l2e_pressures = pressures_mapu (dir 0, :196-227) / pressures_mapv (dir 1, :230-254)
+ *   pace_l2e_finish    = update_ua + copy_from_below (:257-283), then moist_pt_last_step (moist_cv.py:84-122, last_step
+ *                        != 0) or adjust_divide_stencil (pt / pkz) */
+int pace_l2e_prepare(const pace_geom_t* geom, const double* const* water, double* q_con, double* pt, double* cappa, double* delp,
+                     double* delz, const double* pe, double* pe1, double* pe2, const double* ak, const double* bk, double* dp2,
+                     double* ps, double* pn2, const double* peln, double* pk, double ptop, double akap, double r_vir,
+                     void* stream);
+int pace_l2e_post(const pace_geom_t* geom, const double* const* water, double* q_con, double* pkz, const double* pt,
+                  double* cappa, const double* delp, double* delz, double* peln, double* pe0, const double* pn2, double r_vir,
+                  void* stream);
+int pace_l2e_pressures(const pace_geom_t* geom, int dir, const double* pe, const double* pe1, const double* ak,
+                       const double* bk, double* pe0, double* pe3, void* stream);
+int pace_l2e_finish(const pace_geom_t* geom, const double* const* water, double* pe, const double* pe2, double* pt,
+                    const double* pkz, double r_vir, int last_step, void* stream);
+
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation
  * (rotate.py:4-50) and boundary slicing (_boundary_utils.py:58-95) folded into an affine index map.

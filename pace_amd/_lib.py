@@ -124,6 +124,10 @@ _PROTOS = {
     "pace_mapn_tracer_workspace_bytes": (C.c_int64, [_P(Geom), C.c_int]),
     "pace_mapn_tracer": (C.c_int, [_P(Geom), c_dp, _P(C.c_void_p), C.c_int, c_dp, c_dp, C.c_int, C.c_void_p]),
     "pace_fillz": (C.c_int, [_P(Geom), _P(C.c_void_p), C.c_int, c_dp, C.c_void_p]),
+    "pace_l2e_prepare": (C.c_int, [_P(Geom), _P(C.c_void_p)] + [c_dp] * 15 + [C.c_double] * 3 + [C.c_void_p]),
+    "pace_l2e_post": (C.c_int, [_P(Geom), _P(C.c_void_p)] + [c_dp] * 9 + [C.c_double, C.c_void_p]),
+    "pace_l2e_pressures": (C.c_int, [_P(Geom), C.c_int] + [c_dp] * 6 + [C.c_void_p]),
+    "pace_l2e_finish": (C.c_int, [_P(Geom), _P(C.c_void_p)] + [c_dp] * 4 + [C.c_double, C.c_int, C.c_void_p]),
     "pace_halo_pack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
     "pace_halo_unpack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
 }

@@ -333,6 +333,42 @@ int pace_fillz(const pace_geom_t* geom, double* const* tracers, int nq, const do
   return launch_fillz(make_geo(geom), tracers, nq, dp2, S(stream));
 }
 
+static bool six(const double* const* w) {
+  if (!w) return false;
+  for (int n = 0; n < 6; ++n)
+    if (!w[n]) return false;
+  return true;
+}
+
+int pace_l2e_prepare(const pace_geom_t* geom, const double* const* water, double* q_con, double* pt, double* cappa, double* delp,
+                     double* delz, const double* pe, double* pe1, double* pe2, const double* ak, const double* bk, double* dp2,
+                     double* ps, double* pn2, const double* peln, double* pk, double ptop, double akap, double r_vir,
+                     void* stream) {
+  NEED(geom && six(water) && q_con && pt && cappa && delp && delz && pe && pe1 && pe2 && ak && bk && dp2 && ps && pn2 && peln && pk);
+  return launch_l2e_prepare(make_geo(geom), water, q_con, pt, cappa, delp, delz, pe, pe1, pe2, ak, bk, dp2, ps, pn2, peln, pk,
+                            ptop, akap, r_vir, S(stream));
+}
+
+int pace_l2e_post(const pace_geom_t* geom, const double* const* water, double* q_con, double* pkz, const double* pt,
+                  double* cappa, const double* delp, double* delz, double* peln, double* pe0, const double* pn2, double r_vir,
+                  void* stream) {
+  NEED(geom && six(water) && q_con && pkz && pt && cappa && delp && delz && peln && pe0 && pn2);
+  return launch_l2e_post(make_geo(geom), water, q_con, pkz, pt, cappa, delp, delz, peln, pe0, pn2, r_vir, S(stream));
+}
+
+int pace_l2e_pressures(const pace_geom_t* geom, int dir, const double* pe, const double* pe1, const double* ak,
+                       const double* bk, double* pe0, double* pe3, void* stream) {
+  NEED(geom && pe && pe1 && ak && bk && pe0 && pe3);
+  if (dir != 0 && dir != 1) return PACE_ERR_ARG;
+  return launch_l2e_pressures(make_geo(geom), dir, pe, pe1, ak, bk, pe0, pe3, S(stream));
+}
+
+int pace_l2e_finish(const pace_geom_t* geom, const double* const* water, double* pe, const double* pe2, double* pt,
+                    const double* pkz, double r_vir, int last_step, void* stream) {
+  NEED(geom && six(water) && pe && pe2 && pt && pkz);
+  return launch_l2e_finish(make_geo(geom), water, pe, pe2, pt, pkz, r_vir, last_step, S(stream));
+}
+
 int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {
   NEED(geom && descs && ndesc > 0);
   if (halo_check(geom, descs, ndesc)) return PACE_ERR_ARG;

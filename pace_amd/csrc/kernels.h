@@ -106,6 +106,16 @@ int64_t map_single_workspace_bytes(const Geo& g, int nq);
 int launch_map_fields(const Geo& g, void* ws, double* const* q, int nq, const double* pe1, const double* pe2, const double* qs,
                       double qmin, int kord, int iv, int xstag, int ystag, hipStream_t st);
 int launch_fillz(const Geo& g, double* const* q, int nq, const double* dp, hipStream_t st);
+int launch_l2e_prepare(const Geo& g, const double* const* water, double* q_con, double* pt, double* cappa, double* delp,
+                       double* delz, const double* pe, double* pe1, double* pe2, const double* ak, const double* bk, double* dp2,
+                       double* ps, double* pn2, const double* peln, double* pk, double ptop, double akap, double r_vir,
+                       hipStream_t st);
+int launch_l2e_post(const Geo& g, const double* const* water, double* q_con, double* pkz, const double* pt, double* cappa,
+                    const double* delp, double* delz, double* peln, double* pe0, const double* pn2, double r_vir, hipStream_t st);
+int launch_l2e_pressures(const Geo& g, int dir, const double* pe, const double* pe1, const double* ak, const double* bk,
+                         double* pe0, double* pe3, hipStream_t st);
+int launch_l2e_finish(const Geo& g, const double* const* water, double* pe, const double* pe2, double* pt, const double* pkz,
+                      double r_vir, int last_step, hipStream_t st);
 int launch_swap_dp(const Geo& g, double* dp1, double* dp2, hipStream_t st);
 int launch_zero_data(const Geo& g, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source, double* diss_estd,
                      int first_timestep, hipStream_t st);

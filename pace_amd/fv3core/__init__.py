@@ -2,5 +2,6 @@ from ._config import (  # noqa: F401
     AcousticDynamicsConfig,
     DGridShallowWaterLagrangianDynamicsConfig,
     DynamicalCoreConfig,
+    RemappingConfig,
     RiemannConfig,
 )

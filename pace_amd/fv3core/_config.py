@@ -81,3 +81,16 @@ class DynamicalCoreConfig:
     @property
     def riemann(self):
         return self.acoustic_dynamics.riemann
+
+
+@dataclasses.dataclass(frozen=True)
+class RemappingConfig:
+    """fv3core/pace/fv3core/_config.py:42-56 (without the saturation-adjustment namelist, which is out of scope)."""
+
+    fill: bool = True
+    kord_tm: int = -9
+    kord_tr: int = 9
+    kord_wz: int = 9
+    kord_mt: int = 9
+    do_sat_adj: bool = False
+    hydrostatic: bool = False

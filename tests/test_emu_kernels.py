@@ -172,3 +172,17 @@ def test_mapn_tracer_emulated_vs_oracle(emu_lib, kord):
     got, exp = run_mapn_tracer(env, golden("remap_c12.npz"), kord)
     for t, (g, e) in enumerate(zip(got, exp)):
         assert np.array_equal(g, e), t
+
+
+@pytest.mark.parametrize("last_step", [False, True])
+def test_lagrangian_to_eulerian_emulated(emu_lib, last_step):
+    """The whole LagrangianToEulerian host sequence (k_l2e.hip + the remap / fillz kernels) against the run of the
+    reference: exact for everything that involves no exp / log, 1e-14 for pt, peln, pk, pkz (libm vs numpy)."""
+    from helpers import check_l2e, run_l2e
+
+    d = golden("l2e_c12.npz")
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, 79)
+    worst = check_l2e(run_l2e(env, d, last_step), d, last_step, 1e-14)
+    for name in ("delp", "delz", "u", "v", "w", "q_con", "pe", "cappa", "tr_qvapor", "tr_qsgs_tke", "ps"):
+        if not last_step:
+            assert worst[name] == 0.0, name

@@ -348,3 +348,18 @@ def test_mapn_tracer_and_fillz_match_oracle(lib, kord):
     got, exp = run_mapn_tracer(env, golden("remap_c12.npz"), kord)
     for t, (g, e) in enumerate(zip(got, exp)):
         assert np.array_equal(g, e), t
+
+
+@pytest.mark.parametrize("last_step", [False, True])
+def test_lagrangian_to_eulerian_matches_reference_run(lib, last_step):
+    """LagrangianToEulerian on the GPU against the run of the reference (tests/golden/l2e_c12.npz).  The reference's own
+    bound for this operator is 2e-8; device exp / log differ from numpy's in the last place, and a remap
+    fed with them can take another limiter branch, so: 1e-11 on every variable, and the mass fields exactly."""
+    from helpers import check_l2e, run_l2e
+
+    d = golden("l2e_c12.npz")
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, 79)
+    worst = check_l2e(run_l2e(env, d, last_step), d, last_step, 1e-11)
+    if not last_step:
+        for name in ("delp", "pe", "ps", "tr_qvapor", "w", "u", "v"):
+            assert worst[name] == 0.0, (name, worst[name])
