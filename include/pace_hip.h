@@ -298,6 +298,24 @@ int pace_l2e_pressures(const pace_geom_t* geom, int dir, const double* pe, const
 int pace_l2e_finish(const pace_geom_t* geom, const double* const* water, double* pe, const double* pe2, double* pt,
                     const double* pkz, double r_vir, int last_step, void* stream);
 
+/* ---- DynamicalCore (fv3core/pace/fv3core/stencils/fv_dynamics.py:92-624): the stencils it runs itself.  water: HOST
+ * array of the six device pointers qvapor, qliquid, qrain, qsnow, qice, qgraupel.
+ *   pace_fv_setup_pt  = moist_cv.fv_setup (moist_cv.py:175-234, moist_phys, nwat 6) + pt_to_potential_density_pt
+ *                       (fv_dynamics.py:41-54): compute_preamble's two stencils in one pass
+ *   pace_omega_from_w = fv_dynamics.py:57-67
+ *   pace_neg_adj3     = AdjustNegativeTracerMixingRatio.__call__ (fv3core/pace/fv3core/stencils/neg_adj3.py:377-420),
+ *                       non-hydrostatic: fix_neg_water, fillq(qgraupel), fillq(qrain), fix_water_vapor_down, fix_neg_cloud
+ *   pace_c2l_ord      = CubedToLatLon's stencil (stencils/pace/stencils/c2l_ord.py:15-112), order 2 or 4 (order 4 expects
+ *                       the halos of u, v updated); a11..a22: 2-D metric fields */
+int pace_fv_setup_pt(const pace_geom_t* geom, double* const* water, double* q_con, double* pkz, double* pt, double* cappa,
+                     const double* delp, const double* delz, double* dp1, void* stream);
+int pace_omega_from_w(const pace_geom_t* geom, const double* delp, const double* delz, const double* w, double* omga,
+                      void* stream);
+int pace_neg_adj3(const pace_geom_t* geom, double* const* water, double* qcld, double* pt, const double* delp, void* stream);
+int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const double* u, const double* v,
+                 const double* a11, const double* a12, const double* a21, const double* a22, double* ua, double* va,
+                 void* stream);
+
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation
  * (rotate.py:4-50) and boundary slicing (_boundary_utils.py:58-95) folded into an affine index map.

@@ -369,6 +369,38 @@ int pace_l2e_finish(const pace_geom_t* geom, const double* const* water, double*
   return launch_l2e_finish(make_geo(geom), water, pe, pe2, pt, pkz, r_vir, last_step, S(stream));
 }
 
+static bool six_rw(double* const* w) {
+  if (!w) return false;
+  for (int n = 0; n < 6; ++n)
+    if (!w[n]) return false;
+  return true;
+}
+
+int pace_fv_setup_pt(const pace_geom_t* geom, double* const* water, double* q_con, double* pkz, double* pt, double* cappa,
+                     const double* delp, const double* delz, double* dp1, void* stream) {
+  NEED(geom && six_rw(water) && q_con && pkz && pt && cappa && delp && delz && dp1);
+  return launch_fv_setup_pt(make_geo(geom), water, q_con, pkz, pt, cappa, delp, delz, dp1, S(stream));
+}
+
+int pace_omega_from_w(const pace_geom_t* geom, const double* delp, const double* delz, const double* w, double* omga,
+                      void* stream) {
+  NEED(geom && delp && delz && w && omga);
+  return launch_omega_from_w(make_geo(geom), delp, delz, w, omga, S(stream));
+}
+
+int pace_neg_adj3(const pace_geom_t* geom, double* const* water, double* qcld, double* pt, const double* delp, void* stream) {
+  NEED(geom && six_rw(water) && qcld && pt && delp);
+  return launch_neg_adj3(make_geo(geom), water, qcld, pt, delp, S(stream));
+}
+
+int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const double* u, const double* v,
+                 const double* a11, const double* a12, const double* a21, const double* a22, double* ua, double* va,
+                 void* stream) {
+  NEED(geom && met && u && v && a11 && a12 && a21 && a22 && ua && va);
+  if (order != 2 && order != 4) return PACE_ERR_ARG;
+  return launch_c2l(make_geo(geom), *met, order, u, v, a11, a12, a21, a22, ua, va, S(stream));
+}
+
 int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {
   NEED(geom && descs && ndesc > 0);
   if (halo_check(geom, descs, ndesc)) return PACE_ERR_ARG;

@@ -116,6 +116,12 @@ int launch_l2e_pressures(const Geo& g, int dir, const double* pe, const double* 
                          double* pe0, double* pe3, hipStream_t st);
 int launch_l2e_finish(const Geo& g, const double* const* water, double* pe, const double* pe2, double* pt, const double* pkz,
                       double r_vir, int last_step, hipStream_t st);
+int launch_fv_setup_pt(const Geo& g, double* const* water, double* q_con, double* pkz, double* pt, double* cappa,
+                       const double* delp, const double* delz, double* dp1, hipStream_t st);
+int launch_omega_from_w(const Geo& g, const double* delp, const double* delz, const double* w, double* omga, hipStream_t st);
+int launch_neg_adj3(const Geo& g, double* const* water, double* qcld, double* pt, const double* delp, hipStream_t st);
+int launch_c2l(const Geo& g, const Met& m, int order, const double* u, const double* v, const double* a11, const double* a12,
+               const double* a21, const double* a22, double* ua, double* va, hipStream_t st);
 int launch_swap_dp(const Geo& g, double* dp1, double* dp2, hipStream_t st);
 int launch_zero_data(const Geo& g, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source, double* diss_estd,
                      int first_timestep, hipStream_t st);

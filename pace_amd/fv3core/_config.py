@@ -73,6 +73,33 @@ class DynamicalCoreConfig:
     k_split: int = 1
     n_split: int = 1
     acoustic_dynamics: AcousticDynamicsConfig = dataclasses.field(default_factory=AcousticDynamicsConfig)
+    # what DynamicalCore itself reads (fv3core/pace/fv3core/_config.py:150-420; defaults = util/pace/util/namelist.py:10-70
+    # with the baseline case's values for the ones it sets)
+    nwat: int = 6
+    moist_phys: bool = True
+    hydrostatic: bool = False
+    z_tracer: bool = True
+    inline_q: bool = False
+    adiabatic: bool = False
+    check_negative: bool = False
+    consv_te: float = 0.0
+    rf_fast: bool = True
+    tau: float = 10.0
+    grid_type: int = 0
+    hord_tr: int = 8
+    c2l_ord: int = 4
+    nf_omega: int = 1
+    fill: bool = True
+    kord_tm: int = -9
+    kord_tr: int = 9
+    kord_wz: int = 9
+    kord_mt: int = 9
+    do_sat_adj: bool = False
+
+    @property
+    def remapping(self):
+        return RemappingConfig(fill=self.fill, kord_tm=self.kord_tm, kord_tr=self.kord_tr, kord_wz=self.kord_wz,
+                               kord_mt=self.kord_mt, do_sat_adj=self.do_sat_adj, hydrostatic=self.hydrostatic)
 
     @property
     def d_grid_shallow_water(self):

@@ -1,6 +1,6 @@
 """DycoreState: the fields the acoustic dynamics read and write, with the reference's names and dims
-(fv3core/pace/fv3core/initialization/dycore_state.py:11-340).  Tracer fields, which only the (out of scope) tracer
-advection and remapping touch, are not carried."""
+(fv3core/pace/fv3core/initialization/dycore_state.py:11-340), and the tracer species that the tracer advection, the
+remapping and neg_adj3 work on."""
 import dataclasses
 
 from ...util.constants import X_DIM, X_INTERFACE_DIM, Y_DIM, Y_INTERFACE_DIM, Z_DIM, Z_INTERFACE_DIM
@@ -15,6 +15,8 @@ _FIELDS = {
     "mfxd": ([X_INTERFACE_DIM, Y_DIM, Z_DIM], "unknown"), "mfyd": ([X_DIM, Y_INTERFACE_DIM, Z_DIM], "unknown"),
     "cxd": ([X_INTERFACE_DIM, Y_DIM, Z_DIM], ""), "cyd": ([X_DIM, Y_INTERFACE_DIM, Z_DIM], ""), "diss_estd": (_C, "unknown"),
     "phis": ([X_DIM, Y_DIM], "m^2 s^-2"),
+    "qvapor": (_C, "kg/kg"), "qliquid": (_C, "kg/kg"), "qrain": (_C, "kg/kg"), "qice": (_C, "kg/kg"), "qsnow": (_C, "kg/kg"),
+    "qgraupel": (_C, "kg/kg"), "qo3mr": (_C, "kg/kg"), "qsgs_tke": (_C, "m**2/s**2"), "qcld": (_C, ""),
 }
 
 
@@ -43,6 +45,15 @@ class DycoreState:
     cyd: object = None
     diss_estd: object = None
     phis: object = None
+    qvapor: object = None
+    qliquid: object = None
+    qrain: object = None
+    qice: object = None
+    qsnow: object = None
+    qgraupel: object = None
+    qo3mr: object = None
+    qsgs_tke: object = None
+    qcld: object = None
 
     @classmethod
     def init_zeros(cls, quantity_factory):

@@ -297,6 +297,8 @@ def _child_main(what, out_path):
         result = run_acoustic_six_tiles(lib, "cuda")
     elif what == "tracer":
         result = run_tracer_six_tiles(lib, "cuda")
+    elif what == "dycore":
+        result = run_dycore_six_tiles(lib, "cuda")
     else:
         raise ValueError(what)
     with open(out_path, "wb") as f:
@@ -470,4 +472,114 @@ def check_l2e(out, d, last_step, tol, n=12, km=79):
             e = compare(ref[win][:, :, :kk], out[name][win][:, :, :kk], near_zero=1e-18)
         worst[name] = e
         assert e < tol, (name, e)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DynamicalCore.step_dynamics on six tiles (tests/golden/dycore_c12_tile*.npz, tools/make_golden_dycore.py)
+# ------------------------------------------------------------------------------------------------------------------
+DYCORE_TRACERS = "qvapor qliquid qrain qice qsnow qgraupel qo3mr qsgs_tke qcld".split()
+DYCORE_OUT = "u v w delz delp pt pe pk peln pkz q_con omga ua va mfxd mfyd cxd cyd".split() + DYCORE_TRACERS
+
+
+def dycore_condensates(tile, shape):
+    """The deterministic content the fixture generator gives the species the test case leaves at zero (the same function
+    as tools/make_golden_dycore.py:condensates -- the generator asserts that its inputs equal it)."""
+    i, j, k = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+    base = 0.5 + 0.5 * np.sin(0.7 * i + 1.3 * j + 0.37 * k + tile)
+    out = {}
+    for n, (name, scale) in enumerate((("qliquid", 2e-4), ("qrain", 1e-4), ("qice", 5e-5), ("qsnow", 3e-5), ("qgraupel", 2e-5),
+                                       ("qo3mr", 1e-6), ("qsgs_tke", 1e-2), ("qcld", 0.3))):
+        f = scale * (0.2 + base * (0.5 + 0.5 * np.cos(0.9 * i - 0.4 * j + 0.11 * k + n)))
+        neg = ((3 * i + 5 * j + 7 * k + n + tile) % 23) == 0
+        if name not in ("qo3mr", "qsgs_tke"):
+            f = np.where(neg, -0.3 * f, f)
+        out[name] = f
+    return out
+
+
+def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz):
+    """One tile's program: state = the acoustic fixture's inputs (identical to the dycore run's, as the generator asserts)
+    with the temperature before the preamble, the vapour and the regenerated condensates; one step_dynamics."""
+    import datetime
+
+    import torch
+
+    from pace_amd.fv3core import DynamicalCoreConfig
+    from pace_amd.fv3core.initialization.dycore_state import DycoreState
+    from pace_amd.fv3core.stencils.fv_dynamics import DynamicalCore
+    from pace_amd.util import CubedSphereCommunicator
+
+    tile = comm.Get_rank()
+    metrics = {k[5:]: v for k, v in fix_ac.items() if k.startswith("grid_")}
+    env = Env(lib, device, metrics, n, nz)
+    cube = CubedSphereCommunicator(comm, device=device, lib=lib)
+    arrays = {k: fix_ac["in_" + k] for k in "u v w delz delp pe pk peln phis uc vc ua va".split()}
+    shape = arrays["delp"].shape
+    pt = np.zeros(shape)
+    pt[3:3 + n, 3:3 + n, :] = fix_dy["in_pt"]
+    qv = np.zeros(shape)
+    qv[3:3 + n, 3:3 + n, :] = fix_dy["in_qvapor"]
+    arrays.update(pt=pt, qvapor=qv, ps=fix_dy["in_ps"])
+    for name, f in dycore_condensates(tile, shape).items():
+        arrays[name] = f * (arrays["delp"] > 0)
+    state = DycoreState.init_from_numpy_arrays(arrays, env.qf)
+    n_split = int(fix_dy["n_split"])
+    config = DynamicalCoreConfig(npx=n + 1, npy=n + 1, npz=nz, dt_atmos=float(fix_dy["timestep"]), k_split=1, n_split=n_split,
+                                 acoustic_dynamics=acoustic_config(n_split))
+    core = DynamicalCore(cube, env.grid_data, env.stencil_factory, env.qf, env.damping, config, state.phis, state,
+                         datetime.timedelta(seconds=float(fix_dy["timestep"])))
+    core.step_dynamics(state)
+    if env.qf.device.type == "cuda":
+        torch.cuda.synchronize()
+    out = {k: getattr(state, k).numpy() for k in DYCORE_OUT}
+    out["ps"] = state.ps.numpy()
+    return out
+
+
+def run_dycore_six_tiles(lib, device, n=12, nz=79):
+    from pace_amd.util import run_tiles
+
+    fa = [golden(f"acoustic_c12_tile{t}.npz") for t in range(6)]
+    fd = [golden(f"dycore_c12_tile{t}.npz") for t in range(6)]
+    return fd, run_tiles(6, lambda comm: run_dycore_tile(comm, lib, device, fa[comm.Get_rank()], fd[comm.Get_rank()], n, nz))
+
+
+def dycore_errors(fix, out, n=12):
+    """max reference-metric error per variable on the fixture's level subset and full columns."""
+    errs = {}
+    ks = fix["k_sel"]
+    for k in DYCORE_OUT:
+        full = out[k]
+        di = 1 if k in ("v", "mfxd", "cxd") else 0
+        dj = 1 if k in ("u", "mfyd", "cyd") else 0
+        nk = 80 if k in ("pe", "pk", "peln") else 79
+        kk = [x for x in ks if x < nk]
+        idx = [list(ks).index(x) for x in kk]
+        got = full[3:3 + n + di, 3:3 + n + dj][:, :, kk]
+        ref = fix["out_" + k][:n + di, :n + dj][:, :, idx]
+        band = 1e-6 if k in ("mfxd", "mfyd", "cxd", "cyd") else 1e-12
+        near_zero = band * float(np.abs(ref).max()) + 1e-300
+        e = compare(ref, got, near_zero=near_zero)
+        cols = np.stack([full[i, j, :nk] for (i, j) in fix["cols"]])
+        e = max(e, compare(fix["col_" + k][:, :nk], cols, near_zero=near_zero))
+        errs[k] = e
+    errs["ps"] = compare(fix["out_ps"][:n, :n], out["ps"][3:3 + n, 3:3 + n])
+    return errs
+
+
+DYCORE_TOL = {"w": 5e-6, "omga": 5e-6, "u": 1e-6, "v": 1e-6, "ua": 1e-6, "va": 1e-6, "delz": 1e-6, "mfxd": 1e-7, "mfyd": 1e-7,
+              "cxd": 1e-7, "cyd": 1e-7}
+
+
+def check_dycore(fixes, outs):
+    """Tolerances: the acoustic loop's (5e-6 = the reference's own Riem_Solver3 bound for what the vertical solver feeds, see
+    test_acoustic_dynamics_six_tiles_emulated) carried through tracer advection, remapping (reference bound 2e-8) and the
+    final adjustments; 1e-9 for everything else (masses, temperatures, tracers, pressures)."""
+    worst = {}
+    for t in range(6):
+        for k, e in dycore_errors(fixes[t], outs[t]).items():
+            worst[k] = max(worst.get(k, 0.0), e)
+    for k, e in worst.items():
+        assert e < DYCORE_TOL.get(k, 1e-9), (k, e)
     return worst

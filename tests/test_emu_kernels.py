@@ -186,3 +186,35 @@ def test_lagrangian_to_eulerian_emulated(emu_lib, last_step):
     for name in ("delp", "delz", "u", "v", "w", "q_con", "pe", "cappa", "tr_qvapor", "tr_qsgs_tke", "ps"):
         if not last_step:
             assert worst[name] == 0.0, name
+
+
+def test_neg_adj3_kernels_emulated(emu_lib):
+    """AdjustNegativeTracerMixingRatio (k_fix_neg_water + the four column operators in one launch) against the run of the
+    reference on a state full of negative mixing ratios: bit for bit."""
+    from pace_amd.fv3core.stencils.neg_adj3 import AdjustNegativeTracerMixingRatio
+
+    d = golden("negadj_c12.npz")
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, 79)
+
+    def embed(a):
+        full = np.full((19, 19, 80), np.nan)
+        full[3:15, 3:15, :] = a
+        return env.q3(full)
+
+    names = ["qvapor", "qliquid", "qrain", "qsnow", "qice", "qgraupel", "qcld"]
+    f = {k: embed(d["in_" + k]) for k in names + ["pt", "delp"]}
+    AdjustNegativeTracerMixingRatio(env.stencil_factory, env.qf, False, False)(*[f[k] for k in names], f["pt"], f["delp"])
+    for k in names + ["pt"]:
+        assert np.array_equal(f[k].numpy()[3:15, 3:15, :79], d["out_" + k][:, :, :79]), k
+    with pytest.raises(NotImplementedError):
+        AdjustNegativeTracerMixingRatio(env.stencil_factory, env.qf, True, False)
+
+
+def test_dynamical_core_step_six_tiles_emulated(emu_lib):
+    """One whole DynamicalCore.step_dynamics (fv_setup, pt adjustment, AcousticDynamics with n_split = 2, TracerAdvection of
+    eight tracers, LagrangianToEulerian, omega + its halo update and hyperdiffusion, neg_adj3, CubedToLatLon with its vector
+    halo update) on the six C12 tiles against the run of the reference's DynamicalCore (tools/make_golden_dycore.py)."""
+    from helpers import check_dycore, run_dycore_six_tiles
+
+    fixes, outs = run_dycore_six_tiles(emu_lib, "cpu")
+    check_dycore(fixes, outs)

@@ -363,3 +363,39 @@ def test_lagrangian_to_eulerian_matches_reference_run(lib, last_step):
     if not last_step:
         for name in ("delp", "pe", "ps", "tr_qvapor", "w", "u", "v"):
             assert worst[name] == 0.0, (name, worst[name])
+
+
+def test_neg_adj3_matches_reference_run(lib):
+    from pace_amd.fv3core.stencils.neg_adj3 import AdjustNegativeTracerMixingRatio
+    import torch
+
+    d = golden("negadj_c12.npz")
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, 79)
+
+    def embed(a):
+        full = np.full((19, 19, 80), np.nan)
+        full[3:15, 3:15, :] = a
+        return env.q3(full)
+
+    names = ["qvapor", "qliquid", "qrain", "qsnow", "qice", "qgraupel", "qcld"]
+    f = {k: embed(d["in_" + k]) for k in names + ["pt", "delp"]}
+    AdjustNegativeTracerMixingRatio(env.stencil_factory, env.qf, False, False)(*[f[k] for k in names], f["pt"], f["delp"])
+    torch.cuda.synchronize()
+    for k in names + ["pt"]:
+        assert np.array_equal(f[k].numpy()[3:15, 3:15, :79], d["out_" + k][:, :, :79]), k
+
+
+def test_dynamical_core_step_six_tiles_matches_reference_run(lib, tmp_path):
+    """One whole DynamicalCore.step_dynamics for the six C12 tiles resident on one device against the run of the
+    reference's DynamicalCore (see the emulated twin of this test for what it covers and helpers.check_dycore for the
+    tolerances)."""
+    import json
+    import os
+
+    from helpers import check_dycore
+
+    fixes, outs = run_in_child("dycore", tmp_path)
+    worst = check_dycore(fixes, outs)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        json.dump(worst, open(os.path.join(out_dir, "dycore_c12_gpu_errors.json"), "w"), indent=1)

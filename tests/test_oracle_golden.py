@@ -238,3 +238,15 @@ def test_lagrangian_to_eulerian_oracle_against_reference_run(last_step):
         else:
             kk = km + 1 if name in ("pe", "peln", "pk") else km
             assert np.array_equal(got[win][:, :, :kk], d[key][win][:, :, :kk]), name
+
+
+def test_neg_adj3_oracle_against_reference_run():
+    from oracle import dycore_parts
+
+    d = golden("negadj_c12.npz")
+    names = ["qvapor", "qliquid", "qrain", "qsnow", "qice", "qgraupel", "qcld"]
+    f = {k: d["in_" + k].copy() for k in names + ["pt", "delp"]}
+    dycore_parts.neg_adj3(*[f[k] for k in names], f["pt"], f["delp"], 79)
+    for k in names + ["pt"]:
+        assert np.array_equal(f[k][:, :, :79], d["out_" + k][:, :, :79]), k
+    assert np.abs(d["out_pt"] - d["in_pt"]).max() > 1.0

@@ -17,11 +17,11 @@ import pace.fv3core as fv3core  # noqa: E402
 import pace.util  # noqa: E402
 
 
-def dycore_config(n_split=2, k_split=1, dt_atmos=225.0, npx=13, npz=79):
+def dycore_config(n_split=2, k_split=1, dt_atmos=225.0, npx=13, npz=79, do_sat_adj=True):
     return fv3core.DynamicalCoreConfig(
         layout=(1, 1), npx=npx, npy=npx, npz=npz, ntiles=6, nwat=6, dt_atmos=dt_atmos, a_imp=1.0, beta=0.0,
         consv_te=False, d2_bg=0.0, d2_bg_k1=0.2, d2_bg_k2=0.1, d4_bg=0.15, d_con=1.0, d_ext=0.0, dddmp=0.5,
-        delt_max=0.002, do_sat_adj=True, do_vort_damp=True, fill=True, hord_dp=6, hord_mt=6, hord_tm=6,
+        delt_max=0.002, do_sat_adj=do_sat_adj, do_vort_damp=True, fill=True, hord_dp=6, hord_mt=6, hord_tm=6,
         hord_tr=8, hord_vt=6, hydrostatic=False, k_split=k_split, ke_bg=0.0, kord_mt=9, kord_tm=-9, kord_tr=9,
         kord_wz=9, n_split=n_split, nord=3, p_fac=0.05, rf_fast=True, rf_cutoff=3000.0, tau=10.0, vtdm4=0.06,
         z_tracer=True, do_qa=True,

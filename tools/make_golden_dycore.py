@@ -1,0 +1,128 @@
+"""Generate tests/golden/dycore_c12_tile*.npz and tests/golden/negadj_c12.npz by RUNNING THE REFERENCE in this container
+(6 tile ranks on threads, real halo exchanges, gtscript executed by tools/gtinterp.py):
+
+* one whole ``DynamicalCore.step_dynamics`` (fv_dynamics.py:424-624: fv_setup, the pt adjustment, AcousticDynamics with
+  n_split = 2, TracerAdvection, LagrangianToEulerian, omega + its hyperdiffusion, neg_adj3, CubedToLatLon), k_split = 1,
+  do_sat_adj = False (the saturation adjustment is outside pace_amd's scope).  The condensate species, all zero in the
+  baroclinic test case, are given deterministic content (a few of them negative) so that moist_cv, fillz and neg_adj3
+  act.  Per tile: the state going in (full) and coming out (level subset + a few full columns); the grid metrics are
+  those of acoustic_c12_tile*.npz.
+* AdjustNegativeTracerMixingRatio (neg_adj3.py:296-420) alone on a state with many negative mixing ratios (tile 0).
+
+Data only.
+"""
+import datetime
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+warnings.filterwarnings("ignore")
+
+import numpy as np  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+K_SEL = [0, 1, 2, 3, 4, 40, 77, 78, 79]
+COLS = [(3, 3), (8, 9), (14, 14), (3, 14)]
+N, NZ, N_SPLIT = 12, 79, 2
+TRACERS = "qvapor qliquid qrain qice qsnow qgraupel qo3mr qsgs_tke qcld".split()
+STATE3 = "u v w delz delp pt pe pk peln pkz q_con omga ua va uc vc".split() + TRACERS
+STATE_OUT = "u v w delz delp pt pe pk peln pkz q_con omga ua va mfxd mfyd cxd cyd".split() + TRACERS
+
+
+def condensates(tile, shape):
+    """Deterministic content for the species the test case leaves at zero (function of tile and position only)."""
+    i, j, k = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+    base = 0.5 + 0.5 * np.sin(0.7 * i + 1.3 * j + 0.37 * k + tile)
+    out = {}
+    for n, (name, scale) in enumerate((("qliquid", 2e-4), ("qrain", 1e-4), ("qice", 5e-5), ("qsnow", 3e-5), ("qgraupel", 2e-5),
+                                       ("qo3mr", 1e-6), ("qsgs_tke", 1e-2), ("qcld", 0.3))):
+        f = scale * (0.2 + base * (0.5 + 0.5 * np.cos(0.9 * i - 0.4 * j + 0.11 * k + n)))
+        neg = ((3 * i + 5 * j + 7 * k + n + tile) % 23) == 0
+        if name not in ("qo3mr", "qsgs_tke"):
+            f = np.where(neg, -0.3 * f, f)
+        out[name] = f
+    return out
+
+
+def main():
+    import capture
+    import pace.fv3core as fv3core
+    import refenv
+    from pace.fv3core.stencils.neg_adj3 import AdjustNegativeTracerMixingRatio
+    from threadcomm import run_ranks
+
+    config = capture.dycore_config(n_split=N_SPLIT, npx=N + 1, npz=NZ, do_sat_adj=False)
+
+    def rank(comm):
+        env = refenv.build_rank(comm, N, NZ)
+        state = env.state
+        tile = comm.Get_rank()
+        for name, f in condensates(tile, state.qvapor.data.shape).items():
+            getattr(state, name).data[:] = f * (np.asarray(state.delp.data) > 0)
+        out = {"timestep": np.float64(config.dt_atmos), "n_split": np.int64(N_SPLIT), "k_sel": np.array(K_SEL), "cols": np.array(COLS)}
+        if tile == 0:
+            # neg_adj3 on its own, on a state with many negatives
+            qf, sf = env.qf, env.stencil_factory
+            rng = np.random.default_rng(11)
+            names = ["qvapor", "qliquid", "qrain", "qsnow", "qice", "qgraupel", "qcld"]
+            shp = state.qvapor.data.shape
+            fields = {}
+            for n, nm in enumerate(names):
+                q = qf.zeros(["x", "y", "z"], units="kg/kg")
+                f = (np.abs(np.asarray(state.qvapor.data)) + 1e-5) * (0.3 + rng.random(shp)) * (0.02 if nm != "qvapor" else 1.0)
+                f = np.where(rng.random(shp) < (0.15 + 0.05 * n), -f * rng.random(shp) * 1.5, f)
+                q.data[:] = f
+                fields[nm] = q
+            pt = qf.zeros(["x", "y", "z"], units="K")
+            pt.data[:] = 200.0 + 80.0 * rng.random(shp)
+            delp = qf.zeros(["x", "y", "z"], units="Pa")
+            delp.data[:] = np.where(np.asarray(state.delp.data) > 0, np.asarray(state.delp.data), 1.0)
+            neg = {"in_" + k: np.array(v.data)[3:15, 3:15, :] for k, v in fields.items()}
+            neg["in_pt"], neg["in_delp"] = np.array(pt.data)[3:15, 3:15, :], np.array(delp.data)[3:15, 3:15, :]
+            AdjustNegativeTracerMixingRatio(sf, qf, check_negative=False, hydrostatic=False)(
+                *[fields[k] for k in names], pt, delp)
+            neg.update({"out_" + k: np.array(v.data)[3:15, 3:15, :] for k, v in fields.items()})
+            neg["out_pt"] = np.array(pt.data)[3:15, 3:15, :]
+            np.savez_compressed(os.path.join(GOLDEN, "negadj_c12.npz"), **neg)
+        for name in STATE3:
+            out["in_" + name] = np.array(getattr(state, name).data)
+        out["in_phis"] = np.array(state.phis.data)
+        out["in_ps"] = np.array(state.ps.data)
+        dycore = fv3core.DynamicalCore(
+            comm=env.cube, grid_data=env.grid_data, stencil_factory=env.stencil_factory, quantity_factory=env.qf,
+            damping_coefficients=env.damping, config=config, timestep=datetime.timedelta(seconds=config.dt_atmos),
+            phis=env.state.phis, state=env.state)
+        dycore.step_dynamics(state)
+        for name in STATE_OUT:
+            a = np.array(getattr(state, name).data)
+            out["out_" + name] = np.ascontiguousarray(a[3:16, 3:16][:, :, K_SEL])
+            out["col_" + name] = np.stack([a[i, j, :] for (i, j) in COLS])
+        out["out_ps"] = np.array(state.ps.data)[3:16, 3:16]
+        return out
+
+    res = run_ranks(6, rank)
+    for t, out in enumerate(res):
+        # Inputs: u, v, w, delz, delp, pe, pk, peln, phis, uc, vc, ua, va are those of acoustic_c12_tile{t}.npz (verified
+        # here), the condensates are condensates() (tests/helpers.py carries the same function), q_con / omga / pkz start at
+        # zero or are outputs; what remains is the temperature before the preamble, the vapour and ps.
+        ac = np.load(os.path.join(GOLDEN, f"acoustic_c12_tile{t}.npz"))
+        for k in "u v w delz delp pe pk peln phis uc vc ua va".split():
+            assert np.array_equal(ac["in_" + k], out["in_" + k]), k
+        cond = condensates(t, out["in_qvapor"].shape)
+        for k, f in cond.items():
+            assert np.array_equal(out["in_" + k], f * (out["in_delp"] > 0)), k
+        slim = {k: v for k, v in out.items() if not k.startswith("in_")}
+        for k in ("pt", "qvapor"):
+            slim["in_" + k] = np.ascontiguousarray(out["in_" + k][3:15, 3:15, :])
+        slim["in_ps"] = out["in_ps"]
+        np.savez_compressed(os.path.join(GOLDEN, f"dycore_c12_tile{t}.npz"), **slim)
+        print(t, len(slim))
+    d = np.load(os.path.join(GOLDEN, "negadj_c12.npz"))
+    for k in d.files:
+        if k.startswith("out_"):
+            print(k, float(np.abs(d[k][:, :, :NZ] - d["in_" + k[4:]][:, :, :NZ]).max()), float((d[k][:, :, :NZ] < 0).mean()))
+
+
+if __name__ == "__main__":
+    main()
