@@ -583,3 +583,44 @@ def check_dycore(fixes, outs):
     for k, e in worst.items():
         assert e < DYCORE_TOL.get(k, 1e-9), (k, e)
     return worst
+
+
+def l2e_synthetic_case(n, km, seed=2):
+    """Inputs of LagrangianToEulerian at any size: the synthetic balanced state with its Lagrangian surfaces deformed by a
+    few per cent of a layer ... two layers (column by column), vapour + the deterministic condensates.  Returns
+    (fields, tracers, ak, bk, ptop) as full numpy arrays."""
+    from pace_amd import synthetic
+
+    m = synthetic.tile_metrics(n, km)
+    s = synthetic.acoustic_state(m, n, km)
+    rng = np.random.default_rng(seed)
+    ni = n + 7
+    ak, bk = m["ak"], m["bk"]
+    ptop = float(ak[0])
+    # deform: redistribute the layer thicknesses, keep the column mass
+    sig = np.linspace(0.0, 1.0, km + 1)
+    amp = (2.0 / km) * rng.random((ni, ni))
+    pe_e = s["pe"]
+    ps = pe_e[:, :, km]
+    frac = (pe_e - ptop) / (ps - ptop)[:, :, None]
+    frac = frac + amp[:, :, None] * np.sin(2.0 * np.pi * sig)[None, None, :] * frac * (1.0 - frac) * 4.0
+    frac[:, :, 0], frac[:, :, km] = 0.0, 1.0
+    pe = ptop + (ps - ptop)[:, :, None] * frac
+    f = {}
+    f["pe"] = pe
+    f["peln"] = np.log(pe)
+    delp = np.zeros_like(pe)
+    delp[:, :, :km] = pe[:, :, 1:] - pe[:, :, :-1]
+    f["delp"] = delp
+    for k in ("pt", "delz", "u", "v", "w"):
+        f[k] = s[k].copy()
+    f["pt"][:, :, :km] = s["pt"][:, :, :km] * 300.0  # a temperature-like magnitude (the operator takes logs of it)
+    for k in ("cappa", "q_con", "pkz", "pk", "qcld"):
+        f[k] = np.zeros_like(pe)
+    f["pk"][:, :, km] = np.exp(0.2857 * np.log(pe[:, :, km]))
+    f["ps"] = np.zeros((ni, ni))
+    f["wsd"] = 0.01 * rng.standard_normal((ni, ni))
+    f["phis"] = np.zeros((ni, ni))
+    tracers = {"qvapor": 0.01 * np.exp(-4.0 * (1.0 - frac[:, :, :1] * 0 - np.minimum(frac, 1.0))) * (1 + 0.2 * rng.random(pe.shape))}
+    tracers.update({k: v for k, v in dycore_condensates(0, pe.shape).items() if k != "qcld"})
+    return f, tracers, ak, bk, ptop

@@ -399,3 +399,43 @@ def test_dynamical_core_step_six_tiles_matches_reference_run(lib, tmp_path):
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         json.dump(worst, open(os.path.join(out_dir, "dycore_c12_gpu_errors.json"), "w"), indent=1)
+
+
+@pytest.mark.parametrize("n,last_step", [(48, False), (96, True)])
+def test_lagrangian_to_eulerian_matches_oracle(lib, n, last_step):
+    """LagrangianToEulerian at C48 / C96 x 79 (BASELINE's smaller configurations) against the oracle on a synthetic state
+    whose Lagrangian surfaces are displaced by up to two layers: masses, pressures and remapped winds / tracers exactly or
+    to rounding, log-pressure-driven fields (pt, pkz) to 1e-11."""
+    import torch
+
+    from helpers import l2e_synthetic_case
+
+    from oracle import constants as oc
+    from oracle import remapping
+    from pace_amd import synthetic
+    from pace_amd.fv3core import RemappingConfig
+    from pace_amd.fv3core.stencils.remapping import LagrangianToEulerian
+    from pace_amd.util import constants as c
+
+    km = 79
+    f, tr, ak, bk, ptop = l2e_synthetic_case(n, km)
+    env = Env(lib, "cuda", synthetic.tile_metrics(n, km), n, km)
+    qf = {k: (env.q3(v) if v.ndim == 3 else env.q2(v)) for k, v in f.items()}
+    qt = {k: env.q3(v) for k, v in tr.items()}
+    op = LagrangianToEulerian(env.stencil_factory, env.qf, RemappingConfig(), None, 8, None, qt)
+    op(qt, qf["pt"], qf["delp"], qf["delz"], qf["peln"], qf["u"], qf["v"], qf["w"], qf["cappa"], qf["q_con"], qf["qcld"],
+       qf["pkz"], qf["pk"], qf["pe"], qf["phis"], qf["ps"], qf["wsd"], env.kq(ak), env.kq(bk), None, ptop, c.KAPPA, c.ZVIR, last_step,
+       0.0, 100.0)
+    torch.cuda.synchronize()
+    remapping.lagrangian_to_eulerian(f, tr, ak, bk, ptop, oc.KAPPA, oc.ZVIR, last_step, n, km, o=3, nq=8)
+    cw = (slice(3, 3 + n), slice(3, 3 + n))
+    for name in ("delp", "pe", "ps"):
+        got, ref = qf[name].numpy()[cw], f[name][cw]
+        assert np.array_equal(got[..., :km] if got.ndim == 3 else got, ref[..., :km] if ref.ndim == 3 else ref), name
+    for name in ("pt", "delz", "peln", "w", "q_con", "pkz", "pk", "cappa", "u", "v"):
+        win = {"u": (slice(3, 3 + n), slice(3, 4 + n)), "v": (slice(3, 4 + n), slice(3, 3 + n))}.get(name, cw)
+        e = compare(f[name][win][:, :, :km], qf[name].numpy()[win][:, :, :km], near_zero=1e-14)
+        assert e < 1e-11, (name, e)
+    for name in tr:
+        e = compare(tr[name][cw][:, :, :km], qt[name].numpy()[cw][:, :, :km], near_zero=1e-18)
+        assert e < 1e-11, (name, e)
