@@ -164,6 +164,11 @@ def tile_metrics(n, nz=79, n_halo=3, radius=c.RADIUS):
     m["dp_ref"] = p_int[1:] - p_int[:-1]
     m["p_ref"] = p_int
     m["p"] = (p_int[1:] - p_int[:-1]) / np.log(p_int[1:] / p_int[:-1])
+    # local-to-lat-lon wind transform of CubedToLatLon (the reference derives a11 .. a22 from the unit vectors of the real
+    # grid, util/pace/util/grid/generation.py; here a smooth, well-conditioned stand-in -- only used for timing)
+    la, lo_ = m["lat_agrid"], m["lon_agrid"]
+    m["a11"], m["a12"] = 1.0 + 0.05 * np.cos(la), 0.1 * np.sin(lo_) * np.cos(la)
+    m["a21"], m["a22"] = -0.1 * np.sin(la) * np.cos(lo_), 1.0 + 0.05 * np.sin(la) ** 2
     return m
 
 
