@@ -16,12 +16,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=192)
-    ap.add_argument("--nz", type=int, default=79)
-    ap.add_argument("--reps", type=int, default=10)
-    args = ap.parse_args()
+def build_ops(n, nz):
+    """[(name, callable)] for one acoustic substep on one tile + the fields they work on."""
     from helpers import DSW_ARGS, Env
 
     from pace_amd import _lib, synthetic
@@ -37,7 +33,6 @@ def main():
     from pace_amd.fv3core.stencils.updatedzd import UpdateHeightOnDGrid
 
     lib = _lib.load()
-    n, nz = args.n, args.nz
     m = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(m, n, nz)
     env = Env(lib, "cuda", m, n, nz)
@@ -82,6 +77,17 @@ def main():
         ("nh_p_grad", lambda: nh(f["u"], f["v"], f["ppe"], gz, f["pk3"], f["delp"], dt, ptop, 287.05 / 1004.6)),
         ("ray_fast", lambda: ray(f["u"], f["v"], f["w"], gd.dp_ref, gd.p, dt, ptop)),
     ]
+    return ops, f, (ut, vt, gz, omga)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=192)
+    ap.add_argument("--nz", type=int, default=79)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    n, nz = args.n, args.nz
+    ops, f, (ut, vt, gz, omga) = build_ops(n, nz)
     snap = {}
 
     def save():
