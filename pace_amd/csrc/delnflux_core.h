@@ -38,10 +38,10 @@ __device__ __forceinline__ void delnflux_core(const Geo& g, const Met& m, const 
     lidx[t] = jj * DWP + ii;
     pgi[t] = gi;
     pgj[t] = gj;
-    const long c2 = IDX2(g, gi, gj);
-    dv[t] = flx[t] ? m.del6_v[c2] : 0.0;
-    du[t] = flx[t] ? m.del6_u[c2] : 0.0;
-    ra[t] = cel[t] ? m.rarea[c2] : 0.0;
+    const unsigned c2 = (unsigned)(__mul24(gj, g.sj * 8) + (gi << 3));  // byte offset: uniform base + 32-bit lane offset
+    dv[t] = flx[t] ? *(const double*)((const char*)m.del6_v + c2) : 0.0;
+    du[t] = flx[t] ? *(const double*)((const char*)m.del6_u + c2) : 0.0;
+    ra[t] = cel[t] ? *(const double*)((const char*)m.rarea + c2) : 0.0;
     if (own[t]) sd[lidx[t]] = stored ? d0 * src[lidx[t]] : 0.0;
   }
   __syncthreads();

@@ -19,6 +19,12 @@
 #endif
 #include "delnflux_core.h"
 static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the transport tile");
+// Global accesses: uniform field base (SGPR pair) + 32-bit byte offset per lane, so that loads / stores take the
+// `global_load ... v_off, s[base:base+1]` form and the offset arithmetic is two full-rate 32-bit instructions
+// (v_mad_i32_i24 + shift) instead of a quarter-rate 64-bit multiply-add and a 64-bit add per access.  (A field is < 4 GB.)
+#define OFF2(gi, gj) ((unsigned)(__mul24((gj), sj8) + ((gi) << 3)))
+#define LD(p, off) (*(const double*)((const char*)(p) + (off)))
+#define ST(p, off) (*(double*)((char*)(p) + (off)))
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
@@ -73,6 +79,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   const long kb = (long)k * g.sk;
   const int ilo = i0 - 3, jlo = j0 - 3;
   const int sj = g.sj;
+  const int sj8 = sj * 8;
+  const unsigned kb8 = (unsigned)(kb * 8);
   // Thread maps of the outer sweeps (stage 5): the thread that ran the inner x-run of footprint row jj+3 / the inner y-run
   // of footprint column ii+3 also runs the outer run of tile row jj / tile column ii, so the Courant numbers it loaded
   // for the inner sweep are reused from registers instead of being fetched a second time (by then evicted from L2).
@@ -91,7 +99,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     // -- outside in both -- exist only for EX && EY)
     if ((!EX || (gi >= 0 && gi < g.ni)) && (!EY || (gj >= 0 && gj < g.nj))) {
       if (EX && EY) remap_agrid_y(g, gi, gj);
-      v = q[kb + IDX2(g, gi, gj)];
+      v = LD(q, kb8 + OFF2(gi, gj));
     }
     sq[jj][ii] = v;
   }
@@ -126,7 +134,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       int gi = ilo + ii, gj = jlo + jj;
       if ((!EX || (gi >= 0 && gi < g.ni)) && (!EY || (gj >= 0 && gj < g.nj))) {
         if (EX && EY) remap_agrid_y(g, gi, gj);
-        sq[jj][ii] = sq[jj][ii] + dp.add2d[IDX2(g, gi, gj)];
+        sq[jj][ii] = sq[jj][ii] + LD(dp.add2d, OFF2(gi, gj));
       }
     }
     __syncthreads();
@@ -145,12 +153,11 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
-      cc[f] = (col_ok && jj0 + f <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1))) ? cry[kb + IDX2(g, gi, gj)] : 0.0;
+      cc[f] = (col_ok && jj0 + f <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1))) ? LD(cry, kb8 + OFF2(gi, gj)) : 0.0;
       cy_keep[f] = cc[f];
     }
     const double* dya = m.dya;
-    const long col = gi;
-    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; }, out);
+    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gi, p)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
@@ -165,9 +172,9 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int gi = ilo + ii, gj = j0 + jj;
     double val = 0.0;
     if ((!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je))) {
-      const long c2 = IDX2(g, gi, gj);
-      const double y0 = yfx[kb + c2], y1 = yfx[kb + c2 + g.sj];
-      const double a = m.area[c2];
+      const unsigned c2 = OFF2(gi, gj);
+      const double y0 = LD(yfx, kb8 + c2), y1 = LD(yfx, kb8 + c2 + sj8);
+      const double a = LD(m.area, c2);
       val = (sq[jj + 3][ii] * a + y0 * syin[jj][ii] - y1 * syin[jj + 1][ii]) / (a + y0 - y1);
     }
     sqi[jj][ii] = val;
@@ -181,8 +188,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
         int gi = ilo + ii, gj = jlo + jj;
         if (gi >= 0 && gi < g.ni && gj >= 0 && gj < g.nj && (gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) {
           remap_agrid_x(g, gi, gj);
-          double v = q[kb + IDX2(g, gi, gj)];
-          if (dp.add2d) v = v + dp.add2d[IDX2(g, gi, gj)];
+          double v = LD(q, kb8 + OFF2(gi, gj));
+          if (dp.add2d) v = v + LD(dp.add2d, OFF2(gi, gj));
           sq[jj][ii] = v;
         }
       }
@@ -206,11 +213,11 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
-      cc[f] = (row_ok && ii0 + f <= TI && (!EX || (gi >= g.is && gi <= g.ie + 1))) ? crx[kb + IDX2(g, gi, gj)] : 0.0;
+      cc[f] = (row_ok && ii0 + f <= TI && (!EX || (gi >= g.is && gi <= g.ie + 1))) ? LD(crx, kb8 + OFF2(gi, gj)) : 0.0;
       cx_keep[f] = cc[f];
     }
-    const double* dxa = m.dxa + (long)gj * sj;
-    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return dxa[p]; }, out);
+    const double* dxa = m.dxa;
+    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gj)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
@@ -225,9 +232,9 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int gi = i0 + ii, gj = jlo + jj;
     double val = 0.0;
     if ((!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie))) {
-      const long c2 = IDX2(g, gi, gj);
-      const double x0 = xfx[kb + c2], x1 = xfx[kb + c2 + 1];
-      const double a = m.area[c2];
+      const unsigned c2 = OFF2(gi, gj);
+      const double x0 = LD(xfx, kb8 + c2), x1 = LD(xfx, kb8 + c2 + 8);
+      const double a = LD(m.area, c2);
       val = (sq[jj][ii + 3] * a + x0 * sxin[jj][ii] - x1 * sxin[jj][ii + 1]) / (a + x0 - x1);
     }
     sq[jj][ii + 3] = val;  // q_j in place: this thread is the only one that reads or writes this cell in this stage
@@ -252,24 +259,24 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int ii = ii0 + f, gi = gi0 + f;
       calc[f] = (!EY || gj <= g.je) && (!EX || gi <= g.ie + 1) && ii <= TI;
       if (EPI == 0) calc[f] = calc[f] && (ii < TI || gi == g.ie + 1);  // a neighbour stores its own west face
-      const long c = kb + IDX2(g, gi, gj);
+      const unsigned c = kb8 + OFF2(gi, gj);
       cc[f] = calc[f] ? cx_keep[f] : 0.0;  // = crx[c], loaded by this thread for the inner sweep of the same row
-      xu[f] = calc[f] ? xunit[c] : 0.0;
+      xu[f] = calc[f] ? LD(xunit, c) : 0.0;
     }
-    const double* dxa = m.dxa + (long)gj * sj;
-    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return dxa[p]; }, out);
+    const double* dxa = m.dxa;
+    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gj)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       vxf[f] = 0.0;
       if (calc[f]) {
-        const long c = kb + IDX2(g, gi0 + f, gj);
+        const unsigned c = kb8 + OFF2(gi0 + f, gj);
         double v = 0.5 * (out[f] + sxin[jj + 3][ii0 + f]) * xu[f];
-        if (DMODE == 0 && EPI == 0) dp.fx2o[c] = dvx[f];
+        if (DMODE == 0 && EPI == 0) ST(dp.fx2o, c) = dvx[f];
         if (DMODE == 1) v = v + dvx[f];
-        if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - 1] + dp.mass[c]) * dvx[f];
+        if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - 8) + LD(dp.mass, c)) * dvx[f];
         if (EPI == 0) {
-          fx[c] = v;
-          if (dp.accx && (ii0 + f < TI || gi0 + f == g.ie + 1)) dp.accx[c] = dp.accx[c] + v;
+          ST(fx, c) = v;
+          if (dp.accx && (ii0 + f < TI || gi0 + f == g.ie + 1)) ST(dp.accx, c) = LD(dp.accx, c) + v;
         }
         vxf[f] = v;
       }
@@ -288,25 +295,24 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int jj = jj0 + f, gj = gj0 + f;
       calc[f] = (!EX || gi <= g.ie) && (!EY || gj <= g.je + 1) && jj <= TJ;
       if (EPI == 0) calc[f] = calc[f] && (jj < TJ || gj == g.je + 1);
-      const long c = kb + IDX2(g, gi, gj);
+      const unsigned c = kb8 + OFF2(gi, gj);
       cc[f] = calc[f] ? cy_keep[f] : 0.0;  // = cry[c]
-      yu[f] = calc[f] ? yunit[c] : 0.0;
+      yu[f] = calc[f] ? LD(yunit, c) : 0.0;
     }
     const double* dya = m.dya;
-    const long col = gi;
-    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return dya[col + (long)p * sj]; }, out);
+    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gi, p)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       vyf[f] = 0.0;
       if (calc[f]) {
-        const long c = kb + IDX2(g, gi, gj0 + f);
+        const unsigned c = kb8 + OFF2(gi, gj0 + f);
         double v = 0.5 * (out[f] + syin[jj0 + f][ii + 3]) * yu[f];
-        if (DMODE == 0 && EPI == 0) dp.fy2o[c] = dvy[f];
+        if (DMODE == 0 && EPI == 0) ST(dp.fy2o, c) = dvy[f];
         if (DMODE == 1) v = v + dvy[f];
-        if (DMODE == 2) v = v + 0.5 * damp * (dp.mass[c - sj] + dp.mass[c]) * dvy[f];
+        if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - sj8) + LD(dp.mass, c)) * dvy[f];
         if (EPI == 0) {
-          fy[c] = v;
-          if (dp.accy) dp.accy[c] = dp.accy[c] + v;
+          ST(fy, c) = v;
+          if (dp.accy) ST(dp.accy, c) = LD(dp.accy, c) + v;
         }
         vyf[f] = v;
       }
@@ -346,21 +352,21 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int jj = e / TI, ii = e - jj * TI;
       const int gi = i0 + ii, gj = j0 + jj;
       if ((EX && gi > g.ie) || (EY && gj > g.je)) continue;
-      const long c2 = IDX2(g, gi, gj);
-      const long c = kb + c2;
-      const double ra = m.rarea[c2];
-      const double qv = q[c];  // (the LDS copy of q has become q_j)
-      dp.qout[c] = qv * dp.amass[c] + (ax[jj * AXP + ii] - ax[jj * AXP + ii + 1] + ay[jj * AYP + ii] - ay[(jj + 1) * AYP + ii]) * ra;
+      const unsigned c2 = OFF2(gi, gj);
+      const unsigned c = kb8 + c2;
+      const double ra = LD(m.rarea, c2);
+      const double qv = LD(q, c);  // (the LDS copy of q has become q_j)
+      ST(dp.qout, c) = qv * LD(dp.amass, c) + (ax[jj * AXP + ii] - ax[jj * AXP + ii + 1] + ay[jj * AYP + ii] - ay[(jj + 1) * AYP + ii]) * ra;
       if (EPI == 2) {
         double hs = 0.0;
         if (dp.damp_w_k[k] > 1e-5) {
           const double dd8 = dp.ke_bg_k[k] * fabs(dp.dt);
           const double d = (ax2[jj * AXP + ii] - ax2[jj * AXP + ii + 1] + ay2[jj * AYP + ii] - ay2[(jj + 1) * AYP + ii]) * ra;
-          dp.dw[c] = d;
+          ST(dp.dw, c) = d;
           hs = dd8 - d * (qv + 0.5 * d);
         }
-        dp.heat_s[c] = hs;
-        dp.diss_est[c] = hs;
+        ST(dp.heat_s, c) = hs;
+        ST(dp.diss_est, c) = hs;
       }
     }
   }

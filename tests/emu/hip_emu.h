@@ -29,6 +29,7 @@ extern dim3 blockDim, gridDim;
 #define __global__
 #define __device__
 #define __host__
+static inline int __mul24(int a, int b) { return a * b; }
 #define __forceinline__ inline
 #define __shared__ static
 #define __restrict__
