@@ -316,6 +316,13 @@ int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, 
                  const double* a11, const double* a12, const double* a21, const double* a22, double* ua, double* va,
                  void* stream);
 
+/* EXPERIMENTAL, not used by the host classes: the wave-private (barrier-free, LDS-free) formulation of the plain ord-6
+ * transport of pace_fvtp2d for the box of cells [ib, ib+nx) x [jb, jb+ny) whose stencils stay 3+ cells inside the tile
+ * (PACE_ERR_ARG otherwise).  Writes fx, fy on the box only.  See pace_amd/csrc/k_march.hip and DESIGN.md section 8. */
+int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
+                            const double* cry, const double* xfx, const double* yfx, double* fx, double* fy, int ib, int nx, int jb,
+                            int ny, int nlev, void* stream);
+
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation
  * (rotate.py:4-50) and boundary slicing (_boundary_utils.py:58-95) folded into an affine index map.

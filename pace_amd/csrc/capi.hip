@@ -401,6 +401,14 @@ int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, 
   return launch_c2l(make_geo(geom), *met, order, u, v, a11, a12, a21, a22, ua, va, S(stream));
 }
 
+int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
+                            const double* cry, const double* xfx, const double* yfx, double* fx, double* fy, int ib, int nx, int jb,
+                            int ny, int nlev, void* stream) {
+  NEED(geom && met && q && crx && cry && xfx && yfx && fx && fy);
+  if (nlev < 1 || nlev > geom->nk + 1 || nx < 1 || ny < 1) return PACE_ERR_ARG;
+  return launch_fvtp2d_march(make_geo(geom), *met, q, crx, cry, xfx, yfx, fx, fy, ib, nx, jb, ny, nlev, S(stream));
+}
+
 int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {
   NEED(geom && descs && ndesc > 0);
   if (halo_check(geom, descs, ndesc)) return PACE_ERR_ARG;

@@ -122,6 +122,8 @@ int launch_omega_from_w(const Geo& g, const double* delp, const double* delz, co
 int launch_neg_adj3(const Geo& g, double* const* water, double* qcld, double* pt, const double* delp, hipStream_t st);
 int launch_c2l(const Geo& g, const Met& m, int order, const double* u, const double* v, const double* a11, const double* a12,
                const double* a21, const double* a22, double* ua, double* va, hipStream_t st);
+int launch_fvtp2d_march(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
+                        const double* yfx, double* fx, double* fy, int ib, int nx, int jb, int ny, int nlev, hipStream_t st);
 int launch_swap_dp(const Geo& g, double* dp1, double* dp2, hipStream_t st);
 int launch_zero_data(const Geo& g, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source, double* diss_estd,
                      int first_timestep, hipStream_t st);

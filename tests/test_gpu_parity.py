@@ -439,3 +439,38 @@ def test_lagrangian_to_eulerian_matches_oracle(lib, n, last_step):
     for name in tr:
         e = compare(tr[name][cw][:, :, :km], qt[name].numpy()[cw][:, :, :km], near_zero=1e-18)
         assert e < 1e-11, (name, e)
+
+
+def test_marching_transport_probe_matches_tile_kernel(lib):
+    """The experimental wave-private transport kernel (k_march.hip; not on the product path) must produce the bits of the
+    LDS-tile kernel on the interior box it covers -- it is kept only as a measured design alternative."""
+    import ctypes as C
+
+    import torch
+
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
+    from pace_amd.fv3core.stencils.fxadv import FiniteVolumeFluxPrep
+
+    n, nz = 96, 20
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, "cuda", m, n, nz)
+    f = {k: env.q3(s[k]) for k in ("uc", "vc", "crx", "cry", "xfx", "yfx", "pt")}
+    ut, vt = env.q3(), env.q3()
+    FiniteVolumeFluxPrep(env.stencil_factory, env.grid_data)(f["uc"], f["vc"], f["crx"], f["cry"], f["xfx"], f["yfx"], ut, vt, s["dt"])
+    tp = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 6)
+    fx, fy, gx, gy = env.q3(), env.q3(), env.q3(), env.q3()
+    tp(f["pt"], f["crx"], f["cry"], f["xfx"], f["yfx"], fx, fy)
+    ib, nx, jb, ny = 9, n - 12, 9, n - 13  # a box that is not a multiple of the wave's 58 x 12 patch
+    lib.call("pace_fvtp2d_march_probe", C.byref(tp._geom), C.byref(tp._met), f["pt"].ptr, f["crx"].ptr, f["cry"].ptr,
+             f["xfx"].ptr, f["yfx"].ptr, gx.ptr, gy.ptr, ib, nx, jb, ny, nz, tp.stream())
+    torch.cuda.synchronize()
+    w = (slice(ib, ib + nx), slice(jb, jb + ny), slice(0, nz))
+    assert np.array_equal(fx.numpy()[w], gx.numpy()[w]) and np.array_equal(fy.numpy()[w], gy.numpy()[w])
+    outside = gx.numpy().copy()
+    outside[w] = 0.0
+    assert not outside.any()  # nothing is written outside the box
+    with pytest.raises(Exception):
+        lib.call("pace_fvtp2d_march_probe", C.byref(tp._geom), C.byref(tp._met), f["pt"].ptr, f["crx"].ptr, f["cry"].ptr,
+                 f["xfx"].ptr, f["yfx"].ptr, gx.ptr, gy.ptr, 4, nx, jb, ny, nz, tp.stream())
