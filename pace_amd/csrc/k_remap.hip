@@ -11,8 +11,8 @@
 //                        neighbouring interfaces, the extremum flags of the three neighbouring layers and the layer's
 //                        own coefficients are evaluated in registers; a4_2, a4_3, a4_4 are the only fields written
 //                        (the reference's q, gam, tmp, tmp2, extm, ext5, ext6 never exist)
-//   k_remap_layers       one thread per column: the walk over the source layers (map_single.py:44-93); the
-//                        per-column search index is a register
+//   k_remap_layers       the walk over the source layers (map_single.py:44-93), one thread per column and block of 8
+//                        target levels: the reference's running search index is re-derived by bisection (see there)
 // kord 9 and 10 (the reference asserts |kord| <= 10; kord < 9 is not implemented), every iv.
 #include "common.h"
 #include "kernels.h"
@@ -26,6 +26,7 @@ struct RemapWin {
 // f-th group of five work fields.
 #define REMAP_MAXQ 16
 #define REMAP_NFIELDS 5
+#define REMAP_KB 8  // target levels per thread in k_remap_layers
 struct RemapBatch {
   double* q[REMAP_MAXQ];
   int n;
@@ -104,58 +105,110 @@ k_remap_interfaces(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ p
 #define DP(k) (pe1[c0 + (long)((k) + 1) * sk] - pe1[c0 + (long)(k) * sk])  // set_dp, map_single.py:14-18
 #define QI(k) qi[c0 + (long)(k) * sk]
 #define GW(k) gw[c0 + (long)(k) * sk]
-  for (int k = 0; k < km; ++k) a1[c0 + (long)k * sk] = Q1(k);
+  // Loads are issued a chunk of RC levels ahead of the recurrences that consume them (the loop-carried values are two
+  // doubles; what a level costs otherwise is the latency of its own loads, with less than one wave per SIMD to hide it).
+  constexpr int RC = 8;
+  double pch[RC + 3], qch[RC + 1];
   if (IVM2) {
     // remap_profile.py:183-239 for iv == -2: gw[k] = gam[k]
     const double qsv = qs[c0];
-    double qp = 1.5 * Q1(0);
-    QI(0) = qp;
-    double gam = 0.5;
-    GW(1) = gam;
-    {
-      const double gr = DP(0) / DP(1);
-      const double bet = 2.0 + gr + gr - gam;
-      qp = (3.0 * (Q1(0) + Q1(1)) - qp) / bet;
-      QI(1) = qp;
-    }
-    for (int k = 2; k < km; ++k) {
-      const double old_gr = DP(k - 2) / DP(k - 1);
-      const double old_bet = 2.0 + old_gr + old_gr - gam;
-      gam = old_gr / old_bet;
-      GW(k) = gam;
-      const double gr = DP(k - 1) / DP(k);
-      if (k < km - 1) {
-        const double bet = 2.0 + gr + gr - gam;
-        qp = (3.0 * (Q1(k - 1) + Q1(k)) - qp) / bet;
-      } else {
-        qp = (3.0 * (Q1(k - 1) + Q1(k)) - gr * qsv - qp) / (2.0 + gr + gr - gam);
+    double qp = 0.0, gam = 0.5;
+    for (int kc = 0; kc < km; kc += RC) {
+#pragma unroll
+      for (int t = 0; t < RC + 3; ++t) {
+        const int l = kc - 2 + t;  // pch[t] = pe1[kc - 2 + t]
+        pch[t] = (l >= 0 && l <= km) ? pe1[c0 + (long)l * sk] : 0.0;
       }
-      QI(k) = qp;
+#pragma unroll
+      for (int t = 0; t < RC + 1; ++t) {
+        const int l = kc - 1 + t;  // qch[t] = q1[kc - 1 + t]
+        qch[t] = (l >= 0 && l < km) ? Q1(l) : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < RC; ++t) {
+        const int k = kc + t;
+        if (k >= km) break;
+        const double q0 = qch[t + 1], qm = qch[t];
+        a1[c0 + (long)k * sk] = q0;
+        const double pm2 = pch[t], pm1 = pch[t + 1], p0 = pch[t + 2], pp1 = pch[t + 3];  // pe1[k-2 .. k+1]
+        if (k == 0) {
+          qp = 1.5 * q0;
+        } else if (k == 1) {
+          gam = 0.5;
+          GW(1) = gam;
+          const double gr = (p0 - pm1) / (pp1 - p0);
+          const double bet = 2.0 + gr + gr - gam;
+          qp = (3.0 * (qm + q0) - qp) / bet;
+        } else {
+          const double old_gr = (pm1 - pm2) / (p0 - pm1);
+          const double old_bet = 2.0 + old_gr + old_gr - gam;
+          gam = old_gr / old_bet;
+          GW(k) = gam;
+          const double gr = (p0 - pm1) / (pp1 - p0);
+          if (k < km - 1) {
+            const double bet = 2.0 + gr + gr - gam;
+            qp = (3.0 * (qm + q0) - qp) / bet;
+          } else {
+            qp = (3.0 * (qm + q0) - gr * qsv - qp) / (2.0 + gr + gr - gam);
+          }
+        }
+        QI(k) = qp;
+      }
     }
     QI(km) = qsv;
-    double qn = QI(km - 1);
-    for (int k = km - 2; k >= 0; --k) {
-      qn = QI(k) - GW(k + 1) * qn;
-      QI(k) = qn;
+    double qn = qp;  // = q[km-1]
+    for (int kc = km - 2; kc >= 0; kc -= RC) {
+      double qc[RC], gc[RC];
+#pragma unroll
+      for (int t = 0; t < RC; ++t) {
+        const int k = kc - t;
+        qc[t] = k >= 0 ? QI(k) : 0.0;
+        gc[t] = k >= 0 ? GW(k + 1) : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < RC; ++t) {
+        const int k = kc - t;
+        if (k < 0) break;
+        qn = qc[t] - gc[t] * qn;
+        QI(k) = qn;
+      }
     }
   } else {
     // remap_profile.py:188-253 for iv != -2
-    double gam, qp;
-    {
-      const double gr = DP(1) / DP(0);
-      const double bet = gr * (gr + 0.5);
-      qp = ((gr + gr) * (gr + 1.0) * Q1(0) + Q1(1)) / bet;
-      gam = (1.0 + gr * (gr + 1.5)) / bet;
-      QI(0) = qp;
-      GW(0) = gam;
-    }
-    for (int k = 1; k < km; ++k) {
-      const double d4 = DP(k - 1) / DP(k);
-      const double bet = 2.0 + d4 + d4 - gam;
-      qp = (3.0 * (Q1(k - 1) + d4 * Q1(k)) - qp) / bet;
-      gam = d4 / bet;
-      QI(k) = qp;
-      GW(k) = gam;
+    double gam = 0.0, qp = 0.0;
+    for (int kc = 0; kc < km; kc += RC) {
+#pragma unroll
+      for (int t = 0; t < RC + 2; ++t) {
+        const int l = kc - 1 + t;  // pch[t] = pe1[kc - 1 + t]
+        pch[t] = (l >= 0 && l <= km) ? pe1[c0 + (long)l * sk] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < RC + 1; ++t) {
+        const int l = kc - 1 + t;  // qch[t] = q1[kc - 1 + t]
+        qch[t] = (l >= 0 && l < km) ? Q1(l) : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < RC; ++t) {
+        const int k = kc + t;
+        if (k >= km) break;
+        const double q0 = qch[t + 1], qm = qch[t];
+        a1[c0 + (long)k * sk] = q0;
+        const double pm1 = pch[t], p0 = pch[t + 1], pp1 = pch[t + 2];  // pe1[k-1], pe1[k], pe1[k+1]
+        if (k == 0) {
+          const double pp2 = pch[t + 3];  // pe1[2]
+          const double gr = (pp2 - pp1) / (pp1 - p0);
+          const double bet = gr * (gr + 0.5);
+          qp = ((gr + gr) * (gr + 1.0) * q0 + qch[t + 2]) / bet;
+          gam = (1.0 + gr * (gr + 1.5)) / bet;
+        } else {
+          const double d4 = (p0 - pm1) / (pp1 - p0);
+          const double bet = 2.0 + d4 + d4 - gam;
+          qp = (3.0 * (qm + d4 * q0) - qp) / bet;
+          gam = d4 / bet;
+        }
+        QI(k) = qp;
+        GW(k) = gam;
+      }
     }
     {
       const double d4 = DP(km - 2) / DP(km - 1);
@@ -164,9 +217,21 @@ k_remap_interfaces(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ p
       QI(km) = qp;
     }
     double qn = qp;
-    for (int k = km - 1; k >= 0; --k) {
-      qn = QI(k) - GW(k) * qn;
-      QI(k) = qn;
+    for (int kc = km - 1; kc >= 0; kc -= RC) {
+      double qc[RC], gc[RC];
+#pragma unroll
+      for (int t = 0; t < RC; ++t) {
+        const int k = kc - t;
+        qc[t] = k >= 0 ? QI(k) : 0.0;
+        gc[t] = k >= 0 ? GW(k) : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < RC; ++t) {
+        const int k = kc - t;
+        if (k < 0) break;
+        qn = qc[t] - gc[t] * qn;
+        QI(k) = qn;
+      }
     }
   }
 #undef Q1
@@ -350,16 +415,32 @@ k_remap_layers(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, 
   const long sk = g.sk;
   const int km = w.km;
   const long field = sk * (g.nk + 1);
-  double* __restrict__ q = B.q[blockIdx.z];
-  const double* __restrict__ a1 = ws + (long)blockIdx.z * REMAP_NFIELDS * field;
+  const int nblk = (km + REMAP_KB - 1) / REMAP_KB;
+  const int fld = blockIdx.z / nblk, kblk = blockIdx.z - fld * nblk;
+  double* __restrict__ q = B.q[fld];
+  const double* __restrict__ a1 = ws + (long)fld * REMAP_NFIELDS * field;
   const double* __restrict__ a2 = a1 + 2 * field;
   const double* __restrict__ a3 = a2 + field;
   const double* __restrict__ a4 = a3 + field;
 #define AT(f, l) f[c0 + (long)(l) * sk]
+  // The reference walks the column with one running source-layer index.  Its value when level k begins is
+  // min { L : pe1[L+1] >= pe2[k] } for every k >= 1 (it only ever advances past layers that end strictly above the target
+  // interface, map_single.py:47,65), and 0 for k = 0 -- so a block of levels can start on its own: bisection instead of the
+  // walk from the top, and the column's levels are spread over km / REMAP_KB threads.
+  const int k0 = kblk * REMAP_KB, k1 = (k0 + REMAP_KB < km) ? k0 + REMAP_KB : km;
+  double p2a = AT(pe2, k0);
   int L = 0;
-  double p1a = AT(pe1, 0), p1b = AT(pe1, 1);  // the source layer's bounds
-  double p2a = AT(pe2, 0);
-  for (int k = 0; k < km; ++k) {
+  if (k0 > 0) {
+    int lo = 0, hi = km - 1;  // the answer lies in [lo, hi]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (AT(pe1, mid + 1) >= p2a) hi = mid;
+      else lo = mid + 1;
+    }
+    L = lo;
+  }
+  double p1a = AT(pe1, L), p1b = AT(pe1, L + 1);  // the source layer's bounds
+  for (int k = k0; k < k1; ++k) {
     const double p2b = AT(pe2, k + 1);
     double dpl = p1b - p1a;
     const double pl = (p2a - p1a) / dpl;
@@ -545,7 +626,8 @@ int launch_map_fields(const Geo& g, void* ws_, double* const* q, int nq, const d
   const dim3 pgrid((nx + 63) / 64, (ny + 3) / 4, g.nk * nq);
   if (kord == 9) launch_coeffs<9>(iv, pgrid, st, g, w, ws, qmin);
   else launch_coeffs<10>(iv, pgrid, st, g, w, ws, qmin);
-  hipLaunchKernelGGL(k_remap_layers, cgrid, dim3(64), 0, st, g, w, B, pe1, pe2, ws);
+  const dim3 lgrid((nx + 63) / 64, ny, nq * ((g.nk + REMAP_KB - 1) / REMAP_KB));
+  hipLaunchKernelGGL(k_remap_layers, lgrid, dim3(64), 0, st, g, w, B, pe1, pe2, ws);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
