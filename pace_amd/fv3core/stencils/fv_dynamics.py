@@ -91,14 +91,49 @@ class DynamicalCore(Operator):
                                                                 checkpointer=checkpointer)
         full_xyz_spec = quantity_factory.get_quantity_halo_spec([X_DIM, Y_DIM, Z_DIM], n_halo=self.grid_indexing.n_halo)
         self._omega_halo_updater = WrappedHaloUpdater(comm.get_scalar_halo_updater([full_xyz_spec]), state, ["omga"], comm=comm)
+        self.call_checkpointer = checkpointer is not None
+        self.checkpointer = checkpointer
         self._n_split = config.n_split
         self._k_split = config.k_split
         self._conserve_total_energy = config.consv_te
         self._timestep = timestep.total_seconds()
 
+    # ---- the reference's checkpoint call sites (fv_dynamics.py:321-423): same names, same variables ----
+    def _checkpoint_fvdynamics(self, state, tag: str):
+        if self.call_checkpointer:
+            self.checkpointer(f"FVDynamics-{tag}", u=state.u, v=state.v, w=state.w, delz=state.delz, va=state.va, uc=state.uc,
+                              vc=state.vc, qvapor=state.qvapor)
+
+    def _checkpoint_remapping_in(self, state):
+        if self.call_checkpointer:
+            self.checkpointer("Remapping-In", pt=state.pt, delp=state.delp, delz=state.delz,
+                              peln=state.peln.transpose([X_DIM, Z_INTERFACE_DIM, Y_DIM]), u=state.u, v=state.v, w=state.w,
+                              ua=state.ua, va=state.va, cappa=self._cappa, pk=state.pk,
+                              pe=state.pe.transpose([X_DIM, Z_INTERFACE_DIM, Y_DIM]), phis=state.phis, te_2d=self._te0_2d,
+                              ps=state.ps, wsd=self._wsd, omga=state.omga, dp1=self._dp_initial)
+
+    def _checkpoint_remapping_out(self, state):
+        if self.call_checkpointer:
+            self.checkpointer("Remapping-Out", pt=state.pt, delp=state.delp, delz=state.delz,
+                              peln=state.peln.transpose([X_DIM, Z_INTERFACE_DIM, Y_DIM]), u=state.u, v=state.v, w=state.w,
+                              cappa=self._cappa, pkz=state.pkz, pk=state.pk,
+                              pe=state.pe.transpose([X_DIM, Z_INTERFACE_DIM, Y_DIM]), dp1=self._dp_initial)
+
+    def _checkpoint_tracer_advection_in(self, state):
+        if self.call_checkpointer:
+            self.checkpointer("Tracer2D1L-In", dp1=self._dp_initial, mfxd=state.mfxd, mfyd=state.mfyd, cxd=state.cxd,
+                              cyd=state.cyd)
+
+    def _checkpoint_tracer_advection_out(self, state):
+        if self.call_checkpointer:
+            self.checkpointer("Tracer2D1L-Out", dp1=self._dp_initial, mfxd=state.mfxd, mfyd=state.mfyd, cxd=state.cxd,
+                              cyd=state.cyd)
+
     def step_dynamics(self, state, timer=None):
         """Step the model state forward by one timestep."""
+        self._checkpoint_fvdynamics(state=state, tag="In")
         self._compute(state, timer if timer is not None else _NullTimer())
+        self._checkpoint_fvdynamics(state=state, tag="Out")
 
     def compute_preamble(self, state, is_root_rank: bool):
         if self.config.hydrostatic:
@@ -129,16 +164,20 @@ class DynamicalCore(Operator):
                 self.acoustic_dynamics(state, timestep=self._timestep / self._k_split, n_map=n_map)
             if self.config.z_tracer:
                 with timer.clock("TracerAdvection"):
+                    self._checkpoint_tracer_advection_in(state)
                     self.tracer_advection(self.tracers, self._dp_initial, state.mfxd, state.mfyd, state.cxd, state.cyd)
+                    self._checkpoint_tracer_advection_out(state)
             else:
                 raise NotImplementedError("z_tracer=False is not implemented")
             if self.grid_indexing.domain[2] > 4:
                 with timer.clock("Remapping"):
+                    self._checkpoint_remapping_in(state)
                     self._lagrangian_to_eulerian_obj(
                         self.tracers, state.pt, state.delp, state.delz, state.peln, state.u, state.v, state.w, self._cappa,
                         state.q_con, state.qcld, state.pkz, state.pk, state.pe, state.phis, state.ps, self._wsd, self._ak,
                         self._bk, self._dp_initial, self._ptop, constants.KAPPA, constants.ZVIR, last_step,
                         self._conserve_total_energy, self._timestep / self._k_split)
+                    self._checkpoint_remapping_out(state)
                 if last_step:
                     da_min = float(self._da_min)
                     if not self.config.hydrostatic:

@@ -105,6 +105,16 @@ class Quantity:
     def set(self, array):
         self._data[...] = torch.as_tensor(np.asarray(array), dtype=self._data.dtype, device=self._data.device)
 
+    def transpose(self, target_dims: Sequence[str]) -> "Quantity":
+        """quantity.py:518-560: the same storage seen with its dimensions in another order (a view; what the reference's
+        checkpoint calls use to hand [x, z, y] "Fortran data" to the checkpointer)."""
+        target_dims = tuple(target_dims)
+        if sorted(target_dims) != sorted(self.dims):
+            raise ValueError(f"cannot transpose dims {self.dims} to {target_dims}")
+        order = [self.dims.index(d) for d in target_dims]
+        return Quantity(self._data.permute(*order), target_dims, self.units, origin=[self.origin[n] for n in order],
+                        extent=[self.extent[n] for n in order], base=self._base)
+
     def __repr__(self):
         return f"Quantity(dims={self.dims}, units={self.units!r}, shape={self.shape}, origin={self.origin}, extent={self.extent})"
 

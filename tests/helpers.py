@@ -498,7 +498,7 @@ def dycore_condensates(tile, shape):
     return out
 
 
-def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz):
+def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None):
     """One tile's program: state = the acoustic fixture's inputs (identical to the dycore run's, as the generator asserts)
     with the temperature before the preamble, the vapour and the regenerated condensates; one step_dynamics."""
     import datetime
@@ -528,7 +528,7 @@ def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz):
     config = DynamicalCoreConfig(npx=n + 1, npy=n + 1, npz=nz, dt_atmos=float(fix_dy["timestep"]), k_split=1, n_split=n_split,
                                  acoustic_dynamics=acoustic_config(n_split))
     core = DynamicalCore(cube, env.grid_data, env.stencil_factory, env.qf, env.damping, config, state.phis, state,
-                         datetime.timedelta(seconds=float(fix_dy["timestep"])))
+                         datetime.timedelta(seconds=float(fix_dy["timestep"])), checkpointer=checkpointer)
     core.step_dynamics(state)
     if env.qf.device.type == "cuda":
         torch.cuda.synchronize()
@@ -537,12 +537,14 @@ def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz):
     return out
 
 
-def run_dycore_six_tiles(lib, device, n=12, nz=79):
+def run_dycore_six_tiles(lib, device, n=12, nz=79, checkpointers=None):
     from pace_amd.util import run_tiles
 
     fa = [golden(f"acoustic_c12_tile{t}.npz") for t in range(6)]
     fd = [golden(f"dycore_c12_tile{t}.npz") for t in range(6)]
-    return fd, run_tiles(6, lambda comm: run_dycore_tile(comm, lib, device, fa[comm.Get_rank()], fd[comm.Get_rank()], n, nz))
+    cps = checkpointers or [None] * 6
+    return fd, run_tiles(6, lambda comm: run_dycore_tile(comm, lib, device, fa[comm.Get_rank()], fd[comm.Get_rank()], n, nz,
+                                                         cps[comm.Get_rank()]))
 
 
 def dycore_errors(fix, out, n=12):

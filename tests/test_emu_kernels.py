@@ -216,5 +216,20 @@ def test_dynamical_core_step_six_tiles_emulated(emu_lib):
     halo update) on the six C12 tiles against the run of the reference's DynamicalCore (tools/make_golden_dycore.py)."""
     from helpers import check_dycore, run_dycore_six_tiles
 
-    fixes, outs = run_dycore_six_tiles(emu_lib, "cpu")
+    class Recorder:
+        """Stands in for pace.util.Checkpointer: called with a savepoint name and the variables as keyword arguments."""
+
+        def __init__(self):
+            self.calls = []
+
+        def __call__(self, savepoint_name, **kwargs):
+            self.calls.append((savepoint_name, {k: (tuple(v.dims), tuple(v.shape)) for k, v in kwargs.items()}))
+
+    recs = [Recorder() for _ in range(6)]
+    fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", checkpointers=recs)
     check_dycore(fixes, outs)
+    # the reference's checkpoint call sites, in its order (fv_dynamics.py:436-575), with [x, z, y] views of pe / peln
+    names = [c[0] for c in recs[0].calls]
+    assert names == ["FVDynamics-In", "Tracer2D1L-In", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out", "FVDynamics-Out"]
+    rin = dict(recs[0].calls)["Remapping-In"]
+    assert rin["pe"] == (("x", "z_interface", "y"), (19, 80, 19)) and set(rin) >= {"pt", "delp", "peln", "cappa", "wsd", "dp1"}
