@@ -173,6 +173,26 @@ class AcousticDynamics(Operator):
         return self._da_min
 
     # ----------------------------------------------------------------------------------------------------
+    # ---- the reference's checkpoint call sites (dyn_core.py:608-669) ----
+    def _checkpoint_csw(self, state, tag: str):
+        if self.call_checkpointer:
+            self.checkpointer(f"C_SW-{tag}", delpd=state.delp, ptd=state.pt, ud=state.u, vd=state.v, wd=state.w, ucd=state.uc,
+                              vcd=state.vc, uad=state.ua, vad=state.va, utd=self._ut, vtd=self._vt, divgdd=self._divgd)
+
+    def _checkpoint_dsw_in(self, state):
+        if self.call_checkpointer:
+            # delpc is a temporary and not a variable in D_SW savepoint
+            self.checkpointer("D_SW-In", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt, delpd=state.delp, ud=state.u,
+                              vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, zhd=self._zh, divgdd=self._divgd,
+                              xfxd=self._xfx, yfxd=self._yfx, mfxd=state.mfxd, mfyd=state.mfyd)
+
+    def _checkpoint_dsw_out(self, state):
+        if self.call_checkpointer:
+            self.dgrid_shallow_water_lagrangian_dynamics.join()  # the wind half may still be running on the side stream
+            self.checkpointer("D_SW-Out", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt, delpd=state.delp, ud=state.u,
+                              vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, divgdd=self._divgd, xfxd=self._xfx,
+                              yfxd=self._yfx, mfxd=state.mfxd, mfyd=state.mfyd)
+
     def __call__(self, state, timestep: float, n_map=1):
         """dyn_core.py:670-970."""
         cfg = self.config
@@ -200,8 +220,10 @@ class AcousticDynamics(Operator):
                 self._interface_pressure_from_toa_pressure_and_thickness(state.delp, self._pem, self._ptop)
             halo.u__v.wait()
             halo.w.wait()
+            self._checkpoint_csw(state, tag="In")
             csw(state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._ut, self._vt,
                 self._divgd, state.omga, dt2)
+            self._checkpoint_csw(state, tag="Out")
             if cfg.nord > 0:
                 halo.divgd.start()
             if it == 0:
@@ -217,11 +239,13 @@ class AcousticDynamics(Operator):
             if cfg.nord > 0:
                 halo.divgd.wait()
             halo.uc__vc.wait()
+            self._checkpoint_dsw_in(state)
             # delpc of d_sw aliases vt, as in the reference (dyn_core.py:825)
             self.dgrid_shallow_water_lagrangian_dynamics(
                 self._vt, state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._divgd,
                 state.mfxd, state.mfyd, state.cxd, state.cyd, self._crx, self._cry, self._xfx, self._yfx, state.q_con, self._zh,
                 self._heat_source, state.diss_estd, dt_acoustic_substep, overlap_winds=True)
+            self._checkpoint_dsw_out(state)
             halo.delp__pt__q_con.update()
             self.update_height_on_d_grid(surface_height=self._zs, height=self._zh, courant_number_x=self._crx,
                                          courant_number_y=self._cry, x_area_flux=self._xfx, y_area_flux=self._yfx, ws=self._wsd,

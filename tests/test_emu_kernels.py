@@ -230,6 +230,8 @@ def test_dynamical_core_step_six_tiles_emulated(emu_lib):
     check_dycore(fixes, outs)
     # the reference's checkpoint call sites, in its order (fv_dynamics.py:436-575), with [x, z, y] views of pe / peln
     names = [c[0] for c in recs[0].calls]
-    assert names == ["FVDynamics-In", "Tracer2D1L-In", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out", "FVDynamics-Out"]
+    acoustic = ["C_SW-In", "C_SW-Out", "D_SW-In", "D_SW-Out"] * 2  # n_split = 2 (dyn_core.py:744-850)
+    assert names == ["FVDynamics-In"] + acoustic + ["Tracer2D1L-In", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out",
+                                                     "FVDynamics-Out"]
     rin = dict(recs[0].calls)["Remapping-In"]
     assert rin["pe"] == (("x", "z_interface", "y"), (19, 80, 19)) and set(rin) >= {"pt", "delp", "peln", "cappa", "wsd", "dp1"}
