@@ -257,3 +257,42 @@ def test_ring_exchange_two_processes_gloo(tmp_path):
     for p in procs:
         assert p.wait(timeout=300) == 0
     _check_ring([pickle.load(open(tmp_path / f"ring{r}.pkl", "rb")) for r in range(2)], 2)
+
+
+# ---- the whole dynamical core, one PROCESS per tile over torch.distributed ----
+_DYCORE_WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+torch.set_num_threads(1)
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=6)
+from pace_amd import _lib
+from pace_amd.util import TorchDistComm
+import helpers
+lib = _lib.Library(os.path.join({root!r}, "tests", "emu", "libpace_emu.so"))
+r = int(sys.argv[1])
+out = helpers.run_dycore_tile(TorchDistComm(), lib, "cpu", helpers.golden(f"acoustic_c12_tile{{r}}.npz"),
+                              helpers.golden(f"dycore_c12_tile{{r}}.npz"), 12, 79)
+pickle.dump(out, open(sys.argv[2], "wb"))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_dynamical_core_step_six_processes_gloo(tmp_path):
+    """One whole DynamicalCore.step_dynamics with one process per tile over torch.distributed (gloo here; the identical code
+    path runs over RCCL with one process per GPU): every halo-update group of the acoustic loop, the tracer advection, the
+    omega update and CubedToLatLon goes through TorchDistComm.  Checked against the run of the reference."""
+    import pickle
+
+    from helpers import check_dycore, golden
+
+    build_emu()
+    port = 33500 + os.getpid() % 2000
+    script = tmp_path / "dycore_worker.py"
+    script.write_text(_DYCORE_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path / f"dy{r}.pkl")]) for r in range(6)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    outs = [pickle.load(open(tmp_path / f"dy{r}.pkl", "rb")) for r in range(6)]
+    check_dycore([golden(f"dycore_c12_tile{t}.npz") for t in range(6)], outs)
