@@ -474,3 +474,36 @@ def test_marching_transport_probe_matches_tile_kernel(lib):
     with pytest.raises(Exception):
         lib.call("pace_fvtp2d_march_probe", C.byref(tp._geom), C.byref(tp._met), f["pt"].ptr, f["crx"].ptr, f["cry"].ptr,
                  f["xfx"].ptr, f["yfx"].ptr, gx.ptr, gy.ptr, 4, nx, jb, ny, nz, tp.stream())
+
+
+@pytest.mark.parametrize("cfg", [dict(hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5), dict(hord_dp=5, hord_tm=6, hord_vt=5, hord_mt=6),
+                                 dict(d_con=0.0), dict(nord=2)])
+def test_d_sw_other_namelists_match_oracle(lib, cfg):
+    """d_sw with the other advection orders the reference supports (5; mixed 5 / 6), without dissipative heating and with a
+    lower damping order, C48 x 79 against the oracle (whose PPM ord-5 / ord-6 and damping functions are pinned one by one
+    against the reference, tools/crosscheck_oracle.py): covers the <5, ...> instantiations of the transport and kinetic-
+    energy kernels that the ord-6 fixtures never reach."""
+    from oracle import dgrid_sw
+    from pace_amd import synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import get_column_namelist
+
+    n, nz = 48, 79
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    env = Env(lib, "cuda", metrics, n, nz)
+    full = dict(DSW_CFG, **cfg)
+    pcfg = DGridShallowWaterLagrangianDynamicsConfig(**full)
+    colq = get_column_namelist(pcfg, env.qf)
+    col = {k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v))[:nz] for k, v in colq.items()}
+    out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"], cfg=full)
+    g = oracle_grid(metrics, n, nz)
+    st = dgrid_sw.DSWState(s["u"].shape)
+    a = {k: s[k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(g, col, full, st, *[a[k] for k in DSW_ARGS], s["dt"])
+    for k in DSW_ARGS:
+        if k in ("divgd", "uc", "vc", "zh"):
+            continue
+        scale = float(np.abs(a[k][dsw_window(k, n, nz)]).max())
+        err = compare(a[k][dsw_window(k, n, nz)], out[k][dsw_window(k, n, nz)], near_zero=1e-12 * max(scale, 1e-300))
+        assert err < 3.2e-10, (cfg, k, err)
