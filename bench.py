@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--n", type=int, default=192)
     p.add_argument("--nz", type=int, default=79)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--watchdog", type=float, default=900.0, help="multi-rank runs: seconds after which a stuck run exits")
     p.add_argument("--exchange", choices=("on", "off"), default="on",
                    help="multi-rank runs: keep the delp/pt/q_con halo exchange inside the measured step (default) or run the tiles independently")
     p.add_argument("--graph", choices=("on", "off"), default="off",
@@ -98,8 +99,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
+        import threading
+
         import torch.distributed as dist
 
+        # A multi-rank run that stops making progress (a peer died, a transport problem) must end by itself: exit with an
+        # error after a generous bound instead of occupying the node.
+        def _give_up():
+            sys.stderr.write(f"bench.py: rank {rank} made no progress for {args.watchdog} s, giving up\n")
+            sys.stderr.flush()
+            os._exit(124)
+
+        watchdog = threading.Timer(args.watchdog, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
@@ -270,7 +283,7 @@ def main():
             "step_hbm_frac": BYTES_PER_CELL_UPDATE * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_n, nz)
         print(json.dumps(line))
     if world > 1:
