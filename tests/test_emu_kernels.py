@@ -263,3 +263,39 @@ def test_d_sw_other_namelists_emulated_vs_oracle(emu_lib, cfg):
         if k in ("divgd", "uc", "vc", "zh"):
             continue
         assert compare(a[k][dsw_window(k, n, nz)], out[k][dsw_window(k, n, nz)]) == 0.0, (cfg, k)
+
+
+@pytest.mark.parametrize("nz", [32, 91, 127])
+def test_other_level_counts_emulated_vs_oracle(emu_lib, nz):
+    """Nothing in d_sw / riem_solver3 may assume the 79 layers of the baseline configuration: 32, 91 and 127 layers against
+    the oracle (d_sw bit for bit, the column solver to the exp / log rounding)."""
+    from helpers import DSW_CFG
+
+    from oracle import dgrid_sw, vertical
+    from pace_amd import synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import get_column_namelist
+
+    n = 12
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    env = Env(emu_lib, "cpu", metrics, n, nz)
+    colq = get_column_namelist(DGridShallowWaterLagrangianDynamicsConfig(**DSW_CFG), env.qf)
+    col = {k: (v.numpy() if hasattr(v, "numpy") else np.asarray(v))[:nz] for k, v in colq.items()}
+    out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"])
+    g = oracle_grid(metrics, n, nz)
+    a = {k: s[k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(g, col, DSW_CFG, dgrid_sw.DSWState(s["u"].shape), *[a[k] for k in DSW_ARGS], s["dt"])
+    for k in DSW_ARGS:
+        if k not in ("divgd", "uc", "vc", "zh"):
+            assert compare(a[k][dsw_window(k, n, nz)], out[k][dsw_window(k, n, nz)]) == 0.0, k
+    inp = {"cappa": s["cappa"], "zs": s["zs"], "ws": s["ws"], "delz": s["delz"], "q_con": a["q_con"], "delp": a["delp"],
+           "pt": a["pt"], "zh": s["zh"], "p": s["pe"], "ppe": s["ppe"], "pk3": s["pk3"], "pk": s["pk"],
+           "log_p_interface": s["peln"], "w": a["w"]}
+    got = run_riem3(env, inp, False, s["dt"], metrics["ptop"])
+    b = {k: v.copy() for k, v in inp.items()}
+    vertical.riem_solver3(g, False, s["dt"], b["cappa"], metrics["ptop"], b["zs"], b["ws"], b["delz"], b["q_con"], b["delp"], b["pt"],
+                          b["zh"], b["p"], b["ppe"], b["pk3"], b["pk"], b["log_p_interface"], b["w"], p_fac=0.05)
+    for k in ("delz", "zh", "ppe", "pk3", "w"):
+        nk = nz if k in ("delz", "w") else nz + 1
+        assert compare(b[k][window(n, 0, 0, nk)], got[k][window(n, 0, 0, nk)], near_zero=1e-9 * float(np.abs(b[k]).max())) < 5e-6, k
