@@ -299,3 +299,57 @@ def test_other_level_counts_emulated_vs_oracle(emu_lib, nz):
     for k in ("delz", "zh", "ppe", "pk3", "w"):
         nk = nz if k in ("delz", "w") else nz + 1
         assert compare(b[k][window(n, 0, 0, nk)], got[k][window(n, 0, 0, nk)], near_zero=1e-9 * float(np.abs(b[k]).max())) < 5e-6, k
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_c2l_and_preamble_kernels_emulated_vs_oracle(emu_lib, order):
+    """pace_c2l_ord (both orders), pace_fv_setup_pt and pace_omega_from_w against oracle/dycore_parts.py on a synthetic tile:
+    the wind transform bit for bit, the preamble to the rounding of exp / log."""
+    import ctypes as C
+
+    from oracle import constants as oc
+    from oracle import dycore_parts
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils._common import dptr
+    from pace_amd.fv3core.stencils.fillz import pointer_table
+    from helpers import dycore_condensates
+
+    n, nz = 12, 10
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    env = Env(emu_lib, "cpu", metrics, n, nz)
+    from pace_amd.util.grid import geom_struct
+
+    geom = geom_struct(env.qf)
+    gd = env.grid_data
+    u, v, ua, va = env.q3(s["u"]), env.q3(s["v"]), env.q3(), env.q3()
+    emu_lib.call("pace_c2l_ord", C.byref(geom), C.byref(gd.c_struct()), order, dptr(u), dptr(v), dptr(gd.a11), dptr(gd.a12),
+                 dptr(gd.a21), dptr(gd.a22), dptr(ua), dptr(va), None)
+    fn = dycore_parts.c2l_ord2 if order == 2 else dycore_parts.c2l_ord4
+    rua, rva = fn(s["u"], s["v"], metrics["dx"], metrics["dy"], metrics["a11"], metrics["a12"], metrics["a21"], metrics["a22"], n, nz)
+    h = 1 if order == 2 else 0
+    w = (slice(3 - h, 3 + n + h), slice(3 - h, 3 + n + h), slice(0, nz))
+    assert np.array_equal(ua.numpy()[w], rua[w]) and np.array_equal(va.numpy()[w], rva[w])
+    if order == 4:
+        return
+    # compute_preamble + omega
+    cond = dycore_condensates(0, s["delp"].shape)
+    t = {k: np.abs(cond[k]) for k in ("qliquid", "qrain", "qice", "qsnow", "qgraupel")}
+    t["qvapor"] = 0.01 * np.ones_like(s["delp"])
+    qt = {k: env.q3(a) for k, a in t.items()}
+    pt0 = s["pt"] * 300.0
+    f = {k: env.q3(a) for k, a in (("pt", pt0), ("delp", s["delp"]), ("delz", s["delz"]), ("w", s["w"]))}
+    q_con, pkz, cappa, dp1, omga = env.q3(), env.q3(), env.q3(), env.q3(), env.q3()
+    water = pointer_table([qt[k] for k in ("qvapor", "qliquid", "qrain", "qsnow", "qice", "qgraupel")])
+    emu_lib.call("pace_fv_setup_pt", C.byref(geom), water, dptr(q_con), dptr(pkz), dptr(f["pt"]), dptr(cappa), dptr(f["delp"]),
+                 dptr(f["delz"]), dptr(dp1), None)
+    emu_lib.call("pace_omega_from_w", C.byref(geom), dptr(f["delp"]), dptr(f["delz"]), dptr(f["w"]), dptr(omga), None)
+    cw = (slice(3, 3 + n), slice(3, 3 + n), slice(0, nz))
+    tw = {k: a[cw] for k, a in t.items()}
+    gz, _, rpkz, rcappa, rdp1 = dycore_parts.fv_setup(tw, pt0[cw], s["delp"][cw], s["delz"][cw])
+    assert np.array_equal(q_con.numpy()[cw], gz) and np.array_equal(cappa.numpy()[cw], rcappa) and np.array_equal(dp1.numpy()[cw], rdp1)
+    assert compare(rpkz, pkz.numpy()[cw]) < 1e-14
+    rpt = pt0[cw] * (1.0 + rdp1) * (1.0 - gz) / rpkz
+    assert compare(rpt, f["pt"].numpy()[cw]) < 1e-14
+    assert np.array_equal(omga.numpy()[cw], s["delp"][cw] / s["delz"][cw] * s["w"][cw])
+    assert oc.ZVIR > 0
