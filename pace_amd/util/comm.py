@@ -64,6 +64,37 @@ class TorchDistComm:
         return float(t.item())
 
 
+class NullComm:
+    """util/pace/util/null_comm.py:15-80: the rank of a communicator that has no peers -- what it "receives" is a fill value
+    (zero as in the reference's Irecv; halo updates therefore zero the halos).  Lets one tile's operators run alone, as the
+    reference's own drop-in test does (tests/main/fv3core/test_dycore_call.py)."""
+
+    def __init__(self, rank, total_ranks, fill_value=0.0):
+        self.rank, self.total_ranks, self._fill_value = rank, total_ranks, fill_value
+
+    def __repr__(self):
+        return f"NullComm(rank={self.rank}, total_ranks={self.total_ranks})"
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.total_ranks
+
+    def barrier(self):
+        return
+
+    def exchange(self, sends, recvs, tag=0):
+        def fin():
+            for buf, _peer in recvs:
+                buf[:] = 0.0  # NullAsyncResult.wait (null_comm.py:11-13)
+
+        return Request(fin)
+
+    def allreduce_min(self, value: float) -> float:
+        return value
+
+
 class _World:
     """Shared state of the tile threads.  The condition's lock doubles as a run token: a tile thread holds it whenever it
     executes and gives it up only while it waits for a message (``Condition.wait_for`` releases and re-acquires it), so the

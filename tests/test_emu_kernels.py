@@ -353,3 +353,66 @@ def test_c2l_and_preamble_kernels_emulated_vs_oracle(emu_lib, order):
     assert compare(rpt, f["pt"].numpy()[cw]) < 1e-14
     assert np.array_equal(omga.numpy()[cw], s["delp"][cw] / s["delz"][cw] * s["w"][cw])
     assert oc.ZVIR > 0
+
+
+def _lone_dycore(emu_lib):
+    """The reference's drop-in test setup (tests/main/fv3core/test_dycore_call.py:23-137) with what exists here: rank 0 of a
+    six-rank NullComm (halo updates receive zeros), the C12 tile-0 metrics and state of the fixtures."""
+    import datetime
+
+    from helpers import acoustic_config, dycore_condensates
+    from pace_amd.fv3core import DycoreState, DynamicalCore, DynamicalCoreConfig
+    from pace_amd.util import CubedSphereCommunicator, NullComm
+
+    n, nz = 12, 79
+    fa, fd = golden("acoustic_c12_tile0.npz"), golden("dycore_c12_tile0.npz")
+    env = Env(emu_lib, "cpu", {k[5:]: v for k, v in fa.items() if k.startswith("grid_")}, n, nz)
+    cube = CubedSphereCommunicator(NullComm(rank=0, total_ranks=6, fill_value=0.0), device="cpu", lib=emu_lib)
+    arrays = {k: fa["in_" + k] for k in "u v w delz delp pe pk peln phis uc vc ua va".split()}
+    shape = arrays["delp"].shape
+    for name, key in (("pt", "in_pt"), ("qvapor", "in_qvapor")):
+        a = np.zeros(shape)
+        a[3:3 + n, 3:3 + n, :] = fd[key]
+        arrays[name] = a
+    arrays["ps"] = fd["in_ps"]
+    for name, f in dycore_condensates(0, shape).items():
+        arrays[name] = f * (arrays["delp"] > 0)
+    state = DycoreState.init_from_numpy_arrays(arrays, env.qf)
+    config = DynamicalCoreConfig(npx=n + 1, npy=n + 1, npz=nz, dt_atmos=225.0, k_split=1, n_split=1,
+                                 acoustic_dynamics=acoustic_config(1))
+    core = DynamicalCore(cube, env.grid_data, env.stencil_factory, env.qf, env.damping, config, state.phis, state,
+                         datetime.timedelta(seconds=225.0))
+    return core, state, arrays
+
+
+def _snapshot(state):
+    from helpers import DYCORE_OUT
+
+    return {k: getattr(state, k).numpy().copy() for k in DYCORE_OUT}
+
+
+def test_dycore_call_is_deterministic_and_stateless(emu_lib):
+    """The two properties the reference's own drop-in test checks (test_dycore_call.py:146-210): two identically initialised
+    dycores on identical states give identical results, and a dycore called again on the same input gives the same output --
+    it retains nothing between calls that influences the result."""
+    core1, state1, arrays = _lone_dycore(emu_lib)
+    core2, state2, _ = _lone_dycore(emu_lib)
+    core1.step_dynamics(state1)
+    first = _snapshot(state1)
+    core2.step_dynamics(state2)
+    second = _snapshot(state2)
+    for k in first:
+        assert np.array_equal(first[k], second[k], equal_nan=True), k
+    # same dycore, the input restored
+    from pace_amd.fv3core.initialization.dycore_state import _FIELDS
+
+    for name in _FIELDS:
+        q = getattr(state1, name)
+        if name in arrays:
+            q.set(arrays[name])
+        else:
+            q.data[...] = 0.0
+    core1.step_dynamics(state1)
+    third = _snapshot(state1)
+    for k in first:
+        assert np.array_equal(first[k], third[k], equal_nan=True), k
