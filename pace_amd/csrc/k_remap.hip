@@ -441,6 +441,14 @@ k_remap_layers(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, 
   }
   double p1a = AT(pe1, L), p1b = AT(pe1, L + 1);  // the source layer's bounds
   for (int k = k0; k < k1; ++k) {
+    // Memory safety on inputs the operator is not defined for (non-monotone or non-finite coordinates, a target column that
+    // reaches below the source's: the reference indexes out of bounds there): the source index never leaves the column.  On
+    // valid input L <= km - 1 always holds and this does nothing.
+    if (L > km - 1) {
+      L = km - 1;
+      p1a = AT(pe1, L);
+      p1b = AT(pe1, L + 1);
+    }
     const double p2b = AT(pe2, k + 1);
     double dpl = p1b - p1a;
     const double pl = (p2a - p1a) / dpl;
@@ -467,7 +475,8 @@ k_remap_layers(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, 
       const double dp = p2b - p1a;
       dpl = p1b - p1a;
       const double esl = dp / dpl;
-      const double b2 = AT(a2, L), b3 = AT(a3, L), b4 = AT(a4, L);
+      const int Lc = L < km ? L : km - 1;  // (L == km only on invalid input, see above)
+      const double b2 = AT(a2, Lc), b3 = AT(a3, Lc), b4 = AT(a4, Lc);
       qsum += dp * (b2 + 0.5 * esl * (b3 - b2 + b4 * (1.0 - (2.0 / 3.0) * esl)));
       out = qsum / (p2b - p2a);
     }
