@@ -299,6 +299,8 @@ def _child_main(what, out_path):
         result = run_tracer_six_tiles(lib, "cuda")
     elif what == "dycore":
         result = run_dycore_six_tiles(lib, "cuda")
+    elif what == "dycore_k2":
+        result = run_dycore_six_tiles(lib, "cuda", prefix="dycore_k2_c12")
     else:
         raise ValueError(what)
     with open(out_path, "wb") as f:
@@ -525,8 +527,11 @@ def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None)
         arrays[name] = f * (arrays["delp"] > 0)
     state = DycoreState.init_from_numpy_arrays(arrays, env.qf)
     n_split = int(fix_dy["n_split"])
-    config = DynamicalCoreConfig(npx=n + 1, npy=n + 1, npz=nz, dt_atmos=float(fix_dy["timestep"]), k_split=1, n_split=n_split,
-                                 acoustic_dynamics=acoustic_config(n_split))
+    k_split = int(fix_dy["k_split"]) if "k_split" in fix_dy else 1
+    ac = acoustic_config(n_split)
+    ac.k_split = k_split
+    config = DynamicalCoreConfig(npx=n + 1, npy=n + 1, npz=nz, dt_atmos=float(fix_dy["timestep"]), k_split=k_split,
+                                 n_split=n_split, acoustic_dynamics=ac)
     core = DynamicalCore(cube, env.grid_data, env.stencil_factory, env.qf, env.damping, config, state.phis, state,
                          datetime.timedelta(seconds=float(fix_dy["timestep"])), checkpointer=checkpointer)
     core.step_dynamics(state)
@@ -537,11 +542,11 @@ def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None)
     return out
 
 
-def run_dycore_six_tiles(lib, device, n=12, nz=79, checkpointers=None):
+def run_dycore_six_tiles(lib, device, n=12, nz=79, checkpointers=None, prefix="dycore_c12"):
     from pace_amd.util import run_tiles
 
     fa = [golden(f"acoustic_c12_tile{t}.npz") for t in range(6)]
-    fd = [golden(f"dycore_c12_tile{t}.npz") for t in range(6)]
+    fd = [golden(f"{prefix}_tile{t}.npz") for t in range(6)]
     cps = checkpointers or [None] * 6
     return fd, run_tiles(6, lambda comm: run_dycore_tile(comm, lib, device, fa[comm.Get_rank()], fd[comm.Get_rank()], n, nz,
                                                          cps[comm.Get_rank()]))

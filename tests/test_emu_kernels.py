@@ -416,3 +416,13 @@ def test_dycore_call_is_deterministic_and_stateless(emu_lib):
     third = _snapshot(state1)
     for k in first:
         assert np.array_equal(first[k], third[k], equal_nan=True), k
+
+
+def test_dynamical_core_two_remapping_steps_emulated(emu_lib):
+    """k_split = 2 (n_split = 1): two AcousticDynamics calls of which only the second is the end step, two
+    LagrangianToEulerian calls of which only the second is the last -- against the reference's run of that configuration
+    (tools/make_golden_dycore.py 1 2)."""
+    from helpers import check_dycore, run_dycore_six_tiles
+
+    fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", prefix="dycore_k2_c12")
+    check_dycore(fixes, outs)

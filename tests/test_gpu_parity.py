@@ -507,3 +507,11 @@ def test_d_sw_other_namelists_match_oracle(lib, cfg):
         scale = float(np.abs(a[k][dsw_window(k, n, nz)]).max())
         err = compare(a[k][dsw_window(k, n, nz)], out[k][dsw_window(k, n, nz)], near_zero=1e-12 * max(scale, 1e-300))
         assert err < 3.2e-10, (cfg, k, err)
+
+
+def test_dynamical_core_two_remapping_steps_matches_reference_run(lib, tmp_path):
+    """k_split = 2: see the emulated twin of this test."""
+    from helpers import check_dycore
+
+    fixes, outs = run_in_child("dycore_k2", tmp_path)
+    check_dycore(fixes, outs)

@@ -24,7 +24,13 @@ import numpy as np  # noqa: E402
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 K_SEL = [0, 1, 2, 3, 4, 40, 77, 78, 79]
 COLS = [(3, 3), (8, 9), (14, 14), (3, 14)]
-N, NZ, N_SPLIT = 12, 79, 2
+N, NZ = 12, 79
+# default: n_split = 2, k_split = 1 -> dycore_c12_tile*.npz; "python make_golden_dycore.py 1 2" -> n_split = 1, k_split = 2
+# (two remapping steps: the first AcousticDynamics call is not the end step, the first LagrangianToEulerian not the last)
+# -> dycore_k2_c12_tile*.npz
+N_SPLIT = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+K_SPLIT = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+PREFIX = "dycore_c12" if K_SPLIT == 1 else f"dycore_k{K_SPLIT}_c12"
 TRACERS = "qvapor qliquid qrain qice qsnow qgraupel qo3mr qsgs_tke qcld".split()
 STATE3 = "u v w delz delp pt pe pk peln pkz q_con omga ua va uc vc".split() + TRACERS
 STATE_OUT = "u v w delz delp pt pe pk peln pkz q_con omga ua va mfxd mfyd cxd cyd".split() + TRACERS
@@ -52,7 +58,7 @@ def main():
     from pace.fv3core.stencils.neg_adj3 import AdjustNegativeTracerMixingRatio
     from threadcomm import run_ranks
 
-    config = capture.dycore_config(n_split=N_SPLIT, npx=N + 1, npz=NZ, do_sat_adj=False)
+    config = capture.dycore_config(n_split=N_SPLIT, k_split=K_SPLIT, npx=N + 1, npz=NZ, do_sat_adj=False)
 
     def rank(comm):
         env = refenv.build_rank(comm, N, NZ)
@@ -60,8 +66,8 @@ def main():
         tile = comm.Get_rank()
         for name, f in condensates(tile, state.qvapor.data.shape).items():
             getattr(state, name).data[:] = f * (np.asarray(state.delp.data) > 0)
-        out = {"timestep": np.float64(config.dt_atmos), "n_split": np.int64(N_SPLIT), "k_sel": np.array(K_SEL), "cols": np.array(COLS)}
-        if tile == 0:
+        out = {"timestep": np.float64(config.dt_atmos), "n_split": np.int64(N_SPLIT), "k_split": np.int64(K_SPLIT), "k_sel": np.array(K_SEL), "cols": np.array(COLS)}
+        if tile == 0 and K_SPLIT == 1:
             # neg_adj3 on its own, on a state with many negatives
             qf, sf = env.qf, env.stencil_factory
             rng = np.random.default_rng(11)
@@ -116,10 +122,10 @@ def main():
         for k in ("pt", "qvapor"):
             slim["in_" + k] = np.ascontiguousarray(out["in_" + k][3:15, 3:15, :])
         slim["in_ps"] = out["in_ps"]
-        np.savez_compressed(os.path.join(GOLDEN, f"dycore_c12_tile{t}.npz"), **slim)
+        np.savez_compressed(os.path.join(GOLDEN, f"{PREFIX}_tile{t}.npz"), **slim)
         print(t, len(slim))
     d = np.load(os.path.join(GOLDEN, "negadj_c12.npz"))
-    for k in d.files:
+    for k in (d.files if K_SPLIT == 1 else []):
         if k.startswith("out_"):
             print(k, float(np.abs(d[k][:, :, :NZ] - d["in_" + k[4:]][:, :, :NZ]).max()), float((d[k][:, :, :NZ] < 0).mean()))
 
