@@ -631,3 +631,16 @@ def l2e_synthetic_case(n, km, seed=2):
     tracers = {"qvapor": 0.01 * np.exp(-4.0 * (1.0 - frac[:, :, :1] * 0 - np.minimum(frac, 1.0))) * (1 + 0.2 * rng.random(pe.shape))}
     tracers.update({k: v for k, v in dycore_condensates(0, pe.shape).items() if k != "qcld"})
     return f, tracers, ak, bk, ptop
+
+
+def run_d_sw_h5_fixture(env):
+    """The reference run with every advection order set to 5 (tools/make_golden_dsw_variants.py) through the host class."""
+    fix = golden("d_sw_h5_c12_tile0_call1.npz")
+    k_sel = fix["k_sel"]
+    cfg = dict(DSW_CFG, hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5)
+    col = {k[4:]: np.ascontiguousarray(v[np.asarray(k_sel)]) for k, v in fix.items() if k.startswith("col_")}
+    out, _ = run_d_sw(env, col, {k: fix["in_" + k] for k in DSW_ARGS}, float(fix["dt"]), ut0=fix["in_uc_contra"],
+                      vt0=fix["in_vc_contra"], cfg=cfg)
+    nk = len(k_sel)
+    return max(compare(fix["out_" + k][dsw_window(k, 12, nk)], out[k][dsw_window(k, 12, nk)])
+               for k in DSW_ARGS if k not in ("divgd", "uc", "vc", "zh"))

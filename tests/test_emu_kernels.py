@@ -426,3 +426,11 @@ def test_dynamical_core_two_remapping_steps_emulated(emu_lib):
 
     fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", prefix="dycore_k2_c12")
     check_dycore(fixes, outs)
+
+
+def test_d_sw_order5_emulated_against_reference_run(emu_lib):
+    """The <5, ...> transport / kinetic-energy kernels against a run of the reference with hord_* = 5: bit for bit."""
+    from helpers import run_d_sw_h5_fixture
+
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, len(golden("d_sw_h5_c12_tile0_call1.npz")["k_sel"]))
+    assert run_d_sw_h5_fixture(env) == 0.0

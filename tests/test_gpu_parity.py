@@ -515,3 +515,10 @@ def test_dynamical_core_two_remapping_steps_matches_reference_run(lib, tmp_path)
 
     fixes, outs = run_in_child("dycore_k2", tmp_path)
     check_dycore(fixes, outs)
+
+
+def test_d_sw_order5_matches_reference_run(lib):
+    from helpers import run_d_sw_h5_fixture
+
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, len(golden("d_sw_h5_c12_tile0_call1.npz")["k_sel"]))
+    assert run_d_sw_h5_fixture(env) < 3.2e-10  # translate_d_sw.py:19
