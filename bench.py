@@ -114,6 +114,26 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        torch.cuda.set_device(local_rank)
+        if args.exchange != "off":
+            # preflight: the point-to-point pattern of the halo exchange (one grouped send/recv with both ring neighbours)
+            # on a few bytes, under a short watchdog of its own -- a transport that cannot do this should fail here, fast
+            pre = threading.Timer(min(120.0, args.watchdog), _give_up)
+            pre.daemon = True
+            pre.start()
+            dev0 = torch.device(f"cuda:{local_rank}")
+            peers = sorted({(rank - 1) % world, (rank + 1) % world})
+            sb = {p_: torch.full((8,), float(rank), dtype=torch.float64, device=dev0) for p_ in peers}
+            rb = {p_: torch.zeros(8, dtype=torch.float64, device=dev0) for p_ in peers}
+            ops = [dist.P2POp(dist.irecv, rb[p_], p_) for p_ in peers] + [dist.P2POp(dist.isend, sb[p_], p_) for p_ in peers]
+            for w_ in dist.batch_isend_irecv(ops):
+                w_.wait()
+            torch.cuda.synchronize()
+            for p_ in peers:
+                if float(rb[p_][0].item()) != float(p_):
+                    sys.stderr.write(f"bench.py: preflight exchange returned wrong data on rank {rank}\n")
+                    os._exit(125)
+            pre.cancel()
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
