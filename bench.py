@@ -23,7 +23,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 BYTES_PER_CELL_UPDATE = 360.0  # d_sw 32 fields + riem_solver3 13 fields, fp64
@@ -58,7 +57,7 @@ def column_namelist(nz, qf):
 def cpu_baseline(n, nz):
     """The oracle (numpy restatement with the reference's stencil granularity) timed on the host:
     one d_sw + riem_solver3 substep at C<n> x nz.  kind = 'port', 1 thread (numpy elementwise)."""
-    from helpers import DSW_ARGS, DSW_CFG
+    from pace_amd.tile import DSW_ARGS, DSW_CFG
 
     from oracle import dgrid_sw, vertical
     from oracle._np import Grid
@@ -137,7 +136,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
-    from helpers import DSW_ARGS, Env
+    from pace_amd.tile import DSW_ARGS, Env
 
     from pace_amd import _lib, synthetic
     from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig

@@ -12,8 +12,22 @@ void pace_set_err(const char* where, hipError_t e) {
 
 // Entry prologue: argument check, then drop any stale "last error" another library (e.g. the caching
 // allocator's event queries) left on this thread, so PACE_CHECK_LAUNCH only reports our own launches.
-#define NEED(p)                      \
-  if (!(p)) return PACE_ERR_ARG;     \
+// The geometry is validated on every entry: the kernels address fields with 32-bit byte offsets from a uniform base
+// (k_fvtp2d.hip), so a field must stay below 4 GB, and the strides must cover the (N+7) x (N+7) x (nk+1) storage.
+static inline int geom_check(const pace_geom_t* g) {
+  if (g == nullptr) return PACE_ERR_ARG;
+  if (g->n < 1 || g->nk < 1) return PACE_ERR_ARG;
+  if (g->sj < g->n + 7 || g->sk < (int64_t)g->sj * (g->n + 7)) return PACE_ERR_ARG;
+  if ((int64_t)(g->nk + 1) * g->sk * (int64_t)sizeof(double) >= ((int64_t)1 << 32)) return PACE_ERR_UNSUPPORTED;
+  return PACE_OK;
+}
+
+#define NEED(p)                              \
+  if (!(p)) return PACE_ERR_ARG;             \
+  {                                          \
+    const int geom_rc_ = geom_check(geom);   \
+    if (geom_rc_ != PACE_OK) return geom_rc_; \
+  }                                          \
   (void)hipGetLastError()
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }

@@ -274,12 +274,12 @@ struct DivIter {
 
 __global__ void __launch_bounds__(256)
 k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int fill, int adjust,
-               Regions R) {
+               double* __restrict__ uc_out, double* __restrict__ vc_out, Regions R) {
   REGION_POINT(R);
   const int kk = k + k0;
   const long c2 = IDX2(g, i, j);
   const long c = c2 + (long)kk * g.sk;
-  double d;
+  double d, uc_here, vc_here;
   if (interior) {
     // columns is+1 .. ie: no operand lies in a corner region and no corner adjustment applies
     const int sj = g.sj;
@@ -289,6 +289,8 @@ k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict_
     const double vcm = (d0 - din[c - 1]) * m.divg_u[c2 - 1];
     const double vc0 = (din[c + 1] - d0) * m.divg_u[c2];
     d = ucm - uc0 + vcm - vc0;
+    uc_here = uc0;
+    vc_here = vc0;
   } else {
     DivIter it{g, m, din + (long)kk * g.sk, fill != 0};
     const double ucm = it.uc(i, j - 1), uc0 = it.uc(i, j), vcm = it.vc(i - 1, j), vc0 = it.vc(i, j);
@@ -296,19 +298,28 @@ k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict_
     const bool ic = (i == g.is || i == g.ie + 1);
     if (ic && j == g.js) d = d - ucm;
     if (ic && j == g.je + 1) d = d + uc0;
+    uc_here = uc0;
+    vc_here = vc0;
   }
   if (adjust) d = d * m.rarea_c[c2];
   dout[c] = d;
+  // The reference uses the caller's uc / vc as the work fields of this iteration (uc_from_divg / vc_from_divg,
+  // divergence_damping.py:188-209) and its Translate tests compare what is left in them after d_sw on the staggered
+  // compute windows (translate_d_sw.py:36-65): the values of the LAST iteration.
+  if (uc_out != nullptr) {
+    if (j <= g.je) uc_out[c] = uc_here;
+    if (i <= g.ie) vc_out[c] = vc_here;
+  }
 }
 
 static void launch_divdamp_iter(const Geo& g, const Met& m, const double* din, double* dout, int k0, int nlev, int nt, int fill,
-                                hipStream_t st) {
+                                double* uc_out, double* vc_out, hipStream_t st) {
   const int jb = g.js - nt, je_ = g.je + nt + 1;
   Regions r{};
   add_region(r, g.is + 1, g.ie, jb, je_);
   add_region(r, g.is - nt, g.is, jb, je_);
   add_region(r, g.ie + 1, g.ie + nt + 1, jb, je_);
-  hipLaunchKernelGGL(k_divdamp_iter, regions_grid(r, nlev), dim3(64, 4), 0, st, g, m, din, dout, k0, fill, 1, r);
+  hipLaunchKernelGGL(k_divdamp_iter, regions_grid(r, nlev), dim3(64, 4), 0, st, g, m, din, dout, k0, fill, 1, uc_out, vc_out, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,7 +477,7 @@ __global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __rest
 
 // tail of DivergenceDamping for nord > 0 levels: a2b_ord4(wk) -> smagorinsky -> damping
 __global__ void __launch_bounds__(256)
-k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* __restrict__ delpc_src,
+k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* delpc_src, double* divgd_out,
                      double* __restrict__ delpc, const double* __restrict__ divg_d, double* __restrict__ vort_b,
                      double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt,
                      int k0, Regions R) {
@@ -484,9 +495,11 @@ k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* 
     vb = absdt * sqrt(dpc * dpc + qb * qb);
   }
   const double damp = m.da_min_c * fmax(d2_bg[kk], fmin(0.2, dddmp * fabs(vb)));
-  const double vort = damp * dpc + dd8 * divg_d[c];
+  const double dfin = divg_d[c];
+  const double vort = damp * dpc + dd8 * dfin;
   vort_b[c] = vort;
   ke[c] = ke[c] + vort;
+  divgd_out[c] = dfin;  // the caller's divgd ends as the iterated divergence (redo_divg_d; compared by TranslateD_SW)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -715,12 +728,13 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
       const int nt = nonzero_nord - (n + 1);
       const int fill = (n + 1 != nonzero_nord) ? 1 : 0;
       double* dst = bufs[n & 1];
-      launch_divdamp_iter(g, m, src, dst, kstart, nhigh, nt, fill, st);
+      const bool last = (n + 1 == nonzero_nord);  // nt == 0: its region is exactly the (n+1) x (n+1) corner points
+      launch_divdamp_iter(g, m, src, dst, kstart, nhigh, nt, fill, last ? uc : nullptr, last ? vc : nullptr, st);
       src = dst;
     }
     const double dd8 = pow(m.da_min_c * cfg->d4_bg, (double)(nonzero_nord + 1));
     const Regions r = a2b_regions(g);
-    hipLaunchKernelGGL(k_divdamp_high_final, regions_grid(r, nhigh), dim3(64, 4), 0, st, g, m, W.wk, divgd, delpc, src, W.vort_b,
+    hipLaunchKernelGGL(k_divdamp_high_final, regions_grid(r, nhigh), dim3(64, 4), 0, st, g, m, W.wk, divgd, divgd, delpc, src, W.vort_b,
                        W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, r);
   }
   // vorticity transport

@@ -13,10 +13,12 @@ from ._common import Operator, check_layout, dptr, host_column
 dcon_threshold = 1e-5
 
 
-def get_column_namelist(config: DGridShallowWaterLagrangianDynamicsConfig, quantity_factory):
-    """d_sw.py:633-683: dictionary of K-Quantities describing how nord/damp vary with level."""
-    names = ["ke_bg", "d_con", "nord", "nord_v", "nord_w", "nord_t", "damp_vt", "damp_w", "damp_t", "d2_divg"]
-    nz = quantity_factory.sizer.nz
+_COLUMN_NAMES = ["ke_bg", "d_con", "nord", "nord_v", "nord_w", "nord_t", "damp_vt", "damp_w", "damp_t", "d2_divg"]
+
+
+def column_namelist_arrays(config: DGridShallowWaterLagrangianDynamicsConfig, nz: int):
+    """The values of d_sw.py:633-683 as host arrays of nz + 1 entries (the last one is the allocator's zero)."""
+    names = _COLUMN_NAMES
     col = {n: np.zeros(nz + 1) for n in names}
     v = {n: col[n][:nz] for n in names}  # the reference's .view (compute levels)
     for n in ("ke_bg", "d_con", "nord"):
@@ -52,8 +54,14 @@ def get_column_namelist(config: DGridShallowWaterLagrangianDynamicsConfig, quant
         if config.d2_bg_k2 > 0.05:
             v["d2_divg"][2] = max(config.d2_bg, 0.2 * config.d2_bg_k2)
             set_low(2)
+    return col
+
+
+def get_column_namelist(config: DGridShallowWaterLagrangianDynamicsConfig, quantity_factory):
+    """d_sw.py:633-683: dictionary of K-Quantities describing how nord/damp vary with level."""
+    col = column_namelist_arrays(config, quantity_factory.sizer.nz)
     out = {}
-    for n in names:
+    for n in _COLUMN_NAMES:
         q = quantity_factory.zeros([Z_DIM], units="unknown")
         q.set(col[n])
         out[n] = q

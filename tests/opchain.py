@@ -1,0 +1,407 @@
+"""Per-operator parity of the acoustic loop body on ONE tile at any size.
+
+The oracle walks a synthetic tile through the loop body of AcousticDynamics (dyn_core.py:720-945; single tile: the halo
+exchanges are skipped, the halos keep the values of the synthetic state, which is defined on the whole storage).  At every
+operator boundary the state before and after the oracle's operator is handed out; the test then runs the PRODUCT operator
+(host class -> C ABI -> kernels) on a copy of the same "before" state and compares what the operator writes, on the window
+and at the tolerance of the reference's Translate test for that operator:
+
+    D2A2C_Vect 2e-10 (translate_d2a2c_vect.py:47) . C_SW 2e-10 (translate_c_sw.py:107) . UpdateDzC 1e-14 .
+    Riem_Solver_C 5e-14 (translate_riem_solver_c.py:33) . PGradC 1e-14 . D_SW 3.2e-10 . UpdateDzD 1e-14 .
+    Riem_Solver3 5e-6 (overrides/standard.yaml:49-61) . PE_Halo / PK3_Halo 1e-14 . NH_P_Grad 5e-10 (translate_nh_p_grad.py:8) .
+    Ray_Fast 1e-14 . Del2Cubed 1e-14 . apply_diffusive_heating (inside DynCore, 2e-6; held to 1e-13 here)
+
+Operators that contain exp / log / pow (riem_solver_c, riem_solver3, pk3_halo, ray_fast's host table, the heating) can differ
+from numpy in the last place on the device; their bounds below say so.
+"""
+import numpy as np
+
+from helpers import DSW_ARGS, DSW_CFG, compare
+
+from oracle import acoustic_parts as ap
+from oracle import cgrid_sw, dgrid_sw, vertical
+from oracle import constants as oc
+from oracle._np import Grid
+
+P_FAC, RF_CUTOFF, TAU, DELT_MAX, HORD_TM = 0.05, 3000.0, 10.0, 0.002, 6
+
+
+def _win(n, lo=0, hi=0, di=0, dj=0):
+    """(i, j) slices: the compute domain widened by lo cells below / hi above, + di / dj staggered points."""
+    return (slice(3 - lo, 3 + n + hi + di), slice(3 - lo, 3 + n + hi + dj))
+
+
+class OpCase:
+    """name, state before, state after (oracle), checks = [(variable, (i, j) window, number of levels, tolerance, near_zero
+    as a fraction of the field's magnitude)]."""
+
+    def __init__(self, name, before, after, checks):
+        self.name, self.before, self.after, self.checks = name, before, after, checks
+
+
+def column(nz):
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import column_namelist_arrays
+
+    return column_namelist_arrays(DGridShallowWaterLagrangianDynamicsConfig(**DSW_CFG), nz)
+
+
+class Chain:
+    def __init__(self, n, nz, metrics=None, state=None):
+        from pace_amd import synthetic
+
+        self.n, self.nz = n, nz
+        self.metrics = metrics if metrics is not None else synthetic.tile_metrics(n, nz)
+        s = state if state is not None else synthetic.acoustic_state(self.metrics, n, nz)
+        self.g = Grid(n, nz, self.metrics)
+        self.col = column(nz)
+        self.dt = float(s["dt"])
+        self.ptop = float(self.metrics["ptop"])
+        z3 = lambda: np.zeros(s["u"].shape)  # noqa: E731
+        S = {k: s[k].copy() for k in ("delp", "pt", "u", "v", "w", "uc", "vc", "ua", "va", "q_con", "cappa", "delz", "pe", "pk", "peln")}
+        S.update(zs=s["zs"].copy(), phis=s["zs"] * oc.GRAV, ws3=np.zeros(s["zs"].shape), wsd=np.zeros(s["zs"].shape))
+        for k in ("ut", "vt", "divgd", "omga", "delpc", "ptc", "pkc", "mfxd", "mfyd", "cxd", "cyd", "crx", "cry", "xfx", "yfx",
+                  "heat_source", "diss_estd", "utc", "vtc"):
+            S[k] = z3()
+        S["zh"] = s["zh"].copy()
+        S["gz"] = s["zh"].copy()  # dyn_core.py:760-776: on the first substep zh := gz (heights, like the reference's gz here)
+        S["pk3"] = np.full(s["u"].shape, 1.0e40)
+        self.S = S
+        self.csw = cgrid_sw.CSWState(s["u"].shape)
+        self.dsw = dgrid_sw.DSWState(s["u"].shape)
+
+    def _snap(self):
+        return {k: v.copy() for k, v in self.S.items()}
+
+    def cases(self, only=None):
+        """Generator of OpCase in loop order.  The chain always advances through every operator (later ones need the
+        fields of the earlier ones); ``only`` just limits what is handed out."""
+        S, g, n, nz = self.S, self.g, self.n, self.nz
+        dt, dt2, ptop = self.dt, 0.5 * self.dt, self.ptop
+        K = nz + 1
+        C0, C1 = _win(n), _win(n, 1, 1)
+
+        def emit(name, fn, checks):
+            want = only is None or name in only
+            before = self._snap() if want else None
+            fn()
+            if want:
+                yield OpCase(name, before, self._snap(), checks)
+
+        # --- D2A2C_Vect on the initial winds (translate_d2a2c_vect.py:36-47); does not advance the chain ---
+        if only is None or "d2a2c_vect" in only:
+            before = self._snap()
+            T = {k: S[k].copy() for k in ("uc", "vc", "u", "v", "ua", "va", "utc", "vtc")}
+            cgrid_sw.d2a2c_vect(g, cgrid_sw.D2A2CState(S["u"].shape), T["uc"], T["vc"], T["u"], T["v"], T["ua"], T["va"], T["utc"], T["vtc"])
+            after = dict(before)
+            after.update(T)
+            W1 = _win(n, 1, 1)
+            yield OpCase("d2a2c_vect", before, after,
+                         [("uc", _win(n, 1, 1, 1, 0), nz, 2e-10, 1e-13), ("vc", _win(n, 1, 1, 0, 1), nz, 2e-10, 1e-13),
+                          ("ua", W1, nz, 2e-10, 1e-13), ("va", W1, nz, 2e-10, 1e-13),
+                          ("utc", _win(n, 1, 1, 1, 0), nz, 2e-10, 1e-13), ("vtc", _win(n, 1, 1, 0, 1), nz, 2e-10, 1e-13)])
+
+        def f_csw():
+            cgrid_sw.c_sw(g, self.csw, S["delp"], S["pt"], S["u"], S["v"], S["w"], S["uc"], S["vc"], S["ua"], S["va"], S["ut"], S["vt"],
+                          S["divgd"], S["omga"], dt2, nord=DSW_CFG["nord"])
+            S["delpc"][...] = self.csw.delpc
+            S["ptc"][...] = self.csw.ptc
+
+        # translate_c_sw.py:85-107: delpc, ptc, omga on compute +- 1, uc / vc on their staggered compute windows, divgd on corners
+        yield from emit("c_sw", f_csw, [("delpc", C1, nz, 2e-10, 0), ("ptc", C1, nz, 2e-10, 0), ("omga", C1, nz, 2e-10, 1e-12),
+                                        ("uc", _win(n, 0, 0, 1, 0), nz, 2e-10, 1e-12), ("vc", _win(n, 0, 0, 0, 1), nz, 2e-10, 1e-12),
+                                        ("ua", C1, nz, 2e-10, 1e-12), ("va", C1, nz, 2e-10, 1e-12),
+                                        ("ut", C1, nz, 2e-10, 1e-12), ("vt", C1, nz, 2e-10, 1e-12),
+                                        ("divgd", _win(n, 0, 0, 1, 1), nz, 2e-10, 1e-10)])
+
+        def f_dzc():
+            S["zh"][:-1, :-1, :] = S["gz"][:-1, :-1, :]
+            vertical.update_dz_c(g, g.dp_ref, S["zs"], S["ut"], S["vt"], S["gz"], S["ws3"], dt2)
+
+        yield from emit("updatedzc", f_dzc, [("gz", C1, K, 1e-14, 0), ("ws3", C1, None, 1e-14, 1e-12)])
+
+        def f_riemc():
+            vertical.riem_solver_c(g, dt2, S["cappa"], ptop, S["phis"], S["ws3"], S["ptc"], S["q_con"], S["delpc"], S["gz"], S["pkc"],
+                                   S["omga"], p_fac=P_FAC)
+
+        # the reference's own bound is 5e-14 on the numpy backend; the device's exp / log differ from numpy's in the last place
+        # and the tridiagonal solve carries that: 1e-10 on the perturbation pressure (it is ~1e-5 of the full pressure), gz 1e-13
+        yield from emit("riem_solver_c", f_riemc, [("pkc", C1, K, 1e-9, 1e-9), ("gz", C1, K, 1e-12, 0)])
+
+        yield from emit("p_grad_c", lambda: ap.p_grad_c(g, S["uc"], S["vc"], S["delpc"], S["pkc"], S["gz"], dt2),
+                        [("uc", _win(n, 0, 0, 1, 0), nz, 1e-13, 1e-12), ("vc", _win(n, 0, 0, 0, 1), nz, 1e-13, 1e-12)])
+
+        def f_dsw():
+            dgrid_sw.d_sw(g, self.col, DSW_CFG, self.dsw, S["vt"], S["delp"], S["pt"], S["u"], S["v"], S["w"], S["uc"], S["vc"], S["ua"],
+                          S["va"], S["divgd"], S["mfxd"], S["mfyd"], S["cxd"], S["cyd"], S["crx"], S["cry"], S["xfx"], S["yfx"], S["q_con"],
+                          S["zh"], S["heat_source"], S["diss_estd"], dt)
+
+        dchecks = []
+        # translate_d_sw.py:36-65: every argument but zh, incl. what is left in the work fields uc, vc, divgd and delpc (= vt here)
+        for k in ("delp", "pt", "u", "v", "w", "q_con", "mfxd", "mfyd", "cxd", "cyd", "crx", "cry", "xfx", "yfx", "heat_source", "diss_estd",
+                  "uc", "vc", "divgd", "vt"):
+            di = 1 if k in ("mfxd", "cxd", "crx", "xfx", "v", "uc", "divgd", "vt") else 0
+            dj = 1 if k in ("mfyd", "cyd", "cry", "yfx", "u", "vc", "divgd", "vt") else 0
+            dchecks.append((k, _win(n, 0, 0, di, dj), nz, 3.2e-10, 1e-12))
+        yield from emit("d_sw", f_dsw, dchecks)
+
+        def f_dzd():
+            vertical.update_dz_d(g, self.col, g.dp_ref, S["zs"], S["zh"], S["crx"], S["cry"], S["xfx"], S["yfx"], S["wsd"], dt,
+                                 hord_tm=HORD_TM)
+
+        yield from emit("updatedzd", f_dzd, [("zh", C0, K, 1e-14, 0), ("wsd", C0, None, 1e-14, 1e-12)])
+
+        def f_riem3():
+            vertical.riem_solver3(g, True, dt, S["cappa"], ptop, S["zs"], S["wsd"], S["delz"], S["q_con"], S["delp"], S["pt"], S["zh"],
+                                  S["pe"], S["pkc"], S["pk3"], S["pk"], S["peln"], S["w"], p_fac=P_FAC)
+
+        yield from emit("riem_solver3", f_riem3, [("delz", C0, nz, 5e-6, 0), ("zh", C0, K, 5e-6, 0), ("pkc", C0, K, 5e-6, 1e-9),
+                                                  ("pk3", C0, K, 5e-6, 0), ("w", C0, nz, 5e-6, 1e-9), ("pe", C0, K, 5e-6, 0),
+                                                  ("pk", C0, K, 5e-6, 0), ("peln", C0, K, 5e-6, 0)])
+
+        yield from emit("edge_pe", lambda: ap.edge_pe(g, S["pe"], S["delp"], ptop), [("pe", C1, K, 1e-14, 0)])
+        # pow on the device vs numpy: last-place differences
+        yield from emit("pk3_halo", lambda: ap.pk3_halo(g, S["pk3"], S["delp"], ptop, oc.KAPPA), [("pk3", _win(n, 2, 2), K, 1e-14, 0)])
+
+        def f_geo():
+            S["gz"][1:-2, 1:-2, :] = S["zh"][1:-2, 1:-2, :] * oc.GRAV
+
+        yield from emit("compute_geopotential", f_geo, [("gz", _win(n, 2, 2), K, 0.0, 0)])
+
+        yield from emit("nh_p_grad", lambda: ap.nh_p_grad(g, S["u"], S["v"], S["pkc"], S["gz"], S["pk3"], S["delp"], dt, ptop, oc.KAPPA),
+                        [("u", _win(n, 0, 0, 0, 1), nz, 5e-10, 1e-12), ("v", _win(n, 0, 0, 1, 0), nz, 5e-10, 1e-12),
+                         ("pkc", _win(n, 0, 0, 1, 1), K, 5e-10, 1e-9), ("gz", _win(n, 0, 0, 1, 1), K, 5e-10, 0),
+                         ("pk3", _win(n, 0, 0, 1, 1), K, 5e-10, 0)])
+
+        yield from emit("ray_fast", lambda: ap.ray_fast(g, S["u"], S["v"], S["w"], g.dp_ref, g.p, dt, ptop, rf_cutoff=RF_CUTOFF, tau=TAU),
+                        [("u", _win(n, 0, 0, 0, 1), nz, 1e-13, 1e-12), ("v", _win(n, 0, 0, 1, 0), nz, 1e-13, 1e-12),
+                         ("w", C0, nz, 1e-13, 1e-12)])
+
+        yield from emit("del2cubed", lambda: ap.del2_cubed(g, S["heat_source"], oc.CNST_0P20 * g.da_min, 3),
+                        [("heat_source", C0, nz, 1e-14, 1e-12)])
+
+        yield from emit("apply_diffusive_heating",
+                        lambda: ap.apply_diffusive_heating(g, S["delp"], S["delz"], S["cappa"], S["heat_source"], S["pt"],
+                                                           abs(dt * DELT_MAX), nz),
+                        [("pt", C0, nz, 1e-13, 0)])
+
+
+class ProductOps:
+    """The host classes of one tile, built once; run(name, before) applies one operator to a state given as numpy arrays and
+    returns the numpy arrays afterwards."""
+
+    def __init__(self, lib, device, chain):
+        from helpers import Env
+        from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig
+        from pace_amd.fv3core.stencils.c_sw import CGridShallowWaterDynamics
+        from pace_amd.fv3core.stencils.d2a2c_vect import DGrid2AGrid2CGridVectors
+        from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics
+        from pace_amd.fv3core.stencils.del2cubed import HyperdiffusionDamping
+        from pace_amd.fv3core.stencils.nh_p_grad import NonHydrostaticPressureGradient
+        from pace_amd.fv3core.stencils.pk3_halo import PK3Halo
+        from pace_amd.fv3core.stencils.ray_fast import RayleighDamping
+        from pace_amd.fv3core.stencils.riem_solver3 import NonhydrostaticVerticalSolver
+        from pace_amd.fv3core.stencils.riem_solver_c import NonhydrostaticVerticalSolverCGrid
+        from pace_amd.fv3core.stencils.updatedzc import UpdateGeopotentialHeightOnCGrid
+        from pace_amd.fv3core.stencils.updatedzd import UpdateHeightOnDGrid
+
+        n, nz = chain.n, chain.nz
+        self.chain, self.lib = chain, lib
+        self.env = env = Env(lib, device, chain.metrics, n, nz)
+        sf, qf, gd, dc = env.stencil_factory, env.qf, env.grid_data, env.damping
+        colq = {k: env.kq(v) for k, v in chain.col.items()}
+        self.d2a2c = DGrid2AGrid2CGridVectors(sf, qf, gd, False, 0, True)
+        self.csw = CGridShallowWaterDynamics(sf, qf, gd, False, 0, DSW_CFG["nord"])
+        self.dzc = UpdateGeopotentialHeightOnCGrid(sf, qf, gd.area, gd.dp_ref, grid_data=gd)
+        self.riemc = NonhydrostaticVerticalSolverCGrid(sf, qf, P_FAC)
+        self.dsw = DGridShallowWaterLagrangianDynamics(sf, qf, gd, dc, colq, False, False, DGridShallowWaterLagrangianDynamicsConfig(**DSW_CFG))
+        self.dzd = UpdateHeightOnDGrid(sf, qf, dc, gd, 0, HORD_TM, colq)
+        self.riem3 = NonhydrostaticVerticalSolver(sf, qf, RiemannConfig(p_fac=P_FAC))
+        self.nh = NonHydrostaticPressureGradient(sf, qf, gd, 0)
+        self.pk3h = PK3Halo(sf, qf)
+        self.ray = RayleighDamping(sf, RF_CUTOFF, TAU, False, quantity_factory=qf)
+        self.del2 = HyperdiffusionDamping(sf, qf, dc, gd.rarea, 3)
+        self.fields = {}
+
+    def _load(self, before):
+        env = self.env
+        for k, a in before.items():
+            if k not in self.fields:
+                self.fields[k] = env.q2() if a.ndim == 2 else env.q3()
+            self.fields[k].set(a)
+        return self.fields
+
+    def run(self, name, before):
+        import ctypes as C
+
+        import torch
+
+        from pace_amd.fv3core.stencils._common import dptr
+
+        f = self._load(before)
+        ch = self.chain
+        dt, dt2, ptop = ch.dt, 0.5 * ch.dt, ch.ptop
+        geom, met, st = self.csw._geom, self.csw._met, self.csw.stream
+
+        def call(fn, *a):
+            self.lib.call(fn, C.byref(geom), *a)
+
+        if name == "d2a2c_vect":
+            self.d2a2c(f["uc"], f["vc"], f["u"], f["v"], f["ua"], f["va"], f["utc"], f["vtc"])
+        elif name == "c_sw":
+            self.csw(f["delp"], f["pt"], f["u"], f["v"], f["w"], f["uc"], f["vc"], f["ua"], f["va"], f["ut"], f["vt"], f["divgd"], f["omga"], dt2)
+            f["delpc"].data[...] = self.csw.delpc.data
+            f["ptc"].data[...] = self.csw.ptc.data
+        elif name == "updatedzc":
+            call("pace_copy", dptr(f["gz"]), dptr(f["zh"]), st())
+            self.dzc(f["zs"], f["ut"], f["vt"], f["gz"], f["ws3"], dt2)
+        elif name == "riem_solver_c":
+            self.riemc(dt2, f["cappa"], ptop, f["phis"], f["ws3"], f["ptc"], f["q_con"], f["delpc"], f["gz"], f["pkc"], f["omga"])
+        elif name == "p_grad_c":
+            call("pace_p_grad_c", C.byref(met), dptr(f["uc"]), dptr(f["vc"]), dptr(f["delpc"]), dptr(f["pkc"]), dptr(f["gz"]), dt2, st())
+        elif name == "d_sw":
+            names = dict(delpc="vt", mfx="mfxd", mfy="mfyd", cx="cxd", cy="cyd", diss_est="diss_estd")
+            # uc_contra / vc_contra of the previous call are the head of the workspace: the oracle's DSWState starts at zero
+            self.dsw._workspace[: 2 * f["u"]._base.numel()] = 0.0
+            self.dsw(*[f[names.get(k, k)] for k in DSW_ARGS], dt)
+        elif name == "updatedzd":
+            self.dzd(f["zs"], f["zh"], f["crx"], f["cry"], f["xfx"], f["yfx"], f["wsd"], dt)
+        elif name == "riem_solver3":
+            self.riem3(True, dt, f["cappa"], ptop, f["zs"], f["wsd"], f["delz"], f["q_con"], f["delp"], f["pt"], f["zh"], f["pe"], f["pkc"],
+                       f["pk3"], f["pk"], f["peln"], f["w"])
+        elif name == "edge_pe":
+            call("pace_edge_pe", dptr(f["pe"]), dptr(f["delp"]), ptop, st())
+        elif name == "pk3_halo":
+            self.pk3h(f["pk3"], f["delp"], ptop, oc.KAPPA)
+        elif name == "compute_geopotential":
+            call("pace_compute_geopotential", dptr(f["zh"]), dptr(f["gz"]), st())
+        elif name == "nh_p_grad":
+            self.nh(f["u"], f["v"], f["pkc"], f["gz"], f["pk3"], f["delp"], dt, ptop, oc.KAPPA)
+        elif name == "ray_fast":
+            self.ray(f["u"], f["v"], f["w"], self.env.grid_data.dp_ref, self.env.grid_data.p, dt, ptop)
+        elif name == "del2cubed":
+            self.del2(f["heat_source"], oc.CNST_0P20 * self.env.damping.da_min)
+        elif name == "apply_diffusive_heating":
+            call("pace_apply_diffusive_heating", dptr(f["delp"]), dptr(f["delz"]), dptr(f["cappa"]), dptr(f["heat_source"]), dptr(f["pt"]),
+                 abs(dt * DELT_MAX), ch.nz, st())
+        else:
+            raise KeyError(name)
+        if self.env.qf.device.type == "cuda":
+            torch.cuda.synchronize()
+        return f
+
+
+def check_case(ops, case, scale_tol=1.0, report=None):
+    """Run the product operator on case.before and compare with case.after.  Returns {variable: error}."""
+    f = ops.run(case.name, case.before)
+    errs = {}
+    for var, win, nk, tol, nz_frac in case.checks:
+        ref = case.after[var]
+        got = f[var].numpy()
+        if ref.ndim == 3:
+            r, gt = ref[win][:, :, :nk], got[win][:, :, :nk]
+        else:
+            r, gt = ref[win], got[win]
+        assert np.isfinite(r).all(), (case.name, var, "oracle produced non-finite values")
+        near = nz_frac * float(np.abs(r).max()) if nz_frac else 0.0
+        e = compare(r, gt, near_zero=near)
+        errs[var] = e
+        if report is not None:
+            report.setdefault(case.name, {})[var] = e
+        assert e <= tol * scale_tol, (case.name, var, e, tol)
+    return errs
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The whole AcousticDynamics call on six synthetic tiles of any size (every operator chained on its predecessor's output,
+# all halo-update groups), product against oracle/dyn_core.py
+# ----------------------------------------------------------------------------------------------------------------------
+LOOP_STATE = "u v w delz delp pt pe pk peln phis uc vc ua va q_con".split()
+LOOP_OUT = "u v w delz delp pt pe pk peln q_con omga ua va uc vc mfxd mfyd cxd cyd diss_estd heat_source".split()
+
+
+def six_tile_inputs(n, nz):
+    """Six copies of the synthetic tile, each with its own amplitude of the wave / vertical-velocity perturbation, joined by the
+    cubed-sphere halo exchange (the geometry is the same single tile for all six: a consistency configuration, not a sphere)."""
+    from pace_amd import synthetic
+
+    m = synthetic.tile_metrics(n, nz)
+    tiles = []
+    for t in range(6):
+        s = synthetic.acoustic_state(m, n, nz)
+        a = {k: s[k].copy() for k in LOOP_STATE if k != "phis"}
+        a["phis"] = s["zs"] * oc.GRAV
+        a["w"] *= 1.0 + 0.3 * t
+        a["pt"][:, :, :nz] *= 1.0 + 1.0e-3 * t
+        a["v"] *= 1.0 - 0.05 * t
+        tiles.append((a, s["cappa"].copy()))
+    return m, tiles
+
+
+def oracle_loop(n, nz, n_split, timestep):
+    from oracle import dyn_core
+
+    m, tiles = six_tile_inputs(n, nz)
+    grids = [Grid(n, nz, m) for _ in range(6)]
+    states = []
+    for a, _ in tiles:
+        st = {k: v.copy() for k, v in a.items()}
+        for k in ("omga", "mfxd", "mfyd", "cxd", "cyd", "diss_estd"):
+            st[k] = np.zeros(a["u"].shape)
+        states.append(st)
+    cappas = [c.copy() for _, c in tiles]
+    cfg = dict(DSW_CFG, p_fac=P_FAC, rf_cutoff=RF_CUTOFF, tau=TAU, delt_max=DELT_MAX, hord_tm=HORD_TM)
+    tmp = dyn_core.acoustic_dynamics(grids, column(nz), cfg, states, cappas, timestep, n_split, n, nz)
+    for t in range(6):
+        states[t]["heat_source"] = tmp[t].heat_source
+    return states
+
+
+def product_loop_tile(comm, lib, device, m, arrays, cappa, n, nz, n_split, timestep):
+    import torch
+
+    from helpers import Env, acoustic_config
+    from pace_amd.fv3core.initialization.dycore_state import DycoreState
+    from pace_amd.fv3core.stencils.dyn_core import AcousticDynamics
+    from pace_amd.util import CubedSphereCommunicator
+
+    env = Env(lib, device, m, n, nz)
+    cube = CubedSphereCommunicator(comm, device=device, lib=lib)
+    state = DycoreState.init_from_numpy_arrays(arrays, env.qf)
+    dyn = AcousticDynamics(cube, env.stencil_factory, env.qf, env.grid_data, env.damping, 0, False, False, acoustic_config(n_split),
+                           state.phis, env.q2(), state)
+    dyn.cappa.set(cappa)
+    dyn(state, timestep=timestep, n_map=1)
+    if env.qf.device.type == "cuda":
+        torch.cuda.synchronize()
+    out = {k: getattr(state, k).numpy() for k in LOOP_OUT if k != "heat_source"}
+    out["heat_source"] = dyn._heat_source.numpy()
+    return out
+
+
+def product_loop(lib, device, n, nz, n_split, timestep):
+    from pace_amd.util import run_tiles
+
+    m, tiles = six_tile_inputs(n, nz)
+    return run_tiles(6, lambda comm: product_loop_tile(comm, lib, device, m, tiles[comm.Get_rank()][0], tiles[comm.Get_rank()][1], n, nz,
+                                                       n_split, timestep))
+
+
+LOOP_TOL = {"w": 5e-6, "omga": 5e-6, "delz": 5e-6, "u": 5e-6, "v": 5e-6, "ua": 5e-6, "va": 5e-6, "uc": 5e-6, "vc": 5e-6,
+            "diss_estd": 5e-6, "heat_source": 5e-6}
+
+
+def loop_errors(ref, got, n, nz):
+    errs = {}
+    for k in LOOP_OUT:
+        di = 1 if k in ("v", "mfxd", "cxd", "uc") else 0
+        dj = 1 if k in ("u", "mfyd", "cyd", "vc") else 0
+        nk = nz + 1 if k in ("pe", "pk", "peln") else nz
+        W = (slice(3, 3 + n + di), slice(3, 3 + n + dj), slice(0, nk))
+        worst = 0.0
+        for t in range(6):
+            r = ref[t][k][W]
+            assert np.isfinite(r).all(), (k, t)
+            worst = max(worst, compare(r, got[t][k][W], near_zero=1e-9 * float(np.abs(r).max()) + 1e-300))
+        errs[k] = worst
+    return errs

@@ -115,3 +115,28 @@ def test_column_namelist_matches_reference_values():
     ref = golden("column_namelist_c12.npz")
     for k, v in ref.items():
         np.testing.assert_array_equal(col[k].numpy()[:79], v[:79], err_msg=k)
+
+
+def test_entry_points_reject_inconsistent_geometry():
+    """Every entry validates pace_geom_t before anything is launched (the kernels address fields with 32-bit byte offsets):
+    strides that do not cover the storage -> PACE_ERR_ARG, a field of 4 GB or more -> PACE_ERR_UNSUPPORTED.  Checked on the
+    emulation build (argument checking is the same translation unit, csrc/capi.hip); nothing is computed."""
+    import ctypes as C
+
+    from helpers import build_emu
+    from pace_amd import _lib
+
+    lib = _lib.Library(build_emu())
+    buf = (C.c_double * 8)()
+    p = C.cast(buf, C.c_void_p).value
+
+    def copy_rc(n, nk, sj, sk):
+        g = _lib.Geom(n, nk, sj, 0, sk)
+        return lib.cdll.pace_copy(C.byref(g), p, p, None)
+
+    assert copy_rc(12, 79, 16, 32 * 19) == -1            # row stride shorter than N + 7
+    assert copy_rc(12, 79, 32, 32 * 18) == -1            # level stride shorter than sj * (N + 7)
+    assert copy_rc(0, 79, 32, 32 * 19) == -1 and copy_rc(12, 0, 32, 32 * 19) == -1
+    assert copy_rc(3000, 79, 3008, 3008 * 3007) == -3    # (nk + 1) * sk * 8 B >= 4 GB
+    with pytest.raises(_lib.PaceError, match="pace_copy failed"):
+        lib.call("pace_copy", C.byref(_lib.Geom(12, 79, 16, 0, 32 * 19)), p, p, None)

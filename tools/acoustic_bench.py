@@ -18,7 +18,7 @@ import torch  # noqa: E402
 
 def build_ops(n, nz):
     """[(name, callable)] for one acoustic substep on one tile + the fields they work on."""
-    from helpers import DSW_ARGS, Env
+    from pace_amd.tile import DSW_ARGS, Env
 
     from pace_amd import _lib, synthetic
     from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig

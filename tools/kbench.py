@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    from helpers import DSW_ARGS, Env
+    from pace_amd.tile import DSW_ARGS, Env
 
     from pace_amd import _lib, synthetic
     from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--lib", default=None)
     args = ap.parse_args()
-    from helpers import Env
+    from pace_amd.tile import Env
 
     from pace_amd import _lib, synthetic
     from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
