@@ -65,7 +65,17 @@ def expand_riem_fixture(fix, n=12, nz=79):
 # ------------------------------------------------------------------------------------------------------------------
 # whole-AcousticDynamics runs (6 tiles in one process, one thread per tile)
 # ------------------------------------------------------------------------------------------------------------------
-ACOUSTIC_OUT = "u v w delz delp pt pe pk peln q_con omga ua va mfxd mfyd cxd cyd diss_estd heat_source".split()
+ACOUSTIC_OUT = "u v w delz delp pt pe pk peln q_con omga ua va uc vc mfxd mfyd cxd cyd diss_estd heat_source".split()
+
+
+def acoustic_fixture(t):
+    """tests/golden/acoustic_c12_tile<t>.npz + what the reference run left in the work fields uc / vc (a later addition kept
+    in acoustic_c12_ucvc.npz, tools/make_golden_acoustic.py; TranslateDynCore compares them, translate_dyncore.py:84-85)."""
+    fix = golden(f"acoustic_c12_tile{t}.npz")
+    extra = golden("acoustic_c12_ucvc.npz")
+    for k in ("uc", "vc"):
+        fix["out_" + k], fix["col_" + k] = extra[f"out_{k}_tile{t}"], extra[f"col_{k}_tile{t}"]
+    return fix
 
 
 def acoustic_config(n_split):
@@ -106,7 +116,7 @@ def run_acoustic_tile(comm, lib, device, fix, n, nz):
 def run_acoustic_six_tiles(lib, device, n=12, nz=79):
     from pace_amd.util import run_tiles
 
-    fixes = [golden(f"acoustic_c12_tile{t}.npz") for t in range(6)]
+    fixes = [acoustic_fixture(t) for t in range(6)]
     return fixes, run_tiles(6, lambda comm: run_acoustic_tile(comm, lib, device, fixes[comm.Get_rank()], n, nz))
 
 
@@ -117,8 +127,8 @@ def acoustic_errors(fix, out, n=12):
     ks = fix["k_sel"]
     for k in ACOUSTIC_OUT:
         full = out[k]
-        di = 1 if k in ("v", "mfxd", "cxd") else 0
-        dj = 1 if k in ("u", "mfyd", "cyd") else 0
+        di = 1 if k in ("v", "mfxd", "cxd", "uc") else 0
+        dj = 1 if k in ("u", "mfyd", "cyd", "vc") else 0
         kk = [x for x in ks if x < (80 if k in ("pe", "pk", "peln") else 79)]
         idx = [list(ks).index(x) for x in kk]
         got = full[3 : 3 + n + di, 3 : 3 + n + dj][:, :, kk]
@@ -128,7 +138,10 @@ def acoustic_errors(fix, out, n=12):
         # per-variable near_zero overrides (tests/savepoint/translate/overrides/standard.yaml)
         # (mass / Courant fluxes across the tile's symmetry line cancel to ~1e-7 of the field scale and carry the same
         # ABSOLUTE rounding error as every other row, hence the wider band for the four accumulators)
-        band = 1e-6 if k in ("mfxd", "mfyd", "cxd", "cyd") else 1e-12
+        # (uc / vc after the call are work-field leftovers: the C-grid winds on the sponge levels -- where the meridional one
+        # is rounding residue on half of the tiles of this zonal-flow case -- and ~1e-29 elsewhere; the reference ignores them
+        # below 1e-13 ABSOLUTE (overrides/baroclinic.yaml:12-20), here: below 1e-8 of the field's magnitude)
+        band = 1e-6 if k in ("mfxd", "mfyd", "cxd", "cyd") else (1e-8 if k in ("uc", "vc") else 1e-12)
         near_zero = band * float(np.abs(ref).max()) + 1e-300
         e = compare(ref, got, near_zero=near_zero)
         nk = 80 if k in ("pe", "pk", "peln") else 79
@@ -183,9 +196,11 @@ def check_tracer_outputs(fixes, outs, n=12):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# Six-tile GPU runs in a child process.  The six tiles run on host threads inside one process; a rare abort inside the
-# GPU runtime during such a run (seen twice in ~40 runs on the test pool, never reproduced, no message) must not take
-# the whole pytest process down: the run happens in a child and is retried once if the child dies from a signal.
+# Six-tile GPU runs in a child process (six tiles = six host threads sharing one device; run as coroutines, see
+# pace_amd/util/comm.py).  Round 1 retried such a run when the child died from a signal ("seen twice in ~40 runs").  Round 2
+# hunted for it: 240 consecutive runs on an MI355X (tools/abort_hunt.py: 140 acoustic, 60 whole-dycore, 40 tracer; fault
+# handler on) without a single failure (profiles/r02_abort_hunt.json), so the retry is gone: a child that dies fails the test,
+# and its return code + output are kept as an artefact (gpurun_out/child_failure_<what>.txt).
 # ------------------------------------------------------------------------------------------------------------------
 def _child_main(what, out_path, hard_exit=False):
     import pickle
@@ -213,22 +228,22 @@ def _child_main(what, out_path, hard_exit=False):
         os._exit(0)
 
 
-def run_in_child(what, tmp_path, retries=1):
+def run_in_child(what, tmp_path):
     import pickle
-    import sys
 
     out = os.path.join(str(tmp_path), f"{what}.pkl")
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
             f"import helpers; helpers._child_main({what!r}, {out!r})")
-    for attempt in range(retries + 1):
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
-        if p.returncode == 0:
-            with open(out, "rb") as f:
-                return pickle.load(f)
-        died_from_signal = p.returncode < 0 or p.returncode in (134, 139)
-        if not died_from_signal or attempt == retries:
-            raise RuntimeError(f"child run {what!r} failed (rc {p.returncode}):\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}")
-    raise AssertionError("unreachable")
+    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        report = f"child run {what!r} failed (rc {p.returncode}):\n{p.stdout[-4000:]}\n{p.stderr[-8000:]}"
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, f"child_failure_{what}.txt"), "w") as f:
+                f.write(report)
+        raise RuntimeError(report)
+    with open(out, "rb") as f:
+        return pickle.load(f)
 
 
 # ---- vertical remapping (tests/golden/remap_c12.npz: a run of the reference's MapSingle, tools/make_golden_remap.py) ----

@@ -124,9 +124,8 @@ class Chain:
             vertical.riem_solver_c(g, dt2, S["cappa"], ptop, S["phis"], S["ws3"], S["ptc"], S["q_con"], S["delpc"], S["gz"], S["pkc"],
                                    S["omga"], p_fac=P_FAC)
 
-        # the reference's own bound is 5e-14 on the numpy backend; the device's exp / log differ from numpy's in the last place
-        # and the tridiagonal solve carries that: 1e-10 on the perturbation pressure (it is ~1e-5 of the full pressure), gz 1e-13
-        yield from emit("riem_solver_c", f_riemc, [("pkc", C1, K, 1e-9, 1e-9), ("gz", C1, K, 1e-12, 0)])
+        # the reference's own bound: 5e-14 (translate_riem_solver_c.py:33); measured on MI355X: 1.5e-15
+        yield from emit("riem_solver_c", f_riemc, [("pkc", C1, K, 5e-14, 0), ("gz", C1, K, 5e-14, 0)])
 
         yield from emit("p_grad_c", lambda: ap.p_grad_c(g, S["uc"], S["vc"], S["delpc"], S["pkc"], S["gz"], dt2),
                         [("uc", _win(n, 0, 0, 1, 0), nz, 1e-13, 1e-12), ("vc", _win(n, 0, 0, 0, 1), nz, 1e-13, 1e-12)])
@@ -387,8 +386,13 @@ def product_loop(lib, device, n, nz, n_split, timestep):
                                                        n_split, timestep))
 
 
-LOOP_TOL = {"w": 5e-6, "omga": 5e-6, "delz": 5e-6, "u": 5e-6, "v": 5e-6, "ua": 5e-6, "va": 5e-6, "uc": 5e-6, "vc": 5e-6,
-            "diss_estd": 5e-6, "heat_source": 5e-6}
+# The reference's bound for the whole acoustic call is 2e-6 (translate_dyncore.py:120-121), 5e-6 for what Riem_Solver3 feeds
+# (overrides/standard.yaml:49-61).  Measured on MI355X at C96 x 79 (profiles/r02_acoustic_loop_c96_gpu_errors.json): masses,
+# temperatures and pressures agree to 4e-15, winds / mass fluxes / Courant numbers to 1e-7 (last-place differences of the
+# device's exp / log in the two vertical solvers, carried through the pressure-gradient and transport steps), w to 3e-6.
+LOOP_TOL = {"w": 5e-6, "omga": 5e-6, "delz": 5e-6, "diss_estd": 5e-6, "heat_source": 5e-6,
+            "u": 2e-6, "v": 2e-6, "ua": 2e-6, "va": 2e-6, "uc": 2e-6, "vc": 2e-6, "mfxd": 2e-6, "mfyd": 2e-6, "cxd": 2e-6, "cyd": 2e-6,
+            "delp": 1e-12, "pt": 1e-12, "pe": 1e-12, "pk": 1e-12, "peln": 1e-12, "q_con": 1e-12}
 
 
 def loop_errors(ref, got, n, nz):

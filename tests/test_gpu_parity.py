@@ -168,7 +168,7 @@ def test_acoustic_dynamics_six_tiles_matches_reference_run(lib, tmp_path):
     # Device exp/log are 1-2 ulp off numpy's; the two tridiagonal solves per substep amplify that on near-zero w (polar
     # tiles).  5e-6 is the reference's own Riem_Solver3 bound on every backend (overrides/standard.yaml:49-61); fields
     # the vertical solver does not feed stay at 1e-7.
-    loose = ("w", "omga", "delz", "diss_estd", "heat_source", "u", "v", "ua", "va")
+    loose = ("w", "omga", "delz", "diss_estd", "heat_source", "u", "v", "ua", "va", "uc", "vc")
     for k, e in worst.items():
         assert e < (5e-6 if k in loose else 1e-7), (k, e)
 

@@ -126,12 +126,12 @@ def test_oracle_acoustic_dynamics_against_reference_run():
     """The whole oracle (c_sw, d2a2c_vect, updatedzc, riem_solver_c, p_grad_c, d_sw, updatedzd, riem_solver3, pe/pk3 halo,
     nh_p_grad, ray_fast, del2cubed, heating + every halo-exchange flavour) composed into the acoustic loop of
     dyn_core.py:670-970 for all six tiles, against the reference run's output (tests/golden/acoustic_c12_tile*.npz)."""
-    from helpers import ACOUSTIC_OUT, DSW_CFG, acoustic_errors, golden, oracle_grid
+    from helpers import ACOUSTIC_OUT, DSW_CFG, acoustic_errors, acoustic_fixture, golden, oracle_grid
 
     from oracle import dyn_core
 
     n, nz = 12, 79
-    fixes = [golden(f"acoustic_c12_tile{t}.npz") for t in range(6)]
+    fixes = [acoustic_fixture(t) for t in range(6)]
     grids = [oracle_grid({k[5:]: v for k, v in fx.items() if k.startswith("grid_")}, n, nz) for fx in fixes]
     states = [{k[3:]: v.copy() for k, v in fx.items() if k.startswith("in_") and k != "in_cappa"} for fx in fixes]
     cappas = [fx["in_cappa"].copy() for fx in fixes]

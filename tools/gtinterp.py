@@ -215,8 +215,22 @@ def _shift_slab(slab, di, dj):
     return out
 
 
+# Audit of the one execution-model assumption that the reference-held tests do not pin: set to a list
+# and every read, at a non-zero horizontal offset, of an API field that the SAME stencil call has already written is recorded
+# as (stencil, offset).  tools/semantics_audit.py runs the whole reference DynamicalCore with it switched on.
+AUDIT = None
+# Differential execution: set to a dict and every stencil call is executed twice from the same inputs -- once as usual
+# (statements see the writes of earlier statements of the call) and once with every horizontally shifted read of an API field
+# served from the field's contents AT ENTRY -- and the two results are compared; {stencil: [calls, calls that differ]}.
+DIFFERENTIAL = None
+
+
 class Ctx:
+    stencil_name = "?"
+    entry_snapshot = None
+
     def __init__(self, shape, origin, domain, externals):
+        self.written_api = set()
         self.shape = shape
         self.origin = origin
         self.domain = domain
@@ -236,7 +250,11 @@ class Ctx:
     def materialize(self, v):
         if isinstance(v, Ref):
             di, dj, dk = v.off
+            if AUDIT is not None and (di or dj) and id(v.arr) in self.written_api:
+                AUDIT.append((self.stencil_name, (di, dj, dk), tuple(self.origin[:2]), tuple(self.domain[:2]), tuple(self.shape[:2])))
             if v.axes == ("I", "J", "K"):
+                if self.entry_snapshot is not None and (di or dj) and id(v.arr) in self.entry_snapshot:
+                    return _shift3(self.entry_snapshot[id(v.arr)], di, dj, self.k0, self.k1, dk)
                 return _shift3(v.arr, di, dj, self.k0, self.k1, dk)
             if v.axes == ("I", "J"):
                 a = np.asarray(v.arr, dtype=float)[:, :, None]
@@ -651,6 +669,7 @@ class Interp:
         m = mask
         if is_api:
             m = ctx.dom_mask if m is None else (m & ctx.dom_mask)
+            ctx.written_api.add(id(arr))
         if axes == ("I", "J", "K"):
             tgt = arr[:, :, k0:k1]
             full = np.broadcast_to(val, tgt.shape) if not np.isscalar(val) else val
@@ -705,18 +724,48 @@ class StencilObject:
             else:
                 self.field_info[p] = None
                 self.kinds[p] = None
-        self.__class__.__name__ = "StencilObject"
 
     # gt4py call forms -----------------------------------------------------
     def __call__(self, *args, origin=None, domain=None, validate_args=True, exec_info=None, **kwargs):
         named = dict(zip(self.params, args))
         named.update(kwargs)
-        self._execute(named, origin, domain)
+        self._timed(named, origin, domain, exec_info)
 
     def run(self, _origin_=None, _domain_=None, exec_info=None, **kwargs):
-        self._execute(kwargs, _origin_, _domain_)
+        self._timed(kwargs, _origin_, _domain_, exec_info)
+
+    def _timed(self, named, origin, domain, exec_info):
+        """gt4py's exec_info protocol (StencilObject._call_run): per stencil class name, call counts and accumulated times."""
+        import time
+
+        t0 = time.perf_counter()
+        self._execute(named, origin, domain)
+        t1 = time.perf_counter()
+        if exec_info is not None:
+            rec = exec_info.setdefault(type(self).__name__, {"ncalls": 0, "total_call_time": 0.0, "total_run_time": 0.0})
+            rec["ncalls"] += 1
+            rec["call_start_time"], rec["call_end_time"] = t0, t1
+            rec["run_start_time"], rec["run_end_time"] = t0, t1
+            rec["total_call_time"] += t1 - t0
+            rec["total_run_time"] += t1 - t0
 
     def _execute(self, named, origin, domain):
+        if DIFFERENTIAL is None:
+            return self._execute_once(named, origin, domain, False)
+        arrays = {p: named[p] for p in self.params if self.kinds[p] is not None and isinstance(named[p], np.ndarray)}
+        before = {p: a.copy() for p, a in arrays.items()}
+        self._execute_once(named, origin, domain, True)
+        alt = {p: a.copy() for p, a in arrays.items()}
+        for p, a in arrays.items():
+            a[...] = before[p]
+        self._execute_once(named, origin, domain, False)
+        name = f"{self.definition.__module__}.{self.definition.__name__}"
+        rec = DIFFERENTIAL.setdefault(name, [0, 0])
+        rec[0] += 1
+        if any(not np.array_equal(alt[p], arrays[p], equal_nan=True) for p in arrays):
+            rec[1] += 1
+
+    def _execute_once(self, named, origin, domain, from_entry):
         if isinstance(origin, dict):
             o3 = origin.get("_all_")
             if o3 is None:
@@ -736,6 +785,10 @@ class StencilObject:
         if shape is None:
             raise NotImplementedError(f"{self.name}: no 3-D field argument")
         ctx = Ctx(shape, o3, domain, self.externals)
+        ctx.stencil_name = f"{self.definition.__module__}.{self.definition.__name__}"
+        if from_entry:
+            ctx.entry_snapshot = {id(named[p]): named[p].copy() for p in self.params
+                                  if self.kinds[p] == ("I", "J", "K") and isinstance(named[p], np.ndarray)}
         interp = Interp(ctx)
         scope = Scope(self.definition.__globals__, False)
         for p in self.params:
@@ -803,10 +856,26 @@ class StencilObject:
         return lo, hi
 
 
-def stencil(backend=None, definition=None, externals=None, name=None, **kw):
+def _make(definition, externals, name, build_info):
+    """Like gt4py, every stencil is an instance of its own class, named after the definition + an id."""
+    import hashlib
+    import time
+
+    t0 = time.perf_counter()
+    src = inspect.getsource(definition) + repr(sorted((externals or {}).items(), key=lambda kv: kv[0]))
+    gt_id = hashlib.sha256(src.encode()).hexdigest()[:10]
+    cls = type(f"{definition.__name__}____gtinterp_{gt_id}", (StencilObject,), {"_gt_id_": gt_id})
+    obj = cls(definition, externals=externals, name=name)
+    if build_info is not None:
+        dt = time.perf_counter() - t0
+        build_info.update(parse_time=dt, module_time=0.0, codegen_time=0.0, build_time=0.0, load_time=0.0)
+    return obj
+
+
+def stencil(backend=None, definition=None, externals=None, name=None, build_info=None, **kw):
     if definition is None:
-        return lambda fn: StencilObject(fn, externals=externals, name=name)
-    return StencilObject(definition, externals=externals, name=name)
+        return lambda fn: _make(fn, externals, name, build_info)
+    return _make(definition, externals, name, build_info)
 
 
 lazy_stencil = stencil

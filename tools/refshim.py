@@ -146,9 +146,12 @@ def install():
 
     import pace.dsl.gt4py_utils as u
 
-    u.is_gpu_backend = lambda backend: False
+    # gt4py's backend registry answers this from the backend's storage_info: "gpu" for cuda / gt:gpu / dace:gpu
+    gpu_backends = ("cuda", "gt:gpu", "dace:gpu")
+    u.is_gpu_backend = lambda backend: backend in gpu_backends
 
     # compiler-pass selection is meaningless under the interpreter
     import pace.dsl.stencil_config as sc
 
     sc.StencilConfig._get_oir_pipeline = classmethod(lambda cls, skip_passes: None)
+    sc.is_gpu_backend = u.is_gpu_backend
