@@ -3,7 +3,7 @@
 # tests/emu/README.md).
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC := pace_amd/csrc
-SRCS := $(CSRC)/capi.hip $(CSRC)/k_fxadv.hip $(CSRC)/k_fvtp2d.hip $(CSRC)/k_delnflux.hip $(CSRC)/k_dsw.hip $(CSRC)/k_riem3.hip $(CSRC)/k_csw.hip $(CSRC)/k_acoustic.hip $(CSRC)/k_halo.hip $(CSRC)/k_tracer.hip $(CSRC)/k_remap.hip $(CSRC)/k_l2e.hip $(CSRC)/k_dycore.hip $(CSRC)/k_march.hip
+SRCS := $(CSRC)/capi.hip $(CSRC)/k_fxadv.hip $(CSRC)/k_fvtp2d.hip $(CSRC)/k_delnflux.hip $(CSRC)/k_dsw.hip $(CSRC)/k_riem3.hip $(CSRC)/k_riem3f.hip $(CSRC)/k_csw.hip $(CSRC)/k_acoustic.hip $(CSRC)/k_halo.hip $(CSRC)/k_tracer.hip $(CSRC)/k_remap.hip $(CSRC)/k_l2e.hip $(CSRC)/k_dycore.hip $(CSRC)/k_march.hip
 HDRS := $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/delnflux_core.h include/pace_hip.h
 # -ffp-contract=off: no FMA contraction, so horizontal stencils are bit-comparable with the numpy oracle.
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
@@ -46,7 +46,16 @@ emu-small: tests/emu/libpace_emu_small.so
 tests/emu/libpace_emu_small.so: $(SMALLOBJS) build/emu/hip_emu.o
 	g++ -shared -fPIC $(SMALLOBJS) build/emu/hip_emu.o -o $@
 
+# experiments only: the library with the transport kernel's stage-time instrumentation (tools/fv_stage_times.py)
+PROFOBJS := $(patsubst $(CSRC)/%.hip,build/prof/%.o,$(SRCS))
+build/prof/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/prof
+	$(HIPCC) $(HIPFLAGS) -DFV_PROF -c $< -o $@
+prof: build/prof/libpace_prof.so
+build/prof/libpace_prof.so: $(PROFOBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(PROFOBJS) -o $@
+
 clean:
 	rm -rf build pace_amd/libpace_hip.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so
 
-.PHONY: all emu emu-small clean
+.PHONY: all emu emu-small prof clean

@@ -32,6 +32,17 @@ static inline int geom_check(const pace_geom_t* g) {
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
+// PACE_LEGACY_COLUMN_SOLVERS=1 selects the round-1 thread-per-column kernels of k_riem3.hip (kept for more than 128 layers and
+// for A/B measurements); read once.
+#include <cstdlib>
+static bool legacy_column_solvers() {
+  static const bool on = [] {
+    const char* e = getenv("PACE_LEGACY_COLUMN_SOLVERS");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on;
+}
+
 extern "C" {
 
 const char* pace_last_error(void) { return g_pace_err; }
@@ -140,8 +151,12 @@ int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, d
                       const double* delp, const double* pt, double* zh, double* pe, double* ppe, double* pk3, double* pk,
                       double* peln, double* w, double p_fac, void* stream) {
   NEED(geom && workspace && cappa && zs && ws && delz && q_con && delp && pt && zh && pe && ppe && pk3 && pk && peln && w);
-  return launch_riem_solver3(make_geo(geom), workspace, last_call, dt, cappa, ptop, zs, ws, delz, q_con, delp, pt, zh, pe,
-                             ppe, pk3, pk, peln, w, p_fac, S(stream));
+  const Geo g = make_geo(geom);
+  if (riem_column_supported(g) && !legacy_column_solvers())
+    return launch_riem_solver3_column(g, last_call, dt, cappa, ptop, zs, ws, delz, q_con, delp, pt, zh, pe, ppe, pk3, pk, peln, w,
+                                      p_fac, S(stream));
+  return launch_riem_solver3(g, workspace, last_call, dt, cappa, ptop, zs, ws, delz, q_con, delp, pt, zh, pe, ppe, pk3, pk, peln,
+                             w, p_fac, S(stream));
 }
 
 int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom) { return geom ? csw_workspace_bytes(make_geo(geom)) : 0; }
@@ -169,8 +184,10 @@ int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, con
                        const double* hs, const double* ws, const double* ptc, const double* q_con,
                        const double* delpc, double* gz, double* pef, const double* w3, double p_fac, void* stream) {
   NEED(geom && workspace && cappa && hs && ws && ptc && q_con && delpc && gz && pef && w3);
-  return launch_riem_solver_c(make_geo(geom), workspace, dt2, cappa, ptop, hs, ws, ptc, q_con, delpc, gz, pef, w3, p_fac,
-                              S(stream));
+  const Geo g = make_geo(geom);
+  if (riem_column_supported(g) && !legacy_column_solvers())
+    return launch_riem_solver_c_column(g, dt2, cappa, ptop, hs, ws, ptc, q_con, delpc, gz, pef, w3, p_fac, S(stream));
+  return launch_riem_solver_c(g, workspace, dt2, cappa, ptop, hs, ws, ptc, q_con, delpc, gz, pef, w3, p_fac, S(stream));
 }
 
 int64_t pace_updatedzc_workspace_bytes(const pace_geom_t* geom) {

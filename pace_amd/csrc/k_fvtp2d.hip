@@ -28,6 +28,20 @@ static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the tr
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
+// Stage-time instrumentation (experiments only: `make prof` builds build/prof/libpace_prof.so with -DFV_PROF; the product
+// library contains none of this).  One interior workgroup per level records the shader clock at every stage boundary.
+#ifdef FV_PROF
+__device__ long long g_fv_prof[256 * 16];
+#define STAMP(n)                                                                               \
+  if (threadIdx.x == 0 && blockIdx.x == 2 && blockIdx.y == 3 && blockIdx.z < 256)             \
+  g_fv_prof[blockIdx.z * 16 + (n)] = (long long)__builtin_readcyclecounter()
+extern "C" int pace_debug_fv_prof(long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fv_prof), sizeof(long long) * 256 * 16);
+}
+#else
+#define STAMP(n)
+#endif
+
 // EX / EY: whether any x- (y-) interface this workgroup evaluates lies within two cells of a tile edge, where the
 // PPM interface values switch to the one-sided forms (xppm.py:148-181).  Block-uniform, so interior workgroups
 // (25 of 35 at C192) run straight-line code without the per-interface position tests.
@@ -90,20 +104,33 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   const bool y5_on = y5_grp < GY && y5_col >= 0 && y5_col < TI;
   double cx_keep[RF], cy_keep[RF];
 
-  // stage 0: q with corners copied in the y direction (copy_corners_y, corners.py:367-425)
-  for (int e = tid; e < QW * QH; e += 256) {
-    const int jj = e / QW, ii = e - jj * QW;
-    int gi = ilo + ii, gj = jlo + jj;
-    double v = 0.0;
-    // (a workgroup with EX false has its whole footprint inside the compute domain in x, likewise EY in y; corner cells
-    // -- outside in both -- exist only for EX && EY)
-    if ((!EX || (gi >= 0 && gi < g.ni)) && (!EY || (gj >= 0 && gj < g.nj))) {
+  STAMP(0);
+  // stage 0: q with corners copied in the y direction (copy_corners_y, corners.py:367-425).
+  // All of a thread's loads are issued before the first of them is consumed (the straightforward loop waits for every
+  // iteration's load before issuing the next one: 4.5 exposed memory latencies per workgroup, measured with FV_PROF).
+  {
+    constexpr int NE0 = (QW * QH + 255) / 256;
+    double v0[NE0];
+#pragma unroll
+    for (int t = 0; t < NE0; ++t) {
+      const int e = tid + 256 * t;
+      const int jj = e / QW, ii = e - jj * QW;
+      int gi = ilo + ii, gj = jlo + jj;
+      // (a workgroup with EX false has its whole footprint inside the compute domain in x, likewise EY in y; corner cells
+      // -- outside in both -- exist only for EX && EY)
+      const bool ok = e < QW * QH && (!EX || (gi >= 0 && gi < g.ni)) && (!EY || (gj >= 0 && gj < g.nj));
       if (EX && EY) remap_agrid_y(g, gi, gj);
-      v = LD(q, kb8 + OFF2(gi, gj));
+      v0[t] = ok ? LD(q, kb8 + OFF2(gi, gj)) : 0.0;
     }
-    sq[jj][ii] = v;
+#pragma unroll
+    for (int t = 0; t < NE0; ++t) {
+      const int e = tid + 256 * t;
+      const int jj = e / QW, ii = e - jj * QW;
+      if (e < QW * QH) sq[jj][ii] = v0[t];
+    }
   }
   __syncthreads();
+  STAMP(1);
 
   // fused damping: iterate in the LDS space the sweeps will use afterwards, keep this thread's face values in registers
   double dvx[RF], dvy[RF];
@@ -140,6 +167,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     __syncthreads();
   }
 
+  STAMP(2);
   // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1)): one run of RF interfaces of one
   // column per thread, lanes along i
   if (tid < QW * GY) {
@@ -166,18 +194,34 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
   __syncthreads();
 
+  STAMP(3);
   // stage 2: q_i; and re-stage the corner cells of q for the x direction (copy_corners_x)
-  for (int e = tid; e < QW * TJ; e += 256) {
-    const int jj = e / QW, ii = e - jj * QW;
-    const int gi = ilo + ii, gj = j0 + jj;
-    double val = 0.0;
-    if ((!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je))) {
-      const unsigned c2 = OFF2(gi, gj);
-      const double y0 = LD(yfx, kb8 + c2), y1 = LD(yfx, kb8 + c2 + sj8);
-      const double a = LD(m.area, c2);
-      val = (sq[jj + 3][ii] * a + y0 * syin[jj][ii] - y1 * syin[jj + 1][ii]) / (a + y0 - y1);
+  {
+    constexpr int NE2 = (QW * TJ + 255) / 256;
+    double y0_[NE2], y1_[NE2], a_[NE2];
+#pragma unroll
+    for (int t = 0; t < NE2; ++t) {  // loads of all cells of this thread first ...
+      const int e = tid + 256 * t;
+      const int jj = e / QW, ii = e - jj * QW;
+      const int gi = ilo + ii, gj = j0 + jj;
+      const bool ok = e < QW * TJ && (!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je));
+      const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+      y0_[t] = LD(yfx, kb8 + c2);
+      y1_[t] = LD(yfx, kb8 + c2 + sj8);
+      a_[t] = LD(m.area, c2);
     }
-    sqi[jj][ii] = val;
+#pragma unroll
+    for (int t = 0; t < NE2; ++t) {  // ... then the arithmetic
+      const int e = tid + 256 * t;
+      const int jj = e / QW, ii = e - jj * QW;
+      const int gi = ilo + ii, gj = j0 + jj;
+      if (e < QW * TJ) {
+        const bool ok = (!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je));
+        const double y0 = y0_[t], y1 = y1_[t], a = a_[t];
+        const double val = (sq[jj + 3][ii] * a + y0 * syin[jj][ii] - y1 * syin[jj + 1][ii]) / (a + y0 - y1);
+        sqi[jj][ii] = ok ? val : 0.0;
+      }
+    }
   }
   {
     const bool icorner_tile = (i0 == g.is) || (i0 + TI + 3 > g.ie + 1);
@@ -197,6 +241,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
   __syncthreads();
 
+  STAMP(4);
   // stage 3: inner x sweep (XPiecewiseParabolic, origin (is, js-3), domain (N+1, N+7)): one run of RF interfaces of one
   // row per thread
   if (tid < QH * GX) {
@@ -226,21 +271,38 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
   __syncthreads();
 
+  STAMP(5);
   // stage 4: q_j
-  for (int e = tid; e < TI * QH; e += 256) {
-    const int jj = e / TI, ii = e - jj * TI;
-    const int gi = i0 + ii, gj = jlo + jj;
-    double val = 0.0;
-    if ((!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie))) {
-      const unsigned c2 = OFF2(gi, gj);
-      const double x0 = LD(xfx, kb8 + c2), x1 = LD(xfx, kb8 + c2 + 8);
-      const double a = LD(m.area, c2);
-      val = (sq[jj][ii + 3] * a + x0 * sxin[jj][ii] - x1 * sxin[jj][ii + 1]) / (a + x0 - x1);
+  {
+    constexpr int NE4 = (TI * QH + 255) / 256;
+    double x0_[NE4], x1_[NE4], a_[NE4];
+#pragma unroll
+    for (int t = 0; t < NE4; ++t) {
+      const int e = tid + 256 * t;
+      const int jj = e / TI, ii = e - jj * TI;
+      const int gi = i0 + ii, gj = jlo + jj;
+      const bool ok = e < TI * QH && (!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie));
+      const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+      x0_[t] = LD(xfx, kb8 + c2);
+      x1_[t] = LD(xfx, kb8 + c2 + 8);
+      a_[t] = LD(m.area, c2);
     }
-    sq[jj][ii + 3] = val;  // q_j in place: this thread is the only one that reads or writes this cell in this stage
+#pragma unroll
+    for (int t = 0; t < NE4; ++t) {
+      const int e = tid + 256 * t;
+      const int jj = e / TI, ii = e - jj * TI;
+      const int gi = i0 + ii, gj = jlo + jj;
+      if (e < TI * QH) {
+        const bool ok = (!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie));
+        const double x0 = x0_[t], x1 = x1_[t], a = a_[t];
+        const double val = (sq[jj][ii + 3] * a + x0 * sxin[jj][ii] - x1 * sxin[jj][ii + 1]) / (a + x0 - x1);
+        sq[jj][ii + 3] = ok ? val : 0.0;  // q_j in place: this thread is the only one that reads or writes this cell in this stage
+      }
+    }
   }
   __syncthreads();
 
+  STAMP(6);
   // stage 5: outer sweeps + final_fluxes (fvtp2d.py:80-119).  The grid has ceil(N / TI) x ceil(N / TJ) workgroups; the
   // N+1-th face row / column (ie+1, je+1) is produced by the workgroup that owns cell ie / je, not by an extra,
   // almost empty row of workgroups.
@@ -282,6 +344,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       }
     }
   }
+  STAMP(7);
   if (y5_on) {  // outer y on q_j: columns of the tile, runs of y-interfaces, lanes along i
     const int grp = y5_grp, ii = y5_col;
     const int jj0 = grp * RF;
@@ -318,6 +381,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       }
     }
   }
+  STAMP(8);
   if (EPI > 0) {
     // epilogue: put the face fluxes of the tile (both sides of every cell) into LDS, then update the cells
     constexpr int AXP = TI + 2, AYP = TI + 1;
@@ -348,15 +412,30 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       }
     }
     __syncthreads();
-    for (int e = tid; e < TI * TJ; e += 256) {
+    STAMP(9);
+    constexpr int NEC = (TI * TJ + 255) / 256;
+    double ra_[NEC], qv_[NEC], am_[NEC];
+#pragma unroll
+    for (int t = 0; t < NEC; ++t) {  // all loads first (see stage 0)
+      const int e = tid + 256 * t;
       const int jj = e / TI, ii = e - jj * TI;
       const int gi = i0 + ii, gj = j0 + jj;
-      if ((EX && gi > g.ie) || (EY && gj > g.je)) continue;
-      const unsigned c2 = OFF2(gi, gj);
-      const unsigned c = kb8 + c2;
-      const double ra = LD(m.rarea, c2);
-      const double qv = LD(q, c);  // (the LDS copy of q has become q_j)
-      ST(dp.qout, c) = qv * LD(dp.amass, c) + (ax[jj * AXP + ii] - ax[jj * AXP + ii + 1] + ay[jj * AYP + ii] - ay[(jj + 1) * AYP + ii]) * ra;
+      const bool ok = e < TI * TJ && !((EX && gi > g.ie) || (EY && gj > g.je));
+      const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+      ra_[t] = LD(m.rarea, c2);
+      qv_[t] = LD(q, kb8 + c2);  // (the LDS copy of q has become q_j)
+      am_[t] = LD(dp.amass, kb8 + c2);
+    }
+#pragma unroll
+    for (int t = 0; t < NEC; ++t) {
+      const int e = tid + 256 * t;
+      const int jj = e / TI, ii = e - jj * TI;
+      const int gi = i0 + ii, gj = j0 + jj;
+      if (e >= TI * TJ || (EX && gi > g.ie) || (EY && gj > g.je)) continue;
+      const unsigned c = kb8 + OFF2(gi, gj);
+      const double ra = ra_[t];
+      const double qv = qv_[t];
+      ST(dp.qout, c) = qv * am_[t] + (ax[jj * AXP + ii] - ax[jj * AXP + ii + 1] + ay[jj * AYP + ii] - ay[(jj + 1) * AYP + ii]) * ra;
       if (EPI == 2) {
         double hs = 0.0;
         if (dp.damp_w_k[k] > 1e-5) {
@@ -370,10 +449,11 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       }
     }
   }
+  STAMP(10);
 }
 
 template <int MORD, int DMODE, int EPI>
-__global__ void __launch_bounds__(256) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
+__global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
                                                 const double* __restrict__ crx, const double* __restrict__ cry,
                                                 const double* __restrict__ xfx, const double* __restrict__ yfx,
                                                 double* __restrict__ fx, double* __restrict__ fy,

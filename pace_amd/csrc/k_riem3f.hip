@@ -1,0 +1,542 @@
+// NonhydrostaticVerticalSolver / NonhydrostaticVerticalSolverCGrid (Fortran Riem_Solver3 / Riem_Solver_c with sim1_solver) as
+// ONE kernel, k-cooperative: SIXTEEN LANES PER COLUMN.
+// Reference: fv3core/pace/fv3core/stencils/riem_solver3.py:26-321, riem_solver_c.py:21-250, sim1_solver.py:20-141.
+//
+// Why (round-1 profile, C192 x 79): the five-kernel thread-per-column version moved 1.35 GB for 0.30 GB of algorithmic traffic
+// (28 field passes through six workspace fields in the tridiagonal kernel alone) at 0.56 waves per SIMD -- 36 864 columns are
+// not enough threads, and neither LDS (a [80][64] array of doubles is 40 KB) nor registers (six sweeps x 80 unrolled levels) can
+// hold a whole column per lane.  Here a column is spread over a 16-lane row of a wave, each lane owning L consecutive levels
+// (L = 5 for 79 levels); every intermediate of the column lives in the registers of those 16 lanes, nothing but the
+// operator's own inputs and outputs touches memory (15 field passes), and 16 x as many threads exist (590 k at C192).
+//
+// The vertical recurrences become lane-local sweeps over L levels plus a 4-step scan across the 16 lanes of the row:
+//   * prefix sums (interface pressures, perturbation pressure, the height rebuild): scan of additions;
+//   * Thomas elimination of the two tridiagonal systems: the pivots bet_k = D_k - S_k / bet_{k-1} are a Moebius recurrence
+//     (scan of 2 x 2 matrices, rescaled by a power of two at every product), the eliminated right-hand side
+//     y_k = (r_k - s_k y_{k-1}) / bet_k and both back-substitutions are affine recurrences (scan of (a, b) pairs);
+//   * p1_k = a_k - g_k p1_{k+1} (sim1_solver.py:118-132): affine, backwards.
+// A scan only delivers the value ENTERING a lane's block of levels; inside its block every lane then evaluates the
+// reference's own expressions level by level (with the pivot's reciprocal formed once per level and used as a factor where
+// the reference divides three times), so results differ from the sequential solver only through last-place roundings
+// (the systems are diagonally dominant: such perturbations decay).
+// The reference's bound for this operator is 5e-6 on every backend (overrides/standard.yaml:49-61); measured on MI355X
+// against the numpy oracle: see tests/opchain.py.
+//
+// Memory access: a wave holds 4 adjacent columns x 16 level blocks, a workgroup 16 adjacent columns = one 128 B line per level
+// row, so every line fetched is used completely by the workgroup (through the CU's vector L1 / the L2).
+#include "common.h"
+#include "kernels.h"
+
+#define RDGAS 287.05
+#define GRAV 9.80665
+#define RGRAV (1.0 / GRAV)
+#define CP_AIR 1004.6
+#define KAPPA (RDGAS / CP_AIR)
+#define ROW 16  // lanes per column
+
+namespace {
+
+// Value of the lane d places before (up) / after (dn) this one within its 16-lane row; a lane without such a neighbour keeps
+// its own value.  A row of the wave is exactly a DPP row, so these are two `v_mov_b32 ... row_shr:d / row_shl:d` each
+// (register-to-register, no LDS round trip as in ds_bpermute) -- the scans below are chains of 4-5 such steps.
+#ifdef PACE_EMU
+__device__ __forceinline__ double up(double v, int d) { return __shfl_up(v, (unsigned)d, ROW); }
+__device__ __forceinline__ double dn(double v, int d) { return __shfl_down(v, (unsigned)d, ROW); }
+#else
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  const int nlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)nhi << 32) | (long long)(unsigned)nlo);
+}
+__device__ __forceinline__ double up(double v, int d) {  // d is a compile-time constant after unrolling
+  switch (d) {
+    case 1: return dpp_move<0x111>(v);  // row_shr:1
+    case 2: return dpp_move<0x112>(v);
+    case 4: return dpp_move<0x114>(v);
+    default: return dpp_move<0x118>(v);
+  }
+}
+__device__ __forceinline__ double dn(double v, int d) {
+  switch (d) {
+    case 1: return dpp_move<0x101>(v);  // row_shl:1
+    case 2: return dpp_move<0x102>(v);
+    case 4: return dpp_move<0x104>(v);
+    default: return dpp_move<0x108>(v);
+  }
+}
+#endif
+
+// ---- scan of additions over the row: returns the sum of the values of the lanes BEFORE (fwd) / AFTER (bwd) this one ----
+__device__ __forceinline__ double excl_add_fwd(double v, int r) {
+#pragma unroll
+  for (int d = 1; d < ROW; d <<= 1) {
+    const double t = up(v, d);
+    if (r >= d) v = t + v;
+  }
+  const double e = up(v, 1);
+  return r == 0 ? 0.0 : e;
+}
+__device__ __forceinline__ double excl_add_bwd(double v, int r) {
+#pragma unroll
+  for (int d = 1; d < ROW; d <<= 1) {
+    const double t = dn(v, d);
+    if (r + d < ROW) v = t + v;
+  }
+  const double e = dn(v, 1);
+  return r == ROW - 1 ? 0.0 : e;
+}
+
+// ---- affine maps x -> a x + b ----
+struct Aff {
+  double a, b;
+};
+// then(first, second): apply `first`, then `second`
+__device__ __forceinline__ Aff then(const Aff& f, const Aff& s) { return Aff{s.a * f.a, s.a * f.b + s.b}; }
+// composition of the maps of all lanes before this one, in level order (identity for the first lane)
+__device__ __forceinline__ Aff excl_aff_fwd(Aff m, int r) {
+#pragma unroll
+  for (int d = 1; d < ROW; d <<= 1) {
+    const Aff t{up(m.a, d), up(m.b, d)};
+    if (r >= d) m = then(t, m);
+  }
+  const Aff e{up(m.a, 1), up(m.b, 1)};
+  return r == 0 ? Aff{1.0, 0.0} : e;
+}
+// composition of the maps of all lanes after this one, applied from the bottom upwards (identity for the last lane)
+__device__ __forceinline__ Aff excl_aff_bwd(Aff m, int r) {
+#pragma unroll
+  for (int d = 1; d < ROW; d <<= 1) {
+    const Aff t{dn(m.a, d), dn(m.b, d)};
+    if (r + d < ROW) m = then(t, m);
+  }
+  const Aff e{dn(m.a, 1), dn(m.b, 1)};
+  return r == ROW - 1 ? Aff{1.0, 0.0} : e;
+}
+
+// ---- Moebius maps x -> (a x + b) / (c x + d), as 2 x 2 matrices up to a factor ----
+struct Mob {
+  double a, b, c, d;
+};
+__device__ __forceinline__ Mob mob_then(const Mob& f, const Mob& s) {
+  Mob o{s.a * f.a + s.b * f.c, s.a * f.b + s.b * f.d, s.c * f.a + s.d * f.c, s.c * f.b + s.d * f.d};
+  // rescale by a power of two (exact): the pivots of 80 ... 128 levels multiply up to far beyond the double range otherwise
+  const double mx = fmax(fmax(fabs(o.a), fabs(o.b)), fmax(fabs(o.c), fabs(o.d)));
+  const int e = (mx > 0.0 && mx < 1.0e300) ? ilogb(mx) : 0;
+  o.a = ldexp(o.a, -e);
+  o.b = ldexp(o.b, -e);
+  o.c = ldexp(o.c, -e);
+  o.d = ldexp(o.d, -e);
+  return o;
+}
+__device__ __forceinline__ Mob excl_mob_fwd(Mob m, int r) {
+#pragma unroll
+  for (int d = 1; d < ROW; d <<= 1) {
+    const Mob t{up(m.a, d), up(m.b, d), up(m.c, d), up(m.d, d)};
+    if (r >= d) m = mob_then(t, m);
+  }
+  const Mob e{up(m.a, 1), up(m.b, 1), up(m.c, 1), up(m.d, 1)};
+  return r == 0 ? Mob{1.0, 0.0, 0.0, 1.0} : e;
+}
+
+}  // namespace
+
+// CG = 0: riem_solver3 on the compute domain.  CG = 1: riem_solver_c on compute +- 1 (w3 is not modified; outputs gz, pef).
+// L = levels per lane; 16 L >= km.
+template <int CG, int L>
+__global__ void __launch_bounds__(256)
+k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double peln1, double ptk,
+              const double* __restrict__ cappa, const double* __restrict__ zs, const double* __restrict__ ws,
+              const double* __restrict__ q_con, const double* __restrict__ delp, const double* __restrict__ pt,
+              double* __restrict__ delz, double* __restrict__ zh, double* __restrict__ pe, double* __restrict__ ppe,
+              double* __restrict__ pk3, double* __restrict__ pk, double* __restrict__ peln, double* __restrict__ w) {
+  const int r = threadIdx.x & (ROW - 1);   // level block of this lane
+  const int col = threadIdx.x >> 4;        // column within the workgroup
+  const int i = g.is - CG + blockIdx.x * 16 + col;
+  const int j = g.js - CG + blockIdx.y;
+  if (i > g.ie + CG) return;  // whole rows leave together: a row is one column
+  const int km = g.nk;
+  const long sk = g.sk;
+  const long c0 = IDX2(g, i, j);
+  const int k0 = r * L;
+  const double t1g = 2.0 * dt * dt, rdt = 1.0 / dt;
+#define AT(k) (c0 + (long)(k) * sk)
+#define LEV(t) (k0 + (t))
+#define ON(t) (LEV(t) < km)
+#define CL(k) ((k) < km ? (k) : km - 1)
+#define DM(x) (CG ? (x) / GRAV : (x) * RGRAV)
+
+  // ---------------- loads ----------------
+  double d_[L], qc_[L], ca_[L], pt_[L], w1_[L], zh_[L + 1];
+#pragma unroll
+  for (int t = 0; t < L; ++t) {
+    const long a = AT(CL(LEV(t)));
+    d_[t] = delp[a];
+    qc_[t] = q_con[a];
+    ca_[t] = cappa[a];
+    pt_[t] = pt[a];
+    w1_[t] = w[a];
+  }
+#pragma unroll
+  for (int t = 0; t <= L; ++t) zh_[t] = zh[AT(LEV(t) <= km ? LEV(t) : km)];
+
+  // ---------------- interface pressures (riem_solver3.py:63-81 / riem_solver_c.py:50-66) ----------------
+  double sp = 0.0, sg = 0.0;
+#pragma unroll
+  for (int t = 0; t < L; ++t)
+    if (ON(t)) {
+      sp = sp + d_[t];
+      sg = sg + d_[t] * (1.0 - qc_[t]);
+    }
+  double pem_[L + 1], pg_[L + 1];
+  pem_[0] = ptop + excl_add_fwd(sp, r);
+  pg_[0] = ptop + excl_add_fwd(sg, r);
+#pragma unroll
+  for (int t = 0; t < L; ++t) {
+    pem_[t + 1] = pem_[t] + d_[t];
+    pg_[t + 1] = pg_[t] + d_[t] * (1.0 - qc_[t]);
+  }
+
+  // ---------------- per-level quantities of precompute + the first statement of sim1_solver ----------------
+  double dm_[L], gm_[L], dz_[L], pm_[L], pe0_[L];
+  {
+    double lg_prev = CG ? 0.0 : ((LEV(0) == 0) ? peln1 : log(pg_[0]));  // (riem_solver_c takes the log of the ratio instead)
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      dm_[t] = DM(d_[t]);
+      gm_[t] = 1.0 / (1.0 - ca_[t]);
+      dz_[t] = zh_[t + 1] - zh_[t];
+      if (CG) {
+        pm_[t] = (pg_[t + 1] - pg_[t]) / log(pg_[t + 1] / pg_[t]);
+      } else {
+        const double lg = log(pg_[t + 1]);
+        pm_[t] = (pg_[t + 1] - pg_[t]) / (lg - lg_prev);
+        lg_prev = lg;
+      }
+      pe0_[t] = exp(gm_[t] * log(-dm_[t] / dz_[t] * RDGAS * pt_[t])) - pm_[t];
+    }
+  }
+  if (!CG) {
+    // pk3 = p_interface ** kappa, and on the last call peln = log p_interface, pk, pe (riem_solver3.py:66-76,136-141).
+    // A lane writes the interfaces above its own levels; the lane that owns level km - 1 also writes interface km.
+#pragma unroll
+    for (int t = 0; t <= L; ++t) {
+      const int k = LEV(t);
+      const bool mine = (t < L) ? (k < km) : false;
+      const bool bottom = (t >= 1) && (LEV(t - 1) == km - 1);
+      if (mine || bottom) {
+        double logp, pk3v;
+        if (k == 0) {
+          logp = peln1;
+          pk3v = ptk;
+        } else {
+          logp = log(pem_[t]);
+          pk3v = exp(KAPPA * logp);
+        }
+        pk3[AT(k)] = pk3v;
+        if (last_call) {
+          peln[AT(k)] = logp;
+          pk[AT(k)] = pk3v;
+          pe[AT(k)] = pem_[t];
+        }
+      }
+    }
+  }
+
+  // neighbours' edge values
+  const double dm_next = dn(dm_[0], 1);    // dm of the level after this block
+  const double pe0_next = dn(pe0_[0], 1);
+  const double gm_prev = up(gm_[L - 1], 1);
+  const double dz_prev = up(dz_[L - 1], 1);
+
+  // ---------------- system 1: pp on interfaces 1 .. km (sim1_solver.py:76-98) ----------------
+  // row k: pp_k + bb_k pp_{k+1} + g_k pp_{k+2} = dd_k, g_k = dm_k / dm_{k+1} (0 in the last row), bb_k = 2 (1 + g_k)
+  double g_[L], bb_[L], dd_[L];
+#pragma unroll
+  for (int t = 0; t < L; ++t) {
+    const double dmn = (t + 1 < L) ? dm_[t + 1] : dm_next;
+    const double pen = (t + 1 < L) ? pe0_[t + 1] : pe0_next;
+    if (LEV(t) < km - 1) {
+      g_[t] = dm_[t] / dmn;
+      bb_[t] = 2.0 * (1.0 + g_[t]);
+      dd_[t] = 3.0 * (pe0_[t] + g_[t] * pen);
+    } else {
+      g_[t] = 0.0;
+      bb_[t] = 2.0;
+      dd_[t] = 3.0 * pe0_[t];
+    }
+  }
+  const double g_before = up(g_[L - 1], 1);  // g of the level before this block
+  double gam_[L], x_[L];                      // gam_k (k >= 1) and, at the end, pp_{k+1}
+  {
+    // pivots: bet_0 = bb_0, bet_k = bb_k - g_{k-1} / bet_{k-1}
+    Mob P{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      if (!ON(t)) continue;
+      const double gp = (t == 0) ? g_before : g_[t - 1];
+      const Mob Mk = (LEV(t) == 0) ? Mob{0.0, bb_[t], 0.0, 1.0} : Mob{bb_[t], -gp, 1.0, 0.0};
+      P = mob_then(P, Mk);
+    }
+    const Mob E = excl_mob_fwd(P, r);
+    // (one division per level: the reciprocal pivot; products with it replace the reference's divisions by the pivot, a
+    // last-place difference)
+    double rb = (E.c + E.d) / (E.a + E.b);  // 1 / bet of the level before this block: the map applied to 1 (its argument
+                                            // is irrelevant: level 0 is a constant map)
+    double rb_[L];
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      if (LEV(t) == 0) {
+        gam_[t] = 0.0;
+        rb = 1.0 / bb_[t];
+      } else {
+        const double gp = (t == 0) ? g_before : g_[t - 1];
+        gam_[t] = gp * rb;
+        rb = 1.0 / (bb_[t] - gam_[t]);
+      }
+      rb_[t] = rb;
+    }
+    // y_k = (dd_k - y_{k-1}) / bet_k, y_0 = dd_0 / bet_0
+    Aff A{1.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      if (!ON(t)) continue;
+      A = then(A, Aff{LEV(t) == 0 ? 0.0 : -rb_[t], dd_[t] * rb_[t]});
+    }
+    const Aff EA = excl_aff_fwd(A, r);
+    double y = EA.b;  // applied to y_{-1} = 0
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      y = (LEV(t) == 0) ? dd_[t] * rb_[t] : (dd_[t] - y) * rb_[t];
+      x_[t] = y;
+    }
+    // back substitution: pp_{k+1} = y_k - gam_{k+1} pp_{k+2}; the last row keeps y
+    const double gam_after = dn(gam_[0], 1);
+    Aff B{1.0, 0.0};
+#pragma unroll
+    for (int t = L - 1; t >= 0; --t) {
+      if (!ON(t)) continue;
+      const double gn = (t + 1 < L) ? gam_[t + 1] : gam_after;
+      B = then(B, Aff{LEV(t) == km - 1 ? 0.0 : -gn, x_[t]});
+    }
+    const Aff EB = excl_aff_bwd(B, r);
+    double xn = EB.b;  // applied to 0
+#pragma unroll
+    for (int t = L - 1; t >= 0; --t) {
+      if (!ON(t)) continue;
+      const double gn = (t + 1 < L) ? gam_[t + 1] : gam_after;
+      xn = (LEV(t) == km - 1) ? x_[t] : x_[t] - gn * xn;
+      x_[t] = xn;
+    }
+  }
+  // pp on the interfaces of this block: ppi_[t] = pp_{k0+t}
+  double ppi_[L + 1];
+  {
+    const double before = up(x_[L - 1], 1);
+    ppi_[0] = (r == 0) ? 0.0 : before;
+#pragma unroll
+    for (int t = 0; t < L; ++t) ppi_[t + 1] = x_[t];
+  }
+
+  // ---------------- aa on interfaces 1 .. km-1 (sim1_solver.py:92-98) ----------------
+  double aa_[L + 1];
+#pragma unroll
+  for (int t = 0; t < L; ++t) {
+    const double gmp = (t == 0) ? gm_prev : gm_[t - 1];
+    const double dzp = (t == 0) ? dz_prev : dz_[t - 1];
+    aa_[t] = (LEV(t) >= 1 && LEV(t) <= km - 1) ? t1g * 0.5 * (gmp + gm_[t]) / (dzp + dz_[t]) * (pem_[t] + ppi_[t]) : 0.0;
+  }
+  aa_[L] = dn(aa_[0], 1);
+
+  // ---------------- system 2: w (sim1_solver.py:99-117) ----------------
+  double wn_[L];
+  {
+    const double wsv = ws[c0];
+    // the surface term replaces aa_{k+1} in the last row
+    double p1s_[L];
+#pragma unroll
+    for (int t = 0; t < L; ++t)
+      p1s_[t] = (LEV(t) == km - 1) ? t1g * gm_[t] / dz_[t] * (pem_[t + 1] + ppi_[t + 1]) : aa_[t + 1];
+    Mob P{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      if (!ON(t)) continue;
+      const double diag = dm_[t] - (aa_[t] + p1s_[t]);
+      const Mob Mk = (LEV(t) == 0) ? Mob{0.0, diag, 0.0, 1.0} : Mob{diag, -(aa_[t] * aa_[t]), 1.0, 0.0};
+      P = mob_then(P, Mk);
+    }
+    const Mob E = excl_mob_fwd(P, r);
+    double rb = (E.c + E.d) / (E.a + E.b);
+    double rb_[L], gam2_[L], rhs_[L];
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      if (LEV(t) == 0) {
+        gam2_[t] = 0.0;
+        rb = 1.0 / (dm_[t] - aa_[t + 1]);
+        rhs_[t] = dm_[t] * w1_[t] + dt * ppi_[t + 1];
+      } else {
+        gam2_[t] = aa_[t] * rb;
+        rb = 1.0 / (dm_[t] - (aa_[t] + p1s_[t] + aa_[t] * gam2_[t]));
+        rhs_[t] = (LEV(t) == km - 1) ? dm_[t] * w1_[t] + dt * (ppi_[t + 1] - ppi_[t]) - p1s_[t] * wsv
+                                     : dm_[t] * w1_[t] + dt * (ppi_[t + 1] - ppi_[t]);
+      }
+      rb_[t] = rb;
+    }
+    Aff A{1.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      if (!ON(t)) continue;
+      A = then(A, Aff{LEV(t) == 0 ? 0.0 : -aa_[t] * rb_[t], rhs_[t] * rb_[t]});
+    }
+    const Aff EA = excl_aff_fwd(A, r);
+    double y = EA.b;
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      y = (LEV(t) == 0) ? rhs_[t] * rb_[t] : (rhs_[t] - aa_[t] * y) * rb_[t];
+      wn_[t] = y;
+    }
+    const double gam_after = dn(gam2_[0], 1);
+    Aff B{1.0, 0.0};
+#pragma unroll
+    for (int t = L - 1; t >= 0; --t) {
+      if (!ON(t)) continue;
+      const double gn = (t + 1 < L) ? gam2_[t + 1] : gam_after;
+      B = then(B, Aff{LEV(t) == km - 1 ? 0.0 : -gn, wn_[t]});
+    }
+    const Aff EB = excl_aff_bwd(B, r);
+    double xn = EB.b;
+#pragma unroll
+    for (int t = L - 1; t >= 0; --t) {
+      if (!ON(t)) continue;
+      const double gn = (t + 1 < L) ? gam2_[t + 1] : gam_after;
+      xn = (LEV(t) == km - 1) ? wn_[t] : wn_[t] - gn * xn;
+      wn_[t] = xn;
+    }
+  }
+
+  // ---------------- perturbation pressure on interfaces (sim1_solver.py:112-117) ----------------
+  double pei_[L + 2];
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < L; ++t)
+      if (ON(t)) s = s + dm_[t] * (wn_[t] - w1_[t]) * rdt;
+    pei_[0] = excl_add_fwd(s, r);
+#pragma unroll
+    for (int t = 0; t < L; ++t) pei_[t + 1] = ON(t) ? pei_[t] + dm_[t] * (wn_[t] - w1_[t]) * rdt : pei_[t];
+    pei_[L + 1] = dn(pei_[1], 1);
+  }
+
+  // ---------------- p1 (sim1_solver.py:118-132), backwards ----------------
+  double p1_[L];
+  {
+    double a_[L];
+    Aff B{1.0, 0.0};
+#pragma unroll
+    for (int t = L - 1; t >= 0; --t) {
+      if (!ON(t)) continue;
+      if (LEV(t) == km - 1) {
+        a_[t] = (pei_[t] + 2.0 * pei_[t + 1]) * 1.0 / 3.0;
+        B = then(B, Aff{0.0, a_[t]});
+      } else {
+        a_[t] = (pei_[t] + bb_[t] * pei_[t + 1] + g_[t] * pei_[t + 2]) * 1.0 / 3.0;
+        B = then(B, Aff{-g_[t], a_[t]});
+      }
+    }
+    const Aff EB = excl_aff_bwd(B, r);
+    double pn = EB.b;
+#pragma unroll
+    for (int t = L - 1; t >= 0; --t) {
+      if (!ON(t)) continue;
+      pn = (LEV(t) == km - 1) ? a_[t] : a_[t] - g_[t] * pn;
+      p1_[t] = pn;
+    }
+  }
+
+  // ---------------- new layer thickness (sim1_solver.py:133-141) and the height rebuild ----------------
+  double dzn_[L];
+  double sdz = 0.0;
+#pragma unroll
+  for (int t = 0; t < L; ++t) {
+    // NB: the reference tests p_fac * delta_mass (sim1_solver.py:134), kept as is
+    const double maxp = (p_fac * dm_[t] > p1_[t] + pm_[t]) ? p_fac * pm_[t] : p1_[t] + pm_[t];
+    dzn_[t] = -dm_[t] * RDGAS * pt_[t] * exp((ca_[t] - 1.0) * log(maxp));
+    if (ON(t)) sdz = sdz + (CG ? dzn_[t] * GRAV : dzn_[t]);
+  }
+  {
+    // zh_km = zs, zh_k = zh_{k+1} - delz_k (riem_solver3.py:142-145); gz_km = hs, gz_k = gz_{k+1} - dz_k g (riem_solver_c.py:117-123)
+    double z = zs[c0] - excl_add_bwd(sdz, r);  // height of the interface below this block
+    // (interface km is written by the lane whose block ends with level km - 1 or, if km is a multiple of L, by nobody else)
+#pragma unroll
+    for (int t = L - 1; t >= 0; --t) {
+      if (!ON(t)) continue;
+      if (LEV(t) == km - 1) zh[AT(km)] = z;
+      z = z - (CG ? dzn_[t] * GRAV : dzn_[t]);
+      zh[AT(LEV(t))] = z;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < L; ++t) {
+    if (!ON(t)) continue;
+    const long a = AT(LEV(t));
+    if (CG) {
+      // finalize (riem_solver_c.py:91-116): pef = pe + pem below the top
+      ppe[a] = (LEV(t) == 0) ? ptop : pei_[t] + pem_[t];
+      if (LEV(t) == km - 1) ppe[AT(km)] = pei_[t + 1] + pem_[t + 1];
+    } else {
+      delz[a] = dzn_[t];
+      w[a] = wn_[t];
+      ppe[a] = pei_[t];
+      if (LEV(t) == km - 1) ppe[AT(km)] = pei_[t + 1];
+    }
+  }
+#undef AT
+#undef LEV
+#undef ON
+#undef CL
+#undef DM
+}
+
+template <int CG>
+static int launch_column(const Geo& g, int last_call, double dt, double ptop, double p_fac, const double* cappa, const double* zs,
+                         const double* ws, const double* q_con, const double* delp, const double* pt, double* delz, double* zh,
+                         double* pe, double* ppe, double* pk3, double* pk, double* peln, double* w, hipStream_t st) {
+  const double peln1 = log(ptop);
+  const double ptk = exp(KAPPA * peln1);
+  const int ncol = g.n + 2 * CG;
+  const dim3 grid((ncol + 15) / 16, ncol), block(256);
+#define GO(L)                                                                                                                  \
+  hipLaunchKernelGGL((k_riem_column<CG, L>), grid, block, 0, st, g, last_call, dt, ptop, p_fac, peln1, ptk, cappa, zs, ws, q_con, \
+                     delp, pt, delz, zh, pe, ppe, pk3, pk, peln, w)
+  const int km = g.nk;
+  if (km < 2) return PACE_ERR_UNSUPPORTED;
+  if (km <= 16 * 2) GO(2);
+  else if (km <= 16 * 4) GO(4);
+  else if (km <= 16 * 5) GO(5);
+  else if (km <= 16 * 6) GO(6);
+  else if (km <= 16 * 8) GO(8);
+  else return PACE_ERR_UNSUPPORTED;
+#undef GO
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
+// the column solvers accept up to 128 layers in this form (the thread-per-column kernels of k_riem3.hip serve beyond that)
+bool riem_column_supported(const Geo& g) { return g.nk >= 2 && g.nk <= 128; }
+
+int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const double* cappa, double ptop, const double* zs,
+                               const double* wsd, double* delz, const double* q_con, const double* delp, const double* pt,
+                               double* zh, double* pe, double* ppe, double* pk3, double* pk, double* peln, double* w,
+                               double p_fac, hipStream_t st) {
+  return launch_column<0>(g, last_call, dt, ptop, p_fac, cappa, zs, wsd, q_con, delp, pt, delz, zh, pe, ppe, pk3, pk, peln, w, st);
+}
+
+int launch_riem_solver_c_column(const Geo& g, double dt2, const double* cappa, double ptop, const double* hs, const double* ws3,
+                                const double* ptc, const double* q_con, const double* delpc, double* gz, double* pef,
+                                const double* w3, double p_fac, hipStream_t st) {
+  // the C-grid solver does not return w: the kernel reads w3 and writes nothing back (CG = 1 stores only gz and pef)
+  return launch_column<1>(g, 0, dt2, ptop, p_fac, cappa, hs, ws3, q_con, delpc, ptc, nullptr, gz, nullptr, pef, nullptr, nullptr,
+                          nullptr, const_cast<double*>(w3), st);
+}

@@ -55,6 +55,15 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
                         const double* zs, const double* wsd, double* delz, const double* q_con, const double* delp,
                         const double* pt, double* zh, double* pe, double* ppe, double* pk3, double* pk, double* peln,
                         double* w, double p_fac, hipStream_t st);
+// k_riem3f.hip: both column solvers as one k-cooperative kernel (16 lanes per column), no workspace
+bool riem_column_supported(const Geo& g);
+int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const double* cappa, double ptop, const double* zs,
+                               const double* wsd, double* delz, const double* q_con, const double* delp, const double* pt,
+                               double* zh, double* pe, double* ppe, double* pk3, double* pk, double* peln, double* w,
+                               double p_fac, hipStream_t st);
+int launch_riem_solver_c_column(const Geo& g, double dt2, const double* cappa, double ptop, const double* hs, const double* ws3,
+                                const double* ptc, const double* q_con, const double* delpc, double* gz, double* pef,
+                                const double* w3, double p_fac, hipStream_t st);
 // k_csw.hip
 int64_t csw_workspace_bytes(const Geo& g);
 int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, double* uc, double* vc, const double* u, const double* v,

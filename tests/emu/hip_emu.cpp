@@ -34,6 +34,20 @@ void __syncthreads() {
   swapcontext(&g_cur->ctx, &g_main);
 }
 
+namespace {
+unsigned char g_shfl[1024][16];
+}
+
+void emu_shuffle_exchange(const void* mine, void* out, int src_lane_in_wave, int nbytes) {
+  if (g_plain) throw NeedsFibers();
+  const unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  const unsigned wave_base = tid & ~63u;
+  __builtin_memcpy(g_shfl[tid], mine, (size_t)nbytes);
+  swapcontext(&g_cur->ctx, &g_main);  // every lane has deposited
+  __builtin_memcpy(out, g_shfl[wave_base + (unsigned)src_lane_in_wave], (size_t)nbytes);
+  swapcontext(&g_cur->ctx, &g_main);  // every lane has read
+}
+
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode) {
   // one launch at a time: the scheduler state is global (several tile threads may call into the library)
   static std::mutex mu;

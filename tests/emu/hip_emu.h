@@ -54,5 +54,32 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* m
     emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); }, &emu_mode__);   \
   } while (0)
 
+// Wave shuffles (wave = 64 consecutive threads of the block, `width`-lane groups as in HIP): every lane deposits its value,
+// all fibers are switched once, every lane reads its source lane's deposit, all fibers are switched again (so that the
+// next shuffle cannot overwrite a deposit that has not been read yet).  Needs fibers, like __syncthreads().
+void emu_shuffle_exchange(const void* mine, void* out, int src_lane_in_wave, int nbytes);
+template <class T>
+static inline T emu_shfl_from(T v, int src) {
+  T out;
+  emu_shuffle_exchange(&v, &out, src, (int)sizeof(T));
+  return out;
+}
+static inline int emu_lane() { return (int)((threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63u); }
+template <class T>
+static inline T __shfl_up(T v, unsigned d, int width = 64) {
+  const int lane = emu_lane(), idx = lane % width;
+  return emu_shfl_from(v, idx >= (int)d ? lane - (int)d : lane);
+}
+template <class T>
+static inline T __shfl_down(T v, unsigned d, int width = 64) {
+  const int lane = emu_lane(), idx = lane % width;
+  return emu_shfl_from(v, idx + (int)d < width ? lane + (int)d : lane);
+}
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+  const int lane = emu_lane();
+  return emu_shfl_from(v, (lane / width) * width + (src % width));
+}
+
 using std::exp; using std::log; using std::sqrt; using std::fabs; using std::fmin; using std::fmax;
 using std::sin; using std::cos; using std::asin; using std::pow;

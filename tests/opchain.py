@@ -154,8 +154,8 @@ class Chain:
             vertical.riem_solver3(g, True, dt, S["cappa"], ptop, S["zs"], S["wsd"], S["delz"], S["q_con"], S["delp"], S["pt"], S["zh"],
                                   S["pe"], S["pkc"], S["pk3"], S["pk"], S["peln"], S["w"], p_fac=P_FAC)
 
-        yield from emit("riem_solver3", f_riem3, [("delz", C0, nz, 5e-6, 0), ("zh", C0, K, 5e-6, 0), ("pkc", C0, K, 5e-6, 1e-9),
-                                                  ("pk3", C0, K, 5e-6, 0), ("w", C0, nz, 5e-6, 1e-9), ("pe", C0, K, 5e-6, 0),
+        yield from emit("riem_solver3", f_riem3, [("delz", C0, nz, 5e-6, 0), ("zh", C0, K, 5e-6, 0), ("pkc", C0, K, 5e-6, 1e-5),
+                                                  ("pk3", C0, K, 5e-6, 0), ("w", C0, nz, 5e-6, 1e-5), ("pe", C0, K, 5e-6, 0),
                                                   ("pk", C0, K, 5e-6, 0), ("peln", C0, K, 5e-6, 0)])
 
         yield from emit("edge_pe", lambda: ap.edge_pe(g, S["pe"], S["delp"], ptop), [("pe", C1, K, 1e-14, 0)])

@@ -103,8 +103,12 @@ def test_d_sw_and_riem3_match_oracle(lib, n):
     for k in ("delz", "zh", "ppe", "pk3", "w"):
         nk = nz if k in ("delz", "w") else nz + 1
         scale = float(np.abs(b[k][window(n, 0, 0, nk)]).max())
-        err = compare(b[k][window(n, 0, 0, nk)], got[k][window(n, 0, 0, nk)], near_zero=1e-9 * scale)
+        # The reference's metric is relative (5e-6, overrides/standard.yaml:49-61); the perturbation pressure and w of this
+        # synthetic state cross zero, where a relative metric is meaningless: values below 1e-5 of the field's magnitude are
+        # exempt (measured absolute errors are < 1e-11 of the magnitude for both, tools/riem_check.py)
+        err = compare(b[k][window(n, 0, 0, nk)], got[k][window(n, 0, 0, nk)], near_zero=(1e-5 if k in ("ppe", "w") else 1e-9) * scale)
         assert err < 5e-6, (k, err)
+        assert float(np.abs(b[k][window(n, 0, 0, nk)] - got[k][window(n, 0, 0, nk)]).max()) < 1e-10 * scale, k
 
 
 def test_c192_properties(lib):
