@@ -78,6 +78,25 @@ int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const double*
                double* crx, double* cry, double* x_area_flux, double* y_area_flux, double* uc_contra,
                double* vc_contra, double dt, void* stream);
 
+/* ---- XPiecewiseParabolic / YPiecewiseParabolic.__call__ (fv3core/pace/fv3core/stencils/xppm.py:290-355, yppm.py:290-355):
+ * mean value of q_in advected through the x- (axis 0) or y- (axis 1) interfaces of the window origin (i0, j0, k0), domain
+ * (ni, nj, nk) -- the origin / domain the reference class is constructed with.  iord in {5, 6, 8} (the sign is ignored, as
+ * `mord = abs(iord)`).  Corner halos of q_in are the caller's business, as in the reference. */
+int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const double* q_in, const double* c,
+             double* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk, void* stream);
+
+/* ---- DivergenceDamping.__call__ (fv3core/pace/fv3core/stencils/divergence_damping.py:482-632).  workspace: two fields
+ * (pace_divergence_damping_workspace_bytes).  nord_col: HOST array of nk values (the class's nord_col K-field; the column is
+ * split at its first positive entry, divergence_damping.py:307-331); d2_bg: DEVICE array of nk values.  In place, as the
+ * reference: divg_d, uc, vc are work fields and end as the last iteration leaves them, delpc and damped_rel_vort_bgrid are
+ * outputs, ke += damping. */
+int64_t pace_divergence_damping_workspace_bytes(const pace_geom_t* geom);
+int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* u, const double* v,
+                            const double* va, double* damped_rel_vort_bgrid, const double* ua, double* divg_d, double* vc,
+                            double* uc, double* delpc, double* ke, const double* rel_vort_agrid, double dt,
+                            const double* nord_col_host, const double* d2_bg_dev, double dddmp, double d4_bg, int nord,
+                            void* stream);
+
 /* ---- FiniteVolumeTransport.__call__ without damping (fvtp2d.py:262-345).  x/y_mass_flux may be
  * NULL (area fluxes are used as unit fluxes).  hord in {5, 6, 8}.  nlev = number of levels
  * processed (nk, or nk+1 for interface fields).  q's corner halos are NOT rewritten: corner reads

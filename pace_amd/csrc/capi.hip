@@ -105,6 +105,44 @@ int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, double* qi
   return launch_a2b_ord4(make_geo(geom), *met, qin, qout, k0, k1, replace, S(stream));
 }
 
+int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const double* q_in, const double* c,
+             double* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk, void* stream) {
+  NEED(geom && met && q_in && c && q_mean_advected);
+  if (axis < 0 || axis > 1 || ni < 1 || nj < 1 || nk < 1 || k0 < 0 || k0 + nk > geom->nk + 1) return PACE_ERR_ARG;
+  // the window must leave the three cells an interface needs on either side inside the storage
+  const int lo_i = axis == 0 ? 3 : 0, lo_j = axis == 1 ? 3 : 0;
+  if (i0 < lo_i || j0 < lo_j || i0 + ni > geom->n + 7 - (axis == 0 ? 2 : 0) || j0 + nj > geom->n + 7 - (axis == 1 ? 2 : 0))
+    return PACE_ERR_ARG;
+  return launch_ppm1d(make_geo(geom), *met, axis, iord, q_in, c, q_mean_advected, i0, j0, k0, ni, nj, nk, S(stream));
+}
+
+int64_t pace_divergence_damping_workspace_bytes(const pace_geom_t* geom) {
+  return geom ? (int64_t)2 * geom->sk * (geom->nk + 1) * (int64_t)sizeof(double) : 0;
+}
+
+int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* u, const double* v,
+                            const double* va, double* damped_rel_vort_bgrid, const double* ua, double* divg_d, double* vc,
+                            double* uc, double* delpc, double* ke, const double* rel_vort_agrid, double dt,
+                            const double* nord_col_host, const double* d2_bg_dev, double dddmp, double d4_bg, int nord,
+                            void* stream) {
+  NEED(geom && met && workspace && u && v && va && damped_rel_vort_bgrid && ua && divg_d && vc && uc && delpc && ke);
+  NEED(rel_vort_agrid && nord_col_host && d2_bg_dev);
+  const Geo g = make_geo(geom);
+  // the column is split at the first level with nord > 0 (divergence_damping.py:307-331)
+  int kstart = 0, nonzero_nord = nord;
+  for (int k = 0; k < g.nk; ++k)
+    if (nord_col_host[k] > 0) {
+      kstart = k;
+      nonzero_nord = (int)nord_col_host[k];
+      break;
+    }
+  if (nonzero_nord < 0 || nonzero_nord > 3) return PACE_ERR_UNSUPPORTED;
+  double* da = (double*)workspace;
+  double* db = da + (long)g.sk * (g.nk + 1);
+  return launch_divergence_damping(g, *met, u, v, va, damped_rel_vort_bgrid, ua, divg_d, vc, uc, delpc, ke, rel_vort_agrid, dt,
+                                   d2_bg_dev, kstart, nonzero_nord, dddmp, d4_bg, da, db, S(stream));
+}
+
 int64_t pace_d_sw_workspace_bytes(const pace_geom_t* geom) { return geom ? dsw_workspace_bytes(make_geo(geom)) : 0; }
 
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream) {

@@ -598,6 +598,40 @@ int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k
   return PACE_OK;
 }
 
+// DivergenceDamping.__call__ (divergence_damping.py:482-632): second-order damping on the levels above `kstart` (the sponge
+// layers, nord = 0 there), `nonzero_nord` iterations of the divergence of the gradient of the divergence below, then
+// a2b_ord4 of the relative vorticity, the Smagorinsky term and the damped vorticity; ke += damping.  uc, vc and divg_d end as
+// the reference leaves them (the last iteration's work values on the staggered compute windows).  da / db: two scratch fields.
+int launch_divergence_damping(const Geo& g, const Met& m, const double* u, const double* v, const double* va, double* vort_b,
+                              const double* ua, double* divg_d, double* vc, double* uc, double* delpc, double* ke,
+                              const double* rel_vort_agrid, double dt, const double* d2_bg_dev, int kstart, int nonzero_nord,
+                              double dddmp, double d4_bg, double* da, double* db, hipStream_t st) {
+  const int nk = g.nk;
+  if (kstart > 0) {
+    hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
+                       d2_bg_dev, dddmp, dt);
+  }
+  const int nhigh = nk - kstart;
+  if (nhigh > 0) {
+    const double* src = divg_d;
+    double* bufs[2] = {da, db};
+    for (int n = 0; n < nonzero_nord; ++n) {
+      const int nt = nonzero_nord - (n + 1);
+      const int fill = (n + 1 != nonzero_nord) ? 1 : 0;
+      double* dst = bufs[n & 1];
+      const bool last = (n + 1 == nonzero_nord);  // nt == 0: its region is exactly the (n+1) x (n+1) corner points
+      launch_divdamp_iter(g, m, src, dst, kstart, nhigh, nt, fill, last ? uc : nullptr, last ? vc : nullptr, st);
+      src = dst;
+    }
+    const double dd8 = pow(m.da_min_c * d4_bg, (double)(nonzero_nord + 1));
+    const Regions r = a2b_regions(g);
+    hipLaunchKernelGGL(k_divdamp_high_final, regions_grid(r, nhigh), dim3(64, 4), 0, st, g, m, rel_vort_agrid, divg_d, divg_d,
+                       delpc, src, vort_b, ke, d2_bg_dev, dddmp, dd8, fabs(dt), kstart, r);
+  }
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+}
+
 struct DswWork {
   double *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv;
   double* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
@@ -716,27 +750,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
   // divergence damping
-  if (kstart > 0) {
-    hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), block, 0, st, g, m, u, v, ua, va, uc, vc, delpc, W.vort_b, W.ke,
-                       d_d2, cfg->dddmp, dt);
-  }
-  {
-    const int nhigh = nk - kstart;
-    const double* src = divgd;
-    double* bufs[2] = {W.da, W.db};
-    for (int n = 0; n < nonzero_nord; ++n) {
-      const int nt = nonzero_nord - (n + 1);
-      const int fill = (n + 1 != nonzero_nord) ? 1 : 0;
-      double* dst = bufs[n & 1];
-      const bool last = (n + 1 == nonzero_nord);  // nt == 0: its region is exactly the (n+1) x (n+1) corner points
-      launch_divdamp_iter(g, m, src, dst, kstart, nhigh, nt, fill, last ? uc : nullptr, last ? vc : nullptr, st);
-      src = dst;
-    }
-    const double dd8 = pow(m.da_min_c * cfg->d4_bg, (double)(nonzero_nord + 1));
-    const Regions r = a2b_regions(g);
-    hipLaunchKernelGGL(k_divdamp_high_final, regions_grid(r, nhigh), dim3(64, 4), 0, st, g, m, W.wk, divgd, divgd, delpc, src, W.vort_b,
-                       W.ke, d_d2, cfg->dddmp, dd8, fabs(dt), kstart, r);
-  }
+  launch_divergence_damping(g, m, u, v, va, W.vort_b, ua, divgd, vc, uc, delpc, W.ke, W.wk, dt, d_d2, kstart, nonzero_nord,
+                            cfg->dddmp, cfg->d4_bg, W.da, W.db, st);
   // vorticity transport
   // vorticity: transport of the absolute vorticity (wk + fC_agrid) -> W.fy2, W.fyv (own flux buffers: the mass fluxes
   // in W.fx / W.fy may still be in use by phase 2 on another stream) and the del-n damping fluxes of the relative

@@ -55,6 +55,14 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
                         const double* zs, const double* wsd, double* delz, const double* q_con, const double* delp,
                         const double* pt, double* zh, double* pe, double* ppe, double* pk3, double* pk, double* peln,
                         double* w, double p_fac, hipStream_t st);
+// k_ppm.hip: XPiecewiseParabolic / YPiecewiseParabolic on a window (axis 0 = x, 1 = y)
+int launch_ppm1d(const Geo& g, const Met& m, int axis, int iord, const double* q, const double* c, double* out, int i0, int j0,
+                 int k0, int ni, int nj, int nk, hipStream_t st);
+// k_dsw.hip: DivergenceDamping.__call__
+int launch_divergence_damping(const Geo& g, const Met& m, const double* u, const double* v, const double* va, double* vort_b,
+                              const double* ua, double* divg_d, double* vc, double* uc, double* delpc, double* ke,
+                              const double* rel_vort_agrid, double dt, const double* d2_bg_dev, int kstart, int nonzero_nord,
+                              double dddmp, double d4_bg, double* da, double* db, hipStream_t st);
 // k_riem3f.hip: both column solvers as one k-cooperative kernel (16 lanes per column), no workspace
 bool riem_column_supported(const Geo& g);
 int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const double* cappa, double ptop, const double* zs,

@@ -9,6 +9,9 @@ from .stencil import (  # noqa: F401
 )
 
 
+from . import device_stencils  # noqa: F401,E402  (fills the registry)
+
+
 def orchestrate(*args, **kwargs):
     """No-op: the reference's DaCe whole-program orchestration hook (dsl/pace/dsl/dace/orchestration.py:439)."""
     return None

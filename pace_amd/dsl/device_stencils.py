@@ -1,0 +1,166 @@
+"""Per-stencil device implementations behind ``FrozenStencil`` (the L3 boundary, dsl/pace/dsl/stencil.py:395-434).
+
+A ``FrozenStencil`` here is a lookup of the stencil's identity in this registry, not a compilation.  Registered are the
+definition functions of the acoustic path that are launched as stencils of their own by the reference's classes and tests
+and whose semantics one device entry point provides:
+
+* the dyn_core one-liners (``zero_data``, ``gz_from_surface_height_and_thicknesses``,
+  ``interface_pressure_from_toa_pressure_and_thickness``, ``compute_geopotential``, ``p_grad_c_stencil``), ``copy_defn``,
+  ``edge_pe``, ``apply_diffusive_heating`` -- each kernel implements the ONE launch window the reference constructs the stencil
+  with (dyn_core.py:480-587); a FrozenStencil built with another origin / domain is refused at construction, not mis-run;
+* ``compute_x_flux`` / ``compute_y_flux`` (xppm.py:269-287, yppm.py) -- any origin / domain, order from the ``mord`` external.
+
+Identities are matched on ``module.name`` with the reference's module path, on pace_amd's own mirror of it, and on the bare
+function name (the translate tests define some stencils in their own modules).
+"""
+import ctypes as C
+
+from .stencil import register_stencil
+
+
+def _ptr(x):
+    t = x.data if hasattr(x, "dims") else x
+    return t.data_ptr()
+
+
+def _geom(st):
+    from ..util.grid import geom_struct
+
+    f = st._factory
+    if getattr(f, "_geom_cache", None) is None:
+        qf = getattr(f, "quantity_factory", None)
+        if qf is None:
+            raise RuntimeError("this StencilFactory was built without a quantity_factory: device stencils need the field layout "
+                               "(StencilFactory(config, grid_indexing, quantity_factory=...))")
+        f._geom_cache = geom_struct(qf)
+    return f._geom_cache
+
+
+def _stream(st):
+    import torch
+
+    f = st._factory
+    if f.quantity_factory.device.type == "cpu":
+        return None
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _window(st, origin, domain, what):
+    """The device kernel covers exactly the window the reference launches this stencil on."""
+    o = st.origin if isinstance(st.origin, tuple) else st.origin.get("_all_")
+    if tuple(o) != tuple(origin) or tuple(st.domain) != tuple(domain):
+        raise NotImplementedError(f"{st.name}: the device kernel implements the launch window of {what} "
+                                  f"(origin {tuple(origin)}, domain {tuple(domain)}); requested origin {tuple(o)}, domain {st.domain}")
+
+
+def _both(mod, name):
+    return (f"pace.fv3core.stencils.{mod}.{name}", f"pace_amd.fv3core.stencils.{mod}.{name}")
+
+
+class _Impl:
+    """An implementation = a window check at construction + the call."""
+
+    def __init__(self, check, call):
+        self.check, self.call = check, call
+
+    def __call__(self, st, **named):
+        self.call(st, **named)
+
+
+def _register(paths, check, call):
+    impl = _Impl(check, call)
+    for p in paths:
+        register_stencil(p)(impl)
+    register_stencil(paths[0].rsplit(".", 1)[1])(impl)
+    return impl
+
+
+def _gi(st):
+    return st._factory.grid_indexing
+
+
+# ---- dyn_core.py:51-171 ----
+_register(_both("dyn_core", "zero_data"),
+          lambda st: _window(st, _gi(st).origin_full(), _gi(st).domain_full(), "dyn_core.py:539-543"),
+          lambda st, mfxd, mfyd, cxd, cyd, heat_source, diss_estd, first_timestep: st._factory.lib.call(
+              "pace_zero_data", C.byref(_geom(st)), _ptr(mfxd), _ptr(mfyd), _ptr(cxd), _ptr(cyd), _ptr(heat_source), _ptr(diss_estd),
+              int(bool(first_timestep)), _stream(st)))
+_register(_both("dyn_core", "gz_from_surface_height_and_thicknesses"),
+          lambda st: _window(st, _gi(st).origin_compute(), _gi(st).domain_compute(add=(0, 0, 1)), "dyn_core.py:510-514"),
+          lambda st, zs, delz, gz: st._factory.lib.call("pace_gz_from_surface_height_and_thicknesses", C.byref(_geom(st)), _ptr(zs),
+                                                        _ptr(delz), _ptr(gz), _stream(st)))
+_register(_both("dyn_core", "interface_pressure_from_toa_pressure_and_thickness"),
+          lambda st: _window(st, _gi(st).origin_compute(add=(-1, -1, 0)), _gi(st).domain_compute(add=(2, 2, 0)), "dyn_core.py:515-521"),
+          lambda st, delp, pem, ptop: st._factory.lib.call("pace_interface_pressure_from_toa_pressure_and_thickness",
+                                                           C.byref(_geom(st)), _ptr(delp), _ptr(pem), float(ptop), _stream(st)))
+
+
+def _geo_window(st):
+    from ..util.constants import X_DIM, Y_DIM, Z_INTERFACE_DIM
+
+    o, d = _gi(st).get_origin_domain([X_DIM, Y_DIM, Z_INTERFACE_DIM], halos=(2, 2))
+    _window(st, o, d, "dyn_core.py:480-487")
+
+
+_register(_both("dyn_core", "compute_geopotential"), _geo_window,
+          lambda st, zh, gz: st._factory.lib.call("pace_compute_geopotential", C.byref(_geom(st)), _ptr(zh), _ptr(gz), _stream(st)))
+
+
+def _p_grad_c_check(st):
+    _window(st, _gi(st).origin_compute(), _gi(st).domain_compute(add=(1, 1, 0)), "dyn_core.py:523-528")
+    if st.externals.get("hydrostatic", False):
+        raise NotImplementedError("p_grad_c_stencil: hydrostatic = True is not implemented")
+
+
+def _p_grad_c_call(st, rdxc, rdyc, uc, vc, delpc, pkc, gz, dt2):
+    gd = getattr(rdxc, "_grid_data", None)
+    if gd is None:
+        raise ValueError("p_grad_c_stencil: pass grid_data.rdxc / rdyc of a pace_amd GridData")
+    st._factory.lib.call("pace_p_grad_c", C.byref(_geom(st)), C.byref(gd.c_struct()), _ptr(uc), _ptr(vc), _ptr(delpc), _ptr(pkc),
+                         _ptr(gz), float(dt2), _stream(st))
+
+
+_register(_both("dyn_core", "p_grad_c_stencil"), _p_grad_c_check, _p_grad_c_call)
+
+# ---- basic_operations.py:7, pe_halo.py:6-34, temperature_adjust.py:8-43 ----
+_register(_both("basic_operations", "copy_defn"),
+          lambda st: _window(st, _gi(st).origin_full(), _gi(st).domain_full(add=(0, 0, 1)), "dyn_core.py:583-587"),
+          lambda st, q_in, q_out: st._factory.lib.call("pace_copy", C.byref(_geom(st)), _ptr(q_in), _ptr(q_out), _stream(st)))
+_register(_both("pe_halo", "edge_pe"),
+          lambda st: _window(st, _gi(st).origin_full(), _gi(st).domain_full(add=(0, 0, 1)), "dyn_core.py:548-554"),
+          lambda st, pe, delp, ptop: st._factory.lib.call("pace_edge_pe", C.byref(_geom(st)), _ptr(pe), _ptr(delp), float(ptop),
+                                                          _stream(st)))
+
+
+def _heating_check(st):
+    o, d = _gi(st).origin_compute(), _gi(st).domain_compute()
+    got_o = st.origin if isinstance(st.origin, tuple) else st.origin.get("_all_")
+    if tuple(got_o) != tuple(o) or tuple(st.domain[:2]) != tuple(d[:2]) or not (0 < st.domain[2] <= d[2]):
+        raise NotImplementedError(f"{st.name}: the device kernel covers the compute domain, top nk levels (dyn_core.py:575-581)")
+
+
+_register(_both("temperature_adjust", "apply_diffusive_heating"), _heating_check,
+          lambda st, delp, delz, cappa, heat_source, pt, delt_time_factor: st._factory.lib.call(
+              "pace_apply_diffusive_heating", C.byref(_geom(st)), _ptr(delp), _ptr(delz), _ptr(cappa), _ptr(heat_source), _ptr(pt),
+              float(delt_time_factor), int(st.domain[2]), _stream(st)))
+
+
+# ---- xppm.py:269-287 / yppm.py: any window ----
+def _ppm(axis):
+    def check(st):
+        if abs(int(st.externals.get("mord", st.externals.get("iord", 0)))) not in (5, 6, 8):
+            raise NotImplementedError(f"{st.name}: mord must be 5, 6 or 8")
+
+    def call(st, q, courant, dxa, xflux):
+        gd = getattr(dxa, "_grid_data", None)
+        if gd is None:
+            raise ValueError(f"{st.name}: pass grid_data.dxa / dya of a pace_amd GridData")
+        o = st.origin if isinstance(st.origin, tuple) else st.origin.get("_all_")
+        st._factory.lib.call("pace_ppm", C.byref(_geom(st)), C.byref(gd.c_struct()), axis, int(st.externals.get("mord", 6)), _ptr(q),
+                             _ptr(courant), _ptr(xflux), int(o[0]), int(o[1]), int(o[2]), *[int(x) for x in st.domain], _stream(st))
+
+    return check, call
+
+
+_register(_both("xppm", "compute_x_flux"), *_ppm(0))
+_register(_both("yppm", "compute_y_flux"), *_ppm(1))

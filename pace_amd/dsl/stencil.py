@@ -189,6 +189,9 @@ class FrozenStencil:
                 "execute gtscript."
             )
         self._impl = impl
+        check = getattr(impl, "check", None)
+        if check is not None:
+            check(self)  # e.g. the device kernel covers one launch window only: refuse another one here, not at call time
 
     def __call__(self, *args, **kwargs) -> None:
         if "origin" in kwargs:
@@ -203,11 +206,16 @@ class FrozenStencil:
 class StencilFactory:
     """stencil.py:858-970."""
 
-    def __init__(self, config: StencilConfig, grid_indexing: GridIndexing, comm=None, lib: Optional[_lib.Library] = None):
+    def __init__(self, config: StencilConfig, grid_indexing: GridIndexing, comm=None, lib: Optional[_lib.Library] = None,
+                 quantity_factory=None):
+        """``quantity_factory`` (an extension of the reference signature): the field layout the per-stencil device
+        implementations launch on; class-level operators receive their own."""
         self.config = config
         self.grid_indexing = grid_indexing
         self.comm = comm
         self.lib = lib if lib is not None else _lib.load()
+        self.quantity_factory = quantity_factory
+        self._geom_cache = None
 
     @property
     def backend(self):
@@ -225,7 +233,8 @@ class StencilFactory:
         return self.from_origin_domain(func, origin=origin, domain=domain, externals=all_externals, skip_passes=skip_passes)
 
     def restrict_vertical(self, k_start=0, nk=None) -> "StencilFactory":
-        return StencilFactory(self.config, self.grid_indexing.restrict_vertical(k_start=k_start, nk=nk), comm=self.comm, lib=self.lib)
+        return StencilFactory(self.config, self.grid_indexing.restrict_vertical(k_start=k_start, nk=nk), comm=self.comm, lib=self.lib,
+                              quantity_factory=self.quantity_factory)
 
 
 def get_stencils_with_varied_bounds(func, origins, domains, stencil_factory, externals=None):

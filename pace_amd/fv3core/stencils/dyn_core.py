@@ -29,6 +29,29 @@ from .updatedzd import UpdateHeightOnDGrid
 HUGE_R = 1.0e40
 
 
+# The definition functions of the one-launch stencils of dyn_core.py:51-171.  In the reference these are gtscript bodies; here
+# their bodies are the device kernels registered under the same identities (pace_amd/dsl/device_stencils.py), and -- exactly as
+# in the reference -- AcousticDynamics builds FrozenStencils from them through its StencilFactory.
+def zero_data(mfxd, mfyd, cxd, cyd, heat_source, diss_estd, first_timestep):
+    """dyn_core.py:51-80"""
+
+
+def gz_from_surface_height_and_thicknesses(zs, delz, gz):
+    """dyn_core.py:83-96"""
+
+
+def interface_pressure_from_toa_pressure_and_thickness(delp, pem, ptop):
+    """dyn_core.py:99-112"""
+
+
+def compute_geopotential(zh, gz):
+    """dyn_core.py:115-117"""
+
+
+def p_grad_c_stencil(rdxc, rdyc, uc, vc, delpc, pkc, gz, dt2):
+    """dyn_core.py:120-171"""
+
+
 def get_nk_heat_dissipation(config, npz: int) -> int:
     """dyn_core.py:174-189."""
     if config.convert_ke or config.vtdm4 > 1.0e-4:
@@ -137,37 +160,41 @@ class AcousticDynamics(Operator):
             self._rayleigh_damping = RayleighDamping(stencil_factory, rf_cutoff=config.rf_cutoff, tau=config.tau,
                                                      hydrostatic=config.hydrostatic, quantity_factory=quantity_factory)
         self._pk3_halo = PK3Halo(stencil_factory, quantity_factory)
+        self._build_stencils(stencil_factory, grid_indexing)
         self._halo_updaters = AcousticDynamics._HaloUpdaters(comm, grid_indexing, quantity_factory, state, cappa=self.cappa,
                                                              gz=self._gz, zh=self._zh, divgd=self._divgd,
                                                              heat_source=self._heat_source, pkc=self._pkc)
 
-    # ---- the one-launch dyn_core stencils -------------------------------------------------------------
-    def _zero_data(self, mfxd, mfyd, cxd, cyd, heat_source, diss_estd, first_timestep: bool):
-        self.call("pace_zero_data", dptr(mfxd), dptr(mfyd), dptr(cxd), dptr(cyd), dptr(heat_source), dptr(diss_estd),
-                  int(bool(first_timestep)), self.stream())
+    # ---- the one-launch dyn_core stencils: FrozenStencils from the factory, windows as in dyn_core.py:480-587 ----
+    def _build_stencils(self, stencil_factory, grid_indexing):
+        from . import basic_operations as basic
+        from . import pe_halo, temperature_adjust
 
-    def _gz_from_surface_height_and_thickness(self, zs, delz, gz):
-        self.call("pace_gz_from_surface_height_and_thicknesses", dptr(zs), dptr(delz), dptr(gz), self.stream())
-
-    def _copy_stencil(self, src, dst):
-        self.call("pace_copy", dptr(src), dptr(dst), self.stream())
-
-    def _compute_geopotential_stencil(self, zh, gz):
-        self.call("pace_compute_geopotential", dptr(zh), dptr(gz), self.stream())
-
-    def _p_grad_c(self, rdxc, rdyc, uc, vc, delpc, pkc, gz, dt2):
-        self.call("pace_p_grad_c", C.byref(self._met), dptr(uc), dptr(vc), dptr(delpc), dptr(pkc), dptr(gz), float(dt2),
-                  self.stream())
-
-    def _edge_pe_stencil(self, pe, delp, ptop):
-        self.call("pace_edge_pe", dptr(pe), dptr(delp), float(ptop), self.stream())
-
-    def _interface_pressure_from_toa_pressure_and_thickness(self, delp, pem, ptop):
-        self.call("pace_interface_pressure_from_toa_pressure_and_thickness", dptr(delp), dptr(pem), float(ptop), self.stream())
-
-    def _apply_diffusive_heating(self, delp, delz, cappa, heat_source, pt, delt_time_factor):
-        self.call("pace_apply_diffusive_heating", dptr(delp), dptr(delz), dptr(cappa), dptr(heat_source), dptr(pt),
-                  float(delt_time_factor), int(self._nk_heat_dissipation), self.stream())
+        sf = stencil_factory
+        if getattr(sf, "quantity_factory", None) is None:
+            sf.quantity_factory = self._qf  # a factory built with the reference's signature: the layout is this object's
+        origin, domain = grid_indexing.get_origin_domain([X_DIM, Y_DIM, Z_INTERFACE_DIM], halos=(2, 2))
+        self._compute_geopotential_stencil = sf.from_origin_domain(compute_geopotential, origin=origin, domain=domain)
+        self._gz_from_surface_height_and_thickness = sf.from_origin_domain(
+            gz_from_surface_height_and_thicknesses, origin=grid_indexing.origin_compute(),
+            domain=grid_indexing.domain_compute(add=(0, 0, 1)))
+        self._interface_pressure_from_toa_pressure_and_thickness = sf.from_origin_domain(
+            interface_pressure_from_toa_pressure_and_thickness, origin=grid_indexing.origin_compute(add=(-1, -1, 0)),
+            domain=grid_indexing.domain_compute(add=(2, 2, 0)))
+        self._p_grad_c = sf.from_origin_domain(p_grad_c_stencil, origin=grid_indexing.origin_compute(),
+                                               domain=grid_indexing.domain_compute(add=(1, 1, 0)),
+                                               externals={"hydrostatic": self.config.hydrostatic})
+        self._zero_data = sf.from_origin_domain(zero_data, origin=grid_indexing.origin_full(), domain=grid_indexing.domain_full())
+        ax_offsets_pe = grid_indexing.axis_offsets(grid_indexing.origin_full(), grid_indexing.domain_full(add=(0, 0, 1)))
+        self._edge_pe_stencil = sf.from_origin_domain(pe_halo.edge_pe, origin=grid_indexing.origin_full(),
+                                                      domain=grid_indexing.domain_full(add=(0, 0, 1)), externals={**ax_offsets_pe},
+                                                      skip_passes=("PruneKCacheFills",))
+        if self._nk_heat_dissipation > 0:
+            self._apply_diffusive_heating = sf.from_origin_domain(
+                temperature_adjust.apply_diffusive_heating, origin=grid_indexing.origin_compute(),
+                domain=grid_indexing.restrict_vertical(nk=self._nk_heat_dissipation).domain_compute())
+        self._copy_stencil = sf.from_origin_domain(basic.copy_defn, origin=grid_indexing.origin_full(),
+                                                   domain=grid_indexing.domain_full(add=(0, 0, 1)))
 
     def _get_da_min(self) -> float:
         return self._da_min

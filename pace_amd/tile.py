@@ -49,7 +49,8 @@ class Env:
         self.sizer = SubtileGridSizer.from_tile_params(nx_tile=n, ny_tile=n, nz=nz, n_halo=3, extra_dim_lengths={}, layout=(1, 1))
         self.qf = QuantityFactory(self.sizer, device=device)
         self.grid_indexing = GridIndexing.from_sizer_and_communicator(self.sizer, None)
-        self.stencil_factory = StencilFactory(StencilConfig(compilation_config=CompilationConfig()), self.grid_indexing, lib=lib)
+        self.stencil_factory = StencilFactory(StencilConfig(compilation_config=CompilationConfig()), self.grid_indexing, lib=lib,
+                                              quantity_factory=self.qf)
         self.grid_data = GridData(self.qf, metrics)
         self.damping = DampingCoefficients(self.grid_data)
 

@@ -418,3 +418,70 @@ def loop_errors(ref, got, n, nz):
             worst = max(worst, float(rel.max()))
         errs[k] = worst
     return errs
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The operators the reference also tests on their own (TranslateXPPM / YPPM / DivergenceDamping) as stand-alone classes
+# ----------------------------------------------------------------------------------------------------------------------
+def check_standalone_operators(lib, device, n, nz, exact):
+    """XPiecewiseParabolic / YPiecewiseParabolic (iord 5, 6, 8; the windows fvtp2d uses: inner = compute x full, outer =
+    compute + 1) and DivergenceDamping against the oracle.  Returns {name: error}."""
+    import torch
+
+    from helpers import Env
+    from oracle import damping
+    from oracle import ppm_transport as tr
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils.divergence_damping import DivergenceDamping
+    from pace_amd.fv3core.stencils.xppm import XPiecewiseParabolic
+    from pace_amd.fv3core.stencils.yppm import YPiecewiseParabolic
+
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, device, m, n, nz)
+    g = Grid(n, nz, m)
+    col = column(nz)
+    for k in ("crx", "cry", "xfx", "yfx"):
+        s[k] = np.zeros_like(s["pt"])
+    dgrid_sw.fxadv(g, s["uc"], s["vc"], s["crx"], s["cry"], s["xfx"], s["yfx"], np.zeros_like(s["pt"]), np.zeros_like(s["pt"]), s["dt"])
+    errs = {}
+    q, crx, cry = env.q3(s["pt"]), env.q3(s["crx"]), env.q3(s["cry"])
+    for iord in (5, 6, 8):
+        # inner x sweep of fvtp2d: origin (is, jsd), domain (n + 1, n + 6); inner y: origin (isd, js), domain (n + 6, n + 1)
+        for cls, axis, c_q, c_np, metric, name in ((XPiecewiseParabolic, 0, crx, s["crx"], env.grid_data.dxa, "dxa"),
+                                                   (YPiecewiseParabolic, 1, cry, s["cry"], env.grid_data.dya, "dya")):
+            origin = (3, 0, 0) if axis == 0 else (0, 3, 0)
+            domain = (n + 1, n + 6, nz) if axis == 0 else (n + 6, n + 1, nz)
+            out = env.q3()
+            cls(env.stencil_factory, metric, 0, iord, origin, domain)(q, c_q, out)
+            if device != "cpu":
+                torch.cuda.synchronize()
+            ref = np.zeros_like(s["pt"])
+            tr.ppm_flux(s["pt"], c_np, m[name], g, axis, iord, ref, origin, domain)
+            W = tuple(slice(o, o + d) for o, d in zip(origin, domain))
+            e = compare(ref[W], out.numpy()[W])
+            errs[f"{'xy'[axis]}ppm{iord}"] = e
+            assert e == 0.0 if exact else e < 1e-14, (axis, iord, e)
+            untouched = out.numpy().copy()
+            untouched[W] = 0.0
+            assert not untouched.any(), "written outside origin .. origin + domain"
+    # DivergenceDamping on the synthetic winds (vorticity = a smooth field; ke = another)
+    f = {k: s[k].copy() for k in ("u", "v", "va", "ua", "divgd", "vc", "uc")}
+    f["vort_b"], f["delpc"] = np.zeros_like(s["pt"]), np.zeros_like(s["pt"])
+    f["ke"] = 0.5 * (s["u"] ** 2 + s["v"] ** 2)
+    f["wk"] = 1.0e-5 * s["pt"] * np.cos(s["u"] * 0.1)
+    qf = {k: env.q3(a) for k, a in f.items()}
+    op = DivergenceDamping(env.stencil_factory, env.qf, env.grid_data, env.damping, False, False, DSW_CFG["dddmp"], DSW_CFG["d4_bg"],
+                           DSW_CFG["nord"], 0, env.kq(col["nord"]), env.kq(col["d2_divg"]))
+    op(qf["u"], qf["v"], qf["va"], qf["vort_b"], qf["ua"], qf["divgd"], qf["vc"], qf["uc"], qf["delpc"], qf["ke"], qf["wk"], s["dt"])
+    if device != "cpu":
+        torch.cuda.synchronize()
+    damping.divergence_damping(g, f["u"], f["v"], f["va"], f["vort_b"], f["ua"], f["divgd"], f["vc"], f["uc"], f["delpc"], f["ke"],
+                               f["wk"], s["dt"], nord_k=col["nord"], d2_bg_k=col["d2_divg"], dddmp=DSW_CFG["dddmp"],
+                               d4_bg=DSW_CFG["d4_bg"], nord=DSW_CFG["nord"])
+    B = _win(n, 0, 0, 1, 1)
+    for k, W in (("vort_b", B), ("ke", B), ("delpc", B), ("divgd", B), ("uc", _win(n, 0, 0, 1, 0)), ("vc", _win(n, 0, 0, 0, 1))):
+        e = compare(f[k][W][:, :, :nz], qf[k].numpy()[W][:, :, :nz], near_zero=1e-14 * float(np.abs(f[k][W]).max()))
+        errs["divdamp_" + k] = e
+        assert e == 0.0 if exact else e < 1.4e-10, (k, e)  # translate_divergencedamping.py:37
+    return errs

@@ -140,3 +140,46 @@ def test_entry_points_reject_inconsistent_geometry():
     assert copy_rc(3000, 79, 3008, 3008 * 3007) == -3    # (nk + 1) * sk * 8 B >= 4 GB
     with pytest.raises(_lib.PaceError, match="pace_copy failed"):
         lib.call("pace_copy", C.byref(_lib.Geom(12, 79, 16, 0, 32 * 19)), p, p, None)
+
+
+def test_frozen_stencils_of_the_registry():
+    """The per-stencil boundary (dsl/pace/dsl/stencil.py:395-434) is real for the stencils the registry lists: built through
+    StencilFactory.from_origin_domain / from_dims_halo from a definition function with the reference's name and arguments,
+    called with positional / keyword Quantities, refused at CONSTRUCTION for a window the device kernel does not implement,
+    TypeError for origin= / domain= at call (tests/main/dsl/test_stencil_wrapper.py).  Emulation build, CPU."""
+    from helpers import Env, build_emu, golden
+    from pace_amd import _lib
+    from pace_amd.dsl import get_stencils_with_varied_bounds
+    from pace_amd.fv3core.stencils import basic_operations, dyn_core, xppm
+
+    lib = _lib.Library(build_emu())
+    n, nz = 12, 6
+    env = Env(lib, "cpu", golden("grid_c12_tile0.npz"), n, nz)
+    sf, gi = env.stencil_factory, env.grid_indexing
+    rng = np.random.default_rng(0)
+    a = rng.random((n + 7, n + 7, nz + 1))
+    src, dst = env.q3(a), env.q3()
+    copy = sf.from_origin_domain(basic_operations.copy_defn, origin=gi.origin_full(), domain=gi.domain_full(add=(0, 0, 1)))
+    copy(src, q_out=dst)
+    assert np.array_equal(dst.numpy()[:-1, :-1, :], a[:-1, :-1, :]) and not dst.numpy()[-1].any()
+    with pytest.raises(TypeError, match="origin"):
+        copy(src, dst, origin=(0, 0, 0))
+    with pytest.raises(NotImplementedError, match="launch window"):
+        sf.from_origin_domain(basic_operations.copy_defn, origin=gi.origin_compute(), domain=gi.domain_compute())
+    geo = sf.from_dims_halo(dyn_core.compute_geopotential, compute_dims=["x", "y", "z_interface"], compute_halos=(2, 2))
+    gz = env.q3()
+    geo(src, gz)
+    w = (slice(1, n + 5), slice(1, n + 5))
+    assert np.array_equal(gz.numpy()[w], a[w] * 9.80665)
+    # a stencil that honours ANY window: the PPM flux (xppm.py:269-287) on two windows at once
+    q, c = env.q3(a), env.q3(0.3 * (a - 0.5))
+    outs = [env.q3(), env.q3()]
+    origins, domains = [(3, 3, 0), (5, 4, 1)], [(n + 1, n, nz), (3, 2, 2)]
+    sts = get_stencils_with_varied_bounds(xppm.compute_x_flux, origins, domains, sf, externals={"iord": 6, "mord": 6, "xt_minmax": True})
+    for st, o in zip(sts, outs):
+        st(q, c, env.grid_data.dxa, o)
+    big, small = outs[0].numpy(), outs[1].numpy()
+    ws = tuple(slice(o, o + d) for o, d in zip(origins[1], domains[1]))
+    assert np.array_equal(small[ws], big[ws]) and np.count_nonzero(small) == np.count_nonzero(small[ws]) > 0
+    with pytest.raises(NotImplementedError, match="no HIP implementation"):
+        sf.from_origin_domain(lambda q_in, q_out: None, (0, 0, 0), (3, 3, 3))

@@ -469,3 +469,11 @@ def test_acoustic_loop_six_synthetic_tiles_emulated_vs_oracle(emu_lib):
     got = opchain.product_loop(emu_lib, "cpu", n, nz, n_split, 3.5 * n_split)
     for k, e in opchain.loop_errors(ref, got, n, nz).items():
         assert e < opchain.LOOP_TOL.get(k, 1e-9), (k, e)
+
+
+def test_standalone_ppm_and_divergence_damping_emulated_vs_oracle(emu_lib):
+    """XPiecewiseParabolic, YPiecewiseParabolic (orders 5, 6, 8) and DivergenceDamping as stand-alone classes (the reference
+    tests them on their own: TranslateXPPM / YPPM / DivergenceDamping): bit for bit against the oracle."""
+    from opchain import check_standalone_operators
+
+    check_standalone_operators(emu_lib, "cpu", 12, 8, exact=True)

@@ -594,3 +594,11 @@ def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path):
         json.dump(errs, open(os.path.join(out_dir, "acoustic_loop_c96_gpu_errors.json"), "w"), indent=1)
     for k, e in errs.items():
         assert e < opchain.LOOP_TOL.get(k, 1e-9), (k, e)
+
+
+def test_standalone_ppm_and_divergence_damping_match_oracle(lib):
+    """The stand-alone operator classes XPiecewiseParabolic / YPiecewiseParabolic (orders 5, 6, 8) and DivergenceDamping at
+    C96 x 20 against the oracle (reference bounds: 1e-14 and 1.4e-10; no transcendental is involved, so: exact)."""
+    from opchain import check_standalone_operators
+
+    check_standalone_operators(lib, "cuda", 96, 20, exact=True)
