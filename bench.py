@@ -34,9 +34,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--n", type=int, default=192)
+    p.add_argument("--n", "--tile-size", dest="n", type=int, default=192)  # (--n alone is ambiguous to torch.distributed.run)
     p.add_argument("--nz", type=int, default=79)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     p.add_argument("--watchdog", type=float, default=900.0, help="multi-rank runs: seconds after which a stuck run exits")
     p.add_argument("--exchange", choices=("on", "off"), default="on",
                    help="multi-rank runs: keep the delp/pt/q_con halo exchange inside the measured step (default) or run the tiles independently")
@@ -44,6 +45,10 @@ def parse():
                    help="replay each step from a captured HIP graph (measured: no gain at C48 ... C192 -- the launches are "
                         "already queued ahead of the GPU; kept as an option)")
     p.add_argument("--cpu-n", type=int, default=192, help="tile size of the bounded CPU-baseline sample")
+    p.add_argument("--emulate", action="store_true",
+                   help="TEST ONLY (tests/test_halo.py): run the multi-rank code path -- partitioner, pack / exchange / unpack, barrier, "
+                        "max-over-ranks reduction, the JSON line -- on the CPU over gloo with the emulation build of the kernels; no "
+                        "performance meaning, the line says so")
     return p.parse_args()
 
 
@@ -54,40 +59,108 @@ def column_namelist(nz, qf):
     return get_column_namelist(DGridShallowWaterLagrangianDynamicsConfig(), qf)
 
 
-def cpu_baseline(n, nz):
-    """The oracle (numpy restatement with the reference's stencil granularity) timed on the host:
-    one d_sw + riem_solver3 substep at C<n> x nz.  kind = 'port', 1 thread (numpy elementwise)."""
-    from pace_amd.tile import DSW_ARGS, DSW_CFG
+def _cpu_slab(args):
+    """One worker: the numpy oracle on a slab of levels (d_sw: levels are independent) and on all levels of a slab of
+    rows (riem_solver3: columns are independent).  Returns the seconds it took."""
+    n, nz, k0, k1, j0, j1 = args
+    import time as _t
+
+    import numpy as _np
 
     from oracle import dgrid_sw, vertical
     from oracle._np import Grid
     from pace_amd import synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import column_namelist_arrays
+    from pace_amd.tile import DSW_ARGS, DSW_CFG
 
     m = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(m, n, nz)
-    g = Grid(n, nz, m)
-    # column namelist values (d_sw.py:633-683) without touching a device
-    col = {}
-    z = nz + 1
-    col["nord"] = np.full(z, 3.0); col["nord"][:3] = 0  # noqa: E702
-    col["nord_v"] = np.full(z, 2.0); col["nord_v"][:2] = 0  # noqa: E702
-    col["nord_w"] = np.full(z, 2.0); col["nord_w"][:3] = 0  # noqa: E702
-    col["nord_t"] = np.full(z, 2.0)
-    col["damp_vt"] = np.full(z, 0.06); col["damp_vt"][:2] = [0.1, 0.05]  # noqa: E702
-    col["damp_w"] = np.full(z, 0.06); col["damp_w"][:3] = [0.2, 0.1, 0.02]  # noqa: E702
-    col["damp_t"] = np.full(z, 0.06)
-    col["d2_divg"] = np.zeros(z); col["d2_divg"][:3] = [0.2, 0.1, 0.02]  # noqa: E702
-    col["d_con"] = np.full(z, 1.0); col["d_con"][:3] = 0  # noqa: E702
-    col["ke_bg"] = np.zeros(z)
-    st = dgrid_sw.DSWState(s["u"].shape)
-    a = {k: s[k].copy() for k in DSW_ARGS}
-    t0 = time.perf_counter()
-    dgrid_sw.d_sw(g, col, DSW_CFG, st, *[a[k] for k in DSW_ARGS], s["dt"])
-    vertical.riem_solver3(g, False, s["dt"], s["cappa"], m["ptop"], s["zs"], s["ws"], s["delz"], a["q_con"], a["delp"], a["pt"],
-                          s["zh"], s["pe"], s["ppe"], s["pk3"], s["pk"], s["peln"], a["w"], p_fac=0.05)
-    dt = time.perf_counter() - t0
-    return {"value": n * n * nz / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"1 substep (d_sw + riem_solver3) at C{n}x{nz}L, numpy oracle, {dt:.1f} s"}
+    col = column_namelist_arrays(DGridShallowWaterLagrangianDynamicsConfig(), nz)
+    nk = k1 - k0
+    sl = lambda a_: _np.ascontiguousarray(_np.concatenate([a_[:, :, k0:k1], a_[:, :, k1 - 1:k1]], axis=2))  # noqa: E731
+    colk = {k: _np.ascontiguousarray(_np.concatenate([v[k0:k1], v[k1 - 1:k1]])) for k, v in col.items()}
+    g = Grid(n, nk, m)
+    a = {k: sl(s[k]) for k in DSW_ARGS}
+    st = dgrid_sw.DSWState(a["u"].shape)
+    # riem_solver3 on rows j0 .. j1 (a strip of the tile with its own small Grid: the solver is column-local)
+    rows = slice(3 + j0, 3 + j1)
+    t0 = _t.perf_counter()
+    dgrid_sw.d_sw(g, colk, DSW_CFG, st, *[a[k] for k in DSW_ARGS], s["dt"])
+    b = {k: _np.ascontiguousarray(s[k][:, rows]) for k in ("cappa", "delz", "q_con", "delp", "pt", "zh", "pe", "ppe", "pk3", "pk", "peln", "w")}
+    zs, ws = _np.ascontiguousarray(s["zs"][:, rows]), _np.ascontiguousarray(s["ws"][:, rows])
+    gr = Grid(n, nz, m)
+    gr.js, gr.je, gr.nj = 0, (j1 - j0) - 1, j1 - j0
+    vertical.riem_solver3(gr, False, s["dt"], b["cappa"], m["ptop"], zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"],
+                          b["ppe"], b["pk3"], b["pk"], b["peln"], b["w"], p_fac=0.05)
+    return _t.perf_counter() - t0
+
+
+def cpu_baseline(n, nz):
+    """The oracle -- the numpy restatement with the reference's stencil granularity (one array statement per gtscript
+    statement, every temporary a full field) -- on ALL host cores: one process per core, each advancing a slab of levels
+    through d_sw and a slab of rows through riem_solver3 (what an OpenMP loop over k / j around the same statements would
+    do).  kind = 'port'.  A one-core figure is reported next to it.  The reference's own CPU backend (gt:cpu_ifirst) needs
+    GT4Py + GridTools and cannot be built here."""
+    import multiprocessing as mp
+
+    cores = max(1, min(os.cpu_count() or 1, nz, 32))  # (every worker holds its own copy of the synthetic state: bounded)
+    kb = [round(i * nz / cores) for i in range(cores + 1)]
+    jb = [round(i * n / cores) for i in range(cores + 1)]
+    jobs = [(n, nz, kb[i], kb[i + 1], jb[i], jb[i + 1]) for i in range(cores) if kb[i + 1] > kb[i] and jb[i + 1] > jb[i]]
+    ctx = mp.get_context("spawn")  # no fork from a process that has initialised the GPU
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    with ctx.Pool(len(jobs)) as pool:
+        pool.map(_cpu_slab, [(12, 8, 0, 8, 0, 12)] * len(jobs))  # warm-up: imports, page faults
+        secs = pool.map(_cpu_slab, jobs)  # the workers compute concurrently (they share the memory system); each returns
+        wall = max(secs)                  # the time of its own share, without the set-up of its inputs
+        alone = pool.map(_cpu_slab, jobs[:1])[0]  # the first share again with the other cores idle
+    return {"value": n * n * nz / wall, "unit": "cell-updates/s", "cores": len(jobs), "kind": "port",
+            "sample": f"1 substep (d_sw + riem_solver3) at C{n}x{nz}L, numpy oracle, {len(jobs)} processes "
+                      f"(levels / rows split), slowest share {wall:.1f} s",
+            "one_core_value": n * n * nz / (alone * len(jobs))}
+
+
+def measure_traffic(kernel_substring, n, nz):
+    """HBM bytes per launch of the dominant kernel, measured NOW: this script is run twice more as a child under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; no
+    tracing domains beyond the kernel trace) for three steps, and the counters of the kernel are averaged.
+    bytes = FETCH_SIZE x 1024 x 2 (the gfx950 correction; calibrated for this code's 8 B-per-lane loads in
+    profiles/r02_pmc_calibration.json) + WRITE_SIZE x 1024.  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="pace_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "--", sys.executable, os.path.abspath(__file__), "--steps", "3",
+                   "--warmup", "1", "--n", str(n), "--nz", str(nz), "--no-cpu-baseline", "--no-traffic"]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-300:]}"
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if any(k in r["Kernel_Name"] for k in kernel_substring) and r["Counter_Name"] == counter:
+                        got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, f"no {counter} rows for {kernel_substring}"
+            vals[counter] = sum(got) / len(got)
+    except (subprocess.TimeoutExpired, OSError) as e:
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    read_b, write_b = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    return read_b + write_b, {"read_bytes": read_b, "write_bytes": write_b, "method": "rocprofv3 --pmc, two child passes of this command"}
 
 
 def main():
@@ -104,37 +177,61 @@ def main():
 
         # A multi-rank run that stops making progress (a peer died, a transport problem) must end by itself: exit with an
         # error after a generous bound instead of occupying the node.
+        phase = {"name": "init_process_group", "timer": None}
+
         def _give_up():
-            sys.stderr.write(f"bench.py: rank {rank} made no progress for {args.watchdog} s, giving up\n")
+            sys.stderr.write(f"bench.py: rank {rank} spent more than {args.watchdog} s in phase '{phase['name']}', giving up\n")
             sys.stderr.flush()
             os._exit(124)
 
-        watchdog = threading.Timer(args.watchdog, _give_up)
-        watchdog.daemon = True
-        watchdog.start()
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        torch.cuda.set_device(local_rank)
+        def arm(name):
+            """The limit applies per phase (rendezvous, preflight, staging, warm-up, timed loop, reduction): it is re-armed
+            at every phase boundary, so a long run is not killed for being long, only a phase that stops."""
+            if phase["timer"] is not None:
+                phase["timer"].cancel()
+            phase["name"] = name
+            t = threading.Timer(args.watchdog, _give_up)
+            t.daemon = True
+            t.start()
+            phase["timer"] = t
+
+        arm("init_process_group")
+        if args.emulate:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            torch.cuda.set_device(local_rank)
         if args.exchange != "off":
             # preflight: the point-to-point pattern of the halo exchange (one grouped send/recv with both ring neighbours)
             # on a few bytes, under a short watchdog of its own -- a transport that cannot do this should fail here, fast
+            arm("preflight exchange")
             pre = threading.Timer(min(120.0, args.watchdog), _give_up)
             pre.daemon = True
             pre.start()
-            dev0 = torch.device(f"cuda:{local_rank}")
+            dev0 = torch.device("cpu" if args.emulate else f"cuda:{local_rank}")
             peers = sorted({(rank - 1) % world, (rank + 1) % world})
             sb = {p_: torch.full((8,), float(rank), dtype=torch.float64, device=dev0) for p_ in peers}
             rb = {p_: torch.zeros(8, dtype=torch.float64, device=dev0) for p_ in peers}
             ops = [dist.P2POp(dist.irecv, rb[p_], p_) for p_ in peers] + [dist.P2POp(dist.isend, sb[p_], p_) for p_ in peers]
             for w_ in dist.batch_isend_irecv(ops):
                 w_.wait()
-            torch.cuda.synchronize()
+            if not args.emulate:
+                torch.cuda.synchronize()
             for p_ in peers:
                 if float(rb[p_][0].item()) != float(p_):
                     sys.stderr.write(f"bench.py: preflight exchange returned wrong data on rank {rank}\n")
                     os._exit(125)
             pre.cancel()
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    else:
+        def arm(name):
+            return None
+    if args.emulate:
+        dev = "cpu"
+        torch.cuda.synchronize = lambda *a, **k: None  # nothing below touches a GPU in this mode
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = f"cuda:{local_rank}"
+    arm("staging")
 
     from pace_amd.tile import DSW_ARGS, Env
 
@@ -143,7 +240,7 @@ def main():
     from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics
     from pace_amd.fv3core.stencils.riem_solver3 import NonhydrostaticVerticalSolver
 
-    lib = _lib.load()
+    lib = _lib.Library(os.path.join(ROOT, "tests", "emu", "libpace_emu.so")) if args.emulate else _lib.load()
     n, nz = args.n, args.nz
     metrics = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(metrics, n, nz)
@@ -203,6 +300,7 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = args.graph == "on"
+    arm("warm-up")
     for i in range(args.warmup):
         step(batches[i])
     runners = None
@@ -216,6 +314,7 @@ def main():
             with torch.cuda.graph(gr):
                 step(batches[i])
             runners.append(gr)
+    arm("timed loop")
     barrier()
     t0 = time.perf_counter()
     if runners is not None:
@@ -226,6 +325,7 @@ def main():
             step(batches[i])
     barrier()
     elapsed = time.perf_counter() - t0
+    arm("reduction + report")
     if world > 1:
         import torch.distributed as dist
 
@@ -240,7 +340,7 @@ def main():
     # one scalar; q_con and pt in every d_sw, its siblings <6,1,0>, <6,0,2>, <6,-1,0> do delp, w and the vorticity), timed
     # live with events on the launch stream through its own C entry point
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.emulate:
         import ctypes as C
 
         from pace_amd.fv3core.stencils._common import host_column
@@ -269,21 +369,20 @@ def main():
         t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
         # algorithmic bytes per launch: q, crx, cry, xfx, yfx, x/y mass flux, delp in; qout out = 9 fields of N x N x nz doubles
         algo = TRANSPORT_FIELDS * 8.0 * n * n * nz
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
-        # separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/r01_pmc_traffic.json
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pmc["k_fvtp2d<6, 2, 1>"]["hbm_bytes_per_launch"] if n == 192 and nz == 79 else None
-        except (OSError, KeyError):
-            pass
+        # HBM bytes per launch: measured live by two child passes under rocprofv3 --pmc (see measure_traffic), null otherwise
+        traffic, traffic_detail = (None, "skipped (--no-traffic)")
+        if not args.no_traffic and world == 1:
+            torch.cuda.synchronize()
+            traffic, traffic_detail = measure_traffic(("k_fvtp2d<6, 2, 1>", "k_fvtp2dILi6ELi2ELi1E"), n, nz)
         roof = {"kernel": "k_fvtp2d<6, 2, 1>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "us_per_launch": t_kernel * 1e6,
-                "algorithmic_bytes_per_launch": algo}
+                "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
+                "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo,
+                "limited_by": "latency of its barrier-separated stages at 4 waves per SIMD (VALU ~37 % busy, HBM ~3 TB/s): "
+                              "DESIGN.md section 4; the roofline that prices it is HBM"}
 
     if rank == 0:
         line = {
-            "metric": "cell-updates/s per acoustic substep (d_sw+riem3), C192x79L; % HBM roofline",
+            "metric": f"cell-updates/s per acoustic substep (d_sw+riem3), C{n}x{nz}L; % HBM roofline",
             "value": value,
             "unit": "cell-updates/s",
             "n_gpus": world,
@@ -294,7 +393,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not args.emulate else "synthetic (CPU EMULATION DRY RUN: no performance meaning)",
             "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, fp64",
                        "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}",
                        "halo_exchange": topology,

@@ -163,8 +163,13 @@ class Library:
             fn.restype = res
             fn.argtypes = args
 
+    timing = None  # a pace_amd.util.KernelTimes while per-entry-point device times are being collected
+
     def call(self, name, *args):
+        end = self.timing.bracket(name) if self.timing is not None else None
         rc = getattr(self.cdll, name)(*args)
+        if end is not None:
+            end.record()
         if rc != 0:
             detail = self.cdll.pace_last_error().decode() if rc == -2 else ""
             raise PaceError(f"{name} failed: {_ERR.get(rc, rc)} {detail}".rstrip())

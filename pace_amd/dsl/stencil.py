@@ -221,6 +221,18 @@ class StencilFactory:
     def backend(self):
         return self.config.compilation_config.backend
 
+    def collect_kernel_times(self, on: bool = True):
+        """Start (or stop) collecting device times per C entry point (the reference's TimingCollector, stencil.py:103-163)."""
+        from ..util._timing import KernelTimes
+
+        self.lib.timing = KernelTimes() if on else None
+
+    def exec_report(self, key: str = "total_run_time", **kwargs) -> str:
+        """stencil.py:969-970: a table of accumulated device time per kernel entry point."""
+        if self.lib.timing is None:
+            return "Total: 0 (call collect_kernel_times() first)"
+        return self.lib.timing.report(key, **kwargs)
+
     def from_origin_domain(self, func, origin, domain, externals=None, skip_passes=()):
         return FrozenStencil(func, origin, domain, self.config, externals=externals, skip_passes=skip_passes, factory=self)
 

@@ -18,16 +18,7 @@ from .remapping import LagrangianToEulerian
 NQ = 8
 
 
-class _NullTimer:
-    class _Ctx:
-        def __enter__(self):
-            return self
-
-        def __exit__(self, *a):
-            return False
-
-    def clock(self, name):
-        return self._Ctx()
+from ...util._timing import NullTimer as _NullTimer  # noqa: E402
 
 
 def fvdyn_temporaries(quantity_factory):

@@ -183,3 +183,48 @@ def test_frozen_stencils_of_the_registry():
     assert np.array_equal(small[ws], big[ws]) and np.count_nonzero(small) == np.count_nonzero(small[ws]) > 0
     with pytest.raises(NotImplementedError, match="no HIP implementation"):
         sf.from_origin_domain(lambda q_in, q_out: None, (0, 0, 0), (3, 3, 3))
+
+
+def test_timer_and_kernel_times():
+    """pace.util.Timer's contract (util/pace/util/_timing.py:9-98; util/tests/test_timer.py) and the per-entry-point collector
+    behind StencilFactory.exec_report()."""
+    import time
+
+    from pace_amd.util import NullTimer, Timer
+
+    t = Timer()
+    with t.clock("a"):
+        time.sleep(0.01)
+    t.start("b")
+    with pytest.raises(ValueError, match="already started"):
+        t.start("b")
+    with pytest.warns(RuntimeWarning):
+        assert "b" not in t.times
+    t.stop("b")
+    with t.clock("a"):
+        pass
+    assert t.hits == {"a": 2, "b": 1} and t.times["a"] >= 0.01
+    t.disable()
+    with t.clock("c"):
+        pass
+    assert "c" not in t.times and not t.enabled
+    t.enable()
+    t.reset()
+    assert t.times == {} and t.hits == {}
+    n = NullTimer()
+    with n.clock("x"):
+        pass
+    assert n.times == {}
+    with pytest.raises(NotImplementedError):
+        n.enable()
+    # the step_dynamics timer argument accumulates the reference's three phase names (fv_dynamics.py:505-545)
+    from helpers import build_emu
+    from pace_amd import _lib
+
+    lib = _lib.Library(build_emu())
+    from test_emu_kernels import _lone_dycore
+
+    core, state, _ = _lone_dycore(lib)
+    timer = Timer()
+    core.step_dynamics(state, timer)
+    assert set(timer.hits) == {"DynCore", "TracerAdvection", "Remapping"} and all(v == 1 for v in timer.hits.values())

@@ -313,3 +313,29 @@ def test_dynamical_core_step_six_processes_gloo(tmp_path):
     _wait_all(procs, 900)
     outs = [pickle.load(open(tmp_path / f"dy{r}.pkl", "rb")) for r in range(6)]
     check_dycore([golden(f"dycore_c12_tile{t}.npz") for t in range(6)], outs)
+
+
+def test_bench_six_ranks_dry_run_over_gloo(tmp_path):
+    """`bench.py --gpus 6` as the driver launches it (torch.distributed.run, one rank per tile), here on the CPU: gloo instead
+    of RCCL and the emulation build of the kernels (--emulate).  Checks that the six-rank path runs end to end -- cubed-sphere
+    partitioner, HIP-source pack / grouped exchange / unpack of delp, pt, q_con inside every step, barrier, max-over-ranks
+    reduction -- and that rank 0 prints ONE JSON line of the contract's shape."""
+    import json
+
+    build_emu()
+    port = 35500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "6", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1", "--tile-size", "12",
+           "--nz", "8", "--emulate", "--watchdog", "240"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 6 and out["steps"] == 2 and out["scaling"] == "weak" and out["dtype"] == "f64"
+    assert out["config"]["tiles"] == 6 and "cubed sphere" in out["config"]["halo_exchange"]
+    assert out["value"] > 0 and "EMULATION" in out["data"]
