@@ -142,7 +142,7 @@ def measure_traffic(kernel_substring, n, nz):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "--", sys.executable, os.path.abspath(__file__), "--steps", "3",
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--steps", "3",
                    "--warmup", "1", "--n", str(n), "--nz", str(nz), "--no-cpu-baseline", "--no-traffic"]
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             if p.returncode != 0:

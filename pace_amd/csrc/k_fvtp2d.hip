@@ -28,6 +28,35 @@ static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the tr
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
+// Workgroup -> (tile, level).  Workgroups are handed to the eight XCDs round-robin in launch order, and every XCD has its own
+// 4 MB L2: with the plain (x, y, z) order, neighbouring tiles of a level land on DIFFERENT XCDs and every line of their
+// overlapping footprints is fetched from memory once per XCD (measured: 1.9 x the algorithmic bytes).  Here a level belongs to
+// ONE XCD: XCD x works through levels x, x + 8, x + 16, ... tile by tile, so the halo lines shared by neighbouring tiles are
+// L2 hits.  (Affinity only: nothing depends on where a workgroup really runs.)
+struct TileId {
+  int bx, by, bz;
+};
+__device__ __forceinline__ TileId tile_of_workgroup() {
+#if defined(PACE_EMU) || defined(FV_PLAIN_ORDER)
+  return TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#else
+  const int gx = gridDim.x, gy = gridDim.y, nlev = gridDim.z;
+  const int tpl = gx * gy;
+  const int b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int full = (nlev / 8) * 8;  // levels that can be dealt out eight at a time
+  int lev, t;
+  if (b < full * tpl) {
+    const int xcd = b & 7, slot = b >> 3;
+    lev = (slot / tpl) * 8 + xcd;
+    t = slot - (slot / tpl) * tpl;
+  } else {
+    lev = b / tpl;
+    t = b - lev * tpl;
+  }
+  return TileId{t % gx, t / gx, lev};
+#endif
+}
+
 // Stage-time instrumentation (experiments only: `make prof` builds build/prof/libpace_prof.so with -DFV_PROF; the product
 // library contains none of this).  One interior workgroup per level records the shader clock at every stage boundary.
 #ifdef FV_PROF
@@ -87,9 +116,10 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   auto& sxin = L.sxin;
 
   const int tid = threadIdx.x;
-  const int i0 = g.is + blockIdx.x * TI;
-  const int j0 = g.js + blockIdx.y * TJ;
-  const int k = blockIdx.z;
+  const TileId wg = tile_of_workgroup();
+  const int i0 = g.is + wg.bx * TI;
+  const int j0 = g.js + wg.by * TJ;
+  const int k = wg.bz;
   const long kb = (long)k * g.sk;
   const int ilo = i0 - 3, jlo = j0 - 3;
   const int sj = g.sj;
@@ -462,7 +492,8 @@ __global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const double* _
   // x-interfaces evaluated: i0 .. i0+TI (their al's reach one further each way); special forms at is-1 .. is+1 and
   // ie .. ie+2
   __shared__ FvLds<DMODE, EPI> L;
-  const int i0 = g.is + blockIdx.x * TI, j0 = g.js + blockIdx.y * TJ;
+  const TileId wg = tile_of_workgroup();
+  const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
   // (ord 8: the special CELLS are s-1 .. s+1 and e-1 .. e+1; the cells evaluated are i0-1 .. i0+TI -- the same test)
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);

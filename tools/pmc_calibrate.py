@@ -7,8 +7,8 @@ destination fields at C384 x 79 (98 MB each way per launch, 2.3 GB in total: far
 the exact byte counts per launch.  Run it under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
 passes), then `python tools/pmc_calibrate.py --report <fetch dir> <write dir>` gives counter-to-byte factors.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/cal_fetch -- python3 tools/pmc_calibrate.py
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/cal_write -- python3 tools/pmc_calibrate.py
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/cal_fetch -- python3 tools/pmc_calibrate.py
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/cal_write -- python3 tools/pmc_calibrate.py
     python3 tools/pmc_calibrate.py --report gpurun_out/cal_fetch gpurun_out/cal_write > profiles/r02_pmc_calibration.json
 """
 import csv
