@@ -760,9 +760,10 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     FvDamp dp{};
     dp.damp_k = d_dampfac_vt_c; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
     dp.fx2o = W.ut2; dp.fy2o = W.vt2; dp.add2d = m.fC_agrid;
+    // ... and u_and_v_from_ke finished in the kernel's store phase: the vorticity fluxes never reach memory
+    dp.u_upd = u; dp.v_upd = v; dp.ke = W.ke;
     if ((rc = launch_transport(g, m, W.wk, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, 0, 0, dp, st))) return rc;
   }
-  hipLaunchKernelGGL(k_uv_from_ke, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.ke, W.fy2, W.fyv);
   }
   if (phases & 8) {
   hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,

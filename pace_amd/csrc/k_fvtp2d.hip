@@ -367,7 +367,12 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
         if (DMODE == 1) v = v + dvx[f];
         if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - 8) + LD(dp.mass, c)) * dvx[f];
         if (EPI == 0) {
-          ST(fx, c) = v;
+          if (dp.v_upd) {  // v_from_ke (d_sw.py:423-436): same expression, same order as the stand-alone kernel
+            const unsigned c2 = OFF2(gi0 + f, gj);
+            ST(dp.v_upd, c) = LD(dp.v_upd, c) * LD(m.dy, c2) + LD(dp.ke, c) - LD(dp.ke, c + sj8) - v;
+          } else {
+            ST(fx, c) = v;
+          }
           if (dp.accx && (ii0 + f < TI || gi0 + f == g.ie + 1)) ST(dp.accx, c) = LD(dp.accx, c) + v;
         }
         vxf[f] = v;
@@ -404,7 +409,12 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
         if (DMODE == 1) v = v + dvy[f];
         if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - sj8) + LD(dp.mass, c)) * dvy[f];
         if (EPI == 0) {
-          ST(fy, c) = v;
+          if (dp.u_upd) {  // u_from_ke (d_sw.py:406-420)
+            const unsigned c2 = OFF2(gi, gj0 + f);
+            ST(dp.u_upd, c) = LD(dp.u_upd, c) * LD(m.dx, c2) + LD(dp.ke, c) - LD(dp.ke, c + 8) + v;
+          } else {
+            ST(fy, c) = v;
+          }
           if (dp.accy) ST(dp.accy, c) = LD(dp.accy, c) + v;
         }
         vyf[f] = v;

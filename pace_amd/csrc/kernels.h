@@ -34,6 +34,12 @@ struct FvDamp {
   // optional 2-D field added to q AFTER the fused damping has read it: the transported scalar is q + add2d while the damped
   // one is q (d_sw: absolute vorticity = relative vorticity + fC_agrid, d_sw.py:389-402, damping acts on the relative one)
   const double* add2d;
+  // optional (EPI == 0): instead of storing the fluxes, finish u_and_v_from_ke (d_sw.py:406-477) with them -- the transported
+  // scalar is then the absolute vorticity: u = u * dx + ke - ke[i+1] + fy, v = v * dy + ke - ke[j+1] - fx, each on the face the
+  // flux lives on, by the workgroup that owns the face
+  double* u_upd;
+  double* v_upd;
+  const double* ke;
 };
 
 int launch_transport(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
