@@ -16,7 +16,7 @@ import sys
 def main(dirs):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
-        for f in glob.glob(d + "/*counter_collection.csv"):
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
