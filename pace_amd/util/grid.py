@@ -79,6 +79,15 @@ class GridData:
             self.a2b_corner_w = np.zeros((4, 3))
         self._struct = None
 
+    @classmethod
+    def new_from_metric_terms(cls, metric_terms) -> "GridData":
+        """grid/helper.py:306-350: the container of a rank's metric terms, from pace_amd.util.gridgen.MetricTerms."""
+        keep = {k: v for k, v in metric_terms.terms.items() if k not in ("ee1", "ee2", "es1", "ew2")}
+        gd = cls(metric_terms.quantity_factory, keep)
+        gd._unit_vectors = {k: metric_terms.terms[k] for k in ("ee1", "ee2", "es1", "ew2")}
+        gd._tile = metric_terms._tile
+        return gd
+
     def c_struct(self) -> _lib.Metrics:
         if self._struct is None:
             m = _lib.Metrics()
@@ -97,6 +106,11 @@ class GridData:
 
 class DampingCoefficients:
     """helper.py:21-45: view of the same storage under the reference's second container name."""
+
+    @classmethod
+    def new_from_metric_terms(cls, metric_terms, grid_data: "GridData" = None) -> "DampingCoefficients":
+        """helper.py:33-42.  Pass the GridData made from the same metric terms to share its device storage."""
+        return cls(grid_data if grid_data is not None else GridData.new_from_metric_terms(metric_terms))
 
     def __init__(self, grid_data: GridData):
         self._grid_data = grid_data

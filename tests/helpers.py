@@ -223,6 +223,8 @@ def _child_main(what, out_path, hard_exit=False):
         result = run_dycore_six_tiles(lib, "cuda")
     elif what == "dycore_k2":
         result = run_dycore_six_tiles(lib, "cuda", prefix="dycore_k2_c12")
+    elif what == "dycore_generated":
+        result = (run_dycore_six_tiles(lib, "cuda", generated="metrics"), run_dycore_six_tiles(lib, "cuda", generated="all"))
     else:
         raise ValueError(what)
     with open(out_path, "wb") as f:
@@ -428,7 +430,22 @@ def dycore_condensates(tile, shape):
     return out
 
 
-def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None):
+def generated_inputs(n, nz):
+    """Per tile (metrics, state arrays) from pace_amd's OWN grid and initial-state generators -- nothing reference-derived."""
+    from pace_amd.fv3core.initialization.baroclinic import baroclinic_state_six_tiles
+    from pace_amd.util import gridgen
+
+    tiles = gridgen.tiles(n, nz)
+    states = baroclinic_state_six_tiles(tiles, n, nz)
+    out = []
+    for t in range(6):
+        m = {k: v for k, v in tiles[t].items() if k not in ("ee1", "ee2", "es1", "ew2")}
+        s = {k: states[t][k] for k in "u v w delz delp pe pk peln phis uc vc ua va pt qvapor ps".split()}
+        out.append((m, s))
+    return out
+
+
+def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None, generated=None):
     """One tile's program: state = the acoustic fixture's inputs (identical to the dycore run's, as the generator asserts)
     with the temperature before the preamble, the vapour and the regenerated condensates; one step_dynamics."""
     import datetime
@@ -441,16 +458,23 @@ def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None)
     from pace_amd.util import CubedSphereCommunicator
 
     tile = comm.Get_rank()
-    metrics = {k[5:]: v for k, v in fix_ac.items() if k.startswith("grid_")}
+    if generated is not None and generated[tile][1] is not None:
+        metrics, arrays = generated[tile]
+        arrays = {k: v.copy() for k, v in arrays.items()}
+        shape = arrays["delp"].shape
+    else:
+        metrics = {k[5:]: v for k, v in fix_ac.items() if k.startswith("grid_")}
+        if generated is not None:
+            metrics = generated[tile][0]
+        arrays = {k: fix_ac["in_" + k] for k in "u v w delz delp pe pk peln phis uc vc ua va".split()}
+        shape = arrays["delp"].shape
+        pt = np.zeros(shape)
+        pt[3:3 + n, 3:3 + n, :] = fix_dy["in_pt"]
+        qv = np.zeros(shape)
+        qv[3:3 + n, 3:3 + n, :] = fix_dy["in_qvapor"]
+        arrays.update(pt=pt, qvapor=qv, ps=fix_dy["in_ps"])
     env = Env(lib, device, metrics, n, nz)
     cube = CubedSphereCommunicator(comm, device=device, lib=lib)
-    arrays = {k: fix_ac["in_" + k] for k in "u v w delz delp pe pk peln phis uc vc ua va".split()}
-    shape = arrays["delp"].shape
-    pt = np.zeros(shape)
-    pt[3:3 + n, 3:3 + n, :] = fix_dy["in_pt"]
-    qv = np.zeros(shape)
-    qv[3:3 + n, 3:3 + n, :] = fix_dy["in_qvapor"]
-    arrays.update(pt=pt, qvapor=qv, ps=fix_dy["in_ps"])
     for name, f in dycore_condensates(tile, shape).items():
         arrays[name] = f * (arrays["delp"] > 0)
     state = DycoreState.init_from_numpy_arrays(arrays, env.qf)
@@ -470,14 +494,17 @@ def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None)
     return out
 
 
-def run_dycore_six_tiles(lib, device, n=12, nz=79, checkpointers=None, prefix="dycore_c12"):
+def run_dycore_six_tiles(lib, device, n=12, nz=79, checkpointers=None, prefix="dycore_c12", generated=False):
     from pace_amd.util import run_tiles
 
     fa = [golden(f"acoustic_c12_tile{t}.npz") for t in range(6)]
     fd = [golden(f"{prefix}_tile{t}.npz") for t in range(6)]
     cps = checkpointers or [None] * 6
+    gen = generated_inputs(n, nz) if generated else None
+    if generated == "metrics":  # pace_amd's grid generator, the reference run's initial state
+        gen = [(m, None) for m, _ in gen]
     return fd, run_tiles(6, lambda comm: run_dycore_tile(comm, lib, device, fa[comm.Get_rank()], fd[comm.Get_rank()], n, nz,
-                                                         cps[comm.Get_rank()]))
+                                                         cps[comm.Get_rank()], generated=gen))
 
 
 def dycore_errors(fix, out, n=12):
@@ -517,6 +544,39 @@ def check_dycore(fixes, outs):
             worst[k] = max(worst.get(k, 0.0), e)
     for k, e in worst.items():
         assert e < DYCORE_TOL.get(k, 1e-9), (k, e)
+    return worst
+
+
+# Envelope of the fully generated run (tools/wind_noise_sensitivity.py): one step of the REFERENCE ALGORITHM (the oracle)
+# moves by u, v 1.8e-4, w 6e-6, ua / va 1.4e-6, delp 6e-9 of the field's magnitude when 1e-13 m/s of noise is added to the
+# winds of this zonal-flow state (upwind / limiter branches decided by wind components that are zero by symmetry); the
+# generated winds differ from the reference's by up to 3e-13 m/s, so that is the accuracy an end-to-end comparison can have.
+GENERATED_TOL = {"u": 1e-3, "v": 1e-3, "va": 1e-3, "ua": 1e-5, "w": 5e-5, "omga": 5e-5, "mfxd": 5e-6, "mfyd": 5e-6,
+                 "cxd": 5e-6, "cyd": 5e-6}
+
+
+def check_dycore_generated(fixes, outs):
+    worst = dycore_scaled_errors(fixes, outs)
+    for k, e in worst.items():
+        assert e < GENERATED_TOL.get(k, 5e-7), (k, e)
+    return worst
+
+
+def dycore_scaled_errors(fixes, outs, n=12):
+    """max |got - ref| / max |ref| per variable over the six tiles (fixture's level subset)."""
+    worst = {}
+    for fix, out in zip(fixes, outs):
+        ks = fix["k_sel"]
+        for k in DYCORE_OUT:
+            di = 1 if k in ("v", "mfxd", "cxd") else 0
+            dj = 1 if k in ("u", "mfyd", "cyd") else 0
+            nk = 80 if k in ("pe", "pk", "peln") else 79
+            kk = [x for x in ks if x < nk]
+            idx = [list(ks).index(x) for x in kk]
+            got = out[k][3:3 + n + di, 3:3 + n + dj][:, :, kk]
+            ref = fix["out_" + k][:n + di, :n + dj][:, :, idx]
+            e = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-300))
+            worst[k] = max(worst.get(k, 0.0), e)
     return worst
 
 

@@ -602,3 +602,14 @@ def test_standalone_ppm_and_divergence_damping_match_oracle(lib):
     from opchain import check_standalone_operators
 
     check_standalone_operators(lib, "cuda", 96, 20, exact=True)
+
+
+def test_dynamical_core_step_from_generated_inputs_matches_reference_run(lib, tmp_path):
+    """The GPU twin of test_dynamical_core_step_from_generated_inputs_emulated: (a) generated grid + the reference run's
+    initial state, (b) generated grid + generated baroclinic state -> one whole step on six tiles -> the reference run's
+    output, (b) within the algorithm's own sensitivity to 1e-13 m/s of wind noise (helpers.GENERATED_TOL)."""
+    from helpers import check_dycore, check_dycore_generated
+
+    (fixes, outs), (fixes2, outs2) = run_in_child("dycore_generated", tmp_path)
+    check_dycore(fixes, outs)
+    check_dycore_generated(fixes2, outs2)
