@@ -121,3 +121,6 @@ class DampingCoefficients:
 def geom_struct(quantity_factory) -> _lib.Geom:
     s = quantity_factory.sizer
     return _lib.Geom(s.nx, s.nz, quantity_factory.row_stride, 0, quantity_factory.level_stride)
+
+
+from .gridgen import MetricTerms  # noqa: E402,F401  (pace.util.grid exports the three names together)
