@@ -7,6 +7,7 @@ The product path is ``load()``: it loads ``pace_amd/libpace_hip.so`` (built in-t
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libpace_hip.so")
@@ -165,9 +166,20 @@ class Library:
 
     timing = None  # a pace_amd.util.KernelTimes while per-entry-point device times are being collected
 
+    # PACE_TRACE_CALLS=1: name every entry point on stderr and wait for the device after it, so that an asynchronous device
+    # fault is reported right after the call that caused it (debugging aid; serialises everything)
+    _trace = bool(os.environ.get("PACE_TRACE_CALLS"))
+
     def call(self, name, *args):
         end = self.timing.bracket(name) if self.timing is not None else None
+        if self._trace:
+            sys.stderr.write(f"[pace] {name}\n")
+            sys.stderr.flush()
         rc = getattr(self.cdll, name)(*args)
+        if self._trace and "emu" not in os.path.basename(self.path):
+            import torch
+
+            torch.cuda.synchronize()
         if end is not None:
             end.record()
         if rc != 0:

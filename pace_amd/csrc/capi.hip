@@ -6,6 +6,7 @@
 #include <cstdio>
 
 thread_local char g_pace_err[256] = "";
+int g_pace_sync_launches = getenv("PACE_SYNC_LAUNCHES") != nullptr;
 void pace_set_err(const char* where, hipError_t e) {
   snprintf(g_pace_err, sizeof(g_pace_err), "%s: %s", where, hipGetErrorString(e));
 }

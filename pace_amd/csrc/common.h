@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/pace_hip.h"
 
@@ -311,13 +312,21 @@ static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsig
 extern thread_local char g_pace_err[256];
 void pace_set_err(const char* where, hipError_t e);
 
-#define PACE_CHECK_LAUNCH()                               \
-  do {                                                    \
-    hipError_t err__ = hipGetLastError();                 \
-    if (err__ != hipSuccess) {                            \
-      pace_set_err(__func__, err__);                      \
-      return PACE_ERR_LAUNCH;                             \
-    }                                                     \
+// PACE_SYNC_LAUNCHES=1 in the environment: name every launch site on stderr and wait for the device there (debugging aid:
+// an asynchronous device fault is then reported right after the launch that caused it).
+extern int g_pace_sync_launches;
+#define PACE_CHECK_LAUNCH()                                        \
+  do {                                                             \
+    hipError_t err__ = hipGetLastError();                          \
+    if (err__ != hipSuccess) {                                     \
+      pace_set_err(__func__, err__);                               \
+      return PACE_ERR_LAUNCH;                                      \
+    }                                                              \
+    if (g_pace_sync_launches) {                                    \
+      fprintf(stderr, "[pace] %s:%d\n", __func__, __LINE__);       \
+      fflush(stderr);                                              \
+      (void)hipDeviceSynchronize();                                \
+    }                                                              \
   } while (0)
 
 static inline dim3 plane_grid(const Geo& g, int nlev) {

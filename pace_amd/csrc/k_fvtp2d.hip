@@ -215,7 +215,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       cy_keep[f] = cc[f];
     }
     const double* dya = m.dya;
-    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gi, p)); }, out);
+    const int gic = gi < g.ni ? gi : g.ni - 1;  // (a tile may stick out of the storage: the metric row must exist)
+    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gic, p)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
@@ -292,7 +293,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       cx_keep[f] = cc[f];
     }
     const double* dxa = m.dxa;
-    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gj)); }, out);
+    const int gjc = gj < g.nj ? gj : g.nj - 1;  // (a tile may stick out of the storage: the metric row must exist)
+    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gjc)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
@@ -356,7 +358,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       xu[f] = calc[f] ? LD(xunit, c) : 0.0;
     }
     const double* dxa = m.dxa;
-    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gj)); }, out);
+    const int gjc = gj < g.nj ? gj : g.nj - 1;  // (a tile may stick out of the storage: the metric row must exist)
+    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gjc)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       vxf[f] = 0.0;
@@ -398,7 +401,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       yu[f] = calc[f] ? LD(yunit, c) : 0.0;
     }
     const double* dya = m.dya;
-    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gi, p)); }, out);
+    const int gic = gi < g.ni ? gi : g.ni - 1;  // (a tile may stick out of the storage: the metric row must exist)
+    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gic, p)); }, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       vyf[f] = 0.0;

@@ -2,6 +2,10 @@
 #include "hip_emu.h"
 
 #include <mutex>
+#include <signal.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 uint3_emu threadIdx, blockIdx;
 dim3 blockDim, gridDim;
@@ -48,10 +52,55 @@ void emu_shuffle_exchange(const void* mine, void* out, int src_lane_in_wave, int
   swapcontext(&g_cur->ctx, &g_main);  // every lane has read
 }
 
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode) {
+namespace {
+const char* volatile g_kernel_name = "(no kernel)";
+char g_altstack[64 * 1024];
+
+// async-signal-safe enough for a test tool: format by hand, write(2), _exit
+void put(const char* s) { (void)!write(2, s, strlen(s)); }
+void put_num(unsigned long v, int base) {
+  char buf[32];
+  int n = 0;
+  do {
+    const int d = (int)(v % (unsigned)base);
+    buf[n++] = (char)(d < 10 ? '0' + d : 'a' + d - 10);
+    v /= (unsigned)base;
+  } while (v);
+  while (n) (void)!write(2, &buf[--n], 1);
+}
+void on_segv(int, siginfo_t* si, void*) {
+  put("[emu] invalid access at 0x");
+  put_num((unsigned long)si->si_addr, 16);
+  put(" in kernel ");
+  put(g_kernel_name);
+  put(" block (");
+  put_num(blockIdx.x, 10), put(","), put_num(blockIdx.y, 10), put(","), put_num(blockIdx.z, 10);
+  put(") thread (");
+  put_num(threadIdx.x, 10), put(","), put_num(threadIdx.y, 10), put(","), put_num(threadIdx.z, 10);
+  put(")\n");
+  _exit(99);
+}
+struct GuardInit {
+  GuardInit() {
+    if (!getenv("PACE_EMU_GUARD")) return;
+    stack_t ss{};
+    ss.ss_sp = g_altstack;
+    ss.ss_size = sizeof(g_altstack);
+    sigaltstack(&ss, nullptr);  // (per thread: the reporter is reliable for kernels launched from the loading thread)
+    struct sigaction sa {};
+    sa.sa_sigaction = on_segv;
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+    sigaction(SIGSEGV, &sa, nullptr);
+    sigaction(SIGBUS, &sa, nullptr);
+  }
+} g_guard_init;
+}  // namespace
+
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode, const char* name) {
   // one launch at a time: the scheduler state is global (several tile threads may call into the library)
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
+  g_kernel_name = name;
   gridDim = grid;
   blockDim = block;
   g_body = &body;

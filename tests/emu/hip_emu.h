@@ -40,18 +40,21 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 
 void __syncthreads();
 // `mode` is per launch site: 0 = not known yet, 1 = the kernel never synchronises (threads run as plain calls),
 // 2 = it does (threads run as fibers).  A kernel that hits __syncthreads() in plain mode is restarted with fibers;
 // that is safe because nothing but LDS is written before a kernel's first barrier.
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode);
+// `name` is what the SIGSEGV reporter prints (PACE_EMU_GUARD=1: tests/guard.py puts every array against an inaccessible
+// page, so an out-of-bounds access of a kernel faults here instead of only on the GPU).
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode, const char* name);
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)            \
-  do {                                                                          \
-    static int emu_mode__ = 0;                                                  \
-    emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); }, &emu_mode__);   \
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                      \
+  do {                                                                                    \
+    static int emu_mode__ = 0;                                                            \
+    emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); }, &emu_mode__, #kernel);    \
   } while (0)
 
 // Wave shuffles (wave = 64 consecutive threads of the block, `width`-lane groups as in HIP): every lane deposits its value,

@@ -245,11 +245,11 @@ def run_in_child(what, tmp_path):
             f"import helpers; helpers._child_main({what!r}, {out!r})")
     p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=900)
     if p.returncode != 0:
-        report = f"child run {what!r} failed (rc {p.returncode}):\n{p.stdout[-4000:]}\n{p.stderr[-8000:]}"
+        report = f"child run {what!r} failed (rc {p.returncode}):\n{p.stdout[-4000:]}\n{p.stderr[:3000]}\n...\n{p.stderr[-8000:]}"
         out_dir = os.path.join(ROOT, "gpurun_out")
         if os.path.isdir(out_dir):
             with open(os.path.join(out_dir, f"child_failure_{what}.txt"), "w") as f:
-                f.write(report)
+                f.write(f"child run {what!r} failed (rc {p.returncode}):\n{p.stdout}\n{p.stderr}")
         raise RuntimeError(report)
     with open(out, "rb") as f:
         return pickle.load(f)

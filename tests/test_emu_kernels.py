@@ -480,14 +480,12 @@ def test_standalone_ppm_and_divergence_damping_emulated_vs_oracle(emu_lib):
 
 
 def test_dynamical_core_step_from_generated_inputs_emulated(emu_lib):
-    """End to end from pace_amd's own generators, one whole DynamicalCore.step_dynamics on six tiles against the OUTPUT of the
-    reference's run (which started from the reference's own MetricTerms and init_baroclinic_state):
-    (a) grid metrics from pace_amd.util.gridgen + the reference run's initial state: the usual DynamicalCore tolerances;
-    (b) nothing reference-derived at all (state from pace_amd's init_baroclinic_state): within the envelope the reference
-        algorithm itself has for 1e-13 m/s of wind noise (helpers.GENERATED_TOL)."""
-    from helpers import check_dycore, check_dycore_generated, run_dycore_six_tiles
+    """End to end with nothing reference-derived: grid metrics from pace_amd.util.gridgen, state from pace_amd's
+    init_baroclinic_state, one whole DynamicalCore.step_dynamics on six tiles -- against the OUTPUT of the reference's run
+    (which started from the reference's own MetricTerms and init_baroclinic_state), within the envelope the reference
+    algorithm itself has for 1e-13 m/s of wind noise (helpers.GENERATED_TOL).  (Generated metrics + the reference run's
+    initial state, at the usual DynamicalCore tolerances: tests/test_guard_pages.py.)"""
+    from helpers import check_dycore_generated, run_dycore_six_tiles
 
-    fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", generated="metrics")
-    check_dycore(fixes, outs)
     fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", generated="all")
     check_dycore_generated(fixes, outs)
