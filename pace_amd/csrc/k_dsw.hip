@@ -7,6 +7,7 @@
 // stored, so each kernel is a pure streaming pass.  HBM-bound.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -232,18 +233,31 @@ __device__ __forceinline__ void remap_bgrid_y(const Geo& g, int& i, int& j) {
   j = s ? g.js - a : g.je + 1 + a;
 }
 
-struct DivIter {
+// accessors of a 2-D plane by global (i, j): a level of a field in memory, or a tile's footprint staged in LDS
+struct PlaneInMemory {
+  const double* p;  // level base applied
+  int sj;
+  __device__ __forceinline__ double operator()(int i, int j) const { return p[(long)j * sj + i]; }
+};
+struct PlaneInLds {
+  const double* s;
+  int ilo, jlo, pitch;
+  __device__ __forceinline__ double operator()(int i, int j) const { return s[(j - jlo) * pitch + (i - ilo)]; }
+};
+
+template <class Plane>
+struct DivIterT {
   const Geo& g;
   const Met& m;
-  const double* d;  // divergence of the previous iterate, level base applied
+  Plane d;  // divergence of the previous iterate
   bool fill;
   __device__ __forceinline__ double dx_(int i, int j) const {  // divg with corners filled in x
     if (fill) remap_bgrid_x(g, i, j);
-    return d[IDX2(g, i, j)];
+    return d(i, j);
   }
   __device__ __forceinline__ double dy_(int i, int j) const {
     if (fill) remap_bgrid_y(g, i, j);
-    return d[IDX2(g, i, j)];
+    return d(i, j);
   }
   __device__ __forceinline__ double vc_raw(int i, int j) const {  // vc_from_divg :188-197
     return (dx_(i + 1, j) - dx_(i, j)) * m.divg_u[IDX2(g, i, j)];
@@ -292,7 +306,7 @@ k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict_
     uc_here = uc0;
     vc_here = vc0;
   } else {
-    DivIter it{g, m, din + (long)kk * g.sk, fill != 0};
+    DivIterT<PlaneInMemory> it{g, m, PlaneInMemory{din + (long)kk * g.sk, g.sj}, fill != 0};
     const double ucm = it.uc(i, j - 1), uc0 = it.uc(i, j), vcm = it.vc(i - 1, j), vc0 = it.vc(i, j);
     d = ucm - uc0 + vcm - vc0;  // redo_divg_d :212-240
     const bool ic = (i == g.is || i == g.ie + 1);
@@ -326,6 +340,25 @@ static void launch_divdamp_iter(const Geo& g, const Met& m, const double* din, d
 // a2b_ord4 (a2b_ord4.py:59-506) as a point function, + the tail of DivergenceDamping.__call__
 // (smagorinsky_diffusion_approx :243-251, damping_nord_highorder_stencil :161-185)
 // ------------------------------------------------------------------------------------------------
+template <class Plane>
+__device__ __forceinline__ double a2b_interior_point(const Plane& Q, int i, int j) {
+  // is+2 <= i <= ie-1 and js+2 <= j <= je-1: every qx / qy involved is the plain 4-point mean (a2b_ord4.py:329-506)
+  const double a1 = 9.0 / 16.0, a2 = -1.0 / 16.0, b1 = 7.0 / 12.0, b2 = -1.0 / 12.0;
+  double v[4][4];  // v[b][a] = Q(i-2+a, j-2+b)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[b][a] = Q(i - 2 + a, j - 2 + b);
+  double qx_[4], qy_[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) qx_[b] = b2 * (v[b][0] + v[b][3]) + b1 * (v[b][1] + v[b][2]);  // qx(i, j-2+b)
+#pragma unroll
+  for (int a = 0; a < 4; ++a) qy_[a] = b2 * (v[0][a] + v[3][a]) + b1 * (v[1][a] + v[2][a]);  // qy(i-2+a, j)
+  const double qxx = a2 * (qx_[0] + qx_[3]) + a1 * (qx_[1] + qx_[2]);
+  const double qyy = a2 * (qy_[0] + qy_[3]) + a1 * (qy_[1] + qy_[2]);
+  return 0.5 * (qxx + qyy);
+}
+
 struct A2B {
   const Geo& g;
   const Met& m;
@@ -409,24 +442,7 @@ struct A2B {
     }
     return (ec[0] + ec[1] + ec[2]) * (1.0 / 3.0);
   }
-  // is+2 <= i <= ie-1 and js+2 <= j <= je-1: every qx / qy involved is the plain 4-point mean (a2b_ord4.py:329-506)
-  __device__ __forceinline__ double point_interior(int i, int j) const {
-    const double a1 = 9.0 / 16.0, a2 = -1.0 / 16.0, b1 = 7.0 / 12.0, b2 = -1.0 / 12.0;
-    double v[4][4];  // v[b][a] = Q(i-2+a, j-2+b)
-    const double* p = q + IDX2(g, i - 2, j - 2);
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) v[b][a] = p[a + (long)b * g.sj];
-    double qx_[4], qy_[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) qx_[b] = b2 * (v[b][0] + v[b][3]) + b1 * (v[b][1] + v[b][2]);  // qx(i, j-2+b)
-#pragma unroll
-    for (int a = 0; a < 4; ++a) qy_[a] = b2 * (v[0][a] + v[3][a]) + b1 * (v[1][a] + v[2][a]);  // qy(i-2+a, j)
-    const double qxx = a2 * (qx_[0] + qx_[3]) + a1 * (qx_[1] + qx_[2]);
-    const double qyy = a2 * (qy_[0] + qy_[3]) + a1 * (qy_[1] + qy_[2]);
-    return 0.5 * (qxx + qyy);
-  }
+  __device__ __forceinline__ double point_interior(int i, int j) const { return a2b_interior_point(PlaneInMemory{q, g.sj}, i, j); }
   __device__ double point(int i, int j) const {  // value of qout at B-grid point (i, j), is <= i,j <= ie+1
     const double a1 = 9.0 / 16.0, a2 = -1.0 / 16.0, c1 = 2.0 / 3.0, c2 = -1.0 / 6.0;
     const bool iw = (i == g.is), ie_ = (i == g.ie + 1), js_ = (j == g.js), jn = (j == g.je + 1);
@@ -500,6 +516,288 @@ k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* 
   vort_b[c] = vort;
   ke[c] = ke[c] + vort;
   divgd_out[c] = dfin;  // the caller's divgd ends as the iterated divergence (redo_divg_d; compared by TranslateD_SW)
+}
+
+// ------------------------------------------------------------------------------------------------
+// DivergenceDamping, nord > 0 levels, as ONE kernel per (tile, level): the `nord` passes of the divergence of the gradient
+// of the divergence run in LDS on the tile's footprint (halo `nord` <= 3, shrinking by one per pass like the reference's
+// domains, divergence_damping.py:579-600), the last pass at the tile's own points with its uc / vc kept for the caller,
+// then the tail (a2b_ord4 of the relative vorticity, Smagorinsky term, damped vorticity, ke += ...).  `din` holds the
+// divergence c_sw left (the caller copies it to delpc first -- copy_computeplus, :578 -- so din == delpc and this kernel
+// may overwrite divg_d while neighbouring tiles still read their halo from delpc).
+// Replaces 3 x k_divdamp_iter + k_divdamp_high_final: 10 field passes instead of 16.
+// ------------------------------------------------------------------------------------------------
+#ifndef DD_TI
+#define DD_TI 65  // 193 = 3 * 65 - 2 B-grid points per row at C192
+#define DD_TJ 25  // 193 = 8 * 25 - 7
+#endif
+#define DD_W (DD_TI + 6)
+#define DD_H (DD_TJ + 6)
+#define DD_NE ((DD_W * DD_H + 255) / 256)
+#define DD_NP ((DD_TI * DD_TJ + 255) / 256)
+
+template <class Plane>
+__device__ __forceinline__ void divdamp_point(const Geo& g, const Met& m, const Plane& src, int i, int j, bool fill, double& d,
+                                              double& uc_here, double& vc_here) {
+  const long c2 = IDX2(g, i, j);
+  if (i > g.is && i <= g.ie) {
+    // columns is+1 .. ie: no operand lies in a corner region and no corner adjustment applies
+    const int sj = g.sj;
+    const double d0 = src(i, j);
+    const double ucm = (d0 - src(i, j - 1)) * m.divg_v[c2 - sj];
+    const double uc0 = (src(i, j + 1) - d0) * m.divg_v[c2];
+    const double vcm = (d0 - src(i - 1, j)) * m.divg_u[c2 - 1];
+    const double vc0 = (src(i + 1, j) - d0) * m.divg_u[c2];
+    d = ucm - uc0 + vcm - vc0;
+    uc_here = uc0;
+    vc_here = vc0;
+  } else {
+    DivIterT<Plane> it{g, m, src, fill};
+    const double ucm = it.uc(i, j - 1), uc0 = it.uc(i, j), vcm = it.vc(i - 1, j), vc0 = it.vc(i, j);
+    d = ucm - uc0 + vcm - vc0;  // redo_divg_d :212-240
+    const bool ic = (i == g.is || i == g.ie + 1);
+    if (ic && j == g.js) d = d - ucm;
+    if (ic && j == g.je + 1) d = d + uc0;
+    uc_here = uc0;
+    vc_here = vc0;
+  }
+  d = d * m.rarea_c[c2];
+}
+
+#define DD_WKW (DD_TI + 3)  // relative vorticity (A-grid cells) under the tile's B-grid points: [i0-2, i0+TI] x [j0-2, j0+TJ]
+#define DD_WKH (DD_TJ + 3)
+#define DD_NW ((DD_WKW * DD_WKH + 255) / 256)
+static_assert(DD_WKW * DD_WKH <= DD_W * DD_H, "the vorticity tile reuses a divergence plane");
+
+// One pass at the footprint points T0 <= t < T1 of this thread that lie in columns is+1 .. ie (no corner region involved):
+// all metric loads first, then the arithmetic (a loop that loads, computes and stores point by point exposes one L2 latency
+// per point -- measured on the transport kernel, and again on the first version of this kernel: 229 us instead of 70).
+template <int T0, int T1>
+__device__ __forceinline__ void dd_pass_batch(const Geo& g, const Met& m, const double* __restrict__ src, double* __restrict__ dst,
+                                              int tid, int ilo, int jlo, int ia, int ib, int ja, int jb) {
+  constexpr int NB = T1 - T0;
+  double dvm[NB], dv0[NB], dum[NB], du0[NB], ra[NB];
+  bool on[NB];
+  const int fa = ia > g.is + 1 ? ia : g.is + 1, fb = ib < g.ie ? ib : g.ie;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const int e = tid + 256 * (T0 + t);
+    const int jj = e / DD_W, ii = e - jj * DD_W;
+    const int gi = ilo + ii, gj = jlo + jj;
+    on[t] = e < DD_W * DD_H && gi >= fa && gi <= fb && gj >= ja && gj <= jb;
+    const long c2 = on[t] ? IDX2(g, gi, gj) : IDX2(g, g.is + 1, g.js);
+    dvm[t] = m.divg_v[c2 - g.sj];
+    dv0[t] = m.divg_v[c2];
+    dum[t] = m.divg_u[c2 - 1];
+    du0[t] = m.divg_u[c2];
+    ra[t] = m.rarea_c[c2];
+  }
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const int e = tid + 256 * (T0 + t);
+    if (on[t]) {
+      const double d0 = src[e];
+      const double ucm = (d0 - src[e - DD_W]) * dvm[t];
+      const double uc0 = (src[e + DD_W] - d0) * dv0[t];
+      const double vcm = (d0 - src[e - 1]) * dum[t];
+      const double vc0 = (src[e + 1] - d0) * du0[t];
+      double d = ucm - uc0 + vcm - vc0;
+      d = d * ra[t];
+      dst[e] = d;
+    }
+  }
+}
+
+// The tail at the own points T0 <= t < T1 of this thread that are plain in every respect (pass: columns is+1 .. ie; a2b_ord4:
+// the 16-point mean): loads first, then arithmetic.
+template <int T0, int T1>
+__device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const double* __restrict__ src,
+                                              const double* __restrict__ swk, const double* __restrict__ din,
+                                              double* __restrict__ divg_d, double* __restrict__ vort_b, double* __restrict__ ke,
+                                              double* __restrict__ uc_out, double* __restrict__ vc_out, double d2, double dddmp,
+                                              double dd8, double absdt, int tid, int i0, int j0, long kb) {
+  constexpr int NB = T1 - T0;
+  double dvm[NB], dv0[NB], dum[NB], du0[NB], ra[NB], dpc[NB], ke0[NB];
+  bool on[NB];
+  long cc[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const int q = tid + 256 * (T0 + t);
+    const int jj = q / DD_TI, ii = q - jj * DD_TI;
+    const int i = i0 + ii, j = j0 + jj;
+    on[t] = q < DD_TI * DD_TJ && g.n >= 8 && i >= g.is + 2 && i <= g.ie - 1 && j >= g.js + 2 && j <= g.je - 1;
+    const long c2 = on[t] ? IDX2(g, i, j) : IDX2(g, g.is + 1, g.js);
+    cc[t] = kb + c2;
+    dvm[t] = m.divg_v[c2 - g.sj];
+    dv0[t] = m.divg_v[c2];
+    dum[t] = m.divg_u[c2 - 1];
+    du0[t] = m.divg_u[c2];
+    ra[t] = m.rarea_c[c2];
+    dpc[t] = din[cc[t]];
+    ke0[t] = ke[cc[t]];
+  }
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    if (!on[t]) continue;
+    const int q = tid + 256 * (T0 + t);
+    const int jj = q / DD_TI, ii = q - jj * DD_TI;
+    const int e = (jj + 3) * DD_W + ii + 3;
+    const double d0 = src[e];
+    const double ucm = (d0 - src[e - DD_W]) * dvm[t];
+    const double uc0 = (src[e + DD_W] - d0) * dv0[t];
+    const double vcm = (d0 - src[e - 1]) * dum[t];
+    const double vc0 = (src[e + 1] - d0) * du0[t];
+    double dfin = ucm - uc0 + vcm - vc0;
+    dfin = dfin * ra[t];
+    const long c = cc[t];
+    uc_out[c] = uc0;  // (own points here have j <= je and i <= ie)
+    vc_out[c] = vc0;
+    double vb;
+    if (dddmp < 1e-5) {
+      vb = 0.0;
+    } else {
+      const double qb = a2b_interior_point(PlaneInLds{swk, i0 - 2, j0 - 2, DD_WKW}, i0 + ii, j0 + jj);
+      vb = absdt * sqrt(dpc[t] * dpc[t] + qb * qb);
+    }
+    const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(vb)));
+    const double vort = damp * dpc[t] + dd8 * dfin;
+    vort_b[c] = vort;
+    ke[c] = ke0[t] + vort;
+    divg_d[c] = dfin;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_divdamp_fused(Geo g, Met m, const double* __restrict__ wk, const double* __restrict__ din, double* __restrict__ divg_d,
+                double* __restrict__ vort_b, double* __restrict__ ke, double* __restrict__ uc_out, double* __restrict__ vc_out,
+                const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx) {
+  __shared__ double sbuf[2][DD_W * DD_H];
+  const int tid = threadIdx.x;
+  const int bx = (int)blockIdx.x % ntx, by = (int)blockIdx.x / ntx;
+  const int i0 = g.is + bx * DD_TI, j0 = g.js + by * DD_TJ;
+  const int ilo = i0 - 3, jlo = j0 - 3;
+  const int kk = (int)blockIdx.z + k0;
+  const long kb = (long)kk * g.sk;
+  // the divergence on the footprint, and (kept in registers until a plane is free) the relative vorticity under the tile
+  double wreg[DD_NW];
+  {
+    double dreg[DD_NE];
+#pragma unroll
+    for (int t = 0; t < DD_NE; ++t) {
+      const int e = tid + 256 * t;
+      const int jj = e / DD_W, ii = e - jj * DD_W;
+      const int gi = ilo + ii, gj = jlo + jj;
+      const bool ok = e < DD_W * DD_H && gi < g.ni && gj < g.nj;
+      dreg[t] = din[kb + (ok ? IDX2(g, gi, gj) : 0)];
+      if (!ok) dreg[t] = 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < DD_NW; ++t) {
+      const int e = tid + 256 * t;
+      const int jj = e / DD_WKW, ii = e - jj * DD_WKW;
+      const int gi = i0 - 2 + ii, gj = j0 - 2 + jj;
+      const bool ok = e < DD_WKW * DD_WKH && gi < g.ni && gj < g.nj;
+      wreg[t] = wk[kb + (ok ? IDX2(g, gi, gj) : 0)];
+      if (!ok) wreg[t] = 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < DD_NE; ++t) {
+      const int e = tid + 256 * t;
+      if (e < DD_W * DD_H) sbuf[0][e] = dreg[t];
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  // two batches per pass (25 / 20 metric loads in flight; 146 VGPRs = three workgroups per CU.  Three batches at a forced
+  // 128 registers -- four workgroups -- measured 5 % slower)
+  constexpr int E1 = (DD_NE + 1) / 2;
+  for (int n = 1; n < nord; ++n) {
+    const int nt = nord - n;
+    const int ia = i0 - nt, ja = j0 - nt;  // (i0 >= is, j0 >= js)
+    const int ib = (g.ie + 1 < i0 + DD_TI - 1 ? g.ie + 1 : i0 + DD_TI - 1) + nt;
+    const int jb = (g.je + 1 < j0 + DD_TJ - 1 ? g.je + 1 : j0 + DD_TJ - 1) + nt;
+    const double* src = sbuf[cur];
+    double* dst = sbuf[cur ^ 1];
+    dd_pass_batch<0, E1>(g, m, src, dst, tid, ilo, jlo, ia, ib, ja, jb);
+    if constexpr (DD_NE > E1) dd_pass_batch<E1, DD_NE>(g, m, src, dst, tid, ilo, jlo, ia, ib, ja, jb);
+    if (ia <= g.is || ib > g.ie) {  // block-uniform: the tile touches the west / east edge columns (corner regions, edge forms)
+      const int ncl = ia <= g.is ? g.is - ia + 1 : 0, ncr = ib > g.ie ? ib - g.ie : 0;
+      const int ncol = ncl + ncr, total = ncol * (jb - ja + 1);
+      const PlaneInLds plane{src, ilo, jlo, DD_W};
+      for (int p = tid; p < total; p += 256) {
+        const int r = p / ncol, cx = p - r * ncol;
+        const int gi = cx < ncl ? ia + cx : g.ie + 1 + (cx - ncl), gj = ja + r;
+        double d, u_, v_;
+        divdamp_point(g, m, plane, gi, gj, true, d, u_, v_);
+        dst[(gj - jlo) * DD_W + (gi - ilo)] = d;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // the free plane takes the relative vorticity
+  double* swk = sbuf[cur ^ 1];
+#pragma unroll
+  for (int t = 0; t < DD_NW; ++t) {
+    const int e = tid + 256 * t;
+    if (e < DD_WKW * DD_WKH) swk[e] = wreg[t];
+  }
+  __syncthreads();
+  const double d2 = d2_bg[kk];
+  constexpr int P1 = (DD_NP + 1) / 2;
+  dd_tail_batch<0, P1>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb);
+  if constexpr (DD_NP > P1)
+    dd_tail_batch<P1, DD_NP>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb);
+  // The remaining own points: the frame of the tile domain, two points deep (corner regions, edge forms of the pass and of
+  // a2b_ord4).  They are enumerated densely -- first the tile's frame columns over all of its rows, then its frame rows over
+  // the other columns -- so that a wave that runs the long general code is full (left in place, two lanes of EVERY wave of
+  // an edge tile took that path: 110 of 190 us).
+  const PlaneInLds src{sbuf[cur], ilo, jlo, DD_W};
+  const int i1 = (i0 + DD_TI - 1 < g.ie + 1) ? i0 + DD_TI - 1 : g.ie + 1;  // own points: i0 .. i1, j0 .. j1
+  const int j1 = (j0 + DD_TJ - 1 < g.je + 1) ? j0 + DD_TJ - 1 : g.je + 1;
+  const bool all_frame = g.n < 8;
+  // frame columns [i0, fl) and (fr, i1]; frame rows [j0, fb) and (ft, j1]
+  const int fl = all_frame ? i1 + 1 : (i0 < g.is + 2 ? (g.is + 2 < i1 + 1 ? g.is + 2 : i1 + 1) : i0);
+  const int fr = all_frame ? i1 : (i1 > g.ie - 1 ? (g.ie - 1 > fl - 1 ? g.ie - 1 : fl - 1) : i1);
+  const int fb = all_frame ? j1 + 1 : (j0 < g.js + 2 ? (g.js + 2 < j1 + 1 ? g.js + 2 : j1 + 1) : j0);
+  const int ft = all_frame ? j1 : (j1 > g.je - 1 ? (g.je - 1 > fb - 1 ? g.je - 1 : fb - 1) : j1);
+  const int ncol = (fl - i0) + (i1 - fr), nrow_all = j1 - j0 + 1;
+  const int nmid = fr - fl + 1, nrow = (fb - j0) + (j1 - ft);
+  const int n_a = ncol * nrow_all, n_b = nmid > 0 ? nmid * nrow : 0;
+  for (int p = tid; p < n_a + n_b; p += 256) {
+    int i, j;
+    if (p < n_a) {
+      const int r = p / ncol, cx = p - r * ncol;
+      i = cx < fl - i0 ? i0 + cx : fr + 1 + (cx - (fl - i0));
+      j = j0 + r;
+    } else {
+      const int pp = p - n_a;
+      const int r = pp / nmid, cx = pp - r * nmid;
+      i = fl + cx;
+      j = r < fb - j0 ? j0 + r : ft + 1 + (r - (fb - j0));
+    }
+    double dfin, uc_here, vc_here;
+    divdamp_point(g, m, src, i, j, false, dfin, uc_here, vc_here);
+    const long c = kb + IDX2(g, i, j);
+    const double dpc = din[c];  // the divergence before the passes (= delpc)
+    // The reference uses the caller's uc / vc as the work fields of the passes and its Translate tests compare what is left
+    // in them after d_sw on the staggered compute windows (translate_d_sw.py:36-65): the values of the LAST pass.
+    if (j <= g.je) uc_out[c] = uc_here;
+    if (i <= g.ie) vc_out[c] = vc_here;
+    double vb;
+    if (dddmp < 1e-5) {
+      vb = 0.0;
+    } else {
+      A2B a{g, m, wk + kb};
+      const double qb = a.point(i, j);
+      vb = absdt * sqrt(dpc * dpc + qb * qb);
+    }
+    const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(vb)));
+    const double vort = damp * dpc + dd8 * dfin;
+    vort_b[c] = vort;
+    ke[c] = ke[c] + vort;
+    divg_d[c] = dfin;  // the caller's divgd ends as the iterated divergence (redo_divg_d; compared by TranslateD_SW)
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,6 +896,18 @@ int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k
   return PACE_OK;
 }
 
+__global__ void __launch_bounds__(256) k_copy_levels(Geo g, const double* __restrict__ src, double* __restrict__ dst, int k0) {
+  PLANE_IJK(g);
+  const long c = IDX3(g, i, j, k + k0);
+  dst[c] = src[c];
+}
+
+// PACE_LEGACY_DIVERGENCE_DAMPING=1: the round-1 sequence (one kernel per pass + the tail kernel), kept for A/B measurements
+static bool legacy_divergence_damping() {
+  static const bool v = getenv("PACE_LEGACY_DIVERGENCE_DAMPING") != nullptr;
+  return v;
+}
+
 // DivergenceDamping.__call__ (divergence_damping.py:482-632): second-order damping on the levels above `kstart` (the sponge
 // layers, nord = 0 there), `nonzero_nord` iterations of the divergence of the gradient of the divergence below, then
 // a2b_ord4 of the relative vorticity, the Smagorinsky term and the damped vorticity; ke += damping.  uc, vc and divg_d end as
@@ -612,7 +922,14 @@ int launch_divergence_damping(const Geo& g, const Met& m, const double* u, const
                        d2_bg_dev, dddmp, dt);
   }
   const int nhigh = nk - kstart;
-  if (nhigh > 0) {
+  if (nhigh > 0 && !legacy_divergence_damping()) {
+    // delpc = divg_d (copy_computeplus :578; whole planes, so that the fused kernel can take its footprint from delpc)
+    hipLaunchKernelGGL(k_copy_levels, plane_grid(g, nhigh), dim3(256), 0, st, g, divg_d, delpc, kstart);
+    const double dd8 = pow(m.da_min_c * d4_bg, (double)(nonzero_nord + 1));
+    const int ntx = (g.n + 1 + DD_TI - 1) / DD_TI, nty = (g.n + 1 + DD_TJ - 1) / DD_TJ;
+    hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)nhigh), dim3(256), 0, st, g, m, rel_vort_agrid,
+                       delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart, nonzero_nord, ntx);
+  } else if (nhigh > 0) {
     const double* src = divg_d;
     double* bufs[2] = {da, db};
     for (int n = 0; n < nonzero_nord; ++n) {
