@@ -194,6 +194,15 @@ int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspac
 int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* uc, double* vc,
                     const double* u, const double* v, double* ua, double* va, double* utc, double* vtc, void* stream);
 
+/* ---- Sim1Solver.__call__ (sim1_solver.py:144-219) as a class of its own: the semi-implicit vertical solver on the compute
+ * domain widened by n_halo (the reference builds it with n_halo = 0 for riem_solver3 and 1 for riem_solver_c).  gamma, cp3,
+ * delta_mass, pm, pem, potential_temperature in; pe out (nk + 1 interfaces); w, dz inout; ws 2-D.  workspace:
+ * pace_sim1_solver_workspace_bytes.  Inside pace_riem_solver3 / pace_riem_solver_c the same arithmetic runs fused. */
+int64_t pace_sim1_solver_workspace_bytes(const pace_geom_t* geom);
+int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac, const double* gamma,
+                     const double* cp3, double* pe, const double* delta_mass, const double* pm, const double* pem, double* w,
+                     double* dz, const double* potential_temperature, const double* ws, void* stream);
+
 /* ---- NonhydrostaticVerticalSolverCGrid.__call__ (riem_solver_c.py:160-250), compute domain +- 1. */
 int64_t pace_riem_solver_c_workspace_bytes(const pace_geom_t* geom);
 int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const double* cappa, double ptop,

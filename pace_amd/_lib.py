@@ -99,6 +99,8 @@ _PROTOS = {
     "pace_riem_solver_c": (C.c_int, [_P(Geom), c_dp, C.c_double, c_dp, C.c_double] + [c_dp] * 8 + [C.c_double, C.c_void_p]),
     "pace_updatedzc_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_ppm": (C.c_int, [_P(Geom), _P(Metrics), C.c_int, C.c_int, c_dp, c_dp, c_dp] + [C.c_int] * 6 + [C.c_void_p]),
+    "pace_sim1_solver_workspace_bytes": (C.c_int64, [_P(Geom)]),
+    "pace_sim1_solver": (C.c_int, [_P(Geom), C.c_void_p, C.c_int, C.c_double, C.c_double] + [c_dp] * 10 + [C.c_void_p]),
     "pace_divergence_damping_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_divergence_damping": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 12 + [C.c_double, _P(C.c_double), c_dp, C.c_double,
                                                                                    C.c_double, C.c_int, C.c_void_p]),

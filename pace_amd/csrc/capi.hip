@@ -229,6 +229,17 @@ int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, con
   return launch_riem_solver_c(g, workspace, dt2, cappa, ptop, hs, ws, ptc, q_con, delpc, gz, pef, w3, p_fac, S(stream));
 }
 
+int64_t pace_sim1_solver_workspace_bytes(const pace_geom_t* geom) { return geom ? sim1_workspace_bytes(make_geo(geom)) : 0; }
+
+int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac, const double* gamma,
+                     const double* cp3, double* pe, const double* delta_mass, const double* pm, const double* pem, double* w,
+                     double* dz, const double* potential_temperature, const double* ws, void* stream) {
+  NEED(geom && workspace && gamma && cp3 && pe && delta_mass && pm && pem && w && dz && potential_temperature && ws);
+  if (n_halo < 0 || n_halo > 3 || geom->nk < 2) return PACE_ERR_ARG;
+  return launch_sim1_solver(make_geo(geom), workspace, n_halo, dt, p_fac, gamma, cp3, pe, delta_mass, pm, pem, w, dz,
+                            potential_temperature, ws, S(stream));
+}
+
 int64_t pace_updatedzc_workspace_bytes(const pace_geom_t* geom) {
   return geom ? updatedzc_workspace_bytes(make_geo(geom)) : 0;
 }

@@ -78,6 +78,11 @@ int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const dou
 int launch_riem_solver_c_column(const Geo& g, double dt2, const double* cappa, double ptop, const double* hs, const double* ws3,
                                 const double* ptc, const double* q_con, const double* delpc, double* gz, double* pef,
                                 const double* w3, double p_fac, hipStream_t st);
+// k_sim1.hip: Sim1Solver as a class of its own (not the hot path)
+int64_t sim1_workspace_bytes(const Geo& g);
+int launch_sim1_solver(const Geo& g, void* ws, int n_halo, double dt, double p_fac, const double* gamma, const double* cp3,
+                       double* pe, const double* delta_mass, const double* pm, const double* pem, double* w, double* dz,
+                       const double* pt, const double* ws2d, hipStream_t st);
 // k_csw.hip
 int64_t csw_workspace_bytes(const Geo& g);
 int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, double* uc, double* vc, const double* u, const double* v,

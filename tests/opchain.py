@@ -484,4 +484,36 @@ def check_standalone_operators(lib, device, n, nz, exact):
         e = compare(f[k][W][:, :, :nz], qf[k].numpy()[W][:, :, :nz], near_zero=1e-14 * float(np.abs(f[k][W]).max()))
         errs["divdamp_" + k] = e
         assert e == 0.0 if exact else e < 1.4e-10, (k, e)  # translate_divergencedamping.py:37
+    # Sim1Solver with the inputs riem_solver3 prepares for it (riem_solver3.py:26-91), n_halo = 0 and 1
+    with np.errstate(all="ignore"):
+        pem = np.concatenate([np.full(s["delp"].shape[:2] + (1,), float(m["ptop"])), float(m["ptop"]) + np.cumsum(s["delp"][:, :, :nz], axis=2)], axis=2)
+        pm = np.zeros_like(s["pt"])
+        pm[:, :, :nz] = (pem[:, :, 1:] - pem[:, :, :-1]) / (np.log(pem[:, :, 1:]) - np.log(pem[:, :, :-1]))
+    pm[~np.isfinite(pm)] = 1.0e4
+    pem[~np.isfinite(pem)] = 1.0e4
+    gm = 1.0 / (1.0 - s["cappa"])
+    dmass = s["delp"] * oc.RGRAV
+    dmass[dmass <= 0] = 1.0  # (the allocator's extra level and unused halo cells)
+    dz0 = np.where(s["delz"] < 0, s["delz"], -100.0)
+    for n_halo in (0, 1):
+        f = dict(gamma=gm.copy(), cp3=s["cappa"].copy(), pe=np.zeros_like(s["pt"]), dm=dmass.copy(), pm=pm.copy(), pem=pem.copy(),
+                 w=s["w"].copy(), dz=dz0.copy(), pt=np.where(s["pt"] > 0, s["pt"], 300.0), ws=np.zeros(s["pt"].shape[:2]) + 0.01)
+        q = {k: (env.q3(a) if a.ndim == 3 else env.q2(a)) for k, a in f.items()}
+        from pace_amd.fv3core.stencils.sim1_solver import Sim1Solver
+
+        op = Sim1Solver(env.stencil_factory, 0.05, n_halo)
+        op(s["dt"], q["gamma"], q["cp3"], q["pe"], q["dm"], q["pm"], q["pem"], q["w"], q["dz"], q["pt"], q["ws"])
+        if device != "cpu":
+            torch.cuda.synchronize()
+        vertical.sim1_solve(f["w"], f["dm"], f["gamma"], f["dz"], f["pt"], f["pm"], f["pe"], f["pem"], f["ws"], f["cp3"], s["dt"],
+                            0.05, (3 - n_halo, 3 + n + n_halo, 3 - n_halo, 3 + n + n_halo), nz)
+        Wd = (slice(3 - n_halo, 3 + n + n_halo), slice(3 - n_halo, 3 + n + n_halo))
+        for k, nlev in (("w", nz), ("dz", nz), ("pe", nz + 1)):
+            ref, got = f[k][Wd][:, :, :nlev], q[k].numpy()[Wd][:, :, :nlev]
+            e = compare(ref, got, near_zero=1e-5 * float(np.abs(ref).max()))
+            errs[f"sim1_h{n_halo}_{k}"] = e
+            assert e < 5e-6, (n_halo, k, e)  # the reference's Riem_Solver3 bound (the solver's only Translate-level users)
+            untouched = q[k].numpy().copy() - (np.zeros_like(f[k]) if k == "pe" else (s["w"] if k == "w" else dz0))
+            untouched[Wd] = 0.0
+            assert not untouched[:, :, :nlev].any(), ("written outside the compute domain + n_halo", n_halo, k)
     return errs

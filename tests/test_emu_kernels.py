@@ -472,7 +472,7 @@ def test_acoustic_loop_six_synthetic_tiles_emulated_vs_oracle(emu_lib):
 
 
 def test_standalone_ppm_and_divergence_damping_emulated_vs_oracle(emu_lib):
-    """XPiecewiseParabolic, YPiecewiseParabolic (orders 5, 6, 8) and DivergenceDamping as stand-alone classes (the reference
+    """XPiecewiseParabolic, YPiecewiseParabolic (orders 5, 6, 8), DivergenceDamping and Sim1Solver as stand-alone classes (the reference
     tests them on their own: TranslateXPPM / YPPM / DivergenceDamping): bit for bit against the oracle."""
     from opchain import check_standalone_operators
 
