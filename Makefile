@@ -9,7 +9,16 @@ HDRS := $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/delnflux_core.h include/pace_
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 OBJS := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
 
-all: pace_amd/libpace_hip.so
+all: pace_amd/libpace_hip.so pace_amd/libpace_hip_f32.so
+
+# the float32-storage build (BASELINE configuration 5): the same sources with pace_real_t = float
+F32OBJS := $(patsubst $(CSRC)/%.hip,build/hip_f32/%.o,$(SRCS))
+build/hip_f32/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/hip_f32
+	$(HIPCC) $(HIPFLAGS) -DPACE_REAL_FLOAT -c $< -o $@
+f32: pace_amd/libpace_hip_f32.so
+pace_amd/libpace_hip_f32.so: $(F32OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(F32OBJS) -o $@
 
 build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip
@@ -35,6 +44,14 @@ emu: tests/emu/libpace_emu.so
 tests/emu/libpace_emu.so: $(EMUOBJS) build/emu/hip_emu.o
 	g++ -shared -fPIC $(EMUOBJS) build/emu/hip_emu.o -o $@
 
+EMUF32OBJS := $(patsubst $(CSRC)/%.hip,build/emu_f32/%.o,$(SRCS))
+build/emu_f32/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
+	@mkdir -p build/emu_f32
+	g++ $(EMUFLAGS) -DPACE_REAL_FLOAT -c $< -o $@
+emu-f32: tests/emu/libpace_emu_f32.so
+tests/emu/libpace_emu_f32.so: $(EMUF32OBJS) build/emu/hip_emu.o
+	g++ -shared -fPIC $(EMUF32OBJS) build/emu/hip_emu.o -o $@
+
 # the same, with 4 x 4 transport / damping tiles and runs of 2 interfaces: at C12 this gives workgroups that touch no tile
 # edge, so the straight-line interior code paths and every tile seam are exercised by the CPU test-suite as well
 SMALLFLAGS := $(EMUFLAGS) -DFV_TI=4 -DFV_TJ=4 -DDN_TI=4 -DDN_TJ=4 -DFV_RF=2 -DDD_TI=5 -DDD_TJ=4
@@ -56,6 +73,6 @@ build/prof/libpace_prof.so: $(PROFOBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(PROFOBJS) -o $@
 
 clean:
-	rm -rf build pace_amd/libpace_hip.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so
+	rm -rf build pace_amd/libpace_hip.so pace_amd/libpace_hip_f32.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so tests/emu/libpace_emu_f32.so
 
-.PHONY: all emu emu-small prof clean
+.PHONY: all f32 emu emu-f32 emu-small prof clean

@@ -36,6 +36,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--n", "--tile-size", dest="n", type=int, default=192)  # (--n alone is ambiguous to torch.distributed.run)
     p.add_argument("--nz", type=int, default=79)
+    p.add_argument("--precision", type=int, default=64, choices=(64, 32),
+                   help="storage type of the fields (the headline metric is fp64; 32 runs libpace_hip_f32.so: float32 fields, "
+                        "float64 arithmetic in registers)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     p.add_argument("--watchdog", type=float, default=900.0, help="multi-rank runs: seconds after which a stuck run exits")
@@ -121,7 +124,7 @@ def cpu_baseline(n, nz):
             "one_core_value": n * n * nz / (alone * len(jobs))}
 
 
-def measure_traffic(kernel_substring, n, nz):
+def measure_traffic(kernel_substring, n, nz, precision=64):
     """HBM bytes per launch of the dominant kernel, measured NOW: this script is run twice more as a child under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; no
     tracing domains beyond the kernel trace) for three steps, and the counters of the kernel are averaged.
@@ -143,7 +146,7 @@ def measure_traffic(kernel_substring, n, nz):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--steps", "3",
-                   "--warmup", "1", "--n", str(n), "--nz", str(nz), "--no-cpu-baseline", "--no-traffic"]
+                   "--warmup", "1", "--n", str(n), "--nz", str(nz), "--precision", str(precision), "--no-cpu-baseline", "--no-traffic"]
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             if p.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-300:]}"
@@ -240,7 +243,8 @@ def main():
     from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics
     from pace_amd.fv3core.stencils.riem_solver3 import NonhydrostaticVerticalSolver
 
-    lib = _lib.Library(os.path.join(ROOT, "tests", "emu", "libpace_emu.so")) if args.emulate else _lib.load()
+    lib = _lib.Library(os.path.join(ROOT, "tests", "emu", "libpace_emu.so")) if args.emulate else _lib.load(args.precision)
+    item = float(lib.real_bytes)
     n, nz = args.n, args.nz
     metrics = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(metrics, n, nz)
@@ -348,14 +352,14 @@ def main():
         geom = dsw._geom
         da_min = env.damping.da_min
         nord_t, damp_t = host_column(col["nord_t"], nz), host_column(col["damp_t"], nz)
-        kdev = torch.as_tensor(np.concatenate([(damp_t * da_min) ** (nord_t + 1), nord_t]), device=dev)
+        kdev = torch.as_tensor(np.concatenate([(damp_t * da_min) ** (nord_t + 1), nord_t]), dtype=env.qf.real, device=dev)
         out = env.q3()
 
         def kernel(r):
             b = batches[r % nbatch]  # a different state copy every launch: operands come from HBM, as inside a step
             lib.call("pace_fvtp2d_update", C.byref(geom), C.byref(env.grid_data.c_struct()), b["pt"].ptr, b["crx"].ptr, b["cry"].ptr,
                      b["xfx"].ptr, b["yfx"].ptr, b["mfx"].ptr, b["mfy"].ptr, b["delp"].ptr, kdev.data_ptr(),
-                     kdev.data_ptr() + 8 * nz, int(nord_t.max()), out.ptr, 6, nz, dsw.stream())
+                     kdev.data_ptr() + lib.real_bytes * nz, int(nord_t.max()), out.ptr, 6, nz, dsw.stream())
 
         reps = max(10, args.steps)
         for r in range(3):
@@ -368,12 +372,12 @@ def main():
         torch.cuda.synchronize()
         t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
         # algorithmic bytes per launch: q, crx, cry, xfx, yfx, x/y mass flux, delp in; qout out = 9 fields of N x N x nz doubles
-        algo = TRANSPORT_FIELDS * 8.0 * n * n * nz
+        algo = TRANSPORT_FIELDS * item * n * n * nz
         # HBM bytes per launch: measured live by two child passes under rocprofv3 --pmc (see measure_traffic), null otherwise
         traffic, traffic_detail = (None, "skipped (--no-traffic)")
         if not args.no_traffic and world == 1:
             torch.cuda.synchronize()
-            traffic, traffic_detail = measure_traffic(("k_fvtp2d<6, 2, 1>", "k_fvtp2dILi6ELi2ELi1E"), n, nz)
+            traffic, traffic_detail = measure_traffic(("k_fvtp2d<6, 2, 1>", "k_fvtp2dILi6ELi2ELi1E"), n, nz, args.precision)
         roof = {"kernel": "k_fvtp2d<6, 2, 1>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                 "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo,
@@ -392,13 +396,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if lib.real_bytes == 8 else "f32 storage, f64 arithmetic in registers",
             "data": "synthetic" if not args.emulate else "synthetic (CPU EMULATION DRY RUN: no performance meaning)",
-            "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, fp64",
+            "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, " + ("fp64" if lib.real_bytes == 8 else "fp32 fields"),
                        "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}",
                        "halo_exchange": topology,
                        "launch": "hip graph replay" if use_graph else "eager"},
-            "step_hbm_frac": BYTES_PER_CELL_UPDATE * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "step_hbm_frac": BYTES_PER_CELL_UPDATE * (item / 8.0) * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only

@@ -3,7 +3,7 @@
  * This is the drop-in boundary: each entry point replaces what the reference executes *under*
  * one of its Python classes (a chain of GT4Py FrozenStencil launches, dsl/pace/dsl/stencil.py:395-434).
  * Plain pointers and sizes only; no allocation, no global state, re-entrant per stream.  All
- * `double*` arguments are DEVICE pointers unless stated otherwise.  Every function returns
+ * `pace_real_t*` arguments are DEVICE pointers unless stated otherwise.  Every function returns
  * PACE_OK (0) or a negative PACE_ERR_* code; nothing is written on error.
  *
  * Field layout: 3-D fields are [k][j][i], i fastest, logical shape (N+7, N+7, nz+1) with origin
@@ -17,6 +17,16 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+
+/* Storage type of every DEVICE field, metric and K-array: double in libpace_hip.so, float in libpace_hip_f32.so (the same
+ * sources compiled with -DPACE_REAL_FLOAT; dsl/pace/dsl/typing.py:24 -- the reference's PACE_FLOAT_PRECISION switch).  Strides
+ * in pace_geom_t count elements of this type.  Scalars passed by value, HOST arrays and the arithmetic inside the kernels stay
+ * double in both builds.  pace_real_bytes() tells which build a library is. */
+#ifdef PACE_REAL_FLOAT
+typedef float pace_real_t;
+#else
+typedef double pace_real_t;
 #endif
 
 #define PACE_OK 0
@@ -35,17 +45,17 @@ typedef struct {
 /* Read-only grid metrics, i.e. pace.util.grid.GridData / DampingCoefficients
  * (util/pace/util/grid/helper.py:21-45,306-530).  2-D device arrays with row stride sj. */
 typedef struct {
-  const double *area, *rarea, *rarea_c;
-  const double *dx, *dy, *dxa, *dya, *dxc, *dyc;
-  const double *rdx, *rdy, *rdxa, *rdya, *rdxc, *rdyc;
-  const double *cosa, *rsina, *cosa_u, *cosa_v, *cosa_s;
-  const double *sina_u, *sina_v, *rsin_u, *rsin_v, *rsin2;
-  const double *sin_sg1, *sin_sg2, *sin_sg3, *sin_sg4;
-  const double *cos_sg1, *cos_sg2, *cos_sg3, *cos_sg4;
-  const double *del6_u, *del6_v, *divg_u, *divg_v;
-  const double *fC, *fC_agrid;
-  const double *edge_w, *edge_e; /* length nj, indexed by j */
-  const double *edge_s, *edge_n; /* length ni, indexed by i */
+  const pace_real_t *area, *rarea, *rarea_c;
+  const pace_real_t *dx, *dy, *dxa, *dya, *dxc, *dyc;
+  const pace_real_t *rdx, *rdy, *rdxa, *rdya, *rdxc, *rdyc;
+  const pace_real_t *cosa, *rsina, *cosa_u, *cosa_v, *cosa_s;
+  const pace_real_t *sina_u, *sina_v, *rsin_u, *rsin_v, *rsin2;
+  const pace_real_t *sin_sg1, *sin_sg2, *sin_sg3, *sin_sg4;
+  const pace_real_t *cos_sg1, *cos_sg2, *cos_sg3, *cos_sg4;
+  const pace_real_t *del6_u, *del6_v, *divg_u, *divg_v;
+  const pace_real_t *fC, *fC_agrid;
+  const pace_real_t *edge_w, *edge_e; /* length nj, indexed by j */
+  const pace_real_t *edge_s, *edge_n; /* length ni, indexed by i */
   /* a2b_ord4 corner extrapolation weights x1/(x2-x1) (a2b_ord4.py:43-56) for the corner
    * points sw(is,js), nw-stencil(ie+1,js), ne(ie+1,je+1), se-stencil(is,je+1), three diagonals
    * each, precomputed on the host from lon/lat (HOST values, copied by value). */
@@ -74,16 +84,16 @@ typedef struct {
 } pace_dsw_config_t;
 
 /* ---- FiniteVolumeFluxPrep.__call__ (fv3core/pace/fv3core/stencils/fxadv.py:565-661) ---- */
-int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const double* uc, const double* vc,
-               double* crx, double* cry, double* x_area_flux, double* y_area_flux, double* uc_contra,
-               double* vc_contra, double dt, void* stream);
+int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* uc, const pace_real_t* vc,
+               pace_real_t* crx, pace_real_t* cry, pace_real_t* x_area_flux, pace_real_t* y_area_flux, pace_real_t* uc_contra,
+               pace_real_t* vc_contra, double dt, void* stream);
 
 /* ---- XPiecewiseParabolic / YPiecewiseParabolic.__call__ (fv3core/pace/fv3core/stencils/xppm.py:290-355, yppm.py:290-355):
  * mean value of q_in advected through the x- (axis 0) or y- (axis 1) interfaces of the window origin (i0, j0, k0), domain
  * (ni, nj, nk) -- the origin / domain the reference class is constructed with.  iord in {5, 6, 8} (the sign is ignored, as
  * `mord = abs(iord)`).  Corner halos of q_in are the caller's business, as in the reference. */
-int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const double* q_in, const double* c,
-             double* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk, void* stream);
+int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const pace_real_t* q_in, const pace_real_t* c,
+             pace_real_t* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk, void* stream);
 
 /* ---- DivergenceDamping.__call__ (fv3core/pace/fv3core/stencils/divergence_damping.py:482-632).  workspace: two fields
  * (pace_divergence_damping_workspace_bytes).  nord_col: HOST array of nk values (the class's nord_col K-field; the column is
@@ -91,46 +101,46 @@ int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int i
  * reference: divg_d, uc, vc are work fields and end as the last iteration leaves them, delpc and damped_rel_vort_bgrid are
  * outputs, ke += damping. */
 int64_t pace_divergence_damping_workspace_bytes(const pace_geom_t* geom);
-int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* u, const double* v,
-                            const double* va, double* damped_rel_vort_bgrid, const double* ua, double* divg_d, double* vc,
-                            double* uc, double* delpc, double* ke, const double* rel_vort_agrid, double dt,
-                            const double* nord_col_host, const double* d2_bg_dev, double dddmp, double d4_bg, int nord,
+int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_real_t* u, const pace_real_t* v,
+                            const pace_real_t* va, pace_real_t* damped_rel_vort_bgrid, const pace_real_t* ua, pace_real_t* divg_d, pace_real_t* vc,
+                            pace_real_t* uc, pace_real_t* delpc, pace_real_t* ke, const pace_real_t* rel_vort_agrid, double dt,
+                            const double* nord_col_host, const pace_real_t* d2_bg_dev, double dddmp, double d4_bg, int nord,
                             void* stream);
 
 /* ---- FiniteVolumeTransport.__call__ without damping (fvtp2d.py:262-345).  x/y_mass_flux may be
  * NULL (area fluxes are used as unit fluxes).  hord in {5, 6, 8}.  nlev = number of levels
  * processed (nk, or nk+1 for interface fields).  q's corner halos are NOT rewritten: corner reads
  * go through the copy_corners index map, which yields identical fluxes. */
-int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
-                const double* cry, const double* x_area_flux, const double* y_area_flux, double* q_x_flux,
-                double* q_y_flux, const double* x_mass_flux, const double* y_mass_flux, int hord, int nlev,
+int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, const pace_real_t* crx,
+                const pace_real_t* cry, const pace_real_t* x_area_flux, const pace_real_t* y_area_flux, pace_real_t* q_x_flux,
+                pace_real_t* q_y_flux, const pace_real_t* x_mass_flux, const pace_real_t* y_mass_flux, int hord, int nlev,
                 void* stream);
 
 /* ---- The fused form d_sw uses for q_con and pt (d_sw.py:1075-1117): FiniteVolumeTransport with mass fluxes AND its
  * DelnFlux(mass = delp) (fvtp2d.py:262-345), followed by apply_fluxes (d_sw.py:122-145):
  *   qout = q * delp + flux_increment(q_x_flux, q_y_flux) * rarea      on the compute domain,
  * in ONE kernel; the flux fields never reach memory.  damp_k / nord_k as for pace_delnflux.  qout must not alias q. */
-int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
-                       const double* cry, const double* x_area_flux, const double* y_area_flux,
-                       const double* x_mass_flux, const double* y_mass_flux, const double* delp, const double* damp_k,
-                       const double* nord_k, int nmax, double* qout, int hord, int nlev, void* stream);
+int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, const pace_real_t* crx,
+                       const pace_real_t* cry, const pace_real_t* x_area_flux, const pace_real_t* y_area_flux,
+                       const pace_real_t* x_mass_flux, const pace_real_t* y_mass_flux, const pace_real_t* delp, const pace_real_t* damp_k,
+                       const pace_real_t* nord_k, int nmax, pace_real_t* qout, int hord, int nlev, void* stream);
 
 /* ---- DelnFluxNoSG.__call__ (delnflux.py:1050-1261): damping fluxes fx2, fy2 of q.
  * nord_k, damp_k: DEVICE arrays, one entry per level (see DESIGN.md for how the reference's
  * nord0..nord3 externals map to per-level values).  If mass_given != 0, d2 starts from q
  * (copy_stencil_interval) instead of damp*q.  nmax = max(nord_k). */
-int pace_delnflux_nosg(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, double* fx2,
-                       double* fy2, const double* damp_k, const double* nord_k, int nmax, int mass_given,
+int pace_delnflux_nosg(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, pace_real_t* fx2,
+                       pace_real_t* fy2, const pace_real_t* damp_k, const pace_real_t* nord_k, int nmax, int mass_given,
                        int nlev, void* stream);
 
 /* ---- DelnFlux.__call__ (delnflux.py:945-1047): fx, fy += damping flux (mass-weighted if
  * mass != NULL).  damp_k = (damp_c*da_min)^(nord+1) per level (calc_damp, delnflux.py:21-38). */
-int pace_delnflux(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, double* fx, double* fy,
-                  const double* mass, const double* damp_k, const double* nord_k, int nmax, int nlev,
+int pace_delnflux(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, pace_real_t* fx, pace_real_t* fy,
+                  const pace_real_t* mass, const pace_real_t* damp_k, const pace_real_t* nord_k, int nmax, int nlev,
                   void* stream);
 
 /* ---- AGrid2BGridFourthOrder.__call__ (a2b_ord4.py:668-761) on levels [k0, k1). ---- */
-int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, double* qin, double* qout, int k0, int k1,
+int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* qin, pace_real_t* qout, int k0, int k1,
                   int replace, void* stream);
 
 /* ---- DGridShallowWaterLagrangianDynamics.__call__ (d_sw.py:935-1237).
@@ -141,26 +151,26 @@ int64_t pace_d_sw_workspace_bytes(const pace_geom_t* geom);
 /* Once per object, after zero-filling the workspace: uploads the column namelist (synchronises). */
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream);
 int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-              const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
-              double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
-              double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx, double* yfx,
-              double* q_con, const double* zh, double* heat_source, double* diss_est, double dt, void* stream);
+              const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt, pace_real_t* u,
+              pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
+              pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry, pace_real_t* xfx, pace_real_t* yfx,
+              pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt, void* stream);
 
 /* The two halves of pace_d_sw, same arguments.  pace_d_sw_transport: flux preparation and the transport of delp, w,
  * q_con, pt (d_sw.py:935-1117) -- everything updatedzd / riem_solver3 read.  pace_d_sw_winds: the rest
  * (d_sw.py:1119-1237); it reads only what the first half left behind, so it may be launched on a second stream
  * and run concurrently with the vertical solver.  pace_d_sw == transport followed by winds on one stream. */
 int pace_d_sw_transport(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-                        const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt,
-                        double* u, double* v, double* w, double* uc, double* vc, const double* ua, const double* va,
-                        double* divgd, double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry,
-                        double* xfx, double* yfx, double* q_con, const double* zh, double* heat_source,
-                        double* diss_est, double dt, void* stream);
+                        const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt,
+                        pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va,
+                        pace_real_t* divgd, pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry,
+                        pace_real_t* xfx, pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source,
+                        pace_real_t* diss_est, double dt, void* stream);
 int pace_d_sw_winds(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-                    const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
-                    double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
-                    double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx,
-                    double* yfx, double* q_con, const double* zh, double* heat_source, double* diss_est, double dt,
+                    const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt, pace_real_t* u,
+                    pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
+                    pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry, pace_real_t* xfx,
+                    pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt,
                     void* stream);
 
 /* Finer split for callers that overlap on two streams (same arguments after `phases`).  Bit mask: 1 = flux preparation
@@ -168,51 +178,51 @@ int pace_d_sw_winds(const pace_geom_t* geom, const pace_metrics_t* met, const pa
  * (dissipative heating, final u/v update).  2 and 4 depend only on 1 and use disjoint workspace fields; 8 needs 2 and
  * 4.  pace_d_sw_transport == phases 3, pace_d_sw_winds == phases 12, pace_d_sw == 15. */
 int pace_d_sw_phases(int phases, const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-                     const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
-                     double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
-                     double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx,
-                     double* yfx, double* q_con, const double* zh, double* heat_source, double* diss_est, double dt,
+                     const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt, pace_real_t* u,
+                     pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
+                     pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry, pace_real_t* xfx,
+                     pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt,
                      void* stream);
 
 /* ---- NonhydrostaticVerticalSolver.__call__ (riem_solver3.py:208-321), compute domain.
  * zs, ws: 2-D.  workspace: pace_riem_solver3_workspace_bytes() bytes of DEVICE scratch. */
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom);
-int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, double dt, const double* cappa,
-                      double ptop, const double* zs, const double* ws, double* delz, const double* q_con,
-                      const double* delp, const double* pt, double* zh, double* pe, double* ppe, double* pk3,
-                      double* pk, double* peln, double* w, double p_fac, void* stream);
+int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, double dt, const pace_real_t* cappa,
+                      double ptop, const pace_real_t* zs, const pace_real_t* ws, pace_real_t* delz, const pace_real_t* q_con,
+                      const pace_real_t* delp, const pace_real_t* pt, pace_real_t* zh, pace_real_t* pe, pace_real_t* ppe, pace_real_t* pk3,
+                      pace_real_t* pk, pace_real_t* peln, pace_real_t* w, double p_fac, void* stream);
 
 /* ---- CGridShallowWaterDynamics.__call__ (fv3core/pace/fv3core/stencils/c_sw.py:599-766), including
  * DGrid2AGrid2CGridVectors (d2a2c_vect.py:529-655).  delpc / ptc are the class attributes the reference
  * exposes (c_sw.py:497-502, read by dyn_core.py:795-800).  workspace: pace_c_sw_workspace_bytes(). */
 int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom);
-int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* delpc, double* ptc,
-              const double* delp, const double* pt, const double* u, const double* v, const double* w, double* uc,
-              double* vc, double* ua, double* va, double* ut, double* vt, double* divgd, double* omga, double dt2,
+int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* delpc, pace_real_t* ptc,
+              const pace_real_t* delp, const pace_real_t* pt, const pace_real_t* u, const pace_real_t* v, const pace_real_t* w, pace_real_t* uc,
+              pace_real_t* vc, pace_real_t* ua, pace_real_t* va, pace_real_t* ut, pace_real_t* vt, pace_real_t* divgd, pace_real_t* omga, double dt2,
               int nord, void* stream);
 /* ---- DGrid2AGrid2CGridVectors.__call__ alone (d2a2c_vect.py:529-655), dord4 = True; same workspace. */
-int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* uc, double* vc,
-                    const double* u, const double* v, double* ua, double* va, double* utc, double* vtc, void* stream);
+int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* uc, pace_real_t* vc,
+                    const pace_real_t* u, const pace_real_t* v, pace_real_t* ua, pace_real_t* va, pace_real_t* utc, pace_real_t* vtc, void* stream);
 
 /* ---- Sim1Solver.__call__ (sim1_solver.py:144-219) as a class of its own: the semi-implicit vertical solver on the compute
  * domain widened by n_halo (the reference builds it with n_halo = 0 for riem_solver3 and 1 for riem_solver_c).  gamma, cp3,
  * delta_mass, pm, pem, potential_temperature in; pe out (nk + 1 interfaces); w, dz inout; ws 2-D.  workspace:
  * pace_sim1_solver_workspace_bytes.  Inside pace_riem_solver3 / pace_riem_solver_c the same arithmetic runs fused. */
 int64_t pace_sim1_solver_workspace_bytes(const pace_geom_t* geom);
-int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac, const double* gamma,
-                     const double* cp3, double* pe, const double* delta_mass, const double* pm, const double* pem, double* w,
-                     double* dz, const double* potential_temperature, const double* ws, void* stream);
+int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac, const pace_real_t* gamma,
+                     const pace_real_t* cp3, pace_real_t* pe, const pace_real_t* delta_mass, const pace_real_t* pm, const pace_real_t* pem, pace_real_t* w,
+                     pace_real_t* dz, const pace_real_t* potential_temperature, const pace_real_t* ws, void* stream);
 
 /* ---- NonhydrostaticVerticalSolverCGrid.__call__ (riem_solver_c.py:160-250), compute domain +- 1. */
 int64_t pace_riem_solver_c_workspace_bytes(const pace_geom_t* geom);
-int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const double* cappa, double ptop,
-                       const double* hs, const double* ws, const double* ptc, const double* q_con,
-                       const double* delpc, double* gz, double* pef, const double* w3, double p_fac, void* stream);
+int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const pace_real_t* cappa, double ptop,
+                       const pace_real_t* hs, const pace_real_t* ws, const pace_real_t* ptc, const pace_real_t* q_con,
+                       const pace_real_t* delpc, pace_real_t* gz, pace_real_t* pef, const pace_real_t* w3, double p_fac, void* stream);
 
 /* ---- UpdateGeopotentialHeightOnCGrid.__call__ (updatedzc.py:172-207).  dp_ref: DEVICE K-array (nk). */
 int64_t pace_updatedzc_workspace_bytes(const pace_geom_t* geom);
-int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* dp_ref,
-                   const double* zs, const double* ut, const double* vt, double* gz, double* ws, double dt,
+int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_real_t* dp_ref,
+                   const pace_real_t* zs, const pace_real_t* ut, const pace_real_t* vt, pace_real_t* gz, pace_real_t* ws, double dt,
                    void* stream);
 
 /* ---- UpdateHeightOnDGrid.__call__ (updatedzd.py:281-356).  K-dependent constants: gk/beta/gamma from
@@ -220,67 +230,67 @@ int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* wor
  * interpolation stencil derives from them (:180-192), and the DelnFluxNoSG column arguments on nk+1 levels
  * (damp = column_namelist["damp_vt"], nord = nord_v expanded per level), DEVICE arrays. */
 typedef struct {
-  const double *gk, *beta, *gamma;
+  const pace_real_t *gk, *beta, *gamma;
   double xt1_top, a_bot, xt1_bot, xt2_bot;
-  const double *damp, *nord;
+  const pace_real_t *damp, *nord;
   int32_t nmax, pad_;
 } pace_updatedzd_k_t;
 int64_t pace_updatedzd_workspace_bytes(const pace_geom_t* geom);
 int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_updatedzd_k_t* kc,
-                   const double* surface_height, double* height, const double* courant_number_x,
-                   const double* courant_number_y, const double* x_area_flux, const double* y_area_flux, double* ws,
+                   const pace_real_t* surface_height, pace_real_t* height, const pace_real_t* courant_number_x,
+                   const pace_real_t* courant_number_y, const pace_real_t* x_area_flux, const pace_real_t* y_area_flux, pace_real_t* ws,
                    double dt, int hord_tm, void* stream);
 
 /* ---- dyn_core.py stencils: gz_from_surface_height_and_thicknesses (:83-96, compute domain),
  * compute_geopotential (:115-117, halo 2, nk+1 levels), basic.copy_defn as used at dyn_core.py:773-781
  * (full domain, nk+1 levels), p_grad_c_stencil (:120-171, hydrostatic = False). */
-int pace_zero_data(const pace_geom_t* geom, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source,
-                   double* diss_estd, int first_timestep, void* stream);                           /* dyn_core.py:51-80 */
-int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const double* delp, double* pem,
+int pace_zero_data(const pace_geom_t* geom, pace_real_t* mfxd, pace_real_t* mfyd, pace_real_t* cxd, pace_real_t* cyd, pace_real_t* heat_source,
+                   pace_real_t* diss_estd, int first_timestep, void* stream);                           /* dyn_core.py:51-80 */
+int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const pace_real_t* delp, pace_real_t* pem,
                                                             double ptop, void* stream);              /* :99-112 */
-int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const double* zs, const double* delz,
-                                                double* gz, void* stream);
-int pace_compute_geopotential(const pace_geom_t* geom, const double* zh, double* gz, void* stream);
-int pace_copy(const pace_geom_t* geom, const double* src, double* dst, void* stream);
-int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, double* uc, double* vc, const double* delpc,
-                  const double* pkc, const double* gz, double dt2, void* stream);
+int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const pace_real_t* zs, const pace_real_t* delz,
+                                                pace_real_t* gz, void* stream);
+int pace_compute_geopotential(const pace_geom_t* geom, const pace_real_t* zh, pace_real_t* gz, void* stream);
+int pace_copy(const pace_geom_t* geom, const pace_real_t* src, pace_real_t* dst, void* stream);
+int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* uc, pace_real_t* vc, const pace_real_t* delpc,
+                  const pace_real_t* pkc, const pace_real_t* gz, double dt2, void* stream);
 
 /* ---- NonHydrostaticPressureGradient.__call__ (nh_p_grad.py:187-255). */
 int64_t pace_nh_p_grad_workspace_bytes(const pace_geom_t* geom);
-int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* u, double* v,
-                   double* pp, double* gz, double* pk3, double* delp, double dt, double ptop, double akap,
+int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* u, pace_real_t* v,
+                   pace_real_t* pp, pace_real_t* gz, pace_real_t* pk3, pace_real_t* delp, double dt, double ptop, double akap,
                    void* stream);
 
 /* ---- pe_halo.edge_pe (pe_halo.py:6-34) and PK3Halo.__call__ (pk3_halo.py:55-69). */
-int pace_edge_pe(const pace_geom_t* geom, double* pe, const double* delp, double ptop, void* stream);
-int pace_pk3_halo(const pace_geom_t* geom, double* pk3, const double* delp, double ptop, double akap, void* stream);
+int pace_edge_pe(const pace_geom_t* geom, pace_real_t* pe, const pace_real_t* delp, double ptop, void* stream);
+int pace_pk3_halo(const pace_geom_t* geom, pace_real_t* pk3, const pace_real_t* delp, double ptop, double akap, void* stream);
 
 /* ---- RayleighDamping.__call__ (ray_fast.py:186-206).  dp, pfull: HOST K-arrays (nk). */
-int pace_ray_fast(const pace_geom_t* geom, double* u, double* v, double* w, const double* dp, const double* pfull,
+int pace_ray_fast(const pace_geom_t* geom, pace_real_t* u, pace_real_t* v, pace_real_t* w, const double* dp, const double* pfull,
                   double dt, double ptop, double rf_cutoff, double tau, int hydrostatic, void* stream);
 
 /* ---- HyperdiffusionDamping.__call__ (del2cubed.py:168-194) and apply_diffusive_heating
  * (temperature_adjust.py:8-43, first nlev levels of the compute domain). */
 int64_t pace_del2cubed_workspace_bytes(const pace_geom_t* geom);
-int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* qdel, double cd,
+int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* qdel, double cd,
                    int nmax, void* stream);
-int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, const double* delz, const double* cappa,
-                                 const double* heat_source, double* pt, double delt_time_factor, int nlev,
+int pace_apply_diffusive_heating(const pace_geom_t* geom, const pace_real_t* delp, const pace_real_t* delz, const pace_real_t* cappa,
+                                 const pace_real_t* heat_source, pace_real_t* pt, double delt_time_factor, int nlev,
                                  void* stream);
 
 /* ---- TracerAdvection (Fortran tracer_2d_1l): the stencils around FiniteVolumeTransport(hord = 8) in
  * fv3core/pace/fv3core/stencils/tracer_2d_1l.py -- flux_compute (:19-77), divide_fluxes_by_n_substeps (:80-106),
  * apply_mass_flux (:115-135), apply_tracer_flux (:138-158), swap_dp (:166-170).  The transport itself is pace_fvtp2d
  * with hord = 8 (monotone PPM, xppm.py:76-145,185-287). */
-int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const double* cx, const double* cy,
-                             double* xfx, double* yfx, void* stream);
-int pace_tracer_divide_fluxes(const pace_geom_t* geom, double* cxd, double* xfx, double* mfxd, double* cyd, double* yfx,
-                              double* mfyd, int n_split, void* stream);
-int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const double* dp1, const double* x_mass_flux,
-                         const double* y_mass_flux, double* dp2, void* stream);
-int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, double* q, const double* dp1,
-                           const double* fx, const double* fy, const double* dp2, void* stream);
-int pace_swap_dp(const pace_geom_t* geom, double* dp1, double* dp2, void* stream);
+int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* cx, const pace_real_t* cy,
+                             pace_real_t* xfx, pace_real_t* yfx, void* stream);
+int pace_tracer_divide_fluxes(const pace_geom_t* geom, pace_real_t* cxd, pace_real_t* xfx, pace_real_t* mfxd, pace_real_t* cyd, pace_real_t* yfx,
+                              pace_real_t* mfyd, int n_split, void* stream);
+int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* dp1, const pace_real_t* x_mass_flux,
+                         const pace_real_t* y_mass_flux, pace_real_t* dp2, void* stream);
+int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* q, const pace_real_t* dp1,
+                           const pace_real_t* fx, const pace_real_t* fy, const pace_real_t* dp2, void* stream);
+int pace_swap_dp(const pace_geom_t* geom, pace_real_t* dp1, pace_real_t* dp2, void* stream);
 
 /* ---- MapSingle (Fortran map_single / map1_ppm / map_scalar): fv3core/pace/fv3core/stencils/map_single.py:96-200 with
  * RemapProfile (cs_profile), remap_profile.py:566-681.  q1 is remapped in place from the nk layers bounded by the
@@ -290,20 +300,20 @@ int pace_swap_dp(const pace_geom_t* geom, double* dp1, double* dp2, void* stream
  * xstag / ystag: the field is staggered in x / y and owns one more column / row (`dims` of the reference's constructor).
  * workspace: pace_map_single_workspace_bytes() of device memory (5 fields; the reference keeps 14). */
 int64_t pace_map_single_workspace_bytes(const pace_geom_t* geom);
-int pace_map_single(const pace_geom_t* geom, void* workspace, double* q1, const double* pe1, const double* pe2,
-                    const double* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream);
+int pace_map_single(const pace_geom_t* geom, void* workspace, pace_real_t* q1, const pace_real_t* pe1, const pace_real_t* pe2,
+                    const pace_real_t* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream);
 
 /* MapNTracer (Fortran mapn_tracer): fv3core/pace/fv3core/stencils/mapn_tracer.py:13-82 -- nq (<= 16) tracers that share
  * pe1 / pe2 are remapped (iv = 0, one kord) by ONE three-launch sequence instead of nq MapSingle calls.  tracers is a
  * HOST array of nq device pointers.  workspace: pace_mapn_tracer_workspace_bytes(geom, nq). */
 int64_t pace_mapn_tracer_workspace_bytes(const pace_geom_t* geom, int nq);
-int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, double* const* tracers, int nq, const double* pe1,
-                     const double* pe2, int kord, void* stream);
+int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, pace_real_t* const* tracers, int nq, const pace_real_t* pe1,
+                     const pace_real_t* pe2, int kord, void* stream);
 
 /* FillNegativeTracerValues (Fortran fillz): fv3core/pace/fv3core/stencils/fillz.py:120-163 -- negative tracer masses
  * borrow from the layers above / below, then the column is rescaled; all nq tracers in one launch.  tracers: HOST array
  * of nq device pointers; dp2: layer thicknesses. */
-int pace_fillz(const pace_geom_t* geom, double* const* tracers, int nq, const double* dp2, void* stream);
+int pace_fillz(const pace_geom_t* geom, pace_real_t* const* tracers, int nq, const pace_real_t* dp2, void* stream);
 
 /* ---- LagrangianToEulerian: the stencils around the remaps (fv3core/pace/fv3core/stencils/remapping.py:286-695 calls them
  * in this order; pace_amd/fv3core/stencils/remapping.py is the host sequence).  Non-hydrostatic, kord_tm < 0, no saturation
@@ -314,17 +324,17 @@ int pace_fillz(const pace_geom_t* geom, double* const* tracers, int nq, const do
  *   pace_l2e_pressures = pressures_mapu (dir 0, :196-227) / pressures_mapv (dir 1, :230-254)
  *   pace_l2e_finish    = update_ua + copy_from_below (:257-283), then moist_pt_last_step (moist_cv.py:84-122, last_step
  *                        != 0) or adjust_divide_stencil (pt / pkz) */
-int pace_l2e_prepare(const pace_geom_t* geom, const double* const* water, double* q_con, double* pt, double* cappa, double* delp,
-                     double* delz, const double* pe, double* pe1, double* pe2, const double* ak, const double* bk, double* dp2,
-                     double* ps, double* pn2, const double* peln, double* pk, double ptop, double akap, double r_vir,
+int pace_l2e_prepare(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pt, pace_real_t* cappa, pace_real_t* delp,
+                     pace_real_t* delz, const pace_real_t* pe, pace_real_t* pe1, pace_real_t* pe2, const pace_real_t* ak, const pace_real_t* bk, pace_real_t* dp2,
+                     pace_real_t* ps, pace_real_t* pn2, const pace_real_t* peln, pace_real_t* pk, double ptop, double akap, double r_vir,
                      void* stream);
-int pace_l2e_post(const pace_geom_t* geom, const double* const* water, double* q_con, double* pkz, const double* pt,
-                  double* cappa, const double* delp, double* delz, double* peln, double* pe0, const double* pn2, double r_vir,
+int pace_l2e_post(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pkz, const pace_real_t* pt,
+                  pace_real_t* cappa, const pace_real_t* delp, pace_real_t* delz, pace_real_t* peln, pace_real_t* pe0, const pace_real_t* pn2, double r_vir,
                   void* stream);
-int pace_l2e_pressures(const pace_geom_t* geom, int dir, const double* pe, const double* pe1, const double* ak,
-                       const double* bk, double* pe0, double* pe3, void* stream);
-int pace_l2e_finish(const pace_geom_t* geom, const double* const* water, double* pe, const double* pe2, double* pt,
-                    const double* pkz, double r_vir, int last_step, void* stream);
+int pace_l2e_pressures(const pace_geom_t* geom, int dir, const pace_real_t* pe, const pace_real_t* pe1, const pace_real_t* ak,
+                       const pace_real_t* bk, pace_real_t* pe0, pace_real_t* pe3, void* stream);
+int pace_l2e_finish(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* pe, const pace_real_t* pe2, pace_real_t* pt,
+                    const pace_real_t* pkz, double r_vir, int last_step, void* stream);
 
 /* ---- DynamicalCore (fv3core/pace/fv3core/stencils/fv_dynamics.py:92-624): the stencils it runs itself.  water: HOST
  * array of the six device pointers qvapor, qliquid, qrain, qsnow, qice, qgraupel.
@@ -335,20 +345,20 @@ int pace_l2e_finish(const pace_geom_t* geom, const double* const* water, double*
  *                       non-hydrostatic: fix_neg_water, fillq(qgraupel), fillq(qrain), fix_water_vapor_down, fix_neg_cloud
  *   pace_c2l_ord      = CubedToLatLon's stencil (stencils/pace/stencils/c2l_ord.py:15-112), order 2 or 4 (order 4 expects
  *                       the halos of u, v updated); a11..a22: 2-D metric fields */
-int pace_fv_setup_pt(const pace_geom_t* geom, double* const* water, double* q_con, double* pkz, double* pt, double* cappa,
-                     const double* delp, const double* delz, double* dp1, void* stream);
-int pace_omega_from_w(const pace_geom_t* geom, const double* delp, const double* delz, const double* w, double* omga,
+int pace_fv_setup_pt(const pace_geom_t* geom, pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pkz, pace_real_t* pt, pace_real_t* cappa,
+                     const pace_real_t* delp, const pace_real_t* delz, pace_real_t* dp1, void* stream);
+int pace_omega_from_w(const pace_geom_t* geom, const pace_real_t* delp, const pace_real_t* delz, const pace_real_t* w, pace_real_t* omga,
                       void* stream);
-int pace_neg_adj3(const pace_geom_t* geom, double* const* water, double* qcld, double* pt, const double* delp, void* stream);
-int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const double* u, const double* v,
-                 const double* a11, const double* a12, const double* a21, const double* a22, double* ua, double* va,
+int pace_neg_adj3(const pace_geom_t* geom, pace_real_t* const* water, pace_real_t* qcld, pace_real_t* pt, const pace_real_t* delp, void* stream);
+int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const pace_real_t* u, const pace_real_t* v,
+                 const pace_real_t* a11, const pace_real_t* a12, const pace_real_t* a21, const pace_real_t* a22, pace_real_t* ua, pace_real_t* va,
                  void* stream);
 
 /* EXPERIMENTAL, not used by the host classes: the wave-private (barrier-free, LDS-free) formulation of the plain ord-6
  * transport of pace_fvtp2d for the box of cells [ib, ib+nx) x [jb, jb+ny) whose stencils stay 3+ cells inside the tile
  * (PACE_ERR_ARG otherwise).  Writes fx, fy on the box only.  See pace_amd/csrc/k_march.hip and DESIGN.md section 8. */
-int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
-                            const double* cry, const double* xfx, const double* yfx, double* fx, double* fy, int ib, int nx, int jb,
+int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, const pace_real_t* crx,
+                            const pace_real_t* cry, const pace_real_t* xfx, const pace_real_t* yfx, pace_real_t* fx, pace_real_t* fy, int ib, int nx, int jb,
                             int ny, int nlev, void* stream);
 
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
@@ -358,8 +368,8 @@ int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, 
  * and at field index (i0 + a*di_a + b*di_b, j0 + a*dj_a + b*dj_b, k).  pack: buf = sign * field;
  * unpack: field = buf.  descs is a HOST array; field / buf are DEVICE pointers. */
 typedef struct {
-  double* field;
-  double* buf;
+  pace_real_t* field;
+  pace_real_t* buf;
   int32_t i0, j0, di_a, dj_a, di_b, dj_b;
   int32_t na, nb, nk, pad_;
   double sign;
@@ -368,6 +378,8 @@ int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int n
 int pace_halo_unpack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream);
 
 const char* pace_version(void);
+/* sizeof(pace_real_t) of this build: 8 (libpace_hip.so) or 4 (libpace_hip_f32.so). */
+int pace_real_bytes(void);
 /* Text of the last HIP error this library saw on the calling thread ("" if none). */
 const char* pace_last_error(void);
 

@@ -11,6 +11,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libpace_hip.so")
+DEFAULT_LIB_F32 = os.path.join(_HERE, "libpace_hip_f32.so")  # the same sources with float32 storage (make f32)
 
 c_dp = C.c_void_p  # device pointer to double
 
@@ -74,6 +75,7 @@ _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported con
 _P = C.POINTER
 _PROTOS = {
     "pace_version": (C.c_char_p, []),
+    "pace_real_bytes": (C.c_int, []),
     "pace_last_error": (C.c_char_p, []),
     "pace_fxadv": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 8 + [C.c_double, C.c_void_p]),
     "pace_fvtp2d": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 9 + [C.c_int, C.c_int, C.c_void_p]),
@@ -165,6 +167,7 @@ class Library:
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        self.real_bytes = int(self.cdll.pace_real_bytes())  # 8: float64 fields; 4: the float32-storage build
 
     timing = None  # a pace_amd.util.KernelTimes while per-entry-point device times are being collected
 
@@ -192,12 +195,13 @@ class Library:
         return self.cdll.pace_version().decode()
 
 
-_default = None
+_default = {}
 
 
-def load():
-    """The product library (gfx950).  Raises PaceError if it has not been built."""
-    global _default
-    if _default is None:
-        _default = Library(DEFAULT_LIB)
-    return _default
+def load(precision: int = 64):
+    """The product library (gfx950): float64 storage, or float32 with precision=32.  Raises PaceError if it has not been built."""
+    if precision not in (64, 32):
+        raise ValueError("precision is 64 or 32")
+    if precision not in _default:
+        _default[precision] = Library(DEFAULT_LIB if precision == 64 else DEFAULT_LIB_F32)
+    return _default[precision]

@@ -19,7 +19,7 @@ static inline int geom_check(const pace_geom_t* g) {
   if (g == nullptr) return PACE_ERR_ARG;
   if (g->n < 1 || g->nk < 1) return PACE_ERR_ARG;
   if (g->sj < g->n + 7 || g->sk < (int64_t)g->sj * (g->n + 7)) return PACE_ERR_ARG;
-  if ((int64_t)(g->nk + 1) * g->sk * (int64_t)sizeof(double) >= ((int64_t)1 << 32)) return PACE_ERR_UNSUPPORTED;
+  if ((int64_t)(g->nk + 1) * g->sk * (int64_t)sizeof(real) >= ((int64_t)1 << 32)) return PACE_ERR_UNSUPPORTED;
   return PACE_OK;
 }
 
@@ -48,6 +48,8 @@ extern "C" {
 
 const char* pace_last_error(void) { return g_pace_err; }
 
+int pace_real_bytes(void) { return (int)sizeof(real); }
+
 const char* pace_version(void) {
 #ifdef PACE_EMU
   return "pace_amd 0.1 (CPU emulation build -- test infrastructure only)";
@@ -56,25 +58,25 @@ const char* pace_version(void) {
 #endif
 }
 
-int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const double* uc, const double* vc, double* crx,
-               double* cry, double* xfx, double* yfx, double* ut, double* vt, double dt, void* stream) {
+int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const real* uc, const real* vc, real* crx,
+               real* cry, real* xfx, real* yfx, real* ut, real* vt, double dt, void* stream) {
   NEED(geom && met && uc && vc && crx && cry && xfx && yfx && ut && vt);
   return launch_fxadv(make_geo(geom), *met, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, nullptr, nullptr, S(stream));
 }
 
-int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
-                const double* cry, const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
-                const double* ymf, int hord, int nlev, void* stream) {
+int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const real* q, const real* crx,
+                const real* cry, const real* xfx, const real* yfx, real* fx, real* fy, const real* xmf,
+                const real* ymf, int hord, int nlev, void* stream) {
   NEED(geom && met && q && crx && cry && xfx && yfx && fx && fy);
   if ((xmf == nullptr) != (ymf == nullptr)) return PACE_ERR_ARG;
   if (nlev < 1 || nlev > geom->nk + 1) return PACE_ERR_ARG;
   return launch_fvtp2d(make_geo(geom), *met, q, crx, cry, xfx, yfx, fx, fy, xmf, ymf, hord, nlev, S(stream));
 }
 
-int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
-                       const double* cry, const double* x_area_flux, const double* y_area_flux,
-                       const double* x_mass_flux, const double* y_mass_flux, const double* delp, const double* damp_k,
-                       const double* nord_k, int nmax, double* qout, int hord, int nlev, void* stream) {
+int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const real* q, const real* crx,
+                       const real* cry, const real* x_area_flux, const real* y_area_flux,
+                       const real* x_mass_flux, const real* y_mass_flux, const real* delp, const real* damp_k,
+                       const real* nord_k, int nmax, real* qout, int hord, int nlev, void* stream) {
   NEED(geom && met && q && crx && cry && x_area_flux && y_area_flux && x_mass_flux && y_mass_flux && delp && damp_k && nord_k && qout);
   if (nlev < 1 || nlev > geom->nk + 1 || qout == q) return PACE_ERR_ARG;
   FvDamp dp{};
@@ -84,30 +86,30 @@ int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const
                           hord, nlev, 2, 1, dp, S(stream));
 }
 
-int pace_delnflux_nosg(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, double* fx2, double* fy2,
-                       const double* damp_k, const double* nord_k, int nmax, int mass_given, int nlev, void* stream) {
+int pace_delnflux_nosg(const pace_geom_t* geom, const pace_metrics_t* met, const real* q, real* fx2, real* fy2,
+                       const real* damp_k, const real* nord_k, int nmax, int mass_given, int nlev, void* stream) {
   NEED(geom && met && q && fx2 && fy2 && damp_k && nord_k);
   if (nlev < 1 || nlev > geom->nk + 1) return PACE_ERR_ARG;
   return launch_delnflux(make_geo(geom), *met, 0, q, fx2, fy2, nullptr, damp_k, nord_k, nmax, mass_given, nlev, S(stream));
 }
 
-int pace_delnflux(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, double* fx, double* fy,
-                  const double* mass, const double* damp_k, const double* nord_k, int nmax, int nlev, void* stream) {
+int pace_delnflux(const pace_geom_t* geom, const pace_metrics_t* met, const real* q, real* fx, real* fy,
+                  const real* mass, const real* damp_k, const real* nord_k, int nmax, int nlev, void* stream) {
   NEED(geom && met && q && fx && fy && damp_k && nord_k);
   if (nlev < 1 || nlev > geom->nk + 1) return PACE_ERR_ARG;
   return launch_delnflux(make_geo(geom), *met, mass ? 2 : 1, q, fx, fy, mass, damp_k, nord_k, nmax, mass ? 1 : 0, nlev,
                          S(stream));
 }
 
-int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, double* qin, double* qout, int k0, int k1,
+int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, real* qin, real* qout, int k0, int k1,
                   int replace, void* stream) {
   NEED(geom && met && qin && qout);
   if (k0 < 0 || k1 <= k0 || k1 > geom->nk + 1) return PACE_ERR_ARG;
   return launch_a2b_ord4(make_geo(geom), *met, qin, qout, k0, k1, replace, S(stream));
 }
 
-int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const double* q_in, const double* c,
-             double* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk, void* stream) {
+int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const real* q_in, const real* c,
+             real* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk, void* stream) {
   NEED(geom && met && q_in && c && q_mean_advected);
   if (axis < 0 || axis > 1 || ni < 1 || nj < 1 || nk < 1 || k0 < 0 || k0 + nk > geom->nk + 1) return PACE_ERR_ARG;
   // the window must leave the three cells an interface needs on either side inside the storage
@@ -118,13 +120,13 @@ int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int i
 }
 
 int64_t pace_divergence_damping_workspace_bytes(const pace_geom_t* geom) {
-  return geom ? (int64_t)2 * geom->sk * (geom->nk + 1) * (int64_t)sizeof(double) : 0;
+  return geom ? (int64_t)2 * geom->sk * (geom->nk + 1) * (int64_t)sizeof(real) : 0;
 }
 
-int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* u, const double* v,
-                            const double* va, double* damped_rel_vort_bgrid, const double* ua, double* divg_d, double* vc,
-                            double* uc, double* delpc, double* ke, const double* rel_vort_agrid, double dt,
-                            const double* nord_col_host, const double* d2_bg_dev, double dddmp, double d4_bg, int nord,
+int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const real* u, const real* v,
+                            const real* va, real* damped_rel_vort_bgrid, const real* ua, real* divg_d, real* vc,
+                            real* uc, real* delpc, real* ke, const real* rel_vort_agrid, double dt,
+                            const double* nord_col_host, const real* d2_bg_dev, double dddmp, double d4_bg, int nord,
                             void* stream) {
   NEED(geom && met && workspace && u && v && va && damped_rel_vort_bgrid && ua && divg_d && vc && uc && delpc && ke);
   NEED(rel_vort_agrid && nord_col_host && d2_bg_dev);
@@ -138,8 +140,8 @@ int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, 
       break;
     }
   if (nonzero_nord < 0 || nonzero_nord > 3) return PACE_ERR_UNSUPPORTED;
-  double* da = (double*)workspace;
-  double* db = da + (long)g.sk * (g.nk + 1);
+  real* da = (real*)workspace;
+  real* db = da + (long)g.sk * (g.nk + 1);
   return launch_divergence_damping(g, *met, u, v, va, damped_rel_vort_bgrid, ua, divg_d, vc, uc, delpc, ke, rel_vort_agrid, dt,
                                    d2_bg_dev, kstart, nonzero_nord, dddmp, d4_bg, da, db, S(stream));
 }
@@ -152,10 +154,10 @@ int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* w
 }
 
 static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-                      const pace_dsw_config_t* cfg, void* workspace, double* delpc, double* delp, double* pt, double* u,
-                      double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd,
-                      double* mfx, double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx, double* yfx,
-                      double* q_con, const double* zh, double* heat_source, double* diss_est, double dt, void* stream) {
+                      const pace_dsw_config_t* cfg, void* workspace, real* delpc, real* delp, real* pt, real* u,
+                      real* v, real* w, real* uc, real* vc, const real* ua, const real* va, real* divgd,
+                      real* mfx, real* mfy, real* cx, real* cy, real* crx, real* cry, real* xfx, real* yfx,
+                      real* q_con, const real* zh, real* heat_source, real* diss_est, double dt, void* stream) {
   NEED(geom && met && col && cfg && workspace);
   NEED(delpc && delp && pt && u && v && w && uc && vc && ua && va && divgd && mfx && mfy && cx && cy);
   NEED(crx && cry && xfx && yfx && q_con && heat_source && diss_est);
@@ -165,9 +167,9 @@ static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t*
 
 #define DSW_PARAMS                                                                                                        \
   const pace_geom_t *geom, const pace_metrics_t *met, const pace_column_t *col, const pace_dsw_config_t *cfg,            \
-      void *workspace, double *delpc, double *delp, double *pt, double *u, double *v, double *w, double *uc, double *vc,  \
-      const double *ua, const double *va, double *divgd, double *mfx, double *mfy, double *cx, double *cy, double *crx,   \
-      double *cry, double *xfx, double *yfx, double *q_con, const double *zh, double *heat_source, double *diss_est,       \
+      void *workspace, real *delpc, real *delp, real *pt, real *u, real *v, real *w, real *uc, real *vc,  \
+      const real *ua, const real *va, real *divgd, real *mfx, real *mfy, real *cx, real *cy, real *crx,   \
+      real *cry, real *xfx, real *yfx, real *q_con, const real *zh, real *heat_source, real *diss_est,       \
       double dt, void *stream
 #define DSW_ARGS_                                                                                                          \
   geom, met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx,  \
@@ -185,10 +187,10 @@ int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom) {
   return geom ? riem3_workspace_bytes(make_geo(geom)) : 0;
 }
 
-int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, double dt, const double* cappa,
-                      double ptop, const double* zs, const double* ws, double* delz, const double* q_con,
-                      const double* delp, const double* pt, double* zh, double* pe, double* ppe, double* pk3, double* pk,
-                      double* peln, double* w, double p_fac, void* stream) {
+int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, double dt, const real* cappa,
+                      double ptop, const real* zs, const real* ws, real* delz, const real* q_con,
+                      const real* delp, const real* pt, real* zh, real* pe, real* ppe, real* pk3, real* pk,
+                      real* peln, real* w, double p_fac, void* stream) {
   NEED(geom && workspace && cappa && zs && ws && delz && q_con && delp && pt && zh && pe && ppe && pk3 && pk && peln && w);
   const Geo g = make_geo(geom);
   if (riem_column_supported(g) && !legacy_column_solvers())
@@ -200,17 +202,17 @@ int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, d
 
 int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom) { return geom ? csw_workspace_bytes(make_geo(geom)) : 0; }
 
-int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* delpc, double* ptc,
-              const double* delp, const double* pt, const double* u, const double* v, const double* w, double* uc,
-              double* vc, double* ua, double* va, double* ut, double* vt, double* divgd, double* omga, double dt2,
+int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* delpc, real* ptc,
+              const real* delp, const real* pt, const real* u, const real* v, const real* w, real* uc,
+              real* vc, real* ua, real* va, real* ut, real* vt, real* divgd, real* omga, double dt2,
               int nord, void* stream) {
   NEED(geom && met && workspace && delpc && ptc && delp && pt && u && v && w && uc && vc && ua && va && ut && vt && divgd && omga);
   return launch_c_sw(make_geo(geom), *met, workspace, delpc, ptc, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2,
                      nord, S(stream));
 }
 
-int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* uc, double* vc,
-                    const double* u, const double* v, double* ua, double* va, double* utc, double* vtc, void* stream) {
+int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* uc, real* vc,
+                    const real* u, const real* v, real* ua, real* va, real* utc, real* vtc, void* stream) {
   NEED(geom && met && workspace && uc && vc && u && v && ua && va && utc && vtc);
   return launch_d2a2c_vect(make_geo(geom), *met, workspace, uc, vc, u, v, ua, va, utc, vtc, S(stream));
 }
@@ -219,9 +221,9 @@ int64_t pace_riem_solver_c_workspace_bytes(const pace_geom_t* geom) {
   return geom ? riemc_workspace_bytes(make_geo(geom)) : 0;
 }
 
-int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const double* cappa, double ptop,
-                       const double* hs, const double* ws, const double* ptc, const double* q_con,
-                       const double* delpc, double* gz, double* pef, const double* w3, double p_fac, void* stream) {
+int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const real* cappa, double ptop,
+                       const real* hs, const real* ws, const real* ptc, const real* q_con,
+                       const real* delpc, real* gz, real* pef, const real* w3, double p_fac, void* stream) {
   NEED(geom && workspace && cappa && hs && ws && ptc && q_con && delpc && gz && pef && w3);
   const Geo g = make_geo(geom);
   if (riem_column_supported(g) && !legacy_column_solvers())
@@ -231,9 +233,9 @@ int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, con
 
 int64_t pace_sim1_solver_workspace_bytes(const pace_geom_t* geom) { return geom ? sim1_workspace_bytes(make_geo(geom)) : 0; }
 
-int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac, const double* gamma,
-                     const double* cp3, double* pe, const double* delta_mass, const double* pm, const double* pem, double* w,
-                     double* dz, const double* potential_temperature, const double* ws, void* stream) {
+int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac, const real* gamma,
+                     const real* cp3, real* pe, const real* delta_mass, const real* pm, const real* pem, real* w,
+                     real* dz, const real* potential_temperature, const real* ws, void* stream) {
   NEED(geom && workspace && gamma && cp3 && pe && delta_mass && pm && pem && w && dz && potential_temperature && ws);
   if (n_halo < 0 || n_halo > 3 || geom->nk < 2) return PACE_ERR_ARG;
   return launch_sim1_solver(make_geo(geom), workspace, n_halo, dt, p_fac, gamma, cp3, pe, delta_mass, pm, pem, w, dz,
@@ -244,8 +246,8 @@ int64_t pace_updatedzc_workspace_bytes(const pace_geom_t* geom) {
   return geom ? updatedzc_workspace_bytes(make_geo(geom)) : 0;
 }
 
-int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const double* dp_ref,
-                   const double* zs, const double* ut, const double* vt, double* gz, double* ws, double dt,
+int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const real* dp_ref,
+                   const real* zs, const real* ut, const real* vt, real* gz, real* ws, double dt,
                    void* stream) {
   NEED(geom && met && workspace && dp_ref && zs && ut && vt && gz && ws);
   return launch_updatedzc(make_geo(geom), *met, workspace, dp_ref, zs, ut, vt, gz, ws, dt, S(stream));
@@ -256,8 +258,8 @@ int64_t pace_updatedzd_workspace_bytes(const pace_geom_t* geom) {
 }
 
 int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_updatedzd_k_t* kc,
-                   const double* surface_height, double* height, const double* courant_number_x,
-                   const double* courant_number_y, const double* x_area_flux, const double* y_area_flux, double* ws,
+                   const real* surface_height, real* height, const real* courant_number_x,
+                   const real* courant_number_y, const real* x_area_flux, const real* y_area_flux, real* ws,
                    double dt, int hord_tm, void* stream) {
   NEED(geom && met && workspace && kc && surface_height && height && courant_number_x && courant_number_y && x_area_flux &&
        y_area_flux && ws);
@@ -266,36 +268,36 @@ int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* wor
                           x_area_flux, y_area_flux, ws, dt, hord_tm, S(stream));
 }
 
-int pace_zero_data(const pace_geom_t* geom, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source,
-                   double* diss_estd, int first_timestep, void* stream) {
+int pace_zero_data(const pace_geom_t* geom, real* mfxd, real* mfyd, real* cxd, real* cyd, real* heat_source,
+                   real* diss_estd, int first_timestep, void* stream) {
   NEED(geom && mfxd && mfyd && cxd && cyd && heat_source && diss_estd);
   return launch_zero_data(make_geo(geom), mfxd, mfyd, cxd, cyd, heat_source, diss_estd, first_timestep, S(stream));
 }
 
-int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const double* delp, double* pem,
+int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const real* delp, real* pem,
                                                             double ptop, void* stream) {
   NEED(geom && delp && pem);
   return launch_interface_pressure(make_geo(geom), delp, pem, ptop, S(stream));
 }
 
-int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const double* zs, const double* delz,
-                                                double* gz, void* stream) {
+int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const real* zs, const real* delz,
+                                                real* gz, void* stream) {
   NEED(geom && zs && delz && gz);
   return launch_gz_from_surface(make_geo(geom), zs, delz, gz, S(stream));
 }
 
-int pace_compute_geopotential(const pace_geom_t* geom, const double* zh, double* gz, void* stream) {
+int pace_compute_geopotential(const pace_geom_t* geom, const real* zh, real* gz, void* stream) {
   NEED(geom && zh && gz);
   return launch_scale_copy(make_geo(geom), zh, gz, 9.80665, 1, 2, geom->nk + 1, S(stream));
 }
 
-int pace_copy(const pace_geom_t* geom, const double* src, double* dst, void* stream) {
+int pace_copy(const pace_geom_t* geom, const real* src, real* dst, void* stream) {
   NEED(geom && src && dst);
   return launch_scale_copy(make_geo(geom), src, dst, 1.0, 0, 3, geom->nk + 1, S(stream));
 }
 
-int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, double* uc, double* vc, const double* delpc,
-                  const double* pkc, const double* gz, double dt2, void* stream) {
+int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, real* uc, real* vc, const real* delpc,
+                  const real* pkc, const real* gz, double dt2, void* stream) {
   NEED(geom && met && uc && vc && delpc && pkc && gz);
   return launch_p_grad_c(make_geo(geom), *met, uc, vc, delpc, pkc, gz, dt2, S(stream));
 }
@@ -304,24 +306,24 @@ int64_t pace_nh_p_grad_workspace_bytes(const pace_geom_t* geom) {
   return geom ? nh_p_grad_workspace_bytes(make_geo(geom)) : 0;
 }
 
-int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* u, double* v,
-                   double* pp, double* gz, double* pk3, double* delp, double dt, double ptop, double akap,
+int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* u, real* v,
+                   real* pp, real* gz, real* pk3, real* delp, double dt, double ptop, double akap,
                    void* stream) {
   NEED(geom && met && workspace && u && v && pp && gz && pk3 && delp);
   return launch_nh_p_grad(make_geo(geom), *met, workspace, u, v, pp, gz, pk3, delp, dt, ptop, akap, S(stream));
 }
 
-int pace_edge_pe(const pace_geom_t* geom, double* pe, const double* delp, double ptop, void* stream) {
+int pace_edge_pe(const pace_geom_t* geom, real* pe, const real* delp, double ptop, void* stream) {
   NEED(geom && pe && delp);
   return launch_edge_pe(make_geo(geom), pe, delp, ptop, S(stream));
 }
 
-int pace_pk3_halo(const pace_geom_t* geom, double* pk3, const double* delp, double ptop, double akap, void* stream) {
+int pace_pk3_halo(const pace_geom_t* geom, real* pk3, const real* delp, double ptop, double akap, void* stream) {
   NEED(geom && pk3 && delp);
   return launch_pk3_halo(make_geo(geom), pk3, delp, ptop, akap, S(stream));
 }
 
-int pace_ray_fast(const pace_geom_t* geom, double* u, double* v, double* w, const double* dp, const double* pfull,
+int pace_ray_fast(const pace_geom_t* geom, real* u, real* v, real* w, const double* dp, const double* pfull,
                   double dt, double ptop, double rf_cutoff, double tau, int hydrostatic, void* stream) {
   NEED(geom && u && v && w && dp && pfull);
   return launch_ray_fast(make_geo(geom), u, v, w, dp, pfull, dt, ptop, rf_cutoff, tau, hydrostatic, S(stream));
@@ -331,46 +333,46 @@ int64_t pace_del2cubed_workspace_bytes(const pace_geom_t* geom) {
   return geom ? del2cubed_workspace_bytes(make_geo(geom)) : 0;
 }
 
-int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, double* qdel, double cd,
+int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* qdel, double cd,
                    int nmax, void* stream) {
   NEED(geom && met && workspace && qdel);
   return launch_del2cubed(make_geo(geom), *met, workspace, qdel, cd, nmax, S(stream));
 }
 
-int pace_apply_diffusive_heating(const pace_geom_t* geom, const double* delp, const double* delz, const double* cappa,
-                                 const double* heat_source, double* pt, double delt_time_factor, int nlev,
+int pace_apply_diffusive_heating(const pace_geom_t* geom, const real* delp, const real* delz, const real* cappa,
+                                 const real* heat_source, real* pt, double delt_time_factor, int nlev,
                                  void* stream) {
   NEED(geom && delp && delz && cappa && heat_source && pt);
   if (nlev < 0 || nlev > geom->nk) return PACE_ERR_ARG;
   return launch_diffusive_heating(make_geo(geom), delp, delz, cappa, heat_source, pt, delt_time_factor, nlev, S(stream));
 }
 
-int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const double* cx, const double* cy,
-                             double* xfx, double* yfx, void* stream) {
+int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const real* cx, const real* cy,
+                             real* xfx, real* yfx, void* stream) {
   NEED(geom && met && cx && cy && xfx && yfx);
   return launch_tracer_flux_compute(make_geo(geom), *met, cx, cy, xfx, yfx, S(stream));
 }
 
-int pace_tracer_divide_fluxes(const pace_geom_t* geom, double* cxd, double* xfx, double* mfxd, double* cyd, double* yfx,
-                              double* mfyd, int n_split, void* stream) {
+int pace_tracer_divide_fluxes(const pace_geom_t* geom, real* cxd, real* xfx, real* mfxd, real* cyd, real* yfx,
+                              real* mfyd, int n_split, void* stream) {
   NEED(geom && cxd && xfx && mfxd && cyd && yfx && mfyd);
   if (n_split < 1) return PACE_ERR_ARG;
   return launch_tracer_divide(make_geo(geom), cxd, xfx, mfxd, cyd, yfx, mfyd, n_split, S(stream));
 }
 
-int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const double* dp1, const double* x_mass_flux,
-                         const double* y_mass_flux, double* dp2, void* stream) {
+int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const real* dp1, const real* x_mass_flux,
+                         const real* y_mass_flux, real* dp2, void* stream) {
   NEED(geom && met && dp1 && x_mass_flux && y_mass_flux && dp2);
   return launch_apply_mass_flux(make_geo(geom), *met, dp1, x_mass_flux, y_mass_flux, dp2, S(stream));
 }
 
-int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, double* q, const double* dp1,
-                           const double* fx, const double* fy, const double* dp2, void* stream) {
+int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, real* q, const real* dp1,
+                           const real* fx, const real* fy, const real* dp2, void* stream) {
   NEED(geom && met && q && dp1 && fx && fy && dp2);
   return launch_apply_tracer_flux(make_geo(geom), *met, q, dp1, fx, fy, dp2, S(stream));
 }
 
-int pace_swap_dp(const pace_geom_t* geom, double* dp1, double* dp2, void* stream) {
+int pace_swap_dp(const pace_geom_t* geom, real* dp1, real* dp2, void* stream) {
   NEED(geom && dp1 && dp2);
   return launch_swap_dp(make_geo(geom), dp1, dp2, S(stream));
 }
@@ -393,8 +395,8 @@ int64_t pace_map_single_workspace_bytes(const pace_geom_t* geom) {
   return geom ? map_single_workspace_bytes(make_geo(geom), 1) : 0;
 }
 
-int pace_map_single(const pace_geom_t* geom, void* workspace, double* q1, const double* pe1, const double* pe2,
-                    const double* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream) {
+int pace_map_single(const pace_geom_t* geom, void* workspace, real* q1, const real* pe1, const real* pe2,
+                    const real* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream) {
   NEED(geom && workspace && q1 && pe1 && pe2);
   return launch_map_fields(make_geo(geom), workspace, &q1, 1, pe1, pe2, qs, qmin, kord, iv, xstag, ystag, S(stream));
 }
@@ -403,87 +405,87 @@ int64_t pace_mapn_tracer_workspace_bytes(const pace_geom_t* geom, int nq) {
   return (geom && nq > 0) ? map_single_workspace_bytes(make_geo(geom), nq) : 0;
 }
 
-int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, double* const* tracers, int nq, const double* pe1,
-                     const double* pe2, int kord, void* stream) {
+int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, real* const* tracers, int nq, const real* pe1,
+                     const real* pe2, int kord, void* stream) {
   NEED(geom && workspace && tracers && pe1 && pe2);
   return launch_map_fields(make_geo(geom), workspace, tracers, nq, pe1, pe2, nullptr, 0.0, kord, 0, 0, 0, S(stream));
 }
 
-int pace_fillz(const pace_geom_t* geom, double* const* tracers, int nq, const double* dp2, void* stream) {
+int pace_fillz(const pace_geom_t* geom, real* const* tracers, int nq, const real* dp2, void* stream) {
   NEED(geom && tracers && dp2);
   return launch_fillz(make_geo(geom), tracers, nq, dp2, S(stream));
 }
 
-static bool six(const double* const* w) {
+static bool six(const real* const* w) {
   if (!w) return false;
   for (int n = 0; n < 6; ++n)
     if (!w[n]) return false;
   return true;
 }
 
-int pace_l2e_prepare(const pace_geom_t* geom, const double* const* water, double* q_con, double* pt, double* cappa, double* delp,
-                     double* delz, const double* pe, double* pe1, double* pe2, const double* ak, const double* bk, double* dp2,
-                     double* ps, double* pn2, const double* peln, double* pk, double ptop, double akap, double r_vir,
+int pace_l2e_prepare(const pace_geom_t* geom, const real* const* water, real* q_con, real* pt, real* cappa, real* delp,
+                     real* delz, const real* pe, real* pe1, real* pe2, const real* ak, const real* bk, real* dp2,
+                     real* ps, real* pn2, const real* peln, real* pk, double ptop, double akap, double r_vir,
                      void* stream) {
   NEED(geom && six(water) && q_con && pt && cappa && delp && delz && pe && pe1 && pe2 && ak && bk && dp2 && ps && pn2 && peln && pk);
   return launch_l2e_prepare(make_geo(geom), water, q_con, pt, cappa, delp, delz, pe, pe1, pe2, ak, bk, dp2, ps, pn2, peln, pk,
                             ptop, akap, r_vir, S(stream));
 }
 
-int pace_l2e_post(const pace_geom_t* geom, const double* const* water, double* q_con, double* pkz, const double* pt,
-                  double* cappa, const double* delp, double* delz, double* peln, double* pe0, const double* pn2, double r_vir,
+int pace_l2e_post(const pace_geom_t* geom, const real* const* water, real* q_con, real* pkz, const real* pt,
+                  real* cappa, const real* delp, real* delz, real* peln, real* pe0, const real* pn2, double r_vir,
                   void* stream) {
   NEED(geom && six(water) && q_con && pkz && pt && cappa && delp && delz && peln && pe0 && pn2);
   return launch_l2e_post(make_geo(geom), water, q_con, pkz, pt, cappa, delp, delz, peln, pe0, pn2, r_vir, S(stream));
 }
 
-int pace_l2e_pressures(const pace_geom_t* geom, int dir, const double* pe, const double* pe1, const double* ak,
-                       const double* bk, double* pe0, double* pe3, void* stream) {
+int pace_l2e_pressures(const pace_geom_t* geom, int dir, const real* pe, const real* pe1, const real* ak,
+                       const real* bk, real* pe0, real* pe3, void* stream) {
   NEED(geom && pe && pe1 && ak && bk && pe0 && pe3);
   if (dir != 0 && dir != 1) return PACE_ERR_ARG;
   return launch_l2e_pressures(make_geo(geom), dir, pe, pe1, ak, bk, pe0, pe3, S(stream));
 }
 
-int pace_l2e_finish(const pace_geom_t* geom, const double* const* water, double* pe, const double* pe2, double* pt,
-                    const double* pkz, double r_vir, int last_step, void* stream) {
+int pace_l2e_finish(const pace_geom_t* geom, const real* const* water, real* pe, const real* pe2, real* pt,
+                    const real* pkz, double r_vir, int last_step, void* stream) {
   NEED(geom && six(water) && pe && pe2 && pt && pkz);
   return launch_l2e_finish(make_geo(geom), water, pe, pe2, pt, pkz, r_vir, last_step, S(stream));
 }
 
-static bool six_rw(double* const* w) {
+static bool six_rw(real* const* w) {
   if (!w) return false;
   for (int n = 0; n < 6; ++n)
     if (!w[n]) return false;
   return true;
 }
 
-int pace_fv_setup_pt(const pace_geom_t* geom, double* const* water, double* q_con, double* pkz, double* pt, double* cappa,
-                     const double* delp, const double* delz, double* dp1, void* stream) {
+int pace_fv_setup_pt(const pace_geom_t* geom, real* const* water, real* q_con, real* pkz, real* pt, real* cappa,
+                     const real* delp, const real* delz, real* dp1, void* stream) {
   NEED(geom && six_rw(water) && q_con && pkz && pt && cappa && delp && delz && dp1);
   return launch_fv_setup_pt(make_geo(geom), water, q_con, pkz, pt, cappa, delp, delz, dp1, S(stream));
 }
 
-int pace_omega_from_w(const pace_geom_t* geom, const double* delp, const double* delz, const double* w, double* omga,
+int pace_omega_from_w(const pace_geom_t* geom, const real* delp, const real* delz, const real* w, real* omga,
                       void* stream) {
   NEED(geom && delp && delz && w && omga);
   return launch_omega_from_w(make_geo(geom), delp, delz, w, omga, S(stream));
 }
 
-int pace_neg_adj3(const pace_geom_t* geom, double* const* water, double* qcld, double* pt, const double* delp, void* stream) {
+int pace_neg_adj3(const pace_geom_t* geom, real* const* water, real* qcld, real* pt, const real* delp, void* stream) {
   NEED(geom && six_rw(water) && qcld && pt && delp);
   return launch_neg_adj3(make_geo(geom), water, qcld, pt, delp, S(stream));
 }
 
-int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const double* u, const double* v,
-                 const double* a11, const double* a12, const double* a21, const double* a22, double* ua, double* va,
+int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const real* u, const real* v,
+                 const real* a11, const real* a12, const real* a21, const real* a22, real* ua, real* va,
                  void* stream) {
   NEED(geom && met && u && v && a11 && a12 && a21 && a22 && ua && va);
   if (order != 2 && order != 4) return PACE_ERR_ARG;
   return launch_c2l(make_geo(geom), *met, order, u, v, a11, a12, a21, a22, ua, va, S(stream));
 }
 
-int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const double* q, const double* crx,
-                            const double* cry, const double* xfx, const double* yfx, double* fx, double* fy, int ib, int nx, int jb,
+int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const real* q, const real* crx,
+                            const real* cry, const real* xfx, const real* yfx, real* fx, real* fy, int ib, int nx, int jb,
                             int ny, int nlev, void* stream) {
   NEED(geom && met && q && crx && cry && xfx && yfx && fx && fy);
   if (nlev < 1 || nlev > geom->nk + 1 || nx < 1 || ny < 1) return PACE_ERR_ARG;

@@ -38,6 +38,9 @@ static inline Geo make_geo(const pace_geom_t* g) {
 }
 
 typedef pace_metrics_t Met;
+// storage type of fields, metrics and device K-arrays (include/pace_hip.h); arithmetic is double in both builds
+typedef pace_real_t real;
+#define REAL_SHIFT (sizeof(real) == 8 ? 3 : 2)  // log2 of the element size, for the byte-offset addressing of some kernels
 
 #define IDX2(g, i, j) ((long)(i) + (long)(j) * (g).sj)
 #define IDX3(g, i, j, k) ((long)(i) + (long)(j) * (g).sj + (long)(k) * (g).sk)

@@ -42,10 +42,10 @@ __device__ __forceinline__ void delnflux_core(const Geo& g, const Met& m, const 
     // first stored cell and discard it) so that all of them are in flight together instead of one branch + wait per point.
     // (Batching the LDS reads of the rounds below the same way was measured: -8 % in this stage, but 17-23 spilled VGPRs
     // at the 128-register budget of four waves per SIMD made the step 6 % slower.)
-    const unsigned c2 = stored ? (unsigned)(__mul24(gj, g.sj * 8) + (gi << 3)) : 0u;
-    const double dv_raw = *(const double*)((const char*)m.del6_v + c2);
-    const double du_raw = *(const double*)((const char*)m.del6_u + c2);
-    const double ra_raw = *(const double*)((const char*)m.rarea + c2);
+    const unsigned c2 = stored ? (unsigned)(__mul24(gj, g.sj * (int)sizeof(real)) + (gi << REAL_SHIFT)) : 0u;
+    const double dv_raw = *(const real*)((const char*)m.del6_v + c2);
+    const double du_raw = *(const real*)((const char*)m.del6_u + c2);
+    const double ra_raw = *(const real*)((const char*)m.rarea + c2);
     dv[t] = flx[t] ? dv_raw : 0.0;
     du[t] = flx[t] ? du_raw : 0.0;
     ra[t] = cel[t] ? ra_raw : 0.0;

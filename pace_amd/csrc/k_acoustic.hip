@@ -47,8 +47,8 @@ __device__ __forceinline__ long zc_yfill(const Geo& g, int i, int j) {
 // updatedzc: interface winds by dp_ref-weighted averages (p_weighted_average_*, updatedzc.py:15-31), first-order
 // upwind advection of gz (xy_flux :34-52, update_dz_c :61-117) on compute +- 1, interface levels
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double pavg(const double* __restrict__ f, long c, long sk, int k, int km,
-                                       const double* __restrict__ dp) {
+__device__ __forceinline__ double pavg(const real* __restrict__ f, long c, long sk, int k, int km,
+                                       const real* __restrict__ dp) {
   if (k == 0) {
     const double ratio = dp[0] / (dp[0] + dp[1]);
     return f[c] + (f[c] - f[c + sk]) * ratio;
@@ -62,8 +62,8 @@ __device__ __forceinline__ double pavg(const double* __restrict__ f, long c, lon
 }
 
 __global__ void __launch_bounds__(256)
-k_updatedzc_advect(Geo g, Met m, const double* __restrict__ dp_ref, const double* __restrict__ ut,
-                   const double* __restrict__ vt, const double* __restrict__ gz, double* __restrict__ gz_new) {
+k_updatedzc_advect(Geo g, Met m, const real* __restrict__ dp_ref, const real* __restrict__ ut,
+                   const real* __restrict__ vt, const real* __restrict__ gz, real* __restrict__ gz_new) {
   PATCH_IJK(g);
   if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1) return;
   const long kb = (long)k * g.sk;
@@ -84,8 +84,8 @@ k_updatedzc_advect(Geo g, Met m, const double* __restrict__ dp_ref, const double
 
 // ws and the monotonicity sweep (updatedzc.py:108-117), columns of compute +- 1
 __global__ void __launch_bounds__(64)
-k_updatedzc_column(Geo g, const double* __restrict__ zs, const double* __restrict__ gz_new, double* __restrict__ gz,
-                   double* __restrict__ ws, double rdt) {
+k_updatedzc_column(Geo g, const real* __restrict__ zs, const real* __restrict__ gz_new, real* __restrict__ gz,
+                   real* __restrict__ ws, double rdt) {
   const int i = g.is - 1 + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js - 1 + blockIdx.y;
   if (i > g.ie + 1 || j > g.je + 1) return;
@@ -102,12 +102,12 @@ k_updatedzc_column(Geo g, const double* __restrict__ zs, const double* __restric
   }
 }
 
-int64_t updatedzc_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double); }
+int64_t updatedzc_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real); }
 
-int launch_updatedzc(const Geo& g, const Met& m, void* ws_, const double* dp_ref, const double* zs, const double* ut,
-                     const double* vt, double* gz, double* ws, double dt, hipStream_t st) {
+int launch_updatedzc(const Geo& g, const Met& m, void* ws_, const real* dp_ref, const real* zs, const real* ut,
+                     const real* vt, real* gz, real* ws, double dt, hipStream_t st) {
   if (g.nk < 3) return PACE_ERR_UNSUPPORTED;
-  double* gz_new = (double*)ws_;
+  real* gz_new = (real*)ws_;
   hipLaunchKernelGGL(k_updatedzc_advect, patch_grid(g, g.nk + 1), PATCH_BLOCK, 0, st, g, m, dp_ref, ut, vt, gz, gz_new);
   hipLaunchKernelGGL(k_updatedzc_column, dim3((g.n + 2 + 63) / 64, g.n + 2), dim3(64), 0, st, g, zs, gz_new, gz, ws, 1.0 / dt);
   PACE_CHECK_LAUNCH();
@@ -118,21 +118,21 @@ int launch_updatedzc(const Geo& g, const Met& m, void* ws_, const double* dp_ref
 // updatedzd
 // ------------------------------------------------------------------------------------------------
 struct SplineK {
-  const double *gk, *beta, *gamma;  // device K-arrays (updatedzd.py:129-154)
+  const real *gk, *beta, *gamma;  // device K-arrays (updatedzd.py:129-154)
   double xt1_top, a_bot, xt1_bot, xt2_bot;
 };
 
 // cubic_spline_interpolation_from_layer_center_to_interfaces (updatedzd.py:157-196), full domain; blockIdx.z picks
 // one of the four fields
 __global__ void __launch_bounds__(64)
-k_spline_to_interfaces(Geo g, SplineK s, const double* __restrict__ q0, const double* __restrict__ q1,
-                       const double* __restrict__ q2, const double* __restrict__ q3, double* __restrict__ o0,
-                       double* __restrict__ o1, double* __restrict__ o2, double* __restrict__ o3) {
+k_spline_to_interfaces(Geo g, SplineK s, const real* __restrict__ q0, const real* __restrict__ q1,
+                       const real* __restrict__ q2, const real* __restrict__ q3, real* __restrict__ o0,
+                       real* __restrict__ o1, real* __restrict__ o2, real* __restrict__ o3) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   const int j = blockIdx.y;
   if (i > g.ni - 2 || j > g.nj - 2) return;
-  const double* qc = (blockIdx.z == 0) ? q0 : (blockIdx.z == 1) ? q1 : (blockIdx.z == 2) ? q2 : q3;
-  double* qi = (blockIdx.z == 0) ? o0 : (blockIdx.z == 1) ? o1 : (blockIdx.z == 2) ? o2 : o3;
+  const real* qc = (blockIdx.z == 0) ? q0 : (blockIdx.z == 1) ? q1 : (blockIdx.z == 2) ? q2 : q3;
+  real* qi = (blockIdx.z == 0) ? o0 : (blockIdx.z == 1) ? o1 : (blockIdx.z == 2) ? o2 : o3;
   const long c0 = IDX2(g, i, j);
   const long sk = g.sk;
   const int km = g.nk;
@@ -176,9 +176,9 @@ k_spline_to_interfaces(Geo g, SplineK s, const double* __restrict__ q0, const do
 // levels in parallel, in place: a cell reads only its own zh); ws and the bottom-up monotonicity sweep are the only
 // column-sequential part and touch one field.
 __global__ void __launch_bounds__(256)
-k_apply_height_fluxes(Geo g, Met m, double* __restrict__ zh, const double* __restrict__ fx, const double* __restrict__ fy,
-                      const double* __restrict__ xfx, const double* __restrict__ yfx, const double* __restrict__ fx2,
-                      const double* __restrict__ fy2) {
+k_apply_height_fluxes(Geo g, Met m, real* __restrict__ zh, const real* __restrict__ fx, const real* __restrict__ fy,
+                      const real* __restrict__ xfx, const real* __restrict__ yfx, const real* __restrict__ fx2,
+                      const real* __restrict__ fy2) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
@@ -189,7 +189,7 @@ k_apply_height_fluxes(Geo g, Met m, double* __restrict__ zh, const double* __res
 }
 
 __global__ void __launch_bounds__(64)
-k_height_column(Geo g, const double* __restrict__ zs, double* __restrict__ zh, double* __restrict__ ws, double dt) {
+k_height_column(Geo g, const real* __restrict__ zs, real* __restrict__ zh, real* __restrict__ ws, double dt) {
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y;
   if (i > g.ie || j > g.je) return;
@@ -217,16 +217,16 @@ k_height_column(Geo g, const double* __restrict__ zs, double* __restrict__ zh, d
 
 #define UZD_NFIELDS 8
 int64_t updatedzd_workspace_bytes(const Geo& g) {
-  return (int64_t)g.sk * (g.nk + 1) * UZD_NFIELDS * (int64_t)sizeof(double);
+  return (int64_t)g.sk * (g.nk + 1) * UZD_NFIELDS * (int64_t)sizeof(real);
 }
 
-int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd_k_t* kc, const double* zs, double* zh,
-                     const double* crx, const double* cry, const double* xfx, const double* yfx, double* wsd, double dt,
+int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd_k_t* kc, const real* zs, real* zh,
+                     const real* crx, const real* cry, const real* xfx, const real* yfx, real* wsd, double dt,
                      int hord_tm, hipStream_t st) {
   if (g.nk < 3) return PACE_ERR_UNSUPPORTED;
   const long field = g.sk * (g.nk + 1);
-  double* p = (double*)ws_;
-  double *crx_i = p, *cry_i = p + field, *xfx_i = p + 2 * field, *yfx_i = p + 3 * field, *fx = p + 4 * field,
+  real* p = (real*)ws_;
+  real *crx_i = p, *cry_i = p + field, *xfx_i = p + 2 * field, *yfx_i = p + 3 * field, *fx = p + 4 * field,
          *fy = p + 5 * field, *fx2 = p + 6 * field, *fy2 = p + 7 * field;
   SplineK s{kc->gk, kc->beta, kc->gamma, kc->xt1_top, kc->a_bot, kc->xt1_bot, kc->xt2_bot};
   hipLaunchKernelGGL(k_spline_to_interfaces, dim3((g.ni - 1 + 63) / 64, g.nj - 1, 4), dim3(64), 0, st, g, s, crx, cry, xfx, yfx,
@@ -245,7 +245,7 @@ int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd
 // ------------------------------------------------------------------------------------------------
 // gz_from_surface_height_and_thicknesses (dyn_core.py:83-96), compute domain
 __global__ void __launch_bounds__(64)
-k_gz_from_surface(Geo g, const double* __restrict__ zs, const double* __restrict__ delz, double* __restrict__ gz) {
+k_gz_from_surface(Geo g, const real* __restrict__ zs, const real* __restrict__ delz, real* __restrict__ gz) {
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y;
   if (i > g.ie || j > g.je) return;
@@ -260,8 +260,8 @@ k_gz_from_surface(Geo g, const double* __restrict__ zs, const double* __restrict
 
 // zero_data (dyn_core.py:51-80): the flux accumulators on the full domain, the heat terms on the compute domain
 __global__ void __launch_bounds__(256)
-k_zero_data(Geo g, double* __restrict__ mfxd, double* __restrict__ mfyd, double* __restrict__ cxd, double* __restrict__ cyd,
-            double* __restrict__ heat_source, double* __restrict__ diss_estd, int first_timestep) {
+k_zero_data(Geo g, real* __restrict__ mfxd, real* __restrict__ mfyd, real* __restrict__ cxd, real* __restrict__ cyd,
+            real* __restrict__ heat_source, real* __restrict__ diss_estd, int first_timestep) {
   PLANE_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
@@ -277,7 +277,7 @@ k_zero_data(Geo g, double* __restrict__ mfxd, double* __restrict__ mfyd, double*
 
 // interface_pressure_from_toa_pressure_and_thickness (dyn_core.py:99-112), compute domain +- 1
 __global__ void __launch_bounds__(64)
-k_interface_pressure(Geo g, const double* __restrict__ delp, double* __restrict__ pem, double ptop) {
+k_interface_pressure(Geo g, const real* __restrict__ delp, real* __restrict__ pem, double ptop) {
   const int i = g.is - 1 + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js - 1 + blockIdx.y;
   if (i > g.ie + 1 || j > g.je + 1) return;
@@ -290,14 +290,14 @@ k_interface_pressure(Geo g, const double* __restrict__ delp, double* __restrict_
   }
 }
 
-int launch_zero_data(const Geo& g, double* mfxd, double* mfyd, double* cxd, double* cyd, double* heat_source, double* diss_estd,
+int launch_zero_data(const Geo& g, real* mfxd, real* mfyd, real* cxd, real* cyd, real* heat_source, real* diss_estd,
                      int first_timestep, hipStream_t st) {
   hipLaunchKernelGGL(k_zero_data, plane_grid(g, g.nk), dim3(256), 0, st, g, mfxd, mfyd, cxd, cyd, heat_source, diss_estd,
                      first_timestep);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_interface_pressure(const Geo& g, const double* delp, double* pem, double ptop, hipStream_t st) {
+int launch_interface_pressure(const Geo& g, const real* delp, real* pem, double ptop, hipStream_t st) {
   hipLaunchKernelGGL(k_interface_pressure, dim3((g.n + 2 + 63) / 64, g.n + 2), dim3(64), 0, st, g, delp, pem, ptop);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
@@ -306,7 +306,7 @@ int launch_interface_pressure(const Geo& g, const double* delp, double* pem, dou
 // dst = src * factor on the window [i0, i1] x [j0, j1], nlev levels: copy_defn (basic_operations.py:7, factor 1)
 // and compute_geopotential (dyn_core.py:115-117, factor GRAV)
 __global__ void __launch_bounds__(256)
-k_scale_copy(Geo g, const double* __restrict__ src, double* __restrict__ dst, double factor, int scale, int i0, int i1,
+k_scale_copy(Geo g, const real* __restrict__ src, real* __restrict__ dst, double factor, int scale, int i0, int i1,
              int j0, int j1) {
   PLANE_IJK(g);
   if (i < i0 || i > i1 || j < j0 || j > j1) return;
@@ -316,8 +316,8 @@ k_scale_copy(Geo g, const double* __restrict__ src, double* __restrict__ dst, do
 
 // p_grad_c_stencil (dyn_core.py:120-171), non-hydrostatic; compute + 1
 __global__ void __launch_bounds__(256)
-k_p_grad_c(Geo g, Met m, double* __restrict__ uc, double* __restrict__ vc, const double* __restrict__ delpc,
-           const double* __restrict__ pkc, const double* __restrict__ gz, double dt2) {
+k_p_grad_c(Geo g, Met m, real* __restrict__ uc, real* __restrict__ vc, const real* __restrict__ delpc,
+           const real* __restrict__ pkc, const real* __restrict__ gz, double dt2) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
@@ -330,20 +330,20 @@ k_p_grad_c(Geo g, Met m, double* __restrict__ uc, double* __restrict__ vc, const
                       ((gz[c - sj + sk] - gz[c]) * (pkc[c + sk] - pkc[c - sj]) + (gz[c - sj] - gz[c + sk]) * (pkc[c - sj + sk] - pkc[c]));
 }
 
-int launch_gz_from_surface(const Geo& g, const double* zs, const double* delz, double* gz, hipStream_t st) {
+int launch_gz_from_surface(const Geo& g, const real* zs, const real* delz, real* gz, hipStream_t st) {
   hipLaunchKernelGGL(k_gz_from_surface, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, zs, delz, gz);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_scale_copy(const Geo& g, const double* src, double* dst, double factor, int scale, int halo, int nlev,
+int launch_scale_copy(const Geo& g, const real* src, real* dst, double factor, int scale, int halo, int nlev,
                       hipStream_t st) {
   hipLaunchKernelGGL(k_scale_copy, plane_grid(g, nlev), dim3(256), 0, st, g, src, dst, factor, scale, g.is - halo, g.ie + halo,
                      g.js - halo, g.je + halo);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_p_grad_c(const Geo& g, const Met& m, double* uc, double* vc, const double* delpc, const double* pkc,
-                    const double* gz, double dt2, hipStream_t st) {
+int launch_p_grad_c(const Geo& g, const Met& m, real* uc, real* vc, const real* delpc, const real* pkc,
+                    const real* gz, double dt2, hipStream_t st) {
   hipLaunchKernelGGL(k_p_grad_c, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, uc, vc, delpc, pkc, gz, dt2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
@@ -354,7 +354,7 @@ int launch_p_grad_c(const Geo& g, const Met& m, double* uc, double* vc, const do
 // ------------------------------------------------------------------------------------------------
 // set_k0_and_calc_wk (nh_p_grad.py:11-26), level 0 only; wk itself is recomputed where it is used
 __global__ void __launch_bounds__(256)
-k_nh_set_top(Geo g, double* __restrict__ pp, double* __restrict__ pk3, double top_value) {
+k_nh_set_top(Geo g, real* __restrict__ pp, real* __restrict__ pk3, double top_value) {
   PLANE_IJK(g);
   (void)k;
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
@@ -365,8 +365,8 @@ k_nh_set_top(Geo g, double* __restrict__ pp, double* __restrict__ pk3, double to
 
 // calc_u (nh_p_grad.py:29-69), calc_v (:72-112)
 __global__ void __launch_bounds__(256)
-k_nh_uv(Geo g, Met m, double* __restrict__ u, double* __restrict__ v, const double* __restrict__ wk1,
-        const double* __restrict__ gz, const double* __restrict__ pk3, const double* __restrict__ pp, double dt) {
+k_nh_uv(Geo g, Met m, real* __restrict__ u, real* __restrict__ v, const real* __restrict__ wk1,
+        const real* __restrict__ gz, const real* __restrict__ pk3, const real* __restrict__ pp, double dt) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
@@ -394,11 +394,11 @@ k_nh_uv(Geo g, Met m, double* __restrict__ u, double* __restrict__ v, const doub
   }
 }
 
-int64_t nh_p_grad_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double); }
+int64_t nh_p_grad_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real); }
 
-int launch_nh_p_grad(const Geo& g, const Met& m, void* ws_, double* u, double* v, double* pp, double* gz, double* pk3,
-                     double* delp, double dt, double ptop, double akap, hipStream_t st) {
-  double* wk1 = (double*)ws_;
+int launch_nh_p_grad(const Geo& g, const Met& m, void* ws_, real* u, real* v, real* pp, real* gz, real* pk3,
+                     real* delp, double dt, double ptop, double akap, hipStream_t st) {
+  real* wk1 = (real*)ws_;
   const int K = g.nk + 1;
   int rc;
   if ((rc = launch_a2b_ord4(g, m, pp, wk1, 1, K, 1, st))) return rc;
@@ -432,7 +432,7 @@ __device__ __forceinline__ bool ring_cell(const Geo& g, int width, int t, int& i
 }
 
 __global__ void __launch_bounds__(64)
-k_edge_pe(Geo g, double* __restrict__ pe, const double* __restrict__ delp, double ptop) {
+k_edge_pe(Geo g, real* __restrict__ pe, const real* __restrict__ delp, double ptop) {
   int i, j;
   if (!ring_cell(g, 1, blockIdx.x * 64 + threadIdx.x, i, j)) return;
   const long c0 = IDX2(g, i, j);
@@ -447,7 +447,7 @@ k_edge_pe(Geo g, double* __restrict__ pe, const double* __restrict__ delp, doubl
 // PK3Halo in two steps: the pressure scan is sequential per ring column (cheap), the power is not -- ~1600 threads
 // doing 79 dependent pow() each was 68 us; all (column, level) pairs in parallel is a few.
 __global__ void __launch_bounds__(64)
-k_pk3_halo_scan(Geo g, double* __restrict__ pk3, const double* __restrict__ delp, double ptop) {
+k_pk3_halo_scan(Geo g, real* __restrict__ pk3, const real* __restrict__ delp, double ptop) {
   int i, j;
   if (!ring_cell(g, 2, blockIdx.x * 64 + threadIdx.x, i, j)) return;
   const long c0 = IDX2(g, i, j);
@@ -459,20 +459,20 @@ k_pk3_halo_scan(Geo g, double* __restrict__ pk3, const double* __restrict__ delp
 }
 
 __global__ void __launch_bounds__(64)
-k_pk3_halo_pow(Geo g, double* __restrict__ pk3, double akap) {
+k_pk3_halo_pow(Geo g, real* __restrict__ pk3, double akap) {
   int i, j;
   if (!ring_cell(g, 2, blockIdx.x * 64 + threadIdx.x, i, j)) return;
   const long c = IDX2(g, i, j) + (long)(blockIdx.y + 1) * g.sk;
   pk3[c] = pow(pk3[c], akap);
 }
 
-int launch_edge_pe(const Geo& g, double* pe, const double* delp, double ptop, hipStream_t st) {
+int launch_edge_pe(const Geo& g, real* pe, const real* delp, double ptop, hipStream_t st) {
   const int cells = 4 * (g.n + 1);
   hipLaunchKernelGGL(k_edge_pe, dim3((cells + 63) / 64), dim3(64), 0, st, g, pe, delp, ptop);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_pk3_halo(const Geo& g, double* pk3, const double* delp, double ptop, double akap, hipStream_t st) {
+int launch_pk3_halo(const Geo& g, real* pk3, const real* delp, double ptop, double akap, hipStream_t st) {
   const int cells = (g.n + 4) * (g.n + 4) - g.n * g.n;
   hipLaunchKernelGGL(k_pk3_halo_scan, dim3((cells + 63) / 64), dim3(64), 0, st, g, pk3, delp, ptop);
   hipLaunchKernelGGL(k_pk3_halo_pow, dim3((cells + 63) / 64, g.nk), dim3(64), 0, st, g, pk3, akap);
@@ -492,7 +492,7 @@ struct RayK {
   int kmax;
 };
 
-__device__ __forceinline__ void ray_wind(const RayK& r, double* __restrict__ wind, long c0, long sk) {
+__device__ __forceinline__ void ray_wind(const RayK& r, real* __restrict__ wind, long c0, long sk) {
   double s_[RAY_MAXK];
   double s = 0.0;
   for (int k = 0; k < r.kmax; ++k) {
@@ -510,7 +510,7 @@ __device__ __forceinline__ void ray_wind(const RayK& r, double* __restrict__ win
 }
 
 __global__ void __launch_bounds__(64)
-k_ray_fast(Geo g, RayK r, double* __restrict__ u, double* __restrict__ v, double* __restrict__ w, int hydrostatic) {
+k_ray_fast(Geo g, RayK r, real* __restrict__ u, real* __restrict__ v, real* __restrict__ w, int hydrostatic) {
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y;
   if (i > g.ie + 1 || j > g.je + 1) return;
@@ -523,7 +523,7 @@ k_ray_fast(Geo g, RayK r, double* __restrict__ u, double* __restrict__ v, double
   }
 }
 
-int launch_ray_fast(const Geo& g, double* u, double* v, double* w, const double* dp, const double* pfull, double dt,
+int launch_ray_fast(const Geo& g, real* u, real* v, real* w, const double* dp, const double* pfull, double dt,
                     double ptop, double rf_cutoff, double tau, int hydrostatic, hipStream_t st) {
   const int nk = g.nk;
   const double SDAY = 86400.0, PI = 3.14159265358979323846;
@@ -582,7 +582,7 @@ int launch_ray_fast(const Geo& g, double* u, double* v, double* w, const double*
 // ------------------------------------------------------------------------------------------------
 struct Del2 {
   const Geo& g;
-  const double* q;  // level base applied
+  const real* q;  // level base applied
   // corner_fill (del2cubed.py:31-68): the inner corner cell and its two out-of-tile neighbours all become
   // the mean of the three
   __device__ __forceinline__ double filled(int i, int j) const {
@@ -604,7 +604,7 @@ struct Del2 {
 };
 
 __global__ void __launch_bounds__(256)
-k_del2cubed_iter(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, double cd, int nt) {
+k_del2cubed_iter(Geo g, Met m, const real* __restrict__ qin, real* __restrict__ qout, double cd, int nt) {
   PATCH_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long kb = (long)k * g.sk;
@@ -622,17 +622,17 @@ k_del2cubed_iter(Geo g, Met m, const double* __restrict__ qin, double* __restric
   qout[kb + c2] = val;
 }
 
-int64_t del2cubed_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double); }
+int64_t del2cubed_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real); }
 
-int launch_del2cubed(const Geo& g, const Met& m, void* ws_, double* qdel, double cd, int nmax, hipStream_t st) {
+int launch_del2cubed(const Geo& g, const Met& m, void* ws_, real* qdel, double cd, int nmax, hipStream_t st) {
   const int ntimes = nmax < 3 ? nmax : 3;
-  double* scratch = (double*)ws_;
-  double* src = qdel;
-  double* dst = scratch;
+  real* scratch = (real*)ws_;
+  real* src = qdel;
+  real* dst = scratch;
   const dim3 grid = plane_grid(g, g.nk), block(256);
   for (int n = 0; n < ntimes; ++n) {
     hipLaunchKernelGGL(k_del2cubed_iter, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, src, dst, cd, ntimes - (n + 1));
-    double* t = src;
+    real* t = src;
     src = dst;
     dst = t;
   }
@@ -643,8 +643,8 @@ int launch_del2cubed(const Geo& g, const Met& m, void* ws_, double* qdel, double
 
 // apply_diffusive_heating (temperature_adjust.py:8-43), compute domain, first nlev levels
 __global__ void __launch_bounds__(256)
-k_diffusive_heating(Geo g, const double* __restrict__ delp, const double* __restrict__ delz,
-                    const double* __restrict__ cappa, const double* __restrict__ heat_source, double* __restrict__ pt,
+k_diffusive_heating(Geo g, const real* __restrict__ delp, const real* __restrict__ delz,
+                    const real* __restrict__ cappa, const real* __restrict__ heat_source, real* __restrict__ pt,
                     double delt_time_factor) {
   PLANE_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
@@ -658,8 +658,8 @@ k_diffusive_heating(Geo g, const double* __restrict__ delp, const double* __rest
   pt[c] = pt[c] + deltmin / pkz;
 }
 
-int launch_diffusive_heating(const Geo& g, const double* delp, const double* delz, const double* cappa,
-                             const double* heat_source, double* pt, double delt_time_factor, int nlev, hipStream_t st) {
+int launch_diffusive_heating(const Geo& g, const real* delp, const real* delz, const real* cappa,
+                             const real* heat_source, real* pt, double delt_time_factor, int nlev, hipStream_t st) {
   if (nlev < 1) return PACE_OK;
   hipLaunchKernelGGL(k_diffusive_heating, plane_grid(g, nlev), dim3(256), 0, st, g, delp, delz, cappa, heat_source, pt,
                      delt_time_factor);

@@ -24,8 +24,8 @@ __device__ __forceinline__ double contra2(double v1, double v2, double cosa, dou
 
 struct D2A {
   const Geo& g;
-  const double* u;  // level base applied
-  const double* v;
+  const real* u;  // level base applied
+  const real* v;
   // d2a2c_vect.py:283-360 (lagrange_interpolation_{y,x}_p1 inside the tile, avg_box within 3 of an edge)
   __device__ __forceinline__ bool boxed(int i, int j) const {
     return (j < g.js + 3) || (j >= g.je - 2) || (i < g.is + 3) || (i >= g.ie - 2);
@@ -68,8 +68,8 @@ __device__ __forceinline__ bool fill_y_src(const Geo& g, int ncells, int i, int 
 
 // pass A
 __global__ void __launch_bounds__(256)
-k_d2a2c_a(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ utmp,
-          double* __restrict__ vtmp, double* __restrict__ ua, double* __restrict__ va) {
+k_d2a2c_a(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ utmp,
+          real* __restrict__ vtmp, real* __restrict__ ua, real* __restrict__ va) {
   PLANE_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
@@ -103,10 +103,10 @@ k_d2a2c_a(Geo g, Met m, const double* __restrict__ u, const double* __restrict__
 // pass B: d2a2c_vect.py:362-527 (ut_main / east_west_edges / north_south_edges / vt_main), geoadjust_ut/vt
 // (c_sw.py:159-203) and divergence_corner (c_sw.py:31-156)
 __global__ void __launch_bounds__(256)
-k_d2a2c_b(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
-          const double* __restrict__ utmp, const double* __restrict__ vtmp, const double* __restrict__ ua,
-          const double* __restrict__ va, double* __restrict__ uc, double* __restrict__ vc, double* __restrict__ ut,
-          double* __restrict__ vt, double* __restrict__ divgd, double dt2, int do_divg, int geoadjust, Regions R) {
+k_d2a2c_b(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
+          const real* __restrict__ utmp, const real* __restrict__ vtmp, const real* __restrict__ ua,
+          const real* __restrict__ va, real* __restrict__ uc, real* __restrict__ vc, real* __restrict__ ut,
+          real* __restrict__ vt, real* __restrict__ divgd, double dt2, int do_divg, int geoadjust, Regions R) {
   REGION_POINT(R);
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -124,8 +124,8 @@ k_d2a2c_b(Geo g, Met m, const double* __restrict__ u, const double* __restrict__
     if (geoadjust) vtv = (vtv > 0.0) ? dt2 * vtv * m.dx[c2] * m.sin_sg4[c2 - sj] : dt2 * vtv * m.dx[c2] * m.sin_sg2[c2];
     vt[c] = vtv;
     if (do_divg) {
-      const double* sg1 = m.sin_sg1; const double* sg2 = m.sin_sg2; const double* sg3 = m.sin_sg3; const double* sg4 = m.sin_sg4;
-      const double* cg1 = m.cos_sg1; const double* cg2 = m.cos_sg2; const double* cg3 = m.cos_sg3; const double* cg4 = m.cos_sg4;
+      const real* sg1 = m.sin_sg1; const real* sg2 = m.sin_sg2; const real* sg3 = m.sin_sg3; const real* sg4 = m.sin_sg4;
+      const real* cg1 = m.cos_sg1; const real* cg2 = m.cos_sg2; const real* cg3 = m.cos_sg3; const real* cg4 = m.cos_sg4;
       const double uf = (u[c] - 0.25 * (va[c - sj] + va[c]) * (cg4[c2 - sj] + cg2[c2])) * m.dyc[c2] * 0.5 * (sg4[c2 - sj] + sg2[c2]);
       const double uf1 = (u[c - 1] - 0.25 * (va[c - 1 - sj] + va[c - 1]) * (cg4[c2 - 1 - sj] + cg2[c2 - 1])) * m.dyc[c2 - 1] * 0.5 * (sg4[c2 - 1 - sj] + sg2[c2 - 1]);
       const double vf = (v[c] - 0.25 * (ua[c - 1] + ua[c]) * (cg3[c2 - 1] + cg1[c2])) * m.dxc[c2] * 0.5 * (sg3[c2 - 1] + sg1[c2]);
@@ -137,7 +137,7 @@ k_d2a2c_b(Geo g, Met m, const double* __restrict__ u, const double* __restrict__
   if (j <= g.je + 1) {  // uc, ut on i = is-1 .. ie+2, j = js-1 .. je+1
     double ucv, utv;
     if (i == g.is || i == g.ie + 1) {
-      const double* dxa = m.dxa;
+      const real* dxa = m.dxa;
       const double t1 = dxa[c2 - 2] + dxa[c2 - 1];
       const double t2 = dxa[c2] + dxa[c2 + 1];
       const double n1 = (t1 + dxa[c2 - 1]) * ua[c - 1] - dxa[c2 - 1] * ua[c - 2];
@@ -161,7 +161,7 @@ k_d2a2c_b(Geo g, Met m, const double* __restrict__ u, const double* __restrict__
   if (i <= g.ie + 1) {  // vc, vt on i = is-1 .. ie+1, j = js-1 .. je+2
     double vcv, vtv;
     if (j == g.js || j == g.je + 1) {
-      const double* dya = m.dya;
+      const real* dya = m.dya;
       const double t1 = dya[c2 - 2 * sj] + dya[c2 - sj];
       const double t2 = dya[c2] + dya[c2 + sj];
       const double n1 = (t1 + dya[c2 - sj]) * va[c - sj] - dya[c2 - sj] * va[c - 2 * sj];
@@ -184,8 +184,8 @@ k_d2a2c_b(Geo g, Met m, const double* __restrict__ u, const double* __restrict__
   }
   if (do_divg && i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1) {
     const bool iedge = (i == g.is || i == g.ie + 1), jedge = (j == g.js || j == g.je + 1);
-    const double* sg1 = m.sin_sg1; const double* sg2 = m.sin_sg2; const double* sg3 = m.sin_sg3; const double* sg4 = m.sin_sg4;
-    const double* cg1 = m.cos_sg1; const double* cg2 = m.cos_sg2; const double* cg3 = m.cos_sg3; const double* cg4 = m.cos_sg4;
+    const real* sg1 = m.sin_sg1; const real* sg2 = m.sin_sg2; const real* sg3 = m.sin_sg3; const real* sg4 = m.sin_sg4;
+    const real* cg1 = m.cos_sg1; const real* cg2 = m.cos_sg2; const real* cg3 = m.cos_sg3; const real* cg4 = m.cos_sg4;
     // uf at (i, j) and (i-1, j); vf at (i, j) and (i, j-1), interior or edge form (c_sw.py:60-156)
     const double uf = jedge ? u[c] * m.dyc[c2] * 0.5 * (sg4[c2 - sj] + sg2[c2])
                             : (u[c] - 0.25 * (va[c - sj] + va[c]) * (cg4[c2 - sj] + cg2[c2])) * m.dyc[c2] * 0.5 * (sg4[c2 - sj] + sg2[c2]);
@@ -221,12 +221,12 @@ __device__ __forceinline__ long cell_yfill(const Geo& g, int i, int j) {
 // pass C: compute_nonhydrostatic_fluxes_x (c_sw.py:231-259), transportdelp_update_vorticity_and_kineticenergy
 // (:262-364), circulation_cgrid (:367-397), absolute_vorticity (:400-408)
 __global__ void __launch_bounds__(256)
-k_csw_transport(Geo g, Met m, const double* __restrict__ delp, const double* __restrict__ pt,
-                const double* __restrict__ w, const double* __restrict__ u, const double* __restrict__ v,
-                const double* __restrict__ ua, const double* __restrict__ va, const double* __restrict__ uc,
-                const double* __restrict__ vc, const double* __restrict__ ut, const double* __restrict__ vt,
-                double* __restrict__ delpc, double* __restrict__ ptc, double* __restrict__ omga,
-                double* __restrict__ ke, double* __restrict__ vort, double dt2, Regions R) {
+k_csw_transport(Geo g, Met m, const real* __restrict__ delp, const real* __restrict__ pt,
+                const real* __restrict__ w, const real* __restrict__ u, const real* __restrict__ v,
+                const real* __restrict__ ua, const real* __restrict__ va, const real* __restrict__ uc,
+                const real* __restrict__ vc, const real* __restrict__ ut, const real* __restrict__ vt,
+                real* __restrict__ delpc, real* __restrict__ ptc, real* __restrict__ omga,
+                real* __restrict__ ke, real* __restrict__ vort, double dt2, Regions R) {
   REGION_POINT(R);
   const long kb = (long)k * g.sk;
   const long c2 = IDX2(g, i, j);
@@ -315,9 +315,9 @@ k_csw_transport(Geo g, Met m, const double* __restrict__ delp, const double* __r
 
 // pass D: update_y_velocity (c_sw.py:445-480), update_x_velocity (:411-442)
 __global__ void __launch_bounds__(256)
-k_csw_update_uc_vc(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
-                   const double* __restrict__ ke, const double* __restrict__ vort, double* __restrict__ uc,
-                   double* __restrict__ vc, double dt2) {
+k_csw_update_uc_vc(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
+                   const real* __restrict__ ke, const real* __restrict__ vort, real* __restrict__ uc,
+                   real* __restrict__ vc, double dt2) {
   PLANE_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
@@ -348,32 +348,32 @@ static Regions d2a2c_regions(const Geo& g) {
 }
 
 #define CSW_NFIELDS 4
-int64_t csw_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * CSW_NFIELDS * (int64_t)sizeof(double); }
+int64_t csw_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * CSW_NFIELDS * (int64_t)sizeof(real); }
 
-int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, double* uc, double* vc, const double* u, const double* v,
-                      double* ua, double* va, double* utc, double* vtc, hipStream_t st) {
+int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, real* uc, real* vc, const real* u, const real* v,
+                      real* ua, real* va, real* utc, real* vtc, hipStream_t st) {
   if (g.n < 8) return PACE_ERR_UNSUPPORTED;  // npt = 4 branch of d2a2c_vect.py:421-424 only
   const long field = g.sk * (g.nk + 1);
-  double* utmp = (double*)ws;
-  double* vtmp = utmp + field;
+  real* utmp = (real*)ws;
+  real* vtmp = utmp + field;
   const dim3 grid = plane_grid(g, g.nk), block(256);
   hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
   const Regions rb = d2a2c_regions(g);
   hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, utc, vtc,
-                     (double*)nullptr, 0.0, 0, 0, rb);
+                     (real*)nullptr, 0.0, 0, 0, rb);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
 
-int launch_c_sw(const Geo& g, const Met& m, void* ws, double* delpc, double* ptc, const double* delp, const double* pt,
-                const double* u, const double* v, const double* w, double* uc, double* vc, double* ua, double* va,
-                double* ut, double* vt, double* divgd, double* omga, double dt2, int nord, hipStream_t st) {
+int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, const real* delp, const real* pt,
+                const real* u, const real* v, const real* w, real* uc, real* vc, real* ua, real* va,
+                real* ut, real* vt, real* divgd, real* omga, double dt2, int nord, hipStream_t st) {
   if (g.n < 8) return PACE_ERR_UNSUPPORTED;
   const long field = g.sk * (g.nk + 1);
-  double* utmp = (double*)ws;
-  double* vtmp = utmp + field;
-  double* ke = utmp + 2 * field;
-  double* vort = utmp + 3 * field;
+  real* utmp = (real*)ws;
+  real* vtmp = utmp + field;
+  real* ke = utmp + 2 * field;
+  real* vort = utmp + 3 * field;
   const dim3 grid = plane_grid(g, g.nk), block(256);
   hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
   const Regions rb = d2a2c_regions(g);

@@ -14,10 +14,10 @@
 
 // MODE 0: write fx2, fy2.  MODE 1: fx += fx2, fy += fy2.  MODE 2: mass-weighted add (delnflux.py:318-328).
 template <int MODE>
-__global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __restrict__ q, double* fxo,
-                                                  double* fyo, const double* __restrict__ mass,
-                                                  const double* __restrict__ damp_k,
-                                                  const double* __restrict__ nord_k, int nmax, int mass_given) {
+__global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const real* __restrict__ q, real* fxo,
+                                                  real* fyo, const real* __restrict__ mass,
+                                                  const real* __restrict__ damp_k,
+                                                  const real* __restrict__ nord_k, int nmax, int mass_given) {
   __shared__ double sraw[DH * DWP];
   __shared__ double sd[DH * DWP];
   __shared__ double sfx[DH * DWP];
@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(256) k_delnflux(Geo g, Met m, const double* __
   }
 }
 
-int launch_delnflux(const Geo& g, const Met& m, int mode, const double* q, double* fx, double* fy,
-                    const double* mass, const double* damp_k, const double* nord_k, int nmax, int mass_given,
+int launch_delnflux(const Geo& g, const Met& m, int mode, const real* q, real* fx, real* fy,
+                    const real* mass, const real* damp_k, const real* nord_k, int nmax, int mass_given,
                     int nlev, hipStream_t st) {
   if (nmax > 2) return PACE_ERR_UNSUPPORTED;  // 3-cell halo (the reference would index out of range too)
   const dim3 grid((g.n + DN_TI - 1) / DN_TI, (g.n + DN_TJ - 1) / DN_TJ, nlev), block(256);

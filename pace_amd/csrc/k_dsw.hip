@@ -20,10 +20,10 @@
 // apply_pt_delp_fluxes (d_sw.py:148-201) + adjust_w_and_qcon (:331-350), given the flux-form updates
 // pt*delp + F(pt), w*delp + F(w), q_con*delp + F(q_con) that the transport kernels' epilogues produced
 __global__ void __launch_bounds__(256)
-k_finish_scalars(Geo g, Met m, double* __restrict__ pt, double* __restrict__ delp, double* __restrict__ w,
-                 double* __restrict__ q_con, const double* __restrict__ ptn, const double* __restrict__ wn,
-                 const double* __restrict__ qn, const double* __restrict__ fx, const double* __restrict__ fy,
-                 const double* __restrict__ dw, const double* __restrict__ damp_w) {
+k_finish_scalars(Geo g, Met m, real* __restrict__ pt, real* __restrict__ delp, real* __restrict__ w,
+                 real* __restrict__ q_con, const real* __restrict__ ptn, const real* __restrict__ wn,
+                 const real* __restrict__ qn, const real* __restrict__ fx, const real* __restrict__ fy,
+                 const real* __restrict__ dw, const real* __restrict__ damp_w) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
@@ -66,9 +66,9 @@ __device__ __forceinline__ double wind_flux6(const double* q6, double csign, dou
 
 template <int MORD>
 __global__ void __launch_bounds__(256)
-k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __restrict__ vc,
-                 const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ ut,
-                 const double* __restrict__ vt, double* __restrict__ ke, double dt, Regions R) {
+k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
+                 const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ut,
+                 const real* __restrict__ vt, real* __restrict__ ke, double dt, Regions R) {
   REGION_POINT(R);
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -120,7 +120,7 @@ k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __re
     // advect_v_along_y: cells (i, j-3 .. j+2); spacing passed to compute_al is dy (ytp_v.py:22)
 #pragma unroll
     for (int t = 0; t < 6; ++t) q6[t] = v[c + (long)(t - 3) * sj];
-    const double* dy = m.dy;
+    const real* dy = m.dy;
     const long col = i;
     const bool zi = (i == g.is || i == g.ie + 1);
     auto zrow = [&](int jj) { return zi && (jj == g.js - 1 || jj == g.js || jj == g.je || jj == g.je + 1); };
@@ -129,7 +129,7 @@ k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __re
                                           [=](int p) { return dy[col + (long)p * sj]; }, zrow(j - 1), zrow(j));
 #pragma unroll
     for (int t = 0; t < 6; ++t) q6[t] = u[c + (t - 3)];
-    const double* dx = m.dx + (long)j * sj;
+    const real* dx = m.dx + (long)j * sj;
     const bool zj = (j == g.js || j == g.je + 1);
     auto zcol = [&](int ii) { return zj && (ii == g.is - 1 || ii == g.is || ii == g.ie || ii == g.ie + 1); };
     cfl = (ub > 0.0) ? ub * dt * m.rdx[c2 - 1] : ub * dt * m.rdx[c2];
@@ -141,7 +141,7 @@ k_kinetic_energy(Geo g, Met m, const double* __restrict__ uc, const double* __re
 
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
 __global__ void __launch_bounds__(256)
-k_vorticity(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ vort) {
+k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ vort) {
   PATCH_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
@@ -154,8 +154,8 @@ k_vorticity(Geo g, Met m, const double* __restrict__ u, const double* __restrict
 // ------------------------------------------------------------------------------------------------
 // DivergenceDamping, sponge levels (nord_col == 0): divergence_damping.py:30-158
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double dd_u_contra_dyc(const Geo& g, const Met& m, const double* u, const double* va,
-                                                  const double* vc, long c, long c2, int j) {
+__device__ __forceinline__ double dd_u_contra_dyc(const Geo& g, const Met& m, const real* u, const real* va,
+                                                  const real* vc, long c, long c2, int j) {
   double uc_;
   if (j == g.js || j == g.je + 1) {
     uc_ = (vc[c] > 0.0) ? u[c] * m.sin_sg4[c2 - g.sj] : u[c] * m.sin_sg2[c2];
@@ -166,8 +166,8 @@ __device__ __forceinline__ double dd_u_contra_dyc(const Geo& g, const Met& m, co
   return uc_ * m.dyc[c2];
 }
 
-__device__ __forceinline__ double dd_v_contra_dxc(const Geo& g, const Met& m, const double* v, const double* ua,
-                                                  const double* uc, long c, long c2, int i) {
+__device__ __forceinline__ double dd_v_contra_dxc(const Geo& g, const Met& m, const real* v, const real* ua,
+                                                  const real* uc, long c, long c2, int i) {
   double vc_;
   if (i == g.is || i == g.ie + 1) {
     vc_ = (uc[c] > 0.0) ? v[c] * m.sin_sg3[c2 - 1] : v[c] * m.sin_sg1[c2];
@@ -179,10 +179,10 @@ __device__ __forceinline__ double dd_v_contra_dxc(const Geo& g, const Met& m, co
 }
 
 __global__ void __launch_bounds__(256)
-k_divdamp_low(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
-              const double* __restrict__ ua, const double* __restrict__ va, const double* __restrict__ uc,
-              const double* __restrict__ vc, double* __restrict__ delpc, double* __restrict__ vort_b,
-              double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dt) {
+k_divdamp_low(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
+              const real* __restrict__ ua, const real* __restrict__ va, const real* __restrict__ uc,
+              const real* __restrict__ vc, real* __restrict__ delpc, real* __restrict__ vort_b,
+              real* __restrict__ ke, const real* __restrict__ d2_bg, double dddmp, double dt) {
   PLANE_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
@@ -235,7 +235,7 @@ __device__ __forceinline__ void remap_bgrid_y(const Geo& g, int& i, int& j) {
 
 // accessors of a 2-D plane by global (i, j): a level of a field in memory, or a tile's footprint staged in LDS
 struct PlaneInMemory {
-  const double* p;  // level base applied
+  const real* p;  // level base applied
   int sj;
   __device__ __forceinline__ double operator()(int i, int j) const { return p[(long)j * sj + i]; }
 };
@@ -287,8 +287,8 @@ struct DivIterT {
 };
 
 __global__ void __launch_bounds__(256)
-k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict__ dout, int k0, int fill, int adjust,
-               double* __restrict__ uc_out, double* __restrict__ vc_out, Regions R) {
+k_divdamp_iter(Geo g, Met m, const real* __restrict__ din, real* __restrict__ dout, int k0, int fill, int adjust,
+               real* __restrict__ uc_out, real* __restrict__ vc_out, Regions R) {
   REGION_POINT(R);
   const int kk = k + k0;
   const long c2 = IDX2(g, i, j);
@@ -326,8 +326,8 @@ k_divdamp_iter(Geo g, Met m, const double* __restrict__ din, double* __restrict_
   }
 }
 
-static void launch_divdamp_iter(const Geo& g, const Met& m, const double* din, double* dout, int k0, int nlev, int nt, int fill,
-                                double* uc_out, double* vc_out, hipStream_t st) {
+static void launch_divdamp_iter(const Geo& g, const Met& m, const real* din, real* dout, int k0, int nlev, int nt, int fill,
+                                real* uc_out, real* vc_out, hipStream_t st) {
   const int jb = g.js - nt, je_ = g.je + nt + 1;
   Regions r{};
   add_region(r, g.is + 1, g.ie, jb, je_);
@@ -362,7 +362,7 @@ __device__ __forceinline__ double a2b_interior_point(const Plane& Q, int i, int 
 struct A2B {
   const Geo& g;
   const Met& m;
-  const double* q;  // level base applied
+  const real* q;  // level base applied
   __device__ __forceinline__ double Q(int i, int j) const { return q[IDX2(g, i, j)]; }
   __device__ __forceinline__ double DXA(int i, int j) const { return m.dxa[IDX2(g, i, j)]; }
   __device__ __forceinline__ double DYA(int i, int j) const { return m.dya[IDX2(g, i, j)]; }
@@ -476,14 +476,14 @@ struct A2B {
 };
 
 __global__ void __launch_bounds__(256)
-k_a2b_ord4(Geo g, Met m, const double* __restrict__ qin, double* __restrict__ qout, int k0, Regions R) {
+k_a2b_ord4(Geo g, Met m, const real* __restrict__ qin, real* __restrict__ qout, int k0, Regions R) {
   REGION_POINT(R);
   const int kk = k + k0;
   A2B a{g, m, qin + (long)kk * g.sk};
   qout[IDX3(g, i, j, kk)] = interior ? a.point_interior(i, j) : a.point(i, j);
 }
 
-__global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __restrict__ src, double* __restrict__ dst, int k0, int i1, int j1) {
+__global__ void __launch_bounds__(256) k_copy_window(Geo g, const real* __restrict__ src, real* __restrict__ dst, int k0, int i1, int j1) {
   PLANE_IJK(g);
   const int kk = k + k0;
   if (i < g.is || i > i1 || j < g.js || j > j1) return;
@@ -493,9 +493,9 @@ __global__ void __launch_bounds__(256) k_copy_window(Geo g, const double* __rest
 
 // tail of DivergenceDamping for nord > 0 levels: a2b_ord4(wk) -> smagorinsky -> damping
 __global__ void __launch_bounds__(256)
-k_divdamp_high_final(Geo g, Met m, const double* __restrict__ wk, const double* delpc_src, double* divgd_out,
-                     double* __restrict__ delpc, const double* __restrict__ divg_d, double* __restrict__ vort_b,
-                     double* __restrict__ ke, const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt,
+k_divdamp_high_final(Geo g, Met m, const real* __restrict__ wk, const real* delpc_src, real* divgd_out,
+                     real* __restrict__ delpc, const real* __restrict__ divg_d, real* __restrict__ vort_b,
+                     real* __restrict__ ke, const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt,
                      int k0, Regions R) {
   REGION_POINT(R);
   const int kk = k + k0;
@@ -612,9 +612,9 @@ __device__ __forceinline__ void dd_pass_batch(const Geo& g, const Met& m, const 
 // the 16-point mean): loads first, then arithmetic.
 template <int T0, int T1>
 __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const double* __restrict__ src,
-                                              const double* __restrict__ swk, const double* __restrict__ din,
-                                              double* __restrict__ divg_d, double* __restrict__ vort_b, double* __restrict__ ke,
-                                              double* __restrict__ uc_out, double* __restrict__ vc_out, double d2, double dddmp,
+                                              const double* __restrict__ swk, const real* __restrict__ din,
+                                              real* __restrict__ divg_d, real* __restrict__ vort_b, real* __restrict__ ke,
+                                              real* __restrict__ uc_out, real* __restrict__ vc_out, double d2, double dddmp,
                                               double dd8, double absdt, int tid, int i0, int j0, long kb) {
   constexpr int NB = T1 - T0;
   double dvm[NB], dv0[NB], dum[NB], du0[NB], ra[NB], dpc[NB], ke0[NB];
@@ -668,9 +668,9 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
 }
 
 __global__ void __launch_bounds__(256)
-k_divdamp_fused(Geo g, Met m, const double* __restrict__ wk, const double* __restrict__ din, double* __restrict__ divg_d,
-                double* __restrict__ vort_b, double* __restrict__ ke, double* __restrict__ uc_out, double* __restrict__ vc_out,
-                const double* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx) {
+k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
+                real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
+                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx) {
   __shared__ double sbuf[2][DD_W * DD_H];
   const int tid = threadIdx.x;
   const int bx = (int)blockIdx.x % ntx, by = (int)blockIdx.x / ntx;
@@ -805,8 +805,8 @@ k_divdamp_fused(Geo g, Met m, const double* __restrict__ wk, const double* __res
 // heat_source_from_vorticity_damping (:493-577), update_u_and_v (:582-608)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_uv_from_ke(Geo g, Met m, double* __restrict__ u, double* __restrict__ v, const double* __restrict__ ke,
-             const double* __restrict__ fx, const double* __restrict__ fy) {
+k_uv_from_ke(Geo g, Met m, real* __restrict__ u, real* __restrict__ v, const real* __restrict__ ke,
+             const real* __restrict__ fx, const real* __restrict__ fy) {
   PATCH_IJK(g);
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -818,8 +818,8 @@ struct HeatPt {
   double ubt, vbt, fy, fx, gy, gx;
 };
 
-__device__ __forceinline__ HeatPt heat_point(const Geo& g, const Met& m, const double* u, const double* v,
-                                             const double* vort_b, const double* ut2, const double* vt2, bool don,
+__device__ __forceinline__ HeatPt heat_point(const Geo& g, const Met& m, const real* u, const real* v,
+                                             const real* vort_b, const real* ut2, const real* vt2, bool don,
                                              long c, long c2, int i, int j) {
   // vort_x_delta / vort_y_delta are only written where d_con > threshold and inside their regions
   // (d_sw.py:373-380); elsewhere the reference reads its zero-initialised persistent temporaries.
@@ -839,10 +839,10 @@ __device__ __forceinline__ HeatPt heat_point(const Geo& g, const Met& m, const d
 }
 
 __global__ void __launch_bounds__(256)
-k_heat_source(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v,
-              const double* __restrict__ vort_b, const double* __restrict__ ut2, const double* __restrict__ vt2,
-              const double* __restrict__ delp, double* __restrict__ heat_s, double* __restrict__ heat_source,
-              double* __restrict__ diss_est, const double* __restrict__ d_con_k, double d_con, int do_skeb) {
+k_heat_source(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
+              const real* __restrict__ vort_b, const real* __restrict__ ut2, const real* __restrict__ vt2,
+              const real* __restrict__ delp, real* __restrict__ heat_s, real* __restrict__ heat_source,
+              real* __restrict__ diss_est, const real* __restrict__ d_con_k, double d_con, int do_skeb) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
@@ -869,8 +869,8 @@ k_heat_source(Geo g, Met m, const double* __restrict__ u, const double* __restri
 }
 
 __global__ void __launch_bounds__(256)
-k_update_uv(Geo g, double* __restrict__ u, double* __restrict__ v, const double* __restrict__ ut2,
-            const double* __restrict__ vt2, const double* __restrict__ damp_vt) {
+k_update_uv(Geo g, real* __restrict__ u, real* __restrict__ v, const real* __restrict__ ut2,
+            const real* __restrict__ vt2, const real* __restrict__ damp_vt) {
   PLANE_IJK(g);
   if (!(damp_vt[k] > 1e-5)) return;
   const long c = IDX3(g, i, j, k);
@@ -887,7 +887,7 @@ static Regions a2b_regions(const Geo& g) {
   return r;
 }
 
-int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k0, int k1, int replace, hipStream_t st) {
+int launch_a2b_ord4(const Geo& g, const Met& m, real* qin, real* qout, int k0, int k1, int replace, hipStream_t st) {
   const int nlev = k1 - k0;
   const Regions r = a2b_regions(g);
   hipLaunchKernelGGL(k_a2b_ord4, regions_grid(r, nlev), dim3(64, 4), 0, st, g, m, qin, qout, k0, r);
@@ -896,7 +896,7 @@ int launch_a2b_ord4(const Geo& g, const Met& m, double* qin, double* qout, int k
   return PACE_OK;
 }
 
-__global__ void __launch_bounds__(256) k_copy_levels(Geo g, const double* __restrict__ src, double* __restrict__ dst, int k0) {
+__global__ void __launch_bounds__(256) k_copy_levels(Geo g, const real* __restrict__ src, real* __restrict__ dst, int k0) {
   PLANE_IJK(g);
   const long c = IDX3(g, i, j, k + k0);
   dst[c] = src[c];
@@ -912,10 +912,10 @@ static bool legacy_divergence_damping() {
 // layers, nord = 0 there), `nonzero_nord` iterations of the divergence of the gradient of the divergence below, then
 // a2b_ord4 of the relative vorticity, the Smagorinsky term and the damped vorticity; ke += damping.  uc, vc and divg_d end as
 // the reference leaves them (the last iteration's work values on the staggered compute windows).  da / db: two scratch fields.
-int launch_divergence_damping(const Geo& g, const Met& m, const double* u, const double* v, const double* va, double* vort_b,
-                              const double* ua, double* divg_d, double* vc, double* uc, double* delpc, double* ke,
-                              const double* rel_vort_agrid, double dt, const double* d2_bg_dev, int kstart, int nonzero_nord,
-                              double dddmp, double d4_bg, double* da, double* db, hipStream_t st) {
+int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const real* v, const real* va, real* vort_b,
+                              const real* ua, real* divg_d, real* vc, real* uc, real* delpc, real* ke,
+                              const real* rel_vort_agrid, double dt, const real* d2_bg_dev, int kstart, int nonzero_nord,
+                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st) {
   const int nk = g.nk;
   if (kstart > 0) {
     hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
@@ -930,12 +930,12 @@ int launch_divergence_damping(const Geo& g, const Met& m, const double* u, const
     hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)nhigh), dim3(256), 0, st, g, m, rel_vort_agrid,
                        delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart, nonzero_nord, ntx);
   } else if (nhigh > 0) {
-    const double* src = divg_d;
-    double* bufs[2] = {da, db};
+    const real* src = divg_d;
+    real* bufs[2] = {da, db};
     for (int n = 0; n < nonzero_nord; ++n) {
       const int nt = nonzero_nord - (n + 1);
       const int fill = (n + 1 != nonzero_nord) ? 1 : 0;
-      double* dst = bufs[n & 1];
+      real* dst = bufs[n & 1];
       const bool last = (n + 1 == nonzero_nord);  // nt == 0: its region is exactly the (n+1) x (n+1) corner points
       launch_divdamp_iter(g, m, src, dst, kstart, nhigh, nt, fill, last ? uc : nullptr, last ? vc : nullptr, st);
       src = dst;
@@ -950,21 +950,21 @@ int launch_divergence_damping(const Geo& g, const Met& m, const double* u, const
 }
 
 struct DswWork {
-  double *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv;
-  double* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
+  real *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv;
+  real* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
 };
 #define DSW_NFIELDS 19
 
 int64_t dsw_workspace_bytes(const Geo& g) {
-  const int64_t field = (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double);
-  return field * DSW_NFIELDS + 16 * (int64_t)(g.nk + 1) * (int64_t)sizeof(double) + 256;
+  const int64_t field = (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real);
+  return field * DSW_NFIELDS + 16 * (int64_t)(g.nk + 1) * (int64_t)sizeof(real) + 256;
 }
 
 static DswWork carve(const Geo& g, void* ws) {
   DswWork w;
-  double* p = (double*)ws;
+  real* p = (real*)ws;
   const long field = g.sk * (g.nk + 1);
-  double** f = &w.ut;
+  real** f = &w.ut;
   for (int n = 0; n < DSW_NFIELDS; ++n) f[n] = p + (long)n * field;
   w.kcol = p + (long)DSW_NFIELDS * field;
   return w;
@@ -972,10 +972,10 @@ static DswWork carve(const Geo& g, void* ws) {
 
 #ifdef PACE_EMU
 #include <cstring>
-static void upload(double* dst, const double* src, size_t n, hipStream_t) { memcpy(dst, src, n * sizeof(double)); }
+static void upload(real* dst, const real* src, size_t n, hipStream_t) { memcpy(dst, src, n * sizeof(real)); }
 #else
-static void upload(double* dst, const double* src, size_t n, hipStream_t st) {
-  (void)hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, st);
+static void upload(real* dst, const real* src, size_t n, hipStream_t st) {
+  (void)hipMemcpyAsync(dst, src, n * sizeof(real), hipMemcpyHostToDevice, st);
   (void)hipStreamSynchronize(st);
 }
 #endif
@@ -985,11 +985,11 @@ static void upload(double* dst, const double* src, size_t n, hipStream_t st) {
 int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st) {
   DswWork W = carve(g, ws);
   const int K = g.nk + 1;
-  std::vector<double> h((size_t)NCOL * K, 0.0);
+  std::vector<real> h((size_t)NCOL * K, (real)0.0);
   const double* src[NCOL] = {col->nord_v, col->nord_w, col->nord_t, col->damp_vt, col->damp_w, col->damp_t, col->d2_divg,
                              col->d_con,  col->ke_bg,  col->fac_vt, col->fac_t,   col->fac_vt_c, col->fac_w_c};
   for (int a = 0; a < NCOL; ++a)
-    for (int k = 0; k < g.nk; ++k) h[(size_t)a * K + k] = src[a][k];
+    for (int k = 0; k < g.nk; ++k) h[(size_t)a * K + k] = (real)src[a][k];
   upload(W.kcol, h.data(), h.size(), st);
   return PACE_OK;
 }
@@ -1001,16 +1001,16 @@ int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st
 // 4 (then 8) on a second stream concurrently with 2 and with whatever follows d_sw on the first stream -- the vertical
 // solver -- see pace_amd/fv3core/stencils/d_sw.py.
 int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace_dsw_config_t* cfg, void* ws,
-                double* delpc, double* delp, double* pt, double* u, double* v, double* w, double* uc, double* vc,
-                const double* ua, const double* va, double* divgd, double* mfx, double* mfy, double* cx, double* cy,
-                double* crx, double* cry, double* xfx, double* yfx, double* q_con, const double* zh,
-                double* heat_source, double* diss_est, double dt, int phases, hipStream_t st) {
+                real* delpc, real* delp, real* pt, real* u, real* v, real* w, real* uc, real* vc,
+                const real* ua, const real* va, real* divgd, real* mfx, real* mfy, real* cx, real* cy,
+                real* crx, real* cry, real* xfx, real* yfx, real* q_con, const real* zh,
+                real* heat_source, real* diss_est, double dt, int phases, hipStream_t st) {
   (void)zh;
   const int nk = g.nk;
   DswWork W = carve(g, ws);
   const int K = nk + 1;
-  double* kc = W.kcol;  // filled by dsw_prepare
-  double *d_nord_v = kc, *d_nord_w = kc + K, *d_nord_t = kc + 2 * K, *d_damp_vt_c = kc + 3 * K, *d_damp_w_c = kc + 4 * K,
+  real* kc = W.kcol;  // filled by dsw_prepare
+  real *d_nord_v = kc, *d_nord_w = kc + K, *d_nord_t = kc + 2 * K, *d_damp_vt_c = kc + 3 * K, *d_damp_w_c = kc + 4 * K,
          *d_d2 = kc + 6 * K, *d_dcon = kc + 7 * K, *d_kebg = kc + 8 * K, *d_dampfac_vt = kc + 9 * K,
          *d_dampfac_t = kc + 10 * K, *d_dampfac_vt_c = kc + 11 * K, *d_dampfac_w_c = kc + 12 * K;
   int nmax_v = 0, nmax_w = 0, nmax_t = 0, kstart = 0, nonzero_nord = cfg->nord;

@@ -28,7 +28,7 @@
 #define PACE_LI0 (PACE_HLF - PACE_DC_ICE * PACE_TICE)
 
 struct Water6 {
-  double *qvapor, *qliquid, *qrain, *qsnow, *qice, *qgraupel;
+  real *qvapor, *qliquid, *qrain, *qsnow, *qice, *qgraupel;
 };
 
 #define CELL_IJK()                                     \
@@ -39,9 +39,9 @@ struct Water6 {
   const long c = IDX3(g, i, j, k)
 
 __global__ void __launch_bounds__(256)
-k_fv_setup_pt(Geo g, Water6 q, double* __restrict__ q_con, double* __restrict__ pkz, double* __restrict__ pt,
-              double* __restrict__ cappa, const double* __restrict__ delp, const double* __restrict__ delz,
-              double* __restrict__ dp1) {
+k_fv_setup_pt(Geo g, Water6 q, real* __restrict__ q_con, real* __restrict__ pkz, real* __restrict__ pt,
+              real* __restrict__ cappa, const real* __restrict__ delp, const real* __restrict__ delz,
+              real* __restrict__ dp1) {
   CELL_IJK();
   const double qv = q.qvapor[c];
   const double ql = q.qliquid[c] + q.qrain[c];
@@ -60,14 +60,14 @@ k_fv_setup_pt(Geo g, Water6 q, double* __restrict__ q_con, double* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256)
-k_omega_from_w(Geo g, const double* __restrict__ delp, const double* __restrict__ delz, const double* __restrict__ w,
-               double* __restrict__ omga) {
+k_omega_from_w(Geo g, const real* __restrict__ delp, const real* __restrict__ delz, const real* __restrict__ w,
+               real* __restrict__ omga) {
   CELL_IJK();
   omga[c] = delp[c] / delz[c] * w[c];
 }
 
 __global__ void __launch_bounds__(256)
-k_fix_neg_water(Geo g, Water6 q, double* __restrict__ ptf, double lv00, double d0_vap) {
+k_fix_neg_water(Geo g, Water6 q, real* __restrict__ ptf, double lv00, double d0_vap) {
   CELL_IJK();
   double qv = q.qvapor[c], ql = q.qliquid[c], qr = q.qrain[c], qs = q.qsnow[c], qi = q.qice[c], qg = q.qgraupel[c];
   double pt = ptf[c];
@@ -166,7 +166,7 @@ k_fix_neg_water(Geo g, Water6 q, double* __restrict__ ptf, double lv00, double d
 #define Q(k) q[c0 + (long)(k) * sk]
 #define DP(k) dp[c0 + (long)(k) * sk]
 
-__device__ __forceinline__ void col_fillq(double* __restrict__ q, const double* __restrict__ dp, long c0, long sk, int km) {
+__device__ __forceinline__ void col_fillq(real* __restrict__ q, const real* __restrict__ dp, long c0, long sk, int km) {
   double s1 = 0.0, s2 = 0.0;
   for (int k = 0; k < km; ++k) {
     const double v = Q(k);
@@ -193,7 +193,7 @@ __device__ __forceinline__ void col_fillq(double* __restrict__ q, const double* 
   }
 }
 
-__device__ __forceinline__ void col_vapor_down(double* __restrict__ q, const double* __restrict__ dp, long c0, long sk, int km) {
+__device__ __forceinline__ void col_vapor_down(real* __restrict__ q, const real* __restrict__ dp, long c0, long sk, int km) {
   double dpm = DP(0), dpk = DP(1);
   double qm = Q(0), qk = Q(1);
   if (qm < 0) qk = qk + qm * dpm / dpk;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void col_vapor_down(double* __restrict__ q, const dou
   Q(km - 1) = un;
 }
 
-__device__ __forceinline__ void col_neg_cloud(double* __restrict__ q, const double* __restrict__ dp, long c0, long sk, int km) {
+__device__ __forceinline__ void col_neg_cloud(real* __restrict__ q, const real* __restrict__ dp, long c0, long sk, int km) {
   double qm = Q(0), dpm = DP(0);  // level k-1 as the forward sweep sees it (before the clamp)
   for (int k = 1; k < km - 1; ++k) {
     double v = Q(k);
@@ -268,8 +268,8 @@ __device__ __forceinline__ void col_neg_cloud(double* __restrict__ q, const doub
 #undef DP
 
 __global__ void __launch_bounds__(64)
-k_neg_columns(Geo g, double* __restrict__ qgraupel, double* __restrict__ qrain, double* __restrict__ qvapor,
-              double* __restrict__ qcld, const double* __restrict__ dp) {
+k_neg_columns(Geo g, real* __restrict__ qgraupel, real* __restrict__ qrain, real* __restrict__ qvapor,
+              real* __restrict__ qcld, const real* __restrict__ dp) {
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y;
   if (i > g.ie) return;
@@ -285,9 +285,9 @@ k_neg_columns(Geo g, double* __restrict__ qgraupel, double* __restrict__ qrain, 
 // ---- CubedToLatLon ----------------------------------------------------------------------------------------------
 template <int ORD>
 __global__ void __launch_bounds__(256)
-k_c2l(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ a11,
-      const double* __restrict__ a12, const double* __restrict__ a21, const double* __restrict__ a22, double* __restrict__ ua,
-      double* __restrict__ va) {
+k_c2l(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ a11,
+      const real* __restrict__ a12, const real* __restrict__ a21, const real* __restrict__ a22, real* __restrict__ ua,
+      real* __restrict__ va) {
   const int h = ORD == 2 ? 1 : 0;  // compute_halos (c2l_ord.py:147-152)
   const int i = g.is - h + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js - h + blockIdx.y * 4 + threadIdx.y;
@@ -318,22 +318,22 @@ k_c2l(Geo g, Met m, const double* __restrict__ u, const double* __restrict__ v, 
 
 static dim3 cell_grid(const Geo& g, int pad) { return dim3((g.n + 2 * pad + 63) / 64, (g.n + 2 * pad + 3) / 4, g.nk); }
 
-static Water6 water6(double* const* w) { return Water6{w[0], w[1], w[2], w[3], w[4], w[5]}; }
+static Water6 water6(real* const* w) { return Water6{w[0], w[1], w[2], w[3], w[4], w[5]}; }
 
-int launch_fv_setup_pt(const Geo& g, double* const* water, double* q_con, double* pkz, double* pt, double* cappa,
-                       const double* delp, const double* delz, double* dp1, hipStream_t st) {
+int launch_fv_setup_pt(const Geo& g, real* const* water, real* q_con, real* pkz, real* pt, real* cappa,
+                       const real* delp, const real* delz, real* dp1, hipStream_t st) {
   hipLaunchKernelGGL(k_fv_setup_pt, cell_grid(g, 0), dim3(64, 4), 0, st, g, water6(water), q_con, pkz, pt, cappa, delp, delz, dp1);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
 
-int launch_omega_from_w(const Geo& g, const double* delp, const double* delz, const double* w, double* omga, hipStream_t st) {
+int launch_omega_from_w(const Geo& g, const real* delp, const real* delz, const real* w, real* omga, hipStream_t st) {
   hipLaunchKernelGGL(k_omega_from_w, cell_grid(g, 0), dim3(64, 4), 0, st, g, delp, delz, w, omga);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
 
-int launch_neg_adj3(const Geo& g, double* const* water, double* qcld, double* pt, const double* delp, hipStream_t st) {
+int launch_neg_adj3(const Geo& g, real* const* water, real* qcld, real* pt, const real* delp, hipStream_t st) {
   if (g.nk < 4) return PACE_ERR_UNSUPPORTED;
   const double d0_vap = PACE_CV_VAP - PACE_C_LIQ;        // non-hydrostatic (neg_adj3.py:327-332)
   const double lv00 = PACE_HLV - d0_vap * PACE_TICE;
@@ -344,8 +344,8 @@ int launch_neg_adj3(const Geo& g, double* const* water, double* qcld, double* pt
   return PACE_OK;
 }
 
-int launch_c2l(const Geo& g, const Met& m, int order, const double* u, const double* v, const double* a11, const double* a12,
-               const double* a21, const double* a22, double* ua, double* va, hipStream_t st) {
+int launch_c2l(const Geo& g, const Met& m, int order, const real* u, const real* v, const real* a11, const real* a12,
+               const real* a21, const real* a22, real* ua, real* va, hipStream_t st) {
   if (order == 2) hipLaunchKernelGGL(k_c2l<2>, cell_grid(g, 1), dim3(64, 4), 0, st, g, m, u, v, a11, a12, a21, a22, ua, va);
   else hipLaunchKernelGGL(k_c2l<4>, cell_grid(g, 0), dim3(64, 4), 0, st, g, m, u, v, a11, a12, a21, a22, ua, va);
   PACE_CHECK_LAUNCH();

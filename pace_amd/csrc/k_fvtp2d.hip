@@ -22,9 +22,9 @@ static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the tr
 // Global accesses: uniform field base (SGPR pair) + 32-bit byte offset per lane, so that loads / stores take the
 // `global_load ... v_off, s[base:base+1]` form and the offset arithmetic is two full-rate 32-bit instructions
 // (v_mad_i32_i24 + shift) instead of a quarter-rate 64-bit multiply-add and a 64-bit add per access.  (A field is < 4 GB.)
-#define OFF2(gi, gj) ((unsigned)(__mul24((gj), sj8) + ((gi) << 3)))
-#define LD(p, off) (*(const double*)((const char*)(p) + (off)))
-#define ST(p, off) (*(double*)((char*)(p) + (off)))
+#define OFF2(gi, gj) ((unsigned)(__mul24((gj), sj8) + ((gi) << REAL_SHIFT)))
+#define LD(p, off) (*(const real*)((const char*)(p) + (off)))
+#define ST(p, off) (*(real*)((char*)(p) + (off)))
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
@@ -104,11 +104,11 @@ static_assert((GX - 1) * RF + RF + 4 < 2 * (QW + 1), "an x-run may overrun its r
 static_assert(QW * GY <= 256 && QH * GX <= 256 && (TJ + 3) * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
 template <int MORD, bool EX, bool EY, int DMODE, int EPI>
-__device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, const Met& m, const double* __restrict__ q,
-                                            const double* __restrict__ crx, const double* __restrict__ cry,
-                                            const double* __restrict__ xfx, const double* __restrict__ yfx,
-                                            double* __restrict__ fx, double* __restrict__ fy,
-                                            const double* __restrict__ xunit, const double* __restrict__ yunit,
+__device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, const Met& m, const real* __restrict__ q,
+                                            const real* __restrict__ crx, const real* __restrict__ cry,
+                                            const real* __restrict__ xfx, const real* __restrict__ yfx,
+                                            real* __restrict__ fx, real* __restrict__ fy,
+                                            const real* __restrict__ xunit, const real* __restrict__ yunit,
                                             const FvDamp& dp) {
   auto& sq = L.sq;
   auto& syin = L.syin;
@@ -123,8 +123,9 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   const long kb = (long)k * g.sk;
   const int ilo = i0 - 3, jlo = j0 - 3;
   const int sj = g.sj;
-  const int sj8 = sj * 8;
-  const unsigned kb8 = (unsigned)(kb * 8);
+  const int sj8 = sj * (int)sizeof(real);  // byte strides (the names date from the fp64-only kernel)
+  constexpr int E8 = (int)sizeof(real);
+  const unsigned kb8 = (unsigned)(kb * (long)sizeof(real));
   // Thread maps of the outer sweeps (stage 5): the thread that ran the inner x-run of footprint row jj+3 / the inner y-run
   // of footprint column ii+3 also runs the outer run of tile row jj / tile column ii, so the Courant numbers it loaded
   // for the inner sweep are reused from registers instead of being fetched a second time (by then evicted from L2).
@@ -166,7 +167,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   double dvx[RF], dvy[RF];
   double damp = 0.0;
   if (DMODE >= 0) {
-    static_assert(DMODE < 0 || sizeof(L.syin) + sizeof(L.sqi) + sizeof(L.sxin) + sizeof(L.pad) >= 3 * DH * DWP * sizeof(double),
+    static_assert(DMODE < 0 || sizeof(L.syin) + sizeof(L.sqi) + sizeof(L.sxin) + sizeof(L.pad) >= 3 * DH * DWP * sizeof(real),
                   "scratch");
     double* sd = &L.syin[0][0];
     double* sfx = sd + DH * DWP;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       cc[f] = (col_ok && jj0 + f <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1))) ? LD(cry, kb8 + OFF2(gi, gj)) : 0.0;
       cy_keep[f] = cc[f];
     }
-    const double* dya = m.dya;
+    const real* dya = m.dya;
     const int gic = gi < g.ni ? gi : g.ni - 1;  // (a tile may stick out of the storage: the metric row must exist)
     ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gic, p)); }, out);
 #pragma unroll
@@ -292,7 +293,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       cc[f] = (row_ok && ii0 + f <= TI && (!EX || (gi >= g.is && gi <= g.ie + 1))) ? LD(crx, kb8 + OFF2(gi, gj)) : 0.0;
       cx_keep[f] = cc[f];
     }
-    const double* dxa = m.dxa;
+    const real* dxa = m.dxa;
     const int gjc = gj < g.nj ? gj : g.nj - 1;  // (a tile may stick out of the storage: the metric row must exist)
     ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gjc)); }, out);
 #pragma unroll
@@ -316,7 +317,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const bool ok = e < TI * QH && (!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie));
       const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
       x0_[t] = LD(xfx, kb8 + c2);
-      x1_[t] = LD(xfx, kb8 + c2 + 8);
+      x1_[t] = LD(xfx, kb8 + c2 + E8);
       a_[t] = LD(m.area, c2);
     }
 #pragma unroll
@@ -357,7 +358,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       cc[f] = calc[f] ? cx_keep[f] : 0.0;  // = crx[c], loaded by this thread for the inner sweep of the same row
       xu[f] = calc[f] ? LD(xunit, c) : 0.0;
     }
-    const double* dxa = m.dxa;
+    const real* dxa = m.dxa;
     const int gjc = gj < g.nj ? gj : g.nj - 1;  // (a tile may stick out of the storage: the metric row must exist)
     ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gjc)); }, out);
 #pragma unroll
@@ -368,7 +369,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
         double v = 0.5 * (out[f] + sxin[jj + 3][ii0 + f]) * xu[f];
         if (DMODE == 0 && EPI == 0) ST(dp.fx2o, c) = dvx[f];
         if (DMODE == 1) v = v + dvx[f];
-        if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - 8) + LD(dp.mass, c)) * dvx[f];
+        if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - E8) + LD(dp.mass, c)) * dvx[f];
         if (EPI == 0) {
           if (dp.v_upd) {  // v_from_ke (d_sw.py:423-436): same expression, same order as the stand-alone kernel
             const unsigned c2 = OFF2(gi0 + f, gj);
@@ -400,7 +401,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       cc[f] = calc[f] ? cy_keep[f] : 0.0;  // = cry[c]
       yu[f] = calc[f] ? LD(yunit, c) : 0.0;
     }
-    const double* dya = m.dya;
+    const real* dya = m.dya;
     const int gic = gi < g.ni ? gi : g.ni - 1;  // (a tile may stick out of the storage: the metric row must exist)
     ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gic, p)); }, out);
 #pragma unroll
@@ -415,7 +416,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
         if (EPI == 0) {
           if (dp.u_upd) {  // u_from_ke (d_sw.py:406-420)
             const unsigned c2 = OFF2(gi, gj0 + f);
-            ST(dp.u_upd, c) = LD(dp.u_upd, c) * LD(m.dx, c2) + LD(dp.ke, c) - LD(dp.ke, c + 8) + v;
+            ST(dp.u_upd, c) = LD(dp.u_upd, c) * LD(m.dx, c2) + LD(dp.ke, c) - LD(dp.ke, c + E8) + v;
           } else {
             ST(fy, c) = v;
           }
@@ -497,11 +498,11 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 }
 
 template <int MORD, int DMODE, int EPI>
-__global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const double* __restrict__ q,
-                                                const double* __restrict__ crx, const double* __restrict__ cry,
-                                                const double* __restrict__ xfx, const double* __restrict__ yfx,
-                                                double* __restrict__ fx, double* __restrict__ fy,
-                                                const double* __restrict__ xunit, const double* __restrict__ yunit,
+__global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const real* __restrict__ q,
+                                                const real* __restrict__ crx, const real* __restrict__ cry,
+                                                const real* __restrict__ xfx, const real* __restrict__ yfx,
+                                                real* __restrict__ fx, real* __restrict__ fy,
+                                                const real* __restrict__ xunit, const real* __restrict__ yunit,
                                                 FvDamp dp) {
   // x-interfaces evaluated: i0 .. i0+TI (their al's reach one further each way); special forms at is-1 .. is+1 and
   // ie .. ie+2
@@ -521,9 +522,9 @@ __global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const double* _
   hipLaunchKernelGGL((k_fvtp2d<MORD, D, E>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp)
 
 template <int MORD>
-static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g, const Met& m, const double* q,
-                       const double* crx, const double* cry, const double* xfx, const double* yfx, double* fx, double* fy,
-                       const double* xu, const double* yu, const FvDamp& dp) {
+static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g, const Met& m, const real* q,
+                       const real* crx, const real* cry, const real* xfx, const real* yfx, real* fx, real* fy,
+                       const real* xu, const real* yu, const FvDamp& dp) {
   const dim3 block(256);
   if (epi == 0) {
     switch (dmode) {
@@ -548,13 +549,13 @@ static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo&
 
 // The general launcher.  dmode -1: transport only; otherwise the del-n damping of q is fused (see FvDamp).  epi 0:
 // fluxes are written; 1 / 2: the flux-form update of the cell (and heat_diss) is written instead.
-int launch_transport(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
-                     const double* yfx, double* fx, double* fy, const double* xmf, const double* ymf, int hord, int nlev,
+int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
+                     const real* yfx, real* fx, real* fy, const real* xmf, const real* ymf, int hord, int nlev,
                      int dmode, int epi, const FvDamp& dp, hipStream_t st) {
   if (dmode >= 0 && dp.nmax > 2) return PACE_ERR_UNSUPPORTED;
   const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
-  const double* xu = xmf ? xmf : xfx;
-  const double* yu = ymf ? ymf : yfx;
+  const real* xu = xmf ? xmf : xfx;
+  const real* yu = ymf ? ymf : yfx;
   int rc;
   if (hord == 5) rc = launch_mode<5>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
   else if (hord == 6) rc = launch_mode<6>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
@@ -568,9 +569,9 @@ int launch_transport(const Geo& g, const Met& m, const double* q, const double* 
   return PACE_OK;
 }
 
-int launch_fvtp2d(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry,
-                  const double* xfx, const double* yfx, double* fx, double* fy, const double* xmf,
-                  const double* ymf, int hord, int nlev, hipStream_t st) {
+int launch_fvtp2d(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry,
+                  const real* xfx, const real* yfx, real* fx, real* fy, const real* xmf,
+                  const real* ymf, int hord, int nlev, hipStream_t st) {
   FvDamp dp{};
   return launch_transport(g, m, q, crx, cry, xfx, yfx, fx, fy, xmf, ymf, hord, nlev, -1, 0, dp, st);
 }

@@ -11,9 +11,9 @@ __device__ __forceinline__ double contra(double v1, double v2, double cosa, doub
 }
 
 // stage A: main_uc_vc_contra (fxadv.py:10-48) + uc_contra_y_edge (:51-77)
-__global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const double* __restrict__ uc,
-                                                    const double* __restrict__ vc, double* __restrict__ ut,
-                                                    double* __restrict__ vt) {
+__global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const real* __restrict__ uc,
+                                                    const real* __restrict__ vc, real* __restrict__ ut,
+                                                    real* __restrict__ vt) {
   PLANE_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;  // domain_full = N+6 points
   const long c = IDX3(g, i, j, k);
@@ -32,8 +32,8 @@ __global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const double* 
 }
 
 // stage B: vc_contra_y_edge (:80-125) then vc_contra_x_edge (:128-145); touches edge strips only
-__global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const double* __restrict__ vc,
-                                                        const double* __restrict__ ut, double* __restrict__ vt) {
+__global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const real* __restrict__ vc,
+                                                        const real* __restrict__ ut, real* __restrict__ vt) {
   PLANE_IJK(g);
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
@@ -51,9 +51,9 @@ __global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const doub
 }
 
 // stage C: uc_contra_x_edge (:148-180), uc_contra_corners (:183-300), vc_contra_corners (:303-404)
-__global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, const double* __restrict__ uc,
-                                                                const double* __restrict__ vc, double* ut,
-                                                                double* vt) {
+__global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, const real* __restrict__ uc,
+                                                                const real* __restrict__ vc, real* ut,
+                                                                real* vt) {
   PLANE_IJK(g);
   if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
@@ -96,9 +96,9 @@ __global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, co
   }
 }
 
-__global__ void __launch_bounds__(256) k_fxadv_vt_corners(Geo g, Met m, const double* __restrict__ uc,
-                                                          const double* __restrict__ vc, const double* ut,
-                                                          double* vt) {
+__global__ void __launch_bounds__(256) k_fxadv_vt_corners(Geo g, Met m, const real* __restrict__ uc,
+                                                          const real* __restrict__ vc, const real* ut,
+                                                          real* vt) {
   PLANE_IJK(g);
   if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
   const bool cols = (i == g.is - 1 || i == g.is || i == g.ie || i == g.ie + 1);
@@ -133,11 +133,11 @@ __global__ void __launch_bounds__(256) k_fxadv_vt_corners(Geo g, Met m, const do
 }
 
 // fxadv_fluxes_stencil (:436-486)
-__global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const double* __restrict__ ut,
-                                                      const double* __restrict__ vt, double* __restrict__ crx,
-                                                      double* __restrict__ cry, double* __restrict__ xfx,
-                                                      double* __restrict__ yfx, double dt,
-                                                      double* __restrict__ cx_acc, double* __restrict__ cy_acc) {
+__global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* __restrict__ ut,
+                                                      const real* __restrict__ vt, real* __restrict__ crx,
+                                                      real* __restrict__ cry, real* __restrict__ xfx,
+                                                      real* __restrict__ yfx, double dt,
+                                                      real* __restrict__ cx_acc, real* __restrict__ cy_acc) {
   // cx_acc / cy_acc (optional): the Courant-number half of d_sw's flux_capacitor (d_sw.py:33-60), cx += crx, cy += cry,
   // done where crx / cry are produced
   PLANE_IJK(g);
@@ -172,8 +172,8 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const double
   }
 }
 
-int launch_fxadv(const Geo& g, const Met& m, const double* uc, const double* vc, double* crx, double* cry,
-                 double* xfx, double* yfx, double* ut, double* vt, double dt, double* cx_acc, double* cy_acc,
+int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
+                 real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
                  hipStream_t st) {
   const dim3 grid = plane_grid(g, g.nk), block(256);
   hipLaunchKernelGGL(k_fxadv_main, grid, block, 0, st, g, m, uc, vc, ut, vt);

@@ -21,7 +21,7 @@
 #define PACE_C_LIQ 4.1855e3
 
 struct L2eWater {
-  const double *qvapor, *qliquid, *qrain, *qsnow, *qice, *qgraupel;
+  const real *qvapor, *qliquid, *qrain, *qsnow, *qice, *qgraupel;
 };
 
 // moist_cv_nwat6_fn + moist_cvm + set_cappa (moist_cv.py:16-46)
@@ -46,10 +46,10 @@ __device__ __forceinline__ void moist_cv(const L2eWater& q, long c, double r_vir
   (void)km
 
 __global__ void __launch_bounds__(256)
-k_l2e_prepare(Geo g, L2eWater q, double* __restrict__ q_con, double* __restrict__ pt, double* __restrict__ cappa,
-              double* __restrict__ delp, double* __restrict__ delz, const double* __restrict__ pe, double* __restrict__ pe1,
-              double* __restrict__ pe2, const double* __restrict__ ak, const double* __restrict__ bk, double* __restrict__ dp2,
-              double* __restrict__ ps, double* __restrict__ pn2, const double* __restrict__ peln, double* __restrict__ pk,
+k_l2e_prepare(Geo g, L2eWater q, real* __restrict__ q_con, real* __restrict__ pt, real* __restrict__ cappa,
+              real* __restrict__ delp, real* __restrict__ delz, const real* __restrict__ pe, real* __restrict__ pe1,
+              real* __restrict__ pe2, const real* __restrict__ ak, const real* __restrict__ bk, real* __restrict__ dp2,
+              real* __restrict__ ps, real* __restrict__ pn2, const real* __restrict__ peln, real* __restrict__ pk,
               double ptop, double akap, double r_vir) {
   L2E_CELL(1, 1);
   // init_pe over the compute domain + the extra row je+1 (remapping.py:42-56)
@@ -84,9 +84,9 @@ k_l2e_prepare(Geo g, L2eWater q, double* __restrict__ q_con, double* __restrict_
 }
 
 __global__ void __launch_bounds__(256)
-k_l2e_post(Geo g, L2eWater q, double* __restrict__ q_con, double* __restrict__ pkz, const double* __restrict__ pt,
-           double* __restrict__ cappa, const double* __restrict__ delp, double* __restrict__ delz, double* __restrict__ peln,
-           double* __restrict__ pe0, const double* __restrict__ pn2, double r_vir) {
+k_l2e_post(Geo g, L2eWater q, real* __restrict__ q_con, real* __restrict__ pkz, const real* __restrict__ pt,
+           real* __restrict__ cappa, const real* __restrict__ delp, real* __restrict__ delz, real* __restrict__ peln,
+           real* __restrict__ pe0, const real* __restrict__ pn2, double r_vir) {
   L2E_CELL(0, 1);
   pe0[c] = peln[c];
   peln[c] = pn2[c];
@@ -103,8 +103,8 @@ k_l2e_post(Geo g, L2eWater q, double* __restrict__ q_con, double* __restrict__ p
 // dir 0: pressures_mapu (neighbour to the south, window + 1 row); dir 1: pressures_mapv (neighbour to the west, + 1 column)
 template <int DIR>
 __global__ void __launch_bounds__(256)
-k_l2e_pressures(Geo g, const double* __restrict__ pe, const double* __restrict__ pe1, const double* __restrict__ ak,
-                const double* __restrict__ bk, double* __restrict__ pe0, double* __restrict__ pe3) {
+k_l2e_pressures(Geo g, const real* __restrict__ pe, const real* __restrict__ pe1, const real* __restrict__ ak,
+                const real* __restrict__ bk, real* __restrict__ pe0, real* __restrict__ pe3) {
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y * 4 + threadIdx.y;
   const int k = blockIdx.z;
@@ -131,8 +131,8 @@ k_l2e_pressures(Geo g, const double* __restrict__ pe, const double* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-k_l2e_finish(Geo g, L2eWater q, double* __restrict__ pe, const double* __restrict__ pe2, double* __restrict__ pt,
-             const double* __restrict__ pkz, double r_vir, int last_step) {
+k_l2e_finish(Geo g, L2eWater q, real* __restrict__ pe, const real* __restrict__ pe2, real* __restrict__ pt,
+             const real* __restrict__ pkz, double r_vir, int last_step) {
   L2E_CELL(0, 1);
   if (k >= 1 && k < km) pe[c] = pe2[c];  // update_ua + copy_from_below: pe becomes the Eulerian interfaces
   if (last_step) {
@@ -146,9 +146,9 @@ k_l2e_finish(Geo g, L2eWater q, double* __restrict__ pe, const double* __restric
 
 static dim3 l2e_grid(const Geo& g, int xi, int xj, int nlev) { return dim3((g.n + xi + 63) / 64, (g.n + xj + 3) / 4, nlev); }
 
-int launch_l2e_prepare(const Geo& g, const double* const* water, double* q_con, double* pt, double* cappa, double* delp,
-                       double* delz, const double* pe, double* pe1, double* pe2, const double* ak, const double* bk, double* dp2,
-                       double* ps, double* pn2, const double* peln, double* pk, double ptop, double akap, double r_vir,
+int launch_l2e_prepare(const Geo& g, const real* const* water, real* q_con, real* pt, real* cappa, real* delp,
+                       real* delz, const real* pe, real* pe1, real* pe2, const real* ak, const real* bk, real* dp2,
+                       real* ps, real* pn2, const real* peln, real* pk, double ptop, double akap, double r_vir,
                        hipStream_t st) {
   L2eWater q{water[0], water[1], water[2], water[3], water[4], water[5]};
   hipLaunchKernelGGL(k_l2e_prepare, l2e_grid(g, 0, 1, g.nk + 1), dim3(64, 4), 0, st, g, q, q_con, pt, cappa, delp, delz, pe, pe1,
@@ -157,8 +157,8 @@ int launch_l2e_prepare(const Geo& g, const double* const* water, double* q_con, 
   return PACE_OK;
 }
 
-int launch_l2e_post(const Geo& g, const double* const* water, double* q_con, double* pkz, const double* pt, double* cappa,
-                    const double* delp, double* delz, double* peln, double* pe0, const double* pn2, double r_vir, hipStream_t st) {
+int launch_l2e_post(const Geo& g, const real* const* water, real* q_con, real* pkz, const real* pt, real* cappa,
+                    const real* delp, real* delz, real* peln, real* pe0, const real* pn2, double r_vir, hipStream_t st) {
   L2eWater q{water[0], water[1], water[2], water[3], water[4], water[5]};
   hipLaunchKernelGGL(k_l2e_post, l2e_grid(g, 0, 0, g.nk + 1), dim3(64, 4), 0, st, g, q, q_con, pkz, pt, cappa, delp, delz, peln,
                      pe0, pn2, r_vir);
@@ -166,15 +166,15 @@ int launch_l2e_post(const Geo& g, const double* const* water, double* q_con, dou
   return PACE_OK;
 }
 
-int launch_l2e_pressures(const Geo& g, int dir, const double* pe, const double* pe1, const double* ak, const double* bk,
-                         double* pe0, double* pe3, hipStream_t st) {
+int launch_l2e_pressures(const Geo& g, int dir, const real* pe, const real* pe1, const real* ak, const real* bk,
+                         real* pe0, real* pe3, hipStream_t st) {
   if (dir == 0) hipLaunchKernelGGL(k_l2e_pressures<0>, l2e_grid(g, 0, 1, g.nk + 1), dim3(64, 4), 0, st, g, pe, pe1, ak, bk, pe0, pe3);
   else hipLaunchKernelGGL(k_l2e_pressures<1>, l2e_grid(g, 1, 0, g.nk + 1), dim3(64, 4), 0, st, g, pe, pe1, ak, bk, pe0, pe3);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
 
-int launch_l2e_finish(const Geo& g, const double* const* water, double* pe, const double* pe2, double* pt, const double* pkz,
+int launch_l2e_finish(const Geo& g, const real* const* water, real* pe, const real* pe2, real* pt, const real* pkz,
                       double r_vir, int last_step, hipStream_t st) {
   L2eWater q{water[0], water[1], water[2], water[3], water[4], water[5]};
   hipLaunchKernelGGL(k_l2e_finish, l2e_grid(g, 0, 0, g.nk + 1), dim3(64, 4), 0, st, g, q, pe, pe2, pt, pkz, r_vir, last_step);

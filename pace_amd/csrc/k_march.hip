@@ -54,19 +54,19 @@ __device__ __forceinline__ double ysweep(const double* W, double c) {
 }
 
 __global__ void __launch_bounds__(64)
-k_fvtp2d_march(Geo g, Met m, const double* __restrict__ q, const double* __restrict__ crx, const double* __restrict__ cry,
-               const double* __restrict__ xfx, const double* __restrict__ yfx, double* __restrict__ fx, double* __restrict__ fy,
+k_fvtp2d_march(Geo g, Met m, const real* __restrict__ q, const real* __restrict__ crx, const real* __restrict__ cry,
+               const real* __restrict__ xfx, const real* __restrict__ yfx, real* __restrict__ fx, real* __restrict__ fy,
                int ib, int nx, int jb, int ny) {
   const int lane = threadIdx.x;
   const int gi = ib + blockIdx.x * MW - 3 + lane;
   const int j0 = jb + blockIdx.y * MH;
   const int k = blockIdx.z;
-  const unsigned sj8 = (unsigned)g.sj * 8u;
-  const unsigned col = (unsigned)((long)k * g.sk * 8) + (unsigned)gi * 8u;  // byte offset of (gi, row 0, k)
-  const unsigned col2 = (unsigned)gi * 8u;
-#define LDF(p, row) (*(const double*)((const char*)(p) + (col + (unsigned)(row) * sj8)))
-#define LD2(p, row) (*(const double*)((const char*)(p) + (col2 + (unsigned)(row) * sj8)))
-#define STF(p, row) (*(double*)((char*)(p) + (col + (unsigned)(row) * sj8)))
+  const unsigned sj8 = (unsigned)g.sj * (unsigned)sizeof(real);
+  const unsigned col = (unsigned)((long)k * g.sk * (long)sizeof(real)) + (unsigned)gi * (unsigned)sizeof(real);  // byte offset of (gi, row 0, k)
+  const unsigned col2 = (unsigned)gi * (unsigned)sizeof(real);
+#define LDF(p, row) (*(const real*)((const char*)(p) + (col + (unsigned)(row) * sj8)))
+#define LD2(p, row) (*(const real*)((const char*)(p) + (col2 + (unsigned)(row) * sj8)))
+#define STF(p, row) (*(real*)((char*)(p) + (col + (unsigned)(row) * sj8)))
   const bool out_lane = lane >= 3 && lane <= 60 && gi < ib + nx;
   double Wq[6], Wj[6];      // q and q_j on rows r-5 .. r
   double sx[4];             // inner x values of rows r-3 .. r
@@ -121,8 +121,8 @@ k_fvtp2d_march(Geo g, Met m, const double* __restrict__ q, const double* __restr
 }
 #endif
 
-int launch_fvtp2d_march(const Geo& g, const Met& m, const double* q, const double* crx, const double* cry, const double* xfx,
-                        const double* yfx, double* fx, double* fy, int ib, int nx, int jb, int ny, int nlev, hipStream_t st) {
+int launch_fvtp2d_march(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
+                        const real* yfx, real* fx, real* fy, int ib, int nx, int jb, int ny, int nlev, hipStream_t st) {
 #ifdef PACE_EMU
   return PACE_ERR_UNSUPPORTED;
 #else

@@ -8,7 +8,7 @@
 
 template <int MORD, int AXIS>
 __global__ void __launch_bounds__(256)
-k_ppm1d(Geo g, Met m, const double* __restrict__ q, const double* __restrict__ c, double* __restrict__ out, int i0, int j0, int k0,
+k_ppm1d(Geo g, Met m, const real* __restrict__ q, const real* __restrict__ c, real* __restrict__ out, int i0, int j0, int k0,
         int ni, int nj) {
   const int i = i0 + blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = j0 + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -30,12 +30,12 @@ k_ppm1d(Geo g, Met m, const double* __restrict__ q, const double* __restrict__ c
   const double cv = c[cc];
   double res;
   if (AXIS == 0) {
-    const double* dxa = m.dxa;
+    const real* dxa = m.dxa;
     auto d = [=](int p) { return dxa[IDX2(g, p, j)]; };
     if (MORD == 8) ppm_run8<true, 1>(Q, &cv, pos, g.is, g.ie, d, &res);
     else res = ppm_flux6<MORD, true>(Q, cv, pos, g.is, g.ie, d);
   } else {
-    const double* dya = m.dya;
+    const real* dya = m.dya;
     auto d = [=](int p) { return dya[IDX2(g, i, p)]; };
     if (MORD == 8) ppm_run8<true, 1>(Q, &cv, pos, g.js, g.je, d, &res);
     else res = ppm_flux6<MORD, true>(Q, cv, pos, g.js, g.je, d);
@@ -43,7 +43,7 @@ k_ppm1d(Geo g, Met m, const double* __restrict__ q, const double* __restrict__ c
   out[cc] = res;
 }
 
-int launch_ppm1d(const Geo& g, const Met& m, int axis, int iord, const double* q, const double* c, double* out, int i0, int j0,
+int launch_ppm1d(const Geo& g, const Met& m, int axis, int iord, const real* q, const real* c, real* out, int i0, int j0,
                  int k0, int ni, int nj, int nk, hipStream_t st) {
   const dim3 grid((ni + 63) / 64, (nj + 3) / 4, nk), block(256);
 #define GO(M, A) hipLaunchKernelGGL((k_ppm1d<M, A>), grid, block, 0, st, g, m, q, c, out, i0, j0, k0, ni, nj)

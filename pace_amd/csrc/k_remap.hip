@@ -28,7 +28,7 @@ struct RemapWin {
 #define REMAP_NFIELDS 5
 #define REMAP_KB 8  // target levels per thread in k_remap_layers
 struct RemapBatch {
-  double* q[REMAP_MAXQ];
+  real* q[REMAP_MAXQ];
   int n;
 };
 
@@ -87,8 +87,8 @@ __device__ __forceinline__ double max3(double a, double p, double l) { return (a
 // ---------------------------------------------------------------------------------------------------------------
 template <bool IVM2>
 __global__ void __launch_bounds__(64)
-k_remap_interfaces(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, const double* __restrict__ qs,
-                   double* __restrict__ ws) {
+k_remap_interfaces(Geo g, RemapWin w, RemapBatch B, const real* __restrict__ pe1, const real* __restrict__ qs,
+                   real* __restrict__ ws) {
   const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = w.j0 + blockIdx.y;
   if (i > w.i1 || j > w.j1) return;
@@ -96,10 +96,10 @@ k_remap_interfaces(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ p
   const long sk = g.sk;
   const int km = w.km;
   const long field = sk * (g.nk + 1);
-  const double* __restrict__ q1 = B.q[blockIdx.z];
-  double* __restrict__ a1 = ws + (long)blockIdx.z * REMAP_NFIELDS * field;
-  double* __restrict__ qi = a1 + field;
-  double* __restrict__ gw = qi + field;  // (a2's storage: the back substitution's multipliers live there until the
+  const real* __restrict__ q1 = B.q[blockIdx.z];
+  real* __restrict__ a1 = ws + (long)blockIdx.z * REMAP_NFIELDS * field;
+  real* __restrict__ qi = a1 + field;
+  real* __restrict__ gw = qi + field;  // (a2's storage: the back substitution's multipliers live there until the
                                          // coefficient kernel overwrites it)
 #define Q1(k) q1[c0 + (long)(k) * sk]
 #define DP(k) (pe1[c0 + (long)((k) + 1) * sk] - pe1[c0 + (long)(k) * sk])  // set_dp, map_single.py:14-18
@@ -244,8 +244,8 @@ k_remap_interfaces(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ p
 // coefficients: apply_constraints + set_interpolation_coefficients, one thread per cell
 // ---------------------------------------------------------------------------------------------------------------
 struct RemapCol {
-  const double* a1;  // column base (level 0)
-  const double* qi;
+  const real* a1;  // column base (level 0)
+  const real* qi;
   long sk;
   int km;
   __device__ __forceinline__ double A1(int k) const { return a1[(long)k * sk]; }
@@ -283,7 +283,7 @@ struct RemapCol {
 
 template <int KORD, int IV>
 __global__ void __launch_bounds__(256)
-k_remap_coefficients(Geo g, RemapWin w, double* __restrict__ ws, double qmin) {
+k_remap_coefficients(Geo g, RemapWin w, real* __restrict__ ws, double qmin) {
   const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = w.j0 + blockIdx.y * 4 + threadIdx.y;
   const int km = w.km;
@@ -291,11 +291,11 @@ k_remap_coefficients(Geo g, RemapWin w, double* __restrict__ ws, double qmin) {
   if (i > w.i1 || j > w.j1) return;
   const long c0 = IDX2(g, i, j);
   const long field = g.sk * (g.nk + 1);
-  const double* __restrict__ a1 = ws + (long)f * REMAP_NFIELDS * field;
-  const double* __restrict__ qi = a1 + field;
-  double* __restrict__ a2o = ws + ((long)f * REMAP_NFIELDS + 2) * field;
-  double* __restrict__ a3o = a2o + field;
-  double* __restrict__ a4o = a3o + field;
+  const real* __restrict__ a1 = ws + (long)f * REMAP_NFIELDS * field;
+  const real* __restrict__ qi = a1 + field;
+  real* __restrict__ a2o = ws + ((long)f * REMAP_NFIELDS + 2) * field;
+  real* __restrict__ a3o = a2o + field;
+  real* __restrict__ a4o = a3o + field;
   RemapCol C{a1 + c0, qi + c0, g.sk, km};
   const double A1 = C.A1(k);
   double a2 = C.template qcon<IV>(k), a3 = C.template qcon<IV>(k + 1), a4 = 0.0;
@@ -406,8 +406,8 @@ k_remap_coefficients(Geo g, RemapWin w, double* __restrict__ ws, double qmin) {
 // lagrangian_contributions (map_single.py:21-93)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_remap_layers(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, const double* __restrict__ pe2,
-               const double* __restrict__ ws) {
+k_remap_layers(Geo g, RemapWin w, RemapBatch B, const real* __restrict__ pe1, const real* __restrict__ pe2,
+               const real* __restrict__ ws) {
   const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = w.j0 + blockIdx.y;
   if (i > w.i1 || j > w.j1) return;
@@ -417,11 +417,11 @@ k_remap_layers(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, 
   const long field = sk * (g.nk + 1);
   const int nblk = (km + REMAP_KB - 1) / REMAP_KB;
   const int fld = blockIdx.z / nblk, kblk = blockIdx.z - fld * nblk;
-  double* __restrict__ q = B.q[fld];
-  const double* __restrict__ a1 = ws + (long)fld * REMAP_NFIELDS * field;
-  const double* __restrict__ a2 = a1 + 2 * field;
-  const double* __restrict__ a3 = a2 + field;
-  const double* __restrict__ a4 = a3 + field;
+  real* __restrict__ q = B.q[fld];
+  const real* __restrict__ a1 = ws + (long)fld * REMAP_NFIELDS * field;
+  const real* __restrict__ a2 = a1 + 2 * field;
+  const real* __restrict__ a3 = a2 + field;
+  const real* __restrict__ a4 = a3 + field;
 #define AT(f, l) f[c0 + (long)(l) * sk]
   // The reference walks the column with one running source-layer index.  Its value when level k begins is
   // min { L : pe1[L+1] >= pe2[k] } for every k >= 1 (it only ever advances past layers that end strictly above the target
@@ -493,14 +493,14 @@ k_remap_layers(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ pe1, 
 // rescales the column only where something was fixed.  One thread per (column, tracer).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_fillz(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ dpf) {
+k_fillz(Geo g, RemapWin w, RemapBatch B, const real* __restrict__ dpf) {
   const int i = w.i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = w.j0 + blockIdx.y;
   if (i > w.i1 || j > w.j1) return;
   const long c0 = IDX2(g, i, j);
   const long sk = g.sk;
   const int km = w.km;
-  double* __restrict__ q = B.q[blockIdx.z];
+  real* __restrict__ q = B.q[blockIdx.z];
 #define Q(k) q[c0 + (long)(k) * sk]
 #define DPK(k) dpf[c0 + (long)(k) * sk]
   int zfix = 0;
@@ -579,7 +579,7 @@ k_fillz(Geo g, RemapWin w, RemapBatch B, const double* __restrict__ dpf) {
 #undef DPK
 }
 
-int launch_fillz(const Geo& g, double* const* q, int nq, const double* dp, hipStream_t st) {
+int launch_fillz(const Geo& g, real* const* q, int nq, const real* dp, hipStream_t st) {
   if (nq < 1 || nq > REMAP_MAXQ) return PACE_ERR_ARG;
   if (g.nk < 4) return PACE_ERR_UNSUPPORTED;
   RemapBatch B{};
@@ -595,11 +595,11 @@ int launch_fillz(const Geo& g, double* const* q, int nq, const double* dp, hipSt
 }
 
 int64_t map_single_workspace_bytes(const Geo& g, int nq) {
-  return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double) * REMAP_NFIELDS * nq;
+  return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real) * REMAP_NFIELDS * nq;
 }
 
 template <int KORD>
-static int launch_coeffs(int iv, dim3 grid, hipStream_t st, const Geo& g, const RemapWin& w, double* ws, double qmin) {
+static int launch_coeffs(int iv, dim3 grid, hipStream_t st, const Geo& g, const RemapWin& w, real* ws, double qmin) {
   const dim3 block(64, 4);
 #define RC(IV) hipLaunchKernelGGL((k_remap_coefficients<KORD, IV>), grid, block, 0, st, g, w, ws, qmin)
   switch (iv) {
@@ -613,14 +613,14 @@ static int launch_coeffs(int iv, dim3 grid, hipStream_t st, const Geo& g, const 
 }
 
 // nq fields that share pe1 / pe2, kord, iv, qs and qmin, in one three-launch sequence
-int launch_map_fields(const Geo& g, void* ws_, double* const* q, int nq, const double* pe1, const double* pe2, const double* qs,
+int launch_map_fields(const Geo& g, void* ws_, real* const* q, int nq, const real* pe1, const real* pe2, const real* qs,
                       double qmin, int kord, int iv, int xstag, int ystag, hipStream_t st) {
   kord = kord < 0 ? -kord : kord;
   if (kord != 9 && kord != 10) return PACE_ERR_UNSUPPORTED;
   if (g.nk < 6) return PACE_ERR_UNSUPPORTED;
   if (nq < 1 || nq > REMAP_MAXQ) return PACE_ERR_ARG;
   if (iv == -2 && !qs) return PACE_ERR_ARG;
-  double* ws = (double*)ws_;
+  real* ws = (real*)ws_;
   RemapBatch B{};
   B.n = nq;
   for (int f = 0; f < nq; ++f) {

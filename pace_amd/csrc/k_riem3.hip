@@ -26,12 +26,12 @@
 #define CH RIEM_CH
 
 struct Riem3Work {
-  double *pem, *pm, *w1, *gam, *pp, *aa;
+  real *pem, *pm, *w1, *gam, *pp, *aa;
 };
 #define RIEM3_NFIELDS 6
 
 int64_t riem3_workspace_bytes(const Geo& g) {
-  return (int64_t)g.sk * (g.nk + 1) * RIEM3_NFIELDS * (int64_t)sizeof(double);
+  return (int64_t)g.sk * (g.nk + 1) * RIEM3_NFIELDS * (int64_t)sizeof(real);
 }
 
 #define COLUMN_IJ(g) COLUMN_IJH(g, 0)
@@ -49,7 +49,7 @@ int64_t riem3_workspace_bytes(const Geo& g) {
 //    (riem_solver3.py:63-81 without the logs)
 template <int CG>
 __global__ void __launch_bounds__(64)
-k_riem3_prefix(Geo g, Riem3Work W, double ptop, const double* __restrict__ delp, const double* __restrict__ q_con) {
+k_riem3_prefix(Geo g, Riem3Work W, double ptop, const real* __restrict__ delp, const real* __restrict__ q_con) {
   COLUMN_IJH(g, CG);
   double p_int = ptop, pg = ptop;
   W.pem[AT(0)] = ptop;
@@ -77,15 +77,15 @@ k_riem3_prefix(Geo g, Riem3Work W, double ptop, const double* __restrict__ delp,
 
 // B: logs / exps of precompute + first statement of sim1_solver (sim1_solver.py:70-75), all levels in parallel
 __global__ void __launch_bounds__(256)
-k_riem3_parallel_pre(Geo g, Riem3Work W, int last_call, double peln1, double ptk, const double* __restrict__ cappa,
-                     const double* __restrict__ delp, const double* __restrict__ pt, const double* __restrict__ zh,
-                     double* __restrict__ delz, double* __restrict__ ppe, double* __restrict__ pk3,
-                     double* __restrict__ peln) {
+k_riem3_parallel_pre(Geo g, Riem3Work W, int last_call, double peln1, double ptk, const real* __restrict__ cappa,
+                     const real* __restrict__ delp, const real* __restrict__ pt, const real* __restrict__ zh,
+                     real* __restrict__ delz, real* __restrict__ ppe, real* __restrict__ pk3,
+                     real* __restrict__ peln) {
   PLANE_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
   const int km = g.nk;
-  const double* pg = W.aa;
+  const real* pg = W.aa;
   if (k == 0) {
     pk3[c] = ptk;
     if (last_call) peln[c] = peln1;
@@ -113,9 +113,9 @@ k_riem3_parallel_pre(Geo g, Riem3Work W, int last_call, double peln1, double ptk
 // CG = 1: C-grid solver on compute +- 1, delta_mass = delpc / GRAV (riem_solver_c.py:84)
 template <int CG>
 __global__ void __launch_bounds__(64)
-k_riem3_tridiag(Geo g, Riem3Work W, double dt, const double* __restrict__ cappa, const double* __restrict__ ws,
-                const double* __restrict__ delz, const double* __restrict__ delp, double* __restrict__ ppe,
-                double* __restrict__ w) {
+k_riem3_tridiag(Geo g, Riem3Work W, double dt, const real* __restrict__ cappa, const real* __restrict__ ws,
+                const real* __restrict__ delz, const real* __restrict__ delp, real* __restrict__ ppe,
+                real* __restrict__ w) {
   COLUMN_IJH(g, CG);
   const double t1g = 2.0 * dt * dt, rdt = 1.0 / dt;
 #define DM(x) (CG ? (x) / GRAV : (x)*RGRAV)
@@ -332,9 +332,9 @@ k_riem3_tridiag(Geo g, Riem3Work W, double dt, const double* __restrict__ cappa,
 
 // D: dz update (sim1_solver.py:133-141) + the last_call copies of finalize (riem_solver3.py:136-141)
 __global__ void __launch_bounds__(256)
-k_riem3_parallel_post(Geo g, Riem3Work W, int last_call, const double* __restrict__ cappa,
-                      const double* __restrict__ delp, const double* __restrict__ pt, double* __restrict__ delz,
-                      const double* __restrict__ pk3, double* __restrict__ pk, double* __restrict__ pe, double p_fac) {
+k_riem3_parallel_post(Geo g, Riem3Work W, int last_call, const real* __restrict__ cappa,
+                      const real* __restrict__ delp, const real* __restrict__ pt, real* __restrict__ delz,
+                      const real* __restrict__ pk3, real* __restrict__ pk, real* __restrict__ pe, double p_fac) {
   PLANE_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
@@ -353,7 +353,7 @@ k_riem3_parallel_post(Geo g, Riem3Work W, int last_call, const double* __restric
 
 // E: zh from the surface up (riem_solver3.py:142-145)
 __global__ void __launch_bounds__(64)
-k_riem3_zh(Geo g, const double* __restrict__ zs, const double* __restrict__ delz, double* __restrict__ zh) {
+k_riem3_zh(Geo g, const real* __restrict__ zs, const real* __restrict__ delz, real* __restrict__ zh) {
   COLUMN_IJ(g);
   double z = zs[c0];
   zh[AT(km)] = z;
@@ -375,12 +375,12 @@ k_riem3_zh(Geo g, const double* __restrict__ zs, const double* __restrict__ delz
   }
 }
 
-int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const double* cappa, double ptop,
-                        const double* zs, const double* wsd, double* delz, const double* q_con, const double* delp,
-                        const double* pt, double* zh, double* pe, double* ppe, double* pk3, double* pk, double* peln,
-                        double* w, double p_fac, hipStream_t st) {
+int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const real* cappa, double ptop,
+                        const real* zs, const real* wsd, real* delz, const real* q_con, const real* delp,
+                        const real* pt, real* zh, real* pe, real* ppe, real* pk3, real* pk, real* peln,
+                        real* w, double p_fac, hipStream_t st) {
   Riem3Work W;
-  double* p = (double*)ws;
+  real* p = (real*)ws;
   const long field = g.sk * (g.nk + 1);
   W.pem = p;
   W.pm = p + field;
@@ -408,22 +408,22 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
 // =================================================================================================
 struct RiemCWork {
   Riem3Work r;
-  double *dz, *pe, *w;
+  real *dz, *pe, *w;
 };
 #define RIEMC_NFIELDS 9
 
 int64_t riemc_workspace_bytes(const Geo& g) {
-  return (int64_t)g.sk * (g.nk + 1) * RIEMC_NFIELDS * (int64_t)sizeof(double);
+  return (int64_t)g.sk * (g.nk + 1) * RIEMC_NFIELDS * (int64_t)sizeof(real);
 }
 
 // precompute (riem_solver_c.py:21-88) without the prefix sums + first statement of sim1_solver
 __global__ void __launch_bounds__(256)
-k_riemc_parallel_pre(Geo g, RiemCWork W, const double* __restrict__ cappa, const double* __restrict__ delpc,
-                     const double* __restrict__ ptc, const double* __restrict__ gz, const double* __restrict__ w3) {
+k_riemc_parallel_pre(Geo g, RiemCWork W, const real* __restrict__ cappa, const real* __restrict__ delpc,
+                     const real* __restrict__ ptc, const real* __restrict__ gz, const real* __restrict__ w3) {
   PLANE_IJK(g);
   if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1 || k >= g.nk) return;
   const long c = IDX3(g, i, j, k);
-  const double* peg = W.r.aa;
+  const real* peg = W.r.aa;
   const double pmk = (peg[c + g.sk] - peg[c]) / log(peg[c + g.sk] / peg[c]);
   W.r.pm[c] = pmk;
   const double dz = gz[c + g.sk] - gz[c];
@@ -436,8 +436,8 @@ k_riemc_parallel_pre(Geo g, RiemCWork W, const double* __restrict__ cappa, const
 
 // sim1_solver.py:133-141 (dz) + finalize (riem_solver_c.py:91-123): pef
 __global__ void __launch_bounds__(256)
-k_riemc_parallel_post(Geo g, RiemCWork W, double ptop, const double* __restrict__ cappa, const double* __restrict__ delpc,
-                      const double* __restrict__ ptc, double* __restrict__ pef, double p_fac) {
+k_riemc_parallel_post(Geo g, RiemCWork W, double ptop, const real* __restrict__ cappa, const real* __restrict__ delpc,
+                      const real* __restrict__ ptc, real* __restrict__ pef, double p_fac) {
   PLANE_IJK(g);
   if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
@@ -451,7 +451,7 @@ k_riemc_parallel_post(Geo g, RiemCWork W, double ptop, const double* __restrict_
 }
 
 __global__ void __launch_bounds__(64)
-k_riemc_gz(Geo g, const double* __restrict__ hs, const double* __restrict__ dz, double* __restrict__ gz) {
+k_riemc_gz(Geo g, const real* __restrict__ hs, const real* __restrict__ dz, real* __restrict__ gz) {
   COLUMN_IJH(g, 1);
   double z = hs[c0];
   gz[AT(km)] = z;
@@ -473,11 +473,11 @@ k_riemc_gz(Geo g, const double* __restrict__ hs, const double* __restrict__ dz, 
   }
 }
 
-int launch_riem_solver_c(const Geo& g, void* ws, double dt2, const double* cappa, double ptop, const double* hs,
-                         const double* ws3, const double* ptc, const double* q_con, const double* delpc, double* gz,
-                         double* pef, const double* w3, double p_fac, hipStream_t st) {
+int launch_riem_solver_c(const Geo& g, void* ws, double dt2, const real* cappa, double ptop, const real* hs,
+                         const real* ws3, const real* ptc, const real* q_con, const real* delpc, real* gz,
+                         real* pef, const real* w3, double p_fac, hipStream_t st) {
   RiemCWork W;
-  double* p = (double*)ws;
+  real* p = (real*)ws;
   const long field = g.sk * (g.nk + 1);
   W.r.pem = p;
   W.r.pm = p + field;

@@ -148,10 +148,10 @@ __device__ __forceinline__ Mob excl_mob_fwd(Mob m, int r) {
 template <int CG, int L>
 __global__ void __launch_bounds__(256)
 k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double peln1, double ptk,
-              const double* __restrict__ cappa, const double* __restrict__ zs, const double* __restrict__ ws,
-              const double* __restrict__ q_con, const double* __restrict__ delp, const double* __restrict__ pt,
-              double* __restrict__ delz, double* __restrict__ zh, double* __restrict__ pe, double* __restrict__ ppe,
-              double* __restrict__ pk3, double* __restrict__ pk, double* __restrict__ peln, double* __restrict__ w) {
+              const real* __restrict__ cappa, const real* __restrict__ zs, const real* __restrict__ ws,
+              const real* __restrict__ q_con, const real* __restrict__ delp, const real* __restrict__ pt,
+              real* __restrict__ delz, real* __restrict__ zh, real* __restrict__ pe, real* __restrict__ ppe,
+              real* __restrict__ pk3, real* __restrict__ pk, real* __restrict__ peln, real* __restrict__ w) {
   const int r = threadIdx.x & (ROW - 1);   // level block of this lane
   const int col = threadIdx.x >> 4;        // column within the workgroup
   const int i = g.is - CG + blockIdx.x * 16 + col;
@@ -500,9 +500,9 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
 }
 
 template <int CG>
-static int launch_column(const Geo& g, int last_call, double dt, double ptop, double p_fac, const double* cappa, const double* zs,
-                         const double* ws, const double* q_con, const double* delp, const double* pt, double* delz, double* zh,
-                         double* pe, double* ppe, double* pk3, double* pk, double* peln, double* w, hipStream_t st) {
+static int launch_column(const Geo& g, int last_call, double dt, double ptop, double p_fac, const real* cappa, const real* zs,
+                         const real* ws, const real* q_con, const real* delp, const real* pt, real* delz, real* zh,
+                         real* pe, real* ppe, real* pk3, real* pk, real* peln, real* w, hipStream_t st) {
   const double peln1 = log(ptop);
   const double ptk = exp(KAPPA * peln1);
   const int ncol = g.n + 2 * CG;
@@ -526,17 +526,17 @@ static int launch_column(const Geo& g, int last_call, double dt, double ptop, do
 // the column solvers accept up to 128 layers in this form (the thread-per-column kernels of k_riem3.hip serve beyond that)
 bool riem_column_supported(const Geo& g) { return g.nk >= 2 && g.nk <= 128; }
 
-int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const double* cappa, double ptop, const double* zs,
-                               const double* wsd, double* delz, const double* q_con, const double* delp, const double* pt,
-                               double* zh, double* pe, double* ppe, double* pk3, double* pk, double* peln, double* w,
+int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const real* cappa, double ptop, const real* zs,
+                               const real* wsd, real* delz, const real* q_con, const real* delp, const real* pt,
+                               real* zh, real* pe, real* ppe, real* pk3, real* pk, real* peln, real* w,
                                double p_fac, hipStream_t st) {
   return launch_column<0>(g, last_call, dt, ptop, p_fac, cappa, zs, wsd, q_con, delp, pt, delz, zh, pe, ppe, pk3, pk, peln, w, st);
 }
 
-int launch_riem_solver_c_column(const Geo& g, double dt2, const double* cappa, double ptop, const double* hs, const double* ws3,
-                                const double* ptc, const double* q_con, const double* delpc, double* gz, double* pef,
-                                const double* w3, double p_fac, hipStream_t st) {
+int launch_riem_solver_c_column(const Geo& g, double dt2, const real* cappa, double ptop, const real* hs, const real* ws3,
+                                const real* ptc, const real* q_con, const real* delpc, real* gz, real* pef,
+                                const real* w3, double p_fac, hipStream_t st) {
   // the C-grid solver does not return w: the kernel reads w3 and writes nothing back (CG = 1 stores only gz and pef)
   return launch_column<1>(g, 0, dt2, ptop, p_fac, cappa, hs, ws3, q_con, delpc, ptc, nullptr, gz, nullptr, pef, nullptr, nullptr,
-                          nullptr, const_cast<double*>(w3), st);
+                          nullptr, const_cast<real*>(w3), st);
 }

@@ -9,16 +9,16 @@
 #define RDGAS 287.05  // constants.py:RDGAS (as in k_riem3.hip)
 
 struct Sim1Work {
-  double *pp, *gam, *aa, *w1, *p1;
+  real *pp, *gam, *aa, *w1, *p1;
 };
 
-int64_t sim1_workspace_bytes(const Geo& g) { return 5 * (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(double); }
+int64_t sim1_workspace_bytes(const Geo& g) { return 5 * (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real); }
 
 __global__ void __launch_bounds__(64)
-k_sim1_solver(Geo g, Sim1Work W, int halo, double dt, double p_fac, const double* __restrict__ gm, const double* __restrict__ cp3,
-              double* __restrict__ pe, const double* __restrict__ dm, const double* __restrict__ pm,
-              const double* __restrict__ pem, double* __restrict__ w, double* __restrict__ dz, const double* __restrict__ pt,
-              const double* __restrict__ ws) {
+k_sim1_solver(Geo g, Sim1Work W, int halo, double dt, double p_fac, const real* __restrict__ gm, const real* __restrict__ cp3,
+              real* __restrict__ pe, const real* __restrict__ dm, const real* __restrict__ pm,
+              const real* __restrict__ pem, real* __restrict__ w, real* __restrict__ dz, const real* __restrict__ pt,
+              const real* __restrict__ ws) {
   const int span = g.n + 2 * halo;
   const int t = (int)(blockIdx.x * 64 + threadIdx.x);
   if (t >= span * span) return;
@@ -104,10 +104,10 @@ k_sim1_solver(Geo g, Sim1Work W, int halo, double dt, double p_fac, const double
 #undef AT
 }
 
-int launch_sim1_solver(const Geo& g, void* ws_, int n_halo, double dt, double p_fac, const double* gamma, const double* cp3,
-                       double* pe, const double* delta_mass, const double* pm, const double* pem, double* w, double* dz,
-                       const double* pt, const double* ws, hipStream_t st) {
-  double* p = (double*)ws_;
+int launch_sim1_solver(const Geo& g, void* ws_, int n_halo, double dt, double p_fac, const real* gamma, const real* cp3,
+                       real* pe, const real* delta_mass, const real* pm, const real* pem, real* w, real* dz,
+                       const real* pt, const real* ws, hipStream_t st) {
+  real* p = (real*)ws_;
   const long field = (long)g.sk * (g.nk + 1);
   Sim1Work W{p, p + field, p + 2 * field, p + 3 * field, p + 4 * field};
   const int span = g.n + 2 * n_halo;

@@ -6,8 +6,8 @@
 
 // flux_compute (tracer_2d_1l.py:19-77)
 __global__ void __launch_bounds__(256)
-k_tracer_flux_compute(Geo g, Met m, const double* __restrict__ cx, const double* __restrict__ cy, double* __restrict__ xfx,
-                      double* __restrict__ yfx) {
+k_tracer_flux_compute(Geo g, Met m, const real* __restrict__ cx, const real* __restrict__ cy, real* __restrict__ xfx,
+                      real* __restrict__ yfx) {
   PLANE_IJK(g);
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -23,8 +23,8 @@ k_tracer_flux_compute(Geo g, Met m, const double* __restrict__ cx, const double*
 
 // divide_fluxes_by_n_substeps (tracer_2d_1l.py:80-106): origin_full, domain_full(add = (1, 1, 0)) = the whole storage plane
 __global__ void __launch_bounds__(256)
-k_tracer_divide(Geo g, double* __restrict__ a0, double* __restrict__ a1, double* __restrict__ a2, double* __restrict__ a3,
-                double* __restrict__ a4, double* __restrict__ a5, double frac) {
+k_tracer_divide(Geo g, real* __restrict__ a0, real* __restrict__ a1, real* __restrict__ a2, real* __restrict__ a3,
+                real* __restrict__ a4, real* __restrict__ a5, double frac) {
   PLANE_IJK(g);
   const long c = IDX3(g, i, j, k);
   a0[c] = a0[c] * frac;
@@ -37,8 +37,8 @@ k_tracer_divide(Geo g, double* __restrict__ a0, double* __restrict__ a1, double*
 
 // apply_mass_flux (tracer_2d_1l.py:115-135), compute domain
 __global__ void __launch_bounds__(256)
-k_apply_mass_flux(Geo g, Met m, const double* __restrict__ dp1, const double* __restrict__ mfx, const double* __restrict__ mfy,
-                  double* __restrict__ dp2) {
+k_apply_mass_flux(Geo g, Met m, const real* __restrict__ dp1, const real* __restrict__ mfx, const real* __restrict__ mfy,
+                  real* __restrict__ dp2) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
@@ -47,8 +47,8 @@ k_apply_mass_flux(Geo g, Met m, const double* __restrict__ dp1, const double* __
 
 // apply_tracer_flux (tracer_2d_1l.py:138-158), compute domain
 __global__ void __launch_bounds__(256)
-k_apply_tracer_flux(Geo g, Met m, double* __restrict__ q, const double* __restrict__ dp1, const double* __restrict__ fx,
-                    const double* __restrict__ fy, const double* __restrict__ dp2) {
+k_apply_tracer_flux(Geo g, Met m, real* __restrict__ q, const real* __restrict__ dp1, const real* __restrict__ fx,
+                    const real* __restrict__ fy, const real* __restrict__ dp2) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
@@ -56,7 +56,7 @@ k_apply_tracer_flux(Geo g, Met m, double* __restrict__ q, const double* __restri
 }
 
 // swap_dp (tracer_2d_1l.py:166-170), compute domain
-__global__ void __launch_bounds__(256) k_swap_dp(Geo g, double* __restrict__ dp1, double* __restrict__ dp2) {
+__global__ void __launch_bounds__(256) k_swap_dp(Geo g, real* __restrict__ dp1, real* __restrict__ dp2) {
   PLANE_IJK(g);
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
@@ -65,31 +65,31 @@ __global__ void __launch_bounds__(256) k_swap_dp(Geo g, double* __restrict__ dp1
   dp2[c] = t;
 }
 
-int launch_tracer_flux_compute(const Geo& g, const Met& m, const double* cx, const double* cy, double* xfx, double* yfx,
+int launch_tracer_flux_compute(const Geo& g, const Met& m, const real* cx, const real* cy, real* xfx, real* yfx,
                                hipStream_t st) {
   hipLaunchKernelGGL(k_tracer_flux_compute, plane_grid(g, g.nk), dim3(256), 0, st, g, m, cx, cy, xfx, yfx);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_tracer_divide(const Geo& g, double* cxd, double* xfx, double* mfxd, double* cyd, double* yfx, double* mfyd,
+int launch_tracer_divide(const Geo& g, real* cxd, real* xfx, real* mfxd, real* cyd, real* yfx, real* mfyd,
                          int n_split, hipStream_t st) {
   hipLaunchKernelGGL(k_tracer_divide, plane_grid(g, g.nk), dim3(256), 0, st, g, cxd, xfx, mfxd, cyd, yfx, mfyd, 1.0 / n_split);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_apply_mass_flux(const Geo& g, const Met& m, const double* dp1, const double* mfx, const double* mfy, double* dp2,
+int launch_apply_mass_flux(const Geo& g, const Met& m, const real* dp1, const real* mfx, const real* mfy, real* dp2,
                            hipStream_t st) {
   hipLaunchKernelGGL(k_apply_mass_flux, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, dp1, mfx, mfy, dp2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_apply_tracer_flux(const Geo& g, const Met& m, double* q, const double* dp1, const double* fx, const double* fy,
-                             const double* dp2, hipStream_t st) {
+int launch_apply_tracer_flux(const Geo& g, const Met& m, real* q, const real* dp1, const real* fx, const real* fy,
+                             const real* dp2, hipStream_t st) {
   hipLaunchKernelGGL(k_apply_tracer_flux, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, q, dp1, fx, fy, dp2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
-int launch_swap_dp(const Geo& g, double* dp1, double* dp2, hipStream_t st) {
+int launch_swap_dp(const Geo& g, real* dp1, real* dp2, hipStream_t st) {
   hipLaunchKernelGGL(k_swap_dp, plane_grid(g, g.nk), dim3(256), 0, st, g, dp1, dp2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;

@@ -24,8 +24,9 @@ def check_layout(geom, *fields):
         if t.dim() == 3 and tuple(t.stride()) != (1, geom.sj, geom.sk):
             raise ValueError(f"field layout {tuple(t.stride())} does not match (1, {geom.sj}, {geom.sk}); "
                              "allocate fields with pace_amd.util.QuantityFactory")
-        if t.dtype != torch.float64:
-            raise ValueError("the acoustic step runs in float64 (dsl/pace/dsl/typing.py:24)")
+        if t.dtype != getattr(geom, "_real", torch.float64):
+            raise ValueError(f"field dtype {t.dtype} does not match the library's storage type "
+                             f"{getattr(geom, '_real', torch.float64)} (dsl/pace/dsl/typing.py:24)")
 
 
 class Operator:
@@ -36,6 +37,9 @@ class Operator:
         self.grid_indexing = stencil_factory.grid_indexing
         self._qf = quantity_factory
         self._geom = geom_struct(quantity_factory)
+        if self.lib.real_bytes != quantity_factory.itemsize:
+            raise _lib.PaceError(f"the library stores {self.lib.real_bytes}-byte reals, the quantity factory allocates "
+                                 f"{quantity_factory.real}: load the matching build (pace_amd._lib.load(precision=...))")
         self._grid_data = grid_data
         self._met = grid_data.c_struct() if grid_data is not None else None
         self._emu = quantity_factory.device.type == "cpu"

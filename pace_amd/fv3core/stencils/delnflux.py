@@ -31,8 +31,8 @@ class DelnFluxNoSG(Operator):
         if self._nk <= 3:
             raise NotImplementedError("nk must be more than 3 for DelnFluxNoSG")
         per_level = expand_externals(nord_h, self._nk)
-        self._nord_dev = torch.as_tensor(per_level, device=quantity_factory.device)
-        self._damp_dev = torch.zeros(self._nk, dtype=torch.float64, device=quantity_factory.device)
+        self._nord_dev = torch.as_tensor(per_level, dtype=quantity_factory.real, device=quantity_factory.device)
+        self._damp_dev = torch.zeros(self._nk, dtype=quantity_factory.real, device=quantity_factory.device)
 
     def _damp(self, damp_c):
         if torch.is_tensor(damp_c) and damp_c.device == self._damp_dev.device:
@@ -40,7 +40,7 @@ class DelnFluxNoSG(Operator):
         a = host_column(damp_c, min(self._nk, len(damp_c) if not hasattr(damp_c, "dims") else damp_c.shape[0]))
         per = np.full(self._nk, a[-1])
         per[: len(a)] = a
-        self._damp_dev.copy_(torch.as_tensor(per))
+        self._damp_dev.copy_(torch.as_tensor(per, dtype=self._damp_dev.dtype))
         return self._damp_dev
 
     def __call__(self, q, fx2, fy2, damp_c, d2, mass=None):
@@ -65,8 +65,8 @@ class DelnFlux(Operator):
         nord_h = expand_externals(host_column(nord_col, nz), nz)
         self._nmax = int(nord_h.max())
         fac = (damp_h * damping_coefficients.da_min) ** (nord_h + 1)
-        self._nord_dev = torch.as_tensor(nord_h, device=quantity_factory.device)
-        self._damp_dev = torch.as_tensor(fac, device=quantity_factory.device)
+        self._nord_dev = torch.as_tensor(nord_h, dtype=quantity_factory.real, device=quantity_factory.device)
+        self._damp_dev = torch.as_tensor(fac, dtype=quantity_factory.real, device=quantity_factory.device)
 
     def __call__(self, q, fx, fy, d2=None, mass=None):
         if self._no_compute:

@@ -21,7 +21,7 @@ class DivergenceDamping(Operator):
         nz = self.grid_indexing.domain[2]
         self._dddmp, self._d4_bg, self._nord = float(dddmp), float(d4_bg), int(nord)
         self._nord_col = np.ascontiguousarray(host_column(nord_col, nz))
-        self._d2_bg = torch.as_tensor(host_column(d2_bg, nz), device=quantity_factory.device)
+        self._d2_bg = torch.as_tensor(host_column(d2_bg, nz), dtype=quantity_factory.real, device=quantity_factory.device)
         nbytes = self.lib.cdll.pace_divergence_damping_workspace_bytes(C.byref(self._geom))
         self._workspace = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=quantity_factory.device)
 

@@ -8,6 +8,7 @@ import ctypes as C
 from typing import Dict
 
 import numpy as np
+import torch
 
 from ... import _lib
 from ...util import constants
@@ -131,7 +132,8 @@ class AcousticDynamics(Operator):
         self._heat_source, self._divgd, self._gz, self._pkc, self._zh = t["heat_source"], t["divgd"], t["gz"], t["pkc"], t["zh"]
         self.cappa, self._ut, self._vt, self._pem, self._pk3 = t["cappa"], t["ut"], t["vt"], t["pem"], t["pk3"]
         self._crx, self._cry, self._xfx, self._yfx, self._ws3 = t["crx"], t["cry"], t["xfx"], t["yfx"], t["ws3"]
-        self._pk3.data[:] = HUGE_R
+        # (1e40 overflows float32 storage: the largest finite value then)
+        self._pk3.data[:] = min(HUGE_R, float(torch.finfo(self._pk3.data.dtype).max))
         column_namelist = d_sw.get_column_namelist(config.d_grid_shallow_water, quantity_factory=quantity_factory)
         self._dp_ref = grid_data.dp_ref
         self._zs = quantity_factory.zeros([X_DIM, Y_DIM], units="m")

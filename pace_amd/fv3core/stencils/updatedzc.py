@@ -11,7 +11,7 @@ class UpdateGeopotentialHeightOnCGrid(Operator):
         """``area`` is accepted for signature parity; the kernel reads it from the metrics table."""
         super().__init__(stencil_factory, quantity_factory, grid_data if grid_data is not None else _grid_of(area))
         nz = self.grid_indexing.domain[2]
-        self._dp_ref = torch.as_tensor(host_column(dp_ref, nz), device=quantity_factory.device)
+        self._dp_ref = torch.as_tensor(host_column(dp_ref, nz), dtype=quantity_factory.real, device=quantity_factory.device)
         nbytes = self.lib.cdll.pace_updatedzc_workspace_bytes(C.byref(self._geom))
         self._workspace = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=quantity_factory.device)
 

@@ -39,8 +39,8 @@ class UpdateHeightOnDGrid(Operator):
         nord = expand_externals(host_column(column_namelist["nord_v"], nz), nz + 1)
         damp = np.zeros(nz + 1)
         damp[:nz] = damp_vt  # the K-field has nz+1 entries, the last one is the allocator's zero
-        self._k_dev = torch.as_tensor(np.concatenate([gk, beta, gamma, damp, nord]), device=quantity_factory.device)
-        base, sz = self._k_dev.data_ptr(), 8
+        self._k_dev = torch.as_tensor(np.concatenate([gk, beta, gamma, damp, nord]), dtype=quantity_factory.real, device=quantity_factory.device)
+        base, sz = self._k_dev.data_ptr(), quantity_factory.itemsize
         k = _lib.UpdatedzdK()
         k.gk, k.beta, k.gamma = base, base + nz * sz, base + 2 * nz * sz
         k.damp, k.nord = base + 3 * nz * sz, base + (3 * nz + nz + 1) * sz

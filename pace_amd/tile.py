@@ -47,7 +47,10 @@ class Env:
 
         self.n, self.nz = n, nz
         self.sizer = SubtileGridSizer.from_tile_params(nx_tile=n, ny_tile=n, nz=nz, n_halo=3, extra_dim_lengths={}, layout=(1, 1))
-        self.qf = QuantityFactory(self.sizer, device=device)
+        import torch
+
+        # the storage type follows the library: float64 for libpace_hip.so, float32 for the _f32 build
+        self.qf = QuantityFactory(self.sizer, device=device, dtype=torch.float32 if lib.real_bytes == 4 else torch.float64)
         self.grid_indexing = GridIndexing.from_sizer_and_communicator(self.sizer, None)
         self.stencil_factory = StencilFactory(StencilConfig(compilation_config=CompilationConfig()), self.grid_indexing, lib=lib,
                                               quantity_factory=self.qf)

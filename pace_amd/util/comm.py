@@ -95,6 +95,26 @@ class NullComm:
         return value
 
 
+class LoopbackComm(NullComm):
+    """NOT a reference communicator: a lone rank that receives from each peer what it sent to that peer (the cube's messages
+    are symmetric in size).  The halos then hold values of the right magnitude -- not the neighbour's, and not in the
+    neighbour's orientation -- so that one tile's step can be TIMED alone without the zeros of NullComm turning the state
+    into NaNs (tools/dycore_bench.py --single).  Never used for results."""
+
+    def exchange(self, sends, recvs, tag=0):
+        sent = {peer: buf for buf, peer in sends}
+
+        def fin():
+            for buf, peer in recvs:
+                src = sent.get(peer)
+                if src is None or src.numel() != buf.numel():
+                    buf[:] = 0.0
+                else:
+                    buf.copy_(src)
+
+        return Request(fin)
+
+
 class _World:
     """Shared state of the tile threads.  The condition's lock doubles as a run token: a tile thread holds it whenever it
     executes and gives it up only while it waits for a message (``Condition.wait_for`` releases and re-acquires it), so the

@@ -63,7 +63,7 @@ class GridData:
                 a = a[0, :] if a.ndim == 2 else a
                 import torch
 
-                setattr(self, name, torch.as_tensor(np.ascontiguousarray(a), device=quantity_factory.device))
+                setattr(self, name, torch.as_tensor(np.ascontiguousarray(a), dtype=quantity_factory.real, device=quantity_factory.device))
             else:
                 a = np.asarray(val, dtype=float)
                 if a.ndim != 2:
@@ -120,7 +120,9 @@ class DampingCoefficients:
 
 def geom_struct(quantity_factory) -> _lib.Geom:
     s = quantity_factory.sizer
-    return _lib.Geom(s.nx, s.nz, quantity_factory.row_stride, 0, quantity_factory.level_stride)
+    g = _lib.Geom(s.nx, s.nz, quantity_factory.row_stride, 0, quantity_factory.level_stride)
+    g._real = quantity_factory.real  # (python-side only: what check_layout expects of the fields)
+    return g
 
 
 from .gridgen import MetricTerms  # noqa: E402,F401  (pace.util.grid exports the three names together)

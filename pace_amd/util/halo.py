@@ -152,8 +152,10 @@ def _nk_of(spec):
 class _Messages:
     """Send and receive strips of one exchange pattern, their buffers and ctypes descriptor tables."""
 
-    def __init__(self, device, peers_send, peers_recv):
+    def __init__(self, device, peers_send, peers_recv, dtype=torch.float64):
         self.device = device
+        self.dtype = dtype if isinstance(dtype, torch.dtype) else torch.float64
+        self.itemsize = 8 if self.dtype == torch.float64 else 4
         self.send = {p: [] for p in peers_send}  # peer rank -> [strips]
         self.recv = {p: [] for p in peers_recv}
         self._ready = False
@@ -166,7 +168,7 @@ class _Messages:
                 for s in strips:
                     s.offset = off
                     off += s.size
-                bufs[peer] = torch.zeros(max(off, 1), dtype=torch.float64, device=self.device)
+                bufs[peer] = torch.zeros(max(off, 1), dtype=self.dtype, device=self.device)
         self._desc_cache = {}
         self._ready = True
 
@@ -181,7 +183,7 @@ class _Messages:
             arr = (_lib.HaloDesc * max(len(strips), 1))()
             for d, (peer, s) in zip(arr, strips):
                 d.field = ptrs[s.field]
-                d.buf = bufs[peer].data_ptr() + 8 * s.offset
+                d.buf = bufs[peer].data_ptr() + self.itemsize * s.offset
                 d.i0, d.j0, d.di_a, d.dj_a, d.di_b, d.dj_b = s.i0, s.j0, s.di_a, s.dj_a, s.di_b, s.dj_b
                 d.na, d.nb, d.nk, d.sign = s.na, s.nb, s.nk, s.sign
             out += [arr, len(strips)]
@@ -211,7 +213,7 @@ class HaloUpdater:
         tile = communicator.rank
         topo = communicator.partitioner
         nbrs = {e: topo.neighbour(tile, e) for e in EDGES}
-        msgs = _Messages(communicator.device, [nbrs[e][0] for e in EDGES], [nbrs[e][0] for e in EDGES])
+        msgs = _Messages(communicator.device, [nbrs[e][0] for e in EDGES], [nbrs[e][0] for e in EDGES], first.dtype)
         # One message per peer.  Its strips are ordered by the SENDER's edges, so the receiving side walks the peer's
         # edges too (on the cubed sphere two tiles share one edge and the order is moot; in a two-tile ring they share four).
         recv_edges = {}  # (peer, position in the peer's message) -> my edge
@@ -292,7 +294,7 @@ class VectorInterfaceHaloUpdater:
             raise NotImplementedError("synchronize_vector_interfaces is defined on the cubed sphere only")
         (to_s, rot_s), (to_w, rot_w) = tile_neighbour(tile, SOUTH), tile_neighbour(tile, WEST)
         (from_n, _), (from_e, _) = tile_neighbour(tile, NORTH), tile_neighbour(tile, EAST)
-        msgs = _Messages(communicator.device, [to_s, to_w], [from_n, from_e])
+        msgs = _Messages(communicator.device, [to_s, to_w], [from_n, from_e], spec_x.dtype)
         # south row of x (field 0): reversed if the neighbour's axis runs the other way, sign from the vector rotation
         rev = (-rot_s) % 4 == 1
         sign = -1.0 if rot_s in (3, 2) else 1.0

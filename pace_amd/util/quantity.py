@@ -13,11 +13,12 @@ import torch
 
 from . import constants as c
 
-ROW_ALIGN = 16  # doubles
+ROW_ALIGN = 16  # doubles (128 B; 32 elements of a float32 field)
 
 
-def row_stride(ni: int) -> int:
-    return (ni + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+def row_stride(ni: int, itemsize: int = 8) -> int:
+    align = ROW_ALIGN * 8 // itemsize
+    return (ni + align - 1) // align * align
 
 
 class SubtileGridSizer:
@@ -120,27 +121,33 @@ class Quantity:
 
 
 class QuantityFactory:
-    def __init__(self, sizer: SubtileGridSizer, device="cuda"):
+    def __init__(self, sizer: SubtileGridSizer, device="cuda", dtype=torch.float64):
+        """``dtype``: storage type of every float field -- torch.float64 (libpace_hip.so) or torch.float32 (libpace_hip_f32.so;
+        the reference's PACE_FLOAT_PRECISION=32, dsl/pace/dsl/typing.py:24)."""
         self.sizer = sizer
         self.device = torch.device(device)
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("fields are float64 or float32")
+        self.real = dtype
+        self.itemsize = 8 if dtype == torch.float64 else 4
 
     @classmethod
-    def from_backend(cls, sizer, backend: str):
+    def from_backend(cls, sizer, backend: str, dtype=torch.float64):
         """Reference signature (allocator.py:42-51); the only backend is the HIP one."""
         device = "cpu" if backend in ("emu", "cpu-emulation") else "cuda"
-        return cls(sizer, device)
+        return cls(sizer, device, dtype)
 
     def _allocate(self, fill, dims, units, dtype):
         dims = tuple(dims)
         shape = self.sizer.get_shape(dims)
-        tdtype = {float: torch.float64, int: torch.int64, bool: torch.bool}.get(dtype, dtype)
+        tdtype = {float: self.real, int: torch.int64, bool: torch.bool}.get(dtype, dtype)
         if len(dims) == 3:
             ni, nj, nk = shape
-            base = torch.full((nk, nj, row_stride(ni)), fill, dtype=tdtype, device=self.device)
+            base = torch.full((nk, nj, row_stride(ni, self.itemsize)), fill, dtype=tdtype, device=self.device)
             data = base.permute(2, 1, 0)[:ni]
         elif len(dims) == 2:
             ni, nj = shape
-            base = torch.full((nj, row_stride(ni)), fill, dtype=tdtype, device=self.device)
+            base = torch.full((nj, row_stride(ni, self.itemsize)), fill, dtype=tdtype, device=self.device)
             data = base.permute(1, 0)[:ni]
         elif len(dims) == 1:
             base = torch.full(shape, fill, dtype=tdtype, device=self.device)
@@ -167,13 +174,13 @@ class QuantityFactory:
         """allocator.py:132-155: the memory description a HaloUpdater is built from."""
         from .halo import QuantityHaloSpec
 
-        return QuantityHaloSpec(self.sizer.n_halo if n_halo is None else n_halo, (1, self.row_stride, self.level_stride), 8,
+        return QuantityHaloSpec(self.sizer.n_halo if n_halo is None else n_halo, (1, self.row_stride, self.level_stride), self.itemsize,
                                 self.sizer.get_shape(dims), self.sizer.get_origin(dims), self.sizer.get_extent(dims), tuple(dims),
-                                None, torch.float64)
+                                None, self.real)
 
     @property
     def row_stride(self):
-        return row_stride(self.sizer.nx + 1 + 2 * self.sizer.n_halo)
+        return row_stride(self.sizer.nx + 1 + 2 * self.sizer.n_halo, self.itemsize)
 
     @property
     def level_stride(self):

@@ -223,6 +223,8 @@ def _child_main(what, out_path, hard_exit=False):
         result = run_dycore_six_tiles(lib, "cuda")
     elif what == "dycore_k2":
         result = run_dycore_six_tiles(lib, "cuda", prefix="dycore_k2_c12")
+    elif what == "dycore_f32":
+        result = run_dycore_six_tiles(_lib.load(32), "cuda")
     elif what == "dycore_generated":
         result = (run_dycore_six_tiles(lib, "cuda", generated="metrics"), run_dycore_six_tiles(lib, "cuda", generated="all"))
     else:

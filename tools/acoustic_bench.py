@@ -16,6 +16,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+PRECISION = 64
+
+
 def build_ops(n, nz):
     """[(name, callable)] for one acoustic substep on one tile + the fields they work on."""
     from pace_amd.tile import DSW_ARGS, Env
@@ -32,7 +35,7 @@ def build_ops(n, nz):
     from pace_amd.fv3core.stencils.updatedzc import UpdateGeopotentialHeightOnCGrid
     from pace_amd.fv3core.stencils.updatedzd import UpdateHeightOnDGrid
 
-    lib = _lib.load()
+    lib = _lib.load(PRECISION)
     m = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(m, n, nz)
     env = Env(lib, "cuda", m, n, nz)
@@ -85,7 +88,10 @@ def main():
     ap.add_argument("--n", type=int, default=192)
     ap.add_argument("--nz", type=int, default=79)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--precision", type=int, default=64, choices=(64, 32))
     args = ap.parse_args()
+    global PRECISION
+    PRECISION = args.precision
     n, nz = args.n, args.nz
     ops, f, (ut, vt, gz, omga) = build_ops(n, nz)
     snap = {}

@@ -47,9 +47,10 @@ def main():
     ap.add_argument("--nz", type=int, default=79)
     ap.add_argument("--n-split", type=int, default=4)
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--precision", type=int, default=64, choices=(64, 32), help="storage type of the fields: libpace_hip.so or libpace_hip_f32.so")
     ap.add_argument("--single", action="store_true",
-                    help="one tile only, behind a lone-rank NullComm (halo updates receive zeros): the device time of one tile's "
-                         "step without the thread rendezvous of the six-tile mode")
+                    help="one tile only, behind a lone-rank LoopbackComm (each halo receives what the tile sent to that neighbour): the "
+                         "device time of one tile's step without the thread rendezvous of the six-tile mode")
     args = ap.parse_args()
     if os.environ.get("PACE_BENCH_TRACE"):
         import faulthandler
@@ -61,9 +62,9 @@ def main():
     from pace_amd.fv3core import DynamicalCoreConfig
     from pace_amd.fv3core.initialization.dycore_state import DycoreState
     from pace_amd.fv3core.stencils.fv_dynamics import DynamicalCore
-    from pace_amd.util import CubedSphereCommunicator, NullComm, constants as c, run_tiles
+    from pace_amd.util import CubedSphereCommunicator, LoopbackComm, constants as c, run_tiles
 
-    lib = _lib.load()
+    lib = _lib.load(args.precision)
     n, nz = args.n, args.nz
     metrics = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(metrics, n, nz)
@@ -103,10 +104,10 @@ def main():
             results[tile] = (wall, dict(timer.t), float(np.isnan(state.w.numpy()).mean()), float(np.isnan(state.pt.numpy()).mean()))
 
     if args.single:
-        program(NullComm(rank=0, total_ranks=6))
+        program(LoopbackComm(rank=0, total_ranks=6))
         wall = results[0][0] / args.steps
         cells = n * n * nz
-        print(f"C{n} x {nz}L, ONE tile (lone-rank NullComm), n_split = {args.n_split}, k_split = 1, {args.steps} steps")
+        print(f"C{n} x {nz}L, ONE tile (lone-rank LoopbackComm), n_split = {args.n_split}, k_split = 1, {args.steps} steps")
         print(f"wall per step: {1e3 * wall:9.2f} ms   ({cells * args.n_split / wall / 1e9:5.2f} G cell-updates/s counting the "
               f"acoustic substeps; the timers synchronise the device at every section boundary)")
     else:

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--nz", type=int, default=79)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--precision", type=int, default=64, choices=(64, 32), help="storage type of the fields: libpace_hip.so or libpace_hip_f32.so")
     args = ap.parse_args()
     from pace_amd.tile import DSW_ARGS, Env
 
@@ -32,7 +33,7 @@ def main():
     from pace_amd.fv3core.stencils.fxadv import FiniteVolumeFluxPrep
     from pace_amd.fv3core.stencils.riem_solver3 import NonhydrostaticVerticalSolver
 
-    lib = _lib.Library(args.lib) if args.lib else _lib.load()
+    lib = _lib.Library(args.lib) if args.lib else _lib.load(args.precision)
     n, nz = args.n, args.nz
     m = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(m, n, nz)
