@@ -51,7 +51,7 @@ def main():
                                               DGridShallowWaterLagrangianDynamicsConfig())
     riem = NonhydrostaticVerticalSolver(env.stencil_factory, env.qf, RiemannConfig())
     cells = n * n * nz
-    field_mb = (n + 1) * (n + 1) * nz * 8 / 1e6
+    field_mb = (n + 1) * (n + 1) * nz * (args.precision // 8) / 1e6
     damp_w = torch.as_tensor(np.full(nz, 1.0e9), device="cuda")
 
     def restore():
