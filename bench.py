@@ -39,6 +39,11 @@ def parse():
     p.add_argument("--precision", type=int, default=64, choices=(64, 32),
                    help="storage type of the fields (the headline metric is fp64; 32 runs libpace_hip_f32.so: float32 fields, "
                         "float64 arithmetic in registers)")
+    p.add_argument("--state", choices=("baroclinic", "synthetic"), default="baroclinic",
+                   help="baroclinic: the operands of the second acoustic substep of the Jablonowski-Williamson case on the gnomonic "
+                        "cubed sphere (grid and initial state from pace_amd's own generators, six tiles stepped together on the "
+                        "device once, this rank's tile captured at the reference's D_SW-In checkpoint; cached in the temp dir); "
+                        "synthetic: pace_amd/synthetic.py's single-tile balanced state (no set-up cost)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     p.add_argument("--watchdog", type=float, default=900.0, help="multi-rank runs: seconds after which a stuck run exits")
@@ -141,7 +146,7 @@ def measure_traffic(kernel_substring, n, nz, precision=64):
         return None, "rocprofv3 not found"
     vals = {}
     tmp = tempfile.mkdtemp(prefix="pace_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PACE_BENCH_CACHE=os.environ.get("PACE_BENCH_CACHE", tempfile.gettempdir()))
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
@@ -246,8 +251,22 @@ def main():
     lib = _lib.Library(os.path.join(ROOT, "tests", "emu", "libpace_emu.so")) if args.emulate else _lib.load(args.precision)
     item = float(lib.real_bytes)
     n, nz = args.n, args.nz
-    metrics = synthetic.tile_metrics(n, nz)
-    s = synthetic.acoustic_state(metrics, n, nz)
+    state_kind = "synthetic" if args.emulate else args.state
+    if state_kind == "baroclinic":
+        import tempfile
+
+        from pace_amd.tile import baroclinic_substep_inputs
+
+        metrics, s, sc = baroclinic_substep_inputs(lib, dev, n, nz, rank % 6,
+                                                   cache_dir=os.environ.get("PACE_BENCH_CACHE", tempfile.gettempdir()))
+        s["dt"] = sc["dt"]
+        if lib.real_bytes == 4:  # the reference's fill values of unused entries (1e30 ... 1e40) do not fit float32
+            big = float(np.finfo(np.float32).max)
+            s = {k: (np.clip(v, -big, big) if isinstance(v, np.ndarray) else v) for k, v in s.items()}
+        torch.cuda.empty_cache()
+    else:
+        metrics = synthetic.tile_metrics(n, nz)
+        s = synthetic.acoustic_state(metrics, n, nz)
     env = Env(lib, dev, metrics, n, nz)
     col = column_namelist(nz, env.qf)
     dsw = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, nested=False,
@@ -397,7 +416,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64" if lib.real_bytes == 8 else "f32 storage, f64 arithmetic in registers",
-            "data": "synthetic" if not args.emulate else "synthetic (CPU EMULATION DRY RUN: no performance meaning)",
+            "data": ("synthetic (CPU EMULATION DRY RUN: no performance meaning)" if args.emulate else
+                     "synthetic: Jablonowski-Williamson baroclinic case on the generated cubed sphere, this rank's tile at the D_SW-In "
+                     "checkpoint of the second acoustic substep" if state_kind == "baroclinic" else "synthetic (pace_amd/synthetic.py)"),
             "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, " + ("fp64" if lib.real_bytes == 8 else "fp32 fields"),
                        "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}",
                        "halo_exchange": topology,

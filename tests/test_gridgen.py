@@ -101,3 +101,22 @@ def test_generated_grid_is_consistent_at_c48():
         assert (t["dx"][3:3 + n, 3:4 + n] > 0).all() and (t["sin_sg1"][:-1, :-1] > 0).all()
     # east halo of tile 0 = west interior of tile 1 (no rotation across that edge)
     assert np.allclose(g[0]["area"][3 + n:6 + n, 3:3 + n], g[1]["area"][3:6, 3:3 + n], rtol=0, atol=0)
+
+
+def test_substep_inputs_captured_from_the_baroclinic_case(tmp_path):
+    """bench.py --state baroclinic: the six generated tiles stepped together (emulation library here), tile 4 captured at the
+    D_SW-In checkpoint of the second acoustic substep; every operand of d_sw + riem_solver3 is there, finite on the compute
+    domain, moving (non-zero Courant numbers), and a second call is served from the cache."""
+    from helpers import DSW_ARGS, build_emu
+
+    from pace_amd import _lib
+    from pace_amd.tile import RIEM_ONLY, baroclinic_substep_inputs
+
+    lib = _lib.Library(build_emu())
+    metrics, fields, sc = baroclinic_substep_inputs(lib, "cpu", 12, 10, 4, cache_dir=str(tmp_path))
+    for k in list(DSW_ARGS) + list(RIEM_ONLY) + ["zs", "ws"]:
+        assert np.isfinite(fields[k][3:15, 3:15]).all(), k
+    assert np.abs(fields["crx"][3:15, 3:15, :10]).max() > 1e-4 and np.abs(fields["w"][3:15, 3:15, :10]).max() > 0.0
+    assert (fields["delp"][3:15, 3:15, :10] > 0).all() and sc["ptop"] == float(metrics["ptop"])
+    m2, f2, _ = baroclinic_substep_inputs(lib, "cpu", 12, 10, 4, cache_dir=str(tmp_path))
+    assert all(np.array_equal(fields[k], f2[k]) for k in fields) and set(m2) == set(metrics)
