@@ -363,51 +363,71 @@ k_nh_set_top(Geo g, real* __restrict__ pp, real* __restrict__ pk3, double top_va
   pk3[c] = top_value;
 }
 
-// calc_u (nh_p_grad.py:29-69), calc_v (:72-112)
+// calc_u (nh_p_grad.py:29-69), calc_v (:72-112).  The B-grid values of gz, pk3, pp (and of delp: wk1) come from the
+// a2b_ord4 launches before it; with WRITE_BACK they are stored over the caller's gz / pk3 / pp here (a2b_ord4's replace = True,
+// a2b_ord4.py:505-506: the reference leaves the interpolated values in its arguments) instead of by three copy kernels.
+template <bool WRITE_BACK>
 __global__ void __launch_bounds__(256)
 k_nh_uv(Geo g, Met m, real* __restrict__ u, real* __restrict__ v, const real* __restrict__ wk1,
-        const real* __restrict__ gz, const real* __restrict__ pk3, const real* __restrict__ pp, double dt) {
+        const real* __restrict__ gz, const real* __restrict__ pk3, const real* __restrict__ pp, double dt,
+        real* __restrict__ gz_out, real* __restrict__ pk3_out, real* __restrict__ pp_out) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const long sk = g.sk;
   const int sj = g.sj;
-  const double wk0 = pk3[c + sk] - pk3[c];
+  const double pk_0 = pk3[c], pk_1 = pk3[c + sk], gz_0 = gz[c], gz_1 = gz[c + sk], pp_0 = pp[c], pp_1 = pp[c + sk];
+  const double wk0 = pk_1 - pk_0;
   if (i <= g.ie) {
     const double wkx = pk3[c + 1 + sk] - pk3[c + 1];
     const double du = dt / (wk0 + wkx) *
-                      ((gz[c + sk] - gz[c + 1]) * (pk3[c + 1 + sk] - pk3[c]) + (gz[c] - gz[c + 1 + sk]) * (pk3[c + sk] - pk3[c + 1]));
+                      ((gz_1 - gz[c + 1]) * (pk3[c + 1 + sk] - pk_0) + (gz_0 - gz[c + 1 + sk]) * (pk_1 - pk3[c + 1]));
     u[c] = (u[c] + du +
             dt / (wk1[c] + wk1[c + 1]) *
-                ((gz[c + sk] - gz[c + 1]) * (pp[c + 1 + sk] - pp[c]) + (gz[c] - gz[c + 1 + sk]) * (pp[c + sk] - pp[c + 1]))) *
+                ((gz_1 - gz[c + 1]) * (pp[c + 1 + sk] - pp_0) + (gz_0 - gz[c + 1 + sk]) * (pp_1 - pp[c + 1]))) *
            m.rdx[c2];
   }
   if (j <= g.je) {
     const double wky = pk3[c + sj + sk] - pk3[c + sj];
     const double dv = dt / (wk0 + wky) *
-                      ((gz[c + sk] - gz[c + sj]) * (pk3[c + sj + sk] - pk3[c]) + (gz[c] - gz[c + sj + sk]) * (pk3[c + sk] - pk3[c + sj]));
+                      ((gz_1 - gz[c + sj]) * (pk3[c + sj + sk] - pk_0) + (gz_0 - gz[c + sj + sk]) * (pk_1 - pk3[c + sj]));
     v[c] = (v[c] + dv +
             dt / (wk1[c] + wk1[c + sj]) *
-                ((gz[c + sk] - gz[c + sj]) * (pp[c + sj + sk] - pp[c]) + (gz[c] - gz[c + sj + sk]) * (pp[c + sk] - pp[c + sj]))) *
+                ((gz_1 - gz[c + sj]) * (pp[c + sj + sk] - pp_0) + (gz_0 - gz[c + sj + sk]) * (pp_1 - pp[c + sj]))) *
            m.rdy[c2];
+  }
+  if (WRITE_BACK) {
+    gz_out[c] = gz_0;
+    pk3_out[c] = pk_0;
+    pp_out[c] = pp_0;
+    if (k == g.nk - 1) {
+      gz_out[c + sk] = gz_1;
+      pk3_out[c + sk] = pk_1;
+      pp_out[c + sk] = pp_1;
+    }
   }
 }
 
-int64_t nh_p_grad_workspace_bytes(const Geo& g) { return (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real); }
+// workspace: the four B-grid fields (pp, pk3, gz, delp interpolated to the cell corners)
+int64_t nh_p_grad_workspace_bytes(const Geo& g) { return 4 * (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real); }
 
 int launch_nh_p_grad(const Geo& g, const Met& m, void* ws_, real* u, real* v, real* pp, real* gz, real* pk3,
                      real* delp, double dt, double ptop, double akap, hipStream_t st) {
-  real* wk1 = (real*)ws_;
+  const long field = (long)g.sk * (g.nk + 1);
+  real* pp_b = (real*)ws_;
+  real* pk3_b = pp_b + field;
+  real* gz_b = pk3_b + field;
+  real* wk1 = gz_b + field;
   const int K = g.nk + 1;
-  int rc;
-  if ((rc = launch_a2b_ord4(g, m, pp, wk1, 1, K, 1, st))) return rc;
-  if ((rc = launch_a2b_ord4(g, m, pk3, wk1, 1, K, 1, st))) return rc;
-  if ((rc = launch_a2b_ord4(g, m, gz, wk1, 0, K, 1, st))) return rc;
-  if ((rc = launch_a2b_ord4(g, m, delp, wk1, 0, g.nk, 0, st))) return rc;
+  const real* in[4] = {pp, pk3, gz, delp};
+  real* out[4] = {pp_b, pk3_b, gz_b, wk1};
+  const int k0[4] = {1, 1, 0, 0}, k1[4] = {K, K, K, g.nk};
+  const int rc = launch_a2b_ord4_batch(g, m, in, out, k0, k1, 4, st);
+  if (rc) return rc;
   const double top_value = pow(ptop, akap);
-  hipLaunchKernelGGL(k_nh_set_top, plane_grid(g, 1), dim3(256), 0, st, g, pp, pk3, top_value);
-  hipLaunchKernelGGL(k_nh_uv, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, u, v, wk1, gz, pk3, pp, dt);
+  hipLaunchKernelGGL(k_nh_set_top, plane_grid(g, 1), dim3(256), 0, st, g, pp_b, pk3_b, top_value);
+  hipLaunchKernelGGL(k_nh_uv<true>, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, u, v, wk1, gz_b, pk3_b, pp_b, dt, gz, pk3, pp);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

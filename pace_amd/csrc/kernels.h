@@ -49,6 +49,11 @@ int launch_delnflux(const Geo& g, const Met& m, int mode, const real* q, real* f
                     const real* mass, const real* damp_k, const real* nord_k, int nmax, int mass_given,
                     int nlev, hipStream_t st);
 int launch_a2b_ord4(const Geo& g, const Met& m, real* qin, real* qout, int k0, int k1, int replace, hipStream_t st);
+// the same with the input tile staged in LDS (qout must not alias qin)
+int launch_a2b_ord4_tiled(const Geo& g, const Met& m, const real* qin, real* qout, int k0, int k1, hipStream_t st);
+// up to four fields (each with its own level range) in one pair of launches
+int launch_a2b_ord4_batch(const Geo& g, const Met& m, const real* const* qin, real* const* qout, const int* k0, const int* k1,
+                          int nfields, hipStream_t st);
 int64_t dsw_workspace_bytes(const Geo& g);
 int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st);
 int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace_dsw_config_t* cfg, void* ws,
