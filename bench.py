@@ -309,12 +309,23 @@ def main():
         part = CubedSpherePartitioner() if world == 6 else RingPartitioner(world)
         cube = CubedSphereCommunicator(TorchDistComm(), part, device=dev, lib=lib)
         exchange = cube.get_scalar_halo_updater([env.qf.get_quantity_halo_spec([X_DIM, Y_DIM, Z_DIM])] * 3)
-        topology = "delp,pt,q_con over RCCL (cubed sphere)" if world == 6 else \
-            f"delp,pt,q_con over RCCL (ring of {world} tiles: stand-in topology, cubed-sphere strip sizes)"
+        from pace_amd.util.constants import X_INTERFACE_DIM, Y_INTERFACE_DIM
+
+        # the exchange in front of d_sw (dyn_core.py:817-820): the C-grid winds, as a vector update
+        exchange_winds = cube.get_vector_halo_updater([env.qf.get_quantity_halo_spec([X_INTERFACE_DIM, Y_DIM, Z_DIM])],
+                                                      [env.qf.get_quantity_halo_spec([X_DIM, Y_INTERFACE_DIM, Z_DIM])])
+        topology = "uc,vc before and delp,pt,q_con after d_sw over RCCL (cubed sphere)" if world == 6 else \
+            f"uc,vc before and delp,pt,q_con after d_sw over RCCL (ring of {world} tiles: stand-in topology, cubed-sphere strip sizes)"
 
     def step(b):
+        args = [b[k] for k in DSW_ARGS]
+        if exchange is not None:
+            # the uc / vc strips travel while the interior of d_sw's flux preparation runs (it reads no halo value of them)
+            exchange_winds.start([b["uc"]], [b["vc"]])
+            dsw.start_flux_preparation(*args, dt)
+            exchange_winds.wait()
         # the wind half of d_sw runs on a side stream, concurrently with the (latency-bound) column solver
-        dsw(*[b[k] for k in DSW_ARGS], dt, overlap_winds=True)
+        dsw(*args, dt, overlap_winds=True)
         if exchange is not None:
             exchange.update([b["delp"], b["pt"], b["q_con"]])
         riem(False, dt, b["cappa"], ptop, zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"], b["ppe"], b["pk3"],

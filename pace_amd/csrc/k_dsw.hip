@@ -1139,6 +1139,9 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   const dim3 gk = plane_grid(g, nk);
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
+  } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
+    if ((phases & 16) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 1))) return rc;
+    if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2))) return rc;
   }
   if (phases & 2) {
   {

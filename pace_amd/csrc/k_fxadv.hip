@@ -6,6 +6,19 @@
 #include "common.h"
 #include "kernels.h"
 
+// Interior / frame split (launch_fxadv `part`): the points of the box [is+2, ie-1] x [js+2, je-1] read no halo value of uc / vc
+// and are touched by none of the edge / corner stages, so their share of stage A and of the fluxes can run while the uc / vc
+// halo exchange is in flight (dyn_core.py:817-820); the frame (everything else, incl. the whole halo region) runs after it.
+struct FxBox {
+  int i0, i1, j0, j1;
+  int mode;  // 0: every point; 1: the points inside the box; 2: the points outside it
+  __device__ __forceinline__ bool skip(int i, int j) const {
+    if (mode == 0) return false;
+    const bool in = i >= i0 && i <= i1 && j >= j0 && j <= j1;
+    return mode == 1 ? !in : in;
+  }
+};
+
 __device__ __forceinline__ double contra(double v1, double v2, double cosa, double rsin2) {
   return (v1 - v2 * cosa) * rsin2;  // d2a2c_vect.py:225-281
 }
@@ -13,9 +26,9 @@ __device__ __forceinline__ double contra(double v1, double v2, double cosa, doub
 // stage A: main_uc_vc_contra (fxadv.py:10-48) + uc_contra_y_edge (:51-77)
 __global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const real* __restrict__ uc,
                                                     const real* __restrict__ vc, real* __restrict__ ut,
-                                                    real* __restrict__ vt) {
+                                                    real* __restrict__ vt, FxBox box) {
   PLANE_IJK(g);
-  if (i > g.ni - 2 || j > g.nj - 2) return;  // domain_full = N+6 points
+  if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;  // domain_full = N+6 points
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   if (i == g.is || i == g.ie + 1) {
@@ -32,9 +45,12 @@ __global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const real* __
 }
 
 // stage B: vc_contra_y_edge (:80-125) then vc_contra_x_edge (:128-145); touches edge strips only
+// (stages B, C, D touch O(N) points per level: they are launched on strips that contain those points -- `R` -- instead of on
+// whole planes, where 99 % of the threads only found out that they had nothing to do: 9 + 9 + 6 us -> see profiles)
 __global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const real* __restrict__ vc,
-                                                        const real* __restrict__ ut, real* __restrict__ vt) {
-  PLANE_IJK(g);
+                                                        const real* __restrict__ ut, real* __restrict__ vt, Regions R) {
+  REGION_POINT(R);
+  (void)interior;
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -53,8 +69,9 @@ __global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const real
 // stage C: uc_contra_x_edge (:148-180), uc_contra_corners (:183-300), vc_contra_corners (:303-404)
 __global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, const real* __restrict__ uc,
                                                                 const real* __restrict__ vc, real* ut,
-                                                                real* vt) {
-  PLANE_IJK(g);
+                                                                real* vt, Regions R) {
+  REGION_POINT(R);
+  (void)interior;
   if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -98,8 +115,9 @@ __global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, co
 
 __global__ void __launch_bounds__(256) k_fxadv_vt_corners(Geo g, Met m, const real* __restrict__ uc,
                                                           const real* __restrict__ vc, const real* ut,
-                                                          real* vt) {
-  PLANE_IJK(g);
+                                                          real* vt, Regions R) {
+  REGION_POINT(R);
+  (void)interior;
   if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
   const bool cols = (i == g.is - 1 || i == g.is || i == g.ie || i == g.ie + 1);
   if (!cols || !(j == g.js + 1 || j == g.je)) return;
@@ -137,11 +155,11 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
                                                       const real* __restrict__ vt, real* __restrict__ crx,
                                                       real* __restrict__ cry, real* __restrict__ xfx,
                                                       real* __restrict__ yfx, double dt,
-                                                      real* __restrict__ cx_acc, real* __restrict__ cy_acc) {
+                                                      real* __restrict__ cx_acc, real* __restrict__ cy_acc, FxBox box) {
   // cx_acc / cy_acc (optional): the Courant-number half of d_sw's flux_capacitor (d_sw.py:33-60), cx += crx, cy += cry,
   // done where crx / cry are produced
   PLANE_IJK(g);
-  if (i > g.ni - 2 || j > g.nj - 2) return;
+  if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   if (i >= g.is && i <= g.ie + 1) {
@@ -174,13 +192,30 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
 
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
-                 hipStream_t st) {
+                 hipStream_t st, int part) {
+  // part 0: everything; 1: the interior box only (needs no halo of uc / vc); 2: the rest, to be run after part 1
   const dim3 grid = plane_grid(g, g.nk), block(256);
-  hipLaunchKernelGGL(k_fxadv_main, grid, block, 0, st, g, m, uc, vc, ut, vt);
-  hipLaunchKernelGGL(k_fxadv_vt_edges, grid, block, 0, st, g, m, vc, ut, vt);
-  hipLaunchKernelGGL(k_fxadv_ut_edges_corners, grid, block, 0, st, g, m, uc, vc, ut, vt);
-  hipLaunchKernelGGL(k_fxadv_vt_corners, grid, block, 0, st, g, m, uc, vc, ut, vt);
-  hipLaunchKernelGGL(k_fxadv_fluxes, grid, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc);
+  FxBox box{g.is + 2, g.ie - 1, g.js + 2, g.je - 1, part};
+  if (part == 1 && (box.i1 < box.i0 || box.j1 < box.j0)) return PACE_OK;
+  hipLaunchKernelGGL(k_fxadv_main, grid, block, 0, st, g, m, uc, vc, ut, vt, box);
+  if (part != 1) {
+    const dim3 sblock(64, 4);
+    Regions rb{};  // stage B: rows js, je+1 over the whole width; columns is-1, is, ie, ie+1 between them
+    add_region(rb, 0, g.ni - 2, g.js, g.js);
+    add_region(rb, 0, g.ni - 2, g.je + 1, g.je + 1);
+    add_region(rb, g.is - 1, g.is, g.js + 2, g.je - 1);
+    add_region(rb, g.ie, g.ie + 1, g.js + 2, g.je - 1);
+    hipLaunchKernelGGL(k_fxadv_vt_edges, regions_grid(rb, g.nk), sblock, 0, st, g, m, vc, ut, vt, rb);
+    Regions rc{};  // stage C: rows js-1, js, je, je+1, columns is+1 .. ie
+    add_region(rc, g.is + 1, g.ie, g.js - 1, g.js);
+    add_region(rc, g.is + 1, g.ie, g.je, g.je + 1);
+    hipLaunchKernelGGL(k_fxadv_ut_edges_corners, regions_grid(rc, g.nk), sblock, 0, st, g, m, uc, vc, ut, vt, rc);
+    Regions rd{};  // stage D: the eight points (is-1, is, ie, ie+1) x (js+1, je)
+    add_region(rd, g.is - 1, g.ie + 1, g.js + 1, g.js + 1);
+    add_region(rd, g.is - 1, g.ie + 1, g.je, g.je);
+    hipLaunchKernelGGL(k_fxadv_vt_corners, regions_grid(rd, g.nk), sblock, 0, st, g, m, uc, vc, ut, vt, rd);
+  }
+  hipLaunchKernelGGL(k_fxadv_fluxes, grid, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

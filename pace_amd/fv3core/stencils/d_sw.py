@@ -103,6 +103,24 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         self._workspace = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=quantity_factory.device)
         self.call("pace_d_sw_prepare", C.byref(self._col), self._workspace.data_ptr(), self.stream())
 
+    def _args(self, fields, dt):
+        check_layout(self._geom, *fields)
+        return (C.byref(self._met), C.byref(self._col), C.byref(self._cfg), self._workspace.data_ptr(), *[dptr(f) for f in fields],
+                float(dt))
+
+    def start_flux_preparation(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con,
+                               zh, heat_source, diss_est, dt):
+        """An extension for overlapping the uc / vc halo exchange with compute (dyn_core.py:817-820: `uc__vc.start()` ...
+        `uc__vc.wait()` right before d_sw): the part of FiniteVolumeFluxPrep that reads no halo value of uc / vc -- the box
+        [is+2, ie-1] x [js+2, je-1], 91 % of the points at C192 -- is launched now; the following ``__call__`` (same arguments,
+        after the wait) then computes only the frame of the flux preparation before it goes on.  Same results bit for bit."""
+        fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source,
+                  diss_est)
+        self.lib.call("pace_d_sw_phases", 16, C.byref(self._geom), *self._args(fields, dt), self.stream())
+        self._prep_started = True
+
+    _prep_started = False
+
     def __call__(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                  heat_source, diss_est, dt, overlap_winds: bool = False):
         """overlap_winds=True (an extension; the default is the reference's behaviour): the wind update of d_sw, which
@@ -111,24 +129,28 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         ``join()`` before touching u, v, uc, vc, heat_source, diss_est, delpc or divgd again."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                   heat_source, diss_est)
-        check_layout(self._geom, *fields)
-        args = (C.byref(self._met), C.byref(self._col), C.byref(self._cfg), self._workspace.data_ptr(), *[dptr(f) for f in fields],
-                float(dt))
+        args = self._args(fields, dt)
+        # flux preparation: everything (1), or only its frame (32) if start_flux_preparation did the interior box (16)
+        prep = 32 if self._prep_started else 1
+        self._prep_started = False
+
+        def phases(mask, stream_ptr):
+            self.lib.call("pace_d_sw_phases", mask, C.byref(self._geom), *args, stream_ptr)
+
         if not overlap_winds or self._emu:
-            self.call("pace_d_sw", *args, self.stream())
+            if prep == 1:
+                self.call("pace_d_sw", *args, self.stream())
+            else:
+                phases(prep | 14, self.stream())
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self._workspace.device)
             self._ev_prep, self._ev_scalars, self._done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         main, side = torch.cuda.current_stream(), self._side
         side_ptr = C.c_void_p(side.cuda_stream)
-
-        def phases(mask, stream_ptr):
-            self.lib.call("pace_d_sw_phases", mask, C.byref(self._geom), *args, stream_ptr)
-
         # Measured at C192 x 79: running winds A (mask 4) concurrently with the scalar transport (mask 2) gains nothing -- both
         # saturate the SIMDs -- while the winds next to the bandwidth-shaped column solver do (-10 % per substep).
-        phases(3, self.stream())        # flux preparation + scalar transport on the calling stream
+        phases(prep | 2, self.stream())  # flux preparation + scalar transport on the calling stream
         self._ev_scalars.record(main)
         side.wait_event(self._ev_scalars)
         phases(12, side_ptr)            # the whole wind update on the side stream

@@ -265,15 +265,17 @@ class AcousticDynamics(Operator):
                                        self._gz, self._pkc, state.omga)
             self._p_grad_c(self.grid_data.rdxc, self.grid_data.rdyc, state.uc, state.vc, csw.delpc, self._pkc, self._gz, dt2)
             halo.uc__vc.start()
+            # delpc of d_sw aliases vt, as in the reference (dyn_core.py:825)
+            dsw_args = (self._vt, state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._divgd,
+                        state.mfxd, state.mfyd, state.cxd, state.cyd, self._crx, self._cry, self._xfx, self._yfx, state.q_con,
+                        self._zh, self._heat_source, state.diss_estd, dt_acoustic_substep)
+            # while the uc / vc strips travel: the interior of d_sw's flux preparation (it reads no halo value of uc / vc)
+            self.dgrid_shallow_water_lagrangian_dynamics.start_flux_preparation(*dsw_args)
             if cfg.nord > 0:
                 halo.divgd.wait()
             halo.uc__vc.wait()
             self._checkpoint_dsw_in(state)
-            # delpc of d_sw aliases vt, as in the reference (dyn_core.py:825)
-            self.dgrid_shallow_water_lagrangian_dynamics(
-                self._vt, state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._divgd,
-                state.mfxd, state.mfyd, state.cxd, state.cyd, self._crx, self._cry, self._xfx, self._yfx, state.q_con, self._zh,
-                self._heat_source, state.diss_estd, dt_acoustic_substep, overlap_winds=True)
+            self.dgrid_shallow_water_lagrangian_dynamics(*dsw_args, overlap_winds=True)
             self._checkpoint_dsw_out(state)
             halo.delp__pt__q_con.update()
             self.update_height_on_d_grid(surface_height=self._zs, height=self._zh, courant_number_x=self._crx,
