@@ -96,6 +96,7 @@ _PROTOS = {
     ),
     "pace_c_sw_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_c_sw": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 16 + [C.c_double, C.c_int, C.c_void_p]),
+    "pace_c_sw_part": (C.c_int, [C.c_int, _P(Geom), _P(Metrics)] + [c_dp] * 16 + [C.c_double, C.c_int, C.c_void_p]),
     "pace_d2a2c_vect": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 9 + [C.c_void_p]),
     "pace_riem_solver_c_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_riem_solver_c": (C.c_int, [_P(Geom), c_dp, C.c_double, c_dp, C.c_double] + [c_dp] * 8 + [C.c_double, C.c_void_p]),

@@ -211,6 +211,16 @@ int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspac
                      nord, S(stream));
 }
 
+int pace_c_sw_part(int part, const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* delpc, real* ptc,
+                   const real* delp, const real* pt, const real* u, const real* v, const real* w, real* uc,
+                   real* vc, real* ua, real* va, real* ut, real* vt, real* divgd, real* omga, double dt2,
+                   int nord, void* stream) {
+  NEED(geom && met && workspace && delpc && ptc && delp && pt && u && v && w && uc && vc && ua && va && ut && vt && divgd && omga);
+  if (part < 0 || part > 2) return PACE_ERR_ARG;
+  return launch_c_sw(make_geo(geom), *met, workspace, delpc, ptc, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2,
+                     nord, S(stream), part);
+}
+
 int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* uc, real* vc,
                     const real* u, const real* v, real* ua, real* va, real* utc, real* vtc, void* stream) {
   NEED(geom && met && workspace && uc && vc && u && v && ua && va && utc && vtc);

@@ -332,6 +332,18 @@ extern int g_pace_sync_launches;
     }                                                              \
   } while (0)
 
+// Interior / frame split of a plane launch around a halo exchange: mode 0 = every point, 1 = the points inside the box,
+// 2 = the points outside it (launched after mode 1; together they cover the plane exactly once).
+struct SplitBox {
+  int i0, i1, j0, j1;
+  int mode;
+  __device__ __forceinline__ bool skip(int i, int j) const {
+    if (mode == 0) return false;
+    const bool in = i >= i0 && i <= i1 && j >= j0 && j <= j1;
+    return mode == 1 ? !in : in;
+  }
+};
+
 static inline dim3 plane_grid(const Geo& g, int nlev) {
   return dim3((unsigned)(((long)g.sj * g.nj + 255) / 256), (unsigned)nlev, 1);
 }

@@ -69,9 +69,9 @@ __device__ __forceinline__ bool fill_y_src(const Geo& g, int ncells, int i, int 
 // pass A
 __global__ void __launch_bounds__(256)
 k_d2a2c_a(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ utmp,
-          real* __restrict__ vtmp, real* __restrict__ ua, real* __restrict__ va) {
+          real* __restrict__ vtmp, real* __restrict__ ua, real* __restrict__ va, SplitBox box) {
   PLANE_IJK(g);
-  if (i > g.ni - 2 || j > g.nj - 2) return;
+  if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;
   const long c = IDX3(g, i, j, k);
   const long kb = (long)k * g.sk;
   D2A d{g, u + kb, v + kb};
@@ -357,7 +357,7 @@ int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, real* uc, real* vc, 
   real* utmp = (real*)ws;
   real* vtmp = utmp + field;
   const dim3 grid = plane_grid(g, g.nk), block(256);
-  hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
+  hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va, SplitBox{0, 0, 0, 0, 0});
   const Regions rb = d2a2c_regions(g);
   hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, utc, vtc,
                      (real*)nullptr, 0.0, 0, 0, rb);
@@ -367,7 +367,9 @@ int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, real* uc, real* vc, 
 
 int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, const real* delp, const real* pt,
                 const real* u, const real* v, const real* w, real* uc, real* vc, real* ua, real* va,
-                real* ut, real* vt, real* divgd, real* omga, double dt2, int nord, hipStream_t st) {
+                real* ut, real* vt, real* divgd, real* omga, double dt2, int nord, hipStream_t st, int part) {
+  // part 0: everything.  Around the u / v halo exchange (dyn_core.py:744-745): 1 = the points of pass A that read no halo value
+  // of u / v (the box [is+1, ie-1] x [js+1, je-1]); 2 = the rest of pass A and everything after it.
   if (g.n < 8) return PACE_ERR_UNSUPPORTED;
   const long field = g.sk * (g.nk + 1);
   real* utmp = (real*)ws;
@@ -375,7 +377,12 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, co
   real* ke = utmp + 2 * field;
   real* vort = utmp + 3 * field;
   const dim3 grid = plane_grid(g, g.nk), block(256);
-  hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va);
+  hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va,
+                     SplitBox{g.is + 1, g.ie - 1, g.js + 1, g.je - 1, part});
+  if (part == 1) {
+    PACE_CHECK_LAUNCH();
+    return PACE_OK;
+  }
   const Regions rb = d2a2c_regions(g);
   hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2,
                      nord > 0 ? 1 : 0, 1, rb);

@@ -9,15 +9,7 @@
 // Interior / frame split (launch_fxadv `part`): the points of the box [is+2, ie-1] x [js+2, je-1] read no halo value of uc / vc
 // and are touched by none of the edge / corner stages, so their share of stage A and of the fluxes can run while the uc / vc
 // halo exchange is in flight (dyn_core.py:817-820); the frame (everything else, incl. the whole halo region) runs after it.
-struct FxBox {
-  int i0, i1, j0, j1;
-  int mode;  // 0: every point; 1: the points inside the box; 2: the points outside it
-  __device__ __forceinline__ bool skip(int i, int j) const {
-    if (mode == 0) return false;
-    const bool in = i >= i0 && i <= i1 && j >= j0 && j <= j1;
-    return mode == 1 ? !in : in;
-  }
-};
+typedef SplitBox FxBox;
 
 __device__ __forceinline__ double contra(double v1, double v2, double cosa, double rsin2) {
   return (v1 - v2 * cosa) * rsin2;  // d2a2c_vect.py:225-281

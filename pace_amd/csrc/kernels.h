@@ -94,7 +94,7 @@ int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, real* uc, real* vc, 
                       real* ua, real* va, real* utc, real* vtc, hipStream_t st);
 int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, const real* delp, const real* pt,
                 const real* u, const real* v, const real* w, real* uc, real* vc, real* ua, real* va,
-                real* ut, real* vt, real* divgd, real* omga, double dt2, int nord, hipStream_t st);
+                real* ut, real* vt, real* divgd, real* omga, double dt2, int nord, hipStream_t st, int part = 0);
 // k_riem3.hip (C-grid solver)
 int64_t riemc_workspace_bytes(const Geo& g);
 int launch_riem_solver_c(const Geo& g, void* ws, double dt2, const real* cappa, double ptop, const real* hs,

@@ -23,8 +23,25 @@ class CGridShallowWaterDynamics(Operator):
         nbytes = self.lib.cdll.pace_c_sw_workspace_bytes(C.byref(self._geom))
         self._workspace = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=quantity_factory.device)
 
-    def __call__(self, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2: float):
+    def _args(self, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2):
         check_layout(self._geom, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga)
-        self.call("pace_c_sw", C.byref(self._met), self._workspace.data_ptr(), dptr(self.delpc), dptr(self.ptc), dptr(delp),
-                  dptr(pt), dptr(u), dptr(v), dptr(w), dptr(uc), dptr(vc), dptr(ua), dptr(va), dptr(ut), dptr(vt), dptr(divgd),
-                  dptr(omga), float(dt2), self._nord, self.stream())
+        return (C.byref(self._met), self._workspace.data_ptr(), dptr(self.delpc), dptr(self.ptc), dptr(delp), dptr(pt), dptr(u),
+                dptr(v), dptr(w), dptr(uc), dptr(vc), dptr(ua), dptr(va), dptr(ut), dptr(vt), dptr(divgd), dptr(omga), float(dt2),
+                self._nord, self.stream())
+
+    _started = False
+
+    def start_interior(self, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2: float):
+        """An extension for overlapping the u / v halo exchange in front of c_sw with compute (dyn_core.py:744-745): the points
+        of the first pass (the D-grid winds interpolated to the A grid) that read no halo value of u / v are computed now; the
+        following ``__call__`` (same arguments, after ``u__v.wait()``) does the rest.  Same results bit for bit."""
+        self.lib.call("pace_c_sw_part", 1, C.byref(self._geom), *self._args(delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2))
+        self._started = True
+
+    def __call__(self, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2: float):
+        args = self._args(delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2)
+        if self._started:
+            self._started = False
+            self.lib.call("pace_c_sw_part", 2, C.byref(self._geom), *args)
+        else:
+            self.call("pace_c_sw", *args)

@@ -247,11 +247,14 @@ class AcousticDynamics(Operator):
                 halo.delp__pt.wait()
             if it == n_split - 1 and end_step and cfg.use_old_omega:
                 self._interface_pressure_from_toa_pressure_and_thickness(state.delp, self._pem, self._ptop)
+            csw_args = (state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._ut, self._vt,
+                        self._divgd, state.omga, dt2)
+            # while the u / v (and w) strips travel: the part of c_sw's first pass that reads no halo value of u / v
+            csw.start_interior(*csw_args)
             halo.u__v.wait()
             halo.w.wait()
             self._checkpoint_csw(state, tag="In")
-            csw(state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._ut, self._vt,
-                self._divgd, state.omga, dt2)
+            csw(*csw_args)
             self._checkpoint_csw(state, tag="Out")
             if cfg.nord > 0:
                 halo.divgd.start()
