@@ -1,0 +1,32 @@
+#!/bin/bash
+# Regenerates the round's measurement artefacts on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into
+# profiles/).  Run from the repo root:  /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
+# rocprofv3: the program itself after `--`, counters in their own passes, no tracing domain besides the kernel trace.
+set -u
+TAG=${1:-r02}
+R=$(pwd)
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+export TMPDIR=/tmp
+export PACE_BENCH_CACHE=/tmp
+cd "$R"
+python bench.py > "$O/bench.json" 2> "$O/bench.err"
+for n in 48 96 384; do python bench.py --tile-size $n --no-cpu-baseline --no-traffic 2>/dev/null | tail -1; done > "$O/bench_sizes.jsonl"
+python tools/acoustic_bench.py 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench.txt"
+cd /tmp
+rocprofv3 --kernel-trace --stats -d "$O/trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-traffic > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
+rocprofv3 --kernel-trace --stats -d "$O/trace_loop" -o loop -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2> "$O/trace_loop.err"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-traffic > /dev/null 2>> "$O/pmc.err"
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_loop_$c" -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2>> "$O/pmc.err"
+done
+cd "$R"
+DB=$(find "$O/trace" -name '*.db' | head -1)
+DBL=$(find "$O/trace_loop" -name '*.db' | head -1)
+[ -n "$DB" ] && python tools/rocprof_summary.py "$DB" > "$O/kernel_stats.csv" && python tools/rocprof_timeline.py "$DB" > "$O/timeline.txt"
+[ -n "$DBL" ] && python tools/rocprof_summary.py "$DBL" > "$O/whole_loop_kernel_stats.csv"
+python tools/pmc_summary.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" > "$O/pmc_traffic.json"
+python tools/pmc_summary.py "$O/pmc_loop_FETCH_SIZE" "$O/pmc_loop_WRITE_SIZE" > "$O/whole_loop_pmc_traffic.json"
+rm -rf "$O"/trace "$O"/trace_loop "$O"/pmc_FETCH_SIZE "$O"/pmc_WRITE_SIZE "$O"/pmc_loop_FETCH_SIZE "$O"/pmc_loop_WRITE_SIZE
+ls -la "$O"
+tail -1 "$O/bench.json" | cut -c1-400
