@@ -207,7 +207,9 @@ def baroclinic_substep_inputs(lib, device, n, nz, tile, dt_atmos=None, cache_dir
         raise RuntimeError(f"non-finite values in the captured state: {bad}")
     metrics = {k: np.asarray(v) for k, v in tiles[tile].items() if k not in ("ee1", "ee2", "es1", "ew2")}
     scalars = {"dt": dt_atmos / n_split, "ptop": float(metrics["ptop"])}
-    if path:
-        np.savez(path, dt=scalars["dt"], ptop=scalars["ptop"], **{"m_" + k: v for k, v in metrics.items()},
+    if path:  # written under a private name, then renamed: another rank may be looking for the same tile's file
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        np.savez(tmp, dt=scalars["dt"], ptop=scalars["ptop"], **{"m_" + k: v for k, v in metrics.items()},
                  **{"f_" + k: v for k, v in captured.items()})
+        os.replace(tmp, path)
     return metrics, captured, scalars
