@@ -414,7 +414,25 @@ def main():
         if not args.no_traffic and world == 1:
             torch.cuda.synchronize()
             traffic, traffic_detail = measure_traffic(("k_fvtp2d<6, 2, 1>", "k_fvtp2dILi6ELi2ELi1E"), n, nz, args.precision)
+        # what this memory system sustains on a plain device-to-device copy (read + write of 1 GiB each way), next to the spec
+        # peak the fractions are priced against
+        try:
+            src = torch.empty(1 << 27, dtype=torch.float64, device=dev).normal_()
+            dst = torch.empty_like(src)
+            for _ in range(2):
+                dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 10 * 2 * src.numel() * 8 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:  # noqa: BLE001
+            copy_gbs = None
         roof = {"kernel": "k_fvtp2d<6, 2, 1>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "measured_copy_GBs": copy_gbs,
                 "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                 "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo,
                 "limited_by": "latency of its barrier-separated stages at 4 waves per SIMD (VALU ~37 % busy, HBM ~3 TB/s): "
