@@ -241,27 +241,32 @@ k_apply_height_fluxes(Geo g, Met m, real* __restrict__ zh, const real* __restric
   zh[c] = adv + (fx2[c] - fx2[c + 1] + fy2[c] - fy2[c + g.sj]) / area;
 }
 
+// column part of update_dz_d (updatedzd.py:56-67 after the flux update): ws from the bottom interface, then the heights kept
+// at least DZ_MIN apart from the bottom up.  `zin` holds the flux-updated heights (the transport's epilogue wrote them to a
+// scratch field), `zh` receives the result.
 __global__ void __launch_bounds__(64)
-k_height_column(Geo g, const real* __restrict__ zs, real* __restrict__ zh, real* __restrict__ ws, double dt) {
+k_height_column(Geo g, const real* __restrict__ zs, const real* zin, real* zh, real* __restrict__ ws, double dt) {
+  // (zin may be zh itself: no __restrict__ on the two)
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y;
   if (i > g.ie || j > g.je) return;
   const long c0 = IDX2(g, i, j);
   const int km = g.nk;
   constexpr int CHZ = 16;
-  double below = zh[c0 + (long)km * g.sk];
+  double below = zin[c0 + (long)km * g.sk];
+  zh[c0 + (long)km * g.sk] = below;
   ws[c0] = (zs[c0] - below) / dt;
   for (int k0 = km - 1; k0 >= 0; k0 -= CHZ) {
     double z_[CHZ];
 #pragma unroll
-    for (int t = 0; t < CHZ; ++t) z_[t] = zh[c0 + (long)((k0 - t >= 0) ? k0 - t : 0) * g.sk];
+    for (int t = 0; t < CHZ; ++t) z_[t] = zin[c0 + (long)((k0 - t >= 0) ? k0 - t : 0) * g.sk];
 #pragma unroll
     for (int t = 0; t < CHZ; ++t) {
       const int k = k0 - t;
       if (k >= 0) {
         const double other = below + DZ_MIN;
         const double v = (z_[t] > other) ? z_[t] : other;
-        if (v != z_[t]) zh[c0 + (long)k * g.sk] = v;
+        zh[c0 + (long)k * g.sk] = v;
         below = v;
       }
     }
@@ -289,10 +294,23 @@ int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd
     hipLaunchKernelGGL(k_spline_to_interfaces, dim3((g.ni - 1 + 63) / 64, g.nj - 1, 4), dim3(64), 0, st, g, s, crx, cry, xfx, yfx,
                        crx_i, cry_i, xfx_i, yfx_i);
   int rc;
-  if ((rc = launch_fvtp2d(g, m, zh, crx_i, cry_i, xfx_i, yfx_i, fx, fy, nullptr, nullptr, hord_tm, g.nk + 1, st))) return rc;
-  if ((rc = launch_delnflux(g, m, 0, zh, fx2, fy2, nullptr, kc->damp, kc->nord, kc->nmax, 0, g.nk + 1, st))) return rc;
-  hipLaunchKernelGGL(k_apply_height_fluxes, patch_grid(g, g.nk + 1), PATCH_BLOCK, 0, st, g, m, zh, fx, fy, xfx_i, yfx_i, fx2, fy2);
-  hipLaunchKernelGGL(k_height_column, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, zs, zh, wsd, dt);
+  if (hord_tm == 5 || hord_tm == 6) {
+    // transport of the heights, del-n damping of the same field and apply_height_fluxes in ONE kernel (the transport kernel's
+    // height epilogue): the four flux fields are never written; the updated heights go to a scratch field (`fx`) because
+    // neighbouring tiles still read zh, and the column kernel moves them back (14 field passes -> 4)
+    FvDamp dp{};
+    dp.damp_k = kc->damp; dp.nord_k = kc->nord; dp.nmax = kc->nmax; dp.mass_given = 0;
+    dp.qout = fx;
+    if ((rc = launch_transport(g, m, zh, crx_i, cry_i, xfx_i, yfx_i, nullptr, nullptr, nullptr, nullptr, hord_tm, g.nk + 1, 0, 3, dp,
+                               st)))
+      return rc;
+    hipLaunchKernelGGL(k_height_column, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, zs, fx, zh, wsd, dt);
+  } else {
+    if ((rc = launch_fvtp2d(g, m, zh, crx_i, cry_i, xfx_i, yfx_i, fx, fy, nullptr, nullptr, hord_tm, g.nk + 1, st))) return rc;
+    if ((rc = launch_delnflux(g, m, 0, zh, fx2, fy2, nullptr, kc->damp, kc->nord, kc->nmax, 0, g.nk + 1, st))) return rc;
+    hipLaunchKernelGGL(k_apply_height_fluxes, patch_grid(g, g.nk + 1), PATCH_BLOCK, 0, st, g, m, zh, fx, fy, xfx_i, yfx_i, fx2, fy2);
+    hipLaunchKernelGGL(k_height_column, dim3((g.n + 63) / 64, g.n), dim3(64), 0, st, g, zs, zh, zh, wsd, dt);
+  }
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

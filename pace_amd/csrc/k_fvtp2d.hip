@@ -432,7 +432,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     constexpr int AXP = TI + 2, AYP = TI + 1;
     double* ax = &L.syin[0][0];          // [TJ][AXP]
     double* ay = ax + TJ * AXP;          // [TJ + 1][AYP]
-    double* ax2 = ay + (TJ + 1) * AYP;   // damping fluxes (EPI == 2)
+    double* ax2 = ay + (TJ + 1) * AYP;   // damping fluxes (EPI == 2, 3)
     double* ay2 = ax2 + TJ * AXP;
     static_assert(EPI == 0 || 2 * (TJ * AXP + (TJ + 1) * AYP) <= FvLds<DMODE, EPI>::kSweep + FvLds<DMODE, EPI>::kPad, "epilogue scratch");
     __syncthreads();
@@ -442,7 +442,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       for (int f = 0; f < RF; ++f) {
         if (grp * RF + f <= TI) {
           ax[jj * AXP + grp * RF + f] = vxf[f];
-          if (EPI == 2) ax2[jj * AXP + grp * RF + f] = dvx[f];
+          if (EPI >= 2) ax2[jj * AXP + grp * RF + f] = dvx[f];
         }
       }
     }
@@ -452,13 +452,47 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       for (int f = 0; f < RF; ++f) {
         if (grp * RF + f <= TJ) {
           ay[(grp * RF + f) * AYP + ii] = vyf[f];
-          if (EPI == 2) ay2[(grp * RF + f) * AYP + ii] = dvy[f];
+          if (EPI >= 2) ay2[(grp * RF + f) * AYP + ii] = dvy[f];
         }
       }
     }
     __syncthreads();
     STAMP(9);
     constexpr int NEC = (TI * TJ + 255) / 256;
+    if (EPI == 3) {
+      // apply_height_fluxes (updatedzd.py:70-126): the advected height from the transport's own fluxes over the area the cell
+      // has after the step, plus the damping increment -- written to dp.qout (the height field itself is still being read by
+      // neighbouring tiles); same expressions, same order as the stand-alone kernel it replaces
+      double ar_[NEC], qv_[NEC], x0_[NEC], x1_[NEC], y0_[NEC], y1_[NEC];
+#pragma unroll
+      for (int t = 0; t < NEC; ++t) {
+        const int e = tid + 256 * t;
+        const int jj = e / TI, ii = e - jj * TI;
+        const int gi = i0 + ii, gj = j0 + jj;
+        const bool ok = e < TI * TJ && !((EX && gi > g.ie) || (EY && gj > g.je));
+        const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+        ar_[t] = LD(m.area, c2);
+        qv_[t] = LD(q, kb8 + c2);
+        x0_[t] = LD(xfx, kb8 + c2);
+        x1_[t] = LD(xfx, kb8 + c2 + E8);
+        y0_[t] = LD(yfx, kb8 + c2);
+        y1_[t] = LD(yfx, kb8 + c2 + sj8);
+      }
+#pragma unroll
+      for (int t = 0; t < NEC; ++t) {
+        const int e = tid + 256 * t;
+        const int jj = e / TI, ii = e - jj * TI;
+        const int gi = i0 + ii, gj = j0 + jj;
+        if (e >= TI * TJ || (EX && gi > g.ie) || (EY && gj > g.je)) continue;
+        const unsigned c = kb8 + OFF2(gi, gj);
+        const double area = ar_[t];
+        const double area_after = (area + x0_[t] - x1_[t]) + (area + y0_[t] - y1_[t]) - area;
+        const double adv = (qv_[t] * area + ax[jj * AXP + ii] - ax[jj * AXP + ii + 1] + ay[jj * AYP + ii] - ay[(jj + 1) * AYP + ii]) /
+                           area_after;
+        ST(dp.qout, c) = adv + (ax2[jj * AXP + ii] - ax2[jj * AXP + ii + 1] + ay2[jj * AYP + ii] - ay2[(jj + 1) * AYP + ii]) / area;
+      }
+      return;
+    }
     double ra_[NEC], qv_[NEC], am_[NEC];
 #pragma unroll
     for (int t = 0; t < NEC; ++t) {  // all loads first (see stage 0)
@@ -540,9 +574,12 @@ static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo&
       case -1: FV_LAUNCH(-1, 1); break;
       default: return PACE_ERR_UNSUPPORTED;
     }
-  } else {
+  } else if (epi == 2) {
     if (dmode != 0) return PACE_ERR_UNSUPPORTED;
     FV_LAUNCH(0, 2);
+  } else {
+    if (dmode != 0 || epi != 3) return PACE_ERR_UNSUPPORTED;
+    FV_LAUNCH(0, 3);
   }
   return PACE_OK;
 }
