@@ -179,7 +179,8 @@ int pace_d_sw(DSW_PARAMS) { return d_sw_entry(15, DSW_ARGS_); }
 int pace_d_sw_transport(DSW_PARAMS) { return d_sw_entry(3, DSW_ARGS_); }
 int pace_d_sw_winds(DSW_PARAMS) { return d_sw_entry(12, DSW_ARGS_); }
 int pace_d_sw_phases(int phases, DSW_PARAMS) {
-  if (phases < 1 || phases > 63 || ((phases & 1) && (phases & 48))) return PACE_ERR_ARG;  // (1 and 16 / 32 are alternatives)
+  if (phases < 1 || phases > 255 || ((phases & 1) && (phases & 48)) || ((phases & 4) && (phases & 192)))
+    return PACE_ERR_ARG;  // (1 and 16 / 32, 4 and 64 / 128 are alternatives)
   return d_sw_entry(phases, DSW_ARGS_);
 }
 

@@ -1167,8 +1167,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   }
-  if (phases & 4) {
-  // winds
+  if (phases & (4 | 64)) {
+  // winds A1: kinetic energy and relative vorticity (need only the flux preparation)
   const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
   if (cfg->hord_mt == 5) {
     hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke);
@@ -1178,7 +1178,9 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     return PACE_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
-  // divergence damping
+  }
+  if (phases & (4 | 128)) {
+  // winds A2: divergence damping
   launch_divergence_damping(g, m, u, v, va, W.vort_b, ua, divgd, vc, uc, delpc, W.ke, W.wk, dt, d_d2, kstart, nonzero_nord,
                             cfg->dddmp, cfg->d4_bg, W.da, W.db, st);
   // vorticity transport

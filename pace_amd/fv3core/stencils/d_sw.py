@@ -1,6 +1,7 @@
 """DGridShallowWaterLagrangianDynamics + get_column_namelist
 (reference: fv3core/pace/fv3core/stencils/d_sw.py:614-683,726-1237)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -150,6 +151,8 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         side_ptr = C.c_void_p(side.cuda_stream)
         # Measured at C192 x 79: running winds A (mask 4) concurrently with the scalar transport (mask 2) gains nothing -- both
         # saturate the SIMDs -- while the winds next to the bandwidth-shaped column solver do (-10 % per substep).
+        # (Measured in round 2 as well: only the kinetic energy + vorticity (mask 64, bandwidth-shaped) next to the scalar
+        # transports and the rest of the winds (128 | 8) next to the column solver: no difference either.)
         phases(prep | 2, self.stream())  # flux preparation + scalar transport on the calling stream
         self._ev_scalars.record(main)
         side.wait_event(self._ev_scalars)
