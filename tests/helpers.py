@@ -623,14 +623,30 @@ def l2e_synthetic_case(n, km, seed=2):
     return f, tracers, ak, bk, ptop
 
 
-def run_d_sw_h5_fixture(env):
-    """The reference run with every advection order set to 5 (tools/make_golden_dsw_variants.py) through the host class."""
-    fix = golden("d_sw_h5_c12_tile0_call1.npz")
+DSW_VARIANTS = {  # tools/make_golden_dsw_variants.py: runs of the reference with one namelist option changed
+    "h5": dict(hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5),
+    "nord2": dict(nord=2),
+    "dcon0": dict(d_con=0.0),
+    "skeb": dict(do_skeb=True),
+    "dddmp0": dict(dddmp=0.0),
+}
+
+
+def dsw_variant_fixture(variant):
+    fix = golden(f"d_sw_{variant}_c12_tile0_call1.npz")
     k_sel = fix["k_sel"]
-    cfg = dict(DSW_CFG, hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5)
+    cfg = dict(DSW_CFG, **DSW_VARIANTS[variant])
     col = {k[4:]: np.ascontiguousarray(v[np.asarray(k_sel)]) for k, v in fix.items() if k.startswith("col_")}
+    return fix, cfg, col, len(k_sel)
+
+
+def run_d_sw_variant_fixture(env, variant):
+    """A run of the reference with one namelist option changed, through the host class; returns {field: error}."""
+    fix, cfg, col, nk = dsw_variant_fixture(variant)
     out, _ = run_d_sw(env, col, {k: fix["in_" + k] for k in DSW_ARGS}, float(fix["dt"]), ut0=fix["in_uc_contra"],
                       vt0=fix["in_vc_contra"], cfg=cfg)
-    nk = len(k_sel)
-    return max(compare(fix["out_" + k][dsw_window(k, 12, nk)], out[k][dsw_window(k, 12, nk)])
-               for k in DSW_ARGS if k != "zh")
+    return {k: compare(fix["out_" + k][dsw_window(k, 12, nk)], out[k][dsw_window(k, 12, nk)]) for k in DSW_ARGS if k != "zh"}
+
+
+def run_d_sw_h5_fixture(env):
+    return max(run_d_sw_variant_fixture(env, "h5").values())

@@ -438,6 +438,17 @@ def test_d_sw_order5_emulated_against_reference_run(emu_lib):
     assert run_d_sw_h5_fixture(env) == 0.0
 
 
+@pytest.mark.parametrize("variant", ["nord2", "dcon0", "skeb", "dddmp0"])
+def test_d_sw_namelist_variants_emulated_against_reference_run(emu_lib, variant):
+    """d_sw with one namelist option changed (nord = 2: two damping passes in the fused divergence-damping kernel and second-order
+    del-n damping; d_con = 0; do_skeb; dddmp = 0) against runs of the reference with that namelist: bit for bit."""
+    from helpers import dsw_variant_fixture, run_d_sw_variant_fixture
+
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, dsw_variant_fixture(variant)[3])
+    errs = run_d_sw_variant_fixture(env, variant)
+    assert max(errs.values()) == 0.0, errs
+
+
 @pytest.mark.parametrize("which,n,nz", [("big", 12, 10), ("small", 24, 12)])
 def test_operator_chain_emulated_vs_oracle(emu_lib, emu_small_lib, which, n, nz):
     """Every operator of the acoustic loop body, one at a time, on the oracle's inputs for that operator (tests/opchain.py):

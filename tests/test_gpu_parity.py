@@ -566,6 +566,17 @@ def test_dynamical_core_two_remapping_steps_matches_reference_run(lib, tmp_path)
     check_dycore(fixes, outs)
 
 
+@pytest.mark.parametrize("variant", ["nord2", "dcon0", "skeb", "dddmp0"])
+def test_d_sw_namelist_variants_match_reference_run(lib, variant):
+    """d_sw with one namelist option changed against runs of the reference with that namelist (tools/make_golden_dsw_variants.py)
+    at the Translate tolerance of D_SW."""
+    from helpers import dsw_variant_fixture, run_d_sw_variant_fixture
+
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, dsw_variant_fixture(variant)[3])
+    errs = run_d_sw_variant_fixture(env, variant)
+    assert max(errs.values()) < 3.2e-10, errs  # translate_d_sw.py:19
+
+
 def test_d_sw_order5_matches_reference_run(lib):
     from helpers import run_d_sw_h5_fixture
 

@@ -270,3 +270,23 @@ def test_d_sw_order5_oracle_matches_reference():
     for k in DSW_ARGS:
         if k != "zh":
             assert compare(fix["out_" + k][dsw_window(k, 12, nk)], a[k][dsw_window(k, 12, nk)]) == 0.0, k
+
+
+@pytest.mark.parametrize("variant", ["nord2", "dcon0", "skeb", "dddmp0"])
+def test_d_sw_namelist_variants_oracle_matches_reference(variant):
+    """The oracle's d_sw against runs of the reference with one namelist option changed (two damping passes instead of three;
+    no dissipative heating; the dissipation estimate kept; no Smagorinsky term): bit for bit."""
+    from helpers import dsw_variant_fixture
+
+    from oracle import dgrid_sw
+
+    fix, cfg, col, nk = dsw_variant_fixture(variant)
+    g = oracle_grid(golden("grid_c12_tile0.npz"), 12, nk)
+    st = dgrid_sw.DSWState(fix["in_u"].shape)
+    st.uc_contra[:] = fix["in_uc_contra"]
+    st.vc_contra[:] = fix["in_vc_contra"]
+    a = {k: fix["in_" + k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(g, col, cfg, st, *[a[k] for k in DSW_ARGS], float(fix["dt"]))
+    for k in DSW_ARGS:
+        if k != "zh":
+            assert compare(fix["out_" + k][dsw_window(k, 12, nk)], a[k][dsw_window(k, 12, nk)]) == 0.0, k

@@ -1,7 +1,13 @@
-"""Generate tests/golden/d_sw_h5_c12_tile0_call1.npz by RUNNING THE REFERENCE's AcousticDynamics (six ranks on threads,
-gtscript executed by tools/gtinterp.py) with the advection orders set to 5 (hord_dp = hord_tm = hord_vt = hord_mt = 5; the
-other fixtures are all order 6), capturing the second d_sw call on tile 0 exactly as tools/make_golden.py does for the
-baseline namelist.  Data only: inputs, outputs, the column namelist the reference derives for this configuration."""
+"""Generate tests/golden/d_sw_<variant>_c12_tile0_call1.npz by RUNNING THE REFERENCE's AcousticDynamics (six ranks on threads,
+gtscript executed by tools/gtinterp.py) with one namelist option changed from the baseline_c12 configuration, capturing the
+second d_sw call on tile 0 exactly as tools/make_golden.py does for the baseline namelist.  Data only: inputs, outputs, the
+column namelist the reference derives for this configuration, the changed options.
+
+    python tools/make_golden_dsw_variants.py h5 | nord2 | dcon0 | skeb | dddmp0
+
+h5: advection orders 5 (the other fixtures are all order 6) . nord2: second-order-lower damping (two divergence-damping passes,
+nord_v / nord_t / nord_w follow) . dcon0: no dissipative heating (d_con = 0) . skeb: do_skeb = True (the dissipation estimate
+is kept) . dddmp0: no Smagorinsky term in the divergence damping (dddmp = 0)."""
 import dataclasses
 import datetime
 import os
@@ -26,14 +32,23 @@ def ksub(a):
     return out
 
 
-def main():
+VARIANTS = {
+    "h5": dict(hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5),
+    "nord2": dict(nord=2),
+    "dcon0": dict(d_con=0.0),
+    "skeb": dict(do_skeb=True),
+    "dddmp0": dict(dddmp=0.0),
+}
+
+
+def main(variant):
     import capture
     import pace.fv3core as fv3core
     import refenv
     from pace.fv3core.stencils import d_sw, fxadv
     from threadcomm import run_ranks
 
-    config = dataclasses.replace(capture.dycore_config(n_split=2, npx=N + 1, npz=NZ), hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5)
+    config = dataclasses.replace(capture.dycore_config(n_split=2, npx=N + 1, npz=NZ), **VARIANTS[variant])
     rec = capture.Recorder(ranks=(0,))
     rec.instrument(d_sw.DGridShallowWaterLagrangianDynamics)
     rec.instrument(fxadv.FiniteVolumeFluxPrep)
@@ -69,9 +84,11 @@ def main():
             data["out_" + k] = ksub(v)
     for k, v in cols.items():
         data["col_" + k] = v
-    np.savez_compressed(os.path.join(GOLDEN, "d_sw_h5_c12_tile0_call1.npz"), **data)
-    print(sorted(data)[:12], len(data))
+    for k, v in VARIANTS[variant].items():
+        data["cfg_" + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(GOLDEN, f"d_sw_{variant}_c12_tile0_call1.npz"), **data)
+    print(variant, sorted(data)[:8], len(data))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "h5")
