@@ -78,6 +78,12 @@ def acoustic_fixture(t):
     extra = golden("acoustic_c12_ucvc.npz")
     for k in ("uc", "vc"):
         fix["out_" + k], fix["col_" + k] = extra[f"out_{k}_tile{t}"], extra[f"col_{k}_tile{t}"]
+    # tiles 0 (equatorial) and 2 (polar) also have their FULL output fields: every level of the compute window + the
+    # staggered row / column (acoustic_c12_full.npz, a later addition)
+    full = golden("acoustic_c12_full.npz")
+    if t in full["tiles"]:
+        for k in ACOUSTIC_OUT:
+            fix["full_" + k] = full[f"out_{k}_tile{t}"]
     return fix
 
 
@@ -154,6 +160,8 @@ def acoustic_errors(fix, out, n=12):
         nk = 80 if k in ("pe", "pk", "peln") else 79
         cols = np.stack([full[i, j, :nk] for (i, j) in fix["cols"]])
         e = max(e, compare(fix["col_" + k][:, :nk], cols, near_zero=near_zero))
+        if "full_" + k in fix:  # the whole field, all levels
+            e = max(e, compare(fix["full_" + k][: n + di, : n + dj, :nk], full[3 : 3 + n + di, 3 : 3 + n + dj, :nk], near_zero=near_zero))
         errs[k] = e
     return errs
 

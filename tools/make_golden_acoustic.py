@@ -24,6 +24,7 @@ STATE_OUT = "u v w delz delp pt pe pk peln q_con omga ua va mfxd mfyd cxd cyd di
 # what d_sw leaves in its work fields uc / vc (compared by TranslateDynCore, translate_dyncore.py:84-85): kept in a separate,
 # later-added file (acoustic_c12_ucvc.npz) so that the six per-tile fixtures stay byte-identical
 EXTRA_OUT = ["uc", "vc"]
+FULL_TILES = [0, 2]
 
 
 def main():
@@ -71,6 +72,7 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     extra = {"k_sel": np.array(K_SEL), "cols": np.array(COLS)}
     for t, (grid, before, after, timestep) in enumerate(out):
+        after = dict(after)
         for k in EXTRA_OUT:
             v = after.pop(k)
             extra[f"out_{k}_tile{t}"] = np.ascontiguousarray(v[3 : 3 + N + 1, 3 : 3 + N + 1][:, :, K_SEL])
@@ -97,6 +99,14 @@ def main():
         data["timestep"], data["n_split"] = timestep, N_SPLIT
         np.savez_compressed(os.path.join(GOLDEN, f"acoustic_c12_tile{t}.npz"), **data)
     np.savez_compressed(os.path.join(GOLDEN, "acoustic_c12_ucvc.npz"), **extra)
+    # FULL output fields (every level of the compute window + the staggered row / column) for an equatorial and a polar tile:
+    # the per-tile fixtures above hold a level subset and four columns only
+    full = {}
+    for t in FULL_TILES:
+        after = dict(out[t][2])
+        for k, v in after.items():
+            full[f"out_{k}_tile{t}"] = np.ascontiguousarray(v[3 : 3 + N + 1, 3 : 3 + N + 1, :])
+    np.savez_compressed(os.path.join(GOLDEN, "acoustic_c12_full.npz"), tiles=np.array(FULL_TILES), **full)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)) // 1024, "KB")
 
