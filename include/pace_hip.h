@@ -85,15 +85,16 @@ typedef struct {
 
 /* ---- FiniteVolumeFluxPrep.__call__ (fv3core/pace/fv3core/stencils/fxadv.py:565-661) ---- */
 int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* uc, const pace_real_t* vc,
-               pace_real_t* crx, pace_real_t* cry, pace_real_t* x_area_flux, pace_real_t* y_area_flux, pace_real_t* uc_contra,
-               pace_real_t* vc_contra, double dt, void* stream);
+               pace_real_t* crx, pace_real_t* cry, pace_real_t* x_area_flux, pace_real_t* y_area_flux,
+               pace_real_t* uc_contra, pace_real_t* vc_contra, double dt, void* stream);
 
 /* ---- XPiecewiseParabolic / YPiecewiseParabolic.__call__ (fv3core/pace/fv3core/stencils/xppm.py:290-355, yppm.py:290-355):
  * mean value of q_in advected through the x- (axis 0) or y- (axis 1) interfaces of the window origin (i0, j0, k0), domain
  * (ni, nj, nk) -- the origin / domain the reference class is constructed with.  iord in {5, 6, 8} (the sign is ignored, as
  * `mord = abs(iord)`).  Corner halos of q_in are the caller's business, as in the reference. */
-int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const pace_real_t* q_in, const pace_real_t* c,
-             pace_real_t* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk, void* stream);
+int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int iord, const pace_real_t* q_in,
+             const pace_real_t* c, pace_real_t* q_mean_advected, int i0, int j0, int k0, int ni, int nj, int nk,
+             void* stream);
 
 /* ---- DivergenceDamping.__call__ (fv3core/pace/fv3core/stencils/divergence_damping.py:482-632).  workspace: two fields
  * (pace_divergence_damping_workspace_bytes).  nord_col: HOST array of nk values (the class's nord_col K-field; the column is
@@ -101,47 +102,49 @@ int pace_ppm(const pace_geom_t* geom, const pace_metrics_t* met, int axis, int i
  * reference: divg_d, uc, vc are work fields and end as the last iteration leaves them, delpc and damped_rel_vort_bgrid are
  * outputs, ke += damping. */
 int64_t pace_divergence_damping_workspace_bytes(const pace_geom_t* geom);
-int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_real_t* u, const pace_real_t* v,
-                            const pace_real_t* va, pace_real_t* damped_rel_vort_bgrid, const pace_real_t* ua, pace_real_t* divg_d, pace_real_t* vc,
-                            pace_real_t* uc, pace_real_t* delpc, pace_real_t* ke, const pace_real_t* rel_vort_agrid, double dt,
-                            const double* nord_col_host, const pace_real_t* d2_bg_dev, double dddmp, double d4_bg, int nord,
-                            void* stream);
+int pace_divergence_damping(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_real_t* u,
+                            const pace_real_t* v, const pace_real_t* va, pace_real_t* damped_rel_vort_bgrid,
+                            const pace_real_t* ua, pace_real_t* divg_d, pace_real_t* vc, pace_real_t* uc,
+                            pace_real_t* delpc, pace_real_t* ke, const pace_real_t* rel_vort_agrid, double dt,
+                            const double* nord_col_host, const pace_real_t* d2_bg_dev, double dddmp, double d4_bg,
+                            int nord, void* stream);
 
 /* ---- FiniteVolumeTransport.__call__ without damping (fvtp2d.py:262-345).  x/y_mass_flux may be
  * NULL (area fluxes are used as unit fluxes).  hord in {5, 6, 8}.  nlev = number of levels
  * processed (nk, or nk+1 for interface fields).  q's corner halos are NOT rewritten: corner reads
  * go through the copy_corners index map, which yields identical fluxes. */
 int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, const pace_real_t* crx,
-                const pace_real_t* cry, const pace_real_t* x_area_flux, const pace_real_t* y_area_flux, pace_real_t* q_x_flux,
-                pace_real_t* q_y_flux, const pace_real_t* x_mass_flux, const pace_real_t* y_mass_flux, int hord, int nlev,
-                void* stream);
+                const pace_real_t* cry, const pace_real_t* x_area_flux, const pace_real_t* y_area_flux,
+                pace_real_t* q_x_flux, pace_real_t* q_y_flux, const pace_real_t* x_mass_flux,
+                const pace_real_t* y_mass_flux, int hord, int nlev, void* stream);
 
 /* ---- The fused form d_sw uses for q_con and pt (d_sw.py:1075-1117): FiniteVolumeTransport with mass fluxes AND its
  * DelnFlux(mass = delp) (fvtp2d.py:262-345), followed by apply_fluxes (d_sw.py:122-145):
  *   qout = q * delp + flux_increment(q_x_flux, q_y_flux) * rarea      on the compute domain,
  * in ONE kernel; the flux fields never reach memory.  damp_k / nord_k as for pace_delnflux.  qout must not alias q. */
-int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, const pace_real_t* crx,
-                       const pace_real_t* cry, const pace_real_t* x_area_flux, const pace_real_t* y_area_flux,
-                       const pace_real_t* x_mass_flux, const pace_real_t* y_mass_flux, const pace_real_t* delp, const pace_real_t* damp_k,
-                       const pace_real_t* nord_k, int nmax, pace_real_t* qout, int hord, int nlev, void* stream);
+int pace_fvtp2d_update(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q,
+                       const pace_real_t* crx, const pace_real_t* cry, const pace_real_t* x_area_flux,
+                       const pace_real_t* y_area_flux, const pace_real_t* x_mass_flux, const pace_real_t* y_mass_flux,
+                       const pace_real_t* delp, const pace_real_t* damp_k, const pace_real_t* nord_k, int nmax,
+                       pace_real_t* qout, int hord, int nlev, void* stream);
 
 /* ---- DelnFluxNoSG.__call__ (delnflux.py:1050-1261): damping fluxes fx2, fy2 of q.
  * nord_k, damp_k: DEVICE arrays, one entry per level (see DESIGN.md for how the reference's
  * nord0..nord3 externals map to per-level values).  If mass_given != 0, d2 starts from q
  * (copy_stencil_interval) instead of damp*q.  nmax = max(nord_k). */
 int pace_delnflux_nosg(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, pace_real_t* fx2,
-                       pace_real_t* fy2, const pace_real_t* damp_k, const pace_real_t* nord_k, int nmax, int mass_given,
-                       int nlev, void* stream);
+                       pace_real_t* fy2, const pace_real_t* damp_k, const pace_real_t* nord_k, int nmax,
+                       int mass_given, int nlev, void* stream);
 
 /* ---- DelnFlux.__call__ (delnflux.py:945-1047): fx, fy += damping flux (mass-weighted if
  * mass != NULL).  damp_k = (damp_c*da_min)^(nord+1) per level (calc_damp, delnflux.py:21-38). */
-int pace_delnflux(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, pace_real_t* fx, pace_real_t* fy,
-                  const pace_real_t* mass, const pace_real_t* damp_k, const pace_real_t* nord_k, int nmax, int nlev,
-                  void* stream);
+int pace_delnflux(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, pace_real_t* fx,
+                  pace_real_t* fy, const pace_real_t* mass, const pace_real_t* damp_k, const pace_real_t* nord_k,
+                  int nmax, int nlev, void* stream);
 
 /* ---- AGrid2BGridFourthOrder.__call__ (a2b_ord4.py:668-761) on levels [k0, k1). ---- */
-int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* qin, pace_real_t* qout, int k0, int k1,
-                  int replace, void* stream);
+int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* qin, pace_real_t* qout, int k0,
+                  int k1, int replace, void* stream);
 
 /* ---- DGridShallowWaterLagrangianDynamics.__call__ (d_sw.py:935-1237).
  * workspace: DEVICE scratch of pace_d_sw_workspace_bytes() bytes, owned by the caller for the
@@ -151,27 +154,32 @@ int64_t pace_d_sw_workspace_bytes(const pace_geom_t* geom);
 /* Once per object, after zero-filling the workspace: uploads the column namelist (synchronises). */
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream);
 int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-              const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt, pace_real_t* u,
-              pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
-              pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry, pace_real_t* xfx, pace_real_t* yfx,
-              pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt, void* stream);
+              const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt,
+              pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua,
+              const pace_real_t* va, pace_real_t* divgd, pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx,
+              pace_real_t* cy, pace_real_t* crx, pace_real_t* cry, pace_real_t* xfx, pace_real_t* yfx,
+              pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt,
+              void* stream);
 
 /* The two halves of pace_d_sw, same arguments.  pace_d_sw_transport: flux preparation and the transport of delp, w,
  * q_con, pt (d_sw.py:935-1117) -- everything updatedzd / riem_solver3 read.  pace_d_sw_winds: the rest
  * (d_sw.py:1119-1237); it reads only what the first half left behind, so it may be launched on a second stream
  * and run concurrently with the vertical solver.  pace_d_sw == transport followed by winds on one stream. */
 int pace_d_sw_transport(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-                        const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt,
-                        pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va,
-                        pace_real_t* divgd, pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry,
-                        pace_real_t* xfx, pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source,
-                        pace_real_t* diss_est, double dt, void* stream);
+                        const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp,
+                        pace_real_t* pt, pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc,
+                        pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
+                        pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx,
+                        pace_real_t* cry, pace_real_t* xfx, pace_real_t* yfx, pace_real_t* q_con,
+                        const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt,
+                        void* stream);
 int pace_d_sw_winds(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-                    const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt, pace_real_t* u,
-                    pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
-                    pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry, pace_real_t* xfx,
-                    pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt,
-                    void* stream);
+                    const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp,
+                    pace_real_t* pt, pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc,
+                    const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd, pace_real_t* mfx,
+                    pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry,
+                    pace_real_t* xfx, pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh,
+                    pace_real_t* heat_source, pace_real_t* diss_est, double dt, void* stream);
 
 /* Finer split for callers that overlap on two streams (same arguments after `phases`).  Bit mask: 1 = flux preparation
  * (fxadv), 2 = transport of delp, w, q_con, pt, 4 = winds A (kinetic energy ... vorticity damping fluxes), 8 = winds B
@@ -181,59 +189,66 @@ int pace_d_sw_winds(const pace_geom_t* geom, const pace_metrics_t* met, const pa
  * exchange is in flight (dyn_core.py:817-820) --, 32 = the rest of it, after the exchange.  Instead of 4: 64 = kinetic energy and
  * relative vorticity (they need only the flux preparation), 128 = the rest of winds A. */
 int pace_d_sw_phases(int phases, const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
-                     const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp, pace_real_t* pt, pace_real_t* u,
-                     pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
-                     pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx, pace_real_t* cry, pace_real_t* xfx,
-                     pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh, pace_real_t* heat_source, pace_real_t* diss_est, double dt,
-                     void* stream);
+                     const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp,
+                     pace_real_t* pt, pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc,
+                     pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
+                     pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx,
+                     pace_real_t* cry, pace_real_t* xfx, pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh,
+                     pace_real_t* heat_source, pace_real_t* diss_est, double dt, void* stream);
 
 /* ---- NonhydrostaticVerticalSolver.__call__ (riem_solver3.py:208-321), compute domain.
  * zs, ws: 2-D.  workspace: pace_riem_solver3_workspace_bytes() bytes of DEVICE scratch. */
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom);
 int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, double dt, const pace_real_t* cappa,
-                      double ptop, const pace_real_t* zs, const pace_real_t* ws, pace_real_t* delz, const pace_real_t* q_con,
-                      const pace_real_t* delp, const pace_real_t* pt, pace_real_t* zh, pace_real_t* pe, pace_real_t* ppe, pace_real_t* pk3,
-                      pace_real_t* pk, pace_real_t* peln, pace_real_t* w, double p_fac, void* stream);
+                      double ptop, const pace_real_t* zs, const pace_real_t* ws, pace_real_t* delz,
+                      const pace_real_t* q_con, const pace_real_t* delp, const pace_real_t* pt, pace_real_t* zh,
+                      pace_real_t* pe, pace_real_t* ppe, pace_real_t* pk3, pace_real_t* pk, pace_real_t* peln,
+                      pace_real_t* w, double p_fac, void* stream);
 
 /* ---- CGridShallowWaterDynamics.__call__ (fv3core/pace/fv3core/stencils/c_sw.py:599-766), including
  * DGrid2AGrid2CGridVectors (d2a2c_vect.py:529-655).  delpc / ptc are the class attributes the reference
  * exposes (c_sw.py:497-502, read by dyn_core.py:795-800).  workspace: pace_c_sw_workspace_bytes(). */
 int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom);
-int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* delpc, pace_real_t* ptc,
-              const pace_real_t* delp, const pace_real_t* pt, const pace_real_t* u, const pace_real_t* v, const pace_real_t* w, pace_real_t* uc,
-              pace_real_t* vc, pace_real_t* ua, pace_real_t* va, pace_real_t* ut, pace_real_t* vt, pace_real_t* divgd, pace_real_t* omga, double dt2,
+int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* delpc,
+              pace_real_t* ptc, const pace_real_t* delp, const pace_real_t* pt, const pace_real_t* u,
+              const pace_real_t* v, const pace_real_t* w, pace_real_t* uc, pace_real_t* vc, pace_real_t* ua,
+              pace_real_t* va, pace_real_t* ut, pace_real_t* vt, pace_real_t* divgd, pace_real_t* omga, double dt2,
               int nord, void* stream);
 /* The same in two parts around the u / v halo exchange in front of c_sw (dyn_core.py:744-745; an extension for overlapping
  * that exchange with compute): part 1 = the points of its first pass that read no halo value of u / v (the box
  * [is+1, ie-1] x [js+1, je-1]); part 2 = everything else, after the exchange; part 0 = pace_c_sw.  Same arguments. */
-int pace_c_sw_part(int part, const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* delpc, pace_real_t* ptc,
-                   const pace_real_t* delp, const pace_real_t* pt, const pace_real_t* u, const pace_real_t* v, const pace_real_t* w,
-                   pace_real_t* uc, pace_real_t* vc, pace_real_t* ua, pace_real_t* va, pace_real_t* ut, pace_real_t* vt,
-                   pace_real_t* divgd, pace_real_t* omga, double dt2, int nord, void* stream);
+int pace_c_sw_part(int part, const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* delpc,
+                   pace_real_t* ptc, const pace_real_t* delp, const pace_real_t* pt, const pace_real_t* u,
+                   const pace_real_t* v, const pace_real_t* w, pace_real_t* uc, pace_real_t* vc, pace_real_t* ua,
+                   pace_real_t* va, pace_real_t* ut, pace_real_t* vt, pace_real_t* divgd, pace_real_t* omga,
+                   double dt2, int nord, void* stream);
 /* ---- DGrid2AGrid2CGridVectors.__call__ alone (d2a2c_vect.py:529-655), dord4 = True; same workspace. */
-int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* uc, pace_real_t* vc,
-                    const pace_real_t* u, const pace_real_t* v, pace_real_t* ua, pace_real_t* va, pace_real_t* utc, pace_real_t* vtc, void* stream);
+int pace_d2a2c_vect(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* uc,
+                    pace_real_t* vc, const pace_real_t* u, const pace_real_t* v, pace_real_t* ua, pace_real_t* va,
+                    pace_real_t* utc, pace_real_t* vtc, void* stream);
 
 /* ---- Sim1Solver.__call__ (sim1_solver.py:144-219) as a class of its own: the semi-implicit vertical solver on the compute
  * domain widened by n_halo (the reference builds it with n_halo = 0 for riem_solver3 and 1 for riem_solver_c).  gamma, cp3,
  * delta_mass, pm, pem, potential_temperature in; pe out (nk + 1 interfaces); w, dz inout; ws 2-D.  workspace:
  * pace_sim1_solver_workspace_bytes.  Inside pace_riem_solver3 / pace_riem_solver_c the same arithmetic runs fused. */
 int64_t pace_sim1_solver_workspace_bytes(const pace_geom_t* geom);
-int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac, const pace_real_t* gamma,
-                     const pace_real_t* cp3, pace_real_t* pe, const pace_real_t* delta_mass, const pace_real_t* pm, const pace_real_t* pem, pace_real_t* w,
-                     pace_real_t* dz, const pace_real_t* potential_temperature, const pace_real_t* ws, void* stream);
+int pace_sim1_solver(const pace_geom_t* geom, void* workspace, int n_halo, double dt, double p_fac,
+                     const pace_real_t* gamma, const pace_real_t* cp3, pace_real_t* pe, const pace_real_t* delta_mass,
+                     const pace_real_t* pm, const pace_real_t* pem, pace_real_t* w, pace_real_t* dz,
+                     const pace_real_t* potential_temperature, const pace_real_t* ws, void* stream);
 
 /* ---- NonhydrostaticVerticalSolverCGrid.__call__ (riem_solver_c.py:160-250), compute domain +- 1. */
 int64_t pace_riem_solver_c_workspace_bytes(const pace_geom_t* geom);
 int pace_riem_solver_c(const pace_geom_t* geom, void* workspace, double dt2, const pace_real_t* cappa, double ptop,
                        const pace_real_t* hs, const pace_real_t* ws, const pace_real_t* ptc, const pace_real_t* q_con,
-                       const pace_real_t* delpc, pace_real_t* gz, pace_real_t* pef, const pace_real_t* w3, double p_fac, void* stream);
+                       const pace_real_t* delpc, pace_real_t* gz, pace_real_t* pef, const pace_real_t* w3,
+                       double p_fac, void* stream);
 
 /* ---- UpdateGeopotentialHeightOnCGrid.__call__ (updatedzc.py:172-207).  dp_ref: DEVICE K-array (nk). */
 int64_t pace_updatedzc_workspace_bytes(const pace_geom_t* geom);
 int pace_updatedzc(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_real_t* dp_ref,
-                   const pace_real_t* zs, const pace_real_t* ut, const pace_real_t* vt, pace_real_t* gz, pace_real_t* ws, double dt,
-                   void* stream);
+                   const pace_real_t* zs, const pace_real_t* ut, const pace_real_t* vt, pace_real_t* gz,
+                   pace_real_t* ws, double dt, void* stream);
 
 /* ---- UpdateHeightOnDGrid.__call__ (updatedzd.py:281-356).  K-dependent constants: gk/beta/gamma from
  * cubic_spline_interpolation_constants (updatedzd.py:129-154) as DEVICE arrays of nk, the four scalars the
@@ -248,56 +263,59 @@ typedef struct {
 int64_t pace_updatedzd_workspace_bytes(const pace_geom_t* geom);
 int pace_updatedzd(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, const pace_updatedzd_k_t* kc,
                    const pace_real_t* surface_height, pace_real_t* height, const pace_real_t* courant_number_x,
-                   const pace_real_t* courant_number_y, const pace_real_t* x_area_flux, const pace_real_t* y_area_flux, pace_real_t* ws,
-                   double dt, int hord_tm, void* stream);
+                   const pace_real_t* courant_number_y, const pace_real_t* x_area_flux,
+                   const pace_real_t* y_area_flux, pace_real_t* ws, double dt, int hord_tm, void* stream);
 
 /* ---- dyn_core.py stencils: gz_from_surface_height_and_thicknesses (:83-96, compute domain),
  * compute_geopotential (:115-117, halo 2, nk+1 levels), basic.copy_defn as used at dyn_core.py:773-781
  * (full domain, nk+1 levels), p_grad_c_stencil (:120-171, hydrostatic = False). */
-int pace_zero_data(const pace_geom_t* geom, pace_real_t* mfxd, pace_real_t* mfyd, pace_real_t* cxd, pace_real_t* cyd, pace_real_t* heat_source,
-                   pace_real_t* diss_estd, int first_timestep, void* stream);                           /* dyn_core.py:51-80 */
-int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const pace_real_t* delp, pace_real_t* pem,
-                                                            double ptop, void* stream);              /* :99-112 */
-int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const pace_real_t* zs, const pace_real_t* delz,
-                                                pace_real_t* gz, void* stream);
+int pace_zero_data(const pace_geom_t* geom, pace_real_t* mfxd, pace_real_t* mfyd, pace_real_t* cxd, pace_real_t* cyd,
+                   pace_real_t* heat_source, pace_real_t* diss_estd, int first_timestep, void* stream);  /* dyn_core.py:51-80 */
+int pace_interface_pressure_from_toa_pressure_and_thickness(const pace_geom_t* geom, const pace_real_t* delp,
+                                                            pace_real_t* pem, double ptop, void* stream);  /* :99-112 */
+int pace_gz_from_surface_height_and_thicknesses(const pace_geom_t* geom, const pace_real_t* zs,
+                                                const pace_real_t* delz, pace_real_t* gz, void* stream);
 int pace_compute_geopotential(const pace_geom_t* geom, const pace_real_t* zh, pace_real_t* gz, void* stream);
 int pace_copy(const pace_geom_t* geom, const pace_real_t* src, pace_real_t* dst, void* stream);
-int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* uc, pace_real_t* vc, const pace_real_t* delpc,
-                  const pace_real_t* pkc, const pace_real_t* gz, double dt2, void* stream);
+int pace_p_grad_c(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* uc, pace_real_t* vc,
+                  const pace_real_t* delpc, const pace_real_t* pkc, const pace_real_t* gz, double dt2, void* stream);
 
 /* ---- NonHydrostaticPressureGradient.__call__ (nh_p_grad.py:187-255). */
 int64_t pace_nh_p_grad_workspace_bytes(const pace_geom_t* geom);
-int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* u, pace_real_t* v,
-                   pace_real_t* pp, pace_real_t* gz, pace_real_t* pk3, pace_real_t* delp, double dt, double ptop, double akap,
-                   void* stream);
+int pace_nh_p_grad(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* u,
+                   pace_real_t* v, pace_real_t* pp, pace_real_t* gz, pace_real_t* pk3, pace_real_t* delp, double dt,
+                   double ptop, double akap, void* stream);
 
 /* ---- pe_halo.edge_pe (pe_halo.py:6-34) and PK3Halo.__call__ (pk3_halo.py:55-69). */
 int pace_edge_pe(const pace_geom_t* geom, pace_real_t* pe, const pace_real_t* delp, double ptop, void* stream);
-int pace_pk3_halo(const pace_geom_t* geom, pace_real_t* pk3, const pace_real_t* delp, double ptop, double akap, void* stream);
+int pace_pk3_halo(const pace_geom_t* geom, pace_real_t* pk3, const pace_real_t* delp, double ptop, double akap,
+                  void* stream);
 
 /* ---- RayleighDamping.__call__ (ray_fast.py:186-206).  dp, pfull: HOST K-arrays (nk). */
-int pace_ray_fast(const pace_geom_t* geom, pace_real_t* u, pace_real_t* v, pace_real_t* w, const double* dp, const double* pfull,
-                  double dt, double ptop, double rf_cutoff, double tau, int hydrostatic, void* stream);
+int pace_ray_fast(const pace_geom_t* geom, pace_real_t* u, pace_real_t* v, pace_real_t* w, const double* dp,
+                  const double* pfull, double dt, double ptop, double rf_cutoff, double tau, int hydrostatic,
+                  void* stream);
 
 /* ---- HyperdiffusionDamping.__call__ (del2cubed.py:168-194) and apply_diffusive_heating
  * (temperature_adjust.py:8-43, first nlev levels of the compute domain). */
 int64_t pace_del2cubed_workspace_bytes(const pace_geom_t* geom);
 int pace_del2cubed(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* qdel, double cd,
                    int nmax, void* stream);
-int pace_apply_diffusive_heating(const pace_geom_t* geom, const pace_real_t* delp, const pace_real_t* delz, const pace_real_t* cappa,
-                                 const pace_real_t* heat_source, pace_real_t* pt, double delt_time_factor, int nlev,
-                                 void* stream);
+int pace_apply_diffusive_heating(const pace_geom_t* geom, const pace_real_t* delp, const pace_real_t* delz,
+                                 const pace_real_t* cappa, const pace_real_t* heat_source, pace_real_t* pt,
+                                 double delt_time_factor, int nlev, void* stream);
 
 /* ---- TracerAdvection (Fortran tracer_2d_1l): the stencils around FiniteVolumeTransport(hord = 8) in
  * fv3core/pace/fv3core/stencils/tracer_2d_1l.py -- flux_compute (:19-77), divide_fluxes_by_n_substeps (:80-106),
  * apply_mass_flux (:115-135), apply_tracer_flux (:138-158), swap_dp (:166-170).  The transport itself is pace_fvtp2d
  * with hord = 8 (monotone PPM, xppm.py:76-145,185-287). */
-int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* cx, const pace_real_t* cy,
-                             pace_real_t* xfx, pace_real_t* yfx, void* stream);
-int pace_tracer_divide_fluxes(const pace_geom_t* geom, pace_real_t* cxd, pace_real_t* xfx, pace_real_t* mfxd, pace_real_t* cyd, pace_real_t* yfx,
-                              pace_real_t* mfyd, int n_split, void* stream);
-int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* dp1, const pace_real_t* x_mass_flux,
-                         const pace_real_t* y_mass_flux, pace_real_t* dp2, void* stream);
+int pace_tracer_flux_compute(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* cx,
+                             const pace_real_t* cy, pace_real_t* xfx, pace_real_t* yfx, void* stream);
+int pace_tracer_divide_fluxes(const pace_geom_t* geom, pace_real_t* cxd, pace_real_t* xfx, pace_real_t* mfxd,
+                              pace_real_t* cyd, pace_real_t* yfx, pace_real_t* mfyd, int n_split, void* stream);
+int pace_apply_mass_flux(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* dp1,
+                         const pace_real_t* x_mass_flux, const pace_real_t* y_mass_flux, pace_real_t* dp2,
+                         void* stream);
 int pace_apply_tracer_flux(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_t* q, const pace_real_t* dp1,
                            const pace_real_t* fx, const pace_real_t* fy, const pace_real_t* dp2, void* stream);
 int pace_swap_dp(const pace_geom_t* geom, pace_real_t* dp1, pace_real_t* dp2, void* stream);
@@ -310,15 +328,16 @@ int pace_swap_dp(const pace_geom_t* geom, pace_real_t* dp1, pace_real_t* dp2, vo
  * xstag / ystag: the field is staggered in x / y and owns one more column / row (`dims` of the reference's constructor).
  * workspace: pace_map_single_workspace_bytes() of device memory (5 fields; the reference keeps 14). */
 int64_t pace_map_single_workspace_bytes(const pace_geom_t* geom);
-int pace_map_single(const pace_geom_t* geom, void* workspace, pace_real_t* q1, const pace_real_t* pe1, const pace_real_t* pe2,
-                    const pace_real_t* qs, double qmin, int kord, int iv, int xstag, int ystag, void* stream);
+int pace_map_single(const pace_geom_t* geom, void* workspace, pace_real_t* q1, const pace_real_t* pe1,
+                    const pace_real_t* pe2, const pace_real_t* qs, double qmin, int kord, int iv, int xstag,
+                    int ystag, void* stream);
 
 /* MapNTracer (Fortran mapn_tracer): fv3core/pace/fv3core/stencils/mapn_tracer.py:13-82 -- nq (<= 16) tracers that share
  * pe1 / pe2 are remapped (iv = 0, one kord) by ONE three-launch sequence instead of nq MapSingle calls.  tracers is a
  * HOST array of nq device pointers.  workspace: pace_mapn_tracer_workspace_bytes(geom, nq). */
 int64_t pace_mapn_tracer_workspace_bytes(const pace_geom_t* geom, int nq);
-int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, pace_real_t* const* tracers, int nq, const pace_real_t* pe1,
-                     const pace_real_t* pe2, int kord, void* stream);
+int pace_mapn_tracer(const pace_geom_t* geom, void* workspace, pace_real_t* const* tracers, int nq,
+                     const pace_real_t* pe1, const pace_real_t* pe2, int kord, void* stream);
 
 /* FillNegativeTracerValues (Fortran fillz): fv3core/pace/fv3core/stencils/fillz.py:120-163 -- negative tracer masses
  * borrow from the layers above / below, then the column is rescaled; all nq tracers in one launch.  tracers: HOST array
@@ -334,17 +353,19 @@ int pace_fillz(const pace_geom_t* geom, pace_real_t* const* tracers, int nq, con
  *   pace_l2e_pressures = pressures_mapu (dir 0, :196-227) / pressures_mapv (dir 1, :230-254)
  *   pace_l2e_finish    = update_ua + copy_from_below (:257-283), then moist_pt_last_step (moist_cv.py:84-122, last_step
  *                        != 0) or adjust_divide_stencil (pt / pkz) */
-int pace_l2e_prepare(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pt, pace_real_t* cappa, pace_real_t* delp,
-                     pace_real_t* delz, const pace_real_t* pe, pace_real_t* pe1, pace_real_t* pe2, const pace_real_t* ak, const pace_real_t* bk, pace_real_t* dp2,
-                     pace_real_t* ps, pace_real_t* pn2, const pace_real_t* peln, pace_real_t* pk, double ptop, double akap, double r_vir,
-                     void* stream);
-int pace_l2e_post(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pkz, const pace_real_t* pt,
-                  pace_real_t* cappa, const pace_real_t* delp, pace_real_t* delz, pace_real_t* peln, pace_real_t* pe0, const pace_real_t* pn2, double r_vir,
-                  void* stream);
-int pace_l2e_pressures(const pace_geom_t* geom, int dir, const pace_real_t* pe, const pace_real_t* pe1, const pace_real_t* ak,
-                       const pace_real_t* bk, pace_real_t* pe0, pace_real_t* pe3, void* stream);
-int pace_l2e_finish(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* pe, const pace_real_t* pe2, pace_real_t* pt,
-                    const pace_real_t* pkz, double r_vir, int last_step, void* stream);
+int pace_l2e_prepare(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pt,
+                     pace_real_t* cappa, pace_real_t* delp, pace_real_t* delz, const pace_real_t* pe,
+                     pace_real_t* pe1, pace_real_t* pe2, const pace_real_t* ak, const pace_real_t* bk,
+                     pace_real_t* dp2, pace_real_t* ps, pace_real_t* pn2, const pace_real_t* peln, pace_real_t* pk,
+                     double ptop, double akap, double r_vir, void* stream);
+int pace_l2e_post(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pkz,
+                  const pace_real_t* pt, pace_real_t* cappa, const pace_real_t* delp, pace_real_t* delz,
+                  pace_real_t* peln, pace_real_t* pe0, const pace_real_t* pn2, double r_vir, void* stream);
+int pace_l2e_pressures(const pace_geom_t* geom, int dir, const pace_real_t* pe, const pace_real_t* pe1,
+                       const pace_real_t* ak, const pace_real_t* bk, pace_real_t* pe0, pace_real_t* pe3,
+                       void* stream);
+int pace_l2e_finish(const pace_geom_t* geom, const pace_real_t* const* water, pace_real_t* pe, const pace_real_t* pe2,
+                    pace_real_t* pt, const pace_real_t* pkz, double r_vir, int last_step, void* stream);
 
 /* ---- DynamicalCore (fv3core/pace/fv3core/stencils/fv_dynamics.py:92-624): the stencils it runs itself.  water: HOST
  * array of the six device pointers qvapor, qliquid, qrain, qsnow, qice, qgraupel.
@@ -355,21 +376,24 @@ int pace_l2e_finish(const pace_geom_t* geom, const pace_real_t* const* water, pa
  *                       non-hydrostatic: fix_neg_water, fillq(qgraupel), fillq(qrain), fix_water_vapor_down, fix_neg_cloud
  *   pace_c2l_ord      = CubedToLatLon's stencil (stencils/pace/stencils/c2l_ord.py:15-112), order 2 or 4 (order 4 expects
  *                       the halos of u, v updated); a11..a22: 2-D metric fields */
-int pace_fv_setup_pt(const pace_geom_t* geom, pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pkz, pace_real_t* pt, pace_real_t* cappa,
-                     const pace_real_t* delp, const pace_real_t* delz, pace_real_t* dp1, void* stream);
-int pace_omega_from_w(const pace_geom_t* geom, const pace_real_t* delp, const pace_real_t* delz, const pace_real_t* w, pace_real_t* omga,
-                      void* stream);
-int pace_neg_adj3(const pace_geom_t* geom, pace_real_t* const* water, pace_real_t* qcld, pace_real_t* pt, const pace_real_t* delp, void* stream);
-int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const pace_real_t* u, const pace_real_t* v,
-                 const pace_real_t* a11, const pace_real_t* a12, const pace_real_t* a21, const pace_real_t* a22, pace_real_t* ua, pace_real_t* va,
-                 void* stream);
+int pace_fv_setup_pt(const pace_geom_t* geom, pace_real_t* const* water, pace_real_t* q_con, pace_real_t* pkz,
+                     pace_real_t* pt, pace_real_t* cappa, const pace_real_t* delp, const pace_real_t* delz,
+                     pace_real_t* dp1, void* stream);
+int pace_omega_from_w(const pace_geom_t* geom, const pace_real_t* delp, const pace_real_t* delz, const pace_real_t* w,
+                      pace_real_t* omga, void* stream);
+int pace_neg_adj3(const pace_geom_t* geom, pace_real_t* const* water, pace_real_t* qcld, pace_real_t* pt,
+                  const pace_real_t* delp, void* stream);
+int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, const pace_real_t* u,
+                 const pace_real_t* v, const pace_real_t* a11, const pace_real_t* a12, const pace_real_t* a21,
+                 const pace_real_t* a22, pace_real_t* ua, pace_real_t* va, void* stream);
 
 /* EXPERIMENTAL, not used by the host classes: the wave-private (barrier-free, LDS-free) formulation of the plain ord-6
  * transport of pace_fvtp2d for the box of cells [ib, ib+nx) x [jb, jb+ny) whose stencils stay 3+ cells inside the tile
  * (PACE_ERR_ARG otherwise).  Writes fx, fy on the box only.  See pace_amd/csrc/k_march.hip and DESIGN.md section 8. */
-int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q, const pace_real_t* crx,
-                            const pace_real_t* cry, const pace_real_t* xfx, const pace_real_t* yfx, pace_real_t* fx, pace_real_t* fy, int ib, int nx, int jb,
-                            int ny, int nlev, void* stream);
+int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q,
+                            const pace_real_t* crx, const pace_real_t* cry, const pace_real_t* xfx,
+                            const pace_real_t* yfx, pace_real_t* fx, pace_real_t* fy, int ib, int nx, int jb, int ny,
+                            int nlev, void* stream);
 
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation
