@@ -182,8 +182,22 @@ def run_tiles(n, fn):
     """Run ``fn(comm)`` for n tiles on n threads of this process; returns their results in tile order."""
     world = _World(n)
     results, errors = [None] * n, []
+    # the current device is a per-thread setting: hand the caller's on to the tile threads (a rank of a multi-GPU run owns
+    # device LOCAL_RANK, and a new thread would start on device 0).  Nothing here initialises the GPU.
+    device = None
+    try:
+        import torch
+
+        if torch.cuda.is_initialized():
+            device = torch.cuda.current_device()
+    except Exception:  # noqa: BLE001
+        device = None
 
     def target(r):
+        if device is not None:
+            import torch
+
+            torch.cuda.set_device(device)
         with world.cond:  # the run token (see _World)
             try:
                 results[r] = fn(ThreadComm(world, r))
