@@ -23,6 +23,10 @@ import numpy as np  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 K_SEL = [0, 1, 2, 3, 4, 40, 77, 78, 79]
+# FULL output fields of the state variables below for an equatorial and a polar tile (dycore_c12_full.npz, a later addition: the
+# per-tile fixtures hold a level subset and four columns)
+FULL_TILES = [0, 2]
+FULL_VARS = "u v w delz delp pt qvapor qliquid qice".split()
 COLS = [(3, 3), (8, 9), (14, 14), (3, 14)]
 N, NZ = 12, 79
 # default: n_split = 2, k_split = 1 -> dycore_c12_tile*.npz; "python make_golden_dycore.py 1 2" -> n_split = 1, k_split = 2
@@ -105,10 +109,24 @@ def main():
             out["out_" + name] = np.ascontiguousarray(a[3:16, 3:16][:, :, K_SEL])
             out["col_" + name] = np.stack([a[i, j, :] for (i, j) in COLS])
         out["out_ps"] = np.array(state.ps.data)[3:16, 3:16]
+        if tile in FULL_TILES and K_SPLIT == 1:
+            for name in FULL_VARS:  # every level of the compute window + the staggered row / column
+                out["full_" + name] = np.ascontiguousarray(np.array(getattr(state, name).data)[3:16, 3:16, :])
         return out
 
     res = run_ranks(6, rank)
+    if K_SPLIT == 1:
+        full = {f"out_{k[5:]}_tile{t}": out.pop(k) for t, out in enumerate(res) for k in [k for k in out if k.startswith("full_")]}
+        np.savez_compressed(os.path.join(GOLDEN, "dycore_c12_full.npz"), tiles=np.array(FULL_TILES), **full)
     for t, out in enumerate(res):
+        path = os.path.join(GOLDEN, f"{PREFIX}_tile{t}.npz")
+        if os.path.exists(path) and "--rewrite" not in sys.argv:
+            old = np.load(path)  # regression check of the tool chain: the committed fixture must come out of this run bit for bit
+            for k in old.files:
+                if k.startswith(("out_", "col_")):
+                    assert np.array_equal(old[k], out[k], equal_nan=True), (t, k)
+            print("tile", t, "reproduces the committed fixture")
+            continue
         # Inputs: u, v, w, delz, delp, pe, pk, peln, phis, uc, vc, ua, va are those of acoustic_c12_tile{t}.npz (verified
         # here), the condensates are condensates() (tests/helpers.py carries the same function), q_con / omga / pkz start at
         # zero or are outputs; what remains is the temperature before the preamble, the vapour and ps.
