@@ -90,6 +90,16 @@ def acoustic_fixture(t):
     return fix
 
 
+# Per-variable bounds of the whole-AcousticDynamics comparisons (GPU and emulation; reference metric, bands above).  Measured on
+# the GPU (profiles/r02_acoustic_c12_gpu_errors.json): masses / temperatures / pressures <= 1.1e-15, the A-grid winds 1.4e-11,
+# the mass and Courant accumulators 1e-12, delz 4e-13, heat_source 3e-9, u / v 1.5e-8, omga 8e-8, vc 1.5e-7, w 4e-7,
+# diss_estd 2.3e-6.  What the vertical solvers feed gets the reference's own Riem_Solver3 bound (5e-6,
+# overrides/standard.yaml:49-61); the rest is held two to three orders above what is measured.
+ACOUSTIC_TOL = {"w": 5e-6, "omga": 5e-6, "diss_estd": 5e-6, "uc": 5e-6, "vc": 5e-6, "u": 1e-6, "v": 1e-6, "heat_source": 1e-6,
+                "ua": 1e-8, "va": 1e-8, "delz": 1e-10, "mfxd": 1e-9, "mfyd": 1e-9, "cxd": 1e-9, "cyd": 1e-9}
+ACOUSTIC_TOL_DEFAULT = 1e-12  # delp, pt, pe, pk, peln, q_con
+
+
 def acoustic_config(n_split):
     """The baroclinic_c12 namelist values the fixture was generated with (tools/capture.py dycore_config)."""
     from pace_amd.fv3core import AcousticDynamicsConfig, DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig
@@ -551,20 +561,23 @@ def dycore_errors(fix, out, n=12):
     return errs
 
 
-DYCORE_TOL = {"w": 5e-6, "omga": 5e-6, "u": 1e-6, "v": 1e-6, "ua": 1e-6, "va": 1e-6, "delz": 1e-6, "mfxd": 1e-7, "mfyd": 1e-7,
+# (measured on the GPU, profiles/r02_dycore_c12_gpu_errors.json: pressures 1e-15, delp / pt / pkz / tracers <= 1.5e-13, delz 4e-13,
+# accumulators 5e-10, u / v / va 1e-8, w 3e-7, omga 8e-7; default bound of check_dycore for everything not listed: 1e-9 -> 1e-11)
+DYCORE_TOL = {"w": 5e-6, "omga": 5e-6, "u": 1e-6, "v": 1e-6, "ua": 1e-6, "va": 1e-6, "delz": 1e-10, "mfxd": 1e-7, "mfyd": 1e-7,
               "cxd": 1e-7, "cyd": 1e-7}
 
 
-def check_dycore(fixes, outs):
+def check_dycore(fixes, outs, default=1e-11):
     """Tolerances: the acoustic loop's (5e-6 = the reference's own Riem_Solver3 bound for what the vertical solver feeds, see
     test_acoustic_dynamics_six_tiles_emulated) carried through tracer advection, remapping (reference bound 2e-8) and the
-    final adjustments; 1e-9 for everything else (masses, temperatures, tracers, pressures)."""
+    final adjustments; `default` for everything else (masses, temperatures, tracers, pressures): 1e-11 after one remapping step
+    (measured <= 1.5e-13), 1e-9 for the k_split = 2 run (two remapping steps: the condensates reach 3e-10)."""
     worst = {}
     for t in range(6):
         for k, e in dycore_errors(fixes[t], outs[t]).items():
             worst[k] = max(worst.get(k, 0.0), e)
     for k, e in worst.items():
-        assert e < DYCORE_TOL.get(k, 1e-9), (k, e)
+        assert e < DYCORE_TOL.get(k, default), (k, e)
     return worst
 
 

@@ -67,12 +67,14 @@ def test_acoustic_dynamics_six_tiles_emulated(emu_lib):
     Every horizontal kernel is bit-exact on its own inputs; what is left is the vertical solvers (exp / log of glibc here,
     numpy's SIMD loops in the reference run; lane-cooperative scans instead of sequential sweeps) carried through two substeps.
     The reference accepts 5e-6 for Riem_Solver3 on every backend (overrides/standard.yaml:49-61): that bound for what the
-    solvers feed, 1e-7 for the rest -- the same split as the GPU twin of this test."""
+    solvers feed, per-variable bounds two to three orders above the measured errors for the rest (helpers.ACOUSTIC_TOL; 1e-12
+    for masses, temperatures and pressures) -- the same as the GPU twin of this test."""
     fixes, outs = run_acoustic_six_tiles(emu_lib, "cpu")
-    loose = ("w", "omga", "delz", "diss_estd", "heat_source", "u", "v", "ua", "va", "uc", "vc")
+    from helpers import ACOUSTIC_TOL, ACOUSTIC_TOL_DEFAULT
+
     for t in range(6):
         for k, e in acoustic_errors(fixes[t], outs[t]).items():
-            assert e < (5e-6 if k in loose else 1e-7), (t, k, e)
+            assert e < ACOUSTIC_TOL.get(k, ACOUSTIC_TOL_DEFAULT), (t, k, e)
 
 
 def test_tracer_advection_six_tiles_emulated(emu_lib):
@@ -427,7 +429,7 @@ def test_dynamical_core_two_remapping_steps_emulated(emu_lib):
     from helpers import check_dycore, run_dycore_six_tiles
 
     fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", prefix="dycore_k2_c12")
-    check_dycore(fixes, outs)
+    check_dycore(fixes, outs, default=1e-9)
 
 
 def test_d_sw_order5_emulated_against_reference_run(emu_lib):
