@@ -1145,25 +1145,34 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   if (phases & 2) {
   {
+    // PACE_DSW_LEVEL_BLOCK=<n> (experiment): the four scalar transports issued per block of n levels,
+    // so that the Courant numbers and area fluxes of the block (4 fields x n levels x 0.33 MB at C192) are still in the L2s
+    // when the next scalar of the same block reads them.  Default: whole fields, one launch per scalar.
+    static const int level_block = getenv("PACE_DSW_LEVEL_BLOCK") ? atoi(getenv("PACE_DSW_LEVEL_BLOCK")) : 0;
+    const int kstep = (level_block > 0 && level_block < nk) ? level_block : nk;
+    for (int k0 = 0; k0 < nk; k0 += kstep) {
+    const int nl = (k0 + kstep <= nk) ? kstep : nk - k0;
+    const long o = (long)k0 * g.sk;
     FvDamp dp{};
     // delp: transport + del-n damping of the mass fluxes -> fx, fy
-    dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
-    dp.accx = mfx; dp.accy = mfy;  // flux_capacitor (d_sw.py:33-60); its Courant-number half sits in fxadv
-    if ((rc = launch_transport(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nk, 1, 0, dp, st))) return rc;
+    dp.damp_k = d_dampfac_vt + k0; dp.nord_k = d_nord_v + k0; dp.nmax = nmax_v; dp.mass_given = 0;
+    dp.accx = mfx + o; dp.accy = mfy + o;  // flux_capacitor (d_sw.py:33-60); its Courant-number half sits in fxadv
+    if ((rc = launch_transport(g, m, delp + o, crx + o, cry + o, xfx + o, yfx + o, W.fx + o, W.fy + o, nullptr, nullptr, cfg->hord_dp, nl, 1, 0, dp, st))) return rc;
     // w: transport with the mass fluxes, del-n damping fluxes -> heat_diss, flux-form update -> W.gx (= w*delp + F(w))
     dp = FvDamp{};
-    dp.damp_k = d_dampfac_w_c; dp.nord_k = d_nord_w; dp.nmax = nmax_w; dp.mass_given = 0;
-    dp.qout = W.gx; dp.amass = delp; dp.dw = W.dw; dp.heat_s = W.heat_s; dp.diss_est = diss_est;
-    dp.damp_w_k = d_damp_w_c; dp.ke_bg_k = d_kebg; dp.dt = dt;
-    if ((rc = launch_transport(g, m, w, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_vt, nk, 0, 2, dp, st))) return rc;
+    dp.damp_k = d_dampfac_w_c + k0; dp.nord_k = d_nord_w + k0; dp.nmax = nmax_w; dp.mass_given = 0;
+    dp.qout = W.gx + o; dp.amass = delp + o; dp.dw = W.dw + o; dp.heat_s = W.heat_s + o; dp.diss_est = diss_est + o;
+    dp.damp_w_k = d_damp_w_c + k0; dp.ke_bg_k = d_kebg + k0; dp.dt = dt;
+    if ((rc = launch_transport(g, m, w + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_vt, nl, 0, 2, dp, st))) return rc;
     // q_con -> W.gy
     dp = FvDamp{};
-    dp.damp_k = d_dampfac_t; dp.nord_k = d_nord_t; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp;
-    dp.qout = W.gy; dp.amass = delp;
-    if ((rc = launch_transport(g, m, q_con, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_dp, nk, 2, 1, dp, st))) return rc;
+    dp.damp_k = d_dampfac_t + k0; dp.nord_k = d_nord_t + k0; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp + o;
+    dp.qout = W.gy + o; dp.amass = delp + o;
+    if ((rc = launch_transport(g, m, q_con + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_dp, nl, 2, 1, dp, st))) return rc;
     // pt -> W.fx2
-    dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.qout = W.fx2;
-    if ((rc = launch_transport(g, m, pt, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_tm, nk, 2, 1, dp, st))) return rc;
+    dp.damp_k = d_dampfac_vt + k0; dp.nord_k = d_nord_v + k0; dp.nmax = nmax_v; dp.qout = W.fx2 + o;
+    if ((rc = launch_transport(g, m, pt + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_tm, nl, 2, 1, dp, st))) return rc;
+    }
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   }
