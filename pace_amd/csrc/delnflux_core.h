@@ -18,7 +18,7 @@
 // three metric values are worked out once, so an iteration is LDS reads and a handful of flops.
 __device__ __forceinline__ void delnflux_core(const Geo& g, const Met& m, const double* src, double* sd, double* sfx,
                                               double* sfy, int i0, int j0, double d0, bool hi_order, int nmax) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;  // (256 threads per tile; k_fvtp2d_pair has two tiles per workgroup)
   const int ilo = i0 - 3, jlo = j0 - 3;
   // the corner-copy index maps only matter to workgroups whose footprint reaches a corner of the halo (block-uniform)
   const bool rc = hi_order && (ilo < g.is || ilo + DW - 1 > g.ie) && (jlo < g.js || jlo + DH - 1 > g.je);

@@ -1168,10 +1168,29 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     dp = FvDamp{};
     dp.damp_k = d_dampfac_t + k0; dp.nord_k = d_nord_t + k0; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp + o;
     dp.qout = W.gy + o; dp.amass = delp + o;
-    if ((rc = launch_transport(g, m, q_con + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_dp, nl, 2, 1, dp, st))) return rc;
     // pt -> W.fx2
-    dp.damp_k = d_dampfac_vt + k0; dp.nord_k = d_nord_v + k0; dp.nmax = nmax_v; dp.qout = W.fx2 + o;
-    if ((rc = launch_transport(g, m, pt + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_tm, nl, 2, 1, dp, st))) return rc;
+    FvDamp dp2 = dp;
+    dp2.damp_k = d_dampfac_vt + k0; dp2.nord_k = d_nord_v + k0; dp2.nmax = nmax_v; dp2.qout = W.fx2 + o;
+    static const bool pair = getenv("PACE_DSW_PAIR") != nullptr;  // experiment: both in one launch (k_fvtp2d_pair)
+    // the two halves of a pair must pass the same barriers: pair the levels from which on the damping orders of the two agree
+    // (the sponge levels on top differ in the baseline namelist), the levels above them one scalar at a time
+    int kp = nl;
+    if (pair && cfg->hord_dp == 6 && cfg->hord_tm == 6 && nmax_t == nmax_v) {
+      kp = 0;
+      for (int k = 0; k < nl; ++k)
+        if ((col->nord_t[k0 + k] > 0) != (col->nord_v[k0 + k] > 0)) kp = k + 1;
+    }
+    if (kp > 0) {
+      if ((rc = launch_transport(g, m, q_con + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_dp, kp, 2, 1, dp, st))) return rc;
+      if ((rc = launch_transport(g, m, pt + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_tm, kp, 2, 1, dp2, st))) return rc;
+    }
+    if (kp < nl) {
+      const long o2 = o + (long)kp * g.sk;
+      FvDamp a = dp, b = dp2;
+      a.damp_k += kp; a.nord_k += kp; a.mass += (long)kp * g.sk; a.qout += (long)kp * g.sk; a.amass += (long)kp * g.sk;
+      b.damp_k += kp; b.nord_k += kp; b.mass += (long)kp * g.sk; b.qout += (long)kp * g.sk; b.amass += (long)kp * g.sk;
+      if ((rc = launch_transport_pair(g, m, q_con + o2, pt + o2, crx + o2, cry + o2, xfx + o2, yfx + o2, W.fx + o2, W.fy + o2, 6, nl - kp, a, b, st))) return rc;
+    }
     }
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }

@@ -115,7 +115,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   auto& sqi = L.sqi;
   auto& sxin = L.sxin;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;  // (k_fvtp2d_pair runs two scalars in one workgroup of 512 threads)
   const TileId wg = tile_of_workgroup();
   const int i0 = g.is + wg.bx * TI;
   const int j0 = g.js + wg.by * TJ;
@@ -550,6 +550,42 @@ __global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const real* __r
   else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
   else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
   else fvtp2d_tile<MORD, false, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+}
+
+// EXPERIMENT (PACE_DSW_PAIR=1): two scalars that share every input except q and the damping
+// coefficients (q_con and pt in d_sw) in ONE workgroup of 512 threads -- waves 0-3 run the tile for the first, waves 4-7 for the
+// second, each half in its own LDS; the halves load the same Courant numbers, area fluxes, mass and metrics at about the same
+// time, so one of the two finds them in the CU's L1.  The halves pass the same barriers: the caller guarantees equal damping
+// orders on every level.
+template <int MORD, int DMODE, int EPI>
+__global__ void __launch_bounds__(512, 4) k_fvtp2d_pair(Geo g, Met m, const real* __restrict__ qa, const real* __restrict__ qb,
+                                                     const real* __restrict__ crx, const real* __restrict__ cry,
+                                                     const real* __restrict__ xfx, const real* __restrict__ yfx,
+                                                     const real* __restrict__ xunit, const real* __restrict__ yunit, FvDamp dpa,
+                                                     FvDamp dpb) {
+  __shared__ FvLds<DMODE, EPI> L2[2];
+  const int half = threadIdx.x >> 8;
+  FvLds<DMODE, EPI>& L = L2[half];
+  const real* q = half ? qb : qa;
+  const FvDamp& dp = half ? dpb : dpa;
+  const TileId wg = tile_of_workgroup();
+  const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
+  const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
+  const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
+  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  else fvtp2d_tile<MORD, false, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+}
+
+int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real* qb, const real* crx, const real* cry,
+                          const real* xfx, const real* yfx, const real* xmf, const real* ymf, int hord, int nlev,
+                          const FvDamp& dpa, const FvDamp& dpb, hipStream_t st) {
+  if (hord != 6 || dpa.nmax != dpb.nmax || dpa.nmax > 2) return PACE_ERR_UNSUPPORTED;
+  const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
+  hipLaunchKernelGGL((k_fvtp2d_pair<6, 2, 1>), grid, dim3(512), 0, st, g, m, qa, qb, crx, cry, xfx, yfx, xmf, ymf, dpa, dpb);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
 }
 
 #define FV_LAUNCH(D, E) \

@@ -45,6 +45,10 @@ struct FvDamp {
 int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
                      const real* yfx, real* fx, real* fy, const real* xmf, const real* ymf, int hord, int nlev,
                      int dmode, int epi, const FvDamp& dp, hipStream_t st);
+// experiment: two scalars (DMODE 2, EPI 1, ord 6) in one workgroup of 512 threads
+int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real* qb, const real* crx, const real* cry,
+                          const real* xfx, const real* yfx, const real* xmf, const real* ymf, int hord, int nlev,
+                          const FvDamp& dpa, const FvDamp& dpb, hipStream_t st);
 int launch_delnflux(const Geo& g, const Met& m, int mode, const real* q, real* fx, real* fy,
                     const real* mass, const real* damp_k, const real* nord_k, int nmax, int mass_given,
                     int nlev, hipStream_t st);
