@@ -30,18 +30,29 @@ def oracle_grid(metrics, n, nk):
     return Grid(n, nk, dict(metrics))
 
 
+def _make(target):
+    """`make <target>` under an exclusive file lock: several test processes (pytest -n) may ask for the same library at once."""
+    import fcntl
+
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    with open(os.path.join(ROOT, "build", ".make.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-s", "-j4", target], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def build_emu():
     """Build tests/emu/libpace_emu.so (the kernel sources compiled for the CPU).  Test infrastructure."""
-    path = os.path.join(ROOT, "tests", "emu", "libpace_emu.so")
-    subprocess.run(["make", "-s", "-j4", "emu"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
-    return path
+    _make("emu")
+    return os.path.join(ROOT, "tests", "emu", "libpace_emu.so")
 
 
 def build_emu_small():
     """tests/emu/libpace_emu_small.so: the emulation build with 4 x 4 LDS tiles (interior code paths at C12)."""
-    path = os.path.join(ROOT, "tests", "emu", "libpace_emu_small.so")
-    subprocess.run(["make", "-s", "-j4", "emu-small"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
-    return path
+    _make("emu-small")
+    return os.path.join(ROOT, "tests", "emu", "libpace_emu_small.so")
 
 
 def expand_riem_fixture(fix, n=12, nz=79):

@@ -23,7 +23,9 @@ STEP_TOL = {"u": 2e-3, "v": 2e-3, "va": 2e-3, "ua": 2e-3, "w": 2e-2, "omga": 2e-
 
 
 def build_emu_f32():
-    subprocess.run(["make", "-s", "-j4", "emu-f32"], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+    from helpers import _make
+
+    _make("emu-f32")
     return os.path.join(ROOT, "tests", "emu", "libpace_emu_f32.so")
 
 
