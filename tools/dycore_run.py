@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-emulation", action="store_true", help="gloo + the CPU emulation library (logic check only)")
+    ap.add_argument("--precision", type=int, default=64, choices=(64, 32),
+                    help="storage type of the fields: 32 = libpace_hip_f32.so (BASELINE configuration 5: --tile-size 384 --nz 91 --precision 32)")
     args = ap.parse_args()
     import torch.distributed as dist
 
@@ -53,7 +55,10 @@ def main():
     from pace_amd.fv3core.stencils.fv_dynamics import DynamicalCore
     from pace_amd.util import CubedSphereCommunicator, TorchDistComm, constants as c
 
-    lib = _lib.Library(os.path.join(ROOT, "tests", "emu", "libpace_emu.so")) if args.cpu_emulation else _lib.load()
+    if args.cpu_emulation:
+        lib = _lib.Library(os.path.join(ROOT, "tests", "emu", "libpace_emu_f32.so" if args.precision == 32 else "libpace_emu.so"))
+    else:
+        lib = _lib.load(args.precision)
     n, nz = args.n, args.nz
     metrics = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(metrics, n, nz)
