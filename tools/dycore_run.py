@@ -98,7 +98,7 @@ def main():
     nan = float(np.isnan(state.w.numpy()).mean())
     if rank == 0:
         cells = 6 * n * n * nz
-        print(json.dumps({"workload": f"DynamicalCore.step_dynamics, C{n}x{nz}L, six tiles, n_split={args.n_split}, k_split=1, fp64",
+        print(json.dumps({"workload": f"DynamicalCore.step_dynamics, C{n}x{nz}L, six tiles, n_split={args.n_split}, k_split=1, " + ("fp64" if args.precision == 64 else "float32 fields"),
                           "n_gpus": 0 if args.cpu_emulation else 6, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
                           "cell_updates_per_s": cells * args.n_split * args.steps / elapsed, "nan_fraction_w": nan,
                           "transport": "gloo (CPU emulation)" if args.cpu_emulation else "RCCL, one process per GPU"}))
