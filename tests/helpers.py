@@ -111,17 +111,24 @@ ACOUSTIC_TOL = {"w": 5e-6, "omga": 5e-6, "diss_estd": 5e-6, "uc": 5e-6, "vc": 5e
 ACOUSTIC_TOL_DEFAULT = 1e-12  # delp, pt, pe, pk, peln, q_con
 
 
-def acoustic_config(n_split):
-    """The baroclinic_c12 namelist values the fixture was generated with (tools/capture.py dycore_config)."""
+ACOUSTIC_VARIANTS = {"v2": dict(nord=2, d_con=0.0, hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5)}  # tools/make_golden_acoustic.py
+
+
+def acoustic_config(n_split, variant=None):
+    """The baroclinic_c12 namelist values the fixture was generated with (tools/capture.py dycore_config); `variant`: the
+    options changed in acoustic_c12_<variant>.npz."""
     from pace_amd.fv3core import AcousticDynamicsConfig, DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig
 
-    return AcousticDynamicsConfig(n_split=n_split, k_split=1, nord=3, d_con=1.0, rf_fast=True, rf_cutoff=3000.0, tau=10.0,
-                                  p_fac=0.05, hord_tm=6, delt_max=0.002,
-                                  d_grid_shallow_water=DGridShallowWaterLagrangianDynamicsConfig(),
+    o = dict(nord=3, d_con=1.0, hord_dp=6, hord_tm=6, hord_vt=6, hord_mt=6)
+    o.update(ACOUSTIC_VARIANTS.get(variant, {}))
+    dsw = DGridShallowWaterLagrangianDynamicsConfig(nord=o["nord"], d_con=o["d_con"], hord_dp=o["hord_dp"], hord_tm=o["hord_tm"],
+                                                    hord_vt=o["hord_vt"], hord_mt=o["hord_mt"])
+    return AcousticDynamicsConfig(n_split=n_split, k_split=1, nord=o["nord"], d_con=o["d_con"], rf_fast=True, rf_cutoff=3000.0, tau=10.0,
+                                  p_fac=0.05, hord_tm=o["hord_tm"], delt_max=0.002, d_grid_shallow_water=dsw,
                                   riemann=RiemannConfig(p_fac=0.05))
 
 
-def run_acoustic_tile(comm, lib, device, fix, n, nz):
+def run_acoustic_tile(comm, lib, device, fix, n, nz, variant=None):
     """One tile's program: build the environment from the fixture, run one AcousticDynamics call."""
     import torch
 
@@ -135,8 +142,8 @@ def run_acoustic_tile(comm, lib, device, fix, n, nz):
     state = DycoreState.init_from_numpy_arrays({k[3:]: v for k, v in fix.items() if k.startswith("in_") and k != "in_cappa"}, env.qf)
     n_split = int(fix["n_split"])
     wsd = env.q2()
-    dyn = AcousticDynamics(cube, env.stencil_factory, env.qf, env.grid_data, env.damping, 0, False, False, acoustic_config(n_split),
-                           state.phis, wsd, state)
+    dyn = AcousticDynamics(cube, env.stencil_factory, env.qf, env.grid_data, env.damping, 0, False, False,
+                           acoustic_config(n_split, variant), state.phis, wsd, state)
     dyn.cappa.set(fix["in_cappa"])
     dyn(state, timestep=float(fix["timestep"]), n_map=1)
     if env.qf.device.type == "cuda":
@@ -146,11 +153,20 @@ def run_acoustic_tile(comm, lib, device, fix, n, nz):
     return out
 
 
-def run_acoustic_six_tiles(lib, device, n=12, nz=79):
+def acoustic_variant_fixture(t, variant):
+    """Inputs of the baseline fixture of tile t, outputs of the reference run with the variant's namelist."""
+    fix = {k: v for k, v in acoustic_fixture(t).items() if not k.startswith(("out_", "col_", "full_"))}
+    var = golden(f"acoustic_c12_{variant}.npz")
+    for k in ACOUSTIC_OUT:
+        fix["out_" + k], fix["col_" + k] = var[f"out_{k}_tile{t}"], var[f"col_{k}_tile{t}"]
+    return fix
+
+
+def run_acoustic_six_tiles(lib, device, n=12, nz=79, variant=None):
     from pace_amd.util import run_tiles
 
-    fixes = [acoustic_fixture(t) for t in range(6)]
-    return fixes, run_tiles(6, lambda comm: run_acoustic_tile(comm, lib, device, fixes[comm.Get_rank()], n, nz))
+    fixes = [acoustic_variant_fixture(t, variant) if variant else acoustic_fixture(t) for t in range(6)]
+    return fixes, run_tiles(6, lambda comm: run_acoustic_tile(comm, lib, device, fixes[comm.Get_rank()], n, nz, variant))
 
 
 def acoustic_errors(fix, out, n=12):
@@ -249,6 +265,8 @@ def _child_main(what, out_path, hard_exit=False):
     lib = _lib.load()
     if what == "acoustic":
         result = run_acoustic_six_tiles(lib, "cuda")
+    elif what == "acoustic_v2":
+        result = run_acoustic_six_tiles(lib, "cuda", variant="v2")
     elif what == "tracer":
         result = run_tracer_six_tiles(lib, "cuda")
     elif what == "dycore":

@@ -77,6 +77,18 @@ def test_acoustic_dynamics_six_tiles_emulated(emu_lib):
             assert e < ACOUSTIC_TOL.get(k, ACOUSTIC_TOL_DEFAULT), (t, k, e)
 
 
+def test_acoustic_dynamics_variant_six_tiles_emulated(emu_lib):
+    """The same call with nord = 2, d_con = 0 and all advection orders 5 (c_sw's divergence with nord, two damping passes,
+    second-order del-n damping, no dissipative heating, the order-5 kernels everywhere) against the reference's run of that
+    namelist (tools/make_golden_acoustic.py v2)."""
+    from helpers import ACOUSTIC_TOL, ACOUSTIC_TOL_DEFAULT
+
+    fixes, outs = run_acoustic_six_tiles(emu_lib, "cpu", variant="v2")
+    for t in range(6):
+        for k, e in acoustic_errors(fixes[t], outs[t]).items():
+            assert e < ACOUSTIC_TOL.get(k, ACOUSTIC_TOL_DEFAULT), (t, k, e)
+
+
 def test_tracer_advection_six_tiles_emulated(emu_lib):
     """TracerAdvection (monotone ord-8 PPM transport, sub-cycling, tracer halo updates) on the six C12 tiles against the
     reference's own run (tools/make_golden_tracer.py): bit for bit -- no transcendental is involved."""

@@ -223,6 +223,18 @@ def test_acoustic_dynamics_six_tiles_matches_reference_run(lib, tmp_path):
         assert e < ACOUSTIC_TOL.get(k, ACOUSTIC_TOL_DEFAULT), (k, e)
 
 
+def test_acoustic_dynamics_variant_six_tiles_matches_reference_run(lib, tmp_path):
+    """One whole AcousticDynamics call with nord = 2, d_con = 0 and all advection orders 5 against the reference's run of that
+    namelist (tools/make_golden_acoustic.py v2), six tiles on one device."""
+    from helpers import ACOUSTIC_TOL, ACOUSTIC_TOL_DEFAULT
+
+    fixes, outs = run_in_child("acoustic_v2", tmp_path)
+    errs = [acoustic_errors(fixes[t], outs[t]) for t in range(6)]
+    worst = {k: max(e[k] for e in errs) for k in errs[0]}
+    for k, e in worst.items():
+        assert e < ACOUSTIC_TOL.get(k, ACOUSTIC_TOL_DEFAULT), (k, e)
+
+
 def test_fused_transport_update_matches_oracle_c96(lib):
     """pace_fvtp2d_update (PPM transport + DelnFlux + apply_fluxes in one kernel) against the three oracle steps,
     C96 x 79 (edge, corner and interior workgroups), bit-exact."""

@@ -290,3 +290,28 @@ def test_d_sw_namelist_variants_oracle_matches_reference(variant):
     for k in DSW_ARGS:
         if k != "zh":
             assert compare(fix["out_" + k][dsw_window(k, 12, nk)], a[k][dsw_window(k, 12, nk)]) == 0.0, k
+
+
+def test_oracle_acoustic_dynamics_variant_against_reference_run():
+    """The whole oracle loop with several namelist options changed at once (nord = 2 -- in c_sw's corner divergence, the
+    divergence damping, every del-n damping --, d_con = 0, all advection orders 5) against the reference's run of that namelist
+    on the same inputs (tools/make_golden_acoustic.py v2): bit for bit."""
+    from helpers import ACOUSTIC_VARIANTS, DSW_CFG, acoustic_errors, acoustic_variant_fixture, golden, oracle_grid
+
+    from oracle import dyn_core
+
+    n, nz = 12, 79
+    fixes = [acoustic_variant_fixture(t, "v2") for t in range(6)]
+    var = golden("acoustic_c12_v2.npz")
+    grids = [oracle_grid({k[5:]: v for k, v in fx.items() if k.startswith("grid_")}, n, nz) for fx in fixes]
+    states = [{k[3:]: v.copy() for k, v in fx.items() if k.startswith("in_") and k != "in_cappa"} for fx in fixes]
+    cappas = [fx["in_cappa"].copy() for fx in fixes]
+    col = {k[9:]: v for k, v in var.items() if k.startswith("namelist_")}
+    opts = ACOUSTIC_VARIANTS["v2"]
+    cfg = dict(DSW_CFG, p_fac=0.05, rf_cutoff=3000.0, tau=10.0, delt_max=0.002, **opts)
+    tmp = dyn_core.acoustic_dynamics(grids, col, cfg, states, cappas, float(fixes[0]["timestep"]), int(fixes[0]["n_split"]), n, nz)
+    for t in range(6):
+        out = dict(states[t])
+        out["heat_source"] = tmp[t].heat_source
+        for k, e in acoustic_errors(fixes[t], out).items():
+            assert e == 0.0, (t, k, e)

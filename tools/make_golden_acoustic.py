@@ -25,6 +25,10 @@ STATE_OUT = "u v w delz delp pt pe pk peln q_con omga ua va mfxd mfyd cxd cyd di
 # later-added file (acoustic_c12_ucvc.npz) so that the six per-tile fixtures stay byte-identical
 EXTRA_OUT = ["uc", "vc"]
 FULL_TILES = [0, 2]
+# `python tools/make_golden_acoustic.py <variant>`: the same call with several namelist options changed at once; only the outputs
+# (level subset + columns, all six tiles), the options and the column namelist the reference derives are stored
+# (acoustic_c12_<variant>.npz) -- the inputs are those of the baseline fixtures
+VARIANTS = {"v2": dict(nord=2, d_con=0.0, hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5)}
 
 
 def main():
@@ -34,7 +38,13 @@ def main():
     import refenv
     from threadcomm import run_ranks
 
+    import dataclasses
+
+    variant = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in VARIANTS else None
     config = capture.dycore_config(n_split=N_SPLIT, npx=N + 1, npz=NZ)
+    if variant:
+        config = dataclasses.replace(config, **VARIANTS[variant])
+    cols = {}
 
     def rank(comm):
         env = refenv.build_rank(comm, N, NZ)
@@ -66,9 +76,31 @@ def main():
                 grid[name] = s
         for name in ["del6_u", "del6_v", "divg_u", "divg_v", "da_min", "da_min_c"]:
             grid[name] = snap(getattr(env.damping, name))
+        if comm.Get_rank() == 0:
+            from pace.fv3core.stencils import d_sw
+
+            col = d_sw.get_column_namelist(config.acoustic_dynamics.d_grid_shallow_water, env.qf)
+            cols.update({k: np.array(v.data) for k, v in col.items()})
         return grid, before, after, float(dycore._timestep / dycore._k_split)
 
     out = run_ranks(6, rank)
+    if variant:
+        data = {"k_sel": np.array(K_SEL), "cols": np.array(COLS), "timestep": out[0][3], "n_split": N_SPLIT}
+        for k, v in VARIANTS[variant].items():
+            data["cfg_" + k] = np.asarray(v)
+        for k, v in cols.items():
+            data["namelist_" + k] = v
+        for t, (grid, before, after, timestep) in enumerate(out):
+            ref_in = np.load(os.path.join(GOLDEN, f"acoustic_c12_tile{t}.npz"))
+            for k, v in before.items():
+                assert np.array_equal(ref_in["in_" + k], v, equal_nan=True), (t, k)  # same inputs as the baseline fixture
+            for k, v in after.items():
+                data[f"out_{k}_tile{t}"] = np.ascontiguousarray(v[3 : 3 + N + 1, 3 : 3 + N + 1][:, :, K_SEL])
+                data[f"col_{k}_tile{t}"] = np.stack([v[i, j, :] for (i, j) in COLS])
+        path = os.path.join(GOLDEN, f"acoustic_c12_{variant}.npz")
+        np.savez_compressed(path, **data)
+        print(variant, os.path.getsize(path) // 1024, "KB")
+        return
     os.makedirs(GOLDEN, exist_ok=True)
     extra = {"k_sel": np.array(K_SEL), "cols": np.array(COLS)}
     for t, (grid, before, after, timestep) in enumerate(out):
