@@ -902,6 +902,40 @@ __global__ void __launch_bounds__(256) k_copy_levels(Geo g, const real* __restri
   dst[c] = src[c];
 }
 
+// the two plane-wise preliminaries of the divergence damping in ONE launch: second-order damping on the sponge levels
+// [0, kstart) (k_divdamp_low's arithmetic) and delpc = divg_d on the levels below (k_copy_levels) -- two tiny kernels were two
+// launch latencies on the critical path of the wind phase
+__global__ void __launch_bounds__(256)
+k_divdamp_low_and_copy(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ua,
+                       const real* __restrict__ va, const real* __restrict__ uc, const real* __restrict__ vc,
+                       real* __restrict__ delpc, real* __restrict__ vort_b, real* __restrict__ ke, const real* __restrict__ d2_bg,
+                       double dddmp, double dt, const real* __restrict__ divg_d, int kstart) {
+  PLANE_IJK(g);
+  const long c = IDX3(g, i, j, k);
+  if (k >= kstart) {
+    delpc[c] = divg_d[c];
+    return;
+  }
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  const double a0 = dd_u_contra_dyc(g, m, u, va, vc, c, c2, j);
+  const double am = dd_u_contra_dyc(g, m, u, va, vc, c - 1, c2 - 1, j);
+  const double b0 = dd_v_contra_dxc(g, m, v, ua, uc, c, c2, i);
+  const double bm = dd_v_contra_dxc(g, m, v, ua, uc, c - sj, c2 - sj, i);
+  double d = bm - b0 + am - a0;
+  const bool ic = (i == g.is || i == g.ie + 1);
+  if (ic && j == g.js) d = d - bm;
+  if (ic && j == g.je + 1) d = d + b0;
+  d = m.rarea_c[c2] * d;
+  delpc[c] = d;
+  const double delpcdt = d * dt;
+  const double damp = m.da_min_c * fmax(d2_bg[k], fmin(0.2, dddmp * fabs(delpcdt)));
+  const double vort = damp * d;
+  vort_b[c] = vort;
+  ke[c] = ke[c] + vort;
+}
+
 // PACE_LEGACY_DIVERGENCE_DAMPING=1: the round-1 sequence (one kernel per pass + the tail kernel), kept for A/B measurements
 static bool legacy_divergence_damping() {
   static const bool v = getenv("PACE_LEGACY_DIVERGENCE_DAMPING") != nullptr;
@@ -1026,14 +1060,18 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
                               const real* rel_vort_agrid, double dt, const real* d2_bg_dev, int kstart, int nonzero_nord,
                               double dddmp, double d4_bg, real* da, real* db, hipStream_t st) {
   const int nk = g.nk;
-  if (kstart > 0) {
+  const int nhigh = nk - kstart;
+  const bool fused = nhigh > 0 && !legacy_divergence_damping();
+  if (fused) {
+    // sponge levels + delpc = divg_d below them (copy_computeplus :578; whole planes, so that the fused kernel can take its
+    // footprint from delpc), one launch
+    hipLaunchKernelGGL(k_divdamp_low_and_copy, plane_grid(g, nk), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
+                       d2_bg_dev, dddmp, dt, divg_d, kstart);
+  } else if (kstart > 0) {
     hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
                        d2_bg_dev, dddmp, dt);
   }
-  const int nhigh = nk - kstart;
-  if (nhigh > 0 && !legacy_divergence_damping()) {
-    // delpc = divg_d (copy_computeplus :578; whole planes, so that the fused kernel can take its footprint from delpc)
-    hipLaunchKernelGGL(k_copy_levels, plane_grid(g, nhigh), dim3(256), 0, st, g, divg_d, delpc, kstart);
+  if (fused) {
     const double dd8 = pow(m.da_min_c * d4_bg, (double)(nonzero_nord + 1));
     const int ntx = (g.n + 1 + DD_TI - 1) / DD_TI, nty = (g.n + 1 + DD_TJ - 1) / DD_TJ;
     hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)nhigh), dim3(256), 0, st, g, m, rel_vort_agrid,

@@ -39,10 +39,8 @@ __global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const real* __
 // stage B: vc_contra_y_edge (:80-125) then vc_contra_x_edge (:128-145); touches edge strips only
 // (stages B, C, D touch O(N) points per level: they are launched on strips that contain those points -- `R` -- instead of on
 // whole planes, where 99 % of the threads only found out that they had nothing to do: 9 + 9 + 6 us -> see profiles)
-__global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const real* __restrict__ vc,
-                                                        const real* __restrict__ ut, real* __restrict__ vt, Regions R) {
-  REGION_POINT(R);
-  (void)interior;
+__device__ __forceinline__ void fx_vt_edges_point(const Geo& g, const Met& m, const real* vc, const real* ut, real* vt, int i, int j,
+                                                  int k) {
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -59,11 +57,8 @@ __global__ void __launch_bounds__(256) k_fxadv_vt_edges(Geo g, Met m, const real
 }
 
 // stage C: uc_contra_x_edge (:148-180), uc_contra_corners (:183-300), vc_contra_corners (:303-404)
-__global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, const real* __restrict__ uc,
-                                                                const real* __restrict__ vc, real* ut,
-                                                                real* vt, Regions R) {
-  REGION_POINT(R);
-  (void)interior;
+__device__ __forceinline__ void fx_ut_edges_corners_point(const Geo& g, const Met& m, const real* uc, const real* vc, real* ut,
+                                                          const real* vt, int i, int j, int k) {
   if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -105,11 +100,8 @@ __global__ void __launch_bounds__(256) k_fxadv_ut_edges_corners(Geo g, Met m, co
   }
 }
 
-__global__ void __launch_bounds__(256) k_fxadv_vt_corners(Geo g, Met m, const real* __restrict__ uc,
-                                                          const real* __restrict__ vc, const real* ut,
-                                                          real* vt, Regions R) {
-  REGION_POINT(R);
-  (void)interior;
+__device__ __forceinline__ void fx_vt_corners_point(const Geo& g, const Met& m, const real* uc, const real* vc, const real* ut,
+                                                    real* vt, int i, int j, int k) {
   if (i < 1 || j < 1 || i > g.ni - 2 || j > g.nj - 2) return;
   const bool cols = (i == g.is - 1 || i == g.is || i == g.ie || i == g.ie + 1);
   if (!cols || !(j == g.js + 1 || j == g.je)) return;
@@ -182,6 +174,46 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
   }
 }
 
+// Stages B, C, D in ONE launch: a workgroup of 1024 threads per level walks the strips of each stage (one or two points per thread); a stage reads what the previous one
+// wrote at other points of the same level, so the stages are separated by a workgroup barrier (writes to global memory made
+// visible to the workgroup by the fence).  Three launches of ~5 us each (their cost is launch latency) become one.
+struct FxStrips {
+  Regions b, c, d;
+};
+__device__ __forceinline__ bool strip_point(const Regions& R, int p, int& i, int& j) {
+  for (int q = 0; q < R.n; ++q) {
+    const int w = R.ie[q] - R.ib[q] + 1, h = R.je[q] - R.jb[q] + 1;
+    if (p < w * h) {
+      j = R.jb[q] + p / w;
+      i = R.ib[q] + p % w;
+      return true;
+    }
+    p -= w * h;
+  }
+  return false;
+}
+__device__ __forceinline__ int strip_count(const Regions& R) {
+  int n = 0;
+  for (int q = 0; q < R.n; ++q) n += (R.ie[q] - R.ib[q] + 1) * (R.je[q] - R.jb[q] + 1);
+  return n;
+}
+__global__ void __launch_bounds__(1024) k_fxadv_edges(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
+                                                     real* ut, real* vt, FxStrips S) {
+  const int k = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  int i, j;
+  for (int p = tid, n = strip_count(S.b); p < n; p += 1024)
+    if (strip_point(S.b, p, i, j)) fx_vt_edges_point(g, m, vc, ut, vt, i, j, k);
+  __threadfence_block();
+  __syncthreads();
+  for (int p = tid, n = strip_count(S.c); p < n; p += 1024)
+    if (strip_point(S.c, p, i, j)) fx_ut_edges_corners_point(g, m, uc, vc, ut, vt, i, j, k);
+  __threadfence_block();
+  __syncthreads();
+  for (int p = tid, n = strip_count(S.d); p < n; p += 1024)
+    if (strip_point(S.d, p, i, j)) fx_vt_corners_point(g, m, uc, vc, ut, vt, i, j, k);
+}
+
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
                  hipStream_t st, int part) {
@@ -191,21 +223,19 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
   if (part == 1 && (box.i1 < box.i0 || box.j1 < box.j0)) return PACE_OK;
   hipLaunchKernelGGL(k_fxadv_main, grid, block, 0, st, g, m, uc, vc, ut, vt, box);
   if (part != 1) {
-    const dim3 sblock(64, 4);
-    Regions rb{};  // stage B: rows js, je+1 over the whole width; columns is-1, is, ie, ie+1 between them
-    add_region(rb, 0, g.ni - 2, g.js, g.js);
-    add_region(rb, 0, g.ni - 2, g.je + 1, g.je + 1);
-    add_region(rb, g.is - 1, g.is, g.js + 2, g.je - 1);
-    add_region(rb, g.ie, g.ie + 1, g.js + 2, g.je - 1);
-    hipLaunchKernelGGL(k_fxadv_vt_edges, regions_grid(rb, g.nk), sblock, 0, st, g, m, vc, ut, vt, rb);
-    Regions rc{};  // stage C: rows js-1, js, je, je+1, columns is+1 .. ie
-    add_region(rc, g.is + 1, g.ie, g.js - 1, g.js);
-    add_region(rc, g.is + 1, g.ie, g.je, g.je + 1);
-    hipLaunchKernelGGL(k_fxadv_ut_edges_corners, regions_grid(rc, g.nk), sblock, 0, st, g, m, uc, vc, ut, vt, rc);
-    Regions rd{};  // stage D: the eight points (is-1, is, ie, ie+1) x (js+1, je)
-    add_region(rd, g.is - 1, g.ie + 1, g.js + 1, g.js + 1);
-    add_region(rd, g.is - 1, g.ie + 1, g.je, g.je);
-    hipLaunchKernelGGL(k_fxadv_vt_corners, regions_grid(rd, g.nk), sblock, 0, st, g, m, uc, vc, ut, vt, rd);
+    FxStrips S{};
+    // stage B: rows js, je+1 over the whole width; columns is-1, is, ie, ie+1 between them
+    add_region(S.b, 0, g.ni - 2, g.js, g.js);
+    add_region(S.b, 0, g.ni - 2, g.je + 1, g.je + 1);
+    add_region(S.b, g.is - 1, g.is, g.js + 2, g.je - 1);
+    add_region(S.b, g.ie, g.ie + 1, g.js + 2, g.je - 1);
+    // stage C: rows js-1, js, je, je+1, columns is+1 .. ie
+    add_region(S.c, g.is + 1, g.ie, g.js - 1, g.js);
+    add_region(S.c, g.is + 1, g.ie, g.je, g.je + 1);
+    // stage D: the eight points (is-1, is, ie, ie+1) x (js+1, je)
+    add_region(S.d, g.is - 1, g.ie + 1, g.js + 1, g.js + 1);
+    add_region(S.d, g.is - 1, g.ie + 1, g.je, g.je);
+    hipLaunchKernelGGL(k_fxadv_edges, dim3((unsigned)g.nk), dim3(1024), 0, st, g, m, uc, vc, ut, vt, S);
   }
   hipLaunchKernelGGL(k_fxadv_fluxes, grid, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box);
   PACE_CHECK_LAUNCH();

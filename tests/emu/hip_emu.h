@@ -44,6 +44,8 @@ inline hipError_t hipDeviceSynchronize() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 
 void __syncthreads();
+inline void __threadfence_block() {}
+inline void __threadfence() {}
 // `mode` is per launch site: 0 = not known yet, 1 = the kernel never synchronises (threads run as plain calls),
 // 2 = it does (threads run as fibers).  A kernel that hits __syncthreads() in plain mode is restarted with fibers;
 // that is safe because nothing but LDS is written before a kernel's first barrier.
