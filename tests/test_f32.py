@@ -104,3 +104,39 @@ def test_f32_dynamical_core_step_gpu(tmp_path):
 
     fixes, outs = run_in_child("dycore_f32", tmp_path)
     check_step(fixes, outs)
+
+
+@pytest.mark.gpu
+def test_f32_d_sw_and_riem3_c96_against_f64_gpu():
+    """The float32-storage kernels at a size with interior workgroups and every tile seam (C96 x 79): d_sw and riem_solver3
+    against the SAME kernels of the float64 library on the same synthetic state, to float32 storage accuracy."""
+    from pace_amd import _lib, synthetic
+    from pace_amd.tile import run_riem3
+
+    n, nz = 96, 79
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    col = {k: np.ascontiguousarray(v[:nz]) for k, v in golden("column_namelist_c12.npz").items()}
+    outs = {}
+    for prec in (64, 32):
+        env = Env(_lib.load(prec), "cuda", metrics, n, nz)
+        d, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"])
+        inp = {"cappa": s["cappa"], "zs": s["zs"], "ws": s["ws"], "delz": s["delz"], "q_con": s["q_con"], "delp": s["delp"],
+               "pt": s["pt"], "zh": s["zh"], "p": s["pe"], "ppe": s["ppe"], "pk3": s["pk3"], "pk": s["pk"],
+               "log_p_interface": s["peln"], "w": s["w"]}
+        r = run_riem3(env, inp, False, s["dt"], metrics["ptop"])
+        outs[prec] = (d, r)
+    for k in DSW_ARGS:
+        if k == "zh":
+            continue
+        W = dsw_window(k, n, nz)
+        a, b = outs[64][0][k][W], outs[32][0][k][W]
+        e = float(np.abs(a - b).max() / (np.abs(a).max() + 1e-300))
+        # (measured: 4e-8 ... 2e-6; the dissipative heating and its estimate are differences of kinetic-energy-sized terms: 6e-4)
+        assert e < (5e-3 if k in ("heat_source", "diss_est") else 2e-5), ("d_sw", k, e)
+    for k, nk in (("delz", nz), ("zh", nz + 1), ("pk3", nz + 1), ("w", nz), ("ppe", nz + 1)):
+        a, b = outs[64][1][k][3:3 + n, 3:3 + n, :nk], outs[32][1][k][3:3 + n, 3:3 + n, :nk]
+        e = float(np.abs(a - b).max() / (np.abs(a).max() + 1e-300))
+        # (measured: delz 1.5e-6, zh 1e-7, pk3 4e-8; the perturbation pressure and w come from small differences of large
+        # pressures: 4e-5 and 7e-4 of their ranges)
+        assert e < (5e-3 if k in ("ppe", "w") else 2e-5), ("riem_solver3", k, e)
