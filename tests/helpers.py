@@ -273,6 +273,8 @@ def _child_main(what, out_path, hard_exit=False):
         result = run_dycore_six_tiles(lib, "cuda")
     elif what == "dycore_k2":
         result = run_dycore_six_tiles(lib, "cuda", prefix="dycore_k2_c12")
+    elif what == "dycore_kord10":
+        result = run_dycore_six_tiles(lib, "cuda", prefix="dycore_kord10_c12")
     elif what == "dycore_f32":
         result = run_dycore_six_tiles(_lib.load(32), "cuda")
     elif what == "dycore_generated":
@@ -398,7 +400,15 @@ def run_mapn_tracer(env, d, kord, nq=7, fill=True, n=12):
 L2E_OUT3 = ("pt", "delp", "delz", "peln", "u", "v", "w", "q_con", "pkz", "pk", "pe", "cappa")
 
 
-def run_l2e(env, d, last_step, n=12, km=79):
+def l2e_k10_fixture():
+    """l2e_c12.npz with the inputs / outputs of the reference's run with every remapping order 10 merged over it
+    (tools/make_golden_l2e.py kord10: negatives in four condensates)."""
+    d = golden("l2e_c12.npz")
+    d.update(golden("l2e_k10_c12.npz"))
+    return d
+
+
+def run_l2e(env, d, last_step, n=12, km=79, kord=9):
     """LagrangianToEulerian through the host class on the reference-run fixture (tests/golden/l2e_c12.npz; its arrays are
     the [2:16, 2:16] window of the 19 x 19 storage).  Returns dict name -> full numpy array."""
     import torch
@@ -419,7 +429,8 @@ def run_l2e(env, d, last_step, n=12, km=79):
     f = {k[3:]: embed(d[k]) for k in d if k.startswith("in_") and not k.startswith("in_tr_")}
     tracers = {k[6:]: embed(d[k]) for k in d if k.startswith("in_tr_")}
     ak, bk = env.kq(d["ak"]), env.kq(d["bk"])
-    op = LagrangianToEulerian(env.stencil_factory, env.qf, RemappingConfig(), None, 8, None, tracers)
+    op = LagrangianToEulerian(env.stencil_factory, env.qf,
+                              RemappingConfig(kord_tm=-kord, kord_tr=kord, kord_wz=kord, kord_mt=kord), None, 8, None, tracers)
     op(tracers, f["pt"], f["delp"], f["delz"], f["peln"], f["u"], f["v"], f["w"], f["cappa"], f["q_con"], f["qcld"], f["pkz"],
        f["pk"], f["pe"], f["phis"], f["ps"], f["wsd"], ak, bk, None, float(d["ptop"]), c.KAPPA, c.ZVIR, last_step, 0.0, 112.5)
     if env.qf.device.type == "cuda":
@@ -429,7 +440,7 @@ def run_l2e(env, d, last_step, n=12, km=79):
     return out
 
 
-def check_l2e(out, d, last_step, tol, n=12, km=79):
+def check_l2e(out, d, last_step, tol, n=12, km=79, loose=None):
     """Compare with the fixture on the windows the reference writes; returns the worst metric per variable."""
     cw = (slice(3, 3 + n), slice(3, 3 + n))
     worst = {}
@@ -455,7 +466,7 @@ def check_l2e(out, d, last_step, tol, n=12, km=79):
             kk = km + 1 if name in ("pe", "peln", "pk") else km
             e = compare(ref[win][:, :, :kk], out[name][win][:, :, :kk], near_zero=1e-18)
         worst[name] = e
-        assert e < tol, (name, e)
+        assert e < (loose or {}).get(name, tol), (name, e)
     return worst
 
 
@@ -534,8 +545,9 @@ def run_dycore_tile(comm, lib, device, fix_ac, fix_dy, n, nz, checkpointer=None,
     k_split = int(fix_dy["k_split"]) if "k_split" in fix_dy else 1
     ac = acoustic_config(n_split)
     ac.k_split = k_split
+    kord = int(fix_dy["kord"]) if "kord" in fix_dy else 9  # (dycore_kord10_c12_*: every remapping order 10)
     config = DynamicalCoreConfig(npx=n + 1, npy=n + 1, npz=nz, dt_atmos=float(fix_dy["timestep"]), k_split=k_split,
-                                 n_split=n_split, acoustic_dynamics=ac)
+                                 n_split=n_split, acoustic_dynamics=ac, kord_tm=-kord, kord_tr=kord, kord_wz=kord, kord_mt=kord)
     core = DynamicalCore(cube, env.grid_data, env.stencil_factory, env.qf, env.damping, config, state.phis, state,
                          datetime.timedelta(seconds=float(fix_dy["timestep"])), checkpointer=checkpointer)
     core.step_dynamics(state)
@@ -616,6 +628,21 @@ def check_dycore(fixes, outs, default=1e-11):
 # generated winds differ from the reference's by up to 3e-13 m/s, so that is the accuracy an end-to-end comparison can have.
 GENERATED_TOL = {"u": 1e-3, "v": 1e-3, "va": 1e-3, "ua": 1e-5, "w": 5e-5, "omga": 5e-5, "mfxd": 5e-6, "mfyd": 5e-6,
                  "cxd": 5e-6, "cyd": 5e-6}
+
+
+# One whole step with every remapping order 10: the kord 10 limiter is discontinuous in its inputs -- the reference algorithm
+# (oracle, bit-identical to the reference's LagrangianToEulerian on the same inputs) turns 1e-13 of input noise into 2e-6 (v),
+# 1e-5 (w), 6e-7 (pt), 2e-4 (condensates) of each field's magnitude, where kord 9 leaves 1e-13 -- and its inputs here come out
+# of the acoustic loop, whose vertical solver carries the device's exp / log.  Hence scaled-error bounds:
+KORD10_TOL = {"u": 1e-4, "v": 1e-4, "ua": 1e-4, "va": 1e-4, "w": 1e-4, "omga": 1e-4, "pt": 1e-6, "pkz": 1e-6, "q_con": 1e-3,
+              "qliquid": 1e-3, "qrain": 1e-3, "qice": 1e-3, "qsnow": 1e-3, "qsgs_tke": 1e-8}
+
+
+def check_dycore_kord10(fixes, outs):
+    worst = dycore_scaled_errors(fixes, outs)
+    for k, e in worst.items():
+        assert e < KORD10_TOL.get(k, 1e-10), (k, e)
+    return worst
 
 
 def check_dycore_generated(fixes, outs):

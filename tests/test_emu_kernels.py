@@ -190,6 +190,20 @@ def test_mapn_tracer_emulated_vs_oracle(emu_lib, kord):
         assert np.array_equal(g, e), t
 
 
+def test_lagrangian_to_eulerian_order_10_emulated(emu_lib):
+    """LagrangianToEulerian with every remapping order 10 on the inputs of the reference's own run with that namelist (negatives in
+    four condensates): everything without exp / log bit for bit -- all tracers, winds, w, delz --; pt and pkz are mapped in
+    log-pressure, and the kord 10 limiter amplifies the last-ulp difference of libm's log against numpy's (measured 5e-9)."""
+    from helpers import check_l2e, l2e_k10_fixture, run_l2e
+
+    d = l2e_k10_fixture()
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, 79)
+    worst = check_l2e(run_l2e(env, d, False, kord=10), d, False, 1e-14, loose={"pt": 1e-6, "pkz": 1e-6})
+    for name in ("delp", "delz", "u", "v", "w", "q_con", "pe", "cappa", "ps", "tr_qvapor", "tr_qliquid", "tr_qrain", "tr_qice",
+                 "tr_qsnow", "tr_qgraupel", "tr_qo3mr", "tr_qsgs_tke"):
+        assert worst[name] == 0.0, name
+
+
 @pytest.mark.parametrize("last_step", [False, True])
 def test_lagrangian_to_eulerian_emulated(emu_lib, last_step):
     """The whole LagrangianToEulerian host sequence (k_l2e.hip + the remap / fillz kernels) against the run of the
@@ -442,6 +456,17 @@ def test_dynamical_core_two_remapping_steps_emulated(emu_lib):
 
     fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", prefix="dycore_k2_c12")
     check_dycore(fixes, outs, default=1e-9)
+
+
+def test_dynamical_core_step_remapping_order_10_emulated(emu_lib):
+    """One whole step with every remapping order 10 (kord_tm = -10, kord_tr = kord_wz = kord_mt = 10: the other limiter family of
+    RemapProfile for temperature, tracers, w, delz and the winds) against the reference's run of that namelist
+    (tools/make_golden_dycore.py 2 1 kord10), within what that limiter's discontinuity allows (helpers.KORD10_TOL; the operator
+    on the reference's own inputs: test_lagrangian_to_eulerian_order_10_*)."""
+    from helpers import check_dycore_kord10, run_dycore_six_tiles
+
+    fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", prefix="dycore_kord10_c12")
+    check_dycore_kord10(fixes, outs)
 
 
 def test_d_sw_order5_emulated_against_reference_run(emu_lib):

@@ -412,6 +412,16 @@ def test_mapn_tracer_and_fillz_match_oracle(lib, kord):
         assert np.array_equal(g, e), t
 
 
+def test_lagrangian_to_eulerian_order_10_matches_reference_run(lib):
+    """LagrangianToEulerian with every remapping order 10 on the inputs of the reference's own run with that namelist: tracers,
+    winds, w, delz exact or at rounding level; pt / pkz (log-pressure coordinate, discontinuous limiter) within 1e-6."""
+    from helpers import check_l2e, l2e_k10_fixture, run_l2e
+
+    d = l2e_k10_fixture()
+    env = Env(lib, "cuda", golden("grid_c12_tile0.npz"), 12, 79)
+    check_l2e(run_l2e(env, d, False, kord=10), d, False, 1e-12, loose={"pt": 1e-6, "pkz": 1e-6})
+
+
 @pytest.mark.parametrize("last_step", [False, True])
 def test_lagrangian_to_eulerian_matches_reference_run(lib, last_step):
     """LagrangianToEulerian on the GPU against the run of the reference (tests/golden/l2e_c12.npz).  The reference's own
@@ -577,6 +587,14 @@ def test_dynamical_core_two_remapping_steps_matches_reference_run(lib, tmp_path)
 
     fixes, outs = run_in_child("dycore_k2", tmp_path)
     check_dycore(fixes, outs, default=1e-9)
+
+
+def test_dynamical_core_step_remapping_order_10_matches_reference_run(lib, tmp_path):
+    """One whole DynamicalCore step with every remapping order 10 against the reference's run of that namelist."""
+    from helpers import check_dycore_kord10
+
+    fixes, outs = run_in_child("dycore_kord10", tmp_path)
+    check_dycore_kord10(fixes, outs)
 
 
 @pytest.mark.parametrize("variant", ["nord2", "dcon0", "skeb", "dddmp0"])

@@ -315,3 +315,31 @@ def test_oracle_acoustic_dynamics_variant_against_reference_run():
         out["heat_source"] = tmp[t].heat_source
         for k, e in acoustic_errors(fixes[t], out).items():
             assert e == 0.0, (t, k, e)
+
+
+def test_lagrangian_to_eulerian_order_10_oracle_against_reference_run():
+    """oracle.remapping.lagrangian_to_eulerian with every remapping order 10 == the reference's run with that namelist
+    (tools/make_golden_l2e.py kord10; negatives in four condensates), every output, bit for bit."""
+    from helpers import l2e_k10_fixture
+
+    from oracle import constants as c
+    from oracle import remapping
+
+    d = l2e_k10_fixture()
+    f = {k[3:]: d[k].copy() for k in d if k.startswith("in_") and not k.startswith("in_tr_")}
+    tr = {k[6:]: d[k].copy() for k in d if k.startswith("in_tr_")}
+    km, n = 79, 12
+    remapping.lagrangian_to_eulerian(f, tr, d["ak"], d["bk"], float(d["ptop"]), c.KAPPA, c.ZVIR, False, n, km, o=1, nq=8,
+                                     kord_tm=-10, kord_tr=10, kord_wz=10, kord_mt=10)
+    cw = (slice(1, 13), slice(1, 13))
+    for key in d:
+        if not key.startswith("out_") or key == "out_last_pt":
+            continue
+        name = key[4:]
+        got = tr[name[3:]] if name.startswith("tr_") else f[name]
+        win = {"u": (slice(1, 13), slice(1, 14)), "v": (slice(1, 14), slice(1, 13))}.get(name, cw)
+        if d[key].ndim == 2:
+            assert np.array_equal(got[cw], d[key][cw]), name
+        else:
+            kk = km + 1 if name in ("pe", "peln", "pk") else km
+            assert np.array_equal(got[win][:, :, :kk], d[key][win][:, :, :kk]), name

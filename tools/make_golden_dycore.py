@@ -34,7 +34,10 @@ N, NZ = 12, 79
 # -> dycore_k2_c12_tile*.npz
 N_SPLIT = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 K_SPLIT = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-PREFIX = "dycore_c12" if K_SPLIT == 1 else f"dycore_k{K_SPLIT}_c12"
+# "python make_golden_dycore.py 2 1 kord10": the baseline split with every remapping order 10 (kord_tm = -10, kord_tr = kord_wz =
+# kord_mt = 10) -> dycore_kord10_c12_tile*.npz
+KORD = 10 if (len(sys.argv) > 3 and sys.argv[3] == "kord10") else 9
+PREFIX = ("dycore_c12" if K_SPLIT == 1 else f"dycore_k{K_SPLIT}_c12") if KORD == 9 else "dycore_kord10_c12"
 TRACERS = "qvapor qliquid qrain qice qsnow qgraupel qo3mr qsgs_tke qcld".split()
 STATE3 = "u v w delz delp pt pe pk peln pkz q_con omga ua va uc vc".split() + TRACERS
 STATE_OUT = "u v w delz delp pt pe pk peln pkz q_con omga ua va mfxd mfyd cxd cyd".split() + TRACERS
@@ -63,6 +66,10 @@ def main():
     from threadcomm import run_ranks
 
     config = capture.dycore_config(n_split=N_SPLIT, k_split=K_SPLIT, npx=N + 1, npz=NZ, do_sat_adj=False)
+    if KORD != 9:
+        import dataclasses
+
+        config = dataclasses.replace(config, kord_tm=-KORD, kord_tr=KORD, kord_wz=KORD, kord_mt=KORD)
 
     def rank(comm):
         env = refenv.build_rank(comm, N, NZ)
@@ -70,8 +77,9 @@ def main():
         tile = comm.Get_rank()
         for name, f in condensates(tile, state.qvapor.data.shape).items():
             getattr(state, name).data[:] = f * (np.asarray(state.delp.data) > 0)
-        out = {"timestep": np.float64(config.dt_atmos), "n_split": np.int64(N_SPLIT), "k_split": np.int64(K_SPLIT), "k_sel": np.array(K_SEL), "cols": np.array(COLS)}
-        if tile == 0 and K_SPLIT == 1:
+        out = {"timestep": np.float64(config.dt_atmos), "n_split": np.int64(N_SPLIT), "k_split": np.int64(K_SPLIT), "kord": np.int64(KORD),
+               "k_sel": np.array(K_SEL), "cols": np.array(COLS)}
+        if tile == 0 and K_SPLIT == 1 and KORD == 9:
             # neg_adj3 on its own, on a state with many negatives
             qf, sf = env.qf, env.stencil_factory
             rng = np.random.default_rng(11)
@@ -109,13 +117,13 @@ def main():
             out["out_" + name] = np.ascontiguousarray(a[3:16, 3:16][:, :, K_SEL])
             out["col_" + name] = np.stack([a[i, j, :] for (i, j) in COLS])
         out["out_ps"] = np.array(state.ps.data)[3:16, 3:16]
-        if tile in FULL_TILES and K_SPLIT == 1:
+        if tile in FULL_TILES and K_SPLIT == 1 and KORD == 9:
             for name in FULL_VARS:  # every level of the compute window + the staggered row / column
                 out["full_" + name] = np.ascontiguousarray(np.array(getattr(state, name).data)[3:16, 3:16, :])
         return out
 
     res = run_ranks(6, rank)
-    if K_SPLIT == 1:
+    if K_SPLIT == 1 and KORD == 9:
         full = {f"out_{k[5:]}_tile{t}": out.pop(k) for t, out in enumerate(res) for k in [k for k in out if k.startswith("full_")]}
         np.savez_compressed(os.path.join(GOLDEN, "dycore_c12_full.npz"), tiles=np.array(FULL_TILES), **full)
     for t, out in enumerate(res):
@@ -143,7 +151,7 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, f"{PREFIX}_tile{t}.npz"), **slim)
         print(t, len(slim))
     d = np.load(os.path.join(GOLDEN, "negadj_c12.npz"))
-    for k in (d.files if K_SPLIT == 1 else []):
+    for k in (d.files if (K_SPLIT == 1 and KORD == 9) else []):
         if k.startswith("out_"):
             print(k, float(np.abs(d[k][:, :, :NZ] - d["in_" + k[4:]][:, :, :NZ]).max()), float((d[k][:, :, :NZ] < 0).mean()))
 
