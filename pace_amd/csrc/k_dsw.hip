@@ -1247,8 +1247,10 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   if (phases & (4 | 128)) {
   // winds A2: divergence damping
-  launch_divergence_damping(g, m, u, v, va, W.vort_b, ua, divgd, vc, uc, delpc, W.ke, W.wk, dt, d_d2, kstart, nonzero_nord,
-                            cfg->dddmp, cfg->d4_bg, W.da, W.db, st);
+  if (nonzero_nord < 0 || nonzero_nord > 3) return PACE_ERR_UNSUPPORTED;  // (as pace_divergence_damping: halo 3)
+  if ((rc = launch_divergence_damping(g, m, u, v, va, W.vort_b, ua, divgd, vc, uc, delpc, W.ke, W.wk, dt, d_d2, kstart, nonzero_nord,
+                                      cfg->dddmp, cfg->d4_bg, W.da, W.db, st)))
+    return rc;
   // vorticity transport
   // vorticity: transport of the absolute vorticity (wk + fC_agrid) -> W.fy2, W.fyv (own flux buffers: the mass fluxes
   // in W.fx / W.fy may still be in use by phase 2 on another stream) and the del-n damping fluxes of the relative

@@ -4,6 +4,8 @@
 // full 3-D temporaries.  Here: ONE kernel.  A workgroup owns a TI x TJ tile of one level, stages the
 // (TI+6) x (TJ+6) footprint of q in LDS, runs the five sweeps tile-locally and writes only the two
 // flux fields.  HBM-bound: algorithmic traffic = 5-7 reads + 2 writes of 3-D fields.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -28,6 +30,13 @@ static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the tr
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
+// The metric fields this kernel reads (kernel arguments live in SGPRs: the full pace_metrics_t is 43 pointers, and the
+// register allocator answered with ~300 SGPR spills -- v_readlane / v_writelane traffic on the vector pipe)
+struct FvMet {
+  const real *area, *rarea, *dxa, *dya, *dx, *dy, *del6_u, *del6_v;
+};
+static inline FvMet fv_met(const Met& m) { return FvMet{m.area, m.rarea, m.dxa, m.dya, m.dx, m.dy, m.del6_u, m.del6_v}; }
+
 // Workgroup -> (tile, level).  Workgroups are handed to the eight XCDs round-robin in launch order, and every XCD has its own
 // 4 MB L2: with the plain (x, y, z) order, neighbouring tiles of a level land on DIFFERENT XCDs and every line of their
 // overlapping footprints is fetched from memory once per XCD (measured: 1.9 x the algorithmic bytes).  Here a level belongs to
@@ -39,6 +48,48 @@ struct TileId {
 __device__ __forceinline__ TileId tile_of_workgroup() {
 #if defined(PACE_EMU) || defined(FV_PLAIN_ORDER)
   return TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#elif defined(FV_LPT_ORDER)
+  // slowest tiles first (corner, then edge, then interior tiles; all levels of a class before the next class) so that the tail
+  // of the launch consists of the fast interior workgroups
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nlev = gridDim.z;
+    int b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int ncorner = (gx > 1 ? 2 : 1) * (gy > 1 ? 2 : 1);
+    const int nedge = 2 * (gx > 2 ? gx - 2 : 0) * (gy > 1 ? 1 : 0) + 2 * (gy > 2 ? gy - 2 : 0) * (gx > 1 ? 1 : 0) ;
+    int t, lev;
+    if (b < ncorner * nlev) {
+      lev = b / ncorner; t = b - lev * ncorner;
+      const int cx = t & 1, cy = (gx > 1) ? (t >> 1) : t;
+      return TileId{(gx > 1 && cx) ? gx - 1 : 0, cy ? gy - 1 : 0, lev};
+    }
+    b -= ncorner * nlev;
+    if (b < nedge * nlev && gx > 1 && gy > 1) {
+      lev = b / nedge; t = b - lev * nedge;
+      const int nx = 2 * (gx - 2);
+      if (t < nx) return TileId{1 + (t >> 1), (t & 1) ? gy - 1 : 0, lev};
+      t -= nx;
+      return TileId{(t & 1) ? gx - 1 : 0, 1 + (t >> 1), lev};
+    }
+    if (gx > 1 && gy > 1) b -= nedge * nlev;
+    const int ix = gx > 2 ? gx - 2 : 0, iy = gy > 2 ? gy - 2 : 0;
+    const int nint = ix * iy;
+    if (nint > 0 && gx > 1 && gy > 1) {
+      // interior tiles: a level belongs to one XCD as in the default map
+      const int full = (nlev / 8) * 8;
+      if (b < full * nint) {
+        const int xcd = b & 7, slot = b >> 3;
+        lev = (slot / nint) * 8 + xcd;
+        t = slot - (slot / nint) * nint;
+      } else {
+        lev = b / nint;
+        t = b - lev * nint;
+      }
+      return TileId{1 + t % ix, 1 + t / ix, lev};
+    }
+    // degenerate grids (a single row / column of tiles): plain order of what is left
+    lev = b / (gx * gy); t = b - lev * (gx * gy);
+    return TileId{t % gx, t / gx, lev};
+  }
 #else
   const int gx = gridDim.x, gy = gridDim.y, nlev = gridDim.z;
   const int tpl = gx * gy;
@@ -60,12 +111,12 @@ __device__ __forceinline__ TileId tile_of_workgroup() {
 // Stage-time instrumentation (experiments only: `make prof` builds build/prof/libpace_prof.so with -DFV_PROF; the product
 // library contains none of this).  One interior workgroup per level records the shader clock at every stage boundary.
 #ifdef FV_PROF
-__device__ long long g_fv_prof[256 * 16];
-#define STAMP(n)                                                                               \
-  if (threadIdx.x == 0 && blockIdx.x == 2 && blockIdx.y == 3 && blockIdx.z < 256)             \
-  g_fv_prof[blockIdx.z * 16 + (n)] = (long long)__builtin_readcyclecounter()
+__device__ long long g_fv_prof[2 * 256 * 16];  // [interior tile (2, 3) | corner tile (0, 0)][level][stamp]
+#define STAMP(n)                                                                                        \
+  if (tid == 0 && wg.bz < 256 && ((wg.bx == 2 && wg.by == 3) || (wg.bx == 0 && wg.by == 0)))         \
+  g_fv_prof[((wg.bx == 0) * 256 + wg.bz) * 16 + (n)] = (long long)__builtin_readcyclecounter()
 extern "C" int pace_debug_fv_prof(long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fv_prof), sizeof(long long) * 256 * 16);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fv_prof), sizeof(long long) * 2 * 256 * 16);
 }
 #else
 #define STAMP(n)
@@ -90,7 +141,38 @@ struct FvLds {
   static constexpr int kNeed = kDamp > kEpi ? kDamp : kEpi;
   static constexpr int kPad = kNeed > kSweep ? kNeed - kSweep : 1;
   double pad[kPad];
+#if FV_PF
+  unsigned pf_dummy[64];
+#endif
 };
+
+// EXPERIMENT (-DFV_PF=n): warm the L2 with the lines a later stage will load, through LDS-DMA loads into a dummy LDS area
+// (no VGPR destination, nothing waits for them): thread t touches the 128-byte segment (t % 4) of row (t / 4) of the window.
+#ifndef FV_PF
+#define FV_PF 0
+#endif
+#ifndef FV_DN_EARLY
+#define FV_DN_EARLY 0
+#endif
+#if FV_PF && !defined(PACE_EMU)
+__device__ __forceinline__ void pf_touch(const real* base, unsigned off, unsigned lds_addr) {
+  const char* a = (const char*)base + off;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(a), "s"(lds_addr) : "memory", "m0");
+}
+// rows [r0, r0 + nr) x byte columns [cb, cb + nb) of the level at byte offset kb8
+__device__ __forceinline__ void pf_window(const real* base, unsigned kb8, int r0, int nr, int cb, int nb, int sj8, int tid,
+                                          unsigned lds_addr) {
+  if (tid < nr * 4) {
+    const int r = tid >> 2, sgm = tid & 3;
+    int c = cb + sgm * 128;
+    c = c < cb + nb - 4 ? c : cb + nb - 4;
+    pf_touch(base, kb8 + (unsigned)(__mul24(r0 + r, sj8) + c), lds_addr);
+  }
+}
+#define PF_WINDOW(...) pf_window(__VA_ARGS__)
+#else
+#define PF_WINDOW(...)
+#endif
 
 #ifndef FV_RF
 #define FV_RF 5
@@ -104,7 +186,7 @@ static_assert((GX - 1) * RF + RF + 4 < 2 * (QW + 1), "an x-run may overrun its r
 static_assert(QW * GY <= 256 && QH * GX <= 256 && (TJ + 3) * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
 template <int MORD, bool EX, bool EY, int DMODE, int EPI>
-__device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, const Met& m, const real* __restrict__ q,
+__device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, const FvMet& m, const real* __restrict__ q,
                                             const real* __restrict__ crx, const real* __restrict__ cry,
                                             const real* __restrict__ xfx, const real* __restrict__ yfx,
                                             real* __restrict__ fx, real* __restrict__ fy,
@@ -136,6 +218,13 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   double cx_keep[RF], cy_keep[RF];
 
   STAMP(0);
+  DelnMet DM;
+  if (DMODE >= 0) {
+#if FV_DN_EARLY
+    deln_load(g, m, i0, j0, DM);
+#endif
+    deln_stage_metrics(g, m, &L.syin[0][0] + DH * DWP, &L.syin[0][0] + 2 * DH * DWP, i0, j0);
+  }
   // stage 0: q with corners copied in the y direction (copy_corners_y, corners.py:367-425).
   // All of a thread's loads are issued before the first of them is consumed (the straightforward loop waits for every
   // iteration's load before issuing the next one: 4.5 exposed memory latencies per workgroup, measured with FV_PROF).
@@ -160,29 +249,50 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       if (e < QW * QH) sq[jj][ii] = v0[t];
     }
   }
+#if FV_PF && !defined(PACE_EMU)
+  const unsigned pf_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)&L.pf_dummy[0]);
+  {
+    // clamp the windows to the storage (edge tiles)
+    const int ra = j0 < 0 ? 0 : j0, rb = jlo < 0 ? 0 : jlo;
+    const int na = (j0 + TJ + 1 <= g.nj ? j0 + TJ + 1 : g.nj) - ra, nb = (jlo + QH <= g.nj ? jlo + QH : g.nj) - rb;
+    const int ca = (ilo < 0 ? 0 : ilo) * E8, cb = i0 * E8;
+    const int wa = ((ilo + QW <= g.ni ? ilo + QW : g.ni)) * E8 - ca, wb = ((i0 + TI + 1 <= g.ni ? i0 + TI + 1 : g.ni)) * E8 - cb;
+    PF_WINDOW(cry, kb8, ra, na, ca, wa, sj8, tid, pf_lds);
+    PF_WINDOW(yfx, kb8, ra, na, ca, wa, sj8, tid, pf_lds);
+    PF_WINDOW(crx, kb8, rb, nb, cb, wb, sj8, tid, pf_lds);
+    PF_WINDOW(xfx, kb8, rb, nb, cb, wb, sj8, tid, pf_lds);
+#if FV_PF >= 3
+    PF_WINDOW(xunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
+    PF_WINDOW(yunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
+    if (EPI > 0) PF_WINDOW(dp.amass, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
+    if (DMODE == 2) PF_WINDOW(dp.mass, kb8, (j0 > 0 ? j0 - 1 : 0), na, (i0 - 1) * E8, wb + E8, sj8, tid, pf_lds);
+#endif
+  }
+#endif
   __syncthreads();
   STAMP(1);
 
-  // fused damping: iterate in the LDS space the sweeps will use afterwards, keep this thread's face values in registers
+  // fused damping: the passes run in the LDS space the sweeps will use afterwards; this thread's face values stay in registers
   double dvx[RF], dvy[RF];
   double damp = 0.0;
   if (DMODE >= 0) {
-    static_assert(DMODE < 0 || sizeof(L.syin) + sizeof(L.sqi) + sizeof(L.sxin) + sizeof(L.pad) >= 3 * DH * DWP * sizeof(real),
+    static_assert(DMODE < 0 || sizeof(L.syin) + sizeof(L.sqi) + sizeof(L.sxin) + sizeof(L.pad) >= 3 * DH * DWP * sizeof(double),
                   "scratch");
-    double* sd = &L.syin[0][0];
-    double* sfx = sd + DH * DWP;
-    double* sfy = sfx + DH * DWP;
+    double* pa = &L.syin[0][0];
+    const double* sdv = pa + DH * DWP;
+    const double* sdu = sdv + DH * DWP;
     damp = dp.damp_k[k];
-    delnflux_core(g, m, &sq[0][0], sd, sfx, sfy, i0, j0, dp.mass_given ? 1.0 : damp, dp.nord_k[k] > 0.0, dp.nmax);
+#if !FV_DN_EARLY
+    deln_load(g, m, i0, j0, DM);
+#endif
+    const DelnResult R = deln_iterate(g, m, DM, &sq[0][0], sdv, sdu, pa, i0, j0, dp.mass_given ? 1.0 : damp, dp.nord_k[k] > 0.0, dp.nmax);
     if (x5_on) {
-      const int jj = x5_row, grp = x5_grp;
 #pragma unroll
-      for (int f = 0; f < RF; ++f) dvx[f] = (grp * RF + f <= TI) ? sfx[(jj + 3) * DWP + grp * RF + f + 3] : 0.0;
+      for (int f = 0; f < RF; ++f) dvx[f] = (x5_grp * RF + f <= TI) ? deln_face_x(R, sdv[(x5_row + 3) * DWP + x5_grp * RF + f + 3], x5_grp * RF + f + 3, x5_row + 3) : 0.0;
     }
     if (y5_on) {
-      const int grp = y5_grp, ii = y5_col;
 #pragma unroll
-      for (int f = 0; f < RF; ++f) dvy[f] = (grp * RF + f <= TJ) ? sfy[(grp * RF + f + 3) * DWP + ii + 3] : 0.0;
+      for (int f = 0; f < RF; ++f) dvy[f] = (y5_grp * RF + f <= TJ) ? deln_face_y(R, sdu[(y5_grp * RF + f + 3) * DWP + y5_col + 3], y5_col + 3, y5_grp * RF + f + 3) : 0.0;
     }
     __syncthreads();
   }
@@ -199,6 +309,17 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
 
   STAMP(2);
+#if FV_PF == 2 && !defined(PACE_EMU)
+  {
+    const int ra = j0, cb = i0 * E8;
+    const int na = (j0 + TJ + 1 <= g.nj ? j0 + TJ + 1 : g.nj) - ra;
+    const int wb = ((i0 + TI + 1 <= g.ni ? i0 + TI + 1 : g.ni)) * E8 - cb;
+    PF_WINDOW(xunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
+    PF_WINDOW(yunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
+    if (EPI > 0) PF_WINDOW(dp.amass, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
+    if (DMODE == 2) PF_WINDOW(dp.mass, kb8, (j0 > 0 ? j0 - 1 : 0), na, (i0 - 1) * E8, wb + E8, sj8, tid, pf_lds);
+  }
+#endif
   // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1)): one run of RF interfaces of one
   // column per thread, lanes along i
   if (tid < QW * GY) {
@@ -531,8 +652,11 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   STAMP(10);
 }
 
+#ifndef FV_WAVES
+#define FV_WAVES 4
+#endif
 template <int MORD, int DMODE, int EPI>
-__global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const real* __restrict__ q,
+__global__ void __launch_bounds__(256, FV_WAVES) k_fvtp2d(Geo g, FvMet m, const real* __restrict__ q,
                                                 const real* __restrict__ crx, const real* __restrict__ cry,
                                                 const real* __restrict__ xfx, const real* __restrict__ yfx,
                                                 real* __restrict__ fx, real* __restrict__ fy,
@@ -558,7 +682,7 @@ __global__ void __launch_bounds__(256, 4) k_fvtp2d(Geo g, Met m, const real* __r
 // time, so one of the two finds them in the CU's L1.  The halves pass the same barriers: the caller guarantees equal damping
 // orders on every level.
 template <int MORD, int DMODE, int EPI>
-__global__ void __launch_bounds__(512, 4) k_fvtp2d_pair(Geo g, Met m, const real* __restrict__ qa, const real* __restrict__ qb,
+__global__ void __launch_bounds__(512, 4) k_fvtp2d_pair(Geo g, FvMet m, const real* __restrict__ qa, const real* __restrict__ qb,
                                                      const real* __restrict__ crx, const real* __restrict__ cry,
                                                      const real* __restrict__ xfx, const real* __restrict__ yfx,
                                                      const real* __restrict__ xunit, const real* __restrict__ yunit, FvDamp dpa,
@@ -582,20 +706,50 @@ int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real
                           const real* xfx, const real* yfx, const real* xmf, const real* ymf, int hord, int nlev,
                           const FvDamp& dpa, const FvDamp& dpb, hipStream_t st) {
   if (hord != 6 || dpa.nmax != dpb.nmax || dpa.nmax > 2) return PACE_ERR_UNSUPPORTED;
+#if defined(FV_FAST_BUILD) || defined(FV_ONLY_621)
+  return PACE_ERR_UNSUPPORTED;
+#else
   const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
-  hipLaunchKernelGGL((k_fvtp2d_pair<6, 2, 1>), grid, dim3(512), 0, st, g, m, qa, qb, crx, cry, xfx, yfx, xmf, ymf, dpa, dpb);
+  hipLaunchKernelGGL((k_fvtp2d_pair<6, 2, 1>), grid, dim3(512), 0, st, g, fv_met(m), qa, qb, crx, cry, xfx, yfx, xmf, ymf, dpa, dpb);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
+#endif
 }
 
+#ifdef FV_PROF
+static int fv_dynlds() {
+  static const int v = getenv("PACE_FV_DYNLDS") ? atoi(getenv("PACE_FV_DYNLDS")) : 0;
+  return v;
+}
+#define FV_DYNLDS fv_dynlds()
+#else
+#define FV_DYNLDS 0
+#endif
 #define FV_LAUNCH(D, E) \
-  hipLaunchKernelGGL((k_fvtp2d<MORD, D, E>), grid, block, 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp)
+  hipLaunchKernelGGL((k_fvtp2d<MORD, D, E>), grid, block, FV_DYNLDS, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp)
 
 template <int MORD>
 static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g, const Met& m, const real* q,
                        const real* crx, const real* cry, const real* xfx, const real* yfx, real* fx, real* fy,
                        const real* xu, const real* yu, const FvDamp& dp) {
   const dim3 block(256);
+#ifdef FV_FAST_BUILD  // experiment builds (tools/build_variant.sh): only the instances d_sw uses with hord 6
+  if (MORD != 6) return PACE_ERR_UNSUPPORTED;
+  if constexpr (MORD == 6) {
+    if (epi == 0 && dmode == 1) FV_LAUNCH(1, 0);
+    else if (epi == 0 && dmode == 0) FV_LAUNCH(0, 0);
+    else if (epi == 0 && dmode == -1) FV_LAUNCH(-1, 0);
+    else if (epi == 2 && dmode == 0) FV_LAUNCH(0, 2);
+    else if (epi == 1 && dmode == 2) FV_LAUNCH(2, 1);
+    else return PACE_ERR_UNSUPPORTED;
+  }
+  return PACE_OK;
+#elif defined(FV_ONLY_621)  // register-budget experiments: one instance
+  if constexpr (MORD == 6) {
+    if (epi == 1 && dmode == 2) { FV_LAUNCH(2, 1); return PACE_OK; }
+  }
+  return PACE_ERR_UNSUPPORTED;
+#else
   if (epi == 0) {
     switch (dmode) {
       case 0: FV_LAUNCH(0, 0); break;
@@ -618,6 +772,7 @@ static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo&
     FV_LAUNCH(0, 3);
   }
   return PACE_OK;
+#endif
 }
 
 // The general launcher.  dmode -1: transport only; otherwise the del-n damping of q is fused (see FvDamp).  epi 0:
@@ -632,10 +787,12 @@ int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx,
   int rc;
   if (hord == 5) rc = launch_mode<5>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
   else if (hord == 6) rc = launch_mode<6>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+#if !defined(FV_FAST_BUILD) && !defined(FV_ONLY_621)
   else if (hord == 8 && dmode == -1 && epi == 0) {  // monotone PPM: tracer advection (plain transport only)
-    hipLaunchKernelGGL((k_fvtp2d<8, -1, 0>), grid, dim3(256), 0, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+    hipLaunchKernelGGL((k_fvtp2d<8, -1, 0>), grid, dim3(256), 0, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
     rc = PACE_OK;
   }
+#endif
   else return PACE_ERR_UNSUPPORTED;
   if (rc) return rc;
   PACE_CHECK_LAUNCH();

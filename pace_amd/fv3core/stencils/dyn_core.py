@@ -250,7 +250,11 @@ class AcousticDynamics(Operator):
             csw_args = (state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._ut, self._vt,
                         self._divgd, state.omga, dt2)
             # while the u / v (and w) strips travel: the part of c_sw's first pass that reads no halo value of u / v
-            csw.start_interior(*csw_args)
+            # (not with a checkpointer attached: the "C_SW-In" / "D_SW-In" savepoints must hold the state BEFORE the call, as the
+            # reference's do -- the early starts already overwrite uad / vad, xfx / yfx / crx / cry and accumulate cx / cy)
+            early = not self.call_checkpointer
+            if early:
+                csw.start_interior(*csw_args)
             halo.u__v.wait()
             halo.w.wait()
             self._checkpoint_csw(state, tag="In")
@@ -273,7 +277,8 @@ class AcousticDynamics(Operator):
                         state.mfxd, state.mfyd, state.cxd, state.cyd, self._crx, self._cry, self._xfx, self._yfx, state.q_con,
                         self._zh, self._heat_source, state.diss_estd, dt_acoustic_substep)
             # while the uc / vc strips travel: the interior of d_sw's flux preparation (it reads no halo value of uc / vc)
-            self.dgrid_shallow_water_lagrangian_dynamics.start_flux_preparation(*dsw_args)
+            if early:
+                self.dgrid_shallow_water_lagrangian_dynamics.start_flux_preparation(*dsw_args)
             if cfg.nord > 0:
                 halo.divgd.wait()
             halo.uc__vc.wait()

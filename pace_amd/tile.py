@@ -90,11 +90,13 @@ def run_d_sw(env, col, inputs, dt, ut0=None, vt0=None, cfg=None):
                                               stretched_grid=False, config=config)
     if ut0 is not None:
         # uc_contra / vc_contra carried from the previous call live at the head of the workspace
+        # (the workspace tensor is float64; the kernels carve it in the library's storage type)
+        ws = obj._workspace.view(env.qf.real)
         tmp = env.q3(ut0)
         n = tmp._base.numel()
-        obj._workspace[:n] = tmp._base.reshape(-1)
+        ws[:n] = tmp._base.reshape(-1)
         tmp = env.q3(vt0)
-        obj._workspace[n : 2 * n] = tmp._base.reshape(-1)
+        ws[n : 2 * n] = tmp._base.reshape(-1)
     f = {k: env.q3(inputs[k]) for k in DSW_ARGS}
     obj(*[f[k] for k in DSW_ARGS], dt)
     if env.qf.device.type == "cuda":

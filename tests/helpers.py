@@ -277,6 +277,8 @@ def _child_main(what, out_path, hard_exit=False):
         result = run_dycore_six_tiles(lib, "cuda", prefix="dycore_kord10_c12")
     elif what == "dycore_f32":
         result = run_dycore_six_tiles(_lib.load(32), "cuda")
+    elif what == "dycore_c384_f32":
+        result = (run_dycore_one_tile_synthetic(_lib.load(32), "cuda", 384, 91), run_dycore_one_tile_synthetic(_lib.load(32), "cuda", 384, 91))
     elif what == "dycore_generated":
         result = (run_dycore_six_tiles(lib, "cuda", generated="metrics"), run_dycore_six_tiles(lib, "cuda", generated="all"))
     else:
@@ -307,6 +309,48 @@ def run_in_child(what, tmp_path):
         raise RuntimeError(report)
     with open(out, "rb") as f:
         return pickle.load(f)
+
+
+def run_dycore_one_tile_synthetic(lib, device, n, nz, n_split=2):
+    """One DynamicalCore.step_dynamics of ONE tile at any size behind a lone-rank LoopbackComm (each halo receives what the tile
+    itself sent to that neighbour), pace_amd/synthetic.py's balanced state + smooth condensates.  Returns the prognostic fields
+    after the step as numpy arrays (compute domain)."""
+    import datetime
+
+    import torch
+
+    from pace_amd import synthetic
+    from pace_amd.fv3core import DynamicalCoreConfig
+    from pace_amd.fv3core.initialization.dycore_state import DycoreState
+    from pace_amd.fv3core.stencils.fv_dynamics import DynamicalCore
+    from pace_amd.util import CubedSphereCommunicator, LoopbackComm
+    from pace_amd.util import constants as c
+
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    dt_atmos = float(s["dt"]) * n_split
+    env = Env(lib, device, metrics, n, nz)
+    cube = CubedSphereCommunicator(LoopbackComm(rank=0, total_ranks=6), device=device, lib=lib)
+    arrays = {k: s[k] for k in "u v w delz delp pt pe uc vc ua va q_con".split()}
+    with np.errstate(all="ignore"):
+        arrays["peln"] = np.log(s["pe"])
+        arrays["pk"] = np.exp(c.KAPPA * arrays["peln"])
+    arrays["phis"] = c.GRAV * s["zs"]
+    arrays["ps"] = s["pe"][:, :, nz]
+    arrays["pt"] = s["pt"] * np.exp(c.KAPPA * np.log(1.0e5))
+    arrays["qvapor"] = 0.01 * np.exp(-6.0 * (1.0 - s["pe"] / s["pe"][:, :, nz:])) * (s["delp"] > 0)
+    for name, f in dycore_condensates(0, s["delp"].shape).items():
+        arrays[name] = np.abs(f)
+    state = DycoreState.init_from_numpy_arrays(arrays, env.qf)
+    config = DynamicalCoreConfig(npx=n + 1, npy=n + 1, npz=nz, dt_atmos=dt_atmos, k_split=1, n_split=n_split,
+                                 acoustic_dynamics=acoustic_config(n_split))
+    core = DynamicalCore(cube, env.grid_data, env.stencil_factory, env.qf, env.damping, config, state.phis, state,
+                         datetime.timedelta(seconds=dt_atmos))
+    core.step_dynamics(state)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    W = (slice(3, 3 + n), slice(3, 3 + n), slice(0, nz))
+    return {k: getattr(state, k).numpy()[W].copy() for k in "u v w delz delp pt pe pk peln q_con qvapor qliquid".split() if hasattr(state, k)}
 
 
 # ---- vertical remapping (tests/golden/remap_c12.npz: a run of the reference's MapSingle, tools/make_golden_remap.py) ----

@@ -639,18 +639,19 @@ def test_every_operator_of_the_loop_matches_oracle(lib, n):
         json.dump(report, open(os.path.join(out_dir, f"operator_errors_c{n}.json"), "w"), indent=1)
 
 
-def _loop_child(n, nz, n_split, out_path):
+def _loop_child(n, nz, n_split, out_path, geometry="synthetic", timestep=None):
     import pickle
 
     import opchain
     from pace_amd import _lib
 
-    got = opchain.product_loop(_lib.load(), "cuda", n, nz, n_split, 3.571 * n_split)
+    got = opchain.product_loop(_lib.load(), "cuda", n, nz, n_split, timestep or 3.571 * n_split, geometry)
     with open(out_path, "wb") as f:
         pickle.dump(got, f)
 
 
-def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path):
+@pytest.mark.parametrize("geometry", ["synthetic", "sphere"])
+def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path, geometry):
     """BASELINE configuration 3: the FULL acoustic loop (c_sw, updatedzc, riem_solver_c, p_grad_c, d_sw, updatedzd,
     riem_solver3, pe / pk3 halo, nh_p_grad, ray_fast, del2cubed, heating; every halo-update group) at C96 x 79, six tiles
     resident on the device and joined by the cubed-sphere exchange, every operator running on its predecessor's output,
@@ -665,20 +666,24 @@ def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path):
     import opchain
 
     n, nz, n_split = 96, 79, 1
+    # synthetic: six copies of pace_amd/synthetic.py's tile (dt from its own Courant number); sphere: the gnomonic cubed sphere
+    # with the baroclinic case's state (tests/opchain.py six_tile_inputs_sphere) and the C96 namelist's acoustic substep
+    timestep = 3.571 * n_split if geometry == "synthetic" else 112.5 * n_split
     out = os.path.join(str(tmp_path), "loop.pkl")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (f"import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); "
-            f"import test_gpu_parity as t; t._loop_child({n}, {nz}, {n_split}, {out!r})")
+            f"import test_gpu_parity as t; t._loop_child({n}, {nz}, {n_split}, {out!r}, {geometry!r}, {timestep!r})")
     child = subprocess.Popen([sys.executable, "-X", "faulthandler", "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    ref = opchain.oracle_loop(n, nz, n_split, 3.571 * n_split)  # the oracle runs on the host while the device works
+    ref = opchain.oracle_loop(n, nz, n_split, timestep, geometry)  # the oracle runs on the host while the device works
     so, se = child.communicate(timeout=900)
     assert child.returncode == 0, (child.returncode, so[-2000:], se[-4000:])
     with open(out, "rb") as f:
         got = pickle.load(f)
-    errs = opchain.loop_errors(ref, got, n, nz)
+    detail = {}
+    errs = opchain.loop_errors(ref, got, n, nz, detail=detail)
     out_dir = os.path.join(root, "gpurun_out")
     if os.path.isdir(out_dir):
-        json.dump(errs, open(os.path.join(out_dir, "acoustic_loop_c96_gpu_errors.json"), "w"), indent=1)
+        json.dump(detail, open(os.path.join(out_dir, f"acoustic_loop_c96_{geometry}_gpu_errors.json"), "w"), indent=1)
     for k, e in errs.items():
         assert e < opchain.LOOP_TOL.get(k, 1e-9), (k, e)
 
