@@ -164,7 +164,8 @@ def baroclinic_substep_inputs(lib, device, n, nz, tile, dt_atmos=None, cache_dir
 
             # the current device is per THREAD: a tile thread would otherwise launch on device 0's streams (rank r of a
             # multi-GPU run owns device r)
-            torch.cuda.set_device(torch.device(device))
+            d = torch.device(device)
+            torch.cuda.set_device(d if d.index is not None else torch.device("cuda", torch.cuda.current_device()))
         metrics = {k: v for k, v in tiles[t].items() if k not in ("ee1", "ee2", "es1", "ew2")}
         env = Env(lib, device, metrics, n, nz)
         cube = CubedSphereCommunicator(comm, device=device, lib=lib)

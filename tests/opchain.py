@@ -290,10 +290,26 @@ class ProductOps:
         return f
 
 
-def check_case(ops, case, scale_tol=1.0, report=None):
+# On a BALANCED state (the baroclinic case on the sphere) the C-grid solver's perturbation pressure pkc is (full pressure -
+# hydrostatic pressure), 1e-4 ... 1e-3 of either, and both come out of exp / log whose last place differs between the device
+# and numpy: 1e-16 of the pressure is 1e-12 of the perturbation (measured on MI355X: 1.1e-12 of max |pkc| at C48 and C96; the
+# synthetic state, whose perturbation is as large as the pressure, gives 1.5e-15).  The height gz it returns inherits the same
+# through the dz update.  (operator, variable) -> (tolerance of the relative metric, floor as a fraction of the magnitude,
+# bound on max |error| / magnitude or None where the window holds fill values).  Every operator WITHOUT a transcendental is
+# held to an absolute error of 1e-14 of the magnitude on the sphere as well (measured: exactly 0).
+SPHERE_CHECKS = {("riem_solver_c", "pkc"): (1e-9, 1e-2, 1e-11), ("riem_solver_c", "gz"): (1e-11, 0.0, None)}
+# the operators of the single-tile chain that make sense on a captured sphere state: the chain has no halo exchanges (the
+# synthetic state is defined on the whole storage; a captured tile's halos are those of ONE instant of the loop), so from the
+# D-grid vertical solver on the chain runs on inconsistent halo columns.  riem_solver3 on the sphere: the full-field test of
+# tests/test_gpu_sphere.py; the operators after it: the six-tile loop with its exchanges (geometry "sphere").
+SPHERE_CHAIN = ("d2a2c_vect", "c_sw", "updatedzc", "riem_solver_c", "p_grad_c", "d_sw", "updatedzd")
+
+
+def check_case(ops, case, scale_tol=1.0, report=None, sphere=False):
     """Run the product operator on case.before and compare with case.after.  Returns {variable: error}."""
     f = ops.run(case.name, case.before)
     errs = {}
+    bad = []
     for var, win, nk, tol, nz_frac in case.checks:
         ref = case.after[var]
         got = f[var].numpy()
@@ -302,12 +318,23 @@ def check_case(ops, case, scale_tol=1.0, report=None):
         else:
             r, gt = ref[win], got[win]
         assert np.isfinite(r).all(), (case.name, var, "oracle produced non-finite values")
-        near = nz_frac * float(np.abs(r).max()) if nz_frac else 0.0
+        scale = float(np.abs(r).max())
+        abs_tol = max(tol, 1e-14)
+        if sphere and (case.name, var) in SPHERE_CHECKS:
+            tol, nz_frac, abs_tol = SPHERE_CHECKS[(case.name, var)]
+        near = nz_frac * scale if nz_frac else 0.0
         e = compare(r, gt, near_zero=near)
         errs[var] = e
+        ab = float(np.abs(r - gt).max()) / (scale + 1e-300)
         if report is not None:
             report.setdefault(case.name, {})[var] = e
-        assert e <= tol * scale_tol, (case.name, var, e, tol)
+            report[case.name][var + ".metric_no_floor"] = compare(r, gt)
+            report[case.name][var + ".abs_over_magnitude"] = ab
+        if not e <= tol * scale_tol:
+            bad.append((case.name, var, e, tol))
+        if sphere and abs_tol is not None and not ab <= abs_tol * scale_tol:  # the absolute error, everywhere
+            bad.append((case.name, var, "abs/magnitude", ab, abs_tol))
+    assert not bad, bad
     return errs
 
 
