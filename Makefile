@@ -63,6 +63,18 @@ emu-small: tests/emu/libpace_emu_small.so
 tests/emu/libpace_emu_small.so: $(SMALLOBJS) build/emu/hip_emu.o
 	g++ -shared -fPIC $(SMALLOBJS) build/emu/hip_emu.o -o $@
 
+# the same, with 8 x 8 transport tiles and runs of 3 interfaces: at C16 / C24 every tile edge coincides with a tile boundary of
+# the workgroup tiling AND the run geometry satisfies ppm_run_canon's conditions (AHI = 2), so the CPU test-suite exercises the
+# canonical edge path the C96 ... C384 production tiling takes
+CANONFLAGS := $(EMUFLAGS) -DFV_TI=8 -DFV_TJ=8 -DDN_TI=8 -DDN_TJ=8 -DFV_RF=3
+CANONOBJS := $(patsubst $(CSRC)/%.hip,build/emu_canon/%.o,$(SRCS))
+build/emu_canon/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
+	@mkdir -p build/emu_canon
+	g++ $(CANONFLAGS) -c $< -o $@
+emu-canon: tests/emu/libpace_emu_canon.so
+tests/emu/libpace_emu_canon.so: $(CANONOBJS) build/emu/hip_emu.o
+	g++ -shared -fPIC $(CANONOBJS) build/emu/hip_emu.o -o $@
+
 # experiments only: the library with the transport kernel's stage-time instrumentation (tools/fv_stage_times.py)
 PROFOBJS := $(patsubst $(CSRC)/%.hip,build/prof/%.o,$(SRCS))
 build/prof/%.o: $(CSRC)/%.hip $(HDRS)
@@ -73,6 +85,6 @@ build/prof/libpace_prof.so: $(PROFOBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(PROFOBJS) -o $@
 
 clean:
-	rm -rf build pace_amd/libpace_hip.so pace_amd/libpace_hip_f32.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so tests/emu/libpace_emu_f32.so
+	rm -rf build pace_amd/libpace_hip.so pace_amd/libpace_hip_f32.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so tests/emu/libpace_emu_f32.so tests/emu/libpace_emu_canon.so
 
-.PHONY: all f32 emu emu-f32 emu-small prof clean
+.PHONY: all f32 emu emu-f32 emu-small emu-canon prof clean

@@ -82,17 +82,37 @@ __device__ __forceinline__ void remap_agrid_y(const Geo& g, int& i, int& j) {
 // q[] holds the six cell values at positions pos-3 .. pos+2 along the sweep axis, d[] the matching
 // A-grid spacings (only read next to a tile edge).  s/e are the tile start/end along the axis.
 // ---------------------------------------------------------------------------------------------
+// The one-sided forms next to a tile edge read four A-grid spacings along the sweep axis: positions s-2 .. s+1 for the forms
+// at the start of the tile, e-1 .. e+2 at its end.  A "spacing provider" P(lo, idx, base) returns the idx-th of them (lo: the
+// start set; base: the position of idx 0).  SpacingFn adapts a function of the position (a load per call -- under the
+// position tests that is a branch and a wait per interface); EdgeSpacing holds both sets, loaded once per run before the
+// arithmetic (k_fvtp2d.hip: measured 7 serialized L2 round trips per run in the tiles along an edge before).
 template <class DX>
-__device__ __forceinline__ double ppm_al(const double* q, int off, int pos, int s, int e, DX dxa) {
+struct SpacingFn {
+  DX f;
+  __device__ __forceinline__ double operator()(bool, int idx, int base) const { return f(base + idx); }
+};
+struct EdgeSpacing {
+  double S[4], E[4];
+  __device__ __forceinline__ double operator()(bool lo, int idx, int) const { return lo ? S[idx] : E[idx]; }
+};
+
+template <class P>
+__device__ __forceinline__ double ppm_al_p(const double* q, int off, int pos, int s, int e, const P& sp) {
   // q[off + m] is the cell value at position pos + m
   const double qm2 = q[off - 2], qm1 = q[off - 1], q0 = q[off], qp1 = q[off + 1];
   if (pos == s - 1 || pos == e) return PPM_C1 * qm2 + PPM_C2 * qm1 + PPM_C3 * q0;
   if (pos == s || pos == e + 1) {
-    const double dm2 = dxa(pos - 2), dm1 = dxa(pos - 1), d0 = dxa(pos), dp1 = dxa(pos + 1);
+    const bool lo = pos == s;
+    const double dm2 = sp(lo, 0, pos - 2), dm1 = sp(lo, 1, pos - 2), d0 = sp(lo, 2, pos - 2), dp1 = sp(lo, 3, pos - 2);
     return 0.5 * (((2.0 * dm1 + dm2) * qm1 - dm1 * qm2) / (dm2 + dm1) + ((2.0 * d0 + dp1) * q0 - d0 * qp1) / (d0 + dp1));
   }
   if (pos == s + 1 || pos == e + 2) return PPM_C3 * qm1 + PPM_C2 * q0 + PPM_C1 * qp1;
   return PPM_P1 * (qm1 + q0) + PPM_P2 * (qm2 + qp1);
+}
+template <class DX>
+__device__ __forceinline__ double ppm_al(const double* q, int off, int pos, int s, int e, DX dxa) {
+  return ppm_al_p(q, off, pos, s, e, SpacingFn<DX>{dxa});
 }
 
 // Interior form: valid when no interface of the stencil lies within 2 of a tile edge (block-uniform test in the callers).
@@ -157,8 +177,8 @@ __device__ __forceinline__ void pert_ppm_standard_constraint(double& al, double&
   }
 }
 
-template <bool EDGE, int F, class DX>
-__device__ __forceinline__ void ppm_run8(const double* Q, const double* c, int pos0, int s, int e, DX dxa, double* out) {
+template <bool EDGE, int F, class P>
+__device__ __forceinline__ void ppm_run8_p(const double* Q, const double* c, int pos0, int s, int e, const P& sp, double* out) {
   // Q[u] = cell pos0-3+u.  dm at u = 1 .. F+3, al (interface between u-1 and u) at u = 2 .. F+3, cells u = 2 .. F+2
   double dm[F + 5], al[F + 5];
 #pragma unroll
@@ -179,13 +199,15 @@ __device__ __forceinline__ void ppm_run8(const double* Q, const double* c, int p
         const double qm2 = Q[u - 2], qm1 = Q[u - 1], qp1 = Q[u + 1], qp2 = Q[u + 2];
         double xt_bl, xt_br;
         if (x == s - 1 || x == e) {
-          const double d0 = dxa(x), dm1 = dxa(x - 1), dp1 = dxa(x + 1), dp2 = dxa(x + 2);
+          const bool lo = x == s - 1;
+          const double dm1 = sp(lo, 0, x - 1), d0 = sp(lo, 1, x - 1), dp1 = sp(lo, 2, x - 1), dp2 = sp(lo, 3, x - 1);
           double e0 = 0.5 * (((2.0 * d0 + dm1) * q0 - d0 * qm1) / (dm1 + d0) + ((2.0 * dp1 + dp2) * qp1 - dp1 * qp2) / (dp1 + dp2));
           e0 = fmin(fmax(e0, fmin(fmin(fmin(qm1, q0), qp1), qp2)), fmax(fmax(fmax(qm1, q0), qp1), qp2));
           xt_bl = (x == s - 1) ? PPM_S14 * dm[u - 1] + PPM_S11 * (qm1 - q0) + q0 : PPM_S15 * q0 + PPM_S11 * qm1 + PPM_S14 * dm[u - 1];
           xt_br = e0;
         } else if (x == s || x == e + 1) {
-          const double d0 = dxa(x), dm1 = dxa(x - 1), dm2 = dxa(x - 2), dp1 = dxa(x + 1);
+          const bool lo = x == s;
+          const double dm2 = sp(lo, 0, x - 2), dm1 = sp(lo, 1, x - 2), d0 = sp(lo, 2, x - 2), dp1 = sp(lo, 3, x - 2);
           double e1 = 0.5 * (((2.0 * dm1 + dm2) * qm1 - dm1 * qm2) / (dm2 + dm1) + ((2.0 * d0 + dp1) * q0 - d0 * qp1) / (d0 + dp1));
           e1 = fmin(fmax(e1, fmin(fmin(fmin(qm2, qm1), q0), qp1)), fmax(fmax(fmax(qm2, qm1), q0), qp1));
           xt_bl = e1;
@@ -219,18 +241,17 @@ __device__ __forceinline__ void ppm_run8(const double* Q, const double* c, int p
   }
 }
 
+template <bool EDGE, int F, class DX>
+__device__ __forceinline__ void ppm_run8(const double* Q, const double* c, int pos0, int s, int e, DX dxa, double* out) {
+  ppm_run8_p<EDGE, F>(Q, c, pos0, s, e, SpacingFn<DX>{dxa}, out);
+}
+
 // A run of F consecutive interfaces pos0 .. pos0+F-1 evaluated by one thread: the F+2 interface values and the F+1
 // cell reconstructions (bl, br, b0, steepness flag) are computed once and shared, instead of three interface values
 // and two reconstructions per flux.  Q[u] = cell pos0-3+u, u = 0 .. F+4.  Same expressions as ppm_flux6 -> same bits.
-template <int MORD, bool EDGE, int F, class DX>
-__device__ __forceinline__ void ppm_run(const double* Q, const double* c, int pos0, int s, int e, DX dxa, double* out) {
-  if (MORD == 8) {
-    ppm_run8<EDGE, F>(Q, c, pos0, s, e, dxa, out);
-    return;
-  }
-  double al[F + 2];
-#pragma unroll
-  for (int a = 0; a < F + 2; ++a) al[a] = EDGE ? ppm_al(Q, a + 2, pos0 - 1 + a, s, e, dxa) : ppm_al_interior(Q, a + 2);
+// the fluxes of a run from its F + 2 interface values (shared by the forms of ppm_run below)
+template <int MORD, int F>
+__device__ __forceinline__ void ppm_fluxes_from_al(const double* Q, const double* al, const double* c, double* out) {
   double bl[F + 1], br[F + 1], b0[F + 1];
   bool steep[F + 1];
 #pragma unroll
@@ -253,6 +274,56 @@ __device__ __forceinline__ void ppm_run(const double* Q, const double* c, int po
       out[f] = Q[f + 3] + fx1 * mask;
     }
   }
+}
+
+template <int MORD, bool EDGE, int F, class P>
+__device__ __forceinline__ void ppm_run_p(const double* Q, const double* c, int pos0, int s, int e, const P& sp, double* out) {
+  if (MORD == 8) {
+    ppm_run8_p<EDGE, F>(Q, c, pos0, s, e, sp, out);
+    return;
+  }
+#ifdef FV_X_NOPPM
+#pragma unroll
+  for (int f = 0; f < F; ++f) out[f] = (c[f] > 0.0) ? Q[f + 2] : Q[f + 3];
+  return;
+#endif
+  double al[F + 2];
+#pragma unroll
+  for (int a = 0; a < F + 2; ++a) al[a] = EDGE ? ppm_al_p(Q, a + 2, pos0 - 1 + a, s, e, sp) : ppm_al_interior(Q, a + 2);
+  ppm_fluxes_from_al<MORD, F>(Q, al, c, out);
+}
+
+// The same for a run whose one-sided interface values sit at positions known at compile time: the run's interface values
+// number A, A + 1, A + 2 lie at s-1, s, s+1 (lo: the start of the tile) or e, e+1, e+2 (its end).  ppm_al_p finds them by
+// comparing every interface position with s and e -- three branches per interface value, and since each wave of an x-sweep
+// holds a lane next to the edge, every wave of an edge tile walked through all of that (measured: 6.4 k instead of 3.4 k
+// cycles per sweep).  Here: interior form everywhere, then the three values of the edge lane are overwritten.  Same
+// expressions as ppm_al_p -> same bits.
+template <int A, class P>
+__device__ __forceinline__ void ppm_patch_edge(double* al, const double* Q, bool lo, const P& sp) {
+  al[A] = PPM_C1 * Q[A] + PPM_C2 * Q[A + 1] + PPM_C3 * Q[A + 2];
+  {
+    const double qm2 = Q[A + 1], qm1 = Q[A + 2], q0 = Q[A + 3], qp1 = Q[A + 4];
+    const double dm2 = sp(lo, 0, 0), dm1 = sp(lo, 1, 0), d0 = sp(lo, 2, 0), dp1 = sp(lo, 3, 0);
+    al[A + 1] = 0.5 * (((2.0 * dm1 + dm2) * qm1 - dm1 * qm2) / (dm2 + dm1) + ((2.0 * d0 + dp1) * q0 - d0 * qp1) / (d0 + dp1));
+  }
+  al[A + 2] = PPM_C3 * Q[A + 3] + PPM_C2 * Q[A + 4] + PPM_C1 * Q[A + 5];
+}
+// lane_lo: this run starts at the first interface of the tile (A = 0); lane_hi: it holds the end of the tile at A = AHI
+template <int MORD, int F, int AHI>
+__device__ __forceinline__ void ppm_run_canon(const double* Q, const double* c, bool lane_lo, bool lane_hi, const EdgeSpacing& sp,
+                                              double* out) {
+  static_assert(MORD != 8 && AHI >= 0 && AHI <= F - 1, "ppm_run_canon");
+  double al[F + 2];
+#pragma unroll
+  for (int a = 0; a < F + 2; ++a) al[a] = ppm_al_interior(Q, a + 2);
+  if (lane_lo) ppm_patch_edge<0>(al, Q, true, sp);
+  if (lane_hi) ppm_patch_edge<AHI>(al, Q, false, sp);
+  ppm_fluxes_from_al<MORD, F>(Q, al, c, out);
+}
+template <int MORD, bool EDGE, int F, class DX>
+__device__ __forceinline__ void ppm_run(const double* Q, const double* c, int pos0, int s, int e, DX dxa, double* out) {
+  ppm_run_p<MORD, EDGE, F>(Q, c, pos0, s, e, SpacingFn<DX>{dxa}, out);
 }
 
 // Region launches.  A stencil with edge / corner logic is split into an INTERIOR box (straight-line code, ~95 % of

@@ -312,7 +312,11 @@ template <class MT>
 __device__ __forceinline__ DelnResult deln_iterate(const Geo& g, const MT& m, const DelnMet& M, const double* sq, const double* sdv,
                                                    const double* sdu, double* plane, int i0, int j0, double d0, bool hi_order,
                                                    int nmax) {
+#ifdef FV_X_NODAMP
+  const int iters = 0;
+#else
   const int iters = hi_order ? nmax : 0;
+#endif
   const int ilo = i0 - 3, jlo = j0 - 3;
   const bool rc = hi_order && (ilo < g.is || ilo + DW - 1 > g.ie) && (jlo < g.js || jlo + DH - 1 > g.je);
   for (int it = 0; it < iters; ++it) {

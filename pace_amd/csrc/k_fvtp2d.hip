@@ -111,12 +111,14 @@ __device__ __forceinline__ TileId tile_of_workgroup() {
 // Stage-time instrumentation (experiments only: `make prof` builds build/prof/libpace_prof.so with -DFV_PROF; the product
 // library contains none of this).  One interior workgroup per level records the shader clock at every stage boundary.
 #ifdef FV_PROF
-__device__ long long g_fv_prof[2 * 256 * 16];  // [interior tile (2, 3) | corner tile (0, 0)][level][stamp]
-#define STAMP(n)                                                                                        \
-  if (tid == 0 && wg.bz < 256 && ((wg.bx == 2 && wg.by == 3) || (wg.bx == 0 && wg.by == 0)))         \
-  g_fv_prof[((wg.bx == 0) * 256 + wg.bz) * 16 + (n)] = (long long)__builtin_readcyclecounter()
+// [interior tile (2, 3) | corner tile (0, 0) | west-edge tile (0, 3) | south-edge tile (2, 0)][level][stamp]
+__device__ long long g_fv_prof[4 * 256 * 16];
+#define FV_SLOT ((wg.bx == 2 && wg.by == 3) ? 0 : (wg.bx == 0 && wg.by == 0) ? 1 : (wg.bx == 0 && wg.by == 3) ? 2 : (wg.bx == 2 && wg.by == 0) ? 3 : -1)
+#define STAMP(n)                                                                                      \
+  if (tid == 0 && wg.bz < 256 && FV_SLOT >= 0)                                                        \
+  g_fv_prof[(FV_SLOT * 256 + wg.bz) * 16 + (n)] = (long long)__builtin_readcyclecounter()
 extern "C" int pace_debug_fv_prof(long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fv_prof), sizeof(long long) * 2 * 256 * 16);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fv_prof), sizeof(long long) * 4 * 256 * 16);
 }
 #else
 #define STAMP(n)
@@ -154,6 +156,9 @@ struct FvLds {
 #ifndef FV_DN_EARLY
 #define FV_DN_EARLY 0
 #endif
+#ifndef FV_EPI0_BATCH
+#define FV_EPI0_BATCH 2
+#endif
 #if FV_PF && !defined(PACE_EMU)
 __device__ __forceinline__ void pf_touch(const real* base, unsigned off, unsigned lds_addr) {
   const char* a = (const char*)base + off;
@@ -185,7 +190,26 @@ constexpr bool kClampY = (GY - 1) * RF + RF + 4 >= QH;
 static_assert((GX - 1) * RF + RF + 4 < 2 * (QW + 1), "an x-run may overrun its row by less than one row");
 static_assert(QW * GY <= 256 && QH * GX <= 256 && (TJ + 3) * GX <= 256, "one PPM run per thread: the tile is too large for 256 threads");
 
-template <int MORD, bool EX, bool EY, int DMODE, int EPI>
+// the A-grid spacings the one-sided PPM forms need (common.h EdgeSpacing), for a sweep along x in row gj (AXIS 0: dxa) or along y
+// in column gi (AXIS 1: dya): unconditional loads (every position is inside the storage), only in workgroups next to that edge
+template <int AXIS>
+__device__ __forceinline__ EdgeSpacing load_edge_spacing(const Geo& g, const real* d, int fixed, bool near_s, bool near_e, int sj8) {
+  EdgeSpacing sp;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) sp.S[t] = 0.0, sp.E[t] = 0.0;
+  const int s0 = (AXIS == 0 ? g.is : g.js) - 2, e0 = (AXIS == 0 ? g.ie : g.je) - 1;
+  if (near_s) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sp.S[t] = AXIS == 0 ? LD(d, OFF2(s0 + t, fixed)) : LD(d, OFF2(fixed, s0 + t));
+  }
+  if (near_e) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sp.E[t] = AXIS == 0 ? LD(d, OFF2(e0 + t, fixed)) : LD(d, OFF2(fixed, e0 + t));
+  }
+  return sp;
+}
+
+template <int MORD, bool EX, bool EY, int DMODE, int EPI, bool CANON>
 __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, const FvMet& m, const real* __restrict__ q,
                                             const real* __restrict__ crx, const real* __restrict__ cry,
                                             const real* __restrict__ xfx, const real* __restrict__ yfx,
@@ -216,6 +240,18 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   const int y5_grp = tid / QW, y5_col = tid % QW - 3;
   const bool y5_on = y5_grp < GY && y5_col >= 0 && y5_col < TI;
   double cx_keep[RF], cy_keep[RF];
+  // which tile edges the one-sided PPM forms of this workgroup can touch (block-uniform; see the EX / EY tests in k_fvtp2d)
+  const bool near_w = i0 - 1 <= g.is + 1, near_e = i0 + TI + 1 >= g.ie, near_s = j0 - 1 <= g.js + 1, near_n = j0 + TJ + 1 >= g.je;
+  // ... and whether they sit where ppm_run_canon expects them: the tile starts at the edge (first run, A = 0) / ends exactly at
+  // it (last run, A = AHI).  True for every edge tile when N is a multiple of the tile size (C48 ... C384 with 32 x 24: in x;
+  // in y when 24 divides N); other tilings take the general form.
+  constexpr int AHI_X = TI - (GX - 1) * RF, AHI_Y = TJ - (GY - 1) * RF;
+  // (AHI >= 2: the run before the last one does not reach the interface at e; RF >= 3: the second run does not reach s + 1 --
+  // the interface values of neighbouring runs overlap by two)
+  constexpr bool kCanonX = MORD != 8 && RF >= 3 && AHI_X >= 2 && AHI_X <= RF - 1 && GX >= 2;
+  constexpr bool kCanonY = MORD != 8 && RF >= 3 && AHI_Y >= 2 && AHI_Y <= RF - 1 && GY >= 2;
+  // (CANON: the launcher has checked that the tiling puts every edge there -- fv_canonical_tiling)
+  constexpr bool canon_x = CANON && kCanonX, canon_y = CANON && kCanonY;
 
   STAMP(0);
   DelnMet DM;
@@ -333,12 +369,17 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
-      cc[f] = (col_ok && jj0 + f <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1))) ? LD(cry, kb8 + OFF2(gi, gj)) : 0.0;
+      // (unconditional load from a clamped address + select: a load under a condition is a branch per interface)
+      const bool okf = col_ok && jj0 + f <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1));
+      const double cv = LD(cry, kb8 + (okf ? OFF2(gi, gj) : OFF2(g.is, g.js)));
+      cc[f] = okf ? cv : 0.0;
       cy_keep[f] = cc[f];
     }
-    const real* dya = m.dya;
-    const int gic = gi < g.ni ? gi : g.ni - 1;  // (a tile may stick out of the storage: the metric row must exist)
-    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gic, p)); }, out);
+    const int gic = gi < 0 ? 0 : (gi < g.ni ? gi : g.ni - 1);  // (a tile may stick out of the storage: the metric column must exist)
+    EdgeSpacing sp;
+    if (EY) sp = load_edge_spacing<1>(g, m.dya, gic, near_s, near_n, sj8);
+    if constexpr (EY && canon_y) ppm_run_canon<MORD == 8 ? 6 : MORD, RF, kCanonY ? AHI_Y : 0>(Q, cc, near_s && grp == 0, near_n && grp == GY - 1, sp, out);
+    else ppm_run_p<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, sp, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gj = gj0 + f;
@@ -359,9 +400,13 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int gi = ilo + ii, gj = j0 + jj;
       const bool ok = e < QW * TJ && (!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je));
       const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+#ifdef FV_X_NOLOADS
+      y0_[t] = 1.0e5 + c2; y1_[t] = 1.0e5; a_[t] = 1.0e9;
+#else
       y0_[t] = LD(yfx, kb8 + c2);
       y1_[t] = LD(yfx, kb8 + c2 + sj8);
       a_[t] = LD(m.area, c2);
+#endif
     }
 #pragma unroll
     for (int t = 0; t < NE2; ++t) {  // ... then the arithmetic
@@ -411,12 +456,16 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
-      cc[f] = (row_ok && ii0 + f <= TI && (!EX || (gi >= g.is && gi <= g.ie + 1))) ? LD(crx, kb8 + OFF2(gi, gj)) : 0.0;
+      const bool okf = row_ok && ii0 + f <= TI && (!EX || (gi >= g.is && gi <= g.ie + 1));
+      const double cv = LD(crx, kb8 + (okf ? OFF2(gi, gj) : OFF2(g.is, g.js)));
+      cc[f] = okf ? cv : 0.0;
       cx_keep[f] = cc[f];
     }
-    const real* dxa = m.dxa;
-    const int gjc = gj < g.nj ? gj : g.nj - 1;  // (a tile may stick out of the storage: the metric row must exist)
-    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gjc)); }, out);
+    const int gjc = gj < 0 ? 0 : (gj < g.nj ? gj : g.nj - 1);  // (a tile may stick out of the storage: the metric row must exist)
+    EdgeSpacing sp;
+    if (EX) sp = load_edge_spacing<0>(g, m.dxa, gjc, near_w, near_e, sj8);
+    if constexpr (EX && canon_x) ppm_run_canon<MORD == 8 ? 6 : MORD, RF, kCanonX ? AHI_X : 0>(Q, cc, near_w && grp == 0, near_e && grp == GX - 1, sp, out);
+    else ppm_run_p<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, sp, out);
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
       const int gi = gi0 + f;
@@ -437,9 +486,13 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int gi = i0 + ii, gj = jlo + jj;
       const bool ok = e < TI * QH && (!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie));
       const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+#ifdef FV_X_NOLOADS
+      x0_[t] = 1.0e5 + c2; x1_[t] = 1.0e5; a_[t] = 1.0e9;
+#else
       x0_[t] = LD(xfx, kb8 + c2);
       x1_[t] = LD(xfx, kb8 + c2 + E8);
       a_[t] = LD(m.area, c2);
+#endif
     }
 #pragma unroll
     for (int t = 0; t < NE4; ++t) {
@@ -465,7 +518,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int jj = x5_row, grp = x5_grp;
     const int ii0 = grp * RF;
     const int gi0 = i0 + ii0, gj = j0 + jj;
-    double Q[RF + 5], cc[RF], xu[RF], out[RF];
+    double Q[RF + 5], cc[RF], out[RF];
     bool calc[RF];
     const double* qirow = &sqi[0][0] + jj * (QW + 1) + ii0;
 #pragma unroll
@@ -475,33 +528,82 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int ii = ii0 + f, gi = gi0 + f;
       calc[f] = (!EY || gj <= g.je) && (!EX || gi <= g.ie + 1) && ii <= TI;
       if (EPI == 0) calc[f] = calc[f] && (ii < TI || gi == g.ie + 1);  // a neighbour stores its own west face
-      const unsigned c = kb8 + OFF2(gi, gj);
       cc[f] = calc[f] ? cx_keep[f] : 0.0;  // = crx[c], loaded by this thread for the inner sweep of the same row
-      xu[f] = calc[f] ? LD(xunit, c) : 0.0;
     }
-    const real* dxa = m.dxa;
     const int gjc = gj < g.nj ? gj : g.nj - 1;  // (a tile may stick out of the storage: the metric row must exist)
-    ppm_run<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, [=](int p) { return LD(dxa, OFF2(p, gjc)); }, out);
+    EdgeSpacing sp;
+    if (EX) sp = load_edge_spacing<0>(g, m.dxa, gjc, near_w, near_e, sj8);
+    if constexpr (EX && canon_x) ppm_run_canon<MORD == 8 ? 6 : MORD, RF, kCanonX ? AHI_X : 0>(Q, cc, near_w && grp == 0, near_e && grp == GX - 1, sp, out);
+    else ppm_run_p<MORD, EX, RF>(Q, cc, gi0, g.is, g.ie, sp, out);
 #pragma unroll
-    for (int f = 0; f < RF; ++f) {
-      vxf[f] = 0.0;
-      if (calc[f]) {
-        const unsigned c = kb8 + OFF2(gi0 + f, gj);
-        double v = 0.5 * (out[f] + sxin[jj + 3][ii0 + f]) * xu[f];
-        if (DMODE == 0 && EPI == 0) ST(dp.fx2o, c) = dvx[f];
-        if (DMODE == 1) v = v + dvx[f];
-        if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - E8) + LD(dp.mass, c)) * dvx[f];
-        if (EPI == 0) {
-          if (dp.v_upd) {  // v_from_ke (d_sw.py:423-436): same expression, same order as the stand-alone kernel
-            const unsigned c2 = OFF2(gi0 + f, gj);
-            ST(dp.v_upd, c) = LD(dp.v_upd, c) * LD(m.dy, c2) + LD(dp.ke, c) - LD(dp.ke, c + sj8) - v;
-          } else {
-            ST(fx, c) = v;
-          }
-          if (dp.accx && (ii0 + f < TI || gi0 + f == g.ie + 1)) ST(dp.accx, c) = LD(dp.accx, c) + v;
-        }
-        vxf[f] = v;
+    for (int f = 0; f < RF; ++f) vxf[f] = 0.0;
+    // The face loop.  All operands of a batch of faces are loaded first, from clamped addresses and without conditions: a load
+    // inside `if (calc[f])` is a branch and a full wait per face (the ISA showed 5 + 5 serialized L2 round trips per tile in
+    // these two loops).  Modes that only need the unit flux (+ mass) take all faces in one batch; EPI == 0 with its wind /
+    // accumulator operands (up to five more loads per face) takes two, for the registers.
+    auto faces = [&](auto F0_, auto F1_) {
+      constexpr int F0 = decltype(F0_)::value, F1 = decltype(F1_)::value, NF = F1 - F0;
+      unsigned cf[NF];
+      double xu[NF], si[NF], ms[NF + 1], w0[NF], w1[NF], w2[NF], w3[NF], wa[NF];
+#pragma unroll
+      for (int t = 0; t < NF; ++t) {
+        const int f = F0 + t;
+        cf[t] = kb8 + (calc[f] ? OFF2(gi0 + f, gj) : OFF2(g.is, g.js));
+        xu[t] = LD(xunit, cf[t]);
+        si[t] = sxin[jj + 3][ii0 + f];
       }
+      if (DMODE == 2) {
+#pragma unroll
+        for (int t = 0; t <= NF; ++t) {
+          const int gim = gi0 + F0 - 1 + t;
+          ms[t] = LD(dp.mass, kb8 + OFF2(gim < g.ni ? gim : g.ni - 1, gjc));
+        }
+      }
+      if (EPI == 0) {
+        if (dp.v_upd) {
+#pragma unroll
+          for (int t = 0; t < NF; ++t) {
+            w0[t] = LD(dp.v_upd, cf[t]);
+            w1[t] = LD(m.dy, cf[t] - kb8);
+            w2[t] = LD(dp.ke, cf[t]);
+            w3[t] = LD(dp.ke, cf[t] + sj8);
+          }
+        }
+        if (dp.accx) {
+#pragma unroll
+          for (int t = 0; t < NF; ++t) wa[t] = LD(dp.accx, cf[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NF; ++t) {
+        const int f = F0 + t;
+        if (calc[f]) {
+          const unsigned c = cf[t];
+          double v = 0.5 * (out[f] + si[t]) * xu[t];
+          if (DMODE == 0 && EPI == 0) ST(dp.fx2o, c) = dvx[f];
+          if (DMODE == 1) v = v + dvx[f];
+          if (DMODE == 2) v = v + 0.5 * damp * (ms[t] + ms[t + 1]) * dvx[f];
+          if (EPI == 0) {
+            if (dp.v_upd) {  // v_from_ke (d_sw.py:423-436): same expression, same order as the stand-alone kernel
+              ST(dp.v_upd, c) = w0[t] * w1[t] + w2[t] - w3[t] - v;
+            } else {
+              ST(fx, c) = v;
+            }
+            if (dp.accx && (ii0 + f < TI || gi0 + f == g.ie + 1)) ST(dp.accx, c) = wa[t] + v;
+          }
+          vxf[f] = v;
+        }
+      }
+    };
+    if (EPI == 0) {  // batches of FV_EPI0_BATCH faces (three of them at RF = 5: 114 spilled VGPRs with two larger ones)
+      constexpr int B = FV_EPI0_BATCH;
+      faces(std::integral_constant<int, 0>{}, std::integral_constant<int, (B < RF ? B : RF)>{});
+      if constexpr (B < RF) faces(std::integral_constant<int, B>{}, std::integral_constant<int, (2 * B < RF ? 2 * B : RF)>{});
+      if constexpr (2 * B < RF) faces(std::integral_constant<int, 2 * B>{}, std::integral_constant<int, (3 * B < RF ? 3 * B : RF)>{});
+      if constexpr (3 * B < RF) faces(std::integral_constant<int, 3 * B>{}, std::integral_constant<int, (4 * B < RF ? 4 * B : RF)>{});
+      if constexpr (4 * B < RF) faces(std::integral_constant<int, 4 * B>{}, std::integral_constant<int, RF>{});
+    } else {
+      faces(std::integral_constant<int, 0>{}, std::integral_constant<int, RF>{});
     }
   }
   STAMP(7);
@@ -509,7 +611,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const int grp = y5_grp, ii = y5_col;
     const int jj0 = grp * RF;
     const int gi = i0 + ii, gj0 = j0 + jj0;
-    double Q[RF + 5], cc[RF], yu[RF], out[RF];
+    double Q[RF + 5], cc[RF], out[RF];
     bool calc[RF];
 #pragma unroll
     for (int u = 0; u < RF + 5; ++u) Q[u] = sq[kClampY ? ((jj0 + u < QH) ? jj0 + u : QH - 1) : jj0 + u][ii + 3];  // q_j at gj0-3 ..
@@ -518,33 +620,78 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int jj = jj0 + f, gj = gj0 + f;
       calc[f] = (!EX || gi <= g.ie) && (!EY || gj <= g.je + 1) && jj <= TJ;
       if (EPI == 0) calc[f] = calc[f] && (jj < TJ || gj == g.je + 1);
-      const unsigned c = kb8 + OFF2(gi, gj);
       cc[f] = calc[f] ? cy_keep[f] : 0.0;  // = cry[c]
-      yu[f] = calc[f] ? LD(yunit, c) : 0.0;
     }
-    const real* dya = m.dya;
-    const int gic = gi < g.ni ? gi : g.ni - 1;  // (a tile may stick out of the storage: the metric row must exist)
-    ppm_run<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, [=](int p) { return LD(dya, OFF2(gic, p)); }, out);
+    const int gic = gi < g.ni ? gi : g.ni - 1;  // (a tile may stick out of the storage: the metric column must exist)
+    EdgeSpacing sp;
+    if (EY) sp = load_edge_spacing<1>(g, m.dya, gic, near_s, near_n, sj8);
+    if constexpr (EY && canon_y) ppm_run_canon<MORD == 8 ? 6 : MORD, RF, kCanonY ? AHI_Y : 0>(Q, cc, near_s && grp == 0, near_n && grp == GY - 1, sp, out);
+    else ppm_run_p<MORD, EY, RF>(Q, cc, gj0, g.js, g.je, sp, out);
 #pragma unroll
-    for (int f = 0; f < RF; ++f) {
-      vyf[f] = 0.0;
-      if (calc[f]) {
-        const unsigned c = kb8 + OFF2(gi, gj0 + f);
-        double v = 0.5 * (out[f] + syin[jj0 + f][ii + 3]) * yu[f];
-        if (DMODE == 0 && EPI == 0) ST(dp.fy2o, c) = dvy[f];
-        if (DMODE == 1) v = v + dvy[f];
-        if (DMODE == 2) v = v + 0.5 * damp * (LD(dp.mass, c - sj8) + LD(dp.mass, c)) * dvy[f];
-        if (EPI == 0) {
-          if (dp.u_upd) {  // u_from_ke (d_sw.py:406-420)
-            const unsigned c2 = OFF2(gi, gj0 + f);
-            ST(dp.u_upd, c) = LD(dp.u_upd, c) * LD(m.dx, c2) + LD(dp.ke, c) - LD(dp.ke, c + E8) + v;
-          } else {
-            ST(fy, c) = v;
-          }
-          if (dp.accy) ST(dp.accy, c) = LD(dp.accy, c) + v;
-        }
-        vyf[f] = v;
+    for (int f = 0; f < RF; ++f) vyf[f] = 0.0;
+    auto faces = [&](auto F0_, auto F1_) {  // (see the x loop)
+      constexpr int F0 = decltype(F0_)::value, F1 = decltype(F1_)::value, NF = F1 - F0;
+      unsigned cf[NF];
+      double yu[NF], si[NF], ms[NF + 1], w0[NF], w1[NF], w2[NF], w3[NF], wa[NF];
+#pragma unroll
+      for (int t = 0; t < NF; ++t) {
+        const int f = F0 + t;
+        cf[t] = kb8 + (calc[f] ? OFF2(gi, gj0 + f) : OFF2(g.is, g.js));
+        yu[t] = LD(yunit, cf[t]);
+        si[t] = syin[jj0 + f][ii + 3];
       }
+      if (DMODE == 2) {
+#pragma unroll
+        for (int t = 0; t <= NF; ++t) {
+          const int gjm = gj0 + F0 - 1 + t;
+          ms[t] = LD(dp.mass, kb8 + OFF2(gic, gjm < g.nj ? gjm : g.nj - 1));
+        }
+      }
+      if (EPI == 0) {
+        if (dp.u_upd) {
+#pragma unroll
+          for (int t = 0; t < NF; ++t) {
+            w0[t] = LD(dp.u_upd, cf[t]);
+            w1[t] = LD(m.dx, cf[t] - kb8);
+            w2[t] = LD(dp.ke, cf[t]);
+            w3[t] = LD(dp.ke, cf[t] + E8);
+          }
+        }
+        if (dp.accy) {
+#pragma unroll
+          for (int t = 0; t < NF; ++t) wa[t] = LD(dp.accy, cf[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NF; ++t) {
+        const int f = F0 + t;
+        if (calc[f]) {
+          const unsigned c = cf[t];
+          double v = 0.5 * (out[f] + si[t]) * yu[t];
+          if (DMODE == 0 && EPI == 0) ST(dp.fy2o, c) = dvy[f];
+          if (DMODE == 1) v = v + dvy[f];
+          if (DMODE == 2) v = v + 0.5 * damp * (ms[t] + ms[t + 1]) * dvy[f];
+          if (EPI == 0) {
+            if (dp.u_upd) {  // u_from_ke (d_sw.py:406-420)
+              ST(dp.u_upd, c) = w0[t] * w1[t] + w2[t] - w3[t] + v;
+            } else {
+              ST(fy, c) = v;
+            }
+            if (dp.accy) ST(dp.accy, c) = wa[t] + v;
+          }
+          vyf[f] = v;
+        }
+      }
+    };
+    if (EPI == 0) {  // batches of FV_EPI0_BATCH faces (three of them at RF = 5: 114 spilled VGPRs with two larger ones)
+      constexpr int B = FV_EPI0_BATCH;
+      faces(std::integral_constant<int, 0>{}, std::integral_constant<int, (B < RF ? B : RF)>{});
+      if constexpr (B < RF) faces(std::integral_constant<int, B>{}, std::integral_constant<int, (2 * B < RF ? 2 * B : RF)>{});
+      if constexpr (2 * B < RF) faces(std::integral_constant<int, 2 * B>{}, std::integral_constant<int, (3 * B < RF ? 3 * B : RF)>{});
+      if constexpr (3 * B < RF) faces(std::integral_constant<int, 3 * B>{}, std::integral_constant<int, (4 * B < RF ? 4 * B : RF)>{});
+      if constexpr (4 * B < RF) faces(std::integral_constant<int, 4 * B>{}, std::integral_constant<int, RF>{});
+    } else {
+      faces(std::integral_constant<int, 0>{}, std::integral_constant<int, RF>{});
     }
   }
   STAMP(8);
@@ -655,13 +802,15 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
 #ifndef FV_WAVES
 #define FV_WAVES 4
 #endif
-template <int MORD, int DMODE, int EPI>
+// CANON: every tile edge coincides with a tile boundary of the workgroup tiling (fv_canonical_tiling), so that the one-sided
+// PPM forms sit at compile-time positions of the first / last run of a row or column (common.h ppm_run_canon)
+template <int MORD, int DMODE, int EPI, bool CANON>
 __global__ void __launch_bounds__(256, FV_WAVES) k_fvtp2d(Geo g, FvMet m, const real* __restrict__ q,
-                                                const real* __restrict__ crx, const real* __restrict__ cry,
-                                                const real* __restrict__ xfx, const real* __restrict__ yfx,
-                                                real* __restrict__ fx, real* __restrict__ fy,
-                                                const real* __restrict__ xunit, const real* __restrict__ yunit,
-                                                FvDamp dp) {
+                                                       const real* __restrict__ crx, const real* __restrict__ cry,
+                                                       const real* __restrict__ xfx, const real* __restrict__ yfx,
+                                                       real* __restrict__ fx, real* __restrict__ fy,
+                                                       const real* __restrict__ xunit, const real* __restrict__ yunit,
+                                                       FvDamp dp) {
   // x-interfaces evaluated: i0 .. i0+TI (their al's reach one further each way); special forms at is-1 .. is+1 and
   // ie .. ie+2
   __shared__ FvLds<DMODE, EPI> L;
@@ -670,10 +819,16 @@ __global__ void __launch_bounds__(256, FV_WAVES) k_fvtp2d(Geo g, FvMet m, const 
   // (ord 8: the special CELLS are s-1 .. s+1 and e-1 .. e+1; the cells evaluated are i0-1 .. i0+TI -- the same test)
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
-  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else fvtp2d_tile<MORD, false, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  else fvtp2d_tile<MORD, false, false, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+}
+
+// whether every edge tile of the launch holds its edge at the canonical place: N a multiple of the tile in both directions,
+// at least two tiles each way (so that no run holds both ends)
+static inline bool fv_canonical_tiling(const Geo& g) {
+  return g.n % TI == 0 && g.n % TJ == 0 && g.n >= 2 * TI && g.n >= 2 * TJ;
 }
 
 // EXPERIMENT (PACE_DSW_PAIR=1): two scalars that share every input except q and the damping
@@ -696,17 +851,17 @@ __global__ void __launch_bounds__(512, 4) k_fvtp2d_pair(Geo g, FvMet m, const re
   const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
-  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
-  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
-  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
-  else fvtp2d_tile<MORD, false, false, DMODE, EPI>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  else fvtp2d_tile<MORD, false, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
 }
 
 int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real* qb, const real* crx, const real* cry,
                           const real* xfx, const real* yfx, const real* xmf, const real* ymf, int hord, int nlev,
                           const FvDamp& dpa, const FvDamp& dpb, hipStream_t st) {
   if (hord != 6 || dpa.nmax != dpb.nmax || dpa.nmax > 2) return PACE_ERR_UNSUPPORTED;
-#if defined(FV_FAST_BUILD) || defined(FV_ONLY_621)
+#if defined(FV_FAST_BUILD) || defined(FV_ONLY_621) || defined(FV_ONLY_EPI0)
   return PACE_ERR_UNSUPPORTED;
 #else
   const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
@@ -725,8 +880,15 @@ static int fv_dynlds() {
 #else
 #define FV_DYNLDS 0
 #endif
-#define FV_LAUNCH(D, E) \
-  hipLaunchKernelGGL((k_fvtp2d<MORD, D, E>), grid, block, FV_DYNLDS, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp)
+#define FV_LAUNCH(D, E)                                                                                                          \
+  do {                                                                                                                           \
+    if (MORD != 8 && fv_canonical_tiling(g))                                                                                     \
+      hipLaunchKernelGGL((k_fvtp2d<MORD, D, E, MORD != 8>), grid, block, FV_DYNLDS, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, \
+                         xu, yu, dp);                                                                                            \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((k_fvtp2d<MORD, D, E, false>), grid, block, FV_DYNLDS, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, \
+                         yu, dp);                                                                                                \
+  } while (0)
 
 template <int MORD>
 static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g, const Met& m, const real* q,
@@ -744,6 +906,12 @@ static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo&
     else return PACE_ERR_UNSUPPORTED;
   }
   return PACE_OK;
+#elif defined(FV_ONLY_EPI0)  // register-budget experiments: the two EPI == 0 instances of d_sw
+  if constexpr (MORD == 6) {
+    if (epi == 0 && dmode == 1) { FV_LAUNCH(1, 0); return PACE_OK; }
+    if (epi == 0 && dmode == 0) { FV_LAUNCH(0, 0); return PACE_OK; }
+  }
+  return PACE_ERR_UNSUPPORTED;
 #elif defined(FV_ONLY_621)  // register-budget experiments: one instance
   if constexpr (MORD == 6) {
     if (epi == 1 && dmode == 2) { FV_LAUNCH(2, 1); return PACE_OK; }
@@ -787,9 +955,9 @@ int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx,
   int rc;
   if (hord == 5) rc = launch_mode<5>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
   else if (hord == 6) rc = launch_mode<6>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
-#if !defined(FV_FAST_BUILD) && !defined(FV_ONLY_621)
+#if !defined(FV_FAST_BUILD) && !defined(FV_ONLY_621) && !defined(FV_ONLY_EPI0)
   else if (hord == 8 && dmode == -1 && epi == 0) {  // monotone PPM: tracer advection (plain transport only)
-    hipLaunchKernelGGL((k_fvtp2d<8, -1, 0>), grid, dim3(256), 0, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
+    hipLaunchKernelGGL((k_fvtp2d<8, -1, 0, false>), grid, dim3(256), 0, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
     rc = PACE_OK;
   }
 #endif

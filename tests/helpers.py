@@ -49,6 +49,12 @@ def build_emu():
     return os.path.join(ROOT, "tests", "emu", "libpace_emu.so")
 
 
+def build_emu_canon():
+    """8 x 8 transport tiles, runs of 3: the canonical edge path (ppm_run_canon) at C16 / C24 (Makefile emu-canon)."""
+    _make("emu-canon")
+    return os.path.join(ROOT, "tests", "emu", "libpace_emu_canon.so")
+
+
 def build_emu_small():
     """tests/emu/libpace_emu_small.so: the emulation build with 4 x 4 LDS tiles (interior code paths at C12)."""
     _make("emu-small")

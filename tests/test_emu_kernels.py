@@ -120,6 +120,37 @@ def test_d_sw_small_tiles_bit_exact(emu_small_lib, name, tile):
         assert err < 3.2e-10, (k, err)
 
 
+@pytest.mark.parametrize("cfg", [dict(), dict(hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5)])
+def test_d_sw_canonical_edge_tiling_vs_oracle(cfg):
+    """The tiling the production sizes run with: every tile edge on a workgroup-tile boundary, so the transport kernels take
+    the canonical edge path (k_fvtp2d<..., CANON = true>, common.h ppm_run_canon: interior PPM form + three patched interface
+    values in the first / last run).  8 x 8 tiles with runs of 3 at C24 (3 x 3 workgroups: corner, edge and interior
+    variants), all of d_sw -- the five transport modes, hord 6 and 5 -- against the oracle, exactly."""
+    from helpers import DSW_CFG, build_emu_canon
+    from oracle import dgrid_sw
+    from pace_amd import _lib, synthetic
+
+    lib = _lib.Library(build_emu_canon())
+    n, nz = 24, 5
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    col = column_for_levels(np.arange(nz))
+    env = Env(lib, "cpu", metrics, n, nz)
+    c = dict(DSW_CFG, **cfg)
+    out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"], cfg=c)
+    from helpers import oracle_grid
+
+    g = oracle_grid(metrics, n, nz)
+    st = dgrid_sw.DSWState(s["u"].shape)
+    a = {k: s[k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(g, col, c, st, *[a[k] for k in DSW_ARGS], s["dt"])
+    for k in DSW_ARGS:
+        if k == "zh":
+            continue
+        W = dsw_window(k, n, nz)
+        assert np.array_equal(a[k][W], out[k][W]), (k, compare(a[k][W], out[k][W]))
+
+
 @pytest.mark.parametrize("which", ["big", "small"])
 def test_ord8_transport_emulated_vs_oracle(emu_lib, emu_small_lib, which):
     """Monotone (ord 8) PPM transport against the oracle, bit for bit, with both tilings."""

@@ -114,17 +114,17 @@ def main():
         outs = {"fvtp2d_update": out.numpy().copy()}
         res["fvtp2d_update"] = timed(kernel, args.reps)
         if hasattr(lib.cdll, "pace_debug_fv_prof"):
-            host = (C.c_longlong * (256 * 16 * 2))()
-            rows = [[], []]
+            host = (C.c_longlong * (256 * 16 * 4))()
+            rows = [[], [], [], []]
             for rep in range(8):
                 kernel(rep)
                 torch.cuda.synchronize()
                 assert lib.cdll.pace_debug_fv_prof(host) == 0
-                a = np.frombuffer(host, dtype=np.int64).reshape(2, 256, 16)[:, :nz, :11].astype(float)
+                a = np.frombuffer(host, dtype=np.int64).reshape(4, 256, 16)[:, :nz, :11].astype(float)
                 if rep >= 2:
-                    for w in range(2):
+                    for w in range(4):
                         rows[w].append(np.diff(a[w], axis=1))
-            for w, label in enumerate(("interior", "corner")):
+            for w, label in enumerate(("interior", "corner", "west-edge", "south-edge")):
                 d = np.concatenate(rows[w])
                 med = np.median(d, axis=0)
                 print(f"[{name}] {label} workgroup of k_fvtp2d<6,2,1>: {med.sum():.0f} cycles")
