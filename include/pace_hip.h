@@ -387,13 +387,36 @@ int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, 
                  const pace_real_t* v, const pace_real_t* a11, const pace_real_t* a12, const pace_real_t* a21,
                  const pace_real_t* a22, pace_real_t* ua, pace_real_t* va, void* stream);
 
-/* EXPERIMENTAL, not used by the host classes: the wave-private (barrier-free, LDS-free) formulation of the plain ord-6
- * transport of pace_fvtp2d for the box of cells [ib, ib+nx) x [jb, jb+ny) whose stencils stay 3+ cells inside the tile
- * (PACE_ERR_ARG otherwise).  Writes fx, fy on the box only.  See pace_amd/csrc/k_march.hip and DESIGN.md section 8. */
-int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const pace_real_t* q,
-                            const pace_real_t* crx, const pace_real_t* cry, const pace_real_t* xfx,
-                            const pace_real_t* yfx, pace_real_t* fx, pace_real_t* fy, int ib, int nx, int jb, int ny,
-                            int nlev, void* stream);
+/* Per-stencil device implementations behind FrozenStencil (dsl/pace/dsl/stencil.py:395-434) for gtscript definitions that the
+ * reference's Translate tests launch as stencils of their own: `id` selects the definition, `fields` are its field arguments in
+ * the definition's order (2-D metric arguments come from `met`, K-fields are device arrays of nk + 1 entries), `scalars` its
+ * float arguments, origin / domain the launch window (region statements write only inside it).
+ *   PACE_ST_FLUX_CAPACITOR  d_sw.py:33-60     fields cx, cy, xflux, yflux, crx_adv, cry_adv, fx, fy
+ *   PACE_ST_HEAT_DISS       d_sw.py:63-103    fields fx2, fy2, w, heat_source, diss_est, dw, damp_w (K), ke_bg (K); scalars dt
+ *   PACE_ST_APPLY_FLUXES    d_sw.py:122-145   fields q, delp, gx, gy
+ *   PACE_ST_UBKE / _VBKE    translate_d_sw.py:67-81 / 118-133 (d_sw.py interpolate_uc_vc_to_cell_corners)
+ *                                             fields uc, vc, ut (vt), ub (vb); scalars dt5
+ *   PACE_ST_COPY_CORNERS_X / _Y         corners.py:307-425   fields q_in, q_out
+ *   PACE_ST_FILL_CORNERS_BGRID_X / _Y   corners.py:592-712   fields q_in, q_out
+ *   PACE_ST_FILL_CORNERS_DGRID          corners.py:987-1151  fields x_in, x_out, y_in, y_out; scalars mysign
+ *   PACE_ST_FILL_CORNERS_2CELLS_X / _Y  corners.py:170-177   fields q_out, q_in */
+enum {
+  PACE_ST_FLUX_CAPACITOR = 1,
+  PACE_ST_HEAT_DISS = 2,
+  PACE_ST_APPLY_FLUXES = 3,
+  PACE_ST_UBKE = 4,
+  PACE_ST_VBKE = 5,
+  PACE_ST_COPY_CORNERS_X = 6,
+  PACE_ST_COPY_CORNERS_Y = 7,
+  PACE_ST_FILL_CORNERS_BGRID_X = 8,
+  PACE_ST_FILL_CORNERS_BGRID_Y = 9,
+  PACE_ST_FILL_CORNERS_DGRID = 10,
+  PACE_ST_FILL_CORNERS_2CELLS_X = 11,
+  PACE_ST_FILL_CORNERS_2CELLS_Y = 12
+};
+int pace_stencil(const pace_geom_t* geom, const pace_metrics_t* met, int id, void* const* fields, int nfields, const double* scalars,
+                 int nscalars, const int* origin, const int* domain, void* stream);
+
 
 /* ---- Halo exchange pack / unpack: what HaloDataTransformer.async_pack / async_unpack do
  * (util/pace/util/halo_data_transformer.py:387-461 CPU, :560-921 GPU kernels), with the rotation

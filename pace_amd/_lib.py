@@ -142,7 +142,8 @@ _PROTOS = {
     "pace_omega_from_w": (C.c_int, [_P(Geom)] + [c_dp] * 4 + [C.c_void_p]),
     "pace_neg_adj3": (C.c_int, [_P(Geom), _P(C.c_void_p)] + [c_dp] * 3 + [C.c_void_p]),
     "pace_c2l_ord": (C.c_int, [_P(Geom), _P(Metrics), C.c_int] + [c_dp] * 8 + [C.c_void_p]),
-    "pace_fvtp2d_march_probe": (C.c_int, [_P(Geom), _P(Metrics)] + [c_dp] * 7 + [C.c_int] * 5 + [C.c_void_p]),
+    "pace_stencil": (C.c_int, [_P(Geom), _P(Metrics), C.c_int, _P(C.c_void_p), C.c_int, _P(C.c_double), C.c_int, _P(C.c_int), _P(C.c_int),
+                               C.c_void_p]),
     "pace_halo_pack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
     "pace_halo_unpack": (C.c_int, [_P(Geom), _P(HaloDesc), C.c_int, C.c_void_p]),
 }

@@ -495,13 +495,6 @@ int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, 
   return launch_c2l(make_geo(geom), *met, order, u, v, a11, a12, a21, a22, ua, va, S(stream));
 }
 
-int pace_fvtp2d_march_probe(const pace_geom_t* geom, const pace_metrics_t* met, const real* q, const real* crx,
-                            const real* cry, const real* xfx, const real* yfx, real* fx, real* fy, int ib, int nx, int jb,
-                            int ny, int nlev, void* stream) {
-  NEED(geom && met && q && crx && cry && xfx && yfx && fx && fy);
-  if (nlev < 1 || nlev > geom->nk + 1 || nx < 1 || ny < 1) return PACE_ERR_ARG;
-  return launch_fvtp2d_march(make_geo(geom), *met, q, crx, cry, xfx, yfx, fx, fy, ib, nx, jb, ny, nlev, S(stream));
-}
 
 int pace_halo_pack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int ndesc, void* stream) {
   NEED(geom && descs && ndesc > 0);
@@ -513,6 +506,14 @@ int pace_halo_unpack(const pace_geom_t* geom, const pace_halo_desc_t* descs, int
   NEED(geom && descs && ndesc > 0);
   if (halo_check(geom, descs, ndesc)) return PACE_ERR_ARG;
   return launch_halo_copy(make_geo(geom), descs, ndesc, 1, S(stream));
+}
+
+int pace_stencil(const pace_geom_t* geom, const pace_metrics_t* met, int id, void* const* fields, int nfields, const double* scalars,
+                 int nscalars, const int* origin, const int* domain, void* stream) {
+  NEED(geom && met && fields && origin && domain && nfields >= 1 && nfields <= 16 && nscalars >= 0 && (nscalars == 0 || scalars));
+  for (int n = 0; n < nfields; ++n)
+    if (!fields[n]) return PACE_ERR_ARG;
+  return launch_stencil(make_geo(geom), *met, id, fields, nfields, scalars, nscalars, origin, domain, S(stream));
 }
 
 }  // extern "C"

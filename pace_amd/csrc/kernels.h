@@ -159,8 +159,9 @@ int launch_omega_from_w(const Geo& g, const real* delp, const real* delz, const 
 int launch_neg_adj3(const Geo& g, real* const* water, real* qcld, real* pt, const real* delp, hipStream_t st);
 int launch_c2l(const Geo& g, const Met& m, int order, const real* u, const real* v, const real* a11, const real* a12,
                const real* a21, const real* a22, real* ua, real* va, hipStream_t st);
-int launch_fvtp2d_march(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
-                        const real* yfx, real* fx, real* fy, int ib, int nx, int jb, int ny, int nlev, hipStream_t st);
+// k_stencils.hip: per-stencil device implementations (pace_stencil)
+int launch_stencil(const Geo& g, const Met& m, int id, void* const* fields, int nfields, const double* scalars, int nscalars,
+                   const int* origin, const int* domain, hipStream_t st);
 int launch_swap_dp(const Geo& g, real* dp1, real* dp2, hipStream_t st);
 int launch_zero_data(const Geo& g, real* mfxd, real* mfyd, real* cxd, real* cyd, real* heat_source, real* diss_estd,
                      int first_timestep, hipStream_t st);

@@ -164,3 +164,69 @@ def _ppm(axis):
 
 _register(_both("xppm", "compute_x_flux"), *_ppm(0))
 _register(_both("yppm", "compute_y_flux"), *_ppm(1))
+
+
+# ---- definitions the reference's Translate tests launch as stencils of their own (csrc/k_stencils.hip, pace_stencil) ----
+# ids of include/pace_hip.h
+ST_FLUX_CAPACITOR, ST_HEAT_DISS, ST_APPLY_FLUXES, ST_UBKE, ST_VBKE = 1, 2, 3, 4, 5
+ST_COPY_CORNERS_X, ST_COPY_CORNERS_Y, ST_FILL_CORNERS_BGRID_X, ST_FILL_CORNERS_BGRID_Y = 6, 7, 8, 9
+ST_FILL_CORNERS_DGRID, ST_FILL_CORNERS_2CELLS_X, ST_FILL_CORNERS_2CELLS_Y = 10, 11, 12
+
+
+def _origin(st):
+    return tuple(st.origin if isinstance(st.origin, tuple) else st.origin.get("_all_"))
+
+
+def _call_stencil(st, ident, fields, scalars=(), metrics_from=None):
+    """Any launch window: the kernels honour origin / domain (and refuse windows whose offset reads would leave the storage)."""
+    from .. import _lib
+
+    gd = None
+    for m in (metrics_from or ()):
+        gd = getattr(m, "_grid_data", None)
+        if gd is not None:
+            break
+    if metrics_from is not None and gd is None:
+        raise ValueError(f"{st.name}: pass the metric arguments (rarea, cosa, ...) of a pace_amd GridData")
+    met = gd.c_struct() if gd is not None else _lib.Metrics()  # (definitions without metric arguments never read it)
+    ptrs = (C.c_void_p * len(fields))(*[_ptr(f) for f in fields])
+    sc = (C.c_double * max(1, len(scalars)))(*[float(x) for x in scalars])
+    o, d = _origin(st), tuple(st.domain)
+    st._factory.lib.call("pace_stencil", C.byref(_geom(st)), C.byref(met), int(ident), ptrs, len(fields), sc, len(scalars),
+                         (C.c_int * 3)(*[int(x) for x in o]), (C.c_int * 3)(*[int(x) for x in d]), _stream(st))
+
+
+def _no_check(st):
+    return None
+
+
+_register(_both("d_sw", "flux_capacitor"), _no_check,
+          lambda st, cx, cy, xflux, yflux, crx_adv, cry_adv, fx, fy: _call_stencil(st, ST_FLUX_CAPACITOR,
+                                                                                   [cx, cy, xflux, yflux, crx_adv, cry_adv, fx, fy]))
+_register(_both("d_sw", "heat_diss"), _no_check,
+          lambda st, fx2, fy2, w, rarea, heat_source, diss_est, dw, damp_w, ke_bg, dt: _call_stencil(
+              st, ST_HEAT_DISS, [fx2, fy2, w, heat_source, diss_est, dw, damp_w, ke_bg], [dt], metrics_from=[rarea]))
+_register(_both("d_sw", "apply_fluxes"), _no_check,
+          lambda st, q, delp, gx, gy, rarea: _call_stencil(st, ST_APPLY_FLUXES, [q, delp, gx, gy], metrics_from=[rarea]))
+# (the reference defines ubke / vbke in its test module, tests/savepoint/translate/translate_d_sw.py:67-81,118-133: matched on
+# the bare name)
+_register(("pace_amd.fv3core.stencils.d_sw.ubke",), _no_check,
+          lambda st, uc, vc, cosa, rsina, ut, ub, dt4, dt5: _call_stencil(st, ST_UBKE, [uc, vc, ut, ub], [dt5], metrics_from=[cosa, rsina]))
+_register(("pace_amd.fv3core.stencils.d_sw.vbke",), _no_check,
+          lambda st, vc, uc, cosa, rsina, vt, vb, dt4, dt5: _call_stencil(st, ST_VBKE, [uc, vc, vt, vb], [dt5], metrics_from=[cosa, rsina]))
+
+
+def _corner_paths(name):
+    return (f"pace.stencils.corners.{name}", f"pace_amd.stencils.corners.{name}")
+
+
+_register(_corner_paths("copy_corners_x_stencil_defn"), _no_check, lambda st, q_in, q_out: _call_stencil(st, ST_COPY_CORNERS_X, [q_in, q_out]))
+_register(_corner_paths("copy_corners_y_stencil_defn"), _no_check, lambda st, q_in, q_out: _call_stencil(st, ST_COPY_CORNERS_Y, [q_in, q_out]))
+_register(_corner_paths("fill_corners_bgrid_x_defn"), _no_check, lambda st, q_in, q_out: _call_stencil(st, ST_FILL_CORNERS_BGRID_X, [q_in, q_out]))
+_register(_corner_paths("fill_corners_bgrid_y_defn"), _no_check, lambda st, q_in, q_out: _call_stencil(st, ST_FILL_CORNERS_BGRID_Y, [q_in, q_out]))
+_register(_corner_paths("fill_corners_dgrid_defn"), _no_check,
+          lambda st, x_in, x_out, y_in, y_out, mysign: _call_stencil(st, ST_FILL_CORNERS_DGRID, [x_in, x_out, y_in, y_out], [mysign]))
+_register(_corner_paths("fill_corners_2cells_x_stencil"), _no_check,
+          lambda st, q_out, q_in: _call_stencil(st, ST_FILL_CORNERS_2CELLS_X, [q_out, q_in]))
+_register(_corner_paths("fill_corners_2cells_y_stencil"), _no_check,
+          lambda st, q_out, q_in: _call_stencil(st, ST_FILL_CORNERS_2CELLS_Y, [q_out, q_in]))

@@ -201,6 +201,17 @@ def test_riem_solver3_c192_sampled_columns_match_oracle(lib):
             assert float(np.abs(ref - dev).max()) < 1e-10 * scale, (bi, bj, k)
 
 
+def test_halo_updates_six_tiles_on_one_gpu_equal_the_reference_run(lib):
+    """The HIP pack / unpack kernels and the exchange of six tiles resident on one device against what the reference's own
+    pace.util (run natively, tools/make_golden_halo.py) left in the same arrays: exactly."""
+    from pace_amd.util import run_tiles
+    from test_halo import check_native, native_fixture, native_tile_program
+
+    n, nz, base, exp = native_fixture()
+    results = run_tiles(6, lambda comm: native_tile_program(comm, lib, base, n, nz, device="cuda:0"))
+    check_native(results, exp)
+
+
 def test_acoustic_dynamics_six_tiles_matches_reference_run(lib, tmp_path):
     """One whole AcousticDynamics call (n_split = 2, every operator of the loop and all halo-update groups) for the six C12
     tiles resident on one device, against the reference run's output.  Tolerance: see
@@ -511,41 +522,6 @@ def test_lagrangian_to_eulerian_matches_oracle(lib, n, last_step):
     for name in tr:
         e = compare(tr[name][cw][:, :, :km], qt[name].numpy()[cw][:, :, :km], near_zero=1e-18)
         assert e < 1e-11, (name, e)
-
-
-def test_marching_transport_probe_matches_tile_kernel(lib):
-    """The experimental wave-private transport kernel (k_march.hip; not on the product path) must produce the bits of the
-    LDS-tile kernel on the interior box it covers -- it is kept only as a measured design alternative."""
-    import ctypes as C
-
-    import torch
-
-    from pace_amd import synthetic
-    from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
-    from pace_amd.fv3core.stencils.fxadv import FiniteVolumeFluxPrep
-
-    n, nz = 96, 20
-    m = synthetic.tile_metrics(n, nz)
-    s = synthetic.acoustic_state(m, n, nz)
-    env = Env(lib, "cuda", m, n, nz)
-    f = {k: env.q3(s[k]) for k in ("uc", "vc", "crx", "cry", "xfx", "yfx", "pt")}
-    ut, vt = env.q3(), env.q3()
-    FiniteVolumeFluxPrep(env.stencil_factory, env.grid_data)(f["uc"], f["vc"], f["crx"], f["cry"], f["xfx"], f["yfx"], ut, vt, s["dt"])
-    tp = FiniteVolumeTransport(env.stencil_factory, env.qf, env.grid_data, env.damping, 0, 6)
-    fx, fy, gx, gy = env.q3(), env.q3(), env.q3(), env.q3()
-    tp(f["pt"], f["crx"], f["cry"], f["xfx"], f["yfx"], fx, fy)
-    ib, nx, jb, ny = 9, n - 12, 9, n - 13  # a box that is not a multiple of the wave's 58 x 12 patch
-    lib.call("pace_fvtp2d_march_probe", C.byref(tp._geom), C.byref(tp._met), f["pt"].ptr, f["crx"].ptr, f["cry"].ptr,
-             f["xfx"].ptr, f["yfx"].ptr, gx.ptr, gy.ptr, ib, nx, jb, ny, nz, tp.stream())
-    torch.cuda.synchronize()
-    w = (slice(ib, ib + nx), slice(jb, jb + ny), slice(0, nz))
-    assert np.array_equal(fx.numpy()[w], gx.numpy()[w]) and np.array_equal(fy.numpy()[w], gy.numpy()[w])
-    outside = gx.numpy().copy()
-    outside[w] = 0.0
-    assert not outside.any()  # nothing is written outside the box
-    with pytest.raises(Exception):
-        lib.call("pace_fvtp2d_march_probe", C.byref(tp._geom), C.byref(tp._met), f["pt"].ptr, f["crx"].ptr, f["cry"].ptr,
-                 f["xfx"].ptr, f["yfx"].ptr, gx.ptr, gy.ptr, 4, nx, jb, ny, nz, tp.stream())
 
 
 @pytest.mark.parametrize("cfg", [dict(hord_dp=5, hord_tm=5, hord_vt=5, hord_mt=5), dict(hord_dp=5, hord_tm=6, hord_vt=5, hord_mt=6),

@@ -108,6 +108,75 @@ def _check(results, base):
         assert np.array_equal(results[t]["m_c"][m][:, :NZ], exp["c"][t][m][:, :NZ] + 1.0)
 
 
+# ---- the reference's own pace.util, run natively (tools/make_golden_halo.py; no interpreter involved) ----
+def native_fixture():
+    from helpers import golden
+
+    d = golden("halo_native_c12.npz")
+    base = {k[3:]: [d[k][t] for t in range(6)] for k in d if k.startswith("in_")}
+    exp = {k[4:]: d[k] for k in d if k.startswith("out_")}
+    return int(d["n"]), int(d["nz"]), base, exp
+
+
+def native_tile_program(comm, lib, base, n, nz, device="cpu"):
+    from pace_amd.util import CubedSphereCommunicator, QuantityFactory, SubtileGridSizer
+
+    sizer = SubtileGridSizer.from_tile_params(nx_tile=n, ny_tile=n, nz=nz, n_halo=3, extra_dim_lengths={}, layout=(1, 1))
+    qf = QuantityFactory(sizer, device=device)
+    cube = CubedSphereCommunicator(comm, device=device, lib=lib)
+    r = cube.rank
+
+    def q(key):
+        x = qf.zeros(DIMS[key], "")
+        x.set(base[key][r])
+        return x
+
+    out = {}
+    s = q("c"); cube.halo_update(s, n_points=3); out["c"] = s.numpy()
+    s = q("b"); cube.halo_update(s, n_points=3); out["b"] = s.numpy()
+    s = q("zi"); cube.halo_update(s, n_points=2); out["zi"] = s.numpy()
+    u, v = q("yi"), q("xi"); cube.vector_halo_update(u, v, n_points=3); out["du"], out["dv"] = u.numpy(), v.numpy()
+    u, v = q("xi"), q("yi"); cube.vector_halo_update(u, v, n_points=3); out["cu"], out["cv"] = u.numpy(), v.numpy()
+    u, v = q("yi"), q("xi"); cube.synchronize_vector_interfaces(u, v); out["su"], out["sv"] = u.numpy(), v.numpy()
+    return out
+
+
+def check_native(results, exp):
+    for t in range(6):
+        for k, e in exp.items():
+            assert np.array_equal(results[t][k], e[t]), (t, k)
+
+
+def test_oracle_halo_equals_the_reference_run():
+    """oracle/halo.py against what the reference's CubedSphereCommunicator left in the same arrays (scalar, B-grid, z-interface,
+    D- and C-grid vector updates, interface synchronisation): exactly."""
+    from oracle import halo as oh
+
+    n, nz, base, exp = native_fixture()
+    cp = lambda k: [a.copy() for a in base[k]]  # noqa: E731
+    got = {}
+    f = cp("c"); oh.halo_update(f, n, nk=nz); got["c"] = f
+    f = cp("b"); oh.halo_update(f, n, xi=1, yi=1, nk=nz); got["b"] = f
+    f = cp("zi"); oh.halo_update(f, n, n_pts=2); got["zi"] = f
+    u, v = cp("yi"), cp("xi"); oh.vector_halo_update(u, v, n, grid="d", nk=nz); got["du"], got["dv"] = u, v
+    u, v = cp("xi"), cp("yi"); oh.vector_halo_update(u, v, n, grid="c", nk=nz); got["cu"], got["cv"] = u, v
+    u, v = cp("yi"), cp("xi"); oh.synchronize_vector_interfaces(u, v, n, nk=nz); got["su"], got["sv"] = u, v
+    for k, e in exp.items():
+        for t in range(6):
+            assert np.array_equal(got[k][t], e[t]), (k, t)
+
+
+def test_halo_updates_six_tiles_equal_the_reference_run():
+    """The product's pack / exchange / unpack (HIP kernel sources under emulation, ThreadComm) against the reference run."""
+    from pace_amd import _lib
+    from pace_amd.util import run_tiles
+
+    lib = _lib.Library(build_emu())
+    n, nz, base, exp = native_fixture()
+    results = run_tiles(6, lambda comm: native_tile_program(comm, lib, base, n, nz))
+    check_native(results, exp)
+
+
 def test_halo_updates_six_tiles_on_threads():
     from pace_amd import _lib
     from pace_amd.util import run_tiles
@@ -339,3 +408,9 @@ def test_bench_six_ranks_dry_run_over_gloo(tmp_path):
     assert out["n_gpus"] == 6 and out["steps"] == 2 and out["scaling"] == "weak" and out["dtype"] == "f64"
     assert out["config"]["tiles"] == 6 and "cubed sphere" in out["config"]["halo_exchange"]
     assert out["value"] > 0 and "EMULATION" in out["data"]
+    # what a first real 6-GPU run needs for its diagnosis: the collective library's view and the per-phase times
+    assert out["comm"]["world_size"] == 6 and out["comm"]["backend"] == "gloo"
+    ph = out["comm"]["phase_ms_max_over_ranks_synchronised"]
+    assert set(ph) == {"uc_vc_start(pack+post)", "flux_prep_interior", "uc_vc_wait(+unpack)", "d_sw_rest", "delp_pt_qcon_start(pack+post)",
+                       "delp_pt_qcon_wait(+unpack)", "riem_solver3"}
+    assert all(v >= 0.0 for v in ph.values()) and ph["d_sw_rest"] > 0.0

@@ -223,6 +223,10 @@ AUDIT = None
 # (statements see the writes of earlier statements of the call) and once with every horizontally shifted read of an API field
 # served from the field's contents AT ENTRY -- and the two results are compared; {stencil: [calls, calls that differ]}.
 DIFFERENTIAL = None
+# Audit of region writes: set to a dict and every statement under `with horizontal(region[...])` that assigns to an API field
+# records {(stencil, field): [calls, points of the region mask that lay OUTSIDE origin .. origin + domain and were therefore not
+# written]}.  tools/region_write_audit.py runs the whole reference DynamicalCore with it.
+REGION_AUDIT = None
 
 
 class Ctx:
@@ -271,22 +275,24 @@ class Ctx:
             raise NotImplementedError(v.axes)
         return v
 
-    def region_mask(self, specs):
+    def region_mask(self, specs, open_bounds_clipped=False):
+        """open_bounds_clipped (the region audit): open-ended slice bounds (`:`, `a:`, `:b`) end at the launch window instead of
+        running over the whole storage, so that what is left outside the window comes from EXPLICIT bounds only."""
         total = None
         oi, oj = self.origin[0], self.origin[1]
         ei, ej = oi + self.domain[0], oj + self.domain[1]
         for si, sj in specs:
-            mi = _axis_mask(si, self.I, oi, ei)
-            mj = _axis_mask(sj, self.J, oj, ej)
+            mi = _axis_mask(si, self.I, oi, ei, open_bounds_clipped)
+            mj = _axis_mask(sj, self.J, oj, ej, open_bounds_clipped)
             m = mi & mj
             total = m if total is None else (total | m)
         return total
 
 
-def _axis_mask(spec, idx, start, end):
+def _axis_mask(spec, idx, start, end, open_bounds_clipped=False):
     if isinstance(spec, slice):
-        lo = _resolve_bound(spec.start, start, end, -(10 ** 9))
-        hi = _resolve_bound(spec.stop, start, end, 10 ** 9)
+        lo = _resolve_bound(spec.start, start, end, start if open_bounds_clipped else -(10 ** 9))
+        hi = _resolve_bound(spec.stop, start, end, end if open_bounds_clipped else 10 ** 9)
         return (idx >= lo) & (idx < hi)
     p = _resolve_bound(spec, start, end, None)
     return idx == p
@@ -618,6 +624,16 @@ class Interp:
                     specs.append(tuple(self._region_item(e, scope) for e in sl.elts))
                 rm = self.ctx.region_mask(specs)
                 m = rm if mask is None else (mask & rm)
+                if REGION_AUDIT is not None:
+                    stack = getattr(self.ctx, "region_stack", None)
+                    if stack is None:
+                        stack = self.ctx.region_stack = []
+                    stack.append((rm, self.ctx.region_mask(specs, open_bounds_clipped=True)))
+                    try:
+                        self.exec_block(st.body, scope, m)
+                    finally:
+                        stack.pop()
+                    return
                 self.exec_block(st.body, scope, m)
                 return
             raise NotImplementedError(f"with {name} inside a computation")
@@ -668,6 +684,16 @@ class Interp:
         k0, k1 = ctx.k0, ctx.k1
         m = mask
         if is_api:
+            if REGION_AUDIT is not None and getattr(ctx, "region_stack", None):
+                rm_, ex_ = ctx.region_stack[-1]
+                for r_, e_ in ctx.region_stack[:-1]:
+                    rm_, ex_ = rm_ & r_, ex_ & e_
+                outside = np.broadcast_to(rm_, ctx.dom_mask.shape) & ~ctx.dom_mask
+                explicit = np.broadcast_to(ex_, ctx.dom_mask.shape) & ~ctx.dom_mask
+                rec = REGION_AUDIT.setdefault((ctx.stencil_name, name), [0, 0, 0])
+                rec[0] += 1
+                rec[1] += int(outside.sum())
+                rec[2] += int(explicit.sum())
             m = ctx.dom_mask if m is None else (m & ctx.dom_mask)
             ctx.written_api.add(id(arr))
         if axes == ("I", "J", "K"):
