@@ -656,12 +656,14 @@ def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path, geometry
     with open(out, "rb") as f:
         got = pickle.load(f)
     detail = {}
-    errs = opchain.loop_errors(ref, got, n, nz, detail=detail)
+    errs = opchain.loop_errors(ref, got, n, nz, detail=detail, geometry=geometry)
     out_dir = os.path.join(root, "gpurun_out")
     if os.path.isdir(out_dir):
         json.dump(detail, open(os.path.join(out_dir, f"acoustic_loop_c96_{geometry}_gpu_errors.json"), "w"), indent=1)
     for k, e in errs.items():
         assert e < opchain.LOOP_TOL.get(k, 1e-9), (k, e)
+        if geometry == "sphere":
+            assert detail[k]["max_abs_error_over_magnitude"] < opchain.LOOP_ABS_SPHERE, (k, detail[k])
 
 
 def test_standalone_ppm_and_divergence_damping_match_oracle(lib):
