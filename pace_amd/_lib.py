@@ -178,7 +178,11 @@ class Library:
     _trace = bool(os.environ.get("PACE_TRACE_CALLS"))
 
     def call(self, name, *args):
-        end = self.timing.bracket(name) if self.timing is not None else None
+        end = None
+        if self.timing is not None:
+            last = args[-1] if args else None  # every entry point's last argument is its stream
+            ptr = getattr(last, "value", None) if isinstance(last, C.c_void_p) else None
+            end = self.timing.bracket(name, ptr)
         if self._trace:
             sys.stderr.write(f"[pace] {name}\n")
             sys.stderr.flush()

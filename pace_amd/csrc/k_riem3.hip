@@ -25,13 +25,16 @@
 #endif
 #define CH RIEM_CH
 
+// The solvers' intermediates (workspace fields) are double in BOTH builds: the float32-storage build rounds what the reference's
+// fields hold, not the tridiagonal systems' pivots and right-hand sides.
+typedef double wreal;
 struct Riem3Work {
-  real *pem, *pm, *w1, *gam, *pp, *aa;
+  wreal *pem, *pm, *w1, *gam, *pp, *aa;
 };
 #define RIEM3_NFIELDS 6
 
 int64_t riem3_workspace_bytes(const Geo& g) {
-  return (int64_t)g.sk * (g.nk + 1) * RIEM3_NFIELDS * (int64_t)sizeof(real);
+  return (int64_t)g.sk * (g.nk + 1) * RIEM3_NFIELDS * (int64_t)sizeof(wreal);
 }
 
 #define COLUMN_IJ(g) COLUMN_IJH(g, 0)
@@ -85,7 +88,7 @@ k_riem3_parallel_pre(Geo g, Riem3Work W, int last_call, double peln1, double ptk
   if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
   const long c = IDX3(g, i, j, k);
   const int km = g.nk;
-  const real* pg = W.aa;
+  const wreal* pg = W.aa;
   if (k == 0) {
     pk3[c] = ptk;
     if (last_call) peln[c] = peln1;
@@ -111,11 +114,12 @@ k_riem3_parallel_pre(Geo g, Riem3Work W, int last_call, double peln1, double ptk
 // C: the two tridiagonal systems of sim1_solver (sim1_solver.py:76-132); pe0 arrives in ppe
 // CG = 0: D-grid solver on the compute domain, delta_mass = delp * RGRAV (riem_solver3.py:86);
 // CG = 1: C-grid solver on compute +- 1, delta_mass = delpc / GRAV (riem_solver_c.py:84)
-template <int CG>
+// (T: real for riem_solver3, whose delz / ppe / w are the caller's fields; wreal for riem_solver_c, which hands workspace fields)
+template <int CG, class T>
 __global__ void __launch_bounds__(64)
 k_riem3_tridiag(Geo g, Riem3Work W, double dt, const real* __restrict__ cappa, const real* __restrict__ ws,
-                const real* __restrict__ delz, const real* __restrict__ delp, real* __restrict__ ppe,
-                real* __restrict__ w) {
+                const T* __restrict__ delz, const real* __restrict__ delp, T* __restrict__ ppe,
+                T* __restrict__ w) {
   COLUMN_IJH(g, CG);
   const double t1g = 2.0 * dt * dt, rdt = 1.0 / dt;
 #define DM(x) (CG ? (x) / GRAV : (x)*RGRAV)
@@ -380,7 +384,7 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
                         const real* pt, real* zh, real* pe, real* ppe, real* pk3, real* pk, real* peln,
                         real* w, double p_fac, hipStream_t st) {
   Riem3Work W;
-  real* p = (real*)ws;
+  wreal* p = (wreal*)ws;
   const long field = g.sk * (g.nk + 1);
   W.pem = p;
   W.pm = p + field;
@@ -395,7 +399,7 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
   hipLaunchKernelGGL(k_riem3_prefix<0>, cgrid, cblock, 0, st, g, W, ptop, delp, q_con);
   hipLaunchKernelGGL(k_riem3_parallel_pre, pgrid, pblock, 0, st, g, W, last_call, peln1, ptk, cappa, delp, pt, zh, delz, ppe,
                      pk3, peln);
-  hipLaunchKernelGGL(k_riem3_tridiag<0>, cgrid, cblock, 0, st, g, W, dt, cappa, wsd, delz, delp, ppe, w);
+  hipLaunchKernelGGL((k_riem3_tridiag<0, real>), cgrid, cblock, 0, st, g, W, dt, cappa, wsd, delz, delp, ppe, w);
   hipLaunchKernelGGL(k_riem3_parallel_post, pgrid, pblock, 0, st, g, W, last_call, cappa, delp, pt, delz, pk3, pk, pe, p_fac);
   hipLaunchKernelGGL(k_riem3_zh, cgrid, cblock, 0, st, g, zs, delz, zh);
   PACE_CHECK_LAUNCH();
@@ -408,12 +412,12 @@ int launch_riem_solver3(const Geo& g, void* ws, int last_call, double dt, const 
 // =================================================================================================
 struct RiemCWork {
   Riem3Work r;
-  real *dz, *pe, *w;
+  wreal *dz, *pe, *w;
 };
 #define RIEMC_NFIELDS 9
 
 int64_t riemc_workspace_bytes(const Geo& g) {
-  return (int64_t)g.sk * (g.nk + 1) * RIEMC_NFIELDS * (int64_t)sizeof(real);
+  return (int64_t)g.sk * (g.nk + 1) * RIEMC_NFIELDS * (int64_t)sizeof(wreal);
 }
 
 // precompute (riem_solver_c.py:21-88) without the prefix sums + first statement of sim1_solver
@@ -423,7 +427,7 @@ k_riemc_parallel_pre(Geo g, RiemCWork W, const real* __restrict__ cappa, const r
   PLANE_IJK(g);
   if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1 || k >= g.nk) return;
   const long c = IDX3(g, i, j, k);
-  const real* peg = W.r.aa;
+  const wreal* peg = W.r.aa;
   const double pmk = (peg[c + g.sk] - peg[c]) / log(peg[c + g.sk] / peg[c]);
   W.r.pm[c] = pmk;
   const double dz = gz[c + g.sk] - gz[c];
@@ -451,7 +455,7 @@ k_riemc_parallel_post(Geo g, RiemCWork W, double ptop, const real* __restrict__ 
 }
 
 __global__ void __launch_bounds__(64)
-k_riemc_gz(Geo g, const real* __restrict__ hs, const real* __restrict__ dz, real* __restrict__ gz) {
+k_riemc_gz(Geo g, const real* __restrict__ hs, const wreal* __restrict__ dz, real* __restrict__ gz) {
   COLUMN_IJH(g, 1);
   double z = hs[c0];
   gz[AT(km)] = z;
@@ -477,7 +481,7 @@ int launch_riem_solver_c(const Geo& g, void* ws, double dt2, const real* cappa, 
                          const real* ws3, const real* ptc, const real* q_con, const real* delpc, real* gz,
                          real* pef, const real* w3, double p_fac, hipStream_t st) {
   RiemCWork W;
-  real* p = (real*)ws;
+  wreal* p = (wreal*)ws;
   const long field = g.sk * (g.nk + 1);
   W.r.pem = p;
   W.r.pm = p + field;
@@ -492,7 +496,7 @@ int launch_riem_solver_c(const Geo& g, void* ws, double dt2, const real* cappa, 
   const dim3 pgrid = plane_grid(g, g.nk + 1), pblock(256);
   hipLaunchKernelGGL(k_riem3_prefix<1>, cgrid, cblock, 0, st, g, W.r, ptop, delpc, q_con);
   hipLaunchKernelGGL(k_riemc_parallel_pre, pgrid, pblock, 0, st, g, W, cappa, delpc, ptc, gz, w3);
-  hipLaunchKernelGGL(k_riem3_tridiag<1>, cgrid, cblock, 0, st, g, W.r, dt2, cappa, ws3, W.dz, delpc, W.pe, W.w);
+  hipLaunchKernelGGL((k_riem3_tridiag<1, wreal>), cgrid, cblock, 0, st, g, W.r, dt2, cappa, ws3, W.dz, delpc, W.pe, W.w);
   hipLaunchKernelGGL(k_riemc_parallel_post, pgrid, pblock, 0, st, g, W, ptop, cappa, delpc, ptc, pef, p_fac);
   hipLaunchKernelGGL(k_riemc_gz, cgrid, cblock, 0, st, g, hs, W.dz, gz);
   PACE_CHECK_LAUNCH();

@@ -103,22 +103,32 @@ class NullTimer(Timer):
 
 
 class KernelTimes:
-    """Per-entry-point device times: ``Library.call`` brackets every call with two events on the current stream while a
+    """Per-entry-point device times: ``Library.call`` brackets every call with two events on the call's launch stream while a
     collector is attached (``lib.timing = KernelTimes()``).  ``report()`` resolves the events and prints the table."""
 
     def __init__(self):
         self._pending = []  # (name, start event, end event)
         self.exec_info = {}  # name -> {"ncalls", "total_run_time" (s)}
 
-    def bracket(self, name):
+    def bracket(self, name, stream_ptr=None):
+        """Start event of one entry-point call, recorded on the stream the call launches on (`stream_ptr`: the raw HIP stream
+        the entry point was handed -- its last argument -- or None for the current stream: d_sw's wind half runs on a side
+        stream, and events on a stream that runs nothing would time nothing).  Returns an object whose .record() closes the
+        bracket on the same stream."""
         import torch
 
         if not torch.cuda.is_available():
             return None
+        stream = torch.cuda.ExternalStream(int(stream_ptr)) if stream_ptr else torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(stream)
         self._pending.append((name, e0, e1))
-        return e1
+
+        class _End:
+            def record(self_inner):
+                e1.record(stream)
+
+        return _End()
 
     def resolve(self):
         import torch

@@ -134,7 +134,7 @@ def acoustic_config(n_split, variant=None):
                                   riemann=RiemannConfig(p_fac=0.05))
 
 
-def run_acoustic_tile(comm, lib, device, fix, n, nz, variant=None):
+def run_acoustic_tile(comm, lib, device, fix, n, nz, variant=None, checkpointer=None):
     """One tile's program: build the environment from the fixture, run one AcousticDynamics call."""
     import torch
 
@@ -149,7 +149,7 @@ def run_acoustic_tile(comm, lib, device, fix, n, nz, variant=None):
     n_split = int(fix["n_split"])
     wsd = env.q2()
     dyn = AcousticDynamics(cube, env.stencil_factory, env.qf, env.grid_data, env.damping, 0, False, False,
-                           acoustic_config(n_split, variant), state.phis, wsd, state)
+                           acoustic_config(n_split, variant), state.phis, wsd, state, checkpointer=checkpointer)
     dyn.cappa.set(fix["in_cappa"])
     dyn(state, timestep=float(fix["timestep"]), n_map=1)
     if env.qf.device.type == "cuda":
@@ -168,11 +168,13 @@ def acoustic_variant_fixture(t, variant):
     return fix
 
 
-def run_acoustic_six_tiles(lib, device, n=12, nz=79, variant=None):
+def run_acoustic_six_tiles(lib, device, n=12, nz=79, variant=None, checkpointers=None):
     from pace_amd.util import run_tiles
 
     fixes = [acoustic_variant_fixture(t, variant) if variant else acoustic_fixture(t) for t in range(6)]
-    return fixes, run_tiles(6, lambda comm: run_acoustic_tile(comm, lib, device, fixes[comm.Get_rank()], n, nz, variant))
+    cps = checkpointers or [None] * 6
+    return fixes, run_tiles(6, lambda comm: run_acoustic_tile(comm, lib, device, fixes[comm.Get_rank()], n, nz, variant,
+                                                              checkpointer=cps[comm.Get_rank()]))
 
 
 def acoustic_errors(fix, out, n=12):

@@ -2,6 +2,8 @@
 C ABI, checked against the reference-generated fixtures.  This is how kernel index logic / LDS tiling /
 barrier structure is verified in the GPU-less container (and under ASan); it says nothing about the GPU
 build, which the `-m gpu` tests cover.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,6 +42,98 @@ def test_riem_solver3_kernel_emulated(emu_lib, name):
         nk = 79 if k in ("delz", "w") else 80
         err = compare(fix["out_" + k][:, :, :nk], out[k][3:15, 3:7, :nk], near_zero=1e-12)
         assert err < 5e-6, (k, err)  # overrides/standard.yaml:49-61
+
+
+def test_in_checkpoints_hold_the_state_before_the_call(emu_lib):
+    """AcousticDynamics overlaps the u / v and uc / vc halo exchanges with the interior of c_sw's first pass and
+    of d_sw's flux preparation; with a checkpointer attached those early starts are skipped, so that "C_SW-In" / "D_SW-In" hold
+    what the reference's savepoints hold -- the fields BEFORE the call.  At the first substep's D_SW-In the area fluxes are still
+    the zeros they were allocated with (an early flux preparation would have filled the interior box), at every D_SW-In mfxd
+    equals what the previous D_SW-Out left, and the run ends with the same bits as the run without a checkpointer."""
+    seen = [dict(n=0, xfx0=None, mfx_out=None, ok=True) for _ in range(6)]
+
+    def make(t):
+        rec = seen[t]
+
+        def cp(name, **f):
+            if name == "D_SW-In":
+                if rec["n"] == 0:
+                    rec["xfx0"] = float(np.abs(f["xfxd"].numpy()).max()) + float(np.abs(f["yfxd"].numpy()).max())
+                elif rec["mfx_out"] is not None:
+                    rec["ok"] = rec["ok"] and np.array_equal(f["mfxd"].numpy(), rec["mfx_out"])
+                rec["n"] += 1
+            elif name == "D_SW-Out":
+                rec["mfx_out"] = f["mfxd"].numpy().copy()
+
+        return cp
+
+    _, with_cp = run_acoustic_six_tiles(emu_lib, "cpu", checkpointers=[make(t) for t in range(6)])
+    _, without = run_acoustic_six_tiles(emu_lib, "cpu")
+    for t in range(6):
+        assert seen[t]["n"] == 2 and seen[t]["xfx0"] == 0.0 and seen[t]["ok"], seen[t]
+        for k in with_cp[t]:
+            assert np.array_equal(with_cp[t][k], without[t][k], equal_nan=True), (t, k)
+
+
+def _legacy_solver_child(precision):
+    """(child process, PACE_LEGACY_COLUMN_SOLVERS=1 in its environment: the switch is read once per process)"""
+    import pickle
+    import sys
+
+    from pace_amd import _lib, synthetic
+    from oracle import vertical
+
+    lib = _lib.Library(build_emu() if precision == 64 else __import__("test_f32").build_emu_f32())
+    out = {}
+    # riem_solver3 on the reference-run fixture
+    fix = golden("riem_solver3_c12_tile0_call3.npz")
+    env = Env(lib, "cpu", golden("grid_c12_tile0.npz"), 12, 79)
+    got = run_riem3(env, expand_riem_fixture(fix), bool(fix["last_call"]), float(fix["dt"]), float(fix["ptop"]))
+    for k in ("delz", "zh", "p", "ppe", "pk3", "pk", "log_p_interface", "w"):
+        nk = 79 if k in ("delz", "w") else 80
+        ref = fix["out_" + k][:, :, :nk]
+        out["riem3." + k] = float(np.abs(ref - got[k][3:15, 3:7, :nk]).max() / (np.abs(ref).max() + 1e-300))
+    # riem_solver_c against the oracle on the synthetic state
+    from pace_amd.fv3core.stencils.riem_solver_c import NonhydrostaticVerticalSolverCGrid
+
+    n, nz = 12, 20
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, "cpu", m, n, nz)
+    g = oracle_grid(m, n, nz)
+    a = {k: s[k].copy() for k in ("cappa", "pt", "q_con", "delp", "zh", "w")}
+    hs, ws3 = s["zs"] * 9.80665, np.zeros(s["zs"].shape)
+    pef = np.zeros_like(s["pt"])
+    q = {k: env.q3(v) for k, v in a.items()}
+    qpef, qhs, qws = env.q3(pef), env.q2(hs), env.q2(ws3)
+    op = NonhydrostaticVerticalSolverCGrid(env.stencil_factory, env.qf, 0.05)
+    op(0.5 * s["dt"], q["cappa"], float(m["ptop"]), qhs, qws, q["pt"], q["q_con"], q["delp"], q["zh"], qpef, q["w"])
+    vertical.riem_solver_c(g, 0.5 * s["dt"], a["cappa"], float(m["ptop"]), hs, ws3, a["pt"], a["q_con"], a["delp"], a["zh"], pef, a["w"], p_fac=0.05)
+    W = (slice(2, 4 + n), slice(2, 4 + n), slice(0, nz + 1))
+    for k, ref, dev in (("gz", a["zh"], q["zh"].numpy()), ("pef", pef, qpef.numpy())):
+        out["riem_c." + k] = float(np.abs(ref[W] - dev[W]).max() / (np.abs(ref[W]).max() + 1e-300))
+    pickle.dump(out, sys.stdout.buffer)
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_legacy_thread_per_column_solvers_emulated(precision):
+    """The thread-per-column kernels of k_riem3.hip -- reached for more than 128 layers or with PACE_LEGACY_COLUMN_SOLVERS=1 --
+    after their workspace became double in both builds: riem_solver3 against the reference-run fixture and
+    riem_solver_c against the oracle, float64 library at the operator's bound, float32-storage library at float32 accuracy."""
+    import pickle
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
+            f"import test_emu_kernels as t; t._legacy_solver_child({precision})")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=900, env=dict(os.environ, PACE_LEGACY_COLUMN_SOLVERS="1"))
+    assert p.returncode == 0, p.stderr[-3000:].decode()
+    errs = pickle.loads(p.stdout)
+    for k, e in errs.items():
+        tol = 1e-10 if precision == 64 else (5e-3 if k in ("riem3.ppe", "riem3.w") else 2e-5)
+        assert e < tol, (k, e, errs)
 
 
 def test_fvtp2d_kernel_emulated(emu_lib):
