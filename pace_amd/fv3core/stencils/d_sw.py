@@ -153,6 +153,23 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         # saturate the SIMDs -- while the winds next to the bandwidth-shaped column solver do (-10 % per substep).
         # (Measured in round 2 as well: only the kinetic energy + vorticity (mask 64, bandwidth-shaped) next to the scalar
         # transports and the rest of the winds (128 | 8) next to the column solver: no difference either.)
+        # Winds A (kinetic energy, vorticity, divergence damping, vorticity transport: they need only the flux preparation) run
+        # on the side stream NEXT TO the scalar transports, winds B (heating, final wind update: they need the new delp) after
+        # them, next to whatever the caller launches next (the column solver).  Measured in round 3 (bench.py, C192 x 79, three
+        # alternating runs each): 1.137 ms against 1.191 ms for the round-2 order (all winds after the scalars), which
+        # PACE_DSW_LATE_WINDS=1 restores.  (Round 2 had measured no difference: the transport kernels have changed since.)
+        if not os.environ.get("PACE_DSW_LATE_WINDS"):
+            phases(prep, self.stream())
+            self._ev_prep.record(main)
+            side.wait_event(self._ev_prep)
+            phases(4, side_ptr)
+            phases(2, self.stream())
+            self._ev_scalars.record(main)
+            side.wait_event(self._ev_scalars)
+            phases(8, side_ptr)
+            self._done.record(side)
+            self._pending = True
+            return
         phases(prep | 2, self.stream())  # flux preparation + scalar transport on the calling stream
         self._ev_scalars.record(main)
         side.wait_event(self._ev_scalars)
