@@ -540,7 +540,7 @@ def main():
         traffic, traffic_detail = (None, "skipped (--no-traffic)")
         if not args.no_traffic and world == 1:
             torch.cuda.synchronize()
-            traffic, traffic_detail = measure_traffic(("k_fvtp2d<6, 2, 1>", "k_fvtp2dILi6ELi2ELi1E"), n, nz, args.precision)
+            traffic, traffic_detail = measure_traffic(("k_fvtp2d<6, 2, 1>", "k_fvtp2d<6, 2, 1,", "k_fvtp2dILi6ELi2ELi1E"), n, nz, args.precision)
         # what this memory system sustains on a plain device-to-device copy (read + write of 1 GiB each way), next to the spec
         # peak the fractions are priced against
         try:
@@ -558,12 +558,13 @@ def main():
             del src, dst
         except Exception:  # noqa: BLE001
             copy_gbs = None
-        roof = {"kernel": "k_fvtp2d<6, 2, 1>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"kernel": "k_fvtp2d<6, 2, 1, canonical tiling>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "measured_copy_GBs": copy_gbs,
                 "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                 "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo,
-                "limited_by": "latency of its barrier-separated stages at 4 waves per SIMD (VALU ~37 % busy, HBM ~3 TB/s): "
-                              "DESIGN.md section 4; the roofline that prices it is HBM"}
+                "limited_by": "chains of dependent stages (LDS round trips, global-load waits, barriers) at 4 waves per SIMD with the "
+                              "instruction issue of a SIMD ~saturated by its four waves (DESIGN.md section 4.0, round 3 ablations); "
+                              "the roofline that prices it is HBM"}
 
     if rank == 0:
         line = {

@@ -1258,6 +1258,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     }
     if (kp > 0) {
       if ((rc = launch_transport(g, m, q_con + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_dp, kp, 2, 1, dp, st_q))) return rc;
+      // (pt stays on the caller's stream: with the side streams on, w, q_con and pt are three concurrent launches)
       if ((rc = launch_transport(g, m, pt + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_tm, kp, 2, 1, dp2, st))) return rc;
     }
     if (kp < nl) {
