@@ -159,6 +159,8 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         # alternating runs each): 1.137 ms against 1.191 ms for the round-2 order (all winds after the scalars), which
         # PACE_DSW_LATE_WINDS=1 restores.  (Round 2 had measured no difference: the transport kernels have changed since.)
         if not os.environ.get("PACE_DSW_LATE_WINDS"):
+            # (Round 3, rejected: kinetic energy + vorticity started already after the first half of the flux preparation,
+            # next to its streaming second half: 1.160 ms against 1.141 ms, four alternating runs -- profiles/r03_experiments/x14.)
             phases(prep, self.stream())
             self._ev_prep.record(main)
             side.wait_event(self._ev_prep)
