@@ -130,15 +130,57 @@ def _cpu_riem_strip(args):
     return sec, {k: b[k] for k in ("delz", "zh", "ppe", "pk3", "w")}
 
 
-def cpu_baseline(n, nz, metrics, s, dt, ptop, reps=10):
-    """The oracle -- the numpy restatement with the reference's stencil granularity (one array statement per gtscript
-    statement, every temporary a full field) -- on ALL host cores and on the SAME operands the GPU was timed on: one process
-    per core, phase 1 = d_sw on a slab of levels per process, phase 2 = riem_solver3 on a strip of rows per process on what d_sw
-    left (what an OpenMP loop over k / j around the same statements does).  Protocol of BASELINE.md section 4.1: one warm-up,
-    `reps` timed repetitions, the MEDIAN wall time of a substep (slowest share of phase 1 + slowest share of phase 2).
-    kind = 'port': the reference's own CPU backend (gt:cpu_ifirst) needs GT4Py + GridTools and cannot be built here; a C++ /
-    OpenMP loop-nest version of the same statements has not been written.
-    Returns (record, outputs): the oracle's output fields of the substep, for bench.py's `verified`."""
+def _cpu_omp_job(args):
+    """One child process: the C++ / OpenMP restatement (oracle/omp/dsw_riem3.cpp: one parallel loop nest per reference stencil, i
+    first, whole-field temporaries) of d_sw + riem_solver3 on the operands the GPU was timed on, all host cores.  1 warm-up,
+    `reps` timed substeps (operands restored outside the timed region).  Returns (list of seconds, threads, outputs of the warm-up
+    run in the oracle's layout)."""
+    path, n, nz, reps, threads = args
+    import time as _t
+
+    from oracle import omp_port
+    from oracle._np import Grid
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import column_namelist_arrays
+    from pace_amd.tile import DSW_CFG
+
+    c = _cpu_load(path)
+    s = c["s"]
+    omp_port.load()
+    omp_port.set_threads(threads)
+    col = column_namelist_arrays(DGridShallowWaterLagrangianDynamicsConfig(), nz)
+    tile = omp_port.Tile(Grid(n, nz, c["metrics"]))
+    zero = np.zeros_like(s["u"])
+    dsw = omp_port.DswCall(tile, col, DSW_CFG, zero, zero, {k: s[k] for k in omp_port.DSW_FIELDS}, c["dt"])
+    dsw.run()  # warm-up (page faults, the workspace) -- and the operands of the column solver
+    o = dsw.outputs()
+    names = {"pe": "pe", "peln": "peln"}
+    riem = omp_port.RiemCall(tile, {k: (o[k] if k in ("q_con", "delp", "pt", "w") else s[names.get(k, k)]) for k in omp_port.RIEM_FIELDS},
+                             False, c["dt"], c["ptop"], 0.05)
+    riem.run()
+    r = riem.outputs()
+    out = {k: np.ascontiguousarray(o[k]) for k in omp_port.DSW_FIELDS}
+    out.update({"riem." + k: np.ascontiguousarray(r[k]) for k in ("delz", "zh", "ppe", "pk3", "w")})
+    secs = []
+    for _ in range(reps):
+        dsw.reset()
+        riem.reset()
+        t0 = _t.perf_counter()
+        dsw.run()
+        riem.run()
+        secs.append(_t.perf_counter() - t0)
+    return secs, omp_port.threads(), out
+
+
+def cpu_baseline(n, nz, metrics, s, dt, ptop, reps=10, numpy_reps=3):
+    """The CPU baseline of SURVEY.md section 8(d): the C++ / OpenMP restatement at the reference's granularity (one parallel loop
+    nest per reference stencil, i first, every intermediate a whole field in memory -- what the reference's gt:cpu_ifirst
+    backend generates; oracle/omp/dsw_riem3.cpp, bit-identical to the numpy oracle in d_sw, tests/test_oracle_omp.py) on ALL
+    host cores and on the SAME operands the GPU was timed on.  Protocol of BASELINE.md section 4.1: one warm-up, `reps` timed
+    substeps, the MEDIAN.  kind = 'port' (the reference's own CPU backend needs GT4Py + GridTools and cannot be built here).
+    Beside it, as in rounds 1-2, the numpy oracle in one process per core (`numpy_*` keys; `numpy_reps` timed substeps): phase 1 =
+    d_sw on a slab of levels per process, phase 2 = riem_solver3 on a strip of rows per process.
+    Returns (record, outputs): the NUMPY oracle's output fields of the substep, for bench.py's `verified`."""
     import multiprocessing as mp
     import tempfile
 
@@ -160,7 +202,7 @@ def cpu_baseline(n, nz, metrics, s, dt, ptop, reps=10):
     walls, out = [], {}
     try:
         with ctx.Pool(len(jobs1)) as pool:
-            for rep in range(reps + 1):  # rep 0: warm-up (imports, page faults, the operands file)
+            for rep in range(numpy_reps + 1):  # rep 0: warm-up (imports, page faults, the operands file)
                 r1 = pool.map(_cpu_dsw_slab, jobs1)
                 if rep == 0:
                     for k in r1[0][1]:
@@ -179,15 +221,32 @@ def cpu_baseline(n, nz, metrics, s, dt, ptop, reps=10):
                     continue
                 walls.append(max(x[0] for x in r1) + max(x[0] for x in r2))
             one = pool.map(_cpu_dsw_slab, jobs1[:1])[0][0] + pool.map(_cpu_riem_strip, jobs2[:1])[0][0]  # one share, the other cores idle
+        ncpu = os.cpu_count() or 1
+        with ctx.Pool(1) as pool:  # (its own process: no other OpenMP runtime, no GPU context)
+            omp_secs, omp_threads, omp_out = pool.map(_cpu_omp_job, [(path, n, nz, reps, ncpu)])[0]
     finally:
         import shutil
 
         shutil.rmtree(tmp, ignore_errors=True)
     wall = float(np.median(walls))
-    rec = {"value": n * n * nz / wall, "unit": "cell-updates/s", "cores": len(jobs1), "kind": "port",
-           "sample": f"{reps} substeps (d_sw + riem_solver3) at C{n}x{nz}L after 1 warm-up, the operands the GPU was timed on, numpy "
-                     f"oracle, {len(jobs1)} processes (levels / rows split), median {wall:.2f} s (min {min(walls):.2f}, max {max(walls):.2f})",
-           "one_core_value": n * n * nz / (one * len(jobs1))}
+    owall = float(np.median(omp_secs))
+    # the restatement against the numpy oracle on these operands (d_sw: the same operations in the same order; the column solver
+    # through another libm): worst error relative to each field's magnitude
+    port_err = 0.0
+    for k, v in omp_out.items():
+        if k in out and k != "zh":
+            a_, b_ = np.asarray(out[k], dtype=np.float64)[3:3 + n, 3:3 + n, :nz], v[3:3 + n, 3:3 + n, :nz]
+            port_err = max(port_err, float(np.abs(a_ - b_).max() / max(np.abs(a_).max(), 1e-300)))
+    rec = {"value": n * n * nz / owall, "unit": "cell-updates/s", "cores": omp_threads, "kind": "port",
+           "detail": "restatement, reference granularity: C++ / OpenMP, one parallel loop nest per reference stencil, i first, "
+                     f"OMP_NUM_THREADS = {omp_threads} = host cores (oracle/omp/dsw_riem3.cpp)",
+           "sample": f"{reps} substeps (d_sw + riem_solver3) at C{n}x{nz}L after 1 warm-up, the operands the GPU was timed on, median "
+                     f"{owall * 1e3:.1f} ms (min {min(omp_secs) * 1e3:.1f}, max {max(omp_secs) * 1e3:.1f})",
+           "max_error_vs_numpy_oracle": port_err,
+           "numpy_value": n * n * nz / wall, "numpy_cores": len(jobs1),
+           "numpy_sample": f"{numpy_reps} substeps after 1 warm-up, numpy oracle, {len(jobs1)} processes (levels / rows split), median "
+                           f"{wall:.2f} s (min {min(walls):.2f}, max {max(walls):.2f})",
+           "numpy_one_core_value": n * n * nz / (one * len(jobs1))}
     return rec, out
 
 

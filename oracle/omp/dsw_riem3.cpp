@@ -1,0 +1,1213 @@
+// ORACLE (test infrastructure, never product code) -- C++ / OpenMP restatement of the headline path: the D-grid shallow-water
+// step (Fortran d_sw) and the nonhydrostatic column solver (riem_solver3), at the REFERENCE'S GRANULARITY: one parallel loop
+// nest per reference stencil (`#pragma omp parallel for` over levels, i innermost = unit stride, what the reference's
+// `gt:cpu_ifirst` backend would generate), every intermediate field a whole 3-D array in memory between two stencils.  This is
+// the CPU baseline of bench.py (`cpu_baseline.kind` = "port", "restatement, reference granularity"), checked against the numpy
+// oracle in tests/test_oracle_omp.py.  Only tests/, __graft_entry__ and bench.py's cpu_baseline leg may load it.
+//
+// Follows (all under /root/reference, read for behaviour only):
+//   fv3core/pace/fv3core/stencils/fxadv.py:10-661          FiniteVolumeFluxPrep
+//   fv3core/pace/fv3core/stencils/xppm.py:19-355, yppm.py  piecewise-parabolic fluxes (|ord| < 8)
+//   fv3core/pace/fv3core/stencils/fvtp2d.py:34-346         FiniteVolumeTransport
+//   fv3core/pace/fv3core/stencils/delnflux.py:21-1261      DelnFlux / DelnFluxNoSG
+//   fv3core/pace/fv3core/stencils/xtp_u.py:9-91, ytp_v.py  advect_u_along_x / advect_v_along_y
+//   fv3core/pace/fv3core/stencils/a2b_ord4.py:22-761       AGrid2BGridFourthOrder
+//   fv3core/pace/fv3core/stencils/divergence_damping.py:23-632
+//   fv3core/pace/fv3core/stencils/d_sw.py:33-1237          DGridShallowWaterLagrangianDynamics
+//   fv3core/pace/fv3core/stencils/sim1_solver.py:20-219, riem_solver3.py:26-321
+//   stencils/pace/stencils/corners.py:307-425,591-712,987-1151
+// Storage: [k][j][i], i fastest, (N+7) x (N+7) points per level, nk+1 levels; tile edges at is = js = 3 (one tile per rank).
+// Built by oracle/omp/Makefile with -O3 -fopenmp -ffp-contract=off (no FMA contraction: the horizontal operators are
+// bit-comparable with the numpy oracle).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Grid {
+  int n, nk, ni, nj, is, ie, js, je;
+  long sk;  // level stride = ni * nj
+  // 2-D metric terms [j][i]
+  const double *cosa_u, *cosa_v, *rsin_u, *rsin_v, *sin_sg1, *sin_sg2, *sin_sg3, *sin_sg4, *rdxa, *rdya, *dx, *dy, *dxa, *dya,
+      *rdx, *rdy, *area, *rarea, *del6_u, *del6_v, *cosa, *rsina, *fC_agrid, *rsin2, *cosa_s, *divg_u, *divg_v, *rarea_c, *sina_u,
+      *sina_v, *dxc, *dyc, *lon, *lat, *lon_agrid, *lat_agrid;
+  const double *edge_w, *edge_e, *edge_s, *edge_n;  // 1-D: edge_w / edge_e over j, edge_s / edge_n over i
+  double da_min, da_min_c;
+};
+
+#define NMETRIC 36
+#define AT(a, i, j, k) (a)[(long)(k) * g.sk + (long)(j) * g.ni + (i)]
+#define M2(a, i, j) (g.a)[(long)(j) * g.ni + (i)]
+
+// ppm.py:6-19
+constexpr double C1 = -2.0 / 14.0, C2 = 11.0 / 14.0, C3 = 5.0 / 14.0, P1 = 7.0 / 12.0, P2 = -1.0 / 12.0;
+
+inline double contra(double v1, double v2, double cosa, double rsin2) { return (v1 - v2 * cosa) * rsin2; }  // d2a2c_vect.py:225-281
+
+// -------------------------------------------------------------------------------------------------------- workspace
+struct Work {
+  std::vector<double> buf;
+  long n3 = 0;
+  int used = 0;
+  double* take() { return buf.data() + (long)(used++) * n3; }
+};
+
+// -------------------------------------------------------------------------------------------------------- fxadv
+// FiniteVolumeFluxPrep.__call__ (fxadv.py:565-661): nine stencils, each its own loop nest
+void fxadv(const Grid& g, const double* uc, const double* vc, double* crx, double* cry, double* xfx, double* yfx, double* ut,
+           double* vt, double dt) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, nk = g.nk;
+  const int I1 = g.ni - 1, J1 = g.nj - 1;  // domain_full: N + 6 points
+  // main_uc_vc_contra :10-48
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < J1; ++j)
+      for (int i = 0; i < I1; ++i) {
+        if (i >= is - 1 && i <= ie + 2 && i >= 1 && !((j >= js - 1 && j <= js) || (j >= je && j <= je + 1))) {
+          const double vbar = 0.25 * (AT(vc, i - 1, j, k) + AT(vc, i, j, k) + AT(vc, i - 1, j + 1, k) + AT(vc, i, j + 1, k));
+          AT(ut, i, j, k) = contra(AT(uc, i, j, k), vbar, M2(cosa_u, i, j), M2(rsin_u, i, j));
+        }
+        if (j >= js - 1 && j <= je + 2 && j >= 1) {
+          const double ubar = 0.25 * (AT(uc, i, j - 1, k) + AT(uc, i + 1, j - 1, k) + AT(uc, i, j, k) + AT(uc, i + 1, j, k));
+          AT(vt, i, j, k) = contra(AT(vc, i, j, k), ubar, M2(cosa_v, i, j), M2(rsin_v, i, j));
+        }
+      }
+  // uc_contra_y_edge :51-77
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < J1; ++j)
+      for (int i : {is, ie + 1}) {
+        const double u = AT(uc, i, j, k);
+        AT(ut, i, j, k) = (u > 0.0) ? u / M2(sin_sg3, i - 1, j) : u / M2(sin_sg1, i, j);
+      }
+  // vc_contra_y_edge :80-125
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = js + 2; j <= je - 1; ++j)
+      for (int i : {is - 1, is, ie, ie + 1}) {
+        const double ucb = 0.25 * (AT(ut, i, j - 1, k) + AT(ut, i + 1, j - 1, k) + AT(ut, i, j, k) + AT(ut, i + 1, j, k));
+        AT(vt, i, j, k) = contra(AT(vc, i, j, k), ucb, M2(cosa_v, i, j), 1.0);
+      }
+  // vc_contra_x_edge :128-145
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j : {js, je + 1})
+      for (int i = 0; i < I1; ++i) {
+        const double v = AT(vc, i, j, k);
+        AT(vt, i, j, k) = (v > 0.0) ? v / M2(sin_sg4, i, j - 1) : v / M2(sin_sg2, i, j);
+      }
+  // uc_contra_x_edge :148-180
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j : {js - 1, js, je, je + 1})
+      for (int i = is + 2; i <= ie - 1; ++i) {
+        const double vcb = 0.25 * (AT(vt, i - 1, j, k) + AT(vt, i, j, k) + AT(vt, i - 1, j + 1, k) + AT(vt, i, j + 1, k));
+        AT(ut, i, j, k) = contra(AT(uc, i, j, k), vcb, M2(cosa_u, i, j), 1.0);
+      }
+  // uc_contra_corners :183-300 (reads ut only at points it does not write: in place)
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    auto U = [&](int i, int j) -> double& { return AT(ut, i, j, k); };
+    auto V = [&](int i, int j) -> double { return AT(vt, i, j, k); };
+    for (int j : {js - 1, je}) {
+      int i = is + 1;
+      double cu = M2(cosa_u, i, j), cv = M2(cosa_v, i - 1, j);
+      double damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      U(i, j) = (AT(uc, i, j, k) - 0.25 * cu * (V(i - 1, j + 1) + V(i, j + 1) + V(i, j) + AT(vc, i - 1, j, k) -
+                                                0.25 * cv * (U(i - 1, j) + U(i - 1, j - 1) + U(i, j - 1)))) * damp;
+      i = ie;
+      cu = M2(cosa_u, i, j); cv = M2(cosa_v, i, j);
+      damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      U(i, j) = (AT(uc, i, j, k) - 0.25 * cu * (V(i, j + 1) + V(i - 1, j + 1) + V(i - 1, j) + AT(vc, i, j, k) -
+                                                0.25 * cv * (U(i + 1, j) + U(i + 1, j - 1) + U(i, j - 1)))) * damp;
+    }
+    for (int j : {js, je + 1}) {
+      int i = is + 1;
+      double cu = M2(cosa_u, i, j), cv = M2(cosa_v, i - 1, j + 1);
+      double damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      U(i, j) = (AT(uc, i, j, k) - 0.25 * cu * (V(i - 1, j) + V(i, j) + V(i, j + 1) + AT(vc, i - 1, j + 1, k) -
+                                                0.25 * cv * (U(i - 1, j) + U(i - 1, j + 1) + U(i, j + 1)))) * damp;
+      i = ie;
+      cu = M2(cosa_u, i, j); cv = M2(cosa_v, i, j + 1);
+      damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      U(i, j) = (AT(uc, i, j, k) - 0.25 * cu * (V(i, j) + V(i - 1, j) + V(i - 1, j + 1) + AT(vc, i, j + 1, k) -
+                                                0.25 * cv * (U(i + 1, j) + U(i + 1, j + 1) + U(i, j + 1)))) * damp;
+    }
+  }
+  // vc_contra_corners :303-404
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    auto U = [&](int i, int j) -> double { return AT(ut, i, j, k); };
+    auto V = [&](int i, int j) -> double& { return AT(vt, i, j, k); };
+    int j = js + 1;
+    for (int i : {is - 1, ie}) {
+      const double cv = M2(cosa_v, i, j), cu = M2(cosa_u, i, j - 1);
+      const double damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      V(i, j) = (AT(vc, i, j, k) - 0.25 * cv * (U(i + 1, j - 1) + U(i + 1, j) + U(i, j) + AT(uc, i, j - 1, k) -
+                                                0.25 * cu * (V(i, j - 1) + V(i - 1, j - 1) + V(i - 1, j)))) * damp;
+    }
+    for (int i : {is, ie + 1}) {
+      const double cv = M2(cosa_v, i, j), cu = M2(cosa_u, i + 1, j - 1);
+      const double damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      V(i, j) = (AT(vc, i, j, k) - 0.25 * cv * (U(i, j - 1) + U(i, j) + U(i + 1, j) + AT(uc, i + 1, j - 1, k) -
+                                                0.25 * cu * (V(i, j - 1) + V(i + 1, j - 1) + V(i + 1, j)))) * damp;
+    }
+    j = je;
+    for (int i : {ie + 1, is}) {
+      const double cv = M2(cosa_v, i, j), cu = M2(cosa_u, i + 1, j);
+      const double damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      V(i, j) = (AT(vc, i, j, k) - 0.25 * cv * (U(i, j) + U(i, j - 1) + U(i + 1, j - 1) + AT(uc, i + 1, j, k) -
+                                                0.25 * cu * (V(i, j + 1) + V(i + 1, j + 1) + V(i + 1, j)))) * damp;
+    }
+    for (int i : {ie, is - 1}) {
+      const double cv = M2(cosa_v, i, j), cu = M2(cosa_u, i, j);
+      const double damp = 1.0 / (1.0 - 0.0625 * cu * cv);
+      V(i, j) = (AT(vc, i, j, k) - 0.25 * cv * (U(i + 1, j) + U(i + 1, j - 1) + U(i, j - 1) + AT(uc, i, j, k) -
+                                                0.25 * cu * (V(i, j + 1) + V(i - 1, j + 1) + V(i - 1, j)))) * damp;
+    }
+  }
+  // fxadv_fluxes_stencil :436-486
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < J1; ++j)
+      for (int i = 0; i < I1; ++i) {
+        if (i >= is && i <= ie + 1) {
+          const double u = AT(ut, i, j, k);
+          if (u > 0.0) {
+            AT(crx, i, j, k) = dt * u * M2(rdxa, i - 1, j);
+            AT(xfx, i, j, k) = M2(dy, i, j) * dt * u * M2(sin_sg3, i - 1, j);
+          } else {
+            AT(crx, i, j, k) = dt * u * M2(rdxa, i, j);
+            AT(xfx, i, j, k) = M2(dy, i, j) * dt * u * M2(sin_sg1, i, j);
+          }
+        }
+        if (j >= js && j <= je + 1) {
+          const double v = AT(vt, i, j, k);
+          if (v > 0.0) {
+            AT(cry, i, j, k) = dt * v * M2(rdya, i, j - 1);
+            AT(yfx, i, j, k) = M2(dx, i, j) * dt * v * M2(sin_sg4, i, j - 1);
+          } else {
+            AT(cry, i, j, k) = dt * v * M2(rdya, i, j);
+            AT(yfx, i, j, k) = M2(dx, i, j) * dt * v * M2(sin_sg2, i, j);
+          }
+        }
+      }
+}
+
+// -------------------------------------------------------------------------------------------------------- corners
+// copy_corners_{x,y} (corners.py:307-425) on levels [k0, k1): sources lie in the edge halos, never in a corner block
+void copy_corners(const Grid& g, double* q, bool xdir, int k0, int k1, const double* only_if_pos = nullptr) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je;
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < k1; ++k) {
+    if (only_if_pos && !(only_if_pos[k] > 0.0)) continue;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        if (xdir) {
+          AT(q, is - 1 - a, js - 1 - b, k) = AT(q, is - 1 - b, js + a, k);
+          AT(q, ie + 1 + a, js - 1 - b, k) = AT(q, ie + 1 + b, js + a, k);
+          AT(q, is - 1 - a, je + 1 + b, k) = AT(q, is - 1 - b, je - a, k);
+          AT(q, ie + 1 + a, je + 1 + b, k) = AT(q, ie + 1 + b, je - a, k);
+        } else {
+          AT(q, is - 1 - a, js - 1 - b, k) = AT(q, is + b, js - 1 - a, k);
+          AT(q, is - 1 - a, je + 1 + b, k) = AT(q, is + b, je + 1 + a, k);
+          AT(q, ie + 1 + a, js - 1 - b, k) = AT(q, ie - b, js - 1 - a, k);
+          AT(q, ie + 1 + a, je + 1 + b, k) = AT(q, ie - b, je + 1 + a, k);
+        }
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------- PPM
+// One level of compute_al (xppm.py:148-181) at point (i, j) along AXIS; `sp` = the spacing the reference passes (dxa / dya for
+// the scalar transport, dx / dy for xtp_u / ytp_v).
+template <int AXIS>
+inline double ppm_al(const Grid& g, const double* q, const double* sp, int i, int j, int k) {
+  const int d = AXIS == 0 ? 1 : g.ni;
+  const double* p = &AT(q, i, j, k);
+  const double* s = sp + (long)j * g.ni + i;
+  const int idx = AXIS == 0 ? i : j, s0 = AXIS == 0 ? g.is : g.js, e0 = AXIS == 0 ? g.ie : g.je;
+  const double qm2 = p[-2 * d], qm1 = p[-d], q0 = p[0], qp1 = p[d];
+  if (idx == s0 - 1 || idx == e0) return C1 * qm2 + C2 * qm1 + C3 * q0;
+  if (idx == s0 || idx == e0 + 1) {
+    const double dm2 = s[-2 * d], dm1 = s[-d], d0 = s[0], dp1 = s[d];
+    return 0.5 * (((2.0 * dm1 + dm2) * qm1 - dm1 * qm2) / (dm2 + dm1) + ((2.0 * d0 + dp1) * q0 - d0 * qp1) / (d0 + dp1));
+  }
+  if (idx == s0 + 1 || idx == e0 + 2) return C3 * qm1 + C2 * q0 + C1 * qp1;
+  return P1 * (qm1 + q0) + P2 * (qm2 + qp1);
+}
+
+// XPiecewiseParabolic / YPiecewiseParabolic.__call__ (xppm.py:290-355), |ord| < 8: ONE stencil with temporaries al, bl, br, b0,
+// smt5 -> one parallel loop nest over levels, the temporaries as per-thread 2-D slabs.  Window [i0, i1) x [j0, j1).
+template <int AXIS>
+void ppm_flux(const Grid& g, const double* q, const double* c, const double* sp, int mord, double* out, int i0, int i1, int j0,
+              int j1, int nk) {
+  const int ni = g.ni, nj = g.nj;
+  const long n2 = (long)ni * nj;
+#pragma omp parallel
+  {
+    std::vector<double> tmp(4 * n2);
+    double *al = tmp.data(), *bl = al + n2, *br = bl + n2, *sm = br + n2;
+    const int d = AXIS == 0 ? 1 : ni;
+    // extents along the axis: al on [lo - 1, hi + 1], bl / br / smt5 on [lo - 1, hi], flux on [lo, hi]
+    const int ia0 = AXIS == 0 ? i0 - 1 : i0, ia1 = AXIS == 0 ? i1 + 1 : i1, ja0 = AXIS == 0 ? j0 : j0 - 1, ja1 = AXIS == 0 ? j1 : j1 + 1;
+    const int ib1 = AXIS == 0 ? i1 : i1, jb1 = AXIS == 0 ? j1 : j1;
+#pragma omp for schedule(static)
+    for (int k = 0; k < nk; ++k) {
+      for (int j = ja0; j < ja1; ++j)
+        for (int i = ia0; i < ia1; ++i) al[(long)j * ni + i] = ppm_al<AXIS>(g, q, sp, i, j, k);
+      for (int j = ja0; j < jb1; ++j)
+        for (int i = ia0; i < ib1; ++i) {
+          const long p = (long)j * ni + i;
+          const double q0 = AT(q, i, j, k);
+          const double l = al[p] - q0, r = al[p + d] - q0, b0 = l + r;
+          bl[p] = l;
+          br[p] = r;
+          // advection mask xppm.py:48-61
+          sm[p] = (mord == 5) ? ((l * r < 0.0) ? 1.0 : 0.0) : ((3.0 * std::fabs(b0) < std::fabs(l - r)) ? 1.0 : 0.0);
+        }
+      for (int j = j0; j < j1; ++j)
+        for (int i = i0; i < i1; ++i) {
+          const long p = (long)j * ni + i;
+          const double cc = AT(c, i, j, k);
+          const double mask = (sm[p - d] > 0.5 || sm[p] > 0.5) ? 1.0 : 0.0;
+          double fx1, qq;
+          if (cc > 0.0) {
+            fx1 = (1.0 - cc) * (br[p - d] - cc * (bl[p - d] + br[p - d]));
+            qq = (&AT(q, i, j, k))[-d];
+          } else {
+            fx1 = (1.0 + cc) * (bl[p] + cc * (bl[p] + br[p]));
+            qq = AT(q, i, j, k);
+          }
+          AT(out, i, j, k) = qq + fx1 * mask;
+        }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------- delnflux
+struct Damp {             // what FiniteVolumeTransport passes to DelnFlux
+  const double* nord_k;   // per level
+  const double* damp_c_k; // per level (damp coefficient before calc_damp)
+  double da_min;
+  const double* mass;     // or null
+};
+
+// DelnFluxNoSG.__call__ (delnflux.py:1050-1261).  fac_k = calc_damp(...) per level; q read only; fx2, fy2, d2 written.
+void delnflux_nosg(const Grid& g, const double* q, double* fx2, double* fy2, const double* fac_k, double* d2, const double* nord_k,
+                   bool mass_given, int nk) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, n = g.n;
+  int nmax = 0;
+  for (int k = 0; k < nk; ++k) nmax = std::max(nmax, (int)nord_k[k]);
+  // d2_damp_interval :208-256 / copy_stencil_interval :259-307
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    const bool hi = nord_k[k] > 0.0;
+    const int e = hi ? nmax : 0;
+    for (int j = js - 1 - e; j <= je + 1 + e; ++j)
+      for (int i = is - 1 - e; i <= ie + 1 + e; ++i) AT(d2, i, j, k) = mass_given ? AT(q, i, j, k) : fac_k[k] * AT(q, i, j, k);
+  }
+  copy_corners(g, d2, true, 0, nk, nord_k);
+  // fx_calc_stencil_nord :41-82
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    const int e = nord_k[k] > 0.0 ? nmax : 0;
+    for (int j = js - e; j <= je + e; ++j)
+      for (int i = is - e; i <= ie + 1 + e; ++i) AT(fx2, i, j, k) = M2(del6_v, i, j) * (AT(d2, i - 1, j, k) - AT(d2, i, j, k));
+  }
+  copy_corners(g, d2, false, 0, nk, nord_k);
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    const int e = nord_k[k] > 0.0 ? nmax : 0;
+    for (int j = js - e; j <= je + 1 + e; ++j)
+      for (int i = is - e; i <= ie + e; ++i) AT(fy2, i, j, k) = M2(del6_u, i, j) * (AT(d2, i, j - 1, k) - AT(d2, i, j, k));
+  }
+  for (int it = 0; it < nmax; ++it) {
+    const int nt = nmax - 1 - it;
+    // d2_highorder_stencil :183-205
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nk; ++k) {
+      if (!(nord_k[k] > 0.0)) continue;
+      for (int j = js - nt - 1; j <= je + nt + 1; ++j)
+        for (int i = is - nt - 1; i <= ie + nt + 1; ++i)
+          AT(d2, i, j, k) = (AT(fx2, i, j, k) - AT(fx2, i + 1, j, k) + AT(fy2, i, j, k) - AT(fy2, i, j + 1, k)) * M2(rarea, i, j);
+    }
+    copy_corners(g, d2, true, 0, nk, nord_k);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nk; ++k) {
+      if (!(nord_k[k] > 0.0)) continue;
+      for (int j = js - nt; j <= je + nt; ++j)
+        for (int i = is - nt; i <= ie + 1 + nt; ++i) AT(fx2, i, j, k) = -M2(del6_v, i, j) * (AT(d2, i - 1, j, k) - AT(d2, i, j, k));
+    }
+    copy_corners(g, d2, false, 0, nk, nord_k);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nk; ++k) {
+      if (!(nord_k[k] > 0.0)) continue;
+      for (int j = js - nt; j <= je + 1 + nt; ++j)
+        for (int i = is - nt; i <= ie + nt; ++i) AT(fy2, i, j, k) = -M2(del6_u, i, j) * (AT(d2, i, j - 1, k) - AT(d2, i, j, k));
+    }
+  }
+  (void)n;
+}
+
+inline double calc_damp(double damp_c, double da_min, double nord) { return std::pow(damp_c * da_min, nord + 1.0); }  // delnflux.py:21-38
+
+// DelnFlux.__call__ (delnflux.py:945-1047)
+void delnflux(const Grid& g, Work& W, const double* q, double* fx, double* fy, const Damp& dp, int nk) {
+  bool any = false;
+  for (int k = 0; k < nk; ++k) any = any || dp.damp_c_k[k] > 1e-4;
+  if (!any) return;
+  std::vector<double> fac(nk);
+  for (int k = 0; k < nk; ++k) fac[k] = calc_damp(dp.damp_c_k[k], dp.da_min, dp.nord_k[k]);
+  const int mark = W.used;
+  double *fx2 = W.take(), *fy2 = W.take(), *d2 = W.take();
+  delnflux_nosg(g, q, fx2, fy2, fac.data(), d2, dp.nord_k, dp.mass != nullptr, nk);
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je;
+  // add_diffusive_component :310-328 / diffusive_damp :285-307
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        if (dp.mass == nullptr) {
+          AT(fx, i, j, k) = AT(fx, i, j, k) + AT(fx2, i, j, k);
+          AT(fy, i, j, k) = AT(fy, i, j, k) + AT(fy2, i, j, k);
+        } else {
+          AT(fx, i, j, k) = AT(fx, i, j, k) + 0.5 * fac[k] * (AT(dp.mass, i - 1, j, k) + AT(dp.mass, i, j, k)) * AT(fx2, i, j, k);
+          AT(fy, i, j, k) = AT(fy, i, j, k) + 0.5 * fac[k] * (AT(dp.mass, i, j - 1, k) + AT(dp.mass, i, j, k)) * AT(fy2, i, j, k);
+        }
+      }
+  W.used = mark;
+}
+
+// -------------------------------------------------------------------------------------------------------- fvtp2d
+// FiniteVolumeTransport.__call__ (fvtp2d.py:262-346); q's corner halos are overwritten in place exactly as in the reference
+void fvtp2d(const Grid& g, Work& W, double* q, const double* crx, const double* cry, const double* xfx, const double* yfx, double* qxf,
+            double* qyf, int hord, const double* xmf, const double* ymf, const Damp* dp, int nk) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, n = g.n;
+  const int mord = std::abs(hord);
+  const int mark = W.used;
+  double *q_y_adv = W.take(), *q_adv_y = W.take(), *q_adv_y_x = W.take(), *q_x_adv = W.take(), *q_adv_x = W.take(), *q_adv_x_y = W.take();
+  copy_corners(g, q, false, 0, nk);
+  ppm_flux<1>(g, q, cry, g.dya, mord, q_y_adv, is - 3, ie + 4, js, je + 2, nk);
+  // q_i_stencil :34-56
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = js; j <= je; ++j)
+      for (int i = 0; i < n + 6; ++i) {
+        const double f0 = AT(yfx, i, j, k) * AT(q_y_adv, i, j, k), f1 = AT(yfx, i, j + 1, k) * AT(q_y_adv, i, j + 1, k);
+        AT(q_adv_y, i, j, k) = (AT(q, i, j, k) * M2(area, i, j) + f0 - f1) / (M2(area, i, j) + AT(yfx, i, j, k) - AT(yfx, i, j + 1, k));
+      }
+  ppm_flux<0>(g, q_adv_y, crx, g.dxa, mord, q_adv_y_x, is, ie + 2, js, je + 1, nk);  // (only rows js .. je are used: final_fluxes)
+  copy_corners(g, q, true, 0, nk);
+  ppm_flux<0>(g, q, crx, g.dxa, mord, q_x_adv, is, ie + 2, js - 3, je + 4, nk);
+  // q_j_stencil :59-77
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < n + 6; ++j)
+      for (int i = is; i <= ie; ++i) {
+        const double f0 = AT(xfx, i, j, k) * AT(q_x_adv, i, j, k), f1 = AT(xfx, i + 1, j, k) * AT(q_x_adv, i + 1, j, k);
+        AT(q_adv_x, i, j, k) = (AT(q, i, j, k) * M2(area, i, j) + f0 - f1) / (M2(area, i, j) + AT(xfx, i, j, k) - AT(xfx, i + 1, j, k));
+      }
+  ppm_flux<1>(g, q_adv_x, cry, g.dya, mord, q_adv_x_y, is, ie + 1, js, je + 2, nk);
+  // final_fluxes :80-119
+  const double* xu = xmf ? xmf : xfx;
+  const double* yu = ymf ? ymf : yfx;
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        if (j <= je) AT(qxf, i, j, k) = 0.5 * (AT(q_adv_y_x, i, j, k) + AT(q_x_adv, i, j, k)) * AT(xu, i, j, k);
+        if (i <= ie) AT(qyf, i, j, k) = 0.5 * (AT(q_adv_x_y, i, j, k) + AT(q_y_adv, i, j, k)) * AT(yu, i, j, k);
+      }
+  W.used = mark;
+  if (dp) delnflux(g, W, q, qxf, qyf, *dp, nk);
+}
+
+
+// -------------------------------------------------------------------------------------------------------- a2b_ord4
+constexpr double A_C1 = 2.0 / 3.0, A_C2 = -1.0 / 6.0, B1 = 7.0 / 12.0, B2 = -1.0 / 12.0, A1 = 9.0 / 16.0, A2 = -1.0 / 16.0;  // a2b_ord4.py:22-33
+
+inline double gcd_(double p1a, double p1b, double p2a, double p2b) {  // a2b_ord4.py:36-40
+  const double sb = std::sin((p1b - p2b) / 2.0), sa = std::sin((p1a - p2a) / 2.0);
+  return std::asin(std::sqrt(sb * sb + std::cos(p1b) * std::cos(p2b) * (sa * sa))) * 2.0;
+}
+
+// AGrid2BGridFourthOrder.__call__ (a2b_ord4.py:668-761) on levels [k0, nk): corners, edges, ppm_volume_mean_x / _y,
+// a2b_interpolation -- five stencils; qx, qy, edges are whole fields
+void a2b_ord4(const Grid& g, Work& W, const double* qin, double* qout, int k0, int nk) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ni = g.ni;
+  const int mark = W.used;
+  double *qx = W.take(), *qy = W.take(), *edges = W.take();
+  // corners :59-273, :570-583 (the reference's "nw" sits at (ie+1, js), "se" at (is, je+1))
+  struct Diag { int a0, b0, a1, b1; };
+  const Diag UR{0, 0, 1, 1}, UL{-1, 0, -2, 1}, LR{0, -1, 1, -2}, LL{-1, -1, -2, -2};
+  struct Corner { int i, j; Diag d[3]; };
+  const Corner corners[4] = {{is, js, {UR, UL, LR}}, {ie + 1, js, {UL, LL, UR}}, {ie + 1, je + 1, {LL, LR, UL}}, {is, je + 1, {LR, LL, UR}}};
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < nk; ++k)
+    for (const Corner& c : corners) {
+      double tot = 0.0;
+      for (const Diag& d : c.d) {
+        const double p0a = M2(lon, c.i, c.j), p0b = M2(lat, c.i, c.j);
+        const double x1 = gcd_(M2(lon_agrid, c.i + d.a0, c.j + d.b0), M2(lat_agrid, c.i + d.a0, c.j + d.b0), p0a, p0b);
+        const double x2 = gcd_(M2(lon_agrid, c.i + d.a1, c.j + d.b1), M2(lat_agrid, c.i + d.a1, c.j + d.b1), p0a, p0b);
+        const double qa = AT(qin, c.i + d.a0, c.j + d.b0, k), qb = AT(qin, c.i + d.a1, c.j + d.b1, k);
+        tot = tot + (qa + x1 / (x2 - x1) * (qa - qb));
+      }
+      const double val = tot * (1.0 / 3.0);
+      AT(qout, c.i, c.j, k) = val;
+      AT(edges, c.i, c.j, k) = val;
+    }
+  // qout_x_edge :286-304, qout_y_edge :307-325
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < nk; ++k) {
+    auto q2 = [&](int i, int j) {
+      return (AT(qin, i - 1, j, k) * M2(dxa, i, j) + AT(qin, i, j, k) * M2(dxa, i - 1, j)) / (M2(dxa, i - 1, j) + M2(dxa, i, j));
+    };
+    auto q1 = [&](int i, int j) {
+      return (AT(qin, i, j - 1, k) * M2(dya, i, j) + AT(qin, i, j, k) * M2(dya, i, j - 1)) / (M2(dya, i, j - 1) + M2(dya, i, j));
+    };
+    for (int j = js + 1; j <= je; ++j) {
+      double v = g.edge_w[j] * q2(is, j - 1) + (1.0 - g.edge_w[j]) * q2(is, j);
+      AT(qout, is, j, k) = v; AT(edges, is, j, k) = v;
+      v = g.edge_e[j] * q2(ie + 1, j - 1) + (1.0 - g.edge_e[j]) * q2(ie + 1, j);
+      AT(qout, ie + 1, j, k) = v; AT(edges, ie + 1, j, k) = v;
+    }
+    for (int i = is + 1; i <= ie; ++i) {
+      double v = g.edge_s[i] * q1(i - 1, js) + (1.0 - g.edge_s[i]) * q1(i, js);
+      AT(qout, i, js, k) = v; AT(edges, i, js, k) = v;
+      v = g.edge_n[i] * q1(i - 1, je + 1) + (1.0 - g.edge_n[i]) * q1(i, je + 1);
+      AT(qout, i, je + 1, k) = v; AT(edges, i, je + 1, k) = v;
+    }
+  }
+  // ppm_volume_mean_x :429-450 on i in [is, ie+1], j in [js-2, je+2]
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < nk; ++k)
+    for (int j = js - 2; j <= je + 2; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        const double* q = &AT(qin, i, j, k);
+        const double* d = g.dxa + (long)j * ni + i;
+        double v;
+        if (i == is) {
+          const double gi = d[1] / d[0], go = d[-2] / d[-1];
+          v = 0.5 * (((2.0 + gi) * q[0] - q[1]) / (1.0 + gi) + ((2.0 + go) * q[-1] - q[-2]) / (1.0 + go));
+        } else if (i == is + 1) {
+          const double gi = d[0] / d[-1], go = d[-3] / d[-2];
+          const double left = 0.5 * (((2.0 + gi) * q[-1] - q[0]) / (1.0 + gi) + ((2.0 + go) * q[-2] - q[-3]) / (1.0 + go));
+          const double right = B2 * (q[-1] + q[2]) + B1 * (q[0] + q[1]);
+          v = (3.0 * (gi * q[-1] + q[0]) - (gi * left + right)) / (2.0 + 2.0 * gi);
+        } else if (i == ie + 1) {
+          const double gi = d[-2] / d[-1], go = d[1] / d[0];
+          v = 0.5 * (((2.0 + gi) * q[-1] - q[-2]) / (1.0 + gi) + ((2.0 + go) * q[0] - q[1]) / (1.0 + go));
+        } else if (i == ie) {
+          const double gi = d[-1] / d[0], go = d[2] / d[1];
+          const double right = 0.5 * (((2.0 + gi) * q[0] - q[-1]) / (1.0 + gi) + ((2.0 + go) * q[1] - q[2]) / (1.0 + go));
+          const double left = B2 * (q[-3] + q[0]) + B1 * (q[-2] + q[-1]);
+          v = (3.0 * (q[-1] + gi * q[0]) - (gi * right + left)) / (2.0 + 2.0 * gi);
+        } else {
+          v = B2 * (q[-2] + q[1]) + B1 * (q[-1] + q[0]);
+        }
+        AT(qx, i, j, k) = v;
+      }
+  // ppm_volume_mean_y :453-473 on i in [is-2, ie+2], j in [js, je+1]
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < nk; ++k)
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is - 2; i <= ie + 2; ++i) {
+        const double* q = &AT(qin, i, j, k);
+        const double* d = g.dya + (long)j * ni + i;
+        const int s = ni;
+        double v;
+        if (j == js) {
+          const double gi = d[s] / d[0], go = d[-2 * s] / d[-s];
+          v = 0.5 * (((2.0 + gi) * q[0] - q[s]) / (1.0 + gi) + ((2.0 + go) * q[-s] - q[-2 * s]) / (1.0 + go));
+        } else if (j == js + 1) {
+          const double gi = d[0] / d[-s], go = d[-3 * s] / d[-2 * s];
+          const double lower = 0.5 * (((2.0 + gi) * q[-s] - q[0]) / (1.0 + gi) + ((2.0 + go) * q[-2 * s] - q[-3 * s]) / (1.0 + go));
+          const double upper = B2 * (q[-s] + q[2 * s]) + B1 * (q[0] + q[s]);
+          v = (3.0 * (gi * q[-s] + q[0]) - (gi * lower + upper)) / (2.0 + 2.0 * gi);
+        } else if (j == je + 1) {
+          const double gi = d[-2 * s] / d[-s], go = d[s] / d[0];
+          v = 0.5 * (((2.0 + gi) * q[-s] - q[-2 * s]) / (1.0 + gi) + ((2.0 + go) * q[0] - q[s]) / (1.0 + go));
+        } else if (j == je) {
+          const double gi = d[-s] / d[0], go = d[2 * s] / d[s];
+          const double lower = B2 * (q[-3 * s] + q[0]) + B1 * (q[-2 * s] + q[-s]);
+          const double upper = 0.5 * (((2.0 + gi) * q[0] - q[-s]) / (1.0 + gi) + ((2.0 + go) * q[s] - q[2 * s]) / (1.0 + go));
+          v = (3.0 * (q[-s] + gi * q[0]) - (gi * upper + lower)) / (2.0 + 2.0 * gi);
+        } else {
+          v = B2 * (q[-2 * s] + q[s]) + B1 * (q[-s] + q[0]);
+        }
+        AT(qy, i, j, k) = v;
+      }
+  // a2b_interpolation :476-506 on i in [is+1, ie], j in [js+1, je]
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < nk; ++k)
+    for (int j = js + 1; j <= je; ++j)
+      for (int i = is + 1; i <= ie; ++i) {
+        const double* x = &AT(qx, i, j, k);
+        const double* y = &AT(qy, i, j, k);
+        const double* e = &AT(edges, i, j, k);
+        const int s = ni;
+        double qxx, qyy;
+        if (j == js + 1) {
+          const double up = A2 * (x[-s] + x[2 * s]) + A1 * (x[0] + x[s]);
+          qxx = A_C1 * (x[-s] + x[0]) + A_C2 * (e[-s] + up);
+        } else if (j == je) {
+          const double lo = A2 * (x[-3 * s] + x[0]) + A1 * (x[-2 * s] + x[-s]);
+          qxx = A_C1 * (x[-s] + x[0]) + A_C2 * (e[s] + lo);
+        } else {
+          qxx = A2 * (x[-2 * s] + x[s]) + A1 * (x[-s] + x[0]);
+        }
+        if (i == is + 1) {
+          const double rt = A2 * (y[-1] + y[2]) + A1 * (y[0] + y[1]);
+          qyy = A_C1 * (y[-1] + y[0]) + A_C2 * (e[-1] + rt);
+        } else if (i == ie) {
+          const double lf = A2 * (y[-3] + y[0]) + A1 * (y[-2] + y[-1]);
+          qyy = A_C1 * (y[-1] + y[0]) + A_C2 * (e[1] + lf);
+        } else {
+          qyy = A2 * (y[-2] + y[1]) + A1 * (y[-1] + y[0]);
+        }
+        AT(qout, i, j, k) = 0.5 * (qxx + qyy);
+      }
+  W.used = mark;
+}
+
+// -------------------------------------------------------------------------------------------------------- corner fills (B / D grid)
+void fill_corners_bgrid(const Grid& g, double* q, bool xdir, int k0, int nk) {  // corners.py:591-712
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je;
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < nk; ++k)
+    for (int a = 1; a < 4; ++a)
+      for (int b = 1; b < 4; ++b) {
+        if (xdir) {
+          AT(q, is - a, js - b, k) = AT(q, is - b, js + a, k);
+          AT(q, ie + 1 + a, js - b, k) = AT(q, ie + 1 + b, js + a, k);
+          AT(q, is - a, je + 1 + b, k) = AT(q, is - b, je + 1 - a, k);
+          AT(q, ie + 1 + a, je + 1 + b, k) = AT(q, ie + 1 + b, je + 1 - a, k);
+        } else {
+          AT(q, is - a, js - b, k) = AT(q, is + b, js - a, k);
+          AT(q, is - a, je + 1 + b, k) = AT(q, is + b, je + 1 + a, k);
+          AT(q, ie + 1 + a, js - b, k) = AT(q, ie + 1 - b, js - a, k);
+          AT(q, ie + 1 + a, je + 1 + b, k) = AT(q, ie + 1 - b, je + 1 + a, k);
+        }
+      }
+}
+void fill_corners_dgrid(const Grid& g, double* x, double* y, double sgn, int k0, int nk) {  // corners.py:987-1151
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je;
+#pragma omp parallel for schedule(static)
+  for (int k = k0; k < nk; ++k) {
+    double xv[36], yv[36];
+    int t = 0;
+    for (int a = 1; a < 4; ++a)
+      for (int b = 1; b < 4; ++b) {  // all sources first (they lie outside the corner blocks)
+        xv[t] = sgn * AT(y, is - b, js + a - 1, k);           yv[t++] = sgn * AT(x, is + b - 1, js - a, k);            // SW
+        xv[t] = sgn * AT(y, ie + 1 + b, je + 1 - a, k);       yv[t++] = sgn * AT(x, ie + 1 - b, je + 1 + a, k);        // NE
+        xv[t] = AT(y, is - b, je + 1 - a, k);                 yv[t++] = AT(x, is + b - 1, je + 1 + a, k);              // NW
+        xv[t] = AT(y, ie + 1 + b, js + a - 1, k);             yv[t++] = AT(x, ie + 1 - b, js - a, k);                  // SE
+      }
+    t = 0;
+    for (int a = 1; a < 4; ++a)
+      for (int b = 1; b < 4; ++b) {
+        AT(x, is - a, js - b, k) = xv[t];          AT(y, is - a, js - b, k) = yv[t++];
+        AT(x, ie + a, je + 1 + b, k) = xv[t];      AT(y, ie + 1 + a, je + b, k) = yv[t++];
+        AT(x, is - a, je + 1 + b, k) = xv[t];      AT(y, is - a, je + b, k) = yv[t++];
+        AT(x, ie + a, js - b, k) = xv[t];          AT(y, ie + 1 + a, js - b, k) = yv[t++];
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------- divergence damping
+// DivergenceDamping.__call__ (divergence_damping.py:482-632).  vort_b = damped_rel_vort_bgrid (out), wk = rel_vort_agrid (in).
+void divergence_damping(const Grid& g, Work& W, const double* u, const double* v, const double* va, double* vort_b, const double* ua,
+                        double* divg_d, double* vc, double* uc, double* delpc, double* ke, const double* wk, double dt,
+                        const double* nord_k, const double* d2_bg_k, double dddmp, double d4_bg, int nord) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, nk = g.nk;
+  int kstart = 0, nz_nord = nord;
+  for (int k = 0; k < nk; ++k)
+    if (nord_k[k] > 0.0) { kstart = k; nz_nord = (int)nord_k[k]; break; }
+  const double da_min_c = g.da_min_c;
+  if (kstart > 0) {
+    const int mark = W.used;
+    double *a = W.take(), *b = W.take();  // u_contra_dyc, v_contra_dxc
+    // compute_u_contra_dyc :30-63
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < kstart; ++k)
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = is - 1; i <= ie + 1; ++i) {
+          double uc_;
+          if (j == js || j == je + 1) {
+            uc_ = (AT(vc, i, j, k) > 0.0) ? AT(u, i, j, k) * M2(sin_sg4, i, j - 1) : AT(u, i, j, k) * M2(sin_sg2, i, j);
+          } else {
+            const double vfa = 0.5 * (AT(va, i, j - 1, k) + AT(va, i, j, k));
+            uc_ = (AT(u, i, j, k) - vfa * M2(cosa_v, i, j)) * M2(sina_v, i, j);
+          }
+          AT(a, i, j, k) = uc_ * M2(dyc, i, j);
+        }
+    // compute_v_contra_dxc :66-98
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < kstart; ++k)
+      for (int j = js - 1; j <= je + 1; ++j)
+        for (int i = is; i <= ie + 1; ++i) {
+          double vc_;
+          if (i == is || i == ie + 1) {
+            vc_ = (AT(uc, i, j, k) > 0.0) ? AT(v, i, j, k) * M2(sin_sg3, i - 1, j) : AT(v, i, j, k) * M2(sin_sg1, i, j);
+          } else {
+            const double ufa = 0.5 * (AT(ua, i - 1, j, k) + AT(ua, i, j, k));
+            vc_ = (AT(v, i, j, k) - ufa * M2(cosa_u, i, j)) * M2(sina_u, i, j);
+          }
+          AT(b, i, j, k) = vc_ * M2(dxc, i, j);
+        }
+    // delpc_computation :101-135
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < kstart; ++k)
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = is; i <= ie + 1; ++i) {
+          double d = AT(b, i, j - 1, k) - AT(b, i, j, k) + AT(a, i - 1, j, k) - AT(a, i, j, k);
+          if ((i == is || i == ie + 1) && j == js) d = d - AT(b, i, j - 1, k);
+          if ((i == is || i == ie + 1) && j == je + 1) d = d + AT(b, i, j, k);
+          AT(delpc, i, j, k) = M2(rarea_c, i, j) * d;
+        }
+    // damping :138-158
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < kstart; ++k)
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = is; i <= ie + 1; ++i) {
+          const double delpcdt = AT(delpc, i, j, k) * dt;
+          const double damp = da_min_c * std::max(d2_bg_k[k], std::min(0.2, dddmp * std::fabs(delpcdt)));
+          const double vort = damp * AT(delpc, i, j, k);
+          AT(vort_b, i, j, k) = vort;
+          AT(ke, i, j, k) = AT(ke, i, j, k) + vort;
+        }
+    W.used = mark;
+  }
+  // copy divg_d -> delpc
+#pragma omp parallel for schedule(static)
+  for (int k = kstart; k < nk; ++k)
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) AT(delpc, i, j, k) = AT(divg_d, i, j, k);
+  for (int it = 0; it < nz_nord; ++it) {
+    const int nt = nz_nord - (it + 1);
+    const bool fillc = (it + 1 != nz_nord);
+    if (fillc) fill_corners_bgrid(g, divg_d, true, kstart, nk);
+    // vc_from_divg :188-197
+#pragma omp parallel for schedule(static)
+    for (int k = kstart; k < nk; ++k)
+      for (int j = js - nt; j <= je + nt + 1; ++j)
+        for (int i = is - nt - 1; i <= ie + nt + 1; ++i) AT(vc, i, j, k) = (AT(divg_d, i + 1, j, k) - AT(divg_d, i, j, k)) * M2(divg_u, i, j);
+    if (fillc) fill_corners_bgrid(g, divg_d, false, kstart, nk);
+    // uc_from_divg :200-209
+#pragma omp parallel for schedule(static)
+    for (int k = kstart; k < nk; ++k)
+      for (int j = js - nt - 1; j <= je + nt + 1; ++j)
+        for (int i = is - nt; i <= ie + nt + 1; ++i) AT(uc, i, j, k) = (AT(divg_d, i, j + 1, k) - AT(divg_d, i, j, k)) * M2(divg_v, i, j);
+    if (fillc) fill_corners_dgrid(g, vc, uc, -1.0, kstart, nk);
+    // redo_divg_d :212-240
+#pragma omp parallel for schedule(static)
+    for (int k = kstart; k < nk; ++k)
+      for (int j = js - nt; j <= je + 1 + nt; ++j)
+        for (int i = is - nt; i <= ie + 1 + nt; ++i) {
+          double d = AT(uc, i, j - 1, k) - AT(uc, i, j, k) + AT(vc, i - 1, j, k) - AT(vc, i, j, k);
+          if ((i == is || i == ie + 1) && j == js) d = d - AT(uc, i, j - 1, k);
+          if ((i == is || i == ie + 1) && j == je + 1) d = d + AT(uc, i, j, k);
+          AT(divg_d, i, j, k) = d * M2(rarea_c, i, j);
+        }
+  }
+  if (dddmp < 1e-5) {
+#pragma omp parallel for schedule(static)
+    for (int k = kstart; k < nk; ++k)
+      for (long p = 0; p < g.sk; ++p) vort_b[(long)k * g.sk + p] = 0.0;
+  } else {
+    a2b_ord4(g, W, wk, vort_b, kstart, nk);
+    // smagorinsky_diffusion_approx :243-251
+#pragma omp parallel for schedule(static)
+    for (int k = kstart; k < nk; ++k)
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = is; i <= ie + 1; ++i) {
+          const double d = AT(delpc, i, j, k), w = AT(vort_b, i, j, k);
+          AT(vort_b, i, j, k) = std::fabs(dt) * std::sqrt(d * d + w * w);
+        }
+  }
+  const double dd8 = std::pow(da_min_c * d4_bg, (double)(nz_nord + 1));
+  // damping_nord_highorder_stencil :161-185
+#pragma omp parallel for schedule(static)
+  for (int k = kstart; k < nk; ++k)
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        const double damp = da_min_c * std::max(d2_bg_k[k], std::min(0.2, dddmp * std::fabs(AT(vort_b, i, j, k))));
+        const double vort = damp * AT(delpc, i, j, k) + dd8 * AT(divg_d, i, j, k);
+        AT(vort_b, i, j, k) = vort;
+        AT(ke, i, j, k) = AT(ke, i, j, k) + vort;
+      }
+}
+
+
+// -------------------------------------------------------------------------------------------------------- xtp_u / ytp_v
+// advect_u_along_x / advect_v_along_y (xtp_u.py:9-91, ytp_v.py:9-91) for one level: `adv` on [is, ie+1] x [js, je+1].  They are
+// gtscript FUNCTIONS inside compute_kinetic_energy, i.e. part of that stencil's loop nest; al / bl / br / smt5 are its temporaries.
+template <int AXIS>
+void advect_wind_level(const Grid& g, const double* u, const double* ub, const double* rd, const double* sp, double dt, int mord,
+                       int k, double* al, double* bl, double* br, double* sm, double* adv) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, ni = g.ni;
+  const int d = AXIS == 0 ? 1 : ni;
+  const int i0 = is - (AXIS == 0 ? 1 : 0), i1 = ie + 1, j0 = js - (AXIS == 1 ? 1 : 0), j1 = je + 1;  // bl / br window
+  for (int j = j0; j <= j1 + (AXIS == 1 ? 1 : 0); ++j)
+    for (int i = i0; i <= i1 + (AXIS == 0 ? 1 : 0); ++i) al[(long)j * ni + i] = ppm_al<AXIS>(g, u, sp, i, j, k);
+  for (int j = j0; j <= j1; ++j)
+    for (int i = i0; i <= i1; ++i) {
+      const long p = (long)j * ni + i;
+      const double u0 = AT(u, i, j, k);
+      double l = al[p] - u0, r = al[p + d] - u0;
+      const int idx = AXIS == 0 ? i : j, s0 = AXIS == 0 ? is : js, e0 = AXIS == 0 ? ie : je;
+      const int oidx = AXIS == 0 ? j : i, os = AXIS == 0 ? js : is, oe = AXIS == 0 ? je : ie;
+      if (((idx >= s0 - 1 && idx <= s0) || (idx >= e0 && idx <= e0 + 1)) && (oidx == os || oidx == oe + 1)) l = r = 0.0;  // zero corners :41-49
+      bl[p] = l;
+      br[p] = r;
+      const double b0 = l + r;
+      sm[p] = (mord == 5) ? ((l * r < 0.0) ? 1.0 : 0.0) : ((3.0 * std::fabs(b0) < std::fabs(l - r)) ? 1.0 : 0.0);
+    }
+  for (int j = js; j <= je + 1; ++j)
+    for (int i = is; i <= ie + 1; ++i) {
+      const long p = (long)j * ni + i;
+      const double w = ub[p];
+      const double cfl = (w > 0.0) ? w * dt * rd[p - d] : w * dt * rd[p];
+      const double mask = (sm[p - d] > 0.5 || sm[p] > 0.5) ? 1.0 : 0.0;
+      double fx0, base;
+      if (cfl > 0.0) {
+        fx0 = (1.0 - cfl) * (br[p - d] - cfl * (bl[p - d] + br[p - d]));
+      } else {
+        fx0 = (1.0 + cfl) * (bl[p] + cfl * (bl[p] + br[p]));
+      }
+      base = (w > 0.0) ? (&AT(u, i, j, k))[-d] : AT(u, i, j, k);
+      adv[p] = base + fx0 * mask;
+    }
+}
+
+struct Column {  // d_sw.get_column_namelist (d_sw.py:633-683), per level
+  const double *nord, *nord_v, *nord_w, *nord_t, *damp_vt, *damp_w, *damp_t, *d2_divg, *d_con, *ke_bg;
+};
+struct Config {
+  int hord_dp, hord_tm, hord_vt, hord_mt, nord, do_skeb;
+  double dddmp, d4_bg, d_con;
+};
+
+// -------------------------------------------------------------------------------------------------------- d_sw
+// DGridShallowWaterLagrangianDynamics.__call__ (d_sw.py:935-1237)
+void d_sw(const Grid& g, Work& W, const Column& col, const Config& cfg, double* ut, double* vt, double* delpc, double* delp, double* pt,
+          double* u, double* v, double* w, double* uc, double* vc, const double* ua, const double* va, double* divgd, double* mfx,
+          double* mfy, double* cx, double* cy, double* crx, double* cry, double* xfx, double* yfx, double* q_con, double* heat_source,
+          double* diss_est, double dt) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, n = g.n, nk = g.nk, ni = g.ni;
+  W.used = 0;
+  double *fx = W.take(), *fy = W.take(), *gx = W.take(), *gy = W.take(), *fx2 = W.take(), *fy2 = W.take(), *dw = W.take(),
+         *wk = W.take(), *heat_s = W.take(), *ke = W.take(), *vort_a = W.take(), *vort_b = W.take(), *abs_vort = W.take(),
+         *vxd = W.take(), *vyd = W.take(), *damped = W.take(), *ut2 = W.take(), *vt2 = W.take();
+  for (double* z : {dw, heat_s, vxd, vyd}) std::memset(z, 0, sizeof(double) * g.sk * (nk + 1));
+  fxadv(g, uc, vc, crx, cry, xfx, yfx, ut, vt, dt);
+  Damp dv{col.nord_v, col.damp_vt, g.da_min, nullptr};
+  fvtp2d(g, W, delp, crx, cry, xfx, yfx, fx, fy, cfg.hord_dp, nullptr, nullptr, &dv, nk);
+  // flux_capacitor :33-60
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < n + 6; ++j)
+      for (int i = 0; i < n + 6; ++i) {
+        AT(cx, i, j, k) = AT(cx, i, j, k) + AT(crx, i, j, k);
+        AT(cy, i, j, k) = AT(cy, i, j, k) + AT(cry, i, j, k);
+        AT(mfx, i, j, k) = AT(mfx, i, j, k) + AT(fx, i, j, k);
+        AT(mfy, i, j, k) = AT(mfy, i, j, k) + AT(fy, i, j, k);
+      }
+  std::vector<double> fac_w(nk), fac_vt(nk);
+  for (int k = 0; k < nk; ++k) {
+    fac_w[k] = calc_damp(col.damp_w[k], g.da_min_c, col.nord_w[k]);
+    fac_vt[k] = calc_damp(col.damp_vt[k], g.da_min_c, col.nord_v[k]);
+  }
+  delnflux_nosg(g, w, fx2, fy2, fac_w.data(), wk, col.nord_w, false, nk);
+  // heat_diss :63-103
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    const bool on = col.damp_w[k] > 1e-5;
+    const double dd8 = col.ke_bg[k] * std::fabs(dt);
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        if (on) {
+          const double d = (AT(fx2, i, j, k) - AT(fx2, i + 1, j, k) + AT(fy2, i, j, k) - AT(fy2, i, j + 1, k)) * M2(rarea, i, j);
+          AT(dw, i, j, k) = d;
+          const double h = dd8 - d * (AT(w, i, j, k) + 0.5 * d);
+          AT(heat_s, i, j, k) = h;
+          AT(diss_est, i, j, k) = h;
+        } else {
+          AT(heat_s, i, j, k) = 0.0;
+          AT(diss_est, i, j, k) = 0.0;
+        }
+      }
+  }
+  fvtp2d(g, W, w, crx, cry, xfx, yfx, gx, gy, cfg.hord_vt, fx, fy, nullptr, nk);
+  auto apply_fluxes = [&](double* q) {  // apply_fluxes :122-145
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nk; ++k)
+      for (int j = js; j <= je; ++j)
+        for (int i = is; i <= ie; ++i)
+          AT(q, i, j, k) = AT(q, i, j, k) * AT(delp, i, j, k) +
+                           (AT(gx, i, j, k) - AT(gx, i + 1, j, k) + AT(gy, i, j, k) - AT(gy, i, j + 1, k)) * M2(rarea, i, j);
+  };
+  apply_fluxes(w);
+  Damp dt_{col.nord_t, col.damp_t, g.da_min, delp};
+  fvtp2d(g, W, q_con, crx, cry, xfx, yfx, gx, gy, cfg.hord_dp, fx, fy, &dt_, nk);
+  apply_fluxes(q_con);
+  Damp dvm{col.nord_v, col.damp_vt, g.da_min, delp};
+  fvtp2d(g, W, pt, crx, cry, xfx, yfx, gx, gy, cfg.hord_tm, fx, fy, &dvm, nk);
+  // apply_pt_delp_fluxes :148-201
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        const double ptn = AT(pt, i, j, k) * AT(delp, i, j, k) +
+                           (AT(gx, i, j, k) - AT(gx, i + 1, j, k) + AT(gy, i, j, k) - AT(gy, i, j + 1, k)) * M2(rarea, i, j);
+        const double dpn = AT(delp, i, j, k) + (AT(fx, i, j, k) - AT(fx, i + 1, j, k) + AT(fy, i, j, k) - AT(fy, i, j + 1, k)) * M2(rarea, i, j);
+        AT(pt, i, j, k) = ptn / dpn;
+        AT(delp, i, j, k) = dpn;
+      }
+  // adjust_w_and_qcon :331-350
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    const bool on = col.damp_w[k] > 1e-5;
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        double wn = AT(w, i, j, k) / AT(delp, i, j, k);
+        if (on) wn = wn + AT(dw, i, j, k);
+        AT(w, i, j, k) = wn;
+        AT(q_con, i, j, k) = AT(q_con, i, j, k) / AT(delp, i, j, k);
+      }
+  }
+  // compute_kinetic_energy :204-298 (ub / vb, the two 1-D advections and ke: one stencil, temporaries per thread)
+  const int mord_mt = std::abs(cfg.hord_mt);
+#pragma omp parallel
+  {
+    const long n2 = (long)ni * g.nj;
+    std::vector<double> tmp(8 * n2);
+    double *ub = tmp.data(), *vb = ub + n2, *al = vb + n2, *bl = al + n2, *br = bl + n2, *sm = br + n2, *au = sm + n2, *av = au + n2;
+    const double dt6 = dt / 6.0;
+#pragma omp for schedule(static)
+    for (int k = 0; k < nk; ++k) {
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = is; i <= ie + 1; ++i) {
+          const long p = (long)j * ni + i;
+          const double ubc = 0.5 * (AT(uc, i, j - 1, k) + AT(uc, i, j, k)), vbc = 0.5 * (AT(vc, i - 1, j, k) + AT(vc, i, j, k));
+          double a = (ubc - vbc * M2(cosa, i, j)) * M2(rsina, i, j), b = (vbc - ubc * M2(cosa, i, j)) * M2(rsina, i, j);
+          const bool jedge = (j == js || j == je + 1), iedge = (i == is || i == ie + 1);
+          if (jedge) a = 0.25 * (-AT(ut, i, j - 2, k) + 3.0 * (AT(ut, i, j - 1, k) + AT(ut, i, j, k)) - AT(ut, i, j + 1, k));
+          if (iedge) a = 0.5 * (AT(ut, i, j - 1, k) + AT(ut, i, j, k));
+          if (iedge) b = 0.25 * (-AT(vt, i - 2, j, k) + 3.0 * (AT(vt, i - 1, j, k) + AT(vt, i, j, k)) - AT(vt, i + 1, j, k));
+          if (jedge) b = 0.5 * (AT(vt, i - 1, j, k) + AT(vt, i, j, k));
+          ub[p] = a;
+          vb[p] = b;
+        }
+      advect_wind_level<1>(g, v, vb, g.rdy, g.dy, dt, mord_mt, k, al, bl, br, sm, av);
+      advect_wind_level<0>(g, u, ub, g.rdx, g.dx, dt, mord_mt, k, al, bl, br, sm, au);
+      auto U = [&](int i, int j) { return AT(ut, i, j, k); };
+      auto V = [&](int i, int j) { return AT(vt, i, j, k); };
+      auto corner = [&](int i, int j, int io1, int jo1, int io2, double vs) {  // d_sw.py:259-281
+        return dt6 * ((U(i, j) + U(i, j - 1)) * ((io1 + 1) * AT(u, i, j, k) - (io1 * AT(u, i - 1, j, k))) +
+                      (V(i, j) + V(i - 1, j)) * ((jo1 + 1) * AT(v, i, j, k) - (jo1 * AT(v, i, j - 1, k))) +
+                      (((jo1 + 1) * U(i, j) - (jo1 * U(i, j - 1))) + vs * ((io1 + 1) * V(i, j) - (io1 * V(i - 1, j)))) *
+                          ((io2 + 1) * AT(u, i, j, k) - (io2 * AT(u, i - 1, j, k))));
+      };
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = is; i <= ie + 1; ++i) {
+          const long p = (long)j * ni + i;
+          double kv = 0.5 * dt * (ub[p] * au[p] + vb[p] * av[p]);
+          if (i == is && j == js) kv = corner(i, j, 0, 0, -1, 1.0);
+          if (i == ie + 1 && j == js) kv = corner(i, j, -1, 0, 0, -1.0);
+          if (i == ie + 1 && j == je + 1) kv = corner(i, j, -1, -1, 0, 1.0);
+          if (i == is && j == je + 1) kv = corner(i, j, 0, -1, -1, -1.0);
+          AT(ke, i, j, k) = kv;
+        }
+    }
+  }
+  // compute_vorticity :301-328
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < n + 6; ++j)
+      for (int i = 0; i < n + 6; ++i)
+        AT(vort_a, i, j, k) = (AT(u, i, j, k) - AT(u, i, j + 1, k) * M2(dx, i, j + 1) / M2(dx, i, j)) * (M2(rarea, i, j) * M2(dx, i, j)) +
+                              (AT(v, i + 1, j, k) * M2(dy, i + 1, j) / M2(dy, i, j) - AT(v, i, j, k)) * (M2(rarea, i, j) * M2(dy, i, j));
+  divergence_damping(g, W, u, v, va, vort_b, ua, divgd, vc, uc, delpc, ke, vort_a, dt, col.nord, col.d2_divg, cfg.dddmp, cfg.d4_bg, cfg.nord);
+  // rel_vorticity_to_abs :389-402
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < n + 6; ++j)
+      for (int i = 0; i < n + 6; ++i) AT(abs_vort, i, j, k) = AT(vort_a, i, j, k) + M2(fC_agrid, i, j);
+  fvtp2d(g, W, abs_vort, crx, cry, xfx, yfx, fx, fy, cfg.hord_vt, nullptr, nullptr, nullptr, nk);
+  // u_and_v_from_ke :439-477
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k)
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        if (i <= ie) AT(u, i, j, k) = AT(u, i, j, k) * M2(dx, i, j) + AT(ke, i, j, k) - AT(ke, i + 1, j, k) + AT(fy, i, j, k);
+        if (j <= je) AT(v, i, j, k) = AT(v, i, j, k) * M2(dy, i, j) + AT(ke, i, j, k) - AT(ke, i, j + 1, k) - AT(fx, i, j, k);
+      }
+  delnflux_nosg(g, vort_a, ut2, vt2, fac_vt.data(), damped, col.nord_v, false, nk);
+  // vort_differencing :353-380
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    if (!(col.d_con[k] > 1e-5)) continue;
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        if (i <= ie) AT(vxd, i, j, k) = AT(vort_b, i, j, k) - AT(vort_b, i + 1, j, k);
+        if (j <= je) AT(vyd, i, j, k) = AT(vort_b, i, j, k) - AT(vort_b, i, j + 1, k);
+      }
+  }
+  // heat_source_from_vorticity_damping :493-577
+  const bool skeb = cfg.do_skeb != 0;
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    const bool cond = col.d_con[k] > 1e-5 || skeb;
+    auto ubt = [&](int i, int j) { return (AT(vxd, i, j, k) + AT(vt2, i, j, k)) * M2(rdx, i, j); };
+    auto vbt = [&](int i, int j) { return (AT(vyd, i, j, k) - AT(ut2, i, j, k)) * M2(rdy, i, j); };
+    auto fyv = [&](int i, int j) { return AT(u, i, j, k) * M2(rdx, i, j); };
+    auto fxv = [&](int i, int j) { return AT(v, i, j, k) * M2(rdy, i, j); };
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        const double ub0 = ubt(i, j), ub1 = ubt(i, j + 1), vb0 = vbt(i, j), vb1 = vbt(i + 1, j);
+        const double fy0 = fyv(i, j), fy1 = fyv(i, j + 1), fx0 = fxv(i, j), fx1 = fxv(i + 1, j);
+        const double gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
+        const double u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
+        const double dampterm = M2(rsin2, i, j) * 0.25 *
+                                ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + 2.0 * (gy0 + gy1 + gx0 + gx1) -
+                                 M2(cosa_s, i, j) * (u2 * dv2 + v2 * du2 + du2 * dv2));
+        if (cond) AT(heat_s, i, j, k) = AT(delp, i, j, k) * (AT(heat_s, i, j, k) - col.d_con[k] * dampterm);
+        if (cfg.d_con > 1e-5 || skeb) {
+          AT(heat_source, i, j, k) = AT(heat_source, i, j, k) + AT(heat_s, i, j, k);
+          if (skeb) AT(diss_est, i, j, k) = AT(diss_est, i, j, k) - dampterm;
+        }
+      }
+  }
+  // update_u_and_v :582-608
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < nk; ++k) {
+    if (!(col.damp_vt[k] > 1e-5)) continue;
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        if (i <= ie) AT(u, i, j, k) = AT(u, i, j, k) + AT(vt2, i, j, k);
+        if (j <= je) AT(v, i, j, k) = AT(v, i, j, k) - AT(ut2, i, j, k);
+      }
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------------------- riem_solver3
+constexpr double RDGAS = 287.05, CP_AIR = 1004.6, KAPPA = RDGAS / CP_AIR, GRAV = 9.80665, RGRAV = 1.0 / GRAV;  // util constants.py:36-73
+
+// NonhydrostaticVerticalSolver.__call__ (riem_solver3.py:208-321): precompute (:26-90), Sim1Solver (sim1_solver.py:20-219),
+// finalize (:93-145) -- three stencils; column recurrences run k-sequentially for a row of i at a time (i innermost).
+// 3-D fields hold nk + 1 levels; ws, zs are 2-D.
+void riem_solver3(const Grid& g, Work& W, int last_call, double dt, const double* cappa, double ptop, const double* zs, const double* ws,
+                  double* delz, const double* q_con, const double* delp, const double* pt, double* zh, double* pe, double* ppe,
+                  double* pk3, double* pk, double* peln, double* w, double p_fac, double beta, int use_logp) {
+  const int is = g.is, ie = g.ie, js = g.js, je = g.je, km = g.nk, K = km + 1, ni = g.ni;
+  W.used = 0;
+  double *dm = W.take(), *pe_init = W.take(), *pem = W.take(), *logp = W.take(), *gm = W.take(), *pm = W.take();
+  const double peln1 = std::log(ptop), ptk = std::exp(KAPPA * peln1);
+  // precompute :26-90
+#pragma omp parallel
+  {
+    std::vector<double> row(2 * (long)K * ni);
+    double *pg = row.data(), *lpg = pg + (long)K * ni;
+#pragma omp for schedule(static)
+    for (int j = js; j <= je; ++j) {
+      for (int k = 0; k < K; ++k)
+        for (int i = is; i <= ie; ++i) {
+          AT(dm, i, j, k) = AT(delp, i, j, k);
+          AT(pe_init, i, j, k) = AT(pe, i, j, k);
+        }
+      for (int i = is; i <= ie; ++i) {
+        AT(pem, i, j, 0) = ptop; AT(logp, i, j, 0) = peln1; AT(pk3, i, j, 0) = ptk; pg[i] = ptop; lpg[i] = peln1;
+      }
+      for (int k = 1; k < K; ++k)
+        for (int i = is; i <= ie; ++i) {
+          AT(pem, i, j, k) = AT(pem, i, j, k - 1) + AT(dm, i, j, k - 1);
+          AT(logp, i, j, k) = std::log(AT(pem, i, j, k));
+          pg[(long)k * ni + i] = pg[(long)(k - 1) * ni + i] + AT(dm, i, j, k - 1) * (1.0 - AT(q_con, i, j, k - 1));
+          lpg[(long)k * ni + i] = std::log(pg[(long)k * ni + i]);
+          AT(pk3, i, j, k) = std::exp(KAPPA * AT(logp, i, j, k));
+        }
+      for (int k = 0; k < K; ++k)
+        for (int i = is; i <= ie; ++i) {
+          AT(gm, i, j, k) = 1.0 / (1.0 - AT(cappa, i, j, k));
+          AT(dm, i, j, k) = AT(dm, i, j, k) * RGRAV;
+        }
+      for (int k = 0; k < km; ++k)
+        for (int i = is; i <= ie; ++i) {
+          AT(pm, i, j, k) = (pg[(long)(k + 1) * ni + i] - pg[(long)k * ni + i]) / (lpg[(long)(k + 1) * ni + i] - lpg[(long)k * ni + i]);
+          AT(delz, i, j, k) = AT(zh, i, j, k + 1) - AT(zh, i, j, k);
+        }
+    }
+  }
+  // Sim1Solver :165-219
+  const double t1g = 2.0 * dt * dt, rdt = 1.0 / dt;
+#pragma omp parallel
+  {
+    const long R = (long)K * ni;
+    std::vector<double> row(9 * R, 0.0);
+    double *w1 = row.data(), *gr = w1 + R, *bb = gr + R, *dd = bb + R, *bet = dd + R, *pp = bet + R, *gam = pp + R, *aa = gam + R, *p1 = aa + R;
+#define RW(a, k) (a)[(long)(k) * ni + i]
+#pragma omp for schedule(static)
+    for (int j = js; j <= je; ++j) {
+      for (int k = 0; k < km; ++k)
+        for (int i = is; i <= ie; ++i) {
+          AT(pe, i, j, k) = std::exp(AT(gm, i, j, k) * std::log(-AT(dm, i, j, k) / AT(delz, i, j, k) * RDGAS * AT(pt, i, j, k))) - AT(pm, i, j, k);
+          RW(w1, k) = AT(w, i, j, k);
+        }
+      for (int k = 0; k < km - 1; ++k)
+        for (int i = is; i <= ie; ++i) {
+          RW(gr, k) = AT(dm, i, j, k) / AT(dm, i, j, k + 1);
+          RW(bb, k) = 2.0 * (1.0 + RW(gr, k));
+          RW(dd, k) = 3.0 * (AT(pe, i, j, k) + RW(gr, k) * AT(pe, i, j, k + 1));
+        }
+      for (int i = is; i <= ie; ++i) {
+        RW(bb, km - 1) = 2.0;
+        RW(dd, km - 1) = 3.0 * AT(pe, i, j, km - 1);
+        for (int k = 0; k < km; ++k) RW(bet, k) = RW(bb, 0);
+        RW(pp, 1) = RW(dd, 0) / RW(bet, 1);
+      }
+      for (int k = 1; k < km; ++k)
+        for (int i = is; i <= ie; ++i) {
+          RW(gam, k) = RW(gr, k - 1) / RW(bet, k - 1);
+          RW(bet, k) = RW(bb, k) - RW(gam, k);
+        }
+      for (int k = 2; k < K; ++k)
+        for (int i = is; i <= ie; ++i) RW(pp, k) = (RW(dd, k - 1) - RW(pp, k - 1)) / RW(bet, k - 1);
+      for (int k = km - 1; k >= 1; --k)
+        for (int i = is; i <= ie; ++i) {
+          RW(pp, k) = RW(pp, k) - RW(gam, k) * RW(pp, k + 1);
+          RW(aa, k) = t1g * 0.5 * (AT(gm, i, j, k - 1) + AT(gm, i, j, k)) / (AT(delz, i, j, k - 1) + AT(delz, i, j, k)) * (AT(pem, i, j, k) + RW(pp, k));
+        }
+      for (int i = is; i <= ie; ++i) {
+        RW(bet, 0) = AT(dm, i, j, 0) - RW(aa, 1);
+        for (int k = 1; k < K; ++k) RW(bet, k) = RW(bet, k - 1);
+        AT(w, i, j, 0) = (AT(dm, i, j, 0) * RW(w1, 0) + dt * RW(pp, 1)) / RW(bet, 0);
+      }
+      for (int k = 1; k < km - 1; ++k)
+        for (int i = is; i <= ie; ++i) {
+          RW(gam, k) = RW(aa, k) / RW(bet, k - 1);
+          RW(bet, k) = AT(dm, i, j, k) - (RW(aa, k) + RW(aa, k + 1) + RW(aa, k) * RW(gam, k));
+          AT(w, i, j, k) = (AT(dm, i, j, k) * RW(w1, k) + dt * (RW(pp, k + 1) - RW(pp, k)) - RW(aa, k) * AT(w, i, j, k - 1)) / RW(bet, k);
+        }
+      {
+        const int k = km - 1;
+        for (int i = is; i <= ie; ++i) {
+          RW(p1, k) = t1g * AT(gm, i, j, k) / AT(delz, i, j, k) * (AT(pem, i, j, k + 1) + RW(pp, k + 1));
+          RW(gam, k) = RW(aa, k) / RW(bet, k - 1);
+          RW(bet, k) = AT(dm, i, j, k) - (RW(aa, k) + RW(p1, k) + RW(aa, k) * RW(gam, k));
+          AT(w, i, j, k) = (AT(dm, i, j, k) * RW(w1, k) + dt * (RW(pp, k + 1) - RW(pp, k)) - RW(p1, k) * ws[(long)j * ni + i] -
+                            RW(aa, k) * AT(w, i, j, k - 1)) / RW(bet, k);
+        }
+      }
+      for (int k = km - 2; k >= 0; --k)
+        for (int i = is; i <= ie; ++i) AT(w, i, j, k) = AT(w, i, j, k) - RW(gam, k + 1) * AT(w, i, j, k + 1);
+      for (int i = is; i <= ie; ++i) AT(pe, i, j, 0) = 0.0;
+      for (int k = 1; k < K; ++k)
+        for (int i = is; i <= ie; ++i) AT(pe, i, j, k) = AT(pe, i, j, k - 1) + AT(dm, i, j, k - 1) * (AT(w, i, j, k - 1) - RW(w1, k - 1)) * rdt;
+      for (int i = is; i <= ie; ++i) RW(p1, km - 1) = (AT(pe, i, j, km - 1) + 2.0 * AT(pe, i, j, km)) * 1.0 / 3.0;
+      for (int k = km - 2; k >= 0; --k)
+        for (int i = is; i <= ie; ++i)
+          RW(p1, k) = (AT(pe, i, j, k) + RW(bb, k) * AT(pe, i, j, k + 1) + RW(gr, k) * AT(pe, i, j, k + 2)) * 1.0 / 3.0 - RW(gr, k) * RW(p1, k + 1);
+      for (int k = 0; k < km; ++k)
+        for (int i = is; i <= ie; ++i) {
+          // NB the reference compares p_fac * delta_mass (not p_fac * pm) -- sim1_solver.py:134
+          const double a = RW(p1, k) + AT(pm, i, j, k);
+          const double maxp = (p_fac * AT(dm, i, j, k) > a) ? p_fac * AT(pm, i, j, k) : a;
+          AT(delz, i, j, k) = -AT(dm, i, j, k) * RDGAS * AT(pt, i, j, k) * std::exp((AT(cappa, i, j, k) - 1.0) * std::log(maxp));
+        }
+    }
+#undef RW
+  }
+  // finalize :93-145
+#pragma omp parallel for schedule(static)
+  for (int j = js; j <= je; ++j) {
+    for (int k = 0; k < K; ++k)
+      for (int i = is; i <= ie; ++i) {
+        if (use_logp) AT(pk3, i, j, k) = AT(logp, i, j, k);
+        AT(ppe, i, j, k) = (beta < -0.1) ? (AT(pe, i, j, k) + AT(pem, i, j, k)) : AT(pe, i, j, k);
+        if (last_call) {
+          AT(peln, i, j, k) = AT(logp, i, j, k);
+          AT(pk, i, j, k) = AT(pk3, i, j, k);
+          AT(pe, i, j, k) = AT(pem, i, j, k);
+        } else {
+          AT(pe, i, j, k) = AT(pe_init, i, j, k);
+        }
+      }
+    for (int i = is; i <= ie; ++i) AT(zh, i, j, km) = zs[(long)j * ni + i];
+    for (int k = km - 1; k >= 0; --k)
+      for (int i = is; i <= ie; ++i) AT(zh, i, j, k) = AT(zh, i, j, k + 1) - AT(delz, i, j, k);
+  }
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------------- C entry points
+// (ctypes: oracle/omp_port.py).  metrics: the 36 2-D arrays in the order of struct Grid, then edge_w, edge_e, edge_s, edge_n;
+// fields of d_sw in the order of the reference's call (d_sw.py:935-961) after ut, vt (the object's persistent uc_contra / vc_contra).
+#include <omp.h>
+
+namespace {
+Work& work_for(const Grid& g, int fields) {
+  static Work W;
+  const long n3 = g.sk * (g.nk + 1);
+  if (W.n3 != n3 || (long)W.buf.size() < n3 * fields) {
+    W.n3 = n3;
+    W.buf.assign((size_t)n3 * fields, 0.0);
+  }
+  W.used = 0;
+  return W;
+}
+Grid make_grid(const int* dims, const double* const* m, const double* sc) {
+  Grid g{};
+  g.n = dims[0]; g.nk = dims[1]; g.ni = g.nj = g.n + 7; g.is = g.js = 3; g.ie = g.je = g.n + 2; g.sk = (long)g.ni * g.nj;
+  const double** dst = &g.cosa_u;
+  for (int q = 0; q < NMETRIC + 4; ++q) dst[q] = m[q];
+  g.da_min = sc[0]; g.da_min_c = sc[1];
+  return g;
+}
+}  // namespace
+
+extern "C" {
+int omp_port_threads() { return omp_get_max_threads(); }
+void omp_port_set_threads(int n) { omp_set_num_threads(n); }
+
+void omp_port_d_sw(const int* dims, const double* const* metrics, const double* scalars, const double* const* col, const int* icfg,
+                   const double* dcfg, double* const* f, double dt) {
+  const Grid g = make_grid(dims, metrics, scalars);
+  Work& W = work_for(g, 32);
+  const Column c{col[0], col[1], col[2], col[3], col[4], col[5], col[6], col[7], col[8], col[9]};
+  const Config cfg{icfg[0], icfg[1], icfg[2], icfg[3], icfg[4], icfg[5], dcfg[0], dcfg[1], dcfg[2]};
+  d_sw(g, W, c, cfg, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15], f[16], f[17],
+       f[18], f[19], f[20], f[21], f[22], f[23], dt);
+}
+
+void omp_port_fxadv(const int* dims, const double* const* metrics, const double* scalars, double* const* f, double dt) {
+  const Grid g = make_grid(dims, metrics, scalars);
+  fxadv(g, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], dt);
+}
+
+// f: q, crx, cry, xfx, yfx, qxf, qyf, xmf (or null), ymf (or null), mass (or null); damp: nord_k, damp_c_k (or null: no damping)
+void omp_port_fvtp2d(const int* dims, const double* const* metrics, const double* scalars, double* const* f, int hord,
+                     const double* nord_k, const double* damp_c_k) {
+  const Grid g = make_grid(dims, metrics, scalars);
+  Work& W = work_for(g, 32);
+  Damp dp{nord_k, damp_c_k, g.da_min, f[9]};
+  fvtp2d(g, W, f[0], f[1], f[2], f[3], f[4], f[5], f[6], hord, f[7], f[8], nord_k ? &dp : nullptr, g.nk);
+}
+
+// f: cappa, zs (2-D), ws (2-D), delz, q_con, delp, pt, zh, pe, ppe, pk3, pk, peln, w
+void omp_port_riem3(const int* dims, const double* const* metrics, const double* scalars, double* const* f, int last_call, double dt,
+                    double ptop, double p_fac, double beta, int use_logp) {
+  const Grid g = make_grid(dims, metrics, scalars);
+  Work& W = work_for(g, 32);
+  riem_solver3(g, W, last_call, dt, f[0], ptop, f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9], f[10], f[11], f[12], f[13], p_fac,
+               beta, use_logp);
+}
+}

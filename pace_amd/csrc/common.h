@@ -441,3 +441,32 @@ static inline dim3 patch_grid(const Geo& g, int nlev) {
   const int i = (int)(p__ - (long)j * (g).sj);                        \
   const int k = (int)blockIdx.y;                                      \
   if (j >= (g).nj || i >= (g).ni) return;
+
+// ------------------------------------------------------------------------------------------------
+// advect_u_along_x / advect_v_along_y (xtp_u.py:9-91, ytp_v.py:9-91), ord < 8: the value advected through the face at `pos`
+// from the six cells q6 = q(pos-3 .. pos+2); zero_m / zero_0: the reconstruction of cell pos-1 / pos is zeroed (xtp_u.py:41-49)
+template <int MORD, bool EDGE = true, class DX>
+__device__ __forceinline__ double wind_flux6(const double* q6, double csign, double cfl, int pos, int s, int e,
+                                             DX dxa, bool zero_m, bool zero_0) {
+  const double al_m = EDGE ? ppm_al(q6, 2, pos - 1, s, e, dxa) : ppm_al_interior(q6, 2);
+  const double al_0 = EDGE ? ppm_al(q6, 3, pos, s, e, dxa) : ppm_al_interior(q6, 3);
+  const double al_p = EDGE ? ppm_al(q6, 4, pos + 1, s, e, dxa) : ppm_al_interior(q6, 4);
+  const double qm = q6[2], q0 = q6[3];
+  double bl_m = al_m - qm, br_m = al_0 - qm;
+  double bl_0 = al_0 - q0, br_0 = al_p - q0;
+  if (zero_m) { bl_m = 0.0; br_m = 0.0; }
+  if (zero_0) { bl_0 = 0.0; br_0 = 0.0; }
+  const double b0_m = bl_m + br_m, b0_0 = bl_0 + br_0;
+  bool s_m, s_0;
+  if (MORD == 5) {
+    s_m = bl_m * br_m < 0;
+    s_0 = bl_0 * br_0 < 0;
+  } else {
+    s_m = (3.0 * fabs(b0_m)) < fabs(bl_m - br_m);
+    s_0 = (3.0 * fabs(b0_0)) < fabs(bl_0 - br_0);
+  }
+  const double mask = (s_m || s_0) ? 1.0 : 0.0;
+  const double fx0 = (cfl > 0.0) ? (1.0 - cfl) * (br_m - cfl * b0_m) : (1.0 + cfl) * (bl_0 + cfl * b0_0);
+  return (csign > 0.0) ? (qm + fx0 * mask) : (q0 + fx0 * mask);
+}
+

@@ -39,31 +39,8 @@ k_finish_scalars(Geo g, Met m, real* __restrict__ pt, real* __restrict__ delp, r
 // ------------------------------------------------------------------------------------------------
 // compute_kinetic_energy (d_sw.py:204-298) with xtp_u / ytp_v (xtp_u.py:9-91, ytp_v.py:9-91), ord < 8
 // ------------------------------------------------------------------------------------------------
-template <int MORD, bool EDGE = true, class DX>
-__device__ __forceinline__ double wind_flux6(const double* q6, double csign, double cfl, int pos, int s, int e,
-                                             DX dxa, bool zero_m, bool zero_0) {
-  const double al_m = EDGE ? ppm_al(q6, 2, pos - 1, s, e, dxa) : ppm_al_interior(q6, 2);
-  const double al_0 = EDGE ? ppm_al(q6, 3, pos, s, e, dxa) : ppm_al_interior(q6, 3);
-  const double al_p = EDGE ? ppm_al(q6, 4, pos + 1, s, e, dxa) : ppm_al_interior(q6, 4);
-  const double qm = q6[2], q0 = q6[3];
-  double bl_m = al_m - qm, br_m = al_0 - qm;
-  double bl_0 = al_0 - q0, br_0 = al_p - q0;
-  if (zero_m) { bl_m = 0.0; br_m = 0.0; }
-  if (zero_0) { bl_0 = 0.0; br_0 = 0.0; }
-  const double b0_m = bl_m + br_m, b0_0 = bl_0 + br_0;
-  bool s_m, s_0;
-  if (MORD == 5) {
-    s_m = bl_m * br_m < 0;
-    s_0 = bl_0 * br_0 < 0;
-  } else {
-    s_m = (3.0 * fabs(b0_m)) < fabs(bl_m - br_m);
-    s_0 = (3.0 * fabs(b0_0)) < fabs(bl_0 - br_0);
-  }
-  const double mask = (s_m || s_0) ? 1.0 : 0.0;
-  const double fx0 = (cfl > 0.0) ? (1.0 - cfl) * (br_m - cfl * b0_m) : (1.0 + cfl) * (bl_0 + cfl * b0_0);
-  return (csign > 0.0) ? (qm + fx0 * mask) : (q0 + fx0 * mask);
-}
-
+// (wind_flux6 -- the 1-D advection of a wind component, xtp_u.py:9-91 -- lives in common.h: csrc/k_stencils.hip launches it as a
+// stencil of its own)
 template <int MORD>
 __global__ void __launch_bounds__(256)
 k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,

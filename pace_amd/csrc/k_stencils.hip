@@ -78,6 +78,30 @@ __global__ void k_st_bke(Geo g, Met m, Win w, const real* uc, const real* vc, co
   out[c] = v * dt;
 }
 
+
+// xtp_u_stencil_defn / ytp_v_stencil_defn (tests/savepoint/translate/translate_xtp_u.py:13-23, translate_ytp_v.py): the 1-D
+// advection of a D-grid wind component by the (contravariant wind x dt) on the cell corners, as a stencil of its own
+template <int AXIS, int MORD>
+__global__ void k_st_xtp(Geo g, Met m, Win w, const real* c_dt, const real* u, real* flux) {
+  WIN_IJK(w);
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  const long d = AXIS == 0 ? 1 : sj;
+  const int pos = AXIS == 0 ? i : j, s0 = AXIS == 0 ? g.is : g.js, e0 = AXIS == 0 ? g.ie : g.je;
+  const int opos = AXIS == 0 ? j : i, os = AXIS == 0 ? g.js : g.is, oe = AXIS == 0 ? g.je : g.ie;
+  double q6[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) q6[t] = u[c + (long)(t - 3) * d];
+  const double ub = c_dt[c];  // dt = 1 folded in
+  const real* rd = AXIS == 0 ? m.rdx : m.rdy;
+  const real* sp = (AXIS == 0 ? m.dx : m.dy) + (AXIS == 0 ? (long)j * sj : (long)i);
+  const double cfl = (ub > 0.0) ? ub * 1.0 * rd[c2 - d] : ub * 1.0 * rd[c2];
+  const bool zo = (opos == os || opos == oe + 1);
+  auto zero = [&](int p) { return zo && (p == s0 - 1 || p == s0 || p == e0 || p == e0 + 1); };
+  flux[c] = wind_flux6<MORD>(q6, ub, cfl, pos, s0, e0, [=](int p) { return (double)sp[(long)p * d]; }, zero(pos - 1), zero(pos));
+}
+
 // ---- corner fills: one thread per destination cell of the four 3 x 3 (A-grid) / (B-grid: see below) corner blocks ----
 __device__ __forceinline__ void remap_bgrid(const Geo& g, int dir, int& i, int& j) {  // corners.py:591-712 (oracle/corner_ops.py)
   const bool w_ = i < g.is, e_ = i > g.ie + 1, s_ = j < g.js, n_ = j > g.je + 1;
@@ -218,6 +242,19 @@ int launch_stencil(const Geo& g, const Met& m, int id, void* const* f, int nf, c
     case PACE_ST_FILL_CORNERS_2CELLS_Y:
       hipLaunchKernelGGL(k_st_fill_2cells<1>, dim3((unsigned)w.nk), dim3(64), 0, st, g, w, F(0), F(1));
       break;
+    case PACE_ST_XTP_U:
+    case PACE_ST_YTP_V: {
+      if (nf != 3 || ns != 1) return PACE_ERR_ARG;
+      const int mord = (int)sc[0];
+      if (mord != 5 && mord != 6 && mord != 7) return PACE_ERR_UNSUPPORTED;  // (ord 8: not on this path, as in d_sw)
+      const bool x = id == PACE_ST_XTP_U;  // six cells along the axis: pos-3 .. pos+2
+      if ((x ? w.i0 : w.j0) < 3 || (x ? w.i0 + w.ni + 2 > g.ni : w.j0 + w.nj + 2 > g.nj)) return PACE_ERR_ARG;
+      if (x && mord == 5) hipLaunchKernelGGL((k_st_xtp<0, 5>), win_grid(w), blk, 0, st, g, m, w, F(0), F(1), F(2));
+      else if (x) hipLaunchKernelGGL((k_st_xtp<0, 6>), win_grid(w), blk, 0, st, g, m, w, F(0), F(1), F(2));
+      else if (mord == 5) hipLaunchKernelGGL((k_st_xtp<1, 5>), win_grid(w), blk, 0, st, g, m, w, F(0), F(1), F(2));
+      else hipLaunchKernelGGL((k_st_xtp<1, 6>), win_grid(w), blk, 0, st, g, m, w, F(0), F(1), F(2));
+      break;
+    }
     default:
       return PACE_ERR_UNSUPPORTED;
   }

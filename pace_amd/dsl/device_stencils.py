@@ -171,6 +171,7 @@ _register(_both("yppm", "compute_y_flux"), *_ppm(1))
 ST_FLUX_CAPACITOR, ST_HEAT_DISS, ST_APPLY_FLUXES, ST_UBKE, ST_VBKE = 1, 2, 3, 4, 5
 ST_COPY_CORNERS_X, ST_COPY_CORNERS_Y, ST_FILL_CORNERS_BGRID_X, ST_FILL_CORNERS_BGRID_Y = 6, 7, 8, 9
 ST_FILL_CORNERS_DGRID, ST_FILL_CORNERS_2CELLS_X, ST_FILL_CORNERS_2CELLS_Y = 10, 11, 12
+ST_XTP_U, ST_YTP_V = 13, 14
 
 
 def _origin(st):
@@ -230,3 +231,18 @@ _register(_corner_paths("fill_corners_2cells_x_stencil"), _no_check,
           lambda st, q_out, q_in: _call_stencil(st, ST_FILL_CORNERS_2CELLS_X, [q_out, q_in]))
 _register(_corner_paths("fill_corners_2cells_y_stencil"), _no_check,
           lambda st, q_out, q_in: _call_stencil(st, ST_FILL_CORNERS_2CELLS_Y, [q_out, q_in]))
+
+
+# xtp_u_stencil_defn / ytp_v_stencil_defn: defined in the reference's test modules (tests/savepoint/translate/translate_xtp_u.py:13-23,
+# translate_ytp_v.py), matched on the bare name; externals iord (5, 6, 7: the orders d_sw runs hord_mt with)
+def _xtp_check(st):
+    if int(st.externals.get("iord", 0)) not in (5, 6, 7):
+        raise NotImplementedError(f"{st.name}: iord must be 5, 6 or 7")
+
+
+_register(("pace_amd.fv3core.stencils.xtp_u.xtp_u_stencil_defn",), _xtp_check,
+          lambda st, ub_contra_times_dt, u, updated_u, dx, dxa, rdx: _call_stencil(
+              st, ST_XTP_U, [ub_contra_times_dt, u, updated_u], [int(st.externals["iord"])], metrics_from=[dx, dxa, rdx]))
+_register(("pace_amd.fv3core.stencils.ytp_v.ytp_v_stencil_defn",), _xtp_check,
+          lambda st, vb_contra_times_dt, v, updated_v, dy, dya, rdy: _call_stencil(
+              st, ST_YTP_V, [vb_contra_times_dt, v, updated_v], [int(st.externals["iord"])], metrics_from=[dy, dya, rdy]))

@@ -4,6 +4,7 @@ StencilFactory.from_origin_domain with the windows those tests use and compared,
 definitions (the corner fills: oracle/corner_ops.py, which the whole-operator tests already hold to the reference's runs).
 
 translate_d_sw.py:104 (ubke), :151 (vbke), :184 (flux_capacitor), :226 (heat_diss), :251 (apply_fluxes);
+translate_xtp_u.py:13-23 / translate_ytp_v.py (xtp_u_stencil_defn, ytp_v_stencil_defn);
 translate_corners.py:29-36 (fill_corners_2cells_{x,y}_stencil), :120 (fill_corners_dgrid_defn); corners.py:17-59 (CopyCorners).
 CPU: the kernel sources under emulation; `-m gpu`: the HIP library.
 """
@@ -103,6 +104,25 @@ def run_all(lib, device):
     rvb = np.where(jedge, 0.5 * (sh(a["vt"], -1, 0) + a["vt"]), rvb) * (2.0 * dt5)
     B = (slice(3, 4 + N), slice(3, 4 + N), slice(0, NZ))
     assert np.array_equal(ub.numpy()[B], rub[B]) and np.array_equal(vb.numpy()[B], rvb[B])
+
+
+    # xtp_u / ytp_v: compute + 1 (translate_xtp_u.py:41-42), iord 5 and 6, against the oracle's advect_wind_1d with dt = 1
+    from oracle import ppm_transport as tr
+
+    for iord in (5, 6):
+        a = {k: _rand(rng) for k in "c u".split()}
+        a["c"] *= 0.3  # a Courant number
+        for name, axis, fargs, margs in (("xtp_u_stencil_defn", 0, ["ub_contra_times_dt", "u", "updated_u"], ("dx", "dxa", "rdx")),
+                                         ("ytp_v_stencil_defn", 1, ["vb_contra_times_dt", "v", "updated_v"], ("dy", "dya", "rdy"))):
+            q = {k: env.q3(v) for k, v in a.items()}
+            out = env.q3()
+            st = sf.from_origin_domain(_defn("translate_" + name[:5], name, fargs + list(margs)), origin=gi.origin_compute(),
+                                       domain=gi.domain_compute(add=(1, 1, 0)), externals={"iord": iord, "mord": iord, "xt_minmax": False})
+            st(q["c"], q["u"], out, *[getattr(env.grid_data, k) for k in margs])
+            ref = tr.advect_wind_1d(a["u"], a["c"], m[margs[2]], m[margs[0]], m[margs[1]], 1.0, g, axis, iord)
+            B = (slice(3, 4 + N), slice(3, 4 + N), slice(0, NZ))
+            assert np.array_equal(out.numpy()[B], ref[B]), (name, iord)
+            assert not out.numpy()[2].any() and not out.numpy()[:, 2].any(), "written outside the window"
 
     # corner fills: full domain (translate_corners.py)
     from oracle import corner_ops as co
