@@ -815,44 +815,42 @@ __device__ __forceinline__ HeatPt heat_point(const Geo& g, const Met& m, const r
   return h;
 }
 
+// heat_source_from_vorticity_damping (d_sw.py:493-577) and update_u_and_v (:582-608) in one pass: the winds after
+// u_and_v_from_ke are read from the workspace copy the transport kernel's store phase left (umid / vmid, on the windows
+// (n, n+1) / (n+1, n)), the final winds are written to u / v -- no thread reads what another one writes.
 __global__ void __launch_bounds__(256)
-k_heat_source(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
+k_heat_source(Geo g, Met m, const real* __restrict__ umid, const real* __restrict__ vmid,
               const real* __restrict__ vort_b, const real* __restrict__ ut2, const real* __restrict__ vt2,
               const real* __restrict__ delp, real* __restrict__ heat_s, real* __restrict__ heat_source,
-              real* __restrict__ diss_est, const real* __restrict__ d_con_k, double d_con, int do_skeb) {
+              real* __restrict__ diss_est, const real* __restrict__ d_con_k, double d_con, int do_skeb,
+              real* __restrict__ u, real* __restrict__ v, const real* __restrict__ damp_vt) {
   PATCH_IJK(g);
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
+  const bool upd = damp_vt[k] > 1e-5;
+  if (i <= g.ie) u[c] = upd ? umid[c] + vt2[c] : umid[c];
+  if (j <= g.je) v[c] = upd ? vmid[c] - ut2[c] : vmid[c];
+  if (i > g.ie || j > g.je) return;  // (the reference forms heat_s on compute + 1; only the compute domain of it is ever read)
   const double dck = d_con_k[k];
   const bool don = dck > DCON_THRESHOLD;
-  const HeatPt p0 = heat_point(g, m, u, v, vort_b, ut2, vt2, don, c, c2, i, j);
   if ((dck > DCON_THRESHOLD) || do_skeb) {
-    const HeatPt pj = heat_point(g, m, u, v, vort_b, ut2, vt2, don, c + g.sj, c2 + g.sj, i, j + 1);
-    const HeatPt pi = heat_point(g, m, u, v, vort_b, ut2, vt2, don, c + 1, c2 + 1, i + 1, j);
+    const HeatPt p0 = heat_point(g, m, umid, vmid, vort_b, ut2, vt2, don, c, c2, i, j);
+    const HeatPt pj = heat_point(g, m, umid, vmid, vort_b, ut2, vt2, don, c + g.sj, c2 + g.sj, i, j + 1);
+    const HeatPt pi = heat_point(g, m, umid, vmid, vort_b, ut2, vt2, don, c + 1, c2 + 1, i + 1, j);
     const double u2 = p0.fy + pj.fy, du2 = p0.ubt + pj.ubt, v2 = p0.fx + pi.fx, dv2 = p0.vbt + pi.vbt;
     const double dampterm = m.rsin2[c2] * 0.25 *
                             ((p0.ubt * p0.ubt + pj.ubt * pj.ubt + p0.vbt * p0.vbt + pi.vbt * pi.vbt) +
                              2.0 * (p0.gy + pj.gy + p0.gx + pi.gx) - m.cosa_s[c2] * (u2 * dv2 + v2 * du2 + du2 * dv2));
     const double hs = delp[c] * (heat_s[c] - dck * dampterm);
     heat_s[c] = hs;
-    if ((d_con > DCON_THRESHOLD || do_skeb) && i <= g.ie && j <= g.je) {
+    if (d_con > DCON_THRESHOLD || do_skeb) {
       heat_source[c] = heat_source[c] + hs;
       if (do_skeb) diss_est[c] = diss_est[c] - dampterm;
     }
-  } else if ((d_con > DCON_THRESHOLD || do_skeb) && i <= g.ie && j <= g.je) {
+  } else if (d_con > DCON_THRESHOLD || do_skeb) {
     heat_source[c] = heat_source[c] + heat_s[c];
   }
-}
-
-__global__ void __launch_bounds__(256)
-k_update_uv(Geo g, real* __restrict__ u, real* __restrict__ v, const real* __restrict__ ut2,
-            const real* __restrict__ vt2, const real* __restrict__ damp_vt) {
-  PLANE_IJK(g);
-  if (!(damp_vt[k] > 1e-5)) return;
-  const long c = IDX3(g, i, j, k);
-  if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je + 1) u[c] = u[c] + vt2[c];
-  if (i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je) v[c] = v[c] - ut2[c];
 }
 
 // =================================================================================================
@@ -1102,10 +1100,10 @@ static DswSide* dsw_side() {
 #endif
 
 struct DswWork {
-  real *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv;
+  real *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv, *umid, *vmid;
   real* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
 };
-#define DSW_NFIELDS 19
+#define DSW_NFIELDS 21
 
 int64_t dsw_workspace_bytes(const Geo& g) {
   const int64_t field = (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real);
@@ -1178,8 +1176,6 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     }
   }
   int rc;
-  const dim3 block(256);
-  const dim3 gk = plane_grid(g, nk);
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
   } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
@@ -1285,13 +1281,13 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     dp.fx2o = W.ut2; dp.fy2o = W.vt2; dp.add2d = m.fC_agrid;
     // ... and u_and_v_from_ke finished in the kernel's store phase: the vorticity fluxes never reach memory
     dp.u_upd = u; dp.v_upd = v; dp.ke = W.ke;
+    dp.u_out = W.umid; dp.v_out = W.vmid;  // (read by k_heat_source, which writes the final winds to u, v)
     if ((rc = launch_transport(g, m, W.wk, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, 0, 0, dp, st))) return rc;
   }
   }
   if (phases & 8) {
-  hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source, diss_est,
-                     d_dcon, cfg->d_con, cfg->do_skeb);
-  hipLaunchKernelGGL(k_update_uv, gk, block, 0, st, g, u, v, W.ut2, W.vt2, d_damp_vt_c);
+  hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, W.umid, W.vmid, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source,
+                     diss_est, d_dcon, cfg->d_con, cfg->do_skeb, u, v, d_damp_vt_c);
   }
   PACE_CHECK_LAUNCH();
   return PACE_OK;

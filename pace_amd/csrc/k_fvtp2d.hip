@@ -585,7 +585,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
           if (DMODE == 2) v = v + 0.5 * damp * (ms[t] + ms[t + 1]) * dvx[f];
           if (EPI == 0) {
             if (dp.v_upd) {  // v_from_ke (d_sw.py:423-436): same expression, same order as the stand-alone kernel
-              ST(dp.v_upd, c) = w0[t] * w1[t] + w2[t] - w3[t] - v;
+              ST(dp.v_out ? dp.v_out : dp.v_upd, c) = w0[t] * w1[t] + w2[t] - w3[t] - v;
             } else {
               ST(fx, c) = v;
             }
@@ -673,7 +673,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
           if (DMODE == 2) v = v + 0.5 * damp * (ms[t] + ms[t + 1]) * dvy[f];
           if (EPI == 0) {
             if (dp.u_upd) {  // u_from_ke (d_sw.py:406-420)
-              ST(dp.u_upd, c) = w0[t] * w1[t] + w2[t] - w3[t] + v;
+              ST(dp.u_out ? dp.u_out : dp.u_upd, c) = w0[t] * w1[t] + w2[t] - w3[t] + v;
             } else {
               ST(fy, c) = v;
             }

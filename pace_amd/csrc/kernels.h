@@ -40,6 +40,10 @@ struct FvDamp {
   real* u_upd;
   real* v_upd;
   const real* ke;
+  // optional: where the results of that go instead of u_upd / v_upd themselves (launch_d_sw: a workspace copy, so that the kernel
+  // that follows -- heating + final wind update in one -- reads the intermediate winds of its neighbours race-free)
+  real* u_out;
+  real* v_out;
 };
 
 int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
