@@ -391,33 +391,42 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   STAMP(3);
   // stage 2: q_i; and re-stage the corner cells of q for the x direction (copy_corners_x)
   {
-    constexpr int NE2 = (QW * TJ + 255) / 256;
-    double y0_[NE2], y1_[NE2], a_[NE2];
+    // One thread per column and group of RPG consecutive rows (round 3; before: one cell per thread and pass, every cell loading
+    // both of its faces' area fluxes and reading both advected values from LDS): a face between two cells of the run is loaded
+    // / read once, and the thread's position is computed once.  Same expression per cell.
+    constexpr int NG2 = (256 / QW) < TJ ? (256 / QW) : TJ;  // row groups per column (6 in production: 228 threads)
+    constexpr int RPG = (TJ + NG2 - 1) / NG2;                // rows per thread (4)
+    const int grp2 = tid / QW, ii = tid - grp2 * QW;
+    const int jj0 = grp2 * RPG;
+    const int gi = ilo + ii;
+    const bool act = grp2 < NG2;
+    const bool col_ok = act && (!EX || (gi >= 0 && gi <= g.ni - 1));
+    double y_[RPG + 1], a_[RPG], sy_[RPG + 1];
 #pragma unroll
-    for (int t = 0; t < NE2; ++t) {  // loads of all cells of this thread first ...
-      const int e = tid + 256 * t;
-      const int jj = e / QW, ii = e - jj * QW;
-      const int gi = ilo + ii, gj = j0 + jj;
-      const bool ok = e < QW * TJ && (!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je));
-      const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+    for (int t = 0; t <= RPG; ++t) {  // loads first ...
+      const int gj = j0 + jj0 + t;
+      const bool row_ok = jj0 + t <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1));
+      const unsigned c2 = (col_ok && row_ok) ? OFF2(gi, gj) : OFF2(g.is, g.js);
 #ifdef FV_X_NOLOADS
-      y0_[t] = 1.0e5 + c2; y1_[t] = 1.0e5; a_[t] = 1.0e9;
+      y_[t] = 1.0e5 + c2;
+      if (t < RPG) a_[t] = 1.0e9;
 #else
-      y0_[t] = LD(yfx, kb8 + c2);
-      y1_[t] = LD(yfx, kb8 + c2 + sj8);
-      a_[t] = LD(m.area, c2);
+      y_[t] = LD(yfx, kb8 + c2);
+      if (t < RPG) a_[t] = LD(m.area, c2);
 #endif
     }
+    if (act) {
 #pragma unroll
-    for (int t = 0; t < NE2; ++t) {  // ... then the arithmetic
-      const int e = tid + 256 * t;
-      const int jj = e / QW, ii = e - jj * QW;
-      const int gi = ilo + ii, gj = j0 + jj;
-      if (e < QW * TJ) {
-        const bool ok = (!EX || (gi >= 0 && gi <= g.ni - 1)) && (!EY || (gj >= g.js && gj <= g.je));
-        const double y0 = y0_[t], y1 = y1_[t], a = a_[t];
-        const double val = (sq[jj + 3][ii] * a + y0 * syin[jj][ii] - y1 * syin[jj + 1][ii]) / (a + y0 - y1);
-        sqi[jj][ii] = ok ? val : 0.0;
+      for (int t = 0; t <= RPG; ++t) sy_[t] = (jj0 + t <= TJ) ? syin[jj0 + t][ii] : 0.0;
+#pragma unroll
+      for (int t = 0; t < RPG; ++t) {  // ... then the arithmetic
+        const int jj = jj0 + t, gj = j0 + jj;
+        if (jj < TJ) {
+          const bool ok = col_ok && (!EY || (gj >= g.js && gj <= g.je));
+          const double y0 = y_[t], y1 = y_[t + 1], a = a_[t];
+          const double val = (sq[jj + 3][ii] * a + y0 * sy_[t] - y1 * sy_[t + 1]) / (a + y0 - y1);
+          sqi[jj][ii] = ok ? val : 0.0;
+        }
       }
     }
   }
@@ -477,32 +486,37 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   STAMP(5);
   // stage 4: q_j
   {
-    constexpr int NE4 = (TI * QH + 255) / 256;
-    double x0_[NE4], x1_[NE4], a_[NE4];
+    // the same along x: one thread per row and group of CPG consecutive columns (QH * TI / CPG = 240 threads in production)
+    constexpr int CPG = 4;
+    static_assert(TI % CPG == 0 && QH * (TI / CPG) <= 256, "q_j run mapping");
+    constexpr int NGX4 = TI / CPG;
+    const int jj = tid / NGX4, ii0 = (tid - jj * NGX4) * CPG;
+    const int gj = jlo + jj;
+    const bool act = jj < QH;
+    const bool row_ok = act && (!EY || (gj >= 0 && gj <= g.nj - 1));
+    double x_[CPG + 1], a_[CPG], sx_[CPG + 1];
 #pragma unroll
-    for (int t = 0; t < NE4; ++t) {
-      const int e = tid + 256 * t;
-      const int jj = e / TI, ii = e - jj * TI;
-      const int gi = i0 + ii, gj = jlo + jj;
-      const bool ok = e < TI * QH && (!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie));
-      const unsigned c2 = ok ? OFF2(gi, gj) : OFF2(g.is, g.js);
+    for (int t = 0; t <= CPG; ++t) {
+      const int gi = i0 + ii0 + t;
+      const bool col_ok = !EX || (gi >= g.is && gi <= g.ie + 1);
+      const unsigned c2 = (row_ok && col_ok) ? OFF2(gi, gj) : OFF2(g.is, g.js);
 #ifdef FV_X_NOLOADS
-      x0_[t] = 1.0e5 + c2; x1_[t] = 1.0e5; a_[t] = 1.0e9;
+      x_[t] = 1.0e5 + c2;
+      if (t < CPG) a_[t] = 1.0e9;
 #else
-      x0_[t] = LD(xfx, kb8 + c2);
-      x1_[t] = LD(xfx, kb8 + c2 + E8);
-      a_[t] = LD(m.area, c2);
+      x_[t] = LD(xfx, kb8 + c2);
+      if (t < CPG) a_[t] = LD(m.area, c2);
 #endif
     }
+    if (act) {
 #pragma unroll
-    for (int t = 0; t < NE4; ++t) {
-      const int e = tid + 256 * t;
-      const int jj = e / TI, ii = e - jj * TI;
-      const int gi = i0 + ii, gj = jlo + jj;
-      if (e < TI * QH) {
-        const bool ok = (!EY || (gj >= 0 && gj <= g.nj - 1)) && (!EX || (gi >= g.is && gi <= g.ie));
-        const double x0 = x0_[t], x1 = x1_[t], a = a_[t];
-        const double val = (sq[jj][ii + 3] * a + x0 * sxin[jj][ii] - x1 * sxin[jj][ii + 1]) / (a + x0 - x1);
+      for (int t = 0; t <= CPG; ++t) sx_[t] = sxin[jj][ii0 + t];
+#pragma unroll
+      for (int t = 0; t < CPG; ++t) {
+        const int ii = ii0 + t, gi = i0 + ii;
+        const bool ok = row_ok && (!EX || (gi >= g.is && gi <= g.ie));
+        const double x0 = x_[t], x1 = x_[t + 1], a = a_[t];
+        const double val = (sq[jj][ii + 3] * a + x0 * sx_[t] - x1 * sx_[t + 1]) / (a + x0 - x1);
         sq[jj][ii + 3] = ok ? val : 0.0;  // q_j in place: this thread is the only one that reads or writes this cell in this stage
       }
     }
