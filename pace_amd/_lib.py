@@ -184,7 +184,10 @@ class Library:
             ptr = getattr(last, "value", None) if isinstance(last, C.c_void_p) else None
             end = self.timing.bracket(name, ptr)
         if self._trace:
-            sys.stderr.write(f"[pace] {name}\n")
+            # (the rank, and the leading integer argument of the entry points that have one -- the `phases` mask of
+            # pace_d_sw_phases: tests/test_halo.py reads the order of a multi-rank step from these lines)
+            lead = f" {args[0]}" if args and isinstance(args[0], int) else ""
+            sys.stderr.write(f"[pace r{os.environ.get('RANK', '0')}] {name}{lead}\n")
             sys.stderr.flush()
         rc = getattr(self.cdll, name)(*args)
         if self._trace and "emu" not in os.path.basename(self.path):
