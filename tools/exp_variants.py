@@ -2,6 +2,10 @@
 
     python tools/exp_variants.py base=pace_amd/libpace_hip.so pf1=build/var/pf1/libpace_hip.so ... [--n 192] [--reps 20]
 
+Every library is measured in a process of its own (round 3: two libraries in one process share the runtime's hardware queues --
+each brings its two side streams -- and the one loaded second measured 3 - 5 % slower in the multi-stream phases whichever it
+was; profiles/r03_experiments/x19); the outputs travel through a file for the bit-for-bit comparison with the first library's.
+
 For every library: the fused transport kernel alone (pace_fvtp2d_update, operands rotated through distinct copies so that
 nothing is cache-warm), the scalar phase of d_sw (mask 2), the wind phase (mask 12), riem_solver3 and the whole substep on one
 stream; outputs are compared bit for bit with the first library's.  A library built with -DFV_PROF also prints the stage
@@ -53,11 +57,47 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--copies", type=int, default=8)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--child", default=None, help="(internal) measure the one library given, save its outputs / results under this prefix")
     args = ap.parse_args()
+    if args.child is None:
+        import subprocess
+        import tempfile
+
+        tmp = tempfile.mkdtemp(prefix="pace_exp_")
+        first, results = None, {}
+        for n_, spec in enumerate(args.libs):
+            pre = os.path.join(tmp, f"v{n_}")
+            cmd = [sys.executable, os.path.abspath(__file__), spec, "--n", str(args.n), "--nz", str(args.nz), "--reps", str(args.reps),
+                   "--copies", str(args.copies), "--child", pre]
+            p = subprocess.run(cmd, capture_output=True, text=True)
+            out = [ln for ln in p.stdout.splitlines() if ln.strip()]
+            if p.returncode != 0:
+                print(f"[{spec}] FAILED: {p.stderr[-400:]}")
+                continue
+            res = json.load(open(pre + ".json"))
+            cur = np.load(pre + ".npz")
+            if first is None:
+                first, worst = cur, {}
+            else:
+                worst = {}
+                for k in cur.files:
+                    if not np.array_equal(cur[k], first[k], equal_nan=True):
+                        d = np.abs(cur[k] - first[k])
+                        worst[k] = float(np.nanmax(d) / (np.nanmax(np.abs(first[k])) + 1e-300))
+            for ln in out:
+                print(ln.replace("@@DIFF@@", str(worst) if worst else "no (bit-identical)"), flush=True)
+            res["differs_from_first"] = worst
+            results[spec.split("=", 1)[0]] = res
+        if args.json:
+            with open(args.json, "w") as f:
+                json.dump(results, f, indent=1)
+        import shutil
+
+        shutil.rmtree(tmp, ignore_errors=True)
+        return
     n, nz = args.n, args.nz
     m = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(m, n, nz)
-    ref = {}
     results = {}
     for spec in args.libs:
         name, path = spec.split("=", 1)
@@ -143,23 +183,14 @@ def main():
         torch.cuda.synchronize()
         for k in DSW_ARGS + ["pe", "ppe", "pk3", "delz"]:
             outs[k] = copies[0][k].numpy().copy()
-        worst = {}
-        if not ref:
-            ref.update(outs)
-        else:
-            for k, v in outs.items():
-                if not np.array_equal(v, ref[k], equal_nan=True):
-                    d = np.abs(v - ref[k])
-                    worst[k] = float(np.nanmax(d) / (np.nanmax(np.abs(ref[k])) + 1e-300))
-        res["differs_from_first"] = worst
+        np.savez(args.child + ".npz", **outs)
+        with open(args.child + ".json", "w") as f:
+            json.dump(res, f)
         results[name] = res
         line = "  ".join(f"{k} {v[0]:7.1f}" for k, v in res.items() if isinstance(v, tuple))
-        print(f"[{name}] us (median): {line}   differs: {worst if worst else 'no (bit-identical)'}", flush=True)
+        print(f"[{name}] us (median): {line}   differs: @@DIFF@@", flush=True)
         del copies, dsw, riem, env, out
         torch.cuda.empty_cache()
-    if args.json:
-        with open(args.json, "w") as f:
-            json.dump(results, f, indent=1)
 
 
 if __name__ == "__main__":
