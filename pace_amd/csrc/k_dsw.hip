@@ -821,7 +821,7 @@ __device__ __forceinline__ HeatPt heat_point(const Geo& g, const Met& m, const r
 __global__ void __launch_bounds__(256)
 k_heat_source(Geo g, Met m, const real* __restrict__ umid, const real* __restrict__ vmid,
               const real* __restrict__ vort_b, const real* __restrict__ ut2, const real* __restrict__ vt2,
-              const real* __restrict__ delp, real* __restrict__ heat_s, real* __restrict__ heat_source,
+              const real* __restrict__ delp, const real* __restrict__ heat_s, real* __restrict__ heat_source,
               real* __restrict__ diss_est, const real* __restrict__ d_con_k, double d_con, int do_skeb,
               real* __restrict__ u, real* __restrict__ v, const real* __restrict__ damp_vt) {
   PATCH_IJK(g);
@@ -842,8 +842,7 @@ k_heat_source(Geo g, Met m, const real* __restrict__ umid, const real* __restric
     const double dampterm = m.rsin2[c2] * 0.25 *
                             ((p0.ubt * p0.ubt + pj.ubt * pj.ubt + p0.vbt * p0.vbt + pi.vbt * pi.vbt) +
                              2.0 * (p0.gy + pj.gy + p0.gx + pi.gx) - m.cosa_s[c2] * (u2 * dv2 + v2 * du2 + du2 * dv2));
-    const double hs = delp[c] * (heat_s[c] - dck * dampterm);
-    heat_s[c] = hs;
+    const double hs = delp[c] * (heat_s[c] - dck * dampterm);  // (the reference's temporary: consumed right here, not stored)
     if (d_con > DCON_THRESHOLD || do_skeb) {
       heat_source[c] = heat_source[c] + hs;
       if (do_skeb) diss_est[c] = diss_est[c] - dampterm;
