@@ -33,7 +33,12 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB):
             build()
-        _lib = C.CDLL(LIB)
+        try:
+            _lib = C.CDLL(LIB)
+        except OSError:  # (a stale or foreign build: make it again on this host)
+            os.remove(LIB)
+            build()
+            _lib = C.CDLL(LIB)
         _lib.omp_port_threads.restype = C.c_int
     return _lib
 
