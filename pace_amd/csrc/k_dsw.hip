@@ -1201,6 +1201,26 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     dp.damp_k = d_dampfac_w_c + k0; dp.nord_k = d_nord_w + k0; dp.nmax = nmax_w; dp.mass_given = 0;
     dp.qout = W.gx + o; dp.amass = delp + o; dp.dw = W.dw + o; dp.heat_s = W.heat_s + o; dp.diss_est = diss_est + o;
     dp.damp_w_k = d_damp_w_c + k0; dp.ke_bg_k = d_kebg + k0; dp.dt = dt;
+    const FvDamp dpw = dp;
+    // q_con -> W.gy
+    dp = FvDamp{};
+    dp.damp_k = d_dampfac_t + k0; dp.nord_k = d_nord_t + k0; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp + o;
+    dp.qout = W.gy + o; dp.amass = delp + o;
+    // pt -> W.fx2
+    FvDamp dp2 = dp;
+    dp2.damp_k = d_dampfac_vt + k0; dp2.nord_k = d_nord_v + k0; dp2.nmax = nmax_v; dp2.qout = W.fx2 + o;
+    // The three in ONE launch (k_fvtp2d_scalars3: a grid three tile planes high) when all three run ord 6 -- the baseline --;
+    // PACE_DSW_FUSED3=0 keeps the three launches (on three streams, below).
+    static const bool fused3 = !(getenv("PACE_DSW_FUSED3") && getenv("PACE_DSW_FUSED3")[0] == '0');
+    static const bool pair = getenv("PACE_DSW_PAIR") != nullptr;  // experiment: q_con and pt in one workgroup (k_fvtp2d_pair)
+    bool done3 = false;
+    if (fused3 && !pair && cfg->hord_vt == 6 && cfg->hord_dp == 6 && cfg->hord_tm == 6) {
+      rc = launch_transport_scalars3(g, m, w + o, q_con + o, pt + o, crx + o, cry + o, xfx + o, yfx + o, W.fx + o, W.fy + o, nl, dpw, dp, dp2, st);
+      if (rc == PACE_OK) done3 = true;
+      else if (rc != PACE_ERR_UNSUPPORTED) return rc;
+    }
+    bool used_side = false;
+    if (!done3) {
     hipStream_t st_w = st, st_q = st;
 #ifndef PACE_EMU
     DswSide* side = (kstep == nk) ? dsw_side() : nullptr;
@@ -1209,17 +1229,10 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
       for (int n = 0; n < 2; ++n) (void)hipStreamWaitEvent(side->s[n], side->fork, 0);
       st_w = side->s[0];
       st_q = side->s[1];
+      used_side = true;
     }
 #endif
-    if ((rc = launch_transport(g, m, w + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_vt, nl, 0, 2, dp, st_w))) return rc;
-    // q_con -> W.gy
-    dp = FvDamp{};
-    dp.damp_k = d_dampfac_t + k0; dp.nord_k = d_nord_t + k0; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp + o;
-    dp.qout = W.gy + o; dp.amass = delp + o;
-    // pt -> W.fx2
-    FvDamp dp2 = dp;
-    dp2.damp_k = d_dampfac_vt + k0; dp2.nord_k = d_nord_v + k0; dp2.nmax = nmax_v; dp2.qout = W.fx2 + o;
-    static const bool pair = getenv("PACE_DSW_PAIR") != nullptr;  // experiment: both in one launch (k_fvtp2d_pair)
+    if ((rc = launch_transport(g, m, w + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_vt, nl, 0, 2, dpw, st_w))) return rc;
     // the two halves of a pair must pass the same barriers: pair the levels from which on the damping orders of the two agree
     // (the sponge levels on top differ in the baseline namelist), the levels above them one scalar at a time
     int kp = nl;
@@ -1242,13 +1255,17 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     }
     }
 #ifndef PACE_EMU
-    if (DswSide* side = (kstep == nk) ? dsw_side() : nullptr) {
+    if (used_side) {
+      DswSide* side = dsw_side();
       for (int n = 0; n < 2; ++n) {
         (void)hipEventRecord(side->join[n], side->s[n]);
         (void)hipStreamWaitEvent(st, side->join[n], 0);
       }
     }
+#else
+    (void)used_side;
 #endif
+    }
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   }

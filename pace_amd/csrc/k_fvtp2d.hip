@@ -215,14 +215,13 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
                                             const real* __restrict__ xfx, const real* __restrict__ yfx,
                                             real* __restrict__ fx, real* __restrict__ fy,
                                             const real* __restrict__ xunit, const real* __restrict__ yunit,
-                                            const FvDamp& dp) {
+                                            const FvDamp& dp, const TileId wg) {
   auto& sq = L.sq;
   auto& syin = L.syin;
   auto& sqi = L.sqi;
   auto& sxin = L.sxin;
 
   const int tid = threadIdx.x & 255;  // (k_fvtp2d_pair runs two scalars in one workgroup of 512 threads)
-  const TileId wg = tile_of_workgroup();
   const int i0 = g.is + wg.bx * TI;
   const int j0 = g.js + wg.by * TJ;
   const int k = wg.bz;
@@ -833,10 +832,46 @@ __global__ void __launch_bounds__(256, FV_WAVES) k_fvtp2d(Geo g, FvMet m, const 
   // (ord 8: the special CELLS are s-1 .. s+1 and e-1 .. e+1; the cells evaluated are i0-1 .. i0+TI -- the same test)
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
-  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
-  else fvtp2d_tile<MORD, false, false, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp);
+  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg);
+  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg);
+  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg);
+  else fvtp2d_tile<MORD, false, false, DMODE, EPI, CANON>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg);
+}
+
+// d_sw's three mass-weighted scalars -- w (damping fluxes + heat_diss: DMODE 0, EPI 2), q_con and pt (mass-weighted damping:
+// DMODE 2, EPI 1) -- in ONE launch (round 3): the grid is three tile planes high, a workgroup's plane says which scalar it
+// transports.  The three read the same Courant numbers, area fluxes and mass fluxes level by level (a level belongs to one XCD:
+// tile_of_workgroup), their workgroups fill each other's partly filled rounds, and nothing has to fork to side streams and
+// join again before k_finish_scalars.  The instances are the stand-alone kernels' (same code, same results).
+template <int MORD, bool CANON>
+__global__ void __launch_bounds__(256, FV_WAVES) k_fvtp2d_scalars3(Geo g, FvMet m, const real* __restrict__ crx, const real* __restrict__ cry,
+                                                                const real* __restrict__ xfx, const real* __restrict__ yfx,
+                                                                const real* __restrict__ xunit, const real* __restrict__ yunit,
+                                                                const real* __restrict__ q0, FvDamp dp0, const real* __restrict__ q1,
+                                                                FvDamp dp1, const real* __restrict__ q2, FvDamp dp2, int gy) {
+  constexpr size_t kBytes = sizeof(FvLds<0, 2>) > sizeof(FvLds<2, 1>) ? sizeof(FvLds<0, 2>) : sizeof(FvLds<2, 1>);
+  __shared__ double raw[(kBytes + 7) / 8];
+  TileId wg = tile_of_workgroup();
+  const int which = wg.by / gy;  // block-uniform
+  wg.by -= which * gy;
+  const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
+  const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
+  const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
+  if (which == 0) {
+    FvLds<0, 2>& L = *reinterpret_cast<FvLds<0, 2>*>(raw);
+    if (ex && ey) fvtp2d_tile<MORD, true, true, 0, 2, CANON>(L, g, m, q0, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp0, wg);
+    else if (ex) fvtp2d_tile<MORD, true, false, 0, 2, CANON>(L, g, m, q0, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp0, wg);
+    else if (ey) fvtp2d_tile<MORD, false, true, 0, 2, CANON>(L, g, m, q0, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp0, wg);
+    else fvtp2d_tile<MORD, false, false, 0, 2, CANON>(L, g, m, q0, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp0, wg);
+  } else {
+    FvLds<2, 1>& L = *reinterpret_cast<FvLds<2, 1>*>(raw);
+    const real* q = which == 1 ? q1 : q2;
+    const FvDamp& dp = which == 1 ? dp1 : dp2;
+    if (ex && ey) fvtp2d_tile<MORD, true, true, 2, 1, CANON>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
+    else if (ex) fvtp2d_tile<MORD, true, false, 2, 1, CANON>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
+    else if (ey) fvtp2d_tile<MORD, false, true, 2, 1, CANON>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
+    else fvtp2d_tile<MORD, false, false, 2, 1, CANON>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
+  }
 }
 
 // whether every edge tile of the launch holds its edge at the canonical place: N a multiple of the tile in both directions,
@@ -865,10 +900,10 @@ __global__ void __launch_bounds__(512, 4) k_fvtp2d_pair(Geo g, FvMet m, const re
   const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
   const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
-  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
-  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
-  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
-  else fvtp2d_tile<MORD, false, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp);
+  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
+  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
+  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
+  else fvtp2d_tile<MORD, false, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
 }
 
 int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real* qb, const real* crx, const real* cry,
@@ -880,6 +915,27 @@ int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real
 #else
   const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
   hipLaunchKernelGGL((k_fvtp2d_pair<6, 2, 1>), grid, dim3(512), 0, st, g, fv_met(m), qa, qb, crx, cry, xfx, yfx, xmf, ymf, dpa, dpb);
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+#endif
+}
+
+// w, q_con and pt of d_sw in one launch (k_fvtp2d_scalars3); ord 6 for all three, damping orders <= 2
+int launch_transport_scalars3(const Geo& g, const Met& m, const real* w, const real* q_con, const real* pt, const real* crx,
+                              const real* cry, const real* xfx, const real* yfx, const real* xmf, const real* ymf, int nlev,
+                              const FvDamp& dpw, const FvDamp& dpq, const FvDamp& dpt, hipStream_t st) {
+  if (dpw.nmax > 2 || dpq.nmax > 2 || dpt.nmax > 2) return PACE_ERR_UNSUPPORTED;
+#if defined(FV_ONLY_621) || defined(FV_ONLY_EPI0)
+  return PACE_ERR_UNSUPPORTED;
+#else
+  const int gy = (g.n + TJ - 1) / TJ;
+  const dim3 grid((g.n + TI - 1) / TI, 3 * gy, nlev);
+  if (fv_canonical_tiling(g))
+    hipLaunchKernelGGL((k_fvtp2d_scalars3<6, true>), grid, dim3(256), 0, st, g, fv_met(m), crx, cry, xfx, yfx, xmf, ymf, w, dpw, q_con, dpq, pt,
+                       dpt, gy);
+  else
+    hipLaunchKernelGGL((k_fvtp2d_scalars3<6, false>), grid, dim3(256), 0, st, g, fv_met(m), crx, cry, xfx, yfx, xmf, ymf, w, dpw, q_con, dpq, pt,
+                       dpt, gy);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 #endif

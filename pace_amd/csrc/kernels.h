@@ -49,6 +49,9 @@ struct FvDamp {
 int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
                      const real* yfx, real* fx, real* fy, const real* xmf, const real* ymf, int hord, int nlev,
                      int dmode, int epi, const FvDamp& dp, hipStream_t st);
+int launch_transport_scalars3(const Geo& g, const Met& m, const real* w, const real* q_con, const real* pt, const real* crx,
+                              const real* cry, const real* xfx, const real* yfx, const real* xmf, const real* ymf, int nlev,
+                              const FvDamp& dpw, const FvDamp& dpq, const FvDamp& dpt, hipStream_t st);
 // experiment: two scalars (DMODE 2, EPI 1, ord 6) in one workgroup of 512 threads
 int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real* qb, const real* crx, const real* cry,
                           const real* xfx, const real* yfx, const real* xmf, const real* ymf, int hord, int nlev,
