@@ -649,6 +649,8 @@ def main():
                 "measured_copy_GBs": copy_gbs,
                 "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                 "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo,
+                "where_in_the_step": "the transport family is five of the step's launches; this instance -- launched alone here, one scalar -- is "
+                                     "the one two of the three tile planes of k_fvtp2d_scalars3 (w, q_con, pt in one launch) run inside the step",
                 "limited_by": "chains of dependent stages (LDS round trips, global-load waits, barriers) at 4 waves per SIMD with the "
                               "instruction issue of a SIMD ~saturated by its four waves (DESIGN.md section 4.0, round 3 ablations); "
                               "the roofline that prices it is HBM"}
