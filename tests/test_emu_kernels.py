@@ -136,6 +136,45 @@ def test_legacy_thread_per_column_solvers_emulated(precision):
         assert e < tol, (k, e, errs)
 
 
+def _dsw_child():
+    """(child process: PACE_DSW_FUSED3 is read once per process) d_sw on the synthetic tile, all outputs pickled."""
+    import pickle
+    import sys
+
+    from pace_amd import _lib, synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import column_namelist_arrays
+
+    n, nz = 16, 6
+    lib = _lib.Library(build_emu())
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, "cpu", m, n, nz)
+    col = column_namelist_arrays(DGridShallowWaterLagrangianDynamicsConfig(), nz)
+    out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, float(s["dt"]))
+    pickle.dump({k: np.ascontiguousarray(v) for k, v in out.items()}, sys.stdout.buffer)
+
+
+def test_d_sw_three_scalar_launch_equals_three_launches_emulated():
+    """w, q_con and pt in one launch (k_fvtp2d_scalars3, the default) against the three separate launches
+    (PACE_DSW_FUSED3=0: the fall-back for orders other than 6): every output of d_sw bit for bit."""
+    import pickle
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
+            f"import test_emu_kernels as t; t._dsw_child()")
+    outs = []
+    for fused in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=900, env=dict(os.environ, PACE_DSW_FUSED3=fused))
+        assert p.returncode == 0, p.stderr[-3000:].decode()
+        outs.append(pickle.loads(p.stdout))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
 def test_fvtp2d_kernel_emulated(emu_lib):
     from pace_amd.fv3core.stencils.fvtp2d import FiniteVolumeTransport
 
