@@ -196,6 +196,19 @@ int pace_d_sw_phases(int phases, const pace_geom_t* geom, const pace_metrics_t* 
                      pace_real_t* cry, pace_real_t* xfx, pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh,
                      pace_real_t* heat_source, pace_real_t* diss_est, double dt, void* stream);
 
+/* The same four phases in ONE call, the wind half on `side_stream` (prep: 1 = the whole flux preparation, 32 = its frame after
+ * phases 16): flux preparation and scalars on `stream`, winds A on the side stream after the preparation, winds B there after the
+ * scalars.  The three events are the caller's (hipEvent_t; e.g. torch.cuda.Event.cuda_event); ev_done is recorded on the side
+ * stream at the end -- the caller's stream must wait for it before u, v, uc, vc, heat_source, diss_est, delpc or divgd are used. */
+int pace_d_sw_overlapped(int prep, const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
+                     const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp,
+                     pace_real_t* pt, pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc,
+                     pace_real_t* vc, const pace_real_t* ua, const pace_real_t* va, pace_real_t* divgd,
+                     pace_real_t* mfx, pace_real_t* mfy, pace_real_t* cx, pace_real_t* cy, pace_real_t* crx,
+                     pace_real_t* cry, pace_real_t* xfx, pace_real_t* yfx, pace_real_t* q_con, const pace_real_t* zh,
+                     pace_real_t* heat_source, pace_real_t* diss_est, double dt, void* stream,
+                         void* side_stream, void* ev_prep, void* ev_scalars, void* ev_done);
+
 /* ---- NonhydrostaticVerticalSolver.__call__ (riem_solver3.py:208-321), compute domain.
  * zs, ws: 2-D.  workspace: pace_riem_solver3_workspace_bytes() bytes of DEVICE scratch. */
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom);

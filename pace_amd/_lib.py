@@ -89,6 +89,8 @@ _PROTOS = {
     "pace_d_sw_transport": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_winds": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_phases": (C.c_int, [C.c_int, _P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
+    "pace_d_sw_overlapped": (C.c_int, [C.c_int, _P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23
+                             + [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pace_riem_solver3_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_riem_solver3": (
         C.c_int,
@@ -180,7 +182,8 @@ class Library:
     def call(self, name, *args):
         end = None
         if self.timing is not None:
-            last = args[-1] if args else None  # every entry point's last argument is its stream
+            # every entry point's last argument is its stream (pace_d_sw_overlapped: followed by the side stream and three events)
+            last = (args[-5] if name == "pace_d_sw_overlapped" else args[-1]) if args else None
             ptr = getattr(last, "value", None) if isinstance(last, C.c_void_p) else None
             end = self.timing.bracket(name, ptr)
         if self._trace:

@@ -184,6 +184,37 @@ int pace_d_sw_phases(int phases, DSW_PARAMS) {
   return d_sw_entry(phases, DSW_ARGS_);
 }
 
+// d_sw with its wind half on a second stream, in ONE call (the host layer used to make four calls and three event operations
+// per d_sw; the host time per substep, 105 - 120 us, is the runtime's launches and did not change).  `prep`: 1 = the whole flux preparation, 32 = its frame (the interior was
+// started with phases 16).  Events: the caller's (e.g. torch.cuda.Event.cuda_event), recorded here; afterwards the caller makes
+// its stream wait for ev_done before it touches u, v, uc, vc, heat_source, diss_est, delpc or divgd (pace_amd ... d_sw.py join()).
+int pace_d_sw_overlapped(int prep, DSW_PARAMS, void* side_stream, void* ev_prep, void* ev_scalars, void* ev_done) {
+#ifdef PACE_EMU
+  (void)prep; (void)side_stream; (void)ev_prep; (void)ev_scalars; (void)ev_done;
+  return d_sw_entry(15, DSW_ARGS_);
+#else
+  NEED(side_stream && ev_prep && ev_scalars && ev_done);
+  if (prep != 1 && prep != 32) return PACE_ERR_ARG;
+  hipStream_t main_s = S(stream), side_s = S(side_stream);
+  hipEvent_t e_prep = (hipEvent_t)ev_prep, e_scal = (hipEvent_t)ev_scalars, e_done = (hipEvent_t)ev_done;
+  int rc;
+  if ((rc = d_sw_entry(prep, DSW_ARGS_))) return rc;  // flux preparation on the caller's stream
+  if (hipEventRecord(e_prep, main_s) != hipSuccess || hipStreamWaitEvent(side_s, e_prep, 0) != hipSuccess) return PACE_ERR_LAUNCH;
+  {
+    void* stream = side_stream;  // winds A next to the scalar transports
+    if ((rc = d_sw_entry(4, DSW_ARGS_))) return rc;
+  }
+  if ((rc = d_sw_entry(2, DSW_ARGS_))) return rc;  // the scalars on the caller's stream
+  if (hipEventRecord(e_scal, main_s) != hipSuccess || hipStreamWaitEvent(side_s, e_scal, 0) != hipSuccess) return PACE_ERR_LAUNCH;
+  {
+    void* stream = side_stream;  // winds B (they need the new delp) next to whatever the caller launches next
+    if ((rc = d_sw_entry(8, DSW_ARGS_))) return rc;
+  }
+  if (hipEventRecord(e_done, side_s) != hipSuccess) return PACE_ERR_LAUNCH;
+  return PACE_OK;
+#endif
+}
+
 int64_t pace_riem_solver3_workspace_bytes(const pace_geom_t* geom) {
   return geom ? riem3_workspace_bytes(make_geo(geom)) : 0;
 }

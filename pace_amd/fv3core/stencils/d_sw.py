@@ -161,15 +161,14 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         if not os.environ.get("PACE_DSW_LATE_WINDS"):
             # (Round 3, rejected: kinetic energy + vorticity started already after the first half of the flux preparation,
             # next to its streaming second half: 1.160 ms against 1.141 ms, four alternating runs -- profiles/r03_experiments/x14.)
-            phases(prep, self.stream())
-            self._ev_prep.record(main)
-            side.wait_event(self._ev_prep)
-            phases(4, side_ptr)
-            phases(2, self.stream())
-            self._ev_scalars.record(main)
-            side.wait_event(self._ev_scalars)
-            phases(8, side_ptr)
-            self._done.record(side)
+            # One call does the choreography (flux preparation, event, winds A on the side stream, scalars, event, winds B on the
+            # side stream, event) instead of four calls and three event operations from here.  (The host's 105 - 120 us per
+            # substep did not change with it: they are the runtime's dozen kernel launches, not this layer.)
+            if self._ev_handles is None:
+                for e in (self._ev_prep, self._ev_scalars, self._done):
+                    e.record(main)  # (torch creates the underlying event at its first record)
+                self._ev_handles = tuple(C.c_void_p(e.cuda_event) for e in (self._ev_prep, self._ev_scalars, self._done))
+            self.lib.call("pace_d_sw_overlapped", prep, C.byref(self._geom), *args, self.stream(), side_ptr, *self._ev_handles)
             self._pending = True
             return
         phases(prep | 2, self.stream())  # flux preparation + scalar transport on the calling stream
@@ -180,6 +179,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         self._pending = True
 
     _side = None
+    _ev_handles = None
     _pending = False
 
     def join(self):
