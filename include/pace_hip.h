@@ -414,7 +414,9 @@ int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, 
  *   PACE_ST_FILL_CORNERS_DGRID          corners.py:987-1151  fields x_in, x_out, y_in, y_out; scalars mysign
  *   PACE_ST_FILL_CORNERS_2CELLS_X / _Y  corners.py:170-177   fields q_out, q_in
  *   PACE_ST_XTP_U / _YTP_V   translate_xtp_u.py:13-23 / translate_ytp_v.py (xtp_u.py:9-91, ytp_v.py:9-91)
- *                            fields c (contravariant corner wind x dt), u (v), flux; scalars iord (5, 6 or 7) */
+ *                            fields c (contravariant corner wind x dt), u (v), flux; scalars iord (5, 6 or 7)
+ *   PACE_ST_MOIST_PT_LAST_STEP  moist_cv.py:84-118 (nwat = 6)  fields qvapor, qliquid, qrain, qsnow, qice, qgraupel, gz, pt, pkz;
+ *                            scalars dtmp, r_vir */
 enum {
   PACE_ST_FLUX_CAPACITOR = 1,
   PACE_ST_HEAT_DISS = 2,
@@ -429,7 +431,8 @@ enum {
   PACE_ST_FILL_CORNERS_2CELLS_X = 11,
   PACE_ST_FILL_CORNERS_2CELLS_Y = 12,
   PACE_ST_XTP_U = 13,
-  PACE_ST_YTP_V = 14
+  PACE_ST_YTP_V = 14,
+  PACE_ST_MOIST_PT_LAST_STEP = 15
 };
 int pace_stencil(const pace_geom_t* geom, const pace_metrics_t* met, int id, void* const* fields, int nfields, const double* scalars,
                  int nscalars, const int* origin, const int* domain, void* stream);

@@ -102,6 +102,17 @@ __global__ void k_st_xtp(Geo g, Met m, Win w, const real* c_dt, const real* u, r
   flux[c] = wind_flux6<MORD>(q6, ub, cfl, pos, s0, e0, [=](int p) { return (double)sp[(long)p * d]; }, zero(pos - 1), zero(pos));
 }
 
+// moist_pt_last_step (fv3core/pace/fv3core/stencils/moist_cv.py:84-118, nwat = 6): gz = the condensate, pt back to the (virtual)
+// temperature with the heating of the last remapping step
+__global__ void k_st_moist_pt_last_step(Geo g, Win w, const real* qv, const real* ql, const real* qr, const real* qs, const real* qi,
+                                        const real* qg, real* gz, real* pt, const real* pkz, double dtmp, double r_vir) {
+  WIN_IJK(w);
+  const long c = IDX3(g, i, j, k);
+  const double cond = ql[c] + qr[c] + qi[c] + qs[c] + qg[c];
+  gz[c] = cond;
+  pt[c] = (pt[c] + dtmp * pkz[c]) / ((1.0 + r_vir * qv[c]) * (1.0 - cond));
+}
+
 // ---- corner fills: one thread per destination cell of the four 3 x 3 (A-grid) / (B-grid: see below) corner blocks ----
 __device__ __forceinline__ void remap_bgrid(const Geo& g, int dir, int& i, int& j) {  // corners.py:591-712 (oracle/corner_ops.py)
   const bool w_ = i < g.is, e_ = i > g.ie + 1, s_ = j < g.js, n_ = j > g.je + 1;
@@ -255,6 +266,11 @@ int launch_stencil(const Geo& g, const Met& m, int id, void* const* f, int nf, c
       else hipLaunchKernelGGL((k_st_xtp<1, 6>), win_grid(w), blk, 0, st, g, m, w, F(0), F(1), F(2));
       break;
     }
+    case PACE_ST_MOIST_PT_LAST_STEP:
+      if (nf != 9 || ns != 2) return PACE_ERR_ARG;
+      hipLaunchKernelGGL(k_st_moist_pt_last_step, win_grid(w), blk, 0, st, g, w, F(0), F(1), F(2), F(3), F(4), F(5), F(6), F(7), F(8), sc[0],
+                         sc[1]);
+      break;
     default:
       return PACE_ERR_UNSUPPORTED;
   }

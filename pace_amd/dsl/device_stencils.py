@@ -171,7 +171,7 @@ _register(_both("yppm", "compute_y_flux"), *_ppm(1))
 ST_FLUX_CAPACITOR, ST_HEAT_DISS, ST_APPLY_FLUXES, ST_UBKE, ST_VBKE = 1, 2, 3, 4, 5
 ST_COPY_CORNERS_X, ST_COPY_CORNERS_Y, ST_FILL_CORNERS_BGRID_X, ST_FILL_CORNERS_BGRID_Y = 6, 7, 8, 9
 ST_FILL_CORNERS_DGRID, ST_FILL_CORNERS_2CELLS_X, ST_FILL_CORNERS_2CELLS_Y = 10, 11, 12
-ST_XTP_U, ST_YTP_V = 13, 14
+ST_XTP_U, ST_YTP_V, ST_MOIST_PT_LAST_STEP = 13, 14, 15
 
 
 def _origin(st):
@@ -246,3 +246,9 @@ _register(("pace_amd.fv3core.stencils.xtp_u.xtp_u_stencil_defn",), _xtp_check,
 _register(("pace_amd.fv3core.stencils.ytp_v.ytp_v_stencil_defn",), _xtp_check,
           lambda st, vb_contra_times_dt, v, updated_v, dy, dya, rdy: _call_stencil(
               st, ST_YTP_V, [vb_contra_times_dt, v, updated_v], [int(st.externals["iord"])], metrics_from=[dy, dya, rdy]))
+
+
+# moist_pt_last_step (moist_cv.py:84-118; translate_last_step.py:16 launches it as a stencil of its own)
+_register(_both("moist_cv", "moist_pt_last_step"), _no_check,
+          lambda st, qvapor, qliquid, qrain, qsnow, qice, qgraupel, gz, pt, pkz, dtmp, r_vir: _call_stencil(
+              st, ST_MOIST_PT_LAST_STEP, [qvapor, qliquid, qrain, qsnow, qice, qgraupel, gz, pt, pkz], [dtmp, r_vir]))

@@ -124,6 +124,19 @@ def run_all(lib, device):
             assert np.array_equal(out.numpy()[B], ref[B]), (name, iord)
             assert not out.numpy()[2].any() and not out.numpy()[:, 2].any(), "written outside the window"
 
+    # moist_pt_last_step: compute domain (translate_last_step.py:16)
+    names = "qvapor qliquid qrain qsnow qice qgraupel gz pt pkz".split()
+    a = {k: np.abs(_rand(rng)) * (0.01 if k.startswith("q") else 1.0) + (200.0 if k == "pt" else 0.0) for k in names}
+    q = {k: env.q3(v) for k, v in a.items()}
+    st = sf.from_origin_domain(_defn("pace.fv3core.stencils.moist_cv", "moist_pt_last_step", names + ["dtmp", "r_vir"]),
+                               origin=gi.origin_compute(), domain=gi.domain_compute())
+    dtmp, r_vir = 0.37, 0.6078
+    st(*[q[k] for k in names], dtmp, r_vir)
+    cond = a["qliquid"] + a["qrain"] + a["qice"] + a["qsnow"] + a["qgraupel"]
+    ptn = (a["pt"] + dtmp * a["pkz"]) / ((1.0 + r_vir * a["qvapor"]) * (1.0 - cond))
+    assert np.array_equal(q["gz"].numpy()[W], cond[W]) and np.array_equal(q["pt"].numpy()[W], ptn[W])
+    assert np.array_equal(q["pt"].numpy()[0], a["pt"][0]), "written outside the window"
+
     # corner fills: full domain (translate_corners.py)
     from oracle import corner_ops as co
 
