@@ -172,6 +172,13 @@ class FrozenStencil:
             raise ValueError(f"expected 3d index, received {origin}")
         if len(domain) != 3:
             raise ValueError(f"expected 3d index, received {domain}")
+        if getattr(stencil_config, "compare_to_numpy", False):
+            # The reference runs every stencil a second time on its numpy backend and compares (stencil.py:166-234).  There is no
+            # second backend here -- the kernels are checked against the numpy oracle and, bit for bit, through the emulation
+            # build in tests/ -- so the request is refused rather than silently ignored.
+            raise NotImplementedError(
+                "StencilConfig.compare_to_numpy: pace_amd has no numpy backend to compare with at run time; the device kernels are "
+                "compared with the numpy oracle in tests/ (python -m pytest tests -m gpu) and with their own CPU emulation (make emu)")
         self.origin = origin
         self.domain = tuple(domain)
         self.stencil_config = stencil_config

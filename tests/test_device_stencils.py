@@ -189,6 +189,22 @@ def test_unregistered_definition_is_refused():
                                                origin=env.grid_indexing.origin_compute(), domain=env.grid_indexing.domain_compute())
 
 
+def test_compare_to_numpy_is_refused_not_ignored():
+    """dsl/pace/dsl/stencil.py:166-234: the reference's compare-to-numpy mode has no counterpart at run time here; asking for it
+    raises at construction instead of being dropped silently."""
+    import copy
+
+    from pace_amd import _lib
+
+    env, _ = _env(_lib.Library(build_emu()), "cpu")
+    cfg = copy.copy(env.stencil_factory.config)
+    cfg.compare_to_numpy = True
+    from pace_amd.dsl.stencil import FrozenStencil
+
+    with pytest.raises(NotImplementedError, match="compare_to_numpy"):
+        FrozenStencil(_defn("pace.fv3core.stencils.d_sw", "flux_capacitor", ["cx"]), (0, 0, 0), (1, 1, 1), cfg, factory=env.stencil_factory)
+
+
 def test_device_stencils_emulated():
     from pace_amd import _lib
 
