@@ -506,9 +506,13 @@ def main():
         # the wind half of d_sw runs on a side stream, concurrently with the (latency-bound) column solver
         dsw(*args, dt, overlap_winds=True)
         if exchange is not None:
-            exchange.update([b["delp"], b["pt"], b["q_con"]])
+            # delp / pt / q_con travel while the column solver runs: it works on the compute domain's columns only (the halos are
+            # needed by what follows it -- pk3_halo, nh_p_grad, the next substep's c_sw; dyn_core.py:854 updates them right here)
+            exchange.start([b["delp"], b["pt"], b["q_con"]])
         riem(False, dt, b["cappa"], ptop, zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"], b["ppe"], b["pk3"],
              b["pk"], b["peln"], b["w"])
+        if exchange is not None:
+            exchange.wait()
         dsw.join()
 
     def barrier():
@@ -560,7 +564,7 @@ def main():
     if exchange is not None:
         arm("phase diagnosis")
         names = ["uc_vc_start(pack+post)", "flux_prep_interior", "uc_vc_wait(+unpack)", "d_sw_rest", "delp_pt_qcon_start(pack+post)",
-                 "delp_pt_qcon_wait(+unpack)", "riem_solver3"]
+                 "riem_solver3", "delp_pt_qcon_wait(+unpack)"]
         acc = np.zeros(len(names))
         nd = min(3, nbatch)
         for i in range(nd):
@@ -578,9 +582,9 @@ def main():
             exchange_winds.wait(); mark()
             dsw(*a_, dt, overlap_winds=True); dsw.join(); mark()
             exchange.start([b["delp"], b["pt"], b["q_con"]]); mark()
-            exchange.wait(); mark()
             riem(False, dt, b["cappa"], ptop, zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"], b["ppe"], b["pk3"],
                  b["pk"], b["peln"], b["w"]); mark()
+            exchange.wait(); mark()
             acc += np.diff(marks)
         import torch.distributed as dist
 

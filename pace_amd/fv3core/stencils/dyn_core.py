@@ -285,13 +285,21 @@ class AcousticDynamics(Operator):
             self._checkpoint_dsw_in(state)
             self.dgrid_shallow_water_lagrangian_dynamics(*dsw_args, overlap_winds=True)
             self._checkpoint_dsw_out(state)
-            halo.delp__pt__q_con.update()
+            # dyn_core.py:854 updates the halos of delp / pt / q_con right here.  Nothing before pk3_halo reads them (updatedzd works
+            # on zh and the Courant numbers, the column solver on the compute domain's columns), so without checkpoints the
+            # exchange is only POSTED here and waited for after the column solver -- it travels while the two run.
+            if early:
+                halo.delp__pt__q_con.start()
+            else:
+                halo.delp__pt__q_con.update()
             self.update_height_on_d_grid(surface_height=self._zs, height=self._zh, courant_number_x=self._crx,
                                          courant_number_y=self._cry, x_area_flux=self._xfx, y_area_flux=self._yfx, ws=self._wsd,
                                          dt=dt_acoustic_substep)
             self.vertical_solver(remap_step, dt_acoustic_substep, self.cappa, self._ptop, self._zs, self._wsd, state.delz,
                                  state.q_con, state.delp, state.pt, self._zh, state.pe, self._pkc, self._pk3, state.pk, state.peln,
                                  state.w)
+            if early:
+                halo.delp__pt__q_con.wait()
             halo.zh.start()
             halo.pkc.start()
             if remap_step:

@@ -401,7 +401,7 @@ def test_bench_six_ranks_dry_run_over_gloo(tmp_path):
     assert p.returncode == 0, p.stderr[-3000:]
     # the ORDER of a step on every rank (the entry points named on stderr): the winds' halo is packed and posted, the interior of
     # the flux preparation (phases 16) is launched BEFORE the wait / unpack, the rest of d_sw (a mask with 32) after it, then the
-    # exchange of delp / pt / q_con, then the column solver
+    # exchange of delp / pt / q_con is posted, the column solver (compute domain only) runs, and only then is it waited for
     for rank in range(6):
         calls = [ln.split("] ", 1)[1] for ln in p.stderr.splitlines() if ln.startswith(f"[pace r{rank}] ")]
         seq = [c for c in calls if c.startswith(("pace_halo_pack", "pace_halo_unpack", "pace_d_sw_phases", "pace_riem_solver3"))]
@@ -409,7 +409,7 @@ def test_bench_six_ranks_dry_run_over_gloo(tmp_path):
         for n in range(len(seq) - 6):
             w = seq[n:n + 7]
             if (w[0] == "pace_halo_pack" and w[1] == "pace_d_sw_phases 16" and w[2] == "pace_halo_unpack" and w[3].startswith("pace_d_sw_phases ")
-                    and int(w[3].split()[1]) & 32 and w[4] == "pace_halo_pack" and w[5] == "pace_halo_unpack" and w[6].startswith("pace_riem_solver3")):
+                    and int(w[3].split()[1]) & 32 and w[4] == "pace_halo_pack" and w[5].startswith("pace_riem_solver3") and w[6] == "pace_halo_unpack"):
                 steps += 1
         assert steps >= 3, (rank, seq[:24])  # warm-up + two timed steps (+ the synchronised diagnosis pass)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
