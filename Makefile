@@ -3,8 +3,8 @@
 # tests/emu/README.md).
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC := pace_amd/csrc
-SRCS := $(CSRC)/capi.hip $(CSRC)/k_fxadv.hip $(CSRC)/k_fvtp2d.hip $(CSRC)/k_delnflux.hip $(CSRC)/k_dsw.hip $(CSRC)/k_riem3.hip $(CSRC)/k_riem3f.hip $(CSRC)/k_sim1.hip $(CSRC)/k_ppm.hip $(CSRC)/k_csw.hip $(CSRC)/k_acoustic.hip $(CSRC)/k_halo.hip $(CSRC)/k_tracer.hip $(CSRC)/k_remap.hip $(CSRC)/k_l2e.hip $(CSRC)/k_dycore.hip $(CSRC)/k_stencils.hip
-HDRS := $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/delnflux_core.h include/pace_hip.h
+SRCS := $(CSRC)/capi.hip $(CSRC)/k_fxadv.hip $(CSRC)/k_fvtp2d.hip $(CSRC)/k_fvt.hip $(CSRC)/k_delnflux.hip $(CSRC)/k_dsw.hip $(CSRC)/k_riem3.hip $(CSRC)/k_riem3f.hip $(CSRC)/k_sim1.hip $(CSRC)/k_ppm.hip $(CSRC)/k_csw.hip $(CSRC)/k_acoustic.hip $(CSRC)/k_halo.hip $(CSRC)/k_tracer.hip $(CSRC)/k_remap.hip $(CSRC)/k_l2e.hip $(CSRC)/k_dycore.hip $(CSRC)/k_stencils.hip
+HDRS := $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/delnflux_core.h $(CSRC)/fvt_core.h include/pace_hip.h
 # -ffp-contract=off: no FMA contraction, so horizontal stencils are bit-comparable with the numpy oracle.
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 OBJS := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
@@ -75,16 +75,7 @@ emu-canon: tests/emu/libpace_emu_canon.so
 tests/emu/libpace_emu_canon.so: $(CANONOBJS) build/emu/hip_emu.o
 	g++ -shared -fPIC $(CANONOBJS) build/emu/hip_emu.o -o $@
 
-# experiments only: the library with the transport kernel's stage-time instrumentation (tools/fv_stage_times.py)
-PROFOBJS := $(patsubst $(CSRC)/%.hip,build/prof/%.o,$(SRCS))
-build/prof/%.o: $(CSRC)/%.hip $(HDRS)
-	@mkdir -p build/prof
-	$(HIPCC) $(HIPFLAGS) -DFV_PROF -c $< -o $@
-prof: build/prof/libpace_prof.so
-build/prof/libpace_prof.so: $(PROFOBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(PROFOBJS) -o $@
-
 clean:
 	rm -rf build pace_amd/libpace_hip.so pace_amd/libpace_hip_f32.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so tests/emu/libpace_emu_f32.so tests/emu/libpace_emu_canon.so
 
-.PHONY: all f32 emu emu-f32 emu-small emu-canon prof clean
+.PHONY: all f32 emu emu-f32 emu-small emu-canon clean

@@ -282,11 +282,6 @@ __device__ __forceinline__ void ppm_run_p(const double* Q, const double* c, int 
     ppm_run8_p<EDGE, F>(Q, c, pos0, s, e, sp, out);
     return;
   }
-#ifdef FV_X_NOPPM
-#pragma unroll
-  for (int f = 0; f < F; ++f) out[f] = (c[f] > 0.0) ? Q[f + 2] : Q[f + 3];
-  return;
-#endif
   double al[F + 2];
 #pragma unroll
   for (int a = 0; a < F + 2; ++a) al[a] = EDGE ? ppm_al_p(Q, a + 2, pos0 - 1 + a, s, e, sp) : ppm_al_interior(Q, a + 2);

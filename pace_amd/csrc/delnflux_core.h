@@ -20,7 +20,7 @@
 // three metric values are worked out once, so an iteration is LDS reads and a handful of flops.
 __device__ __forceinline__ void delnflux_core(const Geo& g, const Met& m, const double* src, double* sd, double* sfx,
                                               double* sfy, int i0, int j0, double d0, bool hi_order, int nmax) {
-  const int tid = threadIdx.x & 255;  // (256 threads per tile; k_fvtp2d_pair has two tiles per workgroup)
+  const int tid = threadIdx.x;
   const int ilo = i0 - 3, jlo = j0 - 3;
   // the corner-copy index maps only matter to workgroups whose footprint reaches a corner of the halo (block-uniform)
   const bool rc = hi_order && (ilo < g.is || ilo + DW - 1 > g.ie) && (jlo < g.js || jlo + DH - 1 > g.je);
@@ -154,7 +154,7 @@ __device__ __forceinline__ unsigned deln_off(const Geo& g, int i, int j) {  // b
 // staging q covers them.  All 256 threads.
 template <class MT>
 __device__ __forceinline__ void deln_stage_metrics(const Geo& g, const MT& m, double* sdv, double* sdu, int i0, int j0) {
-  const int tid = threadIdx.x & 255;
+  const int tid = threadIdx.x;
   double v[DN_NE], u[DN_NE];
 #pragma unroll
   for (int t = 0; t < DN_NE; ++t) {
@@ -178,7 +178,7 @@ __device__ __forceinline__ void deln_stage_metrics(const Geo& g, const MT& m, do
 // rarea of this thread's run (global loads: issue early, the first pass consumes them) and the validity of its cells
 template <class MT>
 __device__ __forceinline__ void deln_load(const Geo& g, const MT& m, int i0, int j0, DelnMet& M) {
-  const int tid = threadIdx.x & 255;
+  const int tid = threadIdx.x;
   const int ilo = i0 - 3, jlo = j0 - 3;
   M.active = tid < DW * DN_NR;
   const int r = tid / DW;
@@ -193,6 +193,62 @@ __device__ __forceinline__ void deln_load(const Geo& g, const MT& m, int i0, int
   }
 }
 
+// the run part of a pass: res[t] = divergence at cell (c, r0 + t) of the fluxes of src (zero where the cell is not valid)
+template <bool FIRST>
+__device__ __forceinline__ void deln_run(const DelnMet& M, const double* src, const double* __restrict__ sdv,
+                                         const double* __restrict__ sdu, double d0, double* res) {
+  auto val = [&](double x) { return FIRST ? d0 * x : x; };  // (d0 * x: the reference's first statement, d2 = damp * q)
+  auto sgn = [&](double x) { return FIRST ? x : -x; };
+  const int c = M.c, r0 = M.r0;
+  constexpr bool kExact = DH % DN_RC == 0;  // every run has DN_RC rows inside the footprint
+  // two chunks of the run (cells [0, DN_H) and [DN_H, DN_RC)), each one batch of LDS reads
+  const int b0 = r0 * DWP + c;
+  const double* p = src + b0;
+  const double* pv = sdv + b0;
+  const double* pu = sdu + b0;
+  const int ow = c > 0 ? -1 : 0, oe = c < DW - 1 ? 1 : 0;
+  // offset of row r0 + t relative to row r0, clamped into the footprint (t is a constant after unrolling: only the rows
+  // above / below the run are clamped at run time when kExact)
+  auto ro = [&](int t) {
+    if (kExact && t >= 0 && t < DN_RC) return t * DWP;
+    int jj = r0 + t;
+    jj = jj < 0 ? 0 : (jj > DH - 1 ? DH - 1 : jj);
+    return (jj - r0) * DWP;
+  };
+  auto chunk = [&](auto T0_, auto T1_) {
+    constexpr int T0 = decltype(T0_)::value, T1 = decltype(T1_)::value, N = T1 - T0;
+    double vc[N + 2], vw[N], ve[N], dv0[N], dv1[N], du[N + 1];
+#pragma unroll
+    for (int u = 0; u < N + 2; ++u) vc[u] = val(p[ro(T0 - 1 + u)]);
+#pragma unroll
+    for (int t = 0; t <= N; ++t) du[t] = pu[ro(T0 + t)];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      const int o = ro(T0 + t);
+      vw[t] = val(p[o + ow]);
+      ve[t] = val(p[o + oe]);
+      dv0[t] = pv[o];
+      dv1[t] = pv[o + oe];
+    }
+    double fy[N + 1];
+#pragma unroll
+    for (int t = 0; t <= N; ++t) fy[t] = sgn(du[t] * (vc[t] - vc[t + 1]));
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      const double fw = sgn(dv0[t] * (vw[t] - vc[t + 1]));
+      const double fe = sgn(dv1[t] * (vc[t + 1] - ve[t]));
+      const double d = (fw - fe + fy[t] - fy[t + 1]) * M.ra[T0 + t];
+      res[T0 + t] = M.valid[T0 + t] ? d : 0.0;
+    }
+  };
+  constexpr int DN_H = (DN_RC + 1) / 2;
+  chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, DN_H>{});
+#ifndef PACE_EMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  chunk(std::integral_constant<int, DN_H>{}, std::integral_constant<int, DN_RC>{});
+}
+
 // one pass: dst = divergence of the fluxes of src (FIRST: of d0 * src, fluxes as they are; later passes: fluxes negated,
 // delnflux.py:1232-1254 "fx2 = -fx2").  RC: the footprint reaches a corner of the halo and the corner copies apply
 // (block-uniform: the other instance carries none of that logic).  dst == src is allowed: every thread holds its results until
@@ -202,65 +258,18 @@ __device__ __forceinline__ void deln_pass(const Geo& g, const MT& m, const DelnM
                                           const double* __restrict__ sdu, double* dst, int i0, int j0, double d0) {
   const int ilo = i0 - 3, jlo = j0 - 3;
   const bool inplace = dst == src;  // block-uniform
-  auto val = [&](double x) { return FIRST ? d0 * x : x; };  // (d0 * x: the reference's first statement, d2 = damp * q)
+  auto val = [&](double x) { return FIRST ? d0 * x : x; };
   auto sgn = [&](double x) { return FIRST ? x : -x; };
   double res[DN_RC];
   const int c = M.c, r0 = M.r0;
-  constexpr bool kExact = DH % DN_RC == 0;  // every run has DN_RC rows inside the footprint
-  if (M.active) {
-    // two chunks of the run (cells [0, DN_H) and [DN_H, DN_RC)), each one batch of LDS reads
-    const int b0 = r0 * DWP + c;
-    const double* p = src + b0;
-    const double* pv = sdv + b0;
-    const double* pu = sdu + b0;
-    const int ow = c > 0 ? -1 : 0, oe = c < DW - 1 ? 1 : 0;
-    // offset of row r0 + t relative to row r0, clamped into the footprint (t is a constant after unrolling: only the rows
-    // above / below the run are clamped at run time when kExact)
-    auto ro = [&](int t) {
-      if (kExact && t >= 0 && t < DN_RC) return t * DWP;
-      int jj = r0 + t;
-      jj = jj < 0 ? 0 : (jj > DH - 1 ? DH - 1 : jj);
-      return (jj - r0) * DWP;
-    };
-    auto chunk = [&](auto T0_, auto T1_) {
-      constexpr int T0 = decltype(T0_)::value, T1 = decltype(T1_)::value, N = T1 - T0;
-      double vc[N + 2], vw[N], ve[N], dv0[N], dv1[N], du[N + 1];
-#pragma unroll
-      for (int u = 0; u < N + 2; ++u) vc[u] = val(p[ro(T0 - 1 + u)]);
-#pragma unroll
-      for (int t = 0; t <= N; ++t) du[t] = pu[ro(T0 + t)];
-#pragma unroll
-      for (int t = 0; t < N; ++t) {
-        const int o = ro(T0 + t);
-        vw[t] = val(p[o + ow]);
-        ve[t] = val(p[o + oe]);
-        dv0[t] = pv[o];
-        dv1[t] = pv[o + oe];
-      }
-      double fy[N + 1];
-#pragma unroll
-      for (int t = 0; t <= N; ++t) fy[t] = sgn(du[t] * (vc[t] - vc[t + 1]));
-#pragma unroll
-      for (int t = 0; t < N; ++t) {
-        const double fw = sgn(dv0[t] * (vw[t] - vc[t + 1]));
-        const double fe = sgn(dv1[t] * (vc[t + 1] - ve[t]));
-        const double d = (fw - fe + fy[t] - fy[t + 1]) * M.ra[T0 + t];
-        res[T0 + t] = M.valid[T0 + t] ? d : 0.0;
-      }
-    };
-    constexpr int DN_H = (DN_RC + 1) / 2;
-    chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, DN_H>{});
-#ifndef PACE_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    chunk(std::integral_constant<int, DN_H>{}, std::integral_constant<int, DN_RC>{});
-  }
+  constexpr bool kExact = DH % DN_RC == 0;
+  if (M.active) deln_run<FIRST>(M, src, sdv, sdu, d0, res);
   // the cells next to / inside the corner regions: 4 x 4 blocks (minus the one cell that touches no corner) at the corners of
   // the tile domain, one candidate cell per thread
   double fix = 0.0;
   int fix_at = -1;
   if (RC) {
-    const int tid = threadIdx.x & 255;
+    const int tid = threadIdx.x;
     if (tid < 64) {
       const int q = tid >> 4, a = tid & 3, b = (tid >> 2) & 3;
       const int gi = (q & 1) ? g.ie + a : g.is - 3 + a;
@@ -312,11 +321,7 @@ template <class MT>
 __device__ __forceinline__ DelnResult deln_iterate(const Geo& g, const MT& m, const DelnMet& M, const double* sq, const double* sdv,
                                                    const double* sdu, double* plane, int i0, int j0, double d0, bool hi_order,
                                                    int nmax) {
-#ifdef FV_X_NODAMP
-  const int iters = 0;
-#else
   const int iters = hi_order ? nmax : 0;
-#endif
   const int ilo = i0 - 3, jlo = j0 - 3;
   const bool rc = hi_order && (ilo < g.is || ilo + DW - 1 > g.ie) && (jlo < g.js || jlo + DH - 1 > g.je);
   for (int it = 0; it < iters; ++it) {

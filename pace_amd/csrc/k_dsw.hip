@@ -1070,34 +1070,6 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
   return PACE_OK;
 }
 
-// w, q_con and pt are transported by three independent kernels (all three need only the mass fluxes of delp).  On three streams
-// (the caller's + two of the library's own) their workgroups share the CUs: the partly filled last round of each launch (3792
-// workgroups on 1024 slots: 3.7 rounds) is filled by the others, and the three read the same Courant numbers / area fluxes /
-// mass fluxes at about the same time.  Measured at C192 x 79: scalar phase 546 -> 522 us, bit-identical.  Two side streams and
-// three events, created once per process (fork / join on events: legal under stream capture); PACE_DSW_STREAMS=0 keeps
-// everything on the caller's stream.
-#ifndef PACE_EMU
-struct DswSide {
-  hipStream_t s[2];
-  hipEvent_t fork, join[2];
-  bool ok;
-};
-static DswSide* dsw_side() {
-  static DswSide side = [] {
-    DswSide d{};
-    const char* e = getenv("PACE_DSW_STREAMS");
-    d.ok = !(e != nullptr && e[0] == '0');  // on unless PACE_DSW_STREAMS=0
-    if (d.ok) {
-      for (int n = 0; n < 2; ++n) d.ok = d.ok && hipStreamCreateWithFlags(&d.s[n], hipStreamNonBlocking) == hipSuccess;
-      d.ok = d.ok && hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess;
-      for (int n = 0; n < 2; ++n) d.ok = d.ok && hipEventCreateWithFlags(&d.join[n], hipEventDisableTiming) == hipSuccess;
-    }
-    return d;
-  }();
-  return side.ok ? &side : nullptr;
-}
-#endif
-
 struct DswWork {
   real *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv, *umid, *vmid;
   real* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
@@ -1183,89 +1155,40 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   if (phases & 2) {
   {
-    // PACE_DSW_LEVEL_BLOCK=<n> (experiment): the four scalar transports issued per block of n levels,
-    // so that the Courant numbers and area fluxes of the block (4 fields x n levels x 0.33 MB at C192) are still in the L2s
-    // when the next scalar of the same block reads them.  Default: whole fields, one launch per scalar.
-    static const int level_block = getenv("PACE_DSW_LEVEL_BLOCK") ? atoi(getenv("PACE_DSW_LEVEL_BLOCK")) : 0;
-    const int kstep = (level_block > 0 && level_block < nk) ? level_block : nk;
-    for (int k0 = 0; k0 < nk; k0 += kstep) {
-    const int nl = (k0 + kstep <= nk) ? kstep : nk - k0;
-    const long o = (long)k0 * g.sk;
+    const int nl = nk;
+    const long o = 0;
     FvDamp dp{};
     // delp: transport + del-n damping of the mass fluxes -> fx, fy
-    dp.damp_k = d_dampfac_vt + k0; dp.nord_k = d_nord_v + k0; dp.nmax = nmax_v; dp.mass_given = 0;
-    dp.accx = mfx + o; dp.accy = mfy + o;  // flux_capacitor (d_sw.py:33-60); its Courant-number half sits in fxadv
-    if ((rc = launch_transport(g, m, delp + o, crx + o, cry + o, xfx + o, yfx + o, W.fx + o, W.fy + o, nullptr, nullptr, cfg->hord_dp, nl, 1, 0, dp, st))) return rc;
+    dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
+    dp.accx = mfx; dp.accy = mfy;  // flux_capacitor (d_sw.py:33-60); its Courant-number half sits in fxadv
+    if ((rc = launch_transport(g, m, delp, crx, cry, xfx, yfx, W.fx, W.fy, nullptr, nullptr, cfg->hord_dp, nl, 1, 0, dp, st))) return rc;
     // w: transport with the mass fluxes, del-n damping fluxes -> heat_diss, flux-form update -> W.gx (= w*delp + F(w))
     dp = FvDamp{};
-    dp.damp_k = d_dampfac_w_c + k0; dp.nord_k = d_nord_w + k0; dp.nmax = nmax_w; dp.mass_given = 0;
-    dp.qout = W.gx + o; dp.amass = delp + o; dp.dw = W.dw + o; dp.heat_s = W.heat_s + o; dp.diss_est = diss_est + o;
-    dp.damp_w_k = d_damp_w_c + k0; dp.ke_bg_k = d_kebg + k0; dp.dt = dt;
+    dp.damp_k = d_dampfac_w_c; dp.nord_k = d_nord_w; dp.nmax = nmax_w; dp.mass_given = 0;
+    dp.qout = W.gx; dp.amass = delp; dp.dw = W.dw; dp.heat_s = W.heat_s; dp.diss_est = diss_est;
+    dp.damp_w_k = d_damp_w_c; dp.ke_bg_k = d_kebg; dp.dt = dt;
     const FvDamp dpw = dp;
     // q_con -> W.gy
     dp = FvDamp{};
-    dp.damp_k = d_dampfac_t + k0; dp.nord_k = d_nord_t + k0; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp + o;
-    dp.qout = W.gy + o; dp.amass = delp + o;
+    dp.damp_k = d_dampfac_t; dp.nord_k = d_nord_t; dp.nmax = nmax_t; dp.mass_given = 1; dp.mass = delp;
+    dp.qout = W.gy; dp.amass = delp;
     // pt -> W.fx2
     FvDamp dp2 = dp;
-    dp2.damp_k = d_dampfac_vt + k0; dp2.nord_k = d_nord_v + k0; dp2.nmax = nmax_v; dp2.qout = W.fx2 + o;
-    // The three in ONE launch (k_fvtp2d_scalars3: a grid three tile planes high) when all three run ord 6 -- the baseline --;
-    // PACE_DSW_FUSED3=0 keeps the three launches (on three streams, below).
-    static const bool fused3 = !(getenv("PACE_DSW_FUSED3") && getenv("PACE_DSW_FUSED3")[0] == '0');
-    static const bool pair = getenv("PACE_DSW_PAIR") != nullptr;  // experiment: q_con and pt in one workgroup (k_fvtp2d_pair)
+    dp2.damp_k = d_dampfac_vt; dp2.nord_k = d_nord_v; dp2.nmax = nmax_v; dp2.qout = W.fx2;
+    // General tilings with ord 6 for all three: ONE launch (k_fvtp2d_scalars3: a grid three tile planes high).  The production
+    // tilings take the lean kernel (k_fvt.hip) scalar by scalar.
     bool done3 = false;
-    if (fused3 && !pair && cfg->hord_vt == 6 && cfg->hord_dp == 6 && cfg->hord_tm == 6) {
-      rc = launch_transport_scalars3(g, m, w + o, q_con + o, pt + o, crx + o, cry + o, xfx + o, yfx + o, W.fx + o, W.fy + o, nl, dpw, dp, dp2, st);
+    if (!transport_lean_covers(g, 6) && cfg->hord_vt == 6 && cfg->hord_dp == 6 && cfg->hord_tm == 6) {
+      rc = launch_transport_scalars3(g, m, w, q_con, pt, crx, cry, xfx, yfx, W.fx, W.fy, nl, dpw, dp, dp2, st);
       if (rc == PACE_OK) done3 = true;
       else if (rc != PACE_ERR_UNSUPPORTED) return rc;
     }
-    bool used_side = false;
     if (!done3) {
-    hipStream_t st_w = st, st_q = st;
-#ifndef PACE_EMU
-    DswSide* side = (kstep == nk) ? dsw_side() : nullptr;
-    if (side) {
-      (void)hipEventRecord(side->fork, st);
-      for (int n = 0; n < 2; ++n) (void)hipStreamWaitEvent(side->s[n], side->fork, 0);
-      st_w = side->s[0];
-      st_q = side->s[1];
-      used_side = true;
+      if ((rc = launch_transport(g, m, w, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_vt, nl, 0, 2, dpw, st))) return rc;
+      if ((rc = launch_transport(g, m, q_con, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_dp, nl, 2, 1, dp, st))) return rc;
+      if ((rc = launch_transport(g, m, pt, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_tm, nl, 2, 1, dp2, st))) return rc;
     }
-#endif
-    if ((rc = launch_transport(g, m, w + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_vt, nl, 0, 2, dpw, st_w))) return rc;
-    // the two halves of a pair must pass the same barriers: pair the levels from which on the damping orders of the two agree
-    // (the sponge levels on top differ in the baseline namelist), the levels above them one scalar at a time
-    int kp = nl;
-    if (pair && cfg->hord_dp == 6 && cfg->hord_tm == 6 && nmax_t == nmax_v) {
-      kp = 0;
-      for (int k = 0; k < nl; ++k)
-        if ((col->nord_t[k0 + k] > 0) != (col->nord_v[k0 + k] > 0)) kp = k + 1;
-    }
-    if (kp > 0) {
-      if ((rc = launch_transport(g, m, q_con + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_dp, kp, 2, 1, dp, st_q))) return rc;
-      // (pt stays on the caller's stream: with the side streams on, w, q_con and pt are three concurrent launches)
-      if ((rc = launch_transport(g, m, pt + o, crx + o, cry + o, xfx + o, yfx + o, nullptr, nullptr, W.fx + o, W.fy + o, cfg->hord_tm, kp, 2, 1, dp2, st))) return rc;
-    }
-    if (kp < nl) {
-      const long o2 = o + (long)kp * g.sk;
-      FvDamp a = dp, b = dp2;
-      a.damp_k += kp; a.nord_k += kp; a.mass += (long)kp * g.sk; a.qout += (long)kp * g.sk; a.amass += (long)kp * g.sk;
-      b.damp_k += kp; b.nord_k += kp; b.mass += (long)kp * g.sk; b.qout += (long)kp * g.sk; b.amass += (long)kp * g.sk;
-      if ((rc = launch_transport_pair(g, m, q_con + o2, pt + o2, crx + o2, cry + o2, xfx + o2, yfx + o2, W.fx + o2, W.fy + o2, 6, nl - kp, a, b, st))) return rc;
-    }
-    }
-#ifndef PACE_EMU
-    if (used_side) {
-      DswSide* side = dsw_side();
-      for (int n = 0; n < 2; ++n) {
-        (void)hipEventRecord(side->join[n], side->s[n]);
-        (void)hipStreamWaitEvent(st, side->join[n], 0);
-      }
-    }
-#else
-    (void)used_side;
-#endif
-    }
+    (void)o;
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
   }
   }

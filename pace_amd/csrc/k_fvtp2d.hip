@@ -30,99 +30,6 @@ static_assert(DN_TI == FV_TI && DN_TJ == FV_TJ, "the fused damping shares the tr
 #define QW (TI + 6)
 #define QH (TJ + 6)
 
-// The metric fields this kernel reads (kernel arguments live in SGPRs: the full pace_metrics_t is 43 pointers, and the
-// register allocator answered with ~300 SGPR spills -- v_readlane / v_writelane traffic on the vector pipe)
-struct FvMet {
-  const real *area, *rarea, *dxa, *dya, *dx, *dy, *del6_u, *del6_v;
-};
-static inline FvMet fv_met(const Met& m) { return FvMet{m.area, m.rarea, m.dxa, m.dya, m.dx, m.dy, m.del6_u, m.del6_v}; }
-
-// Workgroup -> (tile, level).  Workgroups are handed to the eight XCDs round-robin in launch order, and every XCD has its own
-// 4 MB L2: with the plain (x, y, z) order, neighbouring tiles of a level land on DIFFERENT XCDs and every line of their
-// overlapping footprints is fetched from memory once per XCD (measured: 1.9 x the algorithmic bytes).  Here a level belongs to
-// ONE XCD: XCD x works through levels x, x + 8, x + 16, ... tile by tile, so the halo lines shared by neighbouring tiles are
-// L2 hits.  (Affinity only: nothing depends on where a workgroup really runs.)
-struct TileId {
-  int bx, by, bz;
-};
-__device__ __forceinline__ TileId tile_of_workgroup() {
-#if defined(PACE_EMU) || defined(FV_PLAIN_ORDER)
-  return TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
-#elif defined(FV_LPT_ORDER)
-  // slowest tiles first (corner, then edge, then interior tiles; all levels of a class before the next class) so that the tail
-  // of the launch consists of the fast interior workgroups
-  {
-    const int gx = gridDim.x, gy = gridDim.y, nlev = gridDim.z;
-    int b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const int ncorner = (gx > 1 ? 2 : 1) * (gy > 1 ? 2 : 1);
-    const int nedge = 2 * (gx > 2 ? gx - 2 : 0) * (gy > 1 ? 1 : 0) + 2 * (gy > 2 ? gy - 2 : 0) * (gx > 1 ? 1 : 0) ;
-    int t, lev;
-    if (b < ncorner * nlev) {
-      lev = b / ncorner; t = b - lev * ncorner;
-      const int cx = t & 1, cy = (gx > 1) ? (t >> 1) : t;
-      return TileId{(gx > 1 && cx) ? gx - 1 : 0, cy ? gy - 1 : 0, lev};
-    }
-    b -= ncorner * nlev;
-    if (b < nedge * nlev && gx > 1 && gy > 1) {
-      lev = b / nedge; t = b - lev * nedge;
-      const int nx = 2 * (gx - 2);
-      if (t < nx) return TileId{1 + (t >> 1), (t & 1) ? gy - 1 : 0, lev};
-      t -= nx;
-      return TileId{(t & 1) ? gx - 1 : 0, 1 + (t >> 1), lev};
-    }
-    if (gx > 1 && gy > 1) b -= nedge * nlev;
-    const int ix = gx > 2 ? gx - 2 : 0, iy = gy > 2 ? gy - 2 : 0;
-    const int nint = ix * iy;
-    if (nint > 0 && gx > 1 && gy > 1) {
-      // interior tiles: a level belongs to one XCD as in the default map
-      const int full = (nlev / 8) * 8;
-      if (b < full * nint) {
-        const int xcd = b & 7, slot = b >> 3;
-        lev = (slot / nint) * 8 + xcd;
-        t = slot - (slot / nint) * nint;
-      } else {
-        lev = b / nint;
-        t = b - lev * nint;
-      }
-      return TileId{1 + t % ix, 1 + t / ix, lev};
-    }
-    // degenerate grids (a single row / column of tiles): plain order of what is left
-    lev = b / (gx * gy); t = b - lev * (gx * gy);
-    return TileId{t % gx, t / gx, lev};
-  }
-#else
-  const int gx = gridDim.x, gy = gridDim.y, nlev = gridDim.z;
-  const int tpl = gx * gy;
-  const int b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-  const int full = (nlev / 8) * 8;  // levels that can be dealt out eight at a time
-  int lev, t;
-  if (b < full * tpl) {
-    const int xcd = b & 7, slot = b >> 3;
-    lev = (slot / tpl) * 8 + xcd;
-    t = slot - (slot / tpl) * tpl;
-  } else {
-    lev = b / tpl;
-    t = b - lev * tpl;
-  }
-  return TileId{t % gx, t / gx, lev};
-#endif
-}
-
-// Stage-time instrumentation (experiments only: `make prof` builds build/prof/libpace_prof.so with -DFV_PROF; the product
-// library contains none of this).  One interior workgroup per level records the shader clock at every stage boundary.
-#ifdef FV_PROF
-// [interior tile (2, 3) | corner tile (0, 0) | west-edge tile (0, 3) | south-edge tile (2, 0)][level][stamp]
-__device__ long long g_fv_prof[4 * 256 * 16];
-#define FV_SLOT ((wg.bx == 2 && wg.by == 3) ? 0 : (wg.bx == 0 && wg.by == 0) ? 1 : (wg.bx == 0 && wg.by == 3) ? 2 : (wg.bx == 2 && wg.by == 0) ? 3 : -1)
-#define STAMP(n)                                                                                      \
-  if (tid == 0 && wg.bz < 256 && FV_SLOT >= 0)                                                        \
-  g_fv_prof[(FV_SLOT * 256 + wg.bz) * 16 + (n)] = (long long)__builtin_readcyclecounter()
-extern "C" int pace_debug_fv_prof(long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fv_prof), sizeof(long long) * 4 * 256 * 16);
-}
-#else
-#define STAMP(n)
-#endif
 
 // EX / EY: whether any x- (y-) interface this workgroup evaluates lies within two cells of a tile edge, where the
 // PPM interface values switch to the one-sided forms (xppm.py:148-181).  Block-uniform, so interior workgroups
@@ -143,40 +50,10 @@ struct FvLds {
   static constexpr int kNeed = kDamp > kEpi ? kDamp : kEpi;
   static constexpr int kPad = kNeed > kSweep ? kNeed - kSweep : 1;
   double pad[kPad];
-#if FV_PF
-  unsigned pf_dummy[64];
-#endif
 };
 
-// EXPERIMENT (-DFV_PF=n): warm the L2 with the lines a later stage will load, through LDS-DMA loads into a dummy LDS area
-// (no VGPR destination, nothing waits for them): thread t touches the 128-byte segment (t % 4) of row (t / 4) of the window.
-#ifndef FV_PF
-#define FV_PF 0
-#endif
-#ifndef FV_DN_EARLY
-#define FV_DN_EARLY 0
-#endif
 #ifndef FV_EPI0_BATCH
 #define FV_EPI0_BATCH 2
-#endif
-#if FV_PF && !defined(PACE_EMU)
-__device__ __forceinline__ void pf_touch(const real* base, unsigned off, unsigned lds_addr) {
-  const char* a = (const char*)base + off;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(a), "s"(lds_addr) : "memory", "m0");
-}
-// rows [r0, r0 + nr) x byte columns [cb, cb + nb) of the level at byte offset kb8
-__device__ __forceinline__ void pf_window(const real* base, unsigned kb8, int r0, int nr, int cb, int nb, int sj8, int tid,
-                                          unsigned lds_addr) {
-  if (tid < nr * 4) {
-    const int r = tid >> 2, sgm = tid & 3;
-    int c = cb + sgm * 128;
-    c = c < cb + nb - 4 ? c : cb + nb - 4;
-    pf_touch(base, kb8 + (unsigned)(__mul24(r0 + r, sj8) + c), lds_addr);
-  }
-}
-#define PF_WINDOW(...) pf_window(__VA_ARGS__)
-#else
-#define PF_WINDOW(...)
 #endif
 
 #ifndef FV_RF
@@ -215,13 +92,13 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
                                             const real* __restrict__ xfx, const real* __restrict__ yfx,
                                             real* __restrict__ fx, real* __restrict__ fy,
                                             const real* __restrict__ xunit, const real* __restrict__ yunit,
-                                            const FvDamp& dp, const TileId wg) {
+                                            const FvDamp& dp, const FvTile wg) {
   auto& sq = L.sq;
   auto& syin = L.syin;
   auto& sqi = L.sqi;
   auto& sxin = L.sxin;
 
-  const int tid = threadIdx.x & 255;  // (k_fvtp2d_pair runs two scalars in one workgroup of 512 threads)
+  const int tid = threadIdx.x;
   const int i0 = g.is + wg.bx * TI;
   const int j0 = g.js + wg.by * TJ;
   const int k = wg.bz;
@@ -252,12 +129,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   // (CANON: the launcher has checked that the tiling puts every edge there -- fv_canonical_tiling)
   constexpr bool canon_x = CANON && kCanonX, canon_y = CANON && kCanonY;
 
-  STAMP(0);
   DelnMet DM;
   if (DMODE >= 0) {
-#if FV_DN_EARLY
-    deln_load(g, m, i0, j0, DM);
-#endif
     deln_stage_metrics(g, m, &L.syin[0][0] + DH * DWP, &L.syin[0][0] + 2 * DH * DWP, i0, j0);
   }
   // stage 0: q with corners copied in the y direction (copy_corners_y, corners.py:367-425).
@@ -284,28 +157,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       if (e < QW * QH) sq[jj][ii] = v0[t];
     }
   }
-#if FV_PF && !defined(PACE_EMU)
-  const unsigned pf_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)&L.pf_dummy[0]);
-  {
-    // clamp the windows to the storage (edge tiles)
-    const int ra = j0 < 0 ? 0 : j0, rb = jlo < 0 ? 0 : jlo;
-    const int na = (j0 + TJ + 1 <= g.nj ? j0 + TJ + 1 : g.nj) - ra, nb = (jlo + QH <= g.nj ? jlo + QH : g.nj) - rb;
-    const int ca = (ilo < 0 ? 0 : ilo) * E8, cb = i0 * E8;
-    const int wa = ((ilo + QW <= g.ni ? ilo + QW : g.ni)) * E8 - ca, wb = ((i0 + TI + 1 <= g.ni ? i0 + TI + 1 : g.ni)) * E8 - cb;
-    PF_WINDOW(cry, kb8, ra, na, ca, wa, sj8, tid, pf_lds);
-    PF_WINDOW(yfx, kb8, ra, na, ca, wa, sj8, tid, pf_lds);
-    PF_WINDOW(crx, kb8, rb, nb, cb, wb, sj8, tid, pf_lds);
-    PF_WINDOW(xfx, kb8, rb, nb, cb, wb, sj8, tid, pf_lds);
-#if FV_PF >= 3
-    PF_WINDOW(xunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
-    PF_WINDOW(yunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
-    if (EPI > 0) PF_WINDOW(dp.amass, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
-    if (DMODE == 2) PF_WINDOW(dp.mass, kb8, (j0 > 0 ? j0 - 1 : 0), na, (i0 - 1) * E8, wb + E8, sj8, tid, pf_lds);
-#endif
-  }
-#endif
   __syncthreads();
-  STAMP(1);
 
   // fused damping: the passes run in the LDS space the sweeps will use afterwards; this thread's face values stay in registers
   double dvx[RF], dvy[RF];
@@ -317,9 +169,7 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     const double* sdv = pa + DH * DWP;
     const double* sdu = sdv + DH * DWP;
     damp = dp.damp_k[k];
-#if !FV_DN_EARLY
     deln_load(g, m, i0, j0, DM);
-#endif
     const DelnResult R = deln_iterate(g, m, DM, &sq[0][0], sdv, sdu, pa, i0, j0, dp.mass_given ? 1.0 : damp, dp.nord_k[k] > 0.0, dp.nmax);
     if (x5_on) {
 #pragma unroll
@@ -343,18 +193,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
     __syncthreads();
   }
 
-  STAMP(2);
-#if FV_PF == 2 && !defined(PACE_EMU)
-  {
-    const int ra = j0, cb = i0 * E8;
-    const int na = (j0 + TJ + 1 <= g.nj ? j0 + TJ + 1 : g.nj) - ra;
-    const int wb = ((i0 + TI + 1 <= g.ni ? i0 + TI + 1 : g.ni)) * E8 - cb;
-    PF_WINDOW(xunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
-    PF_WINDOW(yunit, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
-    if (EPI > 0) PF_WINDOW(dp.amass, kb8, ra, na, cb, wb, sj8, tid, pf_lds);
-    if (DMODE == 2) PF_WINDOW(dp.mass, kb8, (j0 > 0 ? j0 - 1 : 0), na, (i0 - 1) * E8, wb + E8, sj8, tid, pf_lds);
-  }
-#endif
   // stage 1: inner y sweep (YPiecewiseParabolic, origin (is-3, js), domain (N+7, N+1)): one run of RF interfaces of one
   // column per thread, lanes along i
   if (tid < QW * GY) {
@@ -387,7 +225,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
   __syncthreads();
 
-  STAMP(3);
   // stage 2: q_i; and re-stage the corner cells of q for the x direction (copy_corners_x)
   {
     // One thread per column and group of RPG consecutive rows (round 3; before: one cell per thread and pass, every cell loading
@@ -406,13 +243,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int gj = j0 + jj0 + t;
       const bool row_ok = jj0 + t <= TJ && (!EY || (gj >= g.js && gj <= g.je + 1));
       const unsigned c2 = (col_ok && row_ok) ? OFF2(gi, gj) : OFF2(g.is, g.js);
-#ifdef FV_X_NOLOADS
-      y_[t] = 1.0e5 + c2;
-      if (t < RPG) a_[t] = 1.0e9;
-#else
       y_[t] = LD(yfx, kb8 + c2);
       if (t < RPG) a_[t] = LD(m.area, c2);
-#endif
     }
     if (act) {
 #pragma unroll
@@ -447,7 +279,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
   __syncthreads();
 
-  STAMP(4);
   // stage 3: inner x sweep (XPiecewiseParabolic, origin (is, js-3), domain (N+1, N+7)): one run of RF interfaces of one
   // row per thread
   if (tid < QH * GX) {
@@ -482,7 +313,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
   __syncthreads();
 
-  STAMP(5);
   // stage 4: q_j
   {
     // the same along x: one thread per row and group of CPG consecutive columns (QH * TI / CPG = 240 threads in production)
@@ -499,13 +329,8 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       const int gi = i0 + ii0 + t;
       const bool col_ok = !EX || (gi >= g.is && gi <= g.ie + 1);
       const unsigned c2 = (row_ok && col_ok) ? OFF2(gi, gj) : OFF2(g.is, g.js);
-#ifdef FV_X_NOLOADS
-      x_[t] = 1.0e5 + c2;
-      if (t < CPG) a_[t] = 1.0e9;
-#else
       x_[t] = LD(xfx, kb8 + c2);
       if (t < CPG) a_[t] = LD(m.area, c2);
-#endif
     }
     if (act) {
 #pragma unroll
@@ -522,7 +347,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
   }
   __syncthreads();
 
-  STAMP(6);
   // stage 5: outer sweeps + final_fluxes (fvtp2d.py:80-119).  The grid has ceil(N / TI) x ceil(N / TJ) workgroups; the
   // N+1-th face row / column (ie+1, je+1) is produced by the workgroup that owns cell ie / je, not by an extra,
   // almost empty row of workgroups.
@@ -619,7 +443,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       faces(std::integral_constant<int, 0>{}, std::integral_constant<int, RF>{});
     }
   }
-  STAMP(7);
   if (y5_on) {  // outer y on q_j: columns of the tile, runs of y-interfaces, lanes along i
     const int grp = y5_grp, ii = y5_col;
     const int jj0 = grp * RF;
@@ -707,7 +530,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       faces(std::integral_constant<int, 0>{}, std::integral_constant<int, RF>{});
     }
   }
-  STAMP(8);
   if (EPI > 0) {
     // epilogue: put the face fluxes of the tile (both sides of every cell) into LDS, then update the cells
     constexpr int AXP = TI + 2, AYP = TI + 1;
@@ -738,7 +560,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       }
     }
     __syncthreads();
-    STAMP(9);
     constexpr int NEC = (TI * TJ + 255) / 256;
     if (EPI == 3) {
       // apply_height_fluxes (updatedzd.py:70-126): the advected height from the transport's own fluxes over the area the cell
@@ -809,7 +630,6 @@ __device__ __forceinline__ void fvtp2d_tile(FvLds<DMODE, EPI>& L, const Geo& g, 
       }
     }
   }
-  STAMP(10);
 }
 
 #ifndef FV_WAVES
@@ -827,7 +647,7 @@ __global__ void __launch_bounds__(256, FV_WAVES) k_fvtp2d(Geo g, FvMet m, const 
   // x-interfaces evaluated: i0 .. i0+TI (their al's reach one further each way); special forms at is-1 .. is+1 and
   // ie .. ie+2
   __shared__ FvLds<DMODE, EPI> L;
-  const TileId wg = tile_of_workgroup();
+  const FvTile wg = fv_tile_of_workgroup();
   const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
   // (ord 8: the special CELLS are s-1 .. s+1 and e-1 .. e+1; the cells evaluated are i0-1 .. i0+TI -- the same test)
   const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
@@ -851,7 +671,7 @@ __global__ void __launch_bounds__(256, FV_WAVES) k_fvtp2d_scalars3(Geo g, FvMet 
                                                                 FvDamp dp1, const real* __restrict__ q2, FvDamp dp2, int gy) {
   constexpr size_t kBytes = sizeof(FvLds<0, 2>) > sizeof(FvLds<2, 1>) ? sizeof(FvLds<0, 2>) : sizeof(FvLds<2, 1>);
   __shared__ double raw[(kBytes + 7) / 8];
-  TileId wg = tile_of_workgroup();
+  FvTile wg = fv_tile_of_workgroup();
   const int which = wg.by / gy;  // block-uniform
   wg.by -= which * gy;
   const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
@@ -880,54 +700,11 @@ static inline bool fv_canonical_tiling(const Geo& g) {
   return g.n % TI == 0 && g.n % TJ == 0 && g.n >= 2 * TI && g.n >= 2 * TJ;
 }
 
-// EXPERIMENT (PACE_DSW_PAIR=1): two scalars that share every input except q and the damping
-// coefficients (q_con and pt in d_sw) in ONE workgroup of 512 threads -- waves 0-3 run the tile for the first, waves 4-7 for the
-// second, each half in its own LDS; the halves load the same Courant numbers, area fluxes, mass and metrics at about the same
-// time, so one of the two finds them in the CU's L1.  The halves pass the same barriers: the caller guarantees equal damping
-// orders on every level.
-template <int MORD, int DMODE, int EPI>
-__global__ void __launch_bounds__(512, 4) k_fvtp2d_pair(Geo g, FvMet m, const real* __restrict__ qa, const real* __restrict__ qb,
-                                                     const real* __restrict__ crx, const real* __restrict__ cry,
-                                                     const real* __restrict__ xfx, const real* __restrict__ yfx,
-                                                     const real* __restrict__ xunit, const real* __restrict__ yunit, FvDamp dpa,
-                                                     FvDamp dpb) {
-  __shared__ FvLds<DMODE, EPI> L2[2];
-  const int half = threadIdx.x >> 8;
-  FvLds<DMODE, EPI>& L = L2[half];
-  const real* q = half ? qb : qa;
-  const FvDamp& dp = half ? dpb : dpa;
-  const TileId wg = tile_of_workgroup();
-  const int i0 = g.is + wg.bx * TI, j0 = g.js + wg.by * TJ;
-  const bool ex = (i0 - 1 <= g.is + 1) || (i0 + TI + 1 >= g.ie);
-  const bool ey = (j0 - 1 <= g.js + 1) || (j0 + TJ + 1 >= g.je);
-  if (ex && ey) fvtp2d_tile<MORD, true, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
-  else if (ex) fvtp2d_tile<MORD, true, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
-  else if (ey) fvtp2d_tile<MORD, false, true, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
-  else fvtp2d_tile<MORD, false, false, DMODE, EPI, false>(L, g, m, q, crx, cry, xfx, yfx, nullptr, nullptr, xunit, yunit, dp, wg);
-}
-
-int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real* qb, const real* crx, const real* cry,
-                          const real* xfx, const real* yfx, const real* xmf, const real* ymf, int hord, int nlev,
-                          const FvDamp& dpa, const FvDamp& dpb, hipStream_t st) {
-  if (hord != 6 || dpa.nmax != dpb.nmax || dpa.nmax > 2) return PACE_ERR_UNSUPPORTED;
-#if defined(FV_FAST_BUILD) || defined(FV_ONLY_621) || defined(FV_ONLY_EPI0)
-  return PACE_ERR_UNSUPPORTED;
-#else
-  const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
-  hipLaunchKernelGGL((k_fvtp2d_pair<6, 2, 1>), grid, dim3(512), 0, st, g, fv_met(m), qa, qb, crx, cry, xfx, yfx, xmf, ymf, dpa, dpb);
-  PACE_CHECK_LAUNCH();
-  return PACE_OK;
-#endif
-}
-
 // w, q_con and pt of d_sw in one launch (k_fvtp2d_scalars3); ord 6 for all three, damping orders <= 2
 int launch_transport_scalars3(const Geo& g, const Met& m, const real* w, const real* q_con, const real* pt, const real* crx,
                               const real* cry, const real* xfx, const real* yfx, const real* xmf, const real* ymf, int nlev,
                               const FvDamp& dpw, const FvDamp& dpq, const FvDamp& dpt, hipStream_t st) {
   if (dpw.nmax > 2 || dpq.nmax > 2 || dpt.nmax > 2) return PACE_ERR_UNSUPPORTED;
-#if defined(FV_ONLY_621) || defined(FV_ONLY_EPI0)
-  return PACE_ERR_UNSUPPORTED;
-#else
   const int gy = (g.n + TJ - 1) / TJ;
   const dim3 grid((g.n + TI - 1) / TI, 3 * gy, nlev);
   if (fv_canonical_tiling(g))
@@ -938,25 +715,15 @@ int launch_transport_scalars3(const Geo& g, const Met& m, const real* w, const r
                        dpt, gy);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
-#endif
 }
 
-#ifdef FV_PROF
-static int fv_dynlds() {
-  static const int v = getenv("PACE_FV_DYNLDS") ? atoi(getenv("PACE_FV_DYNLDS")) : 0;
-  return v;
-}
-#define FV_DYNLDS fv_dynlds()
-#else
-#define FV_DYNLDS 0
-#endif
 #define FV_LAUNCH(D, E)                                                                                                          \
   do {                                                                                                                           \
     if (MORD != 8 && fv_canonical_tiling(g))                                                                                     \
-      hipLaunchKernelGGL((k_fvtp2d<MORD, D, E, MORD != 8>), grid, block, FV_DYNLDS, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, \
+      hipLaunchKernelGGL((k_fvtp2d<MORD, D, E, MORD != 8>), grid, block, 0, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, \
                          xu, yu, dp);                                                                                            \
     else                                                                                                                         \
-      hipLaunchKernelGGL((k_fvtp2d<MORD, D, E, false>), grid, block, FV_DYNLDS, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, \
+      hipLaunchKernelGGL((k_fvtp2d<MORD, D, E, false>), grid, block, 0, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, \
                          yu, dp);                                                                                                \
   } while (0)
 
@@ -965,29 +732,6 @@ static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo&
                        const real* crx, const real* cry, const real* xfx, const real* yfx, real* fx, real* fy,
                        const real* xu, const real* yu, const FvDamp& dp) {
   const dim3 block(256);
-#ifdef FV_FAST_BUILD  // experiment builds (tools/build_variant.sh): only the instances d_sw uses with hord 6
-  if (MORD != 6) return PACE_ERR_UNSUPPORTED;
-  if constexpr (MORD == 6) {
-    if (epi == 0 && dmode == 1) FV_LAUNCH(1, 0);
-    else if (epi == 0 && dmode == 0) FV_LAUNCH(0, 0);
-    else if (epi == 0 && dmode == -1) FV_LAUNCH(-1, 0);
-    else if (epi == 2 && dmode == 0) FV_LAUNCH(0, 2);
-    else if (epi == 1 && dmode == 2) FV_LAUNCH(2, 1);
-    else return PACE_ERR_UNSUPPORTED;
-  }
-  return PACE_OK;
-#elif defined(FV_ONLY_EPI0)  // register-budget experiments: the two EPI == 0 instances of d_sw
-  if constexpr (MORD == 6) {
-    if (epi == 0 && dmode == 1) { FV_LAUNCH(1, 0); return PACE_OK; }
-    if (epi == 0 && dmode == 0) { FV_LAUNCH(0, 0); return PACE_OK; }
-  }
-  return PACE_ERR_UNSUPPORTED;
-#elif defined(FV_ONLY_621)  // register-budget experiments: one instance
-  if constexpr (MORD == 6) {
-    if (epi == 1 && dmode == 2) { FV_LAUNCH(2, 1); return PACE_OK; }
-  }
-  return PACE_ERR_UNSUPPORTED;
-#else
   if (epi == 0) {
     switch (dmode) {
       case 0: FV_LAUNCH(0, 0); break;
@@ -1010,7 +754,6 @@ static int launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo&
     FV_LAUNCH(0, 3);
   }
   return PACE_OK;
-#endif
 }
 
 // The general launcher.  dmode -1: transport only; otherwise the del-n damping of q is fused (see FvDamp).  epi 0:
@@ -1022,15 +765,14 @@ int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx,
   const dim3 grid((g.n + TI - 1) / TI, (g.n + TJ - 1) / TJ, nlev);
   const real* xu = xmf ? xmf : xfx;
   const real* yu = ymf ? ymf : yfx;
-  int rc;
+  int rc = launch_transport_lean(g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, hord, nlev, dmode, epi, dp, st);
+  if (rc != PACE_ERR_UNSUPPORTED) return rc;
   if (hord == 5) rc = launch_mode<5>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
   else if (hord == 6) rc = launch_mode<6>(dmode, epi, grid, st, g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
-#if !defined(FV_FAST_BUILD) && !defined(FV_ONLY_621) && !defined(FV_ONLY_EPI0)
   else if (hord == 8 && dmode == -1 && epi == 0) {  // monotone PPM: tracer advection (plain transport only)
     hipLaunchKernelGGL((k_fvtp2d<8, -1, 0, false>), grid, dim3(256), 0, st, g, fv_met(m), q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
     rc = PACE_OK;
   }
-#endif
   else return PACE_ERR_UNSUPPORTED;
   if (rc) return rc;
   PACE_CHECK_LAUNCH();

@@ -52,10 +52,50 @@ int launch_transport(const Geo& g, const Met& m, const real* q, const real* crx,
 int launch_transport_scalars3(const Geo& g, const Met& m, const real* w, const real* q_con, const real* pt, const real* crx,
                               const real* cry, const real* xfx, const real* yfx, const real* xmf, const real* ymf, int nlev,
                               const FvDamp& dpw, const FvDamp& dpq, const FvDamp& dpt, hipStream_t st);
-// experiment: two scalars (DMODE 2, EPI 1, ord 6) in one workgroup of 512 threads
-int launch_transport_pair(const Geo& g, const Met& m, const real* qa, const real* qb, const real* crx, const real* cry,
-                          const real* xfx, const real* yfx, const real* xmf, const real* ymf, int hord, int nlev,
-                          const FvDamp& dpa, const FvDamp& dpb, hipStream_t st);
+// k_fvt.hip: the lean transport kernel of the production tilings (every tile edge on a workgroup-tile boundary); same contract
+// as launch_transport with the unit fluxes resolved (xu = xmf or xfx); PACE_ERR_UNSUPPORTED for the calls it does not cover
+int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
+                          const real* yfx, real* fx, real* fy, const real* xu, const real* yu, int hord, int nlev, int dmode,
+                          int epi, const FvDamp& dp, hipStream_t st);
+
+// whether launch_transport_lean takes this geometry with this order (fp64 build, tiling, row alignment)
+bool transport_lean_covers(const Geo& g, int hord);
+
+// The metric fields the transport kernels read (kernel arguments live in SGPRs: the full pace_metrics_t is 43 pointers, and the
+// register allocator answered with ~300 SGPR spills -- v_readlane / v_writelane traffic on the vector pipe)
+struct FvMet {
+  const real *area, *rarea, *dxa, *dya, *dx, *dy, *del6_u, *del6_v;
+};
+static inline FvMet fv_met(const Met& m) { return FvMet{m.area, m.rarea, m.dxa, m.dya, m.dx, m.dy, m.del6_u, m.del6_v}; }
+
+// Workgroup -> (tile, level) of the transport kernels.  Workgroups are handed to the eight XCDs round-robin in launch order, and
+// every XCD has its own 4 MB L2: with the plain (x, y, z) order, neighbouring tiles of a level land on DIFFERENT XCDs and every
+// line of their overlapping footprints is fetched from memory once per XCD (measured: 1.9 x the algorithmic bytes).  Here a level
+// belongs to ONE XCD: XCD x works through levels x, x + 8, x + 16, ... tile by tile, so the halo lines shared by neighbouring
+// tiles are L2 hits.  (Affinity only: nothing depends on where a workgroup really runs.)
+struct FvTile {
+  int bx, by, bz;
+};
+__device__ __forceinline__ FvTile fv_tile_of_workgroup() {
+#ifdef PACE_EMU
+  return FvTile{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#else
+  const int gx = gridDim.x, gy = gridDim.y, nlev = gridDim.z;
+  const int tpl = gx * gy;
+  const int b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int full = (nlev / 8) * 8;  // levels that can be dealt out eight at a time
+  int lev, t;
+  if (b < full * tpl) {
+    const int xcd = b & 7, slot = b >> 3;
+    lev = (slot / tpl) * 8 + xcd;
+    t = slot - (slot / tpl) * tpl;
+  } else {
+    lev = b / tpl;
+    t = b - lev * tpl;
+  }
+  return FvTile{t % gx, t / gx, lev};
+#endif
+}
 int launch_delnflux(const Geo& g, const Met& m, int mode, const real* q, real* fx, real* fy,
                     const real* mass, const real* damp_k, const real* nord_k, int nmax, int mass_given,
                     int nlev, hipStream_t st);

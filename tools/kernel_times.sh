@@ -7,7 +7,9 @@ cd /tmp
 for spec in "$@"; do
   name=${spec%%=*}
   D=/tmp/kt_$name; rm -rf $D
-  rocprofv3 --kernel-trace --stats -d $D -o t -- python3 $R/tools/exp_variants.py $spec --reps 10 > /dev/null 2>&1
+  mkdir -p $D
+  # (the measuring process itself under the profiler: the parent mode of exp_variants.py does no GPU work)
+  rocprofv3 --kernel-trace --stats -d $D -o t -- python3 $R/tools/exp_variants.py $spec --reps 10 --child $D/out > /dev/null 2>&1
   echo "== $name"
   python3 $R/tools/rocprof_summary.py $(find $D -name "*.db" | head -1) | python3 -c "
 import sys,csv,re
