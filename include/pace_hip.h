@@ -81,6 +81,14 @@ typedef struct {
   int32_t nord;
   int32_t do_skeb;
   double dddmp, d4_bg, d_con;
+  /* Optional separate outputs of the four scalars d_sw transports (all four or none; NULL = the reference's in-place update).
+   * d_sw.py:148-201,331-350 overwrite delp, pt, w, q_con cell by cell while the transport of the neighbouring cells still reads
+   * them -- the reference gets away with it through full-field temporaries; here one kernel does transport and update, so the
+   * new values need a buffer of their own.  With outputs given (distinct from the inputs, same layout, 16-byte aligned) the
+   * compute domain AND the halo of each input are written there and the inputs are left as they were: the caller swaps the
+   * buffers (pace_amd: Quantity.swap_storage).  Without them the library writes to its workspace and copies back.
+   * Only where pace_d_sw_pingpong_supported() says so; otherwise PACE_ERR_UNSUPPORTED. */
+  pace_real_t *delp_out, *pt_out, *w_out, *q_con_out;
 } pace_dsw_config_t;
 
 /* ---- FiniteVolumeFluxPrep.__call__ (fv3core/pace/fv3core/stencils/fxadv.py:565-661) ---- */
@@ -151,6 +159,8 @@ int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_
  * object's lifetime (the reference allocates its temporaries in __init__, d_sw.py:765-784);
  * it also carries uc_contra / vc_contra between calls.  col holds HOST arrays. */
 int64_t pace_d_sw_workspace_bytes(const pace_geom_t* geom);
+/* 1 if pace_d_sw* accept separate outputs (pace_dsw_config_t::delp_out ...) for this geometry and these orders, else 0. */
+int pace_d_sw_pingpong_supported(const pace_geom_t* geom, const pace_dsw_config_t* cfg);
 /* Once per object, after zero-filling the workspace: uploads the column namelist (synchronises). */
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream);
 int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,

@@ -249,6 +249,47 @@ __device__ __forceinline__ void deln_run(const DelnMet& M, const double* src, co
   chunk(std::integral_constant<int, DN_H>{}, std::integral_constant<int, DN_RC>{});
 }
 
+// The cells next to / inside the corner regions of the halo -- where the reference reads corner copies, copy_corners_x_nord /
+// _y_nord (delnflux.py:1009-1047): 4 x 4 blocks (minus the one cell that touches no corner) at the corners of the tile domain --
+// one candidate cell per thread (threads 0 .. 63): the divergence with the index-mapped reads.  fix_at: the cell's place in the
+// plane, or -1.
+template <bool FIRST, class MT>
+__device__ __forceinline__ double deln_corner_fix(const Geo& g, const MT& m, const double* src, const double* sdv, const double* sdu,
+                                                  int i0, int j0, double d0, int& fix_at) {
+  const int ilo = i0 - 3, jlo = j0 - 3;
+  auto val = [&](double x) { return FIRST ? d0 * x : x; };
+  auto sgn = [&](double x) { return FIRST ? x : -x; };
+  double fix = 0.0;
+  fix_at = -1;
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int q = tid >> 4, a = tid & 3, b = (tid >> 2) & 3;
+    const int gi = (q & 1) ? g.ie + a : g.is - 3 + a;
+    const int gj = (q & 2) ? g.je + b : g.js - 3 + b;
+    const int ii = gi - ilo, jj = gj - jlo;
+    if (ii >= 0 && ii < DW && jj >= 0 && jj < DH && deln_affected(g, gi, gj)) {
+      fix_at = jj * DWP + ii;
+      const bool valid = ii >= 1 && ii <= DW - 2 && jj >= 1 && jj <= DH - 2 && gi >= 1 && gi + 1 < g.ni && gj >= 1 && gj + 1 < g.nj;
+      if (valid) {
+        auto rd = [&](int i, int j) {
+          const int la = i - ilo, lb = j - jlo;
+          return (la >= 0 && la < DW && lb >= 0 && lb < DH) ? val(src[lb * DWP + la]) : 0.0;
+        };
+        auto X = [&](int i, int j) { remap_agrid_x(g, i, j); return rd(i, j); };
+        auto Y = [&](int i, int j) { remap_agrid_y(g, i, j); return rd(i, j); };
+        const double ra = *(const real*)((const char*)m.rarea + deln_off(g, gi, gj));
+        const double xc = X(gi, gj), yc = Y(gi, gj);
+        const double fw = sgn(sdv[fix_at] * (X(gi - 1, gj) - xc));
+        const double fe = sgn(sdv[fix_at + 1] * (xc - X(gi + 1, gj)));
+        const double fs = sgn(sdu[fix_at] * (Y(gi, gj - 1) - yc));
+        const double fn = sgn(sdu[fix_at + DWP] * (yc - Y(gi, gj + 1)));
+        fix = (fw - fe + fs - fn) * ra;
+      }
+    }
+  }
+  return fix;
+}
+
 // one pass: dst = divergence of the fluxes of src (FIRST: of d0 * src, fluxes as they are; later passes: fluxes negated,
 // delnflux.py:1232-1254 "fx2 = -fx2").  RC: the footprint reaches a corner of the halo and the corner copies apply
 // (block-uniform: the other instance carries none of that logic).  dst == src is allowed: every thread holds its results until
@@ -258,44 +299,13 @@ __device__ __forceinline__ void deln_pass(const Geo& g, const MT& m, const DelnM
                                           const double* __restrict__ sdu, double* dst, int i0, int j0, double d0) {
   const int ilo = i0 - 3, jlo = j0 - 3;
   const bool inplace = dst == src;  // block-uniform
-  auto val = [&](double x) { return FIRST ? d0 * x : x; };
-  auto sgn = [&](double x) { return FIRST ? x : -x; };
   double res[DN_RC];
   const int c = M.c, r0 = M.r0;
   constexpr bool kExact = DH % DN_RC == 0;
   if (M.active) deln_run<FIRST>(M, src, sdv, sdu, d0, res);
-  // the cells next to / inside the corner regions: 4 x 4 blocks (minus the one cell that touches no corner) at the corners of
-  // the tile domain, one candidate cell per thread
   double fix = 0.0;
   int fix_at = -1;
-  if (RC) {
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-      const int q = tid >> 4, a = tid & 3, b = (tid >> 2) & 3;
-      const int gi = (q & 1) ? g.ie + a : g.is - 3 + a;
-      const int gj = (q & 2) ? g.je + b : g.js - 3 + b;
-      const int ii = gi - ilo, jj = gj - jlo;
-      if (ii >= 0 && ii < DW && jj >= 0 && jj < DH && deln_affected(g, gi, gj)) {
-        fix_at = jj * DWP + ii;
-        const bool valid = ii >= 1 && ii <= DW - 2 && jj >= 1 && jj <= DH - 2 && gi >= 1 && gi + 1 < g.ni && gj >= 1 && gj + 1 < g.nj;
-        if (valid) {
-          auto rd = [&](int i, int j) {
-            const int la = i - ilo, lb = j - jlo;
-            return (la >= 0 && la < DW && lb >= 0 && lb < DH) ? val(src[lb * DWP + la]) : 0.0;
-          };
-          auto X = [&](int i, int j) { remap_agrid_x(g, i, j); return rd(i, j); };
-          auto Y = [&](int i, int j) { remap_agrid_y(g, i, j); return rd(i, j); };
-          const double ra = *(const real*)((const char*)m.rarea + deln_off(g, gi, gj));
-          const double xc = X(gi, gj), yc = Y(gi, gj);
-          const double fw = sgn(sdv[fix_at] * (X(gi - 1, gj) - xc));
-          const double fe = sgn(sdv[fix_at + 1] * (xc - X(gi + 1, gj)));
-          const double fs = sgn(sdu[fix_at] * (Y(gi, gj - 1) - yc));
-          const double fn = sgn(sdu[fix_at + DWP] * (yc - Y(gi, gj + 1)));
-          fix = (fw - fe + fs - fn) * ra;
-        }
-      }
-    }
-  }
+  if (RC) fix = deln_corner_fix<FIRST>(g, m, src, sdv, sdu, i0, j0, d0, fix_at);
   if (inplace) __syncthreads();
   if (M.active) {
 #pragma unroll

@@ -1,25 +1,25 @@
+// FiniteVolumeTransport for the production tilings -- the lean form of k_fvtp2d.hip (same arithmetic, same bits) -- and the
+// scalar phase of d_sw (delp, w, q_con, pt) as ONE kernel built from the same stages.
 // (device code of k_fvt.hip; tools/census/ instantiates single tile variants of it for the instruction census)
-// FiniteVolumeTransport for the production tilings -- the lean form of k_fvtp2d.hip (same arithmetic, same bits).
 // Reference: fv3core/pace/fv3core/stencils/fvtp2d.py:262-345, xppm.py:148-181 / yppm.py, delnflux.py:1005-1261,
-// d_sw.py:63-145.
+// d_sw.py:63-201,331-350.
 //
-// Why a second kernel.  Measured on MI355X (tools/ubench, profiles/r04_ubench.txt): ONE wave issues at most one instruction
-// every ~8 cycles, whatever its kind and whether or not it depends on the previous one; four waves per SIMD share an fp64 pipe
-// of ~3.6 cycles per wave-instruction, a 32-bit pipe of ~1.9 and a scalar unit of ~1 per cycle per CU.  The general kernel
-// walks ~4 500 instructions per wave of which ~730 are fp64 arithmetic -- a lone workgroup takes exactly 8 cycles x 4 500 --
-// so its time is its instruction COUNT, and five sixths of that count is position arithmetic, predicates (exec-mask
-// bookkeeping on the scalar unit), selects and spilled-SGPR traffic.  This kernel removes those instead of tuning stages:
-//  * only tilings that put every tile edge on a workgroup-tile boundary (N a multiple of TI and TJ: C96, C192, C384 with
-//    32 x 24) -- the footprint of every tile lies inside the storage, so no load, store or value is predicated;
-//  * a thread's place in every stage is fixed once per workgroup (one y-run and one x-run), LDS and global offsets are
-//    compile-time immediates on two base registers each;
-//  * three barrier intervals instead of seven: [inner y sweep + q_i | inner x sweep + q_j] -> [outer x | outer y] -> cell
-//    update; a run is C = 4 cells with its C + 1 interfaces (neighbouring runs both evaluate the shared interface), so the
-//    inner fluxes stay in the registers of the thread that needs them again in the outer sweep;
-//  * the footprint is loaded 16 bytes per lane;
-//  * w's damping fluxes are never formed at the faces: dw / heat_source / diss_est (heat_diss, d_sw.py:63-103) are one more
-//    divergence of the damping iterate on the thread's own column run, stored from there.
-// Other tilings, ord 8 and the float32 build take k_fvtp2d.hip.
+// What the measurements of round 4 say (tools/ubench, profiles/r04_ubench.txt):
+//  * ONE wave issues at most one instruction every ~8 cycles, whatever its kind; four waves per SIMD share an fp64 pipe of
+//    ~3.6 cycles per wave-instruction, a 32-bit pipe of ~1.9, a scalar unit of ~1 per cycle per CU.  The general kernel walks
+//    ~4 500 instructions per wave of which ~730 are fp64 arithmetic; the rest is position arithmetic, predicates (exec-mask
+//    bookkeeping on the scalar unit), selects and spilled-SGPR traffic.
+//  * Removing 60 % of those instructions (this file's single-scalar kernel: ~1 900 per wave) did NOT shorten the launch: the
+//    transport launches move their L2-miss bytes at 3.5 - 4 TB/s, three quarters of what a device copy reaches on this chip
+//    (4.8 - 5.0 TB/s) -- they are bound by the bytes they really move (1.5 x the algorithmic ones per launch, and every scalar
+//    of d_sw moves the Courant numbers, area fluxes, mass fluxes and the mass again), not by the algorithmic bytes.
+// So: (1) the lean stages below -- fixed thread places, no predication (only tilings that put every tile edge on a
+// workgroup-tile boundary: N a multiple of TI and TJ, every footprint inside the storage), three barrier intervals per
+// scalar instead of seven, 16-byte footprint loads -- and (2) fvt_scalars_tile: one workgroup takes its tile through delp,
+// w, q_con and pt back to back, the mass fluxes of delp stay in the registers of the threads that need them as unit fluxes,
+// the new delp divides the other three in the same workgroup (apply_pt_delp_fluxes / adjust_w_and_qcon, d_sw.py:148-201,
+// 331-350: no k_finish_scalars pass, no flux-form intermediates), results go to buffers of their own (the neighbouring tiles
+// still read the old values).  Other tilings, ord 8 and the float32 build take k_fvtp2d.hip.
 #pragma once
 #include "common.h"
 #include "kernels.h"
@@ -42,19 +42,18 @@
 #endif
 
 #if FVT_AVAILABLE
-namespace {
+namespace fvt {
 
 constexpr int TI = FV_TI, TJ = FV_TJ;
-constexpr int C = 4;                      // cells per run
-constexpr int NF = C + 1;                 // interfaces per run
+constexpr int C = 4;                       // cells per run
+constexpr int NF = C + 1;                  // interfaces per run
 constexpr int GXN = TI / C, GYN = TJ / C;  // runs per row / column of the tile
 constexpr int QW = TI + 6, QH = TJ + 6;    // footprint
 constexpr int P = QW + 1;                  // pitch of sq, sqi and the damping planes
 constexpr int PJ = TI + 1;                 // pitch of sqj and ax
 constexpr int NYO = TI * GYN;              // threads 0 .. NYO-1: the y-runs of the tile's own columns (they run the outer y sweep too)
 constexpr int NYH = 6 * GYN;               // then the y-runs of the six halo columns
-constexpr int NXO = TJ * GXN;              // threads 0 .. NXO-1: the x-runs of the tile's own rows
-constexpr int NXA = QH * GXN;              // ... NXA-1: all x-runs
+constexpr int NEC = (TI * TJ + 255) / 256;  // cells per thread in the cell update
 static_assert(DW == QW && DH == QH && DWP == P, "the damping core shares the footprint");
 static_assert(GXN >= 2 && GYN >= 2, "the first and the last run of a row / column must be different runs");
 
@@ -69,13 +68,29 @@ struct FvtLds {
     struct {
       double sqi[TJ * P];        // q advected in y, tile rows x footprint columns
       double sqj[QH * PJ];       // q advected in x, footprint rows x tile columns
-      double ax[TJ * PJ];        // final x-face fluxes (EPI 1)
+      double ax[TJ * PJ];        // final x-face fluxes (cell update)
       double ay[(TJ + 1) * TI];  // final y-face fluxes
     } s;
     double scratch[3 * QH * P];  // damping: iterate, del6_v, del6_u
   } u;
   double pad1[P];
   double sqc[9];  // the tile's corner block with corners copied in x (corner tiles)
+};
+
+// order pin for the instruction scheduler (register pressure: operands that are only needed after a PPM run are loaded after it)
+#ifdef PACE_EMU
+#define FVT_FENCE()
+#else
+#define FVT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+// ... of the scalar-phase kernel (two workgroups per CU: 80 KB each): the transport's arrays, the mass on the tile and one cell
+// around it (the mass-weighted damping of q_con and pt reads it at the faces, the cell update at the cells), and ten doubles
+// per thread that would otherwise be spilled registers (the damping fluxes of the thread's faces while the inner sweeps run)
+constexpr int MP = TI + 3;  // pitch of the mass tile
+struct FvtLdsScalars {
+  FvtLds t;
+  double mass[(TJ + 2) * MP];
+  double priv[2 * NF][256];
 };
 
 #define LDG(p, off) (*(const real*)((const char*)(p) + (off)))
@@ -147,7 +162,7 @@ __device__ __forceinline__ void fvt_deln_run(const double* p, const double* pv, 
   chunk(std::integral_constant<int, H>{}, std::integral_constant<int, DN_RC>{});
 }
 
-// a footprint-sized plane of a 2-D field, 16 bytes per lane (the pieces stage 0 loads of q)
+// a footprint-sized plane of a field, 16 bytes per lane
 struct FvtPieces {
   static constexpr int HW = QW / 2;             // 16-byte pieces per row
   static constexpr int RPP = 256 / HW;          // rows per pass
@@ -156,7 +171,7 @@ struct FvtPieces {
   unsigned off[NP];
   // whether piece p of this thread is a piece of its own (not a clamped repeat of another thread's)
   __device__ __forceinline__ bool own(int p) const { return lr0 < RPP && lr0 + RPP * p < QH; }
-  __device__ __forceinline__ FvtPieces(int tid, int ilo, int jlo, int sj8) {
+  __device__ __forceinline__ void init(int tid, int ilo, int jlo, int sj8) {
     int lr = tid / HW;
     lc = tid - lr * HW;
     lr0 = lr;
@@ -181,59 +196,90 @@ struct FvtPieces {
   }
 };
 
-// DMODE: -1 transport only; 0 damping fluxes -> dp.fx2o / fy2o (+ dp.add2d, u / v update: the vorticity call of d_sw);
-// 1 damping fluxes added to the transport fluxes; 2 added mass-weighted; 3 damping of q -> dw / heat_s / diss_est only (w).
-// EPI 0: fluxes stored (or accumulated / turned into winds); 1: flux-form update of the cell stored.
-template <int MORD, int DMODE, int EPI, bool EX, bool EY>
-__device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m, const real* __restrict__ q,
-                                         const real* __restrict__ crx, const real* __restrict__ cry,
-                                         const real* __restrict__ xfx, const real* __restrict__ yfx, real* __restrict__ fx,
-                                         real* __restrict__ fy, const real* __restrict__ xunit,
-                                         const real* __restrict__ yunit, const FvDamp& dp, int bx, int by, int k) {
-  const int tid = threadIdx.x;
-  const int i0 = g.is + bx * TI, j0 = g.js + by * TJ;
-  const int ilo = i0 - 3, jlo = j0 - 3;
-  const int sj8 = g.sj * 8;
-  const long kb = (long)k * g.sk;
-  q += kb, crx += kb, cry += kb, xfx += kb, yfx += kb, xunit += kb, yunit += kb;
-  // which edges of the cubed-sphere tile this workgroup tile holds (block-uniform; one per axis at most: >= 2 tiles each way)
-  const bool west = EX && bx == 0, east = EX && !west;
-  const bool south = EY && by == 0, north = EY && !south;
+// The stages of one tile.  EX / EY: the tile holds a west or east / south or north edge of the cubed-sphere tile (block-uniform).
+template <int MORD, bool EX, bool EY>
+struct FvtTile {
+  static constexpr bool RC = EX && EY;  // the footprint reaches a corner of the halo: the corner copies apply
+  FvtLds& L;
+  const Geo& g;
+  const FvMet& m;
+  int tid, i0, j0, ilo, jlo, sj8, k;
+  unsigned kb8;  // byte offset of the level
+  bool west, east, south, north;
+  // the thread's places: one y-run (column ycol of the footprint, rows C*yg ..), one x-run (row xrow, columns C*xg ..)
+  int ycol, yg, xr, xg, xrow;
+  bool y_on, y_outer, x_on, x_outer;
+  int ybase, xbase;     // sq / sqi / damping planes: element (row C*yg, column ycol); sq: element (row xrow, column C*xg)
+  unsigned yoff, xoff;  // byte offsets in a level: the y-run's first interface (ilo + ycol, j0 + C*yg), the x-run's (i0 + C*xg, jlo + xrow)
+  FvtPieces pc;
+  // the thread's column run of the damping: column dc, rows dr0 .. dr0 + DN_RC - 1 of the footprint
+  int dc, dr0, dbase;
+  bool dn_on;
+  double dra[DN_RC];
+  double *plane, *sdv, *sdu;
 
-  // ---- the thread's places: one y-run (column ycol of the footprint, rows C*yg ..), one x-run (row xrow, columns C*xg ..) ----
-  int ycol, yg;
-  bool y_on = true;
-  if (tid < NYO) {
-    yg = tid / TI;
-    ycol = 3 + (tid - yg * TI);
-  } else {
-    const int r = tid - NYO;
-    y_on = r < NYH;
-    yg = y_on ? r / 6 : 0;
-    const int h = y_on ? r - yg * 6 : 0;
-    ycol = h < 3 ? h : TI + h;
+  __device__ __forceinline__ FvtTile(FvtLds& L_, const Geo& g_, const FvMet& m_, int bx, int by, int k_, int tid_) : L(L_), g(g_), m(m_) {
+    tid = tid_;
+    k = k_;
+    i0 = g.is + bx * TI, j0 = g.js + by * TJ;
+    ilo = i0 - 3, jlo = j0 - 3;
+    sj8 = g.sj * 8;
+    kb8 = (unsigned)((long)k * g.sk * 8);
+    // which edges of the cubed-sphere tile this workgroup tile holds (one per axis at most: >= 2 tiles each way)
+    west = EX && bx == 0, east = EX && !west;
+    south = EY && by == 0, north = EY && !south;
+    y_on = true;
+    if (tid < NYO) {
+      yg = tid / TI;
+      ycol = 3 + (tid - yg * TI);
+    } else {
+      const int r = tid - NYO;
+      y_on = r < NYH;
+      yg = y_on ? r / 6 : 0;
+      const int h = y_on ? r - yg * 6 : 0;
+      ycol = h < 3 ? h : TI + h;
+    }
+    y_outer = tid < NYO;
+    xr = tid / GXN, xg = tid - xr * GXN;
+    x_on = xr < QH, x_outer = xr < TJ;
+    xrow = xr + 3;  // the tile's own rows first: footprint rows 3 .. TJ+2, then TJ+3 .. QH-1, then 0 .. 2
+    if (xrow >= QH) xrow -= QH;
+    if (!x_on) xrow = 0;
+    ybase = (C * yg) * P + ycol;
+    xbase = xrow * P + C * xg;
+    yoff = (unsigned)((j0 + C * yg) * sj8 + (ilo + ycol) * 8);
+    xoff = (unsigned)((jlo + xrow) * sj8 + (i0 + C * xg) * 8);
+    pc.init(tid, ilo, jlo, sj8);
+    const int dr = tid / QW;
+    dc = tid - dr * QW;
+    dn_on = dr < DN_NR;
+    dr0 = dn_on ? dr * DN_RC : 0;
+    dbase = dr0 * P + dc;
+    plane = L.u.scratch;
+    sdv = plane + QH * P;
+    sdu = sdv + QH * P;
   }
-  const bool y_outer = tid < NYO;
-  const int xr = tid / GXN, xg = tid - xr * GXN;
-  const bool x_on = xr < QH, x_outer = xr < TJ;
-  int xrow = xr + 3;  // the tile's own rows first: footprint rows 3 .. TJ+2, then TJ+3 .. QH-1, then 0 .. 2
-  if (xrow >= QH) xrow -= QH;
-  if (!x_on) xrow = 0;
-  const int ybase = (C * yg) * P + ycol;  // sq / sqi / damping planes: element (row C*yg, column ycol)
-  const int xbase = xrow * P + C * xg;    // sq: element (row xrow, column C*xg)
-  // byte offsets in a level: the y-run's first interface (ilo + ycol, j0 + C*yg), the x-run's (i0 + C*xg, jlo + xrow)
-  const unsigned yoff = (unsigned)((j0 + C * yg) * sj8 + (ilo + ycol) * 8);
-  const unsigned xoff = (unsigned)((jlo + xrow) * sj8 + (i0 + C * xg) * 8);
 
-  // ---- stage 0: the footprint (and the damping metrics), 16 bytes per lane (rows start 16-byte aligned: ilo = TI * bx, sj even) ----
-  const FvtPieces pc(tid, ilo, jlo, sj8);
-  double* const plane = L.u.scratch;
-  double* const sdv = plane + QH * P;
-  double* const sdu = sdv + QH * P;
-  {
+  // ---- stage 0: the footprint of q (level base applied), 16 bytes per lane (rows start 16-byte aligned: ilo = TI * bx, sj even).
+  // No barrier here.
+  // halo_out (edge tiles of the scalar phase): the footprint's cells outside the compute domain are copied there as they are, so
+  // that the output buffer ends up with the halo the input has (the reference updates its fields in place).
+  __device__ __forceinline__ void load_footprint(const real* __restrict__ q, real* __restrict__ halo_out = nullptr) {
     D2 v[FvtPieces::NP];
     pc.load(q, v);
-    if (EX && EY) {  // corner tile: the corner block holds the values copy_corners_y puts there (corners.py:367-425)
+    if ((EX || EY) && halo_out) {
+#pragma unroll
+      for (int p = 0; p < FvtPieces::NP; ++p) {
+        const int gj = jlo + pc.row[p];
+        const bool rowout = gj < g.js || gj > g.je;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int gi = ilo + 2 * pc.lc + e;
+          if (pc.own(p) && (rowout || gi < g.is || gi > g.ie)) STG(halo_out, pc.off[p] + (unsigned)(8 * e)) = e == 0 ? v[p].x : v[p].y;
+        }
+      }
+    }
+    if (RC) {  // corner tile: the corner block holds the values copy_corners_y puts there (corners.py:367-425)
 #pragma unroll
       for (int p = 0; p < FvtPieces::NP; ++p) {
         const int gj = jlo + pc.row[p];
@@ -257,233 +303,366 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
       }
     }
     pc.store(L.sq, v);
-    if (DMODE >= 0) {
-      D2 mv[FvtPieces::NP], mu[FvtPieces::NP];
-      pc.load(m.del6_v, mv);
-      pc.load(m.del6_u, mu);
-      pc.store(sdv, mv);
-      pc.store(sdu, mu);
+  }
+  // del6_v, del6_u on the footprint -> sdv, sdu; rarea of the thread's damping run
+  __device__ __forceinline__ void stage_damping_metrics() {
+    D2 mv[FvtPieces::NP], mu[FvtPieces::NP];
+    pc.load(m.del6_v, mv);
+    pc.load(m.del6_u, mu);
+    pc.store(sdv, mv);
+    pc.store(sdu, mu);
+#pragma unroll
+    for (int t = 0; t < DN_RC; ++t) {
+      int row = dr0 + t;
+      if (QH % DN_RC != 0 && row >= QH) row = QH - 1;
+      dra[t] = LDG(m.rarea, (unsigned)((jlo + row) * sj8 + (ilo + dc) * 8));
     }
   }
-  // the thread's column run of the damping: column dc, rows dr0 .. dr0 + DN_RC - 1 of the footprint
-  const int dr = tid / QW, dc = tid - dr * QW;
-  const bool dn_on = dr < DN_NR;
-  const int dr0 = dn_on ? dr * DN_RC : 0;
-  const int dbase = dr0 * P + dc;
-  double dra[DN_RC];
-  DelnMet DM;
-  constexpr bool RC = EX && EY;  // the footprint reaches a corner of the halo: the corner copies apply (delnflux_core.h)
-  if (DMODE >= 0) {
-    if (RC) {
-      deln_load(g, m, i0, j0, DM);
-    } else {
-#pragma unroll
-      for (int t = 0; t < DN_RC; ++t) {
-        int row = dr0 + t;
-        if (QH % DN_RC != 0 && row >= QH) row = QH - 1;
-        dra[t] = LDG(m.rarea, (unsigned)((jlo + row) * sj8 + (ilo + dc) * 8));
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- the del-n damping of q on the footprint (delnflux.py:1209-1261); this thread's face values stay in registers ----
-  double dvx[NF], dvy[NF];
-  double damp = 0.0;
-  if (DMODE >= 0) {
-    damp = dp.damp_k[k];
-    const double d0 = dp.mass_given ? 1.0 : damp;
-    const bool hi_order = dp.nord_k[k] > 0.0;
-    const int iters = hi_order ? dp.nmax : 0;
-    if (RC) {
-      (void)deln_iterate(g, m, DM, L.sq, sdv, sdu, plane, i0, j0, d0, hi_order, dp.nmax);
-    } else {
-      for (int it = 0; it < iters; ++it) {
-        double res[DN_RC];
-        if (dn_on) {
-          if (it == 0) fvt_deln_run<true>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
-          else fvt_deln_run<false>(plane + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
-        }
-        if (it > 0) __syncthreads();  // (in place: everyone has read the iterate)
-        if (dn_on) {
-#pragma unroll
-          for (int t = 0; t < DN_RC; ++t)
-            if (QH % DN_RC == 0 || dr0 + t < QH) plane[dbase + t * P] = res[t];
-        }
-        __syncthreads();
-      }
-    }
-    // the damping flux through a face from the last iterate (first == no pass ran: the first flux evaluation, of d0 * q)
-    const bool first = iters == 0;
-    const double* const last = first ? L.sq : plane;
-    auto face = [&](double metric, double a, double b) { return first ? metric * (d0 * a - d0 * b) : -(metric * (a - b)); };
-    if (DMODE != 3) {
-      if (x_outer) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) dvx[f] = face(sdv[xbase + f + 3], last[xbase + f + 2], last[xbase + f + 3]);
-      }
-      if (y_outer) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) dvy[f] = face(sdu[ybase + (f + 3) * P], last[ybase + (f + 2) * P], last[ybase + (f + 3) * P]);
-      }
-    } else if (dn_on) {
-      // heat_diss (d_sw.py:63-103): dw = divergence of the damping fluxes / area -- one more divergence of the iterate on this
-      // thread's column run (the same expression, in the same order, as the flux-difference form of the general kernel)
-      double res[DN_RC];
-      if (RC) {
-#pragma unroll
-        for (int t = 0; t < DN_RC; ++t) dra[t] = DM.ra[t];
-      }
-      if (first) fvt_deln_run<true>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
-      else fvt_deln_run<false>(plane + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
-      const bool on = dp.damp_w_k[k] > 1e-5;
-      const double dd8 = dp.ke_bg_k[k] * fabs(dp.dt);
-      if (dc >= 3 && dc < TI + 3) {
-#pragma unroll
-        for (int t = 0; t < DN_RC; ++t) {
-          const int jj = dr0 + t;
-          if (jj >= 3 && jj < TJ + 3) {
-            const unsigned c = (unsigned)(kb * 8) + (unsigned)((jlo + jj) * sj8 + (ilo + dc) * 8);
-            double hs = 0.0;
-            if (on) {
-              const double d = res[t];
-              const double qv = L.sq[jj * P + dc];
-              STG(dp.dw, c) = d;
-              hs = dd8 - d * (qv + 0.5 * d);
-            }
-            STG(dp.heat_s, c) = hs;
-            STG(dp.diss_est, c) = hs;
-          }
-        }
-      }
-    }
-    __syncthreads();  // the sweeps overwrite the damping planes
-  }
-  if (DMODE == 0 && dp.add2d) {
-    // the transported scalar is q + add2d (absolute vorticity), the damped one was q: every thread adds to the pieces it loaded
+  // the transported scalar is q + add2d (absolute vorticity), the damped one was q: every thread adds to the pieces it loaded.
+  // Ends with a barrier.
+  __device__ __forceinline__ void add_2d(const real* __restrict__ add2d) {
     D2 v[FvtPieces::NP];
-    pc.load(dp.add2d, v);
+    pc.load(add2d, v);
 #pragma unroll
     for (int p = 0; p < FvtPieces::NP; ++p) {
       if (pc.own(p)) {  // (each piece once: the clamped repeats would add twice)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           double add = e == 0 ? v[p].x : v[p].y;
-          if (EX && EY) {
+          if (RC) {
             int gi = ilo + 2 * pc.lc + e, gj = jlo + pc.row[p];
             if ((gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) {
               remap_agrid_y(g, gi, gj);
-              add = LDG(dp.add2d, (unsigned)(gj * sj8 + gi * 8));
+              add = LDG(add2d, (unsigned)(gj * sj8 + gi * 8));
             }
           }
           L.sq[pc.row[p] * P + 2 * pc.lc + e] = L.sq[pc.row[p] * P + 2 * pc.lc + e] + add;
         }
       }
     }
-    if (EX && EY && tid < 9) {
+    if (RC && tid < 9) {
       const int b = tid / 3, a = tid - b * 3;
       int ri = (west ? g.is - 3 : g.ie + 1) + a, rj = (south ? g.js - 3 : g.je + 1) + b;
       remap_agrid_x(g, ri, rj);
-      L.sqc[tid] = L.sqc[tid] + LDG(dp.add2d, (unsigned)(rj * sj8 + ri * 8));
+      L.sqc[tid] = L.sqc[tid] + LDG(add2d, (unsigned)(rj * sj8 + ri * 8));
     }
     __syncthreads();
   }
 
-  // ---- stage I: the inner sweeps and the advected fields (fvtp2d.py:34-77) ----
-  double si_y[NF], si_x[NF], cy[NF], cx[NF];
-  if (y_on) {  // YPiecewiseParabolic on the run's five interfaces, then q_i of the four cells between them
-    double Q[NF + 5], yf[NF], ar[C];
-#pragma unroll
-    for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[ybase + u * P];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      cy[f] = LDG(cry, yoff + (unsigned)(f * sj8));
-      yf[f] = LDG(yfx, yoff + (unsigned)(f * sj8));
-    }
-#pragma unroll
-    for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, yoff + (unsigned)(t * sj8));
-    EdgeSpacing sp;
-    if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
-    fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, si_y);
-#pragma unroll
-    for (int t = 0; t < C; ++t)
-      L.u.s.sqi[ybase + t * P] = (Q[t + 3] * ar[t] + yf[t] * si_y[t] - yf[t + 1] * si_y[t + 1]) / (ar[t] + yf[t] - yf[t + 1]);
-  }
-  if (x_on) {  // XPiecewiseParabolic, then q_j
-    double Q[NF + 5], xf[NF], ar[C];
-#pragma unroll
-    for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[xbase + u];
-    if (EX && EY) {  // halo rows of a corner tile: the three corner columns hold the x-direction copies
-      const bool halo_row = south ? xrow < 3 : xrow >= TJ + 3;
-      const int b = south ? xrow : xrow - (TJ + 3);
-      if (halo_row && west && xg == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) Q[a] = L.sqc[b * 3 + a];
+  // ---- the del-n damping of q on the footprint (delnflux.py:1209-1261).  Call after the barrier that follows stage 0; on return
+  // (after a barrier if a pass ran) the last iterate is in `last` (q itself if no pass ran: `first`).
+  struct Damped {
+    const double* last;
+    double d0;
+    bool first;
+  };
+  __device__ __forceinline__ Damped damp(double d0, bool hi_order, int nmax) {
+    const int iters = hi_order ? nmax : 0;
+    for (int it = 0; it < iters; ++it) {
+      double res[DN_RC];
+      double fix = 0.0;
+      int fix_at = -1;
+      if (dn_on) {
+        if (it == 0) fvt_deln_run<true>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
+        else fvt_deln_run<false>(plane + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
       }
-      if (halo_row && east && xg == GXN - 1) {
+      if (RC) {  // corner tile: the cells whose stencil reaches into a corner region, with the corner copies (delnflux_core.h)
+        if (it == 0) fix = deln_corner_fix<true>(g, m, L.sq, sdv, sdu, i0, j0, d0, fix_at);
+        else fix = deln_corner_fix<false>(g, m, plane, sdv, sdu, i0, j0, d0, fix_at);
+      }
+      if (it > 0) __syncthreads();  // (in place: everyone has read the iterate)
+      if (dn_on) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) Q[NF + 2 + a] = L.sqc[b * 3 + a];
+        for (int t = 0; t < DN_RC; ++t)
+          if (QH % DN_RC == 0 || dr0 + t < QH) plane[dbase + t * P] = res[t];
+      }
+      if (RC) {
+        __syncthreads();  // (the runs have written those cells as if they were interior cells: overwrite)
+        if (fix_at >= 0) plane[fix_at] = fix;
+      }
+      __syncthreads();
+    }
+    return Damped{iters == 0 ? L.sq : plane, d0, iters == 0};
+  }
+  // the damping flux through a face from the last iterate (first: the first flux evaluation, of d0 * q)
+  __device__ __forceinline__ static double face(const Damped& D, double metric, double a, double b) {
+    return D.first ? metric * (D.d0 * a - D.d0 * b) : -(metric * (a - b));
+  }
+  __device__ __forceinline__ void damping_faces(const Damped& D, double* dvx, double* dvy) const {
+    if (x_outer) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) dvx[f] = face(D, sdv[xbase + f + 3], D.last[xbase + f + 2], D.last[xbase + f + 3]);
+    }
+    if (y_outer) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) dvy[f] = face(D, sdu[ybase + (f + 3) * P], D.last[ybase + (f + 2) * P], D.last[ybase + (f + 3) * P]);
+    }
+  }
+  // heat_diss (d_sw.py:63-103): dw = divergence of the damping fluxes / area -- one more divergence of the iterate on this thread's
+  // column run (the same expression, in the same order, as the flux-difference form of the general kernel) --, heat_source and
+  // diss_est from it; stored for the tile's cells of the run (level offsets applied by the caller)
+  __device__ __forceinline__ void heat_diss(const Damped& D, real* __restrict__ dw, real* __restrict__ heat_s,
+                                            real* __restrict__ diss_est, bool on, double dd8) {
+    if (!dn_on) return;
+    double res[DN_RC];
+    if (D.first) fvt_deln_run<true>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, D.d0, res);
+    else fvt_deln_run<false>(plane + dbase, sdv + dbase, sdu + dbase, dra, D.d0, res);
+    if (dc >= 3 && dc < TI + 3) {
+#pragma unroll
+      for (int t = 0; t < DN_RC; ++t) {
+        const int jj = dr0 + t;
+        if (jj >= 3 && jj < TJ + 3) {
+          const unsigned c = (unsigned)((jlo + jj) * sj8 + (ilo + dc) * 8);
+          double hs = 0.0;
+          if (on) {
+            const double d = res[t];
+            const double qv = L.sq[jj * P + dc];
+            STG(dw, c) = d;
+            hs = dd8 - d * (qv + 0.5 * d);
+          }
+          STG(heat_s, c) = hs;
+          STG(diss_est, c) = hs;
+        }
       }
     }
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      cx[f] = LDG(crx, xoff + (unsigned)(f * 8));
-      xf[f] = LDG(xfx, xoff + (unsigned)(f * 8));
-    }
-#pragma unroll
-    for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, xoff + (unsigned)(t * 8));
-    EdgeSpacing sp;
-    if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
-    fvt_run<MORD, EX>(Q, cx, west && xg == 0, east && xg == GXN - 1, sp, si_x);
-#pragma unroll
-    for (int t = 0; t < C; ++t)
-      L.u.s.sqj[xrow * PJ + C * xg + t] = (Q[t + 3] * ar[t] + xf[t] * si_x[t] - xf[t + 1] * si_x[t + 1]) / (ar[t] + xf[t] - xf[t + 1]);
   }
-  __syncthreads();
 
-  // ---- stage II: the outer sweeps and the final fluxes (fvtp2d.py:80-119) ----
-  const unsigned kb8 = (unsigned)(kb * 8);
-  if (x_outer) {  // outer x on q_i, tile row xr (= footprint row xrow), faces i0 + C*xg + f
-    double Q[NF + 5], out[NF], xu[NF], v[NF];
+  // ---- stage I: the inner sweeps and the advected fields (fvtp2d.py:34-77); pointers with the level applied.  Ends with a barrier.
+  __device__ __forceinline__ void inner(const real* __restrict__ crx, const real* __restrict__ cry, const real* __restrict__ xfx,
+                                        const real* __restrict__ yfx, double* si_x, double* si_y, double* cx, double* cy) {
+    if (y_on) {  // YPiecewiseParabolic on the run's five interfaces, then q_i of the four cells between them
+      double Q[NF + 5], yf[NF], ar[C];
+#pragma unroll
+      for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[ybase + u * P];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) cy[f] = LDG(cry, yoff + (unsigned)(f * sj8));
+      EdgeSpacing sp;
+      if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
+      fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, si_y);
+      FVT_FENCE();
+#pragma unroll
+      for (int f = 0; f < NF; ++f) yf[f] = LDG(yfx, yoff + (unsigned)(f * sj8));
+#pragma unroll
+      for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, yoff + (unsigned)(t * sj8));
+#pragma unroll
+      for (int t = 0; t < C; ++t)
+        L.u.s.sqi[ybase + t * P] = (Q[t + 3] * ar[t] + yf[t] * si_y[t] - yf[t + 1] * si_y[t + 1]) / (ar[t] + yf[t] - yf[t + 1]);
+    }
+    FVT_FENCE();
+    if (x_on) {  // XPiecewiseParabolic, then q_j
+      double Q[NF + 5], xf[NF], ar[C];
+#pragma unroll
+      for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[xbase + u];
+      if (RC) {  // halo rows of a corner tile: the three corner columns hold the x-direction copies
+        const bool halo_row = south ? xrow < 3 : xrow >= TJ + 3;
+        const int b = south ? xrow : xrow - (TJ + 3);
+        if (halo_row && west && xg == 0) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) Q[a] = L.sqc[b * 3 + a];
+        }
+        if (halo_row && east && xg == GXN - 1) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) Q[NF + 2 + a] = L.sqc[b * 3 + a];
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) cx[f] = LDG(crx, xoff + (unsigned)(f * 8));
+      EdgeSpacing sp;
+      if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
+      fvt_run<MORD, EX>(Q, cx, west && xg == 0, east && xg == GXN - 1, sp, si_x);
+      FVT_FENCE();
+#pragma unroll
+      for (int f = 0; f < NF; ++f) xf[f] = LDG(xfx, xoff + (unsigned)(f * 8));
+#pragma unroll
+      for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, xoff + (unsigned)(t * 8));
+#pragma unroll
+      for (int t = 0; t < C; ++t)
+        L.u.s.sqj[xrow * PJ + C * xg + t] = (Q[t + 3] * ar[t] + xf[t] * si_x[t] - xf[t + 1] * si_x[t + 1]) / (ar[t] + xf[t] - xf[t + 1]);
+    }
+    __syncthreads();
+  }
+
+  // The operands of the inner sweeps that do not depend on the scalar: the Courant numbers and area fluxes of the thread's five
+  // y- and five x-faces, the areas of its cells (pointers with the level applied).  The scalar-phase kernel loads them once.
+  struct SweepOperands {
+    double cx[NF], cy[NF], xf[NF], yf[NF], arx[C], ary[C];
+  };
+  __device__ __forceinline__ void load_sweep_operands(const real* __restrict__ crx, const real* __restrict__ cry,
+                                                      const real* __restrict__ xfx, const real* __restrict__ yfx, SweepOperands& o) const {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      o.cy[f] = LDG(cry, yoff + (unsigned)(f * sj8));
+      o.yf[f] = LDG(yfx, yoff + (unsigned)(f * sj8));
+      o.cx[f] = LDG(crx, xoff + (unsigned)(f * 8));
+      o.xf[f] = LDG(xfx, xoff + (unsigned)(f * 8));
+    }
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+      o.ary[t] = LDG(m.area, yoff + (unsigned)(t * sj8));
+      o.arx[t] = LDG(m.area, xoff + (unsigned)(t * 8));
+    }
+  }
+  // stage I with the operands given.  Ends with a barrier.
+  __device__ __forceinline__ void inner_with(const SweepOperands& o, double* si_x, double* si_y) {
+    if (y_on) {
+      double Q[NF + 5];
+#pragma unroll
+      for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[ybase + u * P];
+      EdgeSpacing sp;
+      if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
+      fvt_run<MORD, EY>(Q, o.cy, south && yg == 0, north && yg == GYN - 1, sp, si_y);
+#pragma unroll
+      for (int t = 0; t < C; ++t)
+        L.u.s.sqi[ybase + t * P] = (Q[t + 3] * o.ary[t] + o.yf[t] * si_y[t] - o.yf[t + 1] * si_y[t + 1]) / (o.ary[t] + o.yf[t] - o.yf[t + 1]);
+    }
+    if (x_on) {
+      double Q[NF + 5];
+#pragma unroll
+      for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[xbase + u];
+      if (RC) {  // halo rows of a corner tile: the three corner columns hold the x-direction copies
+        const bool halo_row = south ? xrow < 3 : xrow >= TJ + 3;
+        const int b = south ? xrow : xrow - (TJ + 3);
+        if (halo_row && west && xg == 0) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) Q[a] = L.sqc[b * 3 + a];
+        }
+        if (halo_row && east && xg == GXN - 1) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) Q[NF + 2 + a] = L.sqc[b * 3 + a];
+        }
+      }
+      EdgeSpacing sp;
+      if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
+      fvt_run<MORD, EX>(Q, o.cx, west && xg == 0, east && xg == GXN - 1, sp, si_x);
+#pragma unroll
+      for (int t = 0; t < C; ++t)
+        L.u.s.sqj[xrow * PJ + C * xg + t] = (Q[t + 3] * o.arx[t] + o.xf[t] * si_x[t] - o.xf[t + 1] * si_x[t + 1]) / (o.arx[t] + o.xf[t] - o.xf[t + 1]);
+    }
+    __syncthreads();
+  }
+
+  // ---- stage II: the outer sweeps (fvtp2d.py:80-119): the mean advected value through the run's five faces, 0.5 * (outer + inner).
+  // x: on q_i, tile row xr (= footprint row xrow), faces i0 + C*xg + f.  Only for x_outer threads.
+  __device__ __forceinline__ void outer_x(const double* cx, const double* si_x, double* mean) const {
+    double Q[NF + 5], out[NF];
 #pragma unroll
     for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqi[xr * P + C * xg + u];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) xu[f] = LDG(xunit, xoff + (unsigned)(f * 8));
-    double ms[NF + 1];
-    if (DMODE == 2) {
-#pragma unroll
-      for (int t = 0; t <= NF; ++t) ms[t] = LDG(dp.mass, kb8 + xoff + (unsigned)((t - 1) * 8));
-    }
     EdgeSpacing sp;
     if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
     fvt_run<MORD, EX>(Q, cx, west && xg == 0, east && xg == GXN - 1, sp, out);
 #pragma unroll
+    for (int f = 0; f < NF; ++f) mean[f] = 0.5 * (out[f] + si_x[f]);
+  }
+  // y: on q_j, tile column ycol - 3, faces j0 + C*yg + f.  Only for y_outer threads.
+  __device__ __forceinline__ void outer_y(const double* cy, const double* si_y, double* mean) const {
+    double Q[NF + 5], out[NF];
+#pragma unroll
+    for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqj[(C * yg + u) * PJ + ycol - 3];
+    EdgeSpacing sp;
+    if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
+    fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, out);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) mean[f] = 0.5 * (out[f] + si_y[f]);
+  }
+  __device__ __forceinline__ void put_ax(const double* v) const {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) L.u.s.ax[xr * PJ + C * xg + f] = v[f];
+  }
+  __device__ __forceinline__ void put_ay(const double* v) const {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) L.u.s.ay[(C * yg + f) * TI + ycol - 3] = v[f];
+  }
+  // the cells of the cell update: NEC per thread, lanes along i
+  __device__ __forceinline__ void cell_places(int* jj, int* ii, unsigned* c2) const {
+#pragma unroll
+    for (int t = 0; t < NEC; ++t) {
+      int e = tid + 256 * t;
+      if (e >= TI * TJ) e = TI * TJ - 1;  // (spare lanes repeat the last cell)
+      jj[t] = e / TI, ii[t] = e - jj[t] * TI;
+      c2[t] = (unsigned)((j0 + jj[t]) * sj8 + (i0 + ii[t]) * 8);
+    }
+  }
+  // q * mass + the flux increment (apply_fluxes, d_sw.py:122-145) of cell t from the fluxes in ax / ay
+  __device__ __forceinline__ double flux_form(int jj, int ii, double am, double ra) const {
+    const double qv = L.sq[(jj + 3) * P + ii + 3];
+    const double* ax = L.u.s.ax + jj * PJ + ii;
+    const double* ay = L.u.s.ay + jj * TI + ii;
+    return qv * am + (ax[0] - ax[1] + ay[0] - ay[TI]) * ra;
+  }
+  __device__ __forceinline__ double flux_increment(int jj, int ii, double ra) const {
+    const double* ax = L.u.s.ax + jj * PJ + ii;
+    const double* ay = L.u.s.ay + jj * TI + ii;
+    return (ax[0] - ax[1] + ay[0] - ay[TI]) * ra;
+  }
+};
+
+// DMODE: -1 transport only; 0 damping fluxes -> dp.fx2o / fy2o (+ dp.add2d, u / v update: the vorticity call of d_sw);
+// 1 damping fluxes added to the transport fluxes; 2 added mass-weighted; 3 damping of q -> dw / heat_s / diss_est only (w).
+// EPI 0: fluxes stored (or accumulated / turned into winds); 1: flux-form update of the cell stored.
+template <int MORD, int DMODE, int EPI, bool EX, bool EY>
+__device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m, const real* __restrict__ q,
+                                         const real* __restrict__ crx, const real* __restrict__ cry,
+                                         const real* __restrict__ xfx, const real* __restrict__ yfx, real* __restrict__ fx,
+                                         real* __restrict__ fy, const real* __restrict__ xunit,
+                                         const real* __restrict__ yunit, const FvDamp& dp, int bx, int by, int k) {
+  FvtTile<MORD, EX, EY> T(L, g, m, bx, by, k, (int)threadIdx.x);
+  const long kb = (long)k * g.sk;
+  const unsigned kb8 = T.kb8;
+  const int sj8 = T.sj8;
+  T.load_footprint(q + kb);
+  if (DMODE >= 0) T.stage_damping_metrics();
+  __syncthreads();
+
+  double dvx[NF], dvy[NF];
+  double damp = 0.0;
+  if (DMODE >= 0) {
+    damp = dp.damp_k[k];
+    const auto D = T.damp(dp.mass_given ? 1.0 : damp, dp.nord_k[k] > 0.0, dp.nmax);
+    if (DMODE != 3) T.damping_faces(D, dvx, dvy);
+    else T.heat_diss(D, dp.dw + kb, dp.heat_s + kb, dp.diss_est + kb, dp.damp_w_k[k] > 1e-5, dp.ke_bg_k[k] * fabs(dp.dt));
+    __syncthreads();  // the sweeps overwrite the damping planes
+  }
+  if (DMODE == 0 && dp.add2d) T.add_2d(dp.add2d);
+
+  double si_y[NF], si_x[NF], cy[NF], cx[NF];
+  T.inner(crx + kb, cry + kb, xfx + kb, yfx + kb, si_x, si_y, cx, cy);
+
+  if (T.x_outer) {
+    double v[NF], xu[NF], ms[NF + 1];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) xu[f] = LDG(xunit, kb8 + T.xoff + (unsigned)(f * 8));
+    if (DMODE == 2) {
+#pragma unroll
+      for (int t = 0; t <= NF; ++t) ms[t] = LDG(dp.mass, kb8 + T.xoff + (unsigned)((t - 1) * 8));
+    }
+    T.outer_x(cx, si_x, v);
+#pragma unroll
     for (int f = 0; f < NF; ++f) {
-      v[f] = 0.5 * (out[f] + si_x[f]) * xu[f];
+      v[f] = v[f] * xu[f];
       if (DMODE == 1) v[f] = v[f] + dvx[f];
       if (DMODE == 2) v[f] = v[f] + 0.5 * damp * (ms[f] + ms[f + 1]) * dvx[f];
     }
     if (EPI == 0) {
       // a face is stored by the run it opens; the last face of the row (ie + 1) by the last run of the east-edge tile
-      const bool last = east && xg == GXN - 1;
+      const bool last = T.east && T.xg == GXN - 1;
       double w0[NF], w1[NF], w2[NF], w3[NF], wa[NF];
       if (dp.v_upd) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          w0[f] = LDG(dp.v_upd, kb8 + xoff + (unsigned)(f * 8));
-          w1[f] = LDG(m.dy, xoff + (unsigned)(f * 8));
-          w2[f] = LDG(dp.ke, kb8 + xoff + (unsigned)(f * 8));
-          w3[f] = LDG(dp.ke, kb8 + xoff + (unsigned)(f * 8 + sj8));
+          w0[f] = LDG(dp.v_upd, kb8 + T.xoff + (unsigned)(f * 8));
+          w1[f] = LDG(m.dy, T.xoff + (unsigned)(f * 8));
+          w2[f] = LDG(dp.ke, kb8 + T.xoff + (unsigned)(f * 8));
+          w3[f] = LDG(dp.ke, kb8 + T.xoff + (unsigned)(f * 8 + sj8));
         }
       }
       if (dp.accx) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) wa[f] = LDG(dp.accx, kb8 + xoff + (unsigned)(f * 8));
+        for (int f = 0; f < NF; ++f) wa[f] = LDG(dp.accx, kb8 + T.xoff + (unsigned)(f * 8));
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         if (f < C || last) {
-          const unsigned c = kb8 + xoff + (unsigned)(f * 8);
+          const unsigned c = kb8 + T.xoff + (unsigned)(f * 8);
           if (DMODE == 0) STG(dp.fx2o, c) = dvx[f];
           if (dp.v_upd) STG(dp.v_out ? dp.v_out : dp.v_upd, c) = w0[f] * w1[f] + w2[f] - w3[f] - v[f];  // v_from_ke (d_sw.py:423-436)
           else STG(fx, c) = v[f];
@@ -491,50 +670,44 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
         }
       }
     } else {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) L.u.s.ax[xr * PJ + C * xg + f] = v[f];
+      T.put_ax(v);
     }
   }
-  if (y_outer) {  // outer y on q_j, tile column ycol - 3, faces j0 + C*yg + f
-    double Q[NF + 5], out[NF], yu[NF], v[NF];
+  if (T.y_outer) {
+    double v[NF], yu[NF], ms[NF + 1];
 #pragma unroll
-    for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqj[(C * yg + u) * PJ + ycol - 3];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) yu[f] = LDG(yunit, yoff + (unsigned)(f * sj8));
-    double ms[NF + 1];
+    for (int f = 0; f < NF; ++f) yu[f] = LDG(yunit, kb8 + T.yoff + (unsigned)(f * sj8));
     if (DMODE == 2) {
 #pragma unroll
-      for (int t = 0; t <= NF; ++t) ms[t] = LDG(dp.mass, kb8 + yoff + (unsigned)((t - 1) * sj8));
+      for (int t = 0; t <= NF; ++t) ms[t] = LDG(dp.mass, kb8 + T.yoff + (unsigned)((t - 1) * sj8));
     }
-    EdgeSpacing sp;
-    if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
-    fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, out);
+    T.outer_y(cy, si_y, v);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      v[f] = 0.5 * (out[f] + si_y[f]) * yu[f];
+      v[f] = v[f] * yu[f];
       if (DMODE == 1) v[f] = v[f] + dvy[f];
       if (DMODE == 2) v[f] = v[f] + 0.5 * damp * (ms[f] + ms[f + 1]) * dvy[f];
     }
     if (EPI == 0) {
-      const bool last = north && yg == GYN - 1;
+      const bool last = T.north && T.yg == GYN - 1;
       double w0[NF], w1[NF], w2[NF], w3[NF], wa[NF];
       if (dp.u_upd) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          w0[f] = LDG(dp.u_upd, kb8 + yoff + (unsigned)(f * sj8));
-          w1[f] = LDG(m.dx, yoff + (unsigned)(f * sj8));
-          w2[f] = LDG(dp.ke, kb8 + yoff + (unsigned)(f * sj8));
-          w3[f] = LDG(dp.ke, kb8 + yoff + (unsigned)(f * sj8 + 8));
+          w0[f] = LDG(dp.u_upd, kb8 + T.yoff + (unsigned)(f * sj8));
+          w1[f] = LDG(m.dx, T.yoff + (unsigned)(f * sj8));
+          w2[f] = LDG(dp.ke, kb8 + T.yoff + (unsigned)(f * sj8));
+          w3[f] = LDG(dp.ke, kb8 + T.yoff + (unsigned)(f * sj8 + 8));
         }
       }
       if (dp.accy) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) wa[f] = LDG(dp.accy, kb8 + yoff + (unsigned)(f * sj8));
+        for (int f = 0; f < NF; ++f) wa[f] = LDG(dp.accy, kb8 + T.yoff + (unsigned)(f * sj8));
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         if (f < C || last) {
-          const unsigned c = kb8 + yoff + (unsigned)(f * sj8);
+          const unsigned c = kb8 + T.yoff + (unsigned)(f * sj8);
           if (DMODE == 0) STG(dp.fy2o, c) = dvy[f];
           if (dp.u_upd) STG(dp.u_out ? dp.u_out : dp.u_upd, c) = w0[f] * w1[f] + w2[f] - w3[f] + v[f];  // u_from_ke (d_sw.py:406-420)
           else STG(fy, c) = v[f];
@@ -542,35 +715,211 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
         }
       }
     } else {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) L.u.s.ay[(C * yg + f) * TI + ycol - 3] = v[f];
+      T.put_ay(v);
     }
   }
   if (EPI == 1) {
     // apply_fluxes (d_sw.py:122-145): q * mass + the flux increment, one cell per lane, lanes along i
     __syncthreads();
-    constexpr int NEC = (TI * TJ + 255) / 256;
-    double ra[NEC], am[NEC];
     int jj[NEC], ii[NEC];
     unsigned c2[NEC];
+    double ra[NEC], am[NEC];
+    T.cell_places(jj, ii, c2);
 #pragma unroll
     for (int t = 0; t < NEC; ++t) {
-      int e = tid + 256 * t;
-      if (e >= TI * TJ) e = TI * TJ - 1;  // (spare lanes repeat the last cell)
-      jj[t] = e / TI, ii[t] = e - jj[t] * TI;
-      c2[t] = (unsigned)((j0 + jj[t]) * sj8 + (i0 + ii[t]) * 8);
       ra[t] = LDG(m.rarea, c2[t]);
       am[t] = LDG(dp.amass, kb8 + c2[t]);
     }
 #pragma unroll
-    for (int t = 0; t < NEC; ++t) {
-      const double qv = L.sq[(jj[t] + 3) * P + ii[t] + 3];
-      const double* ax = L.u.s.ax + jj[t] * PJ + ii[t];
-      const double* ay = L.u.s.ay + jj[t] * TI + ii[t];
-      STG(dp.qout, kb8 + c2[t]) = qv * am[t] + (ax[0] - ax[1] + ay[0] - ay[TI]) * ra[t];
-    }
+    for (int t = 0; t < NEC; ++t) STG(dp.qout, kb8 + c2[t]) = T.flux_form(jj[t], ii[t], am[t], ra[t]);
   }
 }
 
-}  // namespace
+// ---- the scalar phase of d_sw in one kernel -------------------------------------------------------------------------------
+// delp: transport + del-n damping of the mass fluxes (FiniteVolumeTransport with DelnFlux, d_sw.py:1040-1052), mfx / mfy
+// accumulated (flux_capacitor, :33-60), new delp (apply_pt_delp_fluxes, :148-201).  w: DelnFluxNoSG -> heat_diss (:63-103),
+// transport with the mass fluxes, flux-form update / new delp + dw (adjust_w_and_qcon, :331-350).  q_con, pt: transport with
+// the mass fluxes + mass-weighted damping, flux-form update / new delp.  All outputs to buffers of their own.
+struct FvtScalars {
+  // in the order delp, w, q_con, pt: input (never written), output, damping factor / order columns (device, dsw_prepare)
+  const real* q[4];
+  real* qout[4];
+  const real* fac[4];
+  const real* nord[4];
+  int nmax[4];
+  const real *crx, *cry, *xfx, *yfx;
+  real *mfx, *mfy;  // accumulated mass fluxes
+  real *dw;         // one workspace field
+  real *heat_s, *diss_est;
+  const real *damp_w, *ke_bg;
+  double dt;
+};
+
+#ifndef FVT_STAMP
+#define FVT_STAMP(n)  // (tools/census/fvt_prof.hip: shader-clock stamps of one workgroup per level)
+#endif
+
+template <int MORD, bool EX, bool EY>
+__device__ __forceinline__ void fvt_scalars_tile(FvtLdsScalars& LS, const Geo& g, const FvMet& m, const FvtScalars& S, int bx, int by, int k) {
+  // Register budget: 256 VGPRs = TWO workgroups per CU.  What a thread needs again for the next scalar and nobody else needs --
+  // the Courant numbers and area fluxes of its runs, the mass fluxes through its faces, the new mass of its cells -- stays in
+  // registers; the mass itself sits in the LDS.  At the 128 registers of four workgroups per CU the same kernel spilled (every
+  // spilled register is 8 MB of scratch traffic per launch on a kernel that runs at the speed of its L2 misses: 2.1 GB per
+  // launch against 1.7 GB for the four separate launches), and re-reading the operands per scalar misses the L2 every time (an
+  // XCD's 4 MB turn over in ~6 us, a scalar takes ~20).  Measured: DESIGN.md section 4.
+  FvtLds& L = LS.t;
+  FvtTile<MORD, EX, EY> T(L, g, m, bx, by, k, (int)threadIdx.x);
+  const int tid = T.tid;
+  const long kb = (long)k * g.sk;
+  const int sj8 = T.sj8;
+  const bool w_on = S.damp_w[k] > 1e-5;
+  double cx[NF], cy[NF], xf[NF], yf[NF];  // Courant numbers and area fluxes of the thread's faces
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    cy[f] = LDG(S.cry + kb, T.yoff + (unsigned)(f * sj8));
+    yf[f] = LDG(S.yfx + kb, T.yoff + (unsigned)(f * sj8));
+    cx[f] = LDG(S.crx + kb, T.xoff + (unsigned)(f * 8));
+    xf[f] = LDG(S.xfx + kb, T.xoff + (unsigned)(f * 8));
+  }
+  double mfx[NF], mfy[NF];  // the mass fluxes through them (unit fluxes of w, q_con, pt)
+  double dn[NEC];           // the new mass of the thread's cells
+
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {  // delp, w, q_con, pt
+    FVT_STAMP(4 * s);
+    const real* const q = S.q[s] + kb;
+    real* const qout = S.qout[s] + kb;
+    const bool is_delp = s == 0, is_w = s == 1;
+    const bool mass_weighted = s >= 2;  // DelnFlux with mass (q_con, pt); delp: plain DelnFlux; w: DelnFluxNoSG -> heat_diss
+    const double damp = S.fac[s][k];
+    T.load_footprint(q, qout);
+    T.stage_damping_metrics();
+    __syncthreads();
+    FVT_STAMP(4 * s + 1);
+    if (is_delp) {  // the mass on the tile and one cell around it, from the footprint while it is there
+      for (int e = tid; e < (TJ + 2) * (TI + 2); e += 256) {
+        const int r = e / (TI + 2), c = e - r * (TI + 2);
+        LS.mass[r * MP + c] = L.sq[(r + 2) * P + c + 2];
+      }
+    }
+    {
+      double dvx[NF], dvy[NF];
+      const auto D = T.damp(mass_weighted ? 1.0 : damp, S.nord[s][k] > 0.0, S.nmax[s]);
+      if (is_w) {
+        T.heat_diss(D, S.dw + kb, S.heat_s + kb, S.diss_est + kb, w_on, S.ke_bg[k] * fabs(S.dt));
+      } else {
+        T.damping_faces(D, dvx, dvy);
+        if (T.x_outer) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) LS.priv[f][tid] = dvx[f];
+        }
+        if (T.y_outer) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) LS.priv[NF + f][tid] = dvy[f];
+        }
+      }
+      __syncthreads();  // the sweeps overwrite the damping planes
+    }
+    FVT_STAMP(4 * s + 2);
+    double si_y[NF], si_x[NF];
+    {
+      typename FvtTile<MORD, EX, EY>::SweepOperands O;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) O.cx[f] = cx[f], O.cy[f] = cy[f], O.xf[f] = xf[f], O.yf[f] = yf[f];
+#pragma unroll
+      for (int t = 0; t < C; ++t) {
+        O.ary[t] = LDG(m.area, T.yoff + (unsigned)(t * sj8));
+        O.arx[t] = LDG(m.area, T.xoff + (unsigned)(t * 8));
+      }
+      T.inner_with(O, si_x, si_y);
+    }
+    FVT_STAMP(4 * s + 3);
+    if (T.x_outer) {
+      double v[NF];
+      T.outer_x(cx, si_x, v);
+      FVT_FENCE();
+      if (is_delp) {
+        double wa[NF];
+        const bool last = T.east && T.xg == GXN - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfx + kb, T.xoff + (unsigned)(f * 8));
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          mfx[f] = v[f] * xf[f] + LS.priv[f][tid];
+          v[f] = mfx[f];
+          if (f < C || last) STG(S.mfx + kb, T.xoff + (unsigned)(f * 8)) = wa[f] + mfx[f];  // flux_capacitor (d_sw.py:33-60)
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          v[f] = v[f] * mfx[f];
+          if (mass_weighted) {
+            const double* ms = LS.mass + (T.xr + 1) * MP + C * T.xg + f;  // the cells on either side of the face
+            v[f] = v[f] + 0.5 * damp * (ms[0] + ms[1]) * LS.priv[f][tid];
+          }
+        }
+      }
+      T.put_ax(v);
+    }
+    FVT_FENCE();
+    if (T.y_outer) {
+      double v[NF];
+      T.outer_y(cy, si_y, v);
+      FVT_FENCE();
+      if (is_delp) {
+        double wa[NF];
+        const bool last = T.north && T.yg == GYN - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfy + kb, T.yoff + (unsigned)(f * sj8));
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          mfy[f] = v[f] * yf[f] + LS.priv[NF + f][tid];
+          v[f] = mfy[f];
+          if (f < C || last) STG(S.mfy + kb, T.yoff + (unsigned)(f * sj8)) = wa[f] + mfy[f];
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          v[f] = v[f] * mfy[f];
+          if (mass_weighted) {
+            const double* ms = LS.mass + (C * T.yg + f) * MP + T.ycol - 2;
+            v[f] = v[f] + 0.5 * damp * (ms[0] + ms[MP]) * LS.priv[NF + f][tid];
+          }
+        }
+      }
+      T.put_ay(v);
+    }
+    __syncthreads();
+    {
+      int jj[NEC], ii[NEC];
+      unsigned c2[NEC];
+      double ra[NEC], dwv[NEC];
+      T.cell_places(jj, ii, c2);
+#pragma unroll
+      for (int t = 0; t < NEC; ++t) ra[t] = LDG(m.rarea, c2[t]);
+      if (is_w && w_on) {
+#pragma unroll
+        for (int t = 0; t < NEC; ++t) dwv[t] = LDG(S.dw + kb, c2[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < NEC; ++t) {
+        const double am = LS.mass[(jj[t] + 1) * MP + ii[t] + 1];
+        double val;
+        if (is_delp) {
+          // the new delp (apply_pt_delp_fluxes, d_sw.py:148-201)
+          dn[t] = am + T.flux_increment(jj[t], ii[t], ra[t]);
+          val = dn[t];
+        } else {
+          val = T.flux_form(jj[t], ii[t], am, ra[t]) / dn[t];
+          if (is_w && w_on) val = val + dwv[t];  // adjust_w_and_qcon (d_sw.py:331-350)
+        }
+        STG(qout, c2[t]) = val;
+      }
+    }
+    if (s < 3) __syncthreads();  // (the cell update read sq / ax / ay)
+  }
+  FVT_STAMP(16);
+}
+
+}  // namespace fvt
 #endif  // FVT_AVAILABLE

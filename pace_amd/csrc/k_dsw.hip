@@ -17,6 +17,24 @@
 
 
 
+// the results of the fused scalar phase from their workspace fields back into the caller's fields (compute domain)
+__global__ void __launch_bounds__(256)
+k_copy_scalars(Geo g, real* __restrict__ delp, real* __restrict__ pt, real* __restrict__ w, real* __restrict__ q_con,
+               const real* __restrict__ delp_n, const real* __restrict__ pt_n, const real* __restrict__ w_n,
+               const real* __restrict__ q_con_n) {
+  PATCH_IJK(g);
+  if (i < g.is || i > g.ie || j < g.js || j > g.je) return;
+  const long c = IDX3(g, i, j, k);
+  delp[c] = delp_n[c];
+  pt[c] = pt_n[c];
+  w[c] = w_n[c];
+  q_con[c] = q_con_n[c];
+}
+
+bool dsw_pingpong_supported(const Geo& g, const pace_dsw_config_t* cfg) {
+  return cfg->hord_dp == cfg->hord_vt && cfg->hord_dp == cfg->hord_tm && transport_lean_covers(g, cfg->hord_dp);
+}
+
 // apply_pt_delp_fluxes (d_sw.py:148-201) + adjust_w_and_qcon (:331-350), given the flux-form updates
 // pt*delp + F(pt), w*delp + F(w), q_con*delp + F(q_con) that the transport kernels' epilogues produced
 __global__ void __launch_bounds__(256)
@@ -1071,10 +1089,10 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
 }
 
 struct DswWork {
-  real *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv, *umid, *vmid;
+  real *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv, *umid, *vmid, *wtmp;
   real* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
 };
-#define DSW_NFIELDS 21
+#define DSW_NFIELDS 22
 
 int64_t dsw_workspace_bytes(const Geo& g) {
   const int64_t field = (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real);
@@ -1127,6 +1145,10 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
                 real* crx, real* cry, real* xfx, real* yfx, real* q_con, const real* zh,
                 real* heat_source, real* diss_est, double dt, int phases, hipStream_t st) {
   (void)zh;
+  // optional separate outputs of the four transported scalars (pace_dsw_config_t): delp, pt, w, q_con
+  real* scalar_outs[4] = {cfg->delp_out, cfg->pt_out, cfg->w_out, cfg->q_con_out};
+  const bool pingpong = scalar_outs[0] != nullptr;
+  if (pingpong && !dsw_pingpong_supported(g, cfg)) return PACE_ERR_UNSUPPORTED;
   const int nk = g.nk;
   DswWork W = carve(g, ws);
   const int K = nk + 1;
@@ -1154,9 +1176,24 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2))) return rc;
   }
   if (phases & 2) {
-  {
+    // The production tilings with one order for all four: ONE kernel (k_fvt.hip launch_dsw_scalars_lean) takes a tile through
+    // delp, w, q_con, pt and the division by the new delp; its results go to the caller's separate outputs, or to workspace
+    // fields that are copied back (the in-place contract of pace_d_sw).
+    bool fused = false;
+    if (cfg->hord_dp == cfg->hord_vt && cfg->hord_dp == cfg->hord_tm && transport_lean_covers(g, cfg->hord_dp)) {
+      real* ws_outs[4] = {W.gx, W.fx2, W.wtmp, W.gy};
+      rc = launch_dsw_scalars_lean(g, m, delp, pt, w, q_con, pingpong ? scalar_outs : ws_outs, crx, cry, xfx, yfx, mfx, mfy, W.dw,
+                                   W.heat_s, diss_est, kc, cfg->hord_dp, nmax_v, nmax_w, nmax_t, dt, st);
+      if (rc == PACE_OK) {
+        fused = true;
+        if (!pingpong) hipLaunchKernelGGL(k_copy_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, delp, pt, w, q_con, W.gx, W.fx2, W.wtmp, W.gy);
+      } else if (rc != PACE_ERR_UNSUPPORTED) {
+        return rc;
+      }
+    }
+    if (!fused) {
+    if (pingpong) return PACE_ERR_UNSUPPORTED;
     const int nl = nk;
-    const long o = 0;
     FvDamp dp{};
     // delp: transport + del-n damping of the mass fluxes -> fx, fy
     dp.damp_k = d_dampfac_vt; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
@@ -1175,8 +1212,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     // pt -> W.fx2
     FvDamp dp2 = dp;
     dp2.damp_k = d_dampfac_vt; dp2.nord_k = d_nord_v; dp2.nmax = nmax_v; dp2.qout = W.fx2;
-    // General tilings with ord 6 for all three: ONE launch (k_fvtp2d_scalars3: a grid three tile planes high).  The production
-    // tilings take the lean kernel (k_fvt.hip) scalar by scalar.
+    // General tilings with ord 6 for all three: ONE launch (k_fvtp2d_scalars3: a grid three tile planes high)
     bool done3 = false;
     if (!transport_lean_covers(g, 6) && cfg->hord_vt == 6 && cfg->hord_dp == 6 && cfg->hord_tm == 6) {
       rc = launch_transport_scalars3(g, m, w, q_con, pt, crx, cry, xfx, yfx, W.fx, W.fy, nl, dpw, dp, dp2, st);
@@ -1188,9 +1224,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
       if ((rc = launch_transport(g, m, q_con, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_dp, nl, 2, 1, dp, st))) return rc;
       if ((rc = launch_transport(g, m, pt, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_tm, nl, 2, 1, dp2, st))) return rc;
     }
-    (void)o;
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
-  }
+    }
   }
   if (phases & (4 | 64)) {
   // winds A1: kinetic energy and relative vorticity (need only the flux preparation)
@@ -1225,7 +1260,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   }
   if (phases & 8) {
-  hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, W.umid, W.vmid, W.vort_b, W.ut2, W.vt2, delp, W.heat_s, heat_source,
+  hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, W.umid, W.vmid, W.vort_b, W.ut2, W.vt2, pingpong ? scalar_outs[0] : delp, W.heat_s, heat_source,
                      diss_est, d_dcon, cfg->d_con, cfg->do_skeb, u, v, d_damp_vt_c);
   }
   PACE_CHECK_LAUNCH();

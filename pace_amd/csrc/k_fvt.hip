@@ -3,7 +3,7 @@
 #include "fvt_core.h"
 
 #if FVT_AVAILABLE
-namespace {
+using namespace fvt;
 
 template <int MORD, int DMODE, int EPI>
 __global__ void __launch_bounds__(256, 4) k_fvt(Geo g, FvMet m, const real* __restrict__ q, const real* __restrict__ crx,
@@ -18,6 +18,21 @@ __global__ void __launch_bounds__(256, 4) k_fvt(Geo g, FvMet m, const real* __re
   else if (ex) fvt_tile<MORD, DMODE, EPI, true, false>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg.bx, wg.by, wg.bz);
   else if (ey) fvt_tile<MORD, DMODE, EPI, false, true>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg.bx, wg.by, wg.bz);
   else fvt_tile<MORD, DMODE, EPI, false, false>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg.bx, wg.by, wg.bz);
+}
+
+#ifndef FVT_SCALARS_WAVES
+#define FVT_SCALARS_WAVES 2  // workgroups per CU the register budget of the scalar-phase kernel is set for (fvt_core.h)
+#endif
+template <int MORD>
+__global__ void __launch_bounds__(256, FVT_SCALARS_WAVES) k_fvt_scalars(Geo g, FvMet m, FvtScalars S) {
+  __shared__ FvtLdsScalars L;
+  const FvTile wg = fv_tile_of_workgroup();
+  const int gx = g.n / TI, gy = g.n / TJ;
+  const bool ex = wg.bx == 0 || wg.bx == gx - 1, ey = wg.by == 0 || wg.by == gy - 1;
+  if (ex && ey) fvt_scalars_tile<MORD, true, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else if (ex) fvt_scalars_tile<MORD, true, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else if (ey) fvt_scalars_tile<MORD, false, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else fvt_scalars_tile<MORD, false, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
 }
 
 template <int MORD>
@@ -38,7 +53,6 @@ int fvt_launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g,
   return PACE_ERR_UNSUPPORTED;
 }
 
-}  // namespace
 #endif  // FVT_AVAILABLE
 
 bool transport_lean_covers(const Geo& g, int hord) {
@@ -65,6 +79,42 @@ int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real*
   else if (hord == 6) rc = fvt_launch_mode<6>(dmode, epi, grid, st, g, fm, q, crx, cry, xfx, yfx, fx, fy, xu, yu, dp);
   else return PACE_ERR_UNSUPPORTED;
   if (rc) return rc;
+  PACE_CHECK_LAUNCH();
+  return PACE_OK;
+#else
+  return PACE_ERR_UNSUPPORTED;
+#endif
+}
+
+// The scalar phase of d_sw (delp, w, q_con, pt) in one launch; see fvt_core.h.  kc: the device column block of dsw_prepare
+// (NCOL arrays of nk + 1).  outs[4] = delp, pt, w, q_con outputs, distinct from the inputs.  PACE_ERR_UNSUPPORTED if the geometry /
+// orders are not covered (the caller then runs the scalars one by one).
+int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,
+                            real* const* outs, const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx,
+                            real* mfy, real* dw, real* heat_s, real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w,
+                            int nmax_t, double dt, hipStream_t st) {
+#if FVT_AVAILABLE
+  if (!transport_lean_covers(g, hord) || nmax_v > 2 || nmax_w > 2 || nmax_t > 2) return PACE_ERR_UNSUPPORTED;
+  const real* ins[4] = {delp, pt, w, q_con};
+  for (int n = 0; n < 4; ++n)
+    if (((uintptr_t)ins[n] & 15) != 0 || outs[n] == nullptr || outs[n] == ins[n]) return PACE_ERR_UNSUPPORTED;
+  const int K = g.nk + 1;
+  FvtScalars S{};
+  // (the order of dsw_prepare: nord_v, nord_w, nord_t, damp_vt, damp_w, damp_t, d2_divg, d_con, ke_bg, fac_vt, fac_t, fac_vt_c, fac_w_c)
+  const real *nord_v = kc, *nord_w = kc + K, *nord_t = kc + 2 * K, *fac_vt = kc + 9 * K, *fac_t = kc + 10 * K, *fac_w = kc + 12 * K;
+  // delp, w, q_con, pt
+  S.q[0] = delp, S.q[1] = w, S.q[2] = q_con, S.q[3] = pt;
+  S.qout[0] = outs[0], S.qout[1] = outs[2], S.qout[2] = outs[3], S.qout[3] = outs[1];
+  S.fac[0] = fac_vt, S.fac[1] = fac_w, S.fac[2] = fac_t, S.fac[3] = fac_vt;
+  S.nord[0] = nord_v, S.nord[1] = nord_w, S.nord[2] = nord_t, S.nord[3] = nord_v;
+  S.nmax[0] = nmax_v, S.nmax[1] = nmax_w, S.nmax[2] = nmax_t, S.nmax[3] = nmax_v;
+  S.crx = crx, S.cry = cry, S.xfx = xfx, S.yfx = yfx, S.mfx = mfx, S.mfy = mfy, S.dw = dw, S.heat_s = heat_s,
+  S.diss_est = diss_est;
+  S.damp_w = kc + 4 * K, S.ke_bg = kc + 8 * K;
+  S.dt = dt;
+  const dim3 grid(g.n / TI, g.n / TJ, g.nk);
+  if (hord == 5) hipLaunchKernelGGL(k_fvt_scalars<5>, grid, dim3(256), 0, st, g, fv_met(m), S);
+  else hipLaunchKernelGGL(k_fvt_scalars<6>, grid, dim3(256), 0, st, g, fv_met(m), S);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 #else

@@ -58,6 +58,10 @@ int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real*
                           const real* yfx, real* fx, real* fy, const real* xu, const real* yu, int hord, int nlev, int dmode,
                           int epi, const FvDamp& dp, hipStream_t st);
 
+int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,
+                            real* const* outs, const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx,
+                            real* mfy, real* dw, real* heat_s, real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w,
+                            int nmax_t, double dt, hipStream_t st);
 // whether launch_transport_lean takes this geometry with this order (fp64 build, tiling, row alignment)
 bool transport_lean_covers(const Geo& g, int hord);
 
@@ -106,6 +110,8 @@ int launch_a2b_ord4_tiled(const Geo& g, const Met& m, const real* qin, real* qou
 int launch_a2b_ord4_batch(const Geo& g, const Met& m, const real* const* qin, real* const* qout, const int* k0, const int* k1,
                           int nfields, hipStream_t st);
 int64_t dsw_workspace_bytes(const Geo& g);
+// whether launch_d_sw can write the four transported scalars to separate buffers (pace_dsw_config_t::delp_out ...)
+bool dsw_pingpong_supported(const Geo& g, const pace_dsw_config_t* cfg);
 int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st);
 int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace_dsw_config_t* cfg, void* ws,
                 real* delpc, real* delp, real* pt, real* u, real* v, real* w, real* uc, real* vc,

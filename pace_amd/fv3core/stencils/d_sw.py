@@ -103,6 +103,34 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         nbytes = self.lib.cdll.pace_d_sw_workspace_bytes(C.byref(self._geom))
         self._workspace = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=quantity_factory.device)
         self.call("pace_d_sw_prepare", C.byref(self._col), self._workspace.data_ptr(), self.stream())
+        # The four scalars d_sw transports are written to buffers of their own where the library supports it (the fused scalar
+        # kernel of the production tilings, include/pace_hip.h pace_dsw_config_t) and swapped into the caller's Quantities.
+        self._pingpong = bool(self.lib.cdll.pace_d_sw_pingpong_supported(C.byref(self._geom), C.byref(self._cfg))) and not os.environ.get(
+            "PACE_DSW_INPLACE")
+        self._quantity_factory = quantity_factory
+        self._spares = None
+
+    def _outputs_for(self, delp, pt, w, q_con):
+        """Point the config at the spare buffers (allocated at the first call as copies of the fields, so that the storage line
+        beyond the halo, which no kernel writes, holds what the fields hold)."""
+        if not self._pingpong or not all(hasattr(f, "swap_storage") for f in (delp, pt, w, q_con)):
+            self._cfg.delp_out = self._cfg.pt_out = self._cfg.w_out = self._cfg.q_con_out = None
+            return None
+        if self._spares is None:
+            self._spares = []
+            for f in (delp, pt, w, q_con):
+                sp = self._quantity_factory.empty(f.dims, f.units)
+                sp.data[...] = f.data
+                self._spares.append(sp)
+        sp = self._spares
+        self._cfg.delp_out, self._cfg.pt_out, self._cfg.w_out, self._cfg.q_con_out = (dptr(x) for x in sp)
+        return sp
+
+    @staticmethod
+    def _swap_in(fields, spares):
+        if spares is not None:
+            for f, sp in zip(fields, spares):
+                f.swap_storage(sp)
 
     def _args(self, fields, dt):
         check_layout(self._geom, *fields)
@@ -117,6 +145,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         after the wait) then computes only the frame of the flux preparation before it goes on.  Same results bit for bit."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source,
                   diss_est)
+        self._cfg.delp_out = self._cfg.pt_out = self._cfg.w_out = self._cfg.q_con_out = None
         self.lib.call("pace_d_sw_phases", 16, C.byref(self._geom), *self._args(fields, dt), self.stream())
         self._prep_started = True
 
@@ -130,6 +159,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         ``join()`` before touching u, v, uc, vc, heat_source, diss_est, delpc or divgd again."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                   heat_source, diss_est)
+        spares = self._outputs_for(delp, pt, w, q_con)
         args = self._args(fields, dt)
         # flux preparation: everything (1), or only its frame (32) if start_flux_preparation did the interior box (16)
         prep = 32 if self._prep_started else 1
@@ -143,6 +173,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
                 self.call("pace_d_sw", *args, self.stream())
             else:
                 phases(prep | 14, self.stream())
+            self._swap_in((delp, pt, w, q_con), spares)
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self._workspace.device)
@@ -170,6 +201,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
                 self._ev_handles = tuple(C.c_void_p(e.cuda_event) for e in (self._ev_prep, self._ev_scalars, self._done))
             self.lib.call("pace_d_sw_overlapped", prep, C.byref(self._geom), *args, self.stream(), side_ptr, *self._ev_handles)
             self._pending = True
+            self._swap_in((delp, pt, w, q_con), spares)
             return
         phases(prep | 2, self.stream())  # flux preparation + scalar transport on the calling stream
         self._ev_scalars.record(main)
@@ -177,6 +209,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         phases(12, side_ptr)            # the whole wind update on the side stream
         self._done.record(side)
         self._pending = True
+        self._swap_in((delp, pt, w, q_con), spares)
 
     _side = None
     _ev_handles = None

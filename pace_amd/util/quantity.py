@@ -106,6 +106,16 @@ class Quantity:
     def set(self, array):
         self._data[...] = torch.as_tensor(np.asarray(array), dtype=self._data.dtype, device=self._data.device)
 
+    def swap_storage(self, other: "Quantity"):
+        """Exchange the device buffers of two Quantities of the same layout (an extension: d_sw writes the four scalars it
+        transports to buffers of their own -- include/pace_hip.h pace_dsw_config_t -- and the operator swaps them in, so that the
+        caller's Quantity objects hold the new values as if they had been updated in place).  Tensors taken from ``data`` BEFORE
+        the swap keep pointing at the old buffer."""
+        if self._data.shape != other._data.shape or self._data.stride() != other._data.stride() or self._data.dtype != other._data.dtype:
+            raise ValueError("swap_storage needs two quantities of the same layout")
+        self._data, other._data = other._data, self._data
+        self._base, other._base = other._base, self._base
+
     def transpose(self, target_dims: Sequence[str]) -> "Quantity":
         """quantity.py:518-560: the same storage seen with its dimensions in another order (a view; what the reference's
         checkpoint calls use to hand [x, z, y] "Fortran data" to the checkpointer)."""

@@ -2,6 +2,7 @@
 // kernel IS the dynamic count of that variant's straight-line path.  python tools/isa_census.py ../tools/census/fvt_variants
 #include "../../pace_amd/csrc/fvt_core.h"
 #if FVT_AVAILABLE
+using namespace fvt;
 template <int MORD, int DMODE, int EPI, bool EX, bool EY>
 __global__ void __launch_bounds__(256, 4) k_var(Geo g, FvMet m, const real* __restrict__ q, const real* __restrict__ crx,
                                                 const real* __restrict__ cry, const real* __restrict__ xfx,
@@ -17,4 +18,15 @@ INST4(1, 0)
 INST4(0, 0)
 INST4(3, 1)
 INST4(2, 1)
+#endif
+#if FVT_AVAILABLE
+template <int MORD, bool EX, bool EY>
+__global__ void __launch_bounds__(256, 2) k_var_scalars(Geo g, FvMet m, FvtScalars S) {
+  __shared__ FvtLdsScalars L;
+  fvt_scalars_tile<MORD, EX, EY>(L, g, m, S, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template __global__ void k_var_scalars<6, false, false>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars<6, true, false>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars<6, false, true>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars<6, true, true>(Geo, FvMet, FvtScalars);
 #endif

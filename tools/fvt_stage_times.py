@@ -1,0 +1,60 @@
+"""Where does a workgroup of the scalar-phase kernel (k_fvt_scalars) spend its time?  Development tool: needs
+tools/build_prof.sh (build/var/prof/libpace_hip.so, stage stamps compiled in).  C192 x 79, synthetic state."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pace_amd import _lib, synthetic  # noqa: E402
+from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig  # noqa: E402
+from pace_amd.fv3core.stencils._common import dptr  # noqa: E402
+from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, get_column_namelist  # noqa: E402
+from pace_amd.tile import DSW_ARGS, Env  # noqa: E402
+
+PARTS = ["footprint + metrics -> LDS", "damping + face values", "inner sweeps, q_i / q_j", "outer sweeps, fluxes, cell update"]
+SCALARS = ["delp", "w", "q_con", "pt"]
+
+
+def main():
+    n, nz = 192, 79
+    lib = _lib.Library(os.path.join(ROOT, "build", "var", "prof", "libpace_hip.so"))
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, "cuda", m, n, nz)
+    cfg = DGridShallowWaterLagrangianDynamicsConfig()
+    col = get_column_namelist(cfg, env.qf)
+    dsw = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, False, False, cfg)
+    copies = [{k: env.q3(s[k]) for k in DSW_ARGS} for _ in range(6)]
+
+    def phase(mask, f):
+        lib.call("pace_d_sw_phases", mask, C.byref(dsw._geom), C.byref(dsw._met), C.byref(dsw._col), C.byref(dsw._cfg),
+                 dsw._workspace.data_ptr(), *[dptr(f[k]) for k in DSW_ARGS], float(s["dt"]), None)
+
+    host = (C.c_longlong * (4 * 128 * 20))()
+    rows = [[], [], [], []]
+    for rep in range(6):
+        f = copies[rep]
+        phase(1, f)
+        torch.cuda.synchronize()
+        phase(2, f)
+        torch.cuda.synchronize()
+        assert lib.cdll.pace_debug_fvt_prof(host) == 0
+        a = np.frombuffer(host, dtype=np.int64).reshape(4, 128, 20)[:, :nz, :17].astype(float)
+        if rep >= 1:
+            for w in range(4):
+                rows[w].append(np.diff(a[w], axis=1))
+    for w, label in enumerate(("interior", "corner", "west-edge", "south-edge")):
+        d = np.concatenate(rows[w])
+        med = np.median(d, axis=0)
+        print(f"{label} workgroup of k_fvt_scalars: {med.sum():.0f} cycles")
+        for sc in range(4):
+            line = "  ".join(f"{PARTS[p][:24]:24s} {med[4 * sc + p]:7.0f}" for p in range(4))
+            print(f"   {SCALARS[sc]:6s} {med[4 * sc:4 * sc + 4].sum():7.0f} | {line}")
+
+
+if __name__ == "__main__":
+    main()

@@ -21,7 +21,7 @@ def main(dirs):
                 agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for k, d in agg.items():
-        if not k.startswith(("k_", "void k_")):
+        if not k.startswith(("k_", "void k_")) and "::k_" not in k:
             continue
         e = {"launches": max(len(v) for v in d.values())}
         for c, v in d.items():
