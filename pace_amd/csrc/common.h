@@ -266,13 +266,17 @@ __device__ __forceinline__ void ppm_fluxes_from_al(const double* Q, const double
   for (int f = 0; f < F; ++f) {
     const double mask = (steep[f] || steep[f + 1]) ? 1.0 : 0.0;
     const double cc = c[f];
-    if (cc > 0.0) {
-      const double fx1 = (1.0 - cc) * (br[f] - cc * b0[f]);
-      out[f] = Q[f + 2] + fx1 * mask;
-    } else {
-      const double fx1 = (1.0 + cc) * (bl[f + 1] + cc * b0[f + 1]);
-      out[f] = Q[f + 3] + fx1 * mask;
-    }
+    // xppm.py:56-72: c > 0: q[i-1] + (1 - c) * (br[i-1] - c * b0[i-1]), else q[i] + (1 + c) * (bl[i] + c * b0[i]).  With a = |c|
+    // both are Q + (1 - a) * (X - a * B) on the upwind cell's values -- the same bits (1 + c == 1 - |c| and bl + c * b0 ==
+    // bl - |c| * b0 for c <= 0: a sign moved, no rounding) -- selected as values instead of as branches: a divergent branch per
+    // face costs seven scalar instructions of exec-mask bookkeeping and both arms.
+    const bool up = cc > 0.0;
+    const double a = fabs(cc);
+    const double X = up ? br[f] : bl[f + 1];
+    const double B = up ? b0[f] : b0[f + 1];
+    const double Qs = up ? Q[f + 2] : Q[f + 3];
+    const double fx1 = (1.0 - a) * (X - a * B);
+    out[f] = Qs + fx1 * mask;
   }
 }
 
@@ -305,8 +309,8 @@ __device__ __forceinline__ void ppm_patch_edge(double* al, const double* Q, bool
   al[A + 2] = PPM_C3 * Q[A + 3] + PPM_C2 * Q[A + 4] + PPM_C1 * Q[A + 5];
 }
 // lane_lo: this run starts at the first interface of the tile (A = 0); lane_hi: it holds the end of the tile at A = AHI
-template <int MORD, int F, int AHI>
-__device__ __forceinline__ void ppm_run_canon(const double* Q, const double* c, bool lane_lo, bool lane_hi, const EdgeSpacing& sp,
+template <int MORD, int F, int AHI, class SP = EdgeSpacing>
+__device__ __forceinline__ void ppm_run_canon(const double* Q, const double* c, bool lane_lo, bool lane_hi, const SP& sp,
                                               double* out) {
   static_assert(MORD != 8 && AHI >= 0 && AHI <= F - 1, "ppm_run_canon");
   double al[F + 2];

@@ -96,26 +96,28 @@ struct FvtLdsScalars {
 #define LDG(p, off) (*(const real*)((const char*)(p) + (off)))
 #define STG(p, off) (*(real*)((char*)(p) + (off)))
 
-// A-grid spacings of the one-sided PPM forms (common.h EdgeSpacing): four values along the sweep axis at the start (lo) or at the
-// end of the tile; `fixed` is the byte offset of the run's column (y sweeps) or row (x sweeps), `step` the byte stride along the axis
-__device__ __forceinline__ EdgeSpacing fvt_spacing(const real* d, unsigned fixed, int step, int s, int e, bool lo, bool hi) {
-  EdgeSpacing sp;
+// A-grid spacings of the one-sided PPM forms (the provider interface of common.h ppm_patch_edge): four values along the sweep
+// axis, at the start OR at the end of the tile -- a workgroup tile holds at most one edge per axis.  `fixed` is the byte offset of
+// the run's column (y sweeps) or row (x sweeps), `step` the byte stride along the axis; loaded only by the runs that hold the edge.
+struct FvtSpacing {
+  double d[4];
+  __device__ __forceinline__ double operator()(bool, int idx, int) const { return d[idx]; }
+};
+__device__ __forceinline__ FvtSpacing fvt_spacing(const real* d, unsigned fixed, int step, int s, int e, bool lo, bool hi) {
+  FvtSpacing sp;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) sp.S[t] = 0.0, sp.E[t] = 0.0;
-  if (lo) {
+  for (int t = 0; t < 4; ++t) sp.d[t] = 0.0;
+  if (lo || hi) {
+    const int first = lo ? s - 2 : e - 1;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) sp.S[t] = LDG(d, fixed + (unsigned)((s - 2 + t) * step));
-  }
-  if (hi) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) sp.E[t] = LDG(d, fixed + (unsigned)((e - 1 + t) * step));
+    for (int t = 0; t < 4; ++t) sp.d[t] = LDG(d, fixed + (unsigned)((first + t) * step));
   }
   return sp;
 }
 
 // one run: the NF fluxes of the interfaces between cells Q[2 .. NF+2] (Q[u] = cell first_interface - 3 + u)
 template <int MORD, bool EDGE>
-__device__ __forceinline__ void fvt_run(const double* Q, const double* c, bool lane_lo, bool lane_hi, const EdgeSpacing& sp, double* out) {
+__device__ __forceinline__ void fvt_run(const double* Q, const double* c, bool lane_lo, bool lane_hi, const FvtSpacing& sp, double* out) {
   if constexpr (EDGE) ppm_run_canon<MORD, NF, C>(Q, c, lane_lo, lane_hi, sp, out);
   else ppm_run_p<MORD, false, NF>(Q, c, 0, 0, 0, sp, out);
 }
@@ -216,6 +218,11 @@ struct FvtTile {
   int dc, dr0, dbase;
   bool dn_on;
   double dra[DN_RC];
+  // corner tiles: a cell whose damping stencil reaches into a corner region of the halo (delnflux_core.h deln_affected), one
+  // candidate per thread of the first wave: its place in the plane (or -1) and the places its six operands come from once the
+  // corner copies are applied -- X(i-1), X(i), X(i+1) with copy_corners_x, Y(j-1), Y(j), Y(j+1) with copy_corners_y
+  // (delnflux.py:1009-1047); -1: outside the footprint, the value is zero
+  int fx_at, fx_src[6];
   double *plane, *sdv, *sdu;
 
   __device__ __forceinline__ FvtTile(FvtLds& L_, const Geo& g_, const FvMet& m_, int bx, int by, int k_, int tid_) : L(L_), g(g_), m(m_) {
@@ -258,6 +265,42 @@ struct FvtTile {
     plane = L.u.scratch;
     sdv = plane + QH * P;
     sdu = sdv + QH * P;
+    fx_at = -1;
+    if (RC && tid < 64) {
+      const int q = tid >> 4, a = tid & 3, b = (tid >> 2) & 3;
+      const int gi = (q & 1) ? g.ie + a : g.is - 3 + a;
+      const int gj = (q & 2) ? g.je + b : g.js - 3 + b;
+      const int ci = gi - ilo, cj = gj - jlo;
+      const bool valid = ci >= 1 && ci <= QW - 2 && cj >= 1 && cj <= QH - 2 && gi >= 1 && gi + 1 < g.ni && gj >= 1 && gj + 1 < g.nj;
+      if (ci >= 0 && ci < QW && cj >= 0 && cj < QH && deln_affected(g, gi, gj) && valid) {
+        fx_at = cj * P + ci;
+        auto place = [&](int i, int j) {
+          const int la = i - ilo, lb = j - jlo;
+          return (la >= 0 && la < QW && lb >= 0 && lb < QH) ? lb * P + la : -1;
+        };
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          int xi = gi - 1 + d, xj = gj, yi = gi, yj = gj - 1 + d;
+          remap_agrid_x(g, xi, xj);
+          remap_agrid_y(g, yi, yj);
+          fx_src[d] = place(xi, xj);
+          fx_src[3 + d] = place(yi, yj);
+        }
+      }
+    }
+  }
+  // the divergence at that cell (the expressions of delnflux_core.h deln_corner_fix)
+  template <bool FIRST>
+  __device__ __forceinline__ double corner_fix(const double* src, double d0) const {
+    auto rd = [&](int o) { return o >= 0 ? (FIRST ? d0 * src[o] : src[o]) : 0.0; };
+    auto sgn = [&](double x) { return FIRST ? x : -x; };
+    const double ra = LDG(m.rarea, (unsigned)((jlo + fx_at / P) * sj8 + (ilo + fx_at % P) * 8));
+    const double xm = rd(fx_src[0]), xc = rd(fx_src[1]), xp = rd(fx_src[2]), ym = rd(fx_src[3]), yc = rd(fx_src[4]), yp = rd(fx_src[5]);
+    const double fw = sgn(sdv[fx_at] * (xm - xc));
+    const double fe = sgn(sdv[fx_at + 1] * (xc - xp));
+    const double fs = sgn(sdu[fx_at] * (ym - yc));
+    const double fn = sgn(sdu[fx_at + P] * (yc - yp));
+    return (fw - fe + fs - fn) * ra;
   }
 
   // ---- stage 0: the footprint of q (level base applied), 16 bytes per lane (rows start 16-byte aligned: ilo = TI * bx, sj even).
@@ -279,7 +322,9 @@ struct FvtTile {
         }
       }
     }
-    if (RC) {  // corner tile: the corner block holds the values copy_corners_y puts there (corners.py:367-425)
+    pc.store(L.sq, v);
+    if (RC) {  // corner tile: the corner block holds the values copy_corners_y puts there (corners.py:367-425); the thread that
+               // stored a piece overwrites its corner cells (same thread, same address: program order)
 #pragma unroll
       for (int p = 0; p < FvtPieces::NP; ++p) {
         const int gj = jlo + pc.row[p];
@@ -289,9 +334,7 @@ struct FvtTile {
           if ((gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) {
             int ri = gi, rj = gj;
             remap_agrid_y(g, ri, rj);
-            const double val = LDG(q, (unsigned)(rj * sj8 + ri * 8));
-            if (e == 0) v[p].x = val;
-            else v[p].y = val;
+            L.sq[pc.row[p] * P + 2 * pc.lc + e] = LDG(q, (unsigned)(rj * sj8 + ri * 8));
           }
         }
       }
@@ -302,7 +345,6 @@ struct FvtTile {
         L.sqc[tid] = LDG(q, (unsigned)(rj * sj8 + ri * 8));
       }
     }
-    pc.store(L.sq, v);
   }
   // del6_v, del6_u on the footprint -> sdv, sdu; rarea of the thread's damping run
   __device__ __forceinline__ void stage_damping_metrics() {
@@ -361,14 +403,13 @@ struct FvtTile {
     for (int it = 0; it < iters; ++it) {
       double res[DN_RC];
       double fix = 0.0;
-      int fix_at = -1;
       if (dn_on) {
         if (it == 0) fvt_deln_run<true>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
         else fvt_deln_run<false>(plane + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
       }
-      if (RC) {  // corner tile: the cells whose stencil reaches into a corner region, with the corner copies (delnflux_core.h)
-        if (it == 0) fix = deln_corner_fix<true>(g, m, L.sq, sdv, sdu, i0, j0, d0, fix_at);
-        else fix = deln_corner_fix<false>(g, m, plane, sdv, sdu, i0, j0, d0, fix_at);
+      if (RC && fx_at >= 0) {  // corner tile: the cells whose stencil reaches into a corner region, with the corner copies
+        if (it == 0) fix = corner_fix<true>(L.sq, d0);
+        else fix = corner_fix<false>(plane, d0);
       }
       if (it > 0) __syncthreads();  // (in place: everyone has read the iterate)
       if (dn_on) {
@@ -378,7 +419,7 @@ struct FvtTile {
       }
       if (RC) {
         __syncthreads();  // (the runs have written those cells as if they were interior cells: overwrite)
-        if (fix_at >= 0) plane[fix_at] = fix;
+        if (fx_at >= 0) plane[fx_at] = fix;
       }
       __syncthreads();
     }
@@ -436,7 +477,7 @@ struct FvtTile {
       for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[ybase + u * P];
 #pragma unroll
       for (int f = 0; f < NF; ++f) cy[f] = LDG(cry, yoff + (unsigned)(f * sj8));
-      EdgeSpacing sp;
+      FvtSpacing sp;
       if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
       fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, si_y);
       FVT_FENCE();
@@ -467,7 +508,7 @@ struct FvtTile {
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) cx[f] = LDG(crx, xoff + (unsigned)(f * 8));
-      EdgeSpacing sp;
+      FvtSpacing sp;
       if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
       fvt_run<MORD, EX>(Q, cx, west && xg == 0, east && xg == GXN - 1, sp, si_x);
       FVT_FENCE();
@@ -508,7 +549,7 @@ struct FvtTile {
       double Q[NF + 5];
 #pragma unroll
       for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[ybase + u * P];
-      EdgeSpacing sp;
+      FvtSpacing sp;
       if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
       fvt_run<MORD, EY>(Q, o.cy, south && yg == 0, north && yg == GYN - 1, sp, si_y);
 #pragma unroll
@@ -531,7 +572,7 @@ struct FvtTile {
           for (int a = 0; a < 3; ++a) Q[NF + 2 + a] = L.sqc[b * 3 + a];
         }
       }
-      EdgeSpacing sp;
+      FvtSpacing sp;
       if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
       fvt_run<MORD, EX>(Q, o.cx, west && xg == 0, east && xg == GXN - 1, sp, si_x);
 #pragma unroll
@@ -547,7 +588,7 @@ struct FvtTile {
     double Q[NF + 5], out[NF];
 #pragma unroll
     for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqi[xr * P + C * xg + u];
-    EdgeSpacing sp;
+    FvtSpacing sp;
     if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
     fvt_run<MORD, EX>(Q, cx, west && xg == 0, east && xg == GXN - 1, sp, out);
 #pragma unroll
@@ -558,7 +599,7 @@ struct FvtTile {
     double Q[NF + 5], out[NF];
 #pragma unroll
     for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqj[(C * yg + u) * PJ + ycol - 3];
-    EdgeSpacing sp;
+    FvtSpacing sp;
     if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
     fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, out);
 #pragma unroll

@@ -5,8 +5,12 @@
 #if FVT_AVAILABLE
 using namespace fvt;
 
+#ifndef FVT_WAVES
+#define FVT_WAVES 3  // workgroups per CU the register budget of the single-scalar kernel is set for (168 VGPRs: at 128 the
+                     // damped instances spill, and a spilled register is 8 MB of scratch traffic per launch; measured 172 -> 128 us)
+#endif
 template <int MORD, int DMODE, int EPI>
-__global__ void __launch_bounds__(256, 4) k_fvt(Geo g, FvMet m, const real* __restrict__ q, const real* __restrict__ crx,
+__global__ void __launch_bounds__(256, FVT_WAVES) k_fvt(Geo g, FvMet m, const real* __restrict__ q, const real* __restrict__ crx,
                                                 const real* __restrict__ cry, const real* __restrict__ xfx,
                                                 const real* __restrict__ yfx, real* __restrict__ fx, real* __restrict__ fy,
                                                 const real* __restrict__ xunit, const real* __restrict__ yunit, FvDamp dp) {

@@ -97,6 +97,18 @@ __device__ __forceinline__ FvTile fv_tile_of_workgroup() {
     lev = b / tpl;
     t = b - lev * tpl;
   }
+  // within a level: the four corner tiles first, then the edge tiles, then the interior ones -- the corner and edge forms take
+  // 1.2 - 2 x as long as the straight-line interior code, and the workgroups that start last should not be the longest ones
+  if (gx >= 3 && gy >= 3) {
+    if (t < 4) return FvTile{(t & 1) ? gx - 1 : 0, (t & 2) ? gy - 1 : 0, lev};
+    t -= 4;
+    const int nsn = 2 * (gx - 2), nwe = 2 * (gy - 2);
+    if (t < nsn) return FvTile{1 + (t >> 1), (t & 1) ? gy - 1 : 0, lev};
+    t -= nsn;
+    if (t < nwe) return FvTile{(t & 1) ? gx - 1 : 0, 1 + (t >> 1), lev};
+    t -= nwe;
+    return FvTile{1 + t % (gx - 2), 1 + t / (gx - 2), lev};
+  }
   return FvTile{t % gx, t / gx, lev};
 #endif
 }
