@@ -593,27 +593,52 @@ def main():
         phase_ms = {k: float(v) for k, v in zip(names, t.tolist())}
     cells = n * n * nz
     value = world * cells * args.steps / elapsed
+    # the last TIMED batch's fields as the device left them (taken now: the roofline loop below accumulates into mfx / mfy)
+    got_last = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        torch.cuda.synchronize()
+        got_last = {k: batches[-1][k].numpy().astype(np.float64) for k in list(DSW_ARGS) + ["delz", "ppe", "pk3"]}
 
-    # dominant kernel: the fused transport kernel k_fvtp2d<6, 2, 1> (PPM transport + del-n damping + flux-form update of
-    # one scalar; q_con and pt in every d_sw, its siblings <6,1,0>, <6,0,2>, <6,-1,0> do delp, w and the vorticity), timed
-    # live with events on the launch stream through its own C entry point
+    # The dominant kernel OF THE STEP, timed live with events on the launch stream, alone, on HBM-resident operands that change
+    # from launch to launch.  Production tilings: k_fvt_scalars -- the scalar phase of d_sw (delp, w, q_con, pt transported, damped
+    # and updated in one kernel; pace_amd/csrc/fvt_core.h), launched exactly as the step launches it (pace_d_sw_phases, mask 2,
+    # separate outputs).  Other tilings: the single-scalar transport kernel k_fvtp2d<6, 2, 1> through pace_fvtp2d_update (three of
+    # the step's launches are instances of it).
     roof = None
     if rank == 0 and not args.emulate:
         import ctypes as C
 
-        from pace_amd.fv3core.stencils._common import host_column
+        from pace_amd.fv3core.stencils._common import dptr, host_column
 
         geom = dsw._geom
-        da_min = env.damping.da_min
-        nord_t, damp_t = host_column(col["nord_t"], nz), host_column(col["damp_t"], nz)
-        kdev = torch.as_tensor(np.concatenate([(damp_t * da_min) ** (nord_t + 1), nord_t]), dtype=env.qf.real, device=dev)
-        out = env.q3()
+        fused = bool(getattr(dsw, "_pingpong", False))
+        if fused:
+            roof_kernel = "k_fvt_scalars<6> (d_sw scalar phase: delp, w, q_con, pt in one kernel)"
+            roof_names = ("k_fvt_scalars",)
+            # distinct 3-D fields once per direction: delp, w, q_con, pt, crx, cry, xfx, yfx, mfx, mfy in;
+            # delp, w, q_con, pt, mfx, mfy, diss_est and w's heating term out
+            algo_fields = 18
+            spare_sets = [[env.q3() for _ in range(4)] for _ in range(2)]
 
-        def kernel(r):
-            b = batches[r % nbatch]  # a different state copy every launch: operands come from HBM, as inside a step
-            lib.call("pace_fvtp2d_update", C.byref(geom), C.byref(env.grid_data.c_struct()), b["pt"].ptr, b["crx"].ptr, b["cry"].ptr,
-                     b["xfx"].ptr, b["yfx"].ptr, b["mfx"].ptr, b["mfy"].ptr, b["delp"].ptr, kdev.data_ptr(),
-                     kdev.data_ptr() + lib.real_bytes * nz, int(nord_t.max()), out.ptr, 6, nz, dsw.stream())
+            def kernel(r):
+                b = batches[r % nbatch]  # a different state copy every launch: operands come from HBM, as inside a step
+                sp = spare_sets[r % 2]
+                dsw._cfg.delp_out, dsw._cfg.pt_out, dsw._cfg.w_out, dsw._cfg.q_con_out = (dptr(x) for x in sp)
+                lib.call("pace_d_sw_phases", 2, C.byref(geom), *dsw._args([b[k] for k in DSW_ARGS], dt), dsw.stream())
+        else:
+            roof_kernel = "k_fvtp2d<6, 2, 1> (transport + damping + flux-form update of one scalar)"
+            roof_names = ("k_fvtp2d<6, 2, 1", "k_fvtp2dILi6ELi2ELi1E", "k_fvt<6, 2, 1", "k_fvtILi6ELi2ELi1E")
+            algo_fields = TRANSPORT_FIELDS
+            da_min = env.damping.da_min
+            nord_t, damp_t = host_column(col["nord_t"], nz), host_column(col["damp_t"], nz)
+            kdev = torch.as_tensor(np.concatenate([(damp_t * da_min) ** (nord_t + 1), nord_t]), dtype=env.qf.real, device=dev)
+            out = env.q3()
+
+            def kernel(r):
+                b = batches[r % nbatch]
+                lib.call("pace_fvtp2d_update", C.byref(geom), C.byref(env.grid_data.c_struct()), b["pt"].ptr, b["crx"].ptr, b["cry"].ptr,
+                         b["xfx"].ptr, b["yfx"].ptr, b["mfx"].ptr, b["mfy"].ptr, b["delp"].ptr, kdev.data_ptr(),
+                         kdev.data_ptr() + lib.real_bytes * nz, int(nord_t.max()), out.ptr, 6, nz, dsw.stream())
 
         reps = max(10, args.steps)
         for r in range(3):
@@ -625,13 +650,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
-        # algorithmic bytes per launch: q, crx, cry, xfx, yfx, x/y mass flux, delp in; qout out = 9 fields of N x N x nz doubles
-        algo = TRANSPORT_FIELDS * item * n * n * nz
+        algo = algo_fields * item * n * n * nz
         # HBM bytes per launch: measured live by two child passes under rocprofv3 --pmc (see measure_traffic), null otherwise
         traffic, traffic_detail = (None, "skipped (--no-traffic)")
         if not args.no_traffic and world == 1:
             torch.cuda.synchronize()
-            traffic, traffic_detail = measure_traffic(("k_fvtp2d<6, 2, 1>", "k_fvtp2d<6, 2, 1,", "k_fvtp2dILi6ELi2ELi1E"), n, nz, args.precision)
+            traffic, traffic_detail = measure_traffic(roof_names, n, nz, args.precision)
         # what this memory system sustains on a plain device-to-device copy (read + write of 1 GiB each way), next to the spec
         # peak the fractions are priced against
         try:
@@ -649,15 +673,16 @@ def main():
             del src, dst
         except Exception:  # noqa: BLE001
             copy_gbs = None
-        roof = {"kernel": "k_fvtp2d<6, 2, 1, canonical tiling>", "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"kernel": roof_kernel, "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "measured_copy_GBs": copy_gbs,
                 "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
-                "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo,
-                "where_in_the_step": "the transport family is five of the step's launches; this instance -- launched alone here, one scalar -- is "
-                                     "the one two of the three tile planes of k_fvtp2d_scalars3 (w, q_con, pt in one launch) run inside the step",
-                "limited_by": "chains of dependent stages (LDS round trips, global-load waits, barriers) at 4 waves per SIMD with the "
-                              "instruction issue of a SIMD ~saturated by its four waves (DESIGN.md section 4.0, round 3 ablations); "
-                              "the roofline that prices it is HBM"}
+                "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo, "algorithmic_fields": algo_fields,
+                "where_in_the_step": ("the step's longest launch (a third of it); timed here exactly as the step launches it, alone" if fused else
+                                      "three of the step's launches are instances of this kernel; timed here alone, one scalar"),
+                "limited_by": ("instruction issue at two workgroups per CU (256 VGPRs: what keeps a tile's operands in registers across the "
+                               "four scalars) and the bytes it moves: its L2 misses are ~1.9 x the algorithmic bytes (footprint halos, "
+                               "face rows) -- DESIGN.md section 4" if fused else
+                               "the bytes it really moves (L2 misses ~1.5 x algorithmic at ~3.5 TB/s) -- DESIGN.md section 4")}
 
     if rank == 0:
         line = {
@@ -700,9 +725,7 @@ def main():
                 return
             line["cpu_baseline"] = rec
             # the last TIMED batch's fields as the device left them, against the oracle on the same operands
-            torch.cuda.synchronize()
-            got = {k: batches[-1][k].numpy().astype(np.float64) for k in list(DSW_ARGS) + ["delz", "ppe", "pk3"]}
-            ok, errs = verify_against_oracle(got, ref, n, nz)
+            ok, errs = verify_against_oracle(got_last, ref, n, nz)
             line["verified"] = bool(ok)
             line["verified_detail"] = {"what": "the last timed batch's outputs vs the numpy oracle on the same operands: d_sw at 3.2e-10 "
                                                "(translate_d_sw.py:19), riem_solver3 at 5e-6 (overrides/standard.yaml:49-61)",

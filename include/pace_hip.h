@@ -426,7 +426,11 @@ int pace_c2l_ord(const pace_geom_t* geom, const pace_metrics_t* met, int order, 
  *   PACE_ST_XTP_U / _YTP_V   translate_xtp_u.py:13-23 / translate_ytp_v.py (xtp_u.py:9-91, ytp_v.py:9-91)
  *                            fields c (contravariant corner wind x dt), u (v), flux; scalars iord (5, 6 or 7)
  *   PACE_ST_MOIST_PT_LAST_STEP  moist_cv.py:84-118 (nwat = 6)  fields qvapor, qliquid, qrain, qsnow, qice, qgraupel, gz, pt, pkz;
- *                            scalars dtmp, r_vir */
+ *                            scalars dtmp, r_vir
+ *   PACE_ST_MOIST_PKZ        moist_cv.py:130-172 (nwat = 6; translate_moistcvpluspkz_2d.py:19)  fields qvapor, qliquid, qrain, qsnow,
+ *                            qice, qgraupel, q_con, gz, cvm, pkz, pt, cappa, delp, delz; scalar r_vir
+ *   PACE_ST_MOIST_PT         moist_cv.py:48-70 moist_pt_func as the stencil translate_moistcvpluspt_2d.py:9-50 builds  fields qvapor,
+ *                            qliquid, qrain, qsnow, qice, qgraupel, q_con, pt, cappa, delp, delz; scalar r_vir */
 enum {
   PACE_ST_FLUX_CAPACITOR = 1,
   PACE_ST_HEAT_DISS = 2,
@@ -442,7 +446,9 @@ enum {
   PACE_ST_FILL_CORNERS_2CELLS_Y = 12,
   PACE_ST_XTP_U = 13,
   PACE_ST_YTP_V = 14,
-  PACE_ST_MOIST_PT_LAST_STEP = 15
+  PACE_ST_MOIST_PT_LAST_STEP = 15,
+  PACE_ST_MOIST_PKZ = 16,
+  PACE_ST_MOIST_PT = 17
 };
 int pace_stencil(const pace_geom_t* geom, const pace_metrics_t* met, int id, void* const* fields, int nfields, const double* scalars,
                  int nscalars, const int* origin, const int* domain, void* stream);

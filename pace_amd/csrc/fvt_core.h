@@ -348,11 +348,17 @@ struct FvtTile {
   }
   // del6_v, del6_u on the footprint -> sdv, sdu; rarea of the thread's damping run
   __device__ __forceinline__ void stage_damping_metrics() {
+    stage_damping_planes();
+    load_damping_rarea();
+  }
+  __device__ __forceinline__ void stage_damping_planes() {
     D2 mv[FvtPieces::NP], mu[FvtPieces::NP];
     pc.load(m.del6_v, mv);
     pc.load(m.del6_u, mu);
     pc.store(sdv, mv);
     pc.store(sdu, mu);
+  }
+  __device__ __forceinline__ void load_damping_rarea() {
 #pragma unroll
     for (int t = 0; t < DN_RC; ++t) {
       int row = dr0 + t;
@@ -544,8 +550,9 @@ struct FvtTile {
     }
   }
   // stage I with the operands given.  Ends with a barrier.
+  template <bool DO_Y = true, bool DO_X = true>
   __device__ __forceinline__ void inner_with(const SweepOperands& o, double* si_x, double* si_y) {
-    if (y_on) {
+    if (DO_Y && y_on) {
       double Q[NF + 5];
 #pragma unroll
       for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[ybase + u * P];
@@ -556,7 +563,7 @@ struct FvtTile {
       for (int t = 0; t < C; ++t)
         L.u.s.sqi[ybase + t * P] = (Q[t + 3] * o.ary[t] + o.yf[t] * si_y[t] - o.yf[t + 1] * si_y[t + 1]) / (o.ary[t] + o.yf[t] - o.yf[t + 1]);
     }
-    if (x_on) {
+    if (DO_X && x_on) {
       double Q[NF + 5];
 #pragma unroll
       for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[xbase + u];

@@ -113,6 +113,42 @@ __global__ void k_st_moist_pt_last_step(Geo g, Win w, const real* qv, const real
   pt[c] = (pt[c] + dtmp * pkz[c]) / ((1.0 + r_vir * qv[c]) * (1.0 - cond));
 }
 
+// moist_pkz (moist_cv.py:130-172) and the test-side stencil around moist_pt_func (moist_cv.py:48-70;
+// tests/savepoint/translate/translate_moistcvpluspt_2d.py:9-37), nwat = 6: the condensate, the moist heat capacity, cappa, and pkz /
+// the moist potential temperature.  Constants: util/pace/util/constants.py.
+#define ST_RDGAS 287.05
+#define ST_RVGAS 461.50
+#define ST_GRAV 9.80665
+#define ST_CP_AIR 1004.6
+#define ST_CV_AIR (ST_CP_AIR - ST_RDGAS)
+#define ST_RDG (-ST_RDGAS / ST_GRAV)
+#define ST_CV_VAP (3.0 * ST_RVGAS)
+#define ST_C_ICE 1972.0
+#define ST_C_LIQ 4.1855e3
+template <int PT>  // 0: moist_pkz, 1: moist_pt
+__global__ void k_st_moist_cv(Geo g, Win w, const real* qv_, const real* ql_, const real* qr_, const real* qs_, const real* qi_,
+                              const real* qg_, real* q_con, real* gz_, real* cvm_, real* pkz, real* pt, real* cappa_, const real* delp,
+                              const real* delz, double r_vir) {
+  WIN_IJK(w);
+  const long c = IDX3(g, i, j, k);
+  const double qv = qv_[c];
+  const double ql = ql_[c] + qr_[c];
+  const double qs = qi_[c] + qs_[c] + qg_[c];
+  const double gz = ql + qs;
+  const double cvm = (1.0 - (qv + gz)) * ST_CV_AIR + qv * ST_CV_VAP + ql * ST_C_LIQ + qs * ST_C_ICE;
+  const double cappa = ST_RDGAS / (ST_RDGAS + cvm / (1.0 + r_vir * qv));
+  q_con[c] = gz;
+  cappa_[c] = cappa;
+  if (PT == 0) {
+    gz_[c] = gz;
+    cvm_[c] = cvm;
+    pkz[c] = exp(cappa * log(ST_RDG * delp[c] / delz[c] * pt[c]));
+  } else {
+    const double p = pt[c];
+    pt[c] = p * exp(cappa / (1.0 - cappa) * log(ST_RDG * delp[c] / delz[c] * p));
+  }
+}
+
 // ---- corner fills: one thread per destination cell of the four 3 x 3 (A-grid) / (B-grid: see below) corner blocks ----
 __device__ __forceinline__ void remap_bgrid(const Geo& g, int dir, int& i, int& j) {  // corners.py:591-712 (oracle/corner_ops.py)
   const bool w_ = i < g.is, e_ = i > g.ie + 1, s_ = j < g.js, n_ = j > g.je + 1;
@@ -232,15 +268,19 @@ int launch_stencil(const Geo& g, const Met& m, int id, void* const* f, int nf, c
       else hipLaunchKernelGGL(k_st_bke<1>, win_grid(w), blk, 0, st, g, m, w, F(0), F(1), F(2), F(3), sc[0]);
       break;
     case PACE_ST_COPY_CORNERS_X:
+      if (nf != 2) return PACE_ERR_ARG;
       hipLaunchKernelGGL((k_st_corner_copy<0, 0>), dim3((unsigned)w.nk), dim3(64), 0, st, g, w, F(0), F(1));
       break;
     case PACE_ST_COPY_CORNERS_Y:
+      if (nf != 2) return PACE_ERR_ARG;
       hipLaunchKernelGGL((k_st_corner_copy<0, 1>), dim3((unsigned)w.nk), dim3(64), 0, st, g, w, F(0), F(1));
       break;
     case PACE_ST_FILL_CORNERS_BGRID_X:
+      if (nf != 2) return PACE_ERR_ARG;
       hipLaunchKernelGGL((k_st_corner_copy<1, 0>), dim3((unsigned)w.nk), dim3(64), 0, st, g, w, F(0), F(1));
       break;
     case PACE_ST_FILL_CORNERS_BGRID_Y:
+      if (nf != 2) return PACE_ERR_ARG;
       hipLaunchKernelGGL((k_st_corner_copy<1, 1>), dim3((unsigned)w.nk), dim3(64), 0, st, g, w, F(0), F(1));
       break;
     case PACE_ST_FILL_CORNERS_DGRID:
@@ -248,9 +288,11 @@ int launch_stencil(const Geo& g, const Met& m, int id, void* const* f, int nf, c
       hipLaunchKernelGGL(k_st_fill_corners_dgrid, dim3((unsigned)w.nk), dim3(128), 0, st, g, w, F(0), F(1), F(2), F(3), sc[0]);
       break;
     case PACE_ST_FILL_CORNERS_2CELLS_X:
+      if (nf != 2) return PACE_ERR_ARG;
       hipLaunchKernelGGL(k_st_fill_2cells<0>, dim3((unsigned)w.nk), dim3(64), 0, st, g, w, F(0), F(1));
       break;
     case PACE_ST_FILL_CORNERS_2CELLS_Y:
+      if (nf != 2) return PACE_ERR_ARG;
       hipLaunchKernelGGL(k_st_fill_2cells<1>, dim3((unsigned)w.nk), dim3(64), 0, st, g, w, F(0), F(1));
       break;
     case PACE_ST_XTP_U:
@@ -270,6 +312,17 @@ int launch_stencil(const Geo& g, const Met& m, int id, void* const* f, int nf, c
       if (nf != 9 || ns != 2) return PACE_ERR_ARG;
       hipLaunchKernelGGL(k_st_moist_pt_last_step, win_grid(w), blk, 0, st, g, w, F(0), F(1), F(2), F(3), F(4), F(5), F(6), F(7), F(8), sc[0],
                          sc[1]);
+      break;
+    case PACE_ST_MOIST_PKZ:
+      if (nf != 14 || ns != 1) return PACE_ERR_ARG;
+      hipLaunchKernelGGL(k_st_moist_cv<0>, win_grid(w), blk, 0, st, g, w, F(0), F(1), F(2), F(3), F(4), F(5), F(6), F(7), F(8), F(9), F(10), F(11),
+                         F(12), F(13), sc[0]);
+      break;
+    case PACE_ST_MOIST_PT:
+      if (nf != 11 || ns != 1) return PACE_ERR_ARG;
+      // fields: qvapor, qliquid, qrain, qsnow, qice, qgraupel, q_con, pt, cappa, delp, delz
+      hipLaunchKernelGGL(k_st_moist_cv<1>, win_grid(w), blk, 0, st, g, w, F(0), F(1), F(2), F(3), F(4), F(5), F(6), nullptr, nullptr, nullptr, F(7),
+                         F(8), F(9), F(10), sc[0]);
       break;
     default:
       return PACE_ERR_UNSUPPORTED;

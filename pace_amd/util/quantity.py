@@ -133,7 +133,7 @@ class Quantity:
 class QuantityFactory:
     def __init__(self, sizer: SubtileGridSizer, device="cuda", dtype=torch.float64):
         """``dtype``: storage type of every float field -- torch.float64 (libpace_hip.so) or torch.float32 (libpace_hip_f32.so;
-        the reference's PACE_FLOAT_PRECISION=32, dsl/pace/dsl/typing.py:24)."""
+        an extension: the checked-out reference has no 32-bit mode, dsl/pace/dsl/typing.py:24)."""
         self.sizer = sizer
         self.device = torch.device(device)
         if dtype not in (torch.float64, torch.float32):

@@ -137,6 +137,37 @@ def run_all(lib, device):
     assert np.array_equal(q["gz"].numpy()[W], cond[W]) and np.array_equal(q["pt"].numpy()[W], ptn[W])
     assert np.array_equal(q["pt"].numpy()[0], a["pt"][0]), "written outside the window"
 
+    # moist_pkz / moist_pt: one row of the compute domain (translate_moistcvpluspkz_2d.py:19-24, translate_moistcvpluspt_2d.py:50-55)
+    from oracle import constants as oc
+
+    water = "qvapor qliquid qrain qsnow qice qgraupel".split()
+    a = {k: np.abs(_rand(rng)) * 0.004 for k in water}
+    a.update(pt=np.abs(_rand(rng)) * 3.0 + 250.0, delp=np.abs(_rand(rng)) * 50.0 + 500.0, delz=-(np.abs(_rand(rng)) * 40.0 + 300.0))
+    r_vir = 0.6078
+    ql, qs = a["qliquid"] + a["qrain"], a["qice"] + a["qsnow"] + a["qgraupel"]
+    gz = ql + qs
+    cvm = (1.0 - (a["qvapor"] + gz)) * oc.CV_AIR + a["qvapor"] * oc.CV_VAP + ql * oc.C_LIQ + qs * oc.C_ICE
+    cappa = oc.RDGAS / (oc.RDGAS + cvm / (1.0 + r_vir * a["qvapor"]))
+    row = (slice(3, 3 + N), slice(5, 6), slice(0, NZ))
+    o_row, d_row = (3, 5, 0), (N, 1, NZ)
+    names = water + "q_con gz cvm pkz pt cappa delp delz".split()
+    q = {k: env.q3(a.get(k, np.zeros_like(gz))) for k in names}
+    st = sf.from_origin_domain(_defn("pace.fv3core.stencils.moist_cv", "moist_pkz", names + ["r_vir"]), origin=o_row, domain=d_row)
+    st(*[q[k] for k in names], r_vir)
+    pkz = np.exp(cappa * np.log(oc.RDG * a["delp"] / a["delz"] * a["pt"]))
+    for k, ref in (("q_con", gz), ("gz", gz), ("cvm", cvm), ("cappa", cappa)):
+        assert np.array_equal(q[k].numpy()[row], ref[row]), k
+    assert np.abs(q["pkz"].numpy()[row] / pkz[row] - 1.0).max() < 1e-14  # (the device's exp / log)
+    assert not q["pkz"].numpy()[:, 4].any() and not q["pkz"].numpy()[:, 6].any(), "written outside the window"
+    names = water + "q_con pt cappa delp delz".split()
+    q = {k: env.q3(a.get(k, np.zeros_like(gz))) for k in names}
+    st = sf.from_origin_domain(_defn("translate_moistcvpluspt_2d", "moist_pt", names + ["r_vir"]), origin=o_row, domain=d_row)
+    st(*[q[k] for k in names], r_vir)
+    ptn = a["pt"] * np.exp(cappa / (1.0 - cappa) * np.log(oc.RDG * a["delp"] / a["delz"] * a["pt"]))
+    assert np.array_equal(q["q_con"].numpy()[row], gz[row]) and np.array_equal(q["cappa"].numpy()[row], cappa[row])
+    assert np.abs(q["pt"].numpy()[row] / ptn[row] - 1.0).max() < 1e-14
+    assert np.array_equal(q["pt"].numpy()[:, 4], a["pt"][:, 4]), "written outside the window"
+
     # corner fills: full domain (translate_corners.py)
     from oracle import corner_ops as co
 

@@ -136,28 +136,35 @@ def test_legacy_thread_per_column_solvers_emulated(precision):
         assert e < tol, (k, e, errs)
 
 
-def _dsw_child():
-    """(child process: PACE_DSW_FUSED3 is read once per process) d_sw on the synthetic tile, all outputs pickled."""
+def _dsw_child(gpu=False):
+    """(child process: PACE_DSW_INPLACE is read when the operator is built) d_sw on a C24 synthetic tile with the 8 x 8 tiling of
+    the emulation build `emu-canon` -- the tiling class the scalar-phase kernel takes -- (gpu: C96 x 12 with the product library),
+    all outputs pickled, plus whether the operator wrote to separate outputs."""
     import pickle
     import sys
 
+    from helpers import build_emu_canon
     from pace_amd import _lib, synthetic
     from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
-    from pace_amd.fv3core.stencils.d_sw import column_namelist_arrays
+    from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, column_namelist_arrays, get_column_namelist
 
-    n, nz = 16, 6
-    lib = _lib.Library(build_emu())
+    n, nz = (96, 12) if gpu else (24, 5)
+    lib = _lib.load() if gpu else _lib.Library(build_emu_canon())
     m = synthetic.tile_metrics(n, nz)
     s = synthetic.acoustic_state(m, n, nz)
-    env = Env(lib, "cpu", m, n, nz)
-    col = column_namelist_arrays(DGridShallowWaterLagrangianDynamicsConfig(), nz)
+    env = Env(lib, "cuda" if gpu else "cpu", m, n, nz)
+    cfg = DGridShallowWaterLagrangianDynamicsConfig()
+    col = column_namelist_arrays(cfg, nz)
     out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, float(s["dt"]))
-    pickle.dump({k: np.ascontiguousarray(v) for k, v in out.items()}, sys.stdout.buffer)
+    op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, get_column_namelist(cfg, env.qf), False,
+                                            False, cfg)
+    pickle.dump(({k: np.ascontiguousarray(v) for k, v in out.items()}, bool(op._pingpong)), sys.stdout.buffer)
 
 
-def test_d_sw_three_scalar_launch_equals_three_launches_emulated():
-    """w, q_con and pt in one launch (k_fvtp2d_scalars3, the default) against the three separate launches
-    (PACE_DSW_FUSED3=0: the fall-back for orders other than 6): every output of d_sw bit for bit."""
+def test_d_sw_separate_outputs_equal_in_place_emulated():
+    """The scalar phase of d_sw writes delp, pt, w, q_con to buffers of their own that the operator swaps in (the default where the
+    library supports it: include/pace_hip.h pace_dsw_config_t) against the library's in-place contract (PACE_DSW_INPLACE=1:
+    workspace outputs + copy back): every output of d_sw bit for bit, whole storage (halos included)."""
     import pickle
     import subprocess
     import sys
@@ -167,12 +174,16 @@ def test_d_sw_three_scalar_launch_equals_three_launches_emulated():
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
             f"import test_emu_kernels as t; t._dsw_child()")
     outs = []
-    for fused in ("1", "0"):
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=900, env=dict(os.environ, PACE_DSW_FUSED3=fused))
+    for inplace in ("", "1"):
+        env = {k: v for k, v in os.environ.items() if k != "PACE_DSW_INPLACE"}
+        if inplace:
+            env["PACE_DSW_INPLACE"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=900, env=env)
         assert p.returncode == 0, p.stderr[-3000:].decode()
         outs.append(pickle.loads(p.stdout))
-    for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    assert outs[0][1] and not outs[1][1], "the first run must have taken the separate outputs, the second not"
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k], equal_nan=True), k
 
 
 def test_fvtp2d_kernel_emulated(emu_lib):
@@ -681,8 +692,10 @@ def test_acoustic_loop_six_synthetic_tiles_emulated_vs_oracle(emu_lib):
     n, nz, n_split = 12, 10, 2
     ref = opchain.oracle_loop(n, nz, n_split, 3.5 * n_split)
     got = opchain.product_loop(emu_lib, "cpu", n, nz, n_split, 3.5 * n_split)
-    for k, e in opchain.loop_errors(ref, got, n, nz).items():
+    detail = {}
+    for k, e in opchain.loop_errors(ref, got, n, nz, detail=detail).items():
         assert e < opchain.LOOP_TOL.get(k, 1e-9), (k, e)
+        assert detail[k]["max_abs_error_over_magnitude"] < opchain.LOOP_ABS_SYNTHETIC, (k, detail[k])
 
 
 def test_standalone_ppm_and_divergence_damping_emulated_vs_oracle(emu_lib):

@@ -662,8 +662,10 @@ def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path, geometry
         json.dump(detail, open(os.path.join(out_dir, f"acoustic_loop_c96_{geometry}_gpu_errors.json"), "w"), indent=1)
     for k, e in errs.items():
         assert e < opchain.LOOP_TOL.get(k, 1e-9), (k, e)
-        if geometry == "sphere":
-            assert detail[k]["max_abs_error_over_magnitude"] < opchain.LOOP_ABS_SPHERE, (k, detail[k])
+        # the ABSOLUTE error, as a fraction of the field's magnitude, is bounded on both geometries: the floors of the relative
+        # metric only mask that metric
+        bound = opchain.LOOP_ABS_SPHERE if geometry == "sphere" else opchain.LOOP_ABS_SYNTHETIC
+        assert detail[k]["max_abs_error_over_magnitude"] < bound, (k, detail[k])
 
 
 def test_standalone_ppm_and_divergence_damping_match_oracle(lib):
@@ -683,3 +685,27 @@ def test_dynamical_core_step_from_generated_inputs_matches_reference_run(lib, tm
     (fixes, outs), (fixes2, outs2) = run_in_child("dycore_generated", tmp_path)
     check_dycore(fixes, outs)
     check_dycore_generated(fixes2, outs2)
+
+
+def test_d_sw_separate_outputs_equal_in_place(lib):
+    """The GPU twin of test_d_sw_separate_outputs_equal_in_place_emulated at C96 x 12: the scalar-phase kernel writing to separate
+    outputs that the operator swaps in, against the library's in-place contract (workspace + copy back): every output of d_sw bit
+    for bit over the whole storage (halos included)."""
+    import pickle
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); "
+            f"import test_emu_kernels as t; t._dsw_child(True)")
+    outs = []
+    for inplace in ("", "1"):
+        env = {k: v for k, v in os.environ.items() if k != "PACE_DSW_INPLACE"}
+        if inplace:
+            env["PACE_DSW_INPLACE"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr[-3000:].decode()
+        outs.append(pickle.loads(p.stdout))
+    assert outs[0][1] and not outs[1][1]
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k], equal_nan=True), k
