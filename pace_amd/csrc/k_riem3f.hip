@@ -143,10 +143,13 @@ __device__ __forceinline__ Mob excl_mob_fwd(Mob m, int r) {
 
 }  // namespace
 
+#ifndef RIEM_WAVES
+#define RIEM_WAVES 3  // waves per SIMD the register budget is set for (168 VGPRs: the five-levels-per-lane instance needs 161)
+#endif
 // CG = 0: riem_solver3 on the compute domain.  CG = 1: riem_solver_c on compute +- 1 (w3 is not modified; outputs gz, pef).
 // L = levels per lane; 16 L >= km.
 template <int CG, int L>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, RIEM_WAVES)
 k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double peln1, double ptk,
               const real* __restrict__ cappa, const real* __restrict__ zs, const real* __restrict__ ws,
               const real* __restrict__ q_con, const real* __restrict__ delp, const real* __restrict__ pt,

@@ -691,6 +691,7 @@ def test_d_sw_separate_outputs_equal_in_place(lib):
     """The GPU twin of test_d_sw_separate_outputs_equal_in_place_emulated at C96 x 12: the scalar-phase kernel writing to separate
     outputs that the operator swaps in, against the library's in-place contract (workspace + copy back): every output of d_sw bit
     for bit over the whole storage (halos included)."""
+    import os
     import pickle
     import subprocess
     import sys
