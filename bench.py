@@ -52,6 +52,10 @@ def parse():
     p.add_argument("--graph", choices=("on", "off"), default="off",
                    help="replay each step from a captured HIP graph (measured: no gain at C48 ... C192 -- the launches are "
                         "already queued ahead of the GPU; kept as an option)")
+    p.add_argument("--full-loop", action="store_true",
+                   help="multi-rank runs: after the timed region, run the WHOLE acoustic loop body (AcousticDynamics: c_sw ... nh_p_grad, "
+                        "all seven halo exchanges of a substep over the transport of the run) and report ms per substep and the host time "
+                        "of every halo updater under comm.full_loop -- a diagnosis, never part of `value`")
     p.add_argument("--emulate", action="store_true",
                    help="TEST ONLY (tests/test_halo.py): run the multi-rank code path -- partitioner, pack / exchange / unpack, barrier, "
                         "max-over-ranks reduction, the JSON line -- on the CPU over gloo with the emulation build of the kernels; no "
@@ -350,6 +354,94 @@ def measure_traffic(kernel_substring, n, nz, precision=64):
     return read_b + write_b, {"read_bytes": read_b, "write_bytes": write_b, "method": "rocprofv3 --pmc, two child passes of this command"}
 
 
+def full_loop_diagnosis(lib, dev, n, nz, rank, world, emulate, n_split=4):
+    """The whole acoustic loop body (reference: fv3core/pace/fv3core/stencils/dyn_core.py:686-945) on this rank's tile over the run's
+    transport: the baroclinic case on the generated cubed sphere at 6 ranks, the synthetic tile on a ring of tiles otherwise (the
+    stand-in topology of the timed step).  Returns ms per substep (max over ranks) and, per halo updater, calls per substep and the
+    mean HOST time of start (pack launch + grouped send / receive post) and wait (+ unpack launch) on this rank."""
+    import collections
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from pace_amd import synthetic
+    from pace_amd.fv3core import AcousticDynamicsConfig, DGridShallowWaterLagrangianDynamicsConfig, RiemannConfig
+    from pace_amd.fv3core.initialization.dycore_state import DycoreState
+    from pace_amd.fv3core.stencils.dyn_core import AcousticDynamics
+    from pace_amd.tile import Env
+    from pace_amd.util import CubedSphereCommunicator, CubedSpherePartitioner, RingPartitioner, TorchDistComm
+    from pace_amd.util import halo as halo_mod
+
+    if world == 6:
+        from pace_amd.fv3core.initialization.baroclinic import baroclinic_state_six_tiles
+        from pace_amd.util import gridgen
+
+        tiles = gridgen.tiles(n, nz)
+        st = baroclinic_state_six_tiles(tiles, n, nz)[rank]
+        metrics = {k: v for k, v in tiles[rank].items() if k not in ("ee1", "ee2", "es1", "ew2")}
+        arrays = {k: st[k] for k in "u v w delz delp pe pk peln phis uc vc ua va pt qvapor ps".split()}
+        timestep = 2 * 225.0 * 48.0 / n / 2.0 / 2.0 * n_split
+        part = CubedSpherePartitioner()
+    else:
+        metrics = synthetic.tile_metrics(n, nz)
+        sy = synthetic.acoustic_state(metrics, n, nz)
+        arrays = {k: sy[k] for k in "u v w delz delp pt pe pk peln q_con ua va uc vc".split()}
+        arrays["phis"] = sy["zs"] * 9.80665
+        timestep = float(sy["dt"]) * n_split
+        part = RingPartitioner(world)
+    env = Env(lib, dev, metrics, n, nz)
+    cube = CubedSphereCommunicator(TorchDistComm(), part, device=dev, lib=lib)
+    state = DycoreState.init_from_numpy_arrays(arrays, env.qf)
+    ac = AcousticDynamicsConfig(n_split=n_split, k_split=1, nord=3, d_con=1.0, rf_fast=True, rf_cutoff=3000.0, tau=10.0, p_fac=0.05,
+                                hord_tm=6, delt_max=0.002, d_grid_shallow_water=DGridShallowWaterLagrangianDynamicsConfig(),
+                                riemann=RiemannConfig(p_fac=0.05))
+    dyn = AcousticDynamics(cube, env.stencil_factory, env.qf, env.grid_data, env.damping, 0, False, False, ac, state.phis, env.q2(), state)
+    names = {id(getattr(w, "_updater", None)): k for k, w in vars(dyn._halo_updaters).items() if getattr(w, "_updater", None) is not None}
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    on = {"v": False}
+    saved = {}
+    for method in ("start", "wait"):
+        orig = getattr(halo_mod.HaloUpdater, method)
+        saved[method] = orig
+
+        def timed(self, *a, _orig=orig, _m=method, **kw):
+            t0 = time.perf_counter()
+            r = _orig(self, *a, **kw)
+            if on["v"]:
+                e = acc[(names.get(id(self), f"updater {self._tag}"), _m)]
+                e[0] += time.perf_counter() - t0
+                e[1] += 1
+            return r
+
+        setattr(halo_mod.HaloUpdater, method, timed)
+    try:
+        sync = (lambda: None) if emulate else torch.cuda.synchronize
+        dyn(state, timestep=timestep, n_map=1)  # warm-up
+        sync()
+        dist.barrier()
+        on["v"] = True
+        t0 = time.perf_counter()
+        dyn(state, timestep=timestep, n_map=1)
+        sync()
+        wall = time.perf_counter() - t0
+    finally:
+        for method, orig in saved.items():
+            setattr(halo_mod.HaloUpdater, method, orig)
+    t = torch.tensor([wall], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    finite = bool(torch.isfinite(state.delp.data).all().item())
+    per = {}
+    for (k, m), (sec, cnt) in sorted(acc.items()):
+        per.setdefault(k, {})[m + "_host_us"] = round(1e6 * sec / max(1, cnt), 1)
+        per[k]["calls_per_substep"] = round(cnt / n_split, 2)
+    host_us = 1e6 * sum(v[0] for v in acc.values()) / n_split
+    return {"what": "AcousticDynamics, whole loop body, not part of the timed region", "n_split": n_split,
+            "topology": "cubed sphere" if world == 6 else f"ring of {world} tiles (stand-in)",
+            "ms_per_substep_max_over_ranks": float(t.item()) * 1e3 / n_split, "halo_host_us_per_substep_this_rank": round(host_us, 1),
+            "updaters": per, "finite": finite}
+
+
 def main():
     args = parse()
     import torch
@@ -591,6 +683,15 @@ def main():
         t = torch.tensor(acc / nd * 1e3, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         phase_ms = {k: float(v) for k, v in zip(names, t.tolist())}
+    # The whole loop body over the run's transport (--full-loop; NOT part of the timed region, and never fatal): AcousticDynamics on
+    # this rank's tile of the baroclinic case, four substeps, every HaloUpdater.start / wait timed on the host.
+    full_loop = None
+    if world > 1 and args.full_loop:
+        arm("full loop diagnosis")
+        try:
+            full_loop = full_loop_diagnosis(lib, dev, n, nz, rank, world, args.emulate)
+        except Exception as e:  # noqa: BLE001 -- a diagnosis must not cost the measured line
+            full_loop = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     cells = n * n * nz
     value = world * cells * args.steps / elapsed
     # the last TIMED batch's fields as the device left them (taken now: the roofline loop below accumulates into mfx / mfy)
@@ -713,6 +814,8 @@ def main():
             # what the collective library saw (RCCL is reached through torch.distributed's "nccl" backend)
             line["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                             "phase_ms_max_over_ranks_synchronised": phase_ms}
+            if full_loop is not None:
+                line["comm"]["full_loop"] = full_loop
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             try:
                 rec, ref = cpu_baseline(n, nz, metrics, s, dt, ptop)

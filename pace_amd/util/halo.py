@@ -290,10 +290,12 @@ class VectorInterfaceHaloUpdater:
         nk = _nk_of(spec_x)
         self._geom = _lib.Geom(n, spec_x.shape[2] - 1, spec_x.strides[1], 0, spec_x.strides[2])
         tile = communicator.rank
-        if not isinstance(communicator.partitioner, CubedSpherePartitioner):
-            raise NotImplementedError("synchronize_vector_interfaces is defined on the cubed sphere only")
-        (to_s, rot_s), (to_w, rot_w) = tile_neighbour(tile, SOUTH), tile_neighbour(tile, WEST)
-        (from_n, _), (from_e, _) = tile_neighbour(tile, NORTH), tile_neighbour(tile, EAST)
+        if isinstance(communicator.partitioner, CubedSpherePartitioner):
+            nb = tile_neighbour
+        else:  # (the ring of tiles bench.py uses at rank counts that cannot form a cube: no rotations, both go to the previous tile)
+            nb = communicator.partitioner.neighbour
+        (to_s, rot_s), (to_w, rot_w) = nb(tile, SOUTH), nb(tile, WEST)
+        (from_n, _), (from_e, _) = nb(tile, NORTH), nb(tile, EAST)
         msgs = _Messages(communicator.device, [to_s, to_w], [from_n, from_e], spec_x.dtype)
         # south row of x (field 0): reversed if the neighbour's axis runs the other way, sign from the vector rotation
         rev = (-rot_s) % 4 == 1

@@ -427,3 +427,30 @@ def test_bench_six_ranks_dry_run_over_gloo(tmp_path):
     assert set(ph) == {"uc_vc_start(pack+post)", "flux_prep_interior", "uc_vc_wait(+unpack)", "d_sw_rest", "delp_pt_qcon_start(pack+post)",
                        "delp_pt_qcon_wait(+unpack)", "riem_solver3"}
     assert all(v >= 0.0 for v in ph.values()) and ph["d_sw_rest"] > 0.0
+
+
+def test_bench_full_loop_diagnosis_two_ranks_over_gloo(tmp_path):
+    """`bench.py --gpus 2 --full-loop` on the CPU (gloo, emulation build): after the timed region the whole acoustic loop body
+    (AcousticDynamics, all of a substep's halo exchanges over torch.distributed on the ring of tiles) runs and reports ms per
+    substep and the host time of every halo updater -- what a first multi-GPU run needs to diagnose the whole pattern."""
+    import json
+
+    build_emu()
+    port = 37500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tile-size", "12",
+           "--nz", "8", "--emulate", "--watchdog", "240", "--full-loop"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    fl = json.loads(lines[0])["comm"]["full_loop"]
+    assert "error" not in fl, fl
+    assert fl["finite"] and fl["ms_per_substep_max_over_ranks"] > 0 and "ring of 2" in fl["topology"]
+    # the seven exchanges of a substep (dyn_core.py:720-942) + the three before the loop, gz on the first substep, heat_source after
+    per = fl["updaters"]
+    assert {"w", "divgd", "uc__vc", "delp__pt__q_con", "zh", "pkc", "u__v"} <= set(per)
+    for k in ("w", "divgd", "uc__vc", "delp__pt__q_con", "zh", "pkc", "u__v"):
+        assert per[k]["calls_per_substep"] == 1.0, (k, per[k])
+    for k in ("q_con__cappa", "delp__pt", "gz", "heat_source"):
+        assert per[k]["calls_per_substep"] == 0.25, (k, per[k])

@@ -3,7 +3,7 @@
 # profiles/).  Run from the repo root:  /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 # rocprofv3: the program itself after `--`, counters in their own passes, no tracing domain besides the kernel trace.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -14,9 +14,12 @@ python bench.py > "$O/bench.json" 2> "$O/bench.err"
 # (each size twice, the second line kept: the first run of a size on a fresh box pays for its set-up -- caches of the state, clocks)
 for n in 48 96 384; do python bench.py --tile-size $n --no-cpu-baseline --no-traffic > /dev/null 2>&1; python bench.py --tile-size $n --no-cpu-baseline --no-traffic 2>/dev/null | tail -1; done > "$O/bench_sizes.jsonl"
 python tools/acoustic_bench.py 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench.txt"
-# stage times of the transport kernel's workgroups (interior / corner / edge tiles) and A/B against the round-2 library
-[ -f build/prof/libpace_prof.so ] && python tools/exp_variants.py prod=pace_amd/libpace_hip.so prof=build/prof/libpace_prof.so 2>/dev/null | grep -v amdgpu > "$O/transport_stage_times.txt"
+python tools/acoustic_bench.py --n 96 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench_c96.txt"   # BASELINE configuration 3
+# stage times of the scalar-phase kernel's workgroups (interior / corner / edge tiles): tools/build_prof.sh builds the stamped library
+[ -f build/var/prof/libpace_hip.so ] && python tools/fvt_stage_times.py 2>/dev/null | grep -v amdgpu > "$O/scalar_phase_stage_times.txt"
 bash tools/kernel_times.sh prod=pace_amd/libpace_hip.so 2>/dev/null > "$O/kernel_times_single_stream.txt"
+bash tools/pmc_kernels.sh prod=pace_amd/libpace_hip.so 2>/dev/null > "$O/pmc_kernels.json"
+python tools/step_table.py "$O/kernel_times_single_stream.txt" "$O/pmc_kernels.json" > "$O/step_table.json"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$O/trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-traffic > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
 rocprofv3 --kernel-trace --stats -d "$O/trace_loop" -o loop -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2> "$O/trace_loop.err"
@@ -28,7 +31,7 @@ cd "$R"
 DB=$(find "$O/trace" -name '*.db' | head -1)
 DBL=$(find "$O/trace_loop" -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" > "$O/kernel_stats.csv" && python tools/rocprof_timeline.py "$DB" > "$O/timeline.txt"
-[ -n "$DB" ] && python tools/rocprof_isolated.py "$DB" k_fvtp2dILi6ELi2ELi1E > "$O/dominant_kernel_alone.txt"
+[ -n "$DB" ] && python tools/rocprof_isolated.py "$DB" k_fvt_scalars > "$O/dominant_kernel_alone.txt"
 [ -n "$DBL" ] && python tools/rocprof_summary.py "$DBL" > "$O/whole_loop_kernel_stats.csv"
 python tools/pmc_summary.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" > "$O/pmc_traffic.json"
 python tools/pmc_summary.py "$O/pmc_loop_FETCH_SIZE" "$O/pmc_loop_WRITE_SIZE" > "$O/whole_loop_pmc_traffic.json"
