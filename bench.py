@@ -52,6 +52,11 @@ def parse():
     p.add_argument("--graph", choices=("on", "off"), default="off",
                    help="replay each step from a captured HIP graph (measured: no gain at C48 ... C192 -- the launches are "
                         "already queued ahead of the GPU; kept as an option)")
+    p.add_argument("--overlap", choices=("on", "off", "auto"), default="auto",
+                   help="the wind half of d_sw on a side stream next to the scalar phase / the column solver (on), or the whole step "
+                        "on one stream (off).  auto: off on one GPU -- measured in round 4 at C48 / C96 / C192: 0.224 / 0.345 / 0.966 ms "
+                        "on one stream against 0.248 / 0.373 / 0.978 with the side stream (the sum of the kernels' isolated times is "
+                        "the step: nothing is left to overlap) --, on when a halo exchange is in flight (more than one rank)")
     p.add_argument("--full-loop", action="store_true",
                    help="multi-rank runs: after the timed region, run the WHOLE acoustic loop body (AcousticDynamics: c_sw ... nh_p_grad, "
                         "all seven halo exchanges of a substep over the transport of the run) and report ms per substep and the host time "
@@ -588,6 +593,8 @@ def main():
         topology = "uc,vc before and delp,pt,q_con after d_sw over RCCL (cubed sphere)" if world == 6 else \
             f"uc,vc before and delp,pt,q_con after d_sw over RCCL (ring of {world} tiles: stand-in topology, cubed-sphere strip sizes)"
 
+    overlap = args.overlap == "on" or (args.overlap == "auto" and world > 1)
+
     def step(b):
         args = [b[k] for k in DSW_ARGS]
         if exchange is not None:
@@ -596,7 +603,7 @@ def main():
             dsw.start_flux_preparation(*args, dt)
             exchange_winds.wait()
         # the wind half of d_sw runs on a side stream, concurrently with the (latency-bound) column solver
-        dsw(*args, dt, overlap_winds=True)
+        dsw(*args, dt, overlap_winds=overlap)
         if exchange is not None:
             # delp / pt / q_con travel while the column solver runs: it works on the compute domain's columns only (the halos are
             # needed by what follows it -- pk3_halo, nh_p_grad, the next substep's c_sw; dyn_core.py:854 updates them right here)
@@ -804,7 +811,8 @@ def main():
             "config": {"workload": f"C{n}x{nz}L one tile per GPU, d_sw + riem_solver3 acoustic substep, " + ("fp64" if lib.real_bytes == 8 else "fp32 fields"),
                        "cells_per_tile": cells, "tiles": world, "parallelism": f"tile-per-gpu x{world}",
                        "halo_exchange": topology,
-                       "launch": "hip graph replay" if use_graph else "eager"},
+                       "launch": "hip graph replay" if use_graph else "eager",
+                       "streams": "wind half of d_sw on a side stream" if overlap else "one stream"},
             "step_hbm_frac": BYTES_PER_CELL_UPDATE * (item / 8.0) * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,
         }
