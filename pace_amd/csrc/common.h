@@ -270,11 +270,13 @@ __device__ __forceinline__ void ppm_fluxes_from_al(const double* Q, const double
     // both are Q + (1 - a) * (X - a * B) on the upwind cell's values -- the same bits (1 + c == 1 - |c| and bl + c * b0 ==
     // bl - |c| * b0 for c <= 0: a sign moved, no rounding) -- selected as values instead of as branches: a divergent branch per
     // face costs seven scalar instructions of exec-mask bookkeeping and both arms.
+    // (X = br of the cell behind the face or bl of the cell in front of it: both are al[f + 1] - that cell's value, the very
+    // expressions of the cell loop above -- one select less)
     const bool up = cc > 0.0;
     const double a = fabs(cc);
-    const double X = up ? br[f] : bl[f + 1];
-    const double B = up ? b0[f] : b0[f + 1];
     const double Qs = up ? Q[f + 2] : Q[f + 3];
+    const double X = al[f + 1] - Qs;
+    const double B = up ? b0[f] : b0[f + 1];
     const double fx1 = (1.0 - a) * (X - a * B);
     out[f] = Qs + fx1 * mask;
   }
