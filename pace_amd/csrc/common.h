@@ -382,6 +382,47 @@ static inline Regions bgrid_regions(const Geo& g, int d) {
     if (j > (R).je[reg__]) return;                                                             \
   }
 static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsigned)r.first[r.n], 1, (unsigned)nlev); }
+// The same with the workgroups of a level on ONE XCD (workgroups are dealt to the eight XCDs round-robin in launch order; each
+// XCD has its own L2): for kernels whose points re-read rows of their j-neighbours -- with the plain order the patch above and
+// the patch below run on other XCDs and every XCD fetches its own copy of the shared rows.  XCD x works through levels x, x + 8,
+// ... (affinity only; the map is a bijection of the launch's workgroups).
+#ifdef PACE_EMU
+#define REGION_POINT_XCD(R) REGION_POINT(R)
+#else
+#define REGION_POINT_XCD(R)                                                                    \
+  int bx__, bz__;                                                                              \
+  {                                                                                            \
+    const int nbx__ = (int)gridDim.x, nlev__ = (int)gridDim.z;                                 \
+    const int lin__ = (int)blockIdx.x + nbx__ * (int)blockIdx.z;                               \
+    const int full__ = (nlev__ / 8) * 8;                                                       \
+    if (lin__ < full__ * nbx__) {                                                              \
+      const int slot__ = lin__ >> 3;                                                           \
+      bz__ = (slot__ / nbx__) * 8 + (lin__ & 7);                                               \
+      bx__ = slot__ - (slot__ / nbx__) * nbx__;                                                \
+    } else {                                                                                   \
+      bz__ = lin__ / nbx__;                                                                    \
+      bx__ = lin__ - bz__ * nbx__;                                                             \
+    }                                                                                          \
+  }                                                                                            \
+  int reg__ = 0;                                                                               \
+  while (reg__ + 1 < (R).n && bx__ >= (R).first[reg__ + 1]) ++reg__;                           \
+  const int b__ = bx__ - (R).first[reg__];                                                     \
+  const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
+  const bool interior = reg__ == 0;                                                            \
+  int i, j;                                                                                    \
+  const int k = bz__;                                                                          \
+  if (interior) {                                                                              \
+    i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
+    j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
+    if (i > (R).ie[0] || j > (R).je[0]) return;                                                \
+  } else {                                                                                     \
+    const int w__ = (R).ie[reg__] - (R).ib[reg__] + 1;                                         \
+    const int p__ = b__ * 256 + t__;                                                           \
+    j = (R).jb[reg__] + p__ / w__;                                                             \
+    i = (R).ib[reg__] + p__ % w__;                                                             \
+    if (j > (R).je[reg__]) return;                                                             \
+  }
+#endif
 
 // Last HIP error text seen by this library on the calling thread (pace_last_error()).
 extern thread_local char g_pace_err[256];

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256)
 k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
                  const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ut,
                  const real* __restrict__ vt, real* __restrict__ ke, double dt, Regions R) {
-  REGION_POINT(R);
+  REGION_POINT_XCD(R);  // (six rows of v per point: the j-neighbouring patches share an L2 -- 255 -> 156 MB, round 3's x17)
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;

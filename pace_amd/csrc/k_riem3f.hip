@@ -157,9 +157,13 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
               real* __restrict__ pk3, real* __restrict__ pk, real* __restrict__ peln, real* __restrict__ w) {
   const int r = threadIdx.x & (ROW - 1);   // level block of this lane
   const int col = threadIdx.x >> 4;        // column within the workgroup
-  const int i = g.is - CG + blockIdx.x * 16 + col;
+  // A workgroup's sixteen columns are one 128-byte line of every level row it touches: the column window starts at a multiple of 16
+  // (the compute domain starts at i = 3: windows anchored there straddled two lines each, and the line shared with the neighbouring
+  // workgroup -- which runs on another XCD -- was fetched by both: measured 1.76 x the algorithmic reads).  The first and the
+  // last workgroup of a row hold a few columns outside the domain, which leave.
+  const int i = ((g.is - CG) & ~15) + blockIdx.x * 16 + col;
   const int j = g.js - CG + blockIdx.y;
-  if (i > g.ie + CG) return;  // whole rows leave together: a row is one column
+  if (i < g.is - CG || i > g.ie + CG) return;  // whole rows leave together: a row is one column
   const int km = g.nk;
   const long sk = g.sk;
   const long c0 = IDX2(g, i, j);
@@ -509,7 +513,8 @@ static int launch_column(const Geo& g, int last_call, double dt, double ptop, do
   const double peln1 = log(ptop);
   const double ptk = exp(KAPPA * peln1);
   const int ncol = g.n + 2 * CG;
-  const dim3 grid((ncol + 15) / 16, ncol), block(256);
+  const int first = (g.is - CG) & ~15;  // (the aligned window of the kernel)
+  const dim3 grid((g.ie + CG - first + 16) / 16, ncol), block(256);
 #define GO(L)                                                                                                                  \
   hipLaunchKernelGGL((k_riem_column<CG, L>), grid, block, 0, st, g, last_call, dt, ptop, p_fac, peln1, ptk, cappa, zs, ws, q_con, \
                      delp, pt, delz, zh, pe, ppe, pk3, pk, peln, w)
