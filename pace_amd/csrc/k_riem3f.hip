@@ -69,6 +69,67 @@ __device__ __forceinline__ double dn(double v, int d) {
 }
 #endif
 
+// ---- exp / log of the D-grid solver ----------------------------------------------------------------------------------------
+// riem_solver3 takes seven exp / log per level (riem_solver3.py:63-141, sim1_solver.py:118-141); the library's versions are ~65
+// instructions each with their special-case handling -- a third of this kernel's 6 300 instructions per wave, and the kernel is
+// bound by exactly that count (161 VGPRs = three waves per SIMD: ~12 cycles per instruction).  The arguments here are pressures
+// and pressure ratios -- positive, finite, far from the ends of the exponent range -- and the operator's bound is 5e-6
+// (overrides/standard.yaml:49-61), so: straight range reduction + polynomial, no special cases, ~1e-16 relative error
+// (tools/riem_check.py prints the errors against the numpy oracle).  The C-grid solver (bound 5e-14) keeps the library functions.
+__device__ __forceinline__ double lean_log(double x) {
+  int e;
+  double m = frexp(x, &e);  // [0.5, 1)
+  if (m < 0.70710678118654752440) {
+    m = m + m;
+    e = e - 1;
+  }
+  // log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716
+  const double f = m - 1.0;
+  const double d = 2.0 + f;
+  double r = 1.0 / d;
+  const double s = f * r;
+  const double z = s * s;
+  double p = 2.0 / 21.0;
+  p = fma(p, z, 2.0 / 19.0);
+  p = fma(p, z, 2.0 / 17.0);
+  p = fma(p, z, 2.0 / 15.0);
+  p = fma(p, z, 2.0 / 13.0);
+  p = fma(p, z, 2.0 / 11.0);
+  p = fma(p, z, 2.0 / 9.0);
+  p = fma(p, z, 2.0 / 7.0);
+  p = fma(p, z, 2.0 / 5.0);
+  p = fma(p, z, 2.0 / 3.0);
+  // 2 s + s z p, with the rounding of s = f / d taken back: s_lo = (f - s d) / d
+  const double s_lo = fma(-s, d, f) * r;
+  const double lm = fma(s * z, p, 2.0 * s_lo) + 2.0 * s;
+  const double de = (double)e;
+  return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+}
+__device__ __forceinline__ double lean_exp(double x) {
+  const double k = rint(x * 1.44269504088896338700e+00);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);  // |r| <= 0.3466
+  double p = 1.0 / 6227020800.0;  // 1 / 13!
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+template <int CG>
+__device__ __forceinline__ double col_log(double x) { return CG ? log(x) : lean_log(x); }
+template <int CG>
+__device__ __forceinline__ double col_exp(double x) { return CG ? exp(x) : lean_exp(x); }
+
 // ---- scan of additions over the row: returns the sum of the values of the lanes BEFORE (fwd) / AFTER (bwd) this one ----
 __device__ __forceinline__ double excl_add_fwd(double v, int r) {
 #pragma unroll
@@ -143,6 +204,43 @@ __device__ __forceinline__ Mob excl_mob_fwd(Mob m, int r) {
 
 }  // namespace
 
+// ---- the lanes of a workgroup as movers of whole lines (see k_riem_column) ----
+#ifdef PACE_EMU
+#define RIEM_OPAQUE(x)
+#else
+#define RIEM_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+#define RIEM_LP 17
+#define RIEM_LDG(p, off) (*(const real*)((const char*)(p) + (off)))
+#define RIEM_STG(p, off) (*(real*)((char*)(p) + (off)))
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+template <int L>
+struct Mover {
+  int xl, xc;        // level (of the first piece) and column within the window
+  unsigned row, sk;  // element offset of (column, j) at level 0; level stride
+  bool in;           // the column is in the domain
+  __device__ __forceinline__ Mover(const Geo& g, int cg, int first, int j) {
+    int tid = threadIdx.x;
+    RIEM_OPAQUE(tid);
+    xl = tid >> 4;
+    xc = tid & 15;
+    const int iw = first + xc;
+    in = iw >= g.is - cg && iw <= g.ie + cg;
+    row = (unsigned)IDX2(g, clampi(iw, g.is - cg, g.ie + cg), j);
+    sk = (unsigned)g.sk;
+  }
+  // byte offset of piece n in a field whose last level is `last` (pieces beyond it repeat it); 32 bits: riem_column_supported
+  __device__ __forceinline__ unsigned at(int n, int last) const {
+    const int lv = xl + 16 * n;
+    return (row + (unsigned)(lv < last ? lv : last) * sk) * (unsigned)sizeof(real);
+  }
+  __device__ __forceinline__ int slot(int n) const { return (xl + 16 * n) * RIEM_LP + xc; }
+  __device__ __forceinline__ bool has(int n, int nlev) const { return in && xl + 16 * n < nlev; }
+};
+
+#ifndef RIEM_STAMP
+#define RIEM_STAMP(n)  // (tools/census/riem_prof.hip compiles shader-clock stamps in here)
+#endif
 #ifndef RIEM_WAVES
 #define RIEM_WAVES 3  // waves per SIMD the register budget is set for (168 VGPRs: the five-levels-per-lane instance needs 161)
 #endif
@@ -160,34 +258,83 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
   // A workgroup's sixteen columns are one 128-byte line of every level row it touches: the column window starts at a multiple of 16
   // (the compute domain starts at i = 3: windows anchored there straddled two lines each, and the line shared with the neighbouring
   // workgroup -- which runs on another XCD -- was fetched by both: measured 1.76 x the algorithmic reads).  The first and the
-  // last workgroup of a row hold a few columns outside the domain, which leave.
-  const int i = ((g.is - CG) & ~15) + blockIdx.x * 16 + col;
+  // last workgroup of a row hold a few columns outside the domain: they solve a copy of the nearest column and store nothing.
+  const int first = ((g.is - CG) & ~15) + blockIdx.x * 16;
   const int j = g.js - CG + blockIdx.y;
-  if (i < g.is - CG || i > g.ie + CG) return;  // whole rows leave together: a row is one column
   const int km = g.nk;
-  const long sk = g.sk;
-  const long c0 = IDX2(g, i, j);
+  // (this lane's own column, for the two surface fields)
+#define OWN_COLUMN() IDX2(g, clampi(first + col, g.is - CG, g.ie + CG), j)
+  // Fields move between memory and the lanes that solve through LDS.  In the solver's own arrangement (a lane = five levels of
+  // one column) a wave's load touches sixteen lines for 32 bytes each, and the four waves of the workgroup ask for the same
+  // lines at different times: the load and store stages were 60 % of a wave's 74 000 cycles (tools/riem_stage_times.py), and
+  // the same kernel with line-shaped addresses (wrong data) ran in 92 us instead of 142.  So: as MOVERS the 256 lanes are
+  // 16 levels x 16 columns -- a wave's access is four whole lines -- and level xl + 16 n of column xc is lane (xl, xc)'s n-th
+  // piece; as SOLVERS they read their own levels from the LDS copy ([level][17]: the pad keeps the two views off each other's
+  // banks).
+  constexpr int LP = RIEM_LP, NLV = 16 * L + 1;
+  __shared__ double xs_[3][NLV * LP];
+  // (the movers' addresses are rebuilt from the lane number at each of the three places they are used -- RIEM_OPAQUE keeps the
+  // compiler from holding them in registers across the solver, which sits at the 168-register limit of three waves per SIMD)
+#define MOVER() const Mover<L> M(g, CG, first, j)
+  // fetch: the pieces of a field with nlev levels (16 L + 1 at most: the last one is the extra piece of the movers of level 0)
+#define FETCH(v, f, nlev)                                                                          \
+  double v[L + 1];                                                                                 \
+  _Pragma("unroll") for (int n = 0; n < L; ++n) v[n] = RIEM_LDG(f, M.at(n, (nlev) - 1));           \
+  v[L] = (16 * L < (nlev)) ? (double)RIEM_LDG(f, M.at(L, (nlev) - 1)) : 0.0
+#define PUT(b, v, nlev)                                                                            \
+  do {                                                                                             \
+    _Pragma("unroll") for (int n = 0; n < L; ++n) xs_[b][M.slot(n)] = v[n];                        \
+    if (16 * L < (nlev) && M.xl == 0) xs_[b][M.slot(L)] = v[L];                                    \
+  } while (0)
+  // store: the mover's pieces of the LDS copy b go to field f (levels 0 .. nlev-1, the columns of the domain)
+#define STORE(b, f, nlev)                                                                          \
+  do {                                                                                             \
+    _Pragma("unroll") for (int n = 0; n < L; ++n)                                                  \
+      if (M.has(n, nlev)) RIEM_STG(f, M.at(n, (nlev) - 1)) = xs_[b][M.slot(n)];                    \
+    if (16 * L < (nlev) && M.has(L, nlev)) RIEM_STG(f, M.at(L, (nlev) - 1)) = xs_[b][M.slot(L)];   \
+  } while (0)
+#define MINE(b, k) xs_[b][(k) * LP + col]
   const int k0 = r * L;
   const double t1g = 2.0 * dt * dt, rdt = 1.0 / dt;
-#define AT(k) (c0 + (long)(k) * sk)
 #define LEV(t) (k0 + (t))
 #define ON(t) (LEV(t) < km)
 #define CL(k) ((k) < km ? (k) : km - 1)
 #define DM(x) (CG ? (x) / GRAV : (x) * RGRAV)
 
+  RIEM_STAMP(0);
   // ---------------- loads ----------------
   double d_[L], qc_[L], ca_[L], pt_[L], w1_[L], zh_[L + 1];
+  {
+    MOVER();
+    FETCH(m0, delp, km);
+    FETCH(m1, q_con, km);
+    FETCH(m2, cappa, km);
+    FETCH(m3, pt, km);
+    FETCH(m4, w, km);
+    FETCH(m5, zh, km + 1);
+    PUT(0, m0, km);
+    PUT(1, m1, km);
+    PUT(2, m2, km);
+    __syncthreads();
 #pragma unroll
-  for (int t = 0; t < L; ++t) {
-    const long a = AT(CL(LEV(t)));
-    d_[t] = delp[a];
-    qc_[t] = q_con[a];
-    ca_[t] = cappa[a];
-    pt_[t] = pt[a];
-    w1_[t] = w[a];
+    for (int t = 0; t < L; ++t) {
+      d_[t] = MINE(0, CL(LEV(t)));
+      qc_[t] = MINE(1, CL(LEV(t)));
+      ca_[t] = MINE(2, CL(LEV(t)));
+    }
+    __syncthreads();
+    PUT(0, m3, km);
+    PUT(1, m4, km);
+    PUT(2, m5, km + 1);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      pt_[t] = MINE(0, CL(LEV(t)));
+      w1_[t] = MINE(1, CL(LEV(t)));
+    }
+#pragma unroll
+    for (int t = 0; t <= L; ++t) zh_[t] = MINE(2, LEV(t) <= km ? LEV(t) : km);
   }
-#pragma unroll
-  for (int t = 0; t <= L; ++t) zh_[t] = zh[AT(LEV(t) <= km ? LEV(t) : km)];
 
   // ---------------- interface pressures (riem_solver3.py:63-81 / riem_solver_c.py:50-66) ----------------
   double sp = 0.0, sg = 0.0;
@@ -206,28 +353,31 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
     pg_[t + 1] = pg_[t] + d_[t] * (1.0 - qc_[t]);
   }
 
+  RIEM_STAMP(1);
   // ---------------- per-level quantities of precompute + the first statement of sim1_solver ----------------
   double dm_[L], gm_[L], dz_[L], pm_[L], pe0_[L];
   {
-    double lg_prev = CG ? 0.0 : ((LEV(0) == 0) ? peln1 : log(pg_[0]));  // (riem_solver_c takes the log of the ratio instead)
+    double lg_prev = CG ? 0.0 : ((LEV(0) == 0) ? peln1 : col_log<CG>(pg_[0]));  // (riem_solver_c takes the log of the ratio instead)
 #pragma unroll
     for (int t = 0; t < L; ++t) {
       dm_[t] = DM(d_[t]);
       gm_[t] = 1.0 / (1.0 - ca_[t]);
       dz_[t] = zh_[t + 1] - zh_[t];
       if (CG) {
-        pm_[t] = (pg_[t + 1] - pg_[t]) / log(pg_[t + 1] / pg_[t]);
+        pm_[t] = (pg_[t + 1] - pg_[t]) / col_log<CG>(pg_[t + 1] / pg_[t]);
       } else {
-        const double lg = log(pg_[t + 1]);
+        const double lg = col_log<CG>(pg_[t + 1]);
         pm_[t] = (pg_[t + 1] - pg_[t]) / (lg - lg_prev);
         lg_prev = lg;
       }
-      pe0_[t] = exp(gm_[t] * log(-dm_[t] / dz_[t] * RDGAS * pt_[t])) - pm_[t];
+      pe0_[t] = col_exp<CG>(gm_[t] * col_log<CG>(-dm_[t] / dz_[t] * RDGAS * pt_[t])) - pm_[t];
     }
   }
+  RIEM_STAMP(2);
   if (!CG) {
     // pk3 = p_interface ** kappa, and on the last call peln = log p_interface, pk, pe (riem_solver3.py:66-76,136-141).
     // A lane writes the interfaces above its own levels; the lane that owns level km - 1 also writes interface km.
+    __syncthreads();  // (everyone has read the inputs)
 #pragma unroll
     for (int t = 0; t <= L; ++t) {
       const int k = LEV(t);
@@ -239,19 +389,27 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
           logp = peln1;
           pk3v = ptk;
         } else {
-          logp = log(pem_[t]);
-          pk3v = exp(KAPPA * logp);
+          logp = col_log<CG>(pem_[t]);
+          pk3v = col_exp<CG>(KAPPA * logp);
         }
-        pk3[AT(k)] = pk3v;
+        MINE(0, k) = pk3v;
         if (last_call) {
-          peln[AT(k)] = logp;
-          pk[AT(k)] = pk3v;
-          pe[AT(k)] = pem_[t];
+          MINE(1, k) = logp;
+          MINE(2, k) = pem_[t];
         }
       }
     }
+    __syncthreads();
+    MOVER();
+    STORE(0, pk3, km + 1);
+    if (last_call) {
+      STORE(1, peln, km + 1);
+      STORE(0, pk, km + 1);
+      STORE(2, pe, km + 1);
+    }
   }
 
+  RIEM_STAMP(3);
   // neighbours' edge values
   const double dm_next = dn(dm_[0], 1);    // dm of the level after this block
   const double pe0_next = dn(pe0_[0], 1);
@@ -338,6 +496,7 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
       x_[t] = xn;
     }
   }
+  RIEM_STAMP(4);
   // pp on the interfaces of this block: ppi_[t] = pp_{k0+t}
   double ppi_[L + 1];
   {
@@ -357,10 +516,11 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
   }
   aa_[L] = dn(aa_[0], 1);
 
+  RIEM_STAMP(5);
   // ---------------- system 2: w (sim1_solver.py:99-117) ----------------
   double wn_[L];
   {
-    const double wsv = ws[c0];
+    const double wsv = ws[OWN_COLUMN()];
     // the surface term replaces aa_{k+1} in the last row
     double p1s_[L];
 #pragma unroll
@@ -423,6 +583,7 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
     }
   }
 
+  RIEM_STAMP(6);
   // ---------------- perturbation pressure on interfaces (sim1_solver.py:112-117) ----------------
   double pei_[L + 2];
   {
@@ -436,6 +597,7 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
     pei_[L + 1] = dn(pei_[1], 1);
   }
 
+  RIEM_STAMP(7);
   // ---------------- p1 (sim1_solver.py:118-132), backwards ----------------
   double p1_[L];
   {
@@ -462,6 +624,7 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
     }
   }
 
+  RIEM_STAMP(8);
   // ---------------- new layer thickness (sim1_solver.py:133-141) and the height rebuild ----------------
   double dzn_[L];
   double sdz = 0.0;
@@ -469,37 +632,57 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
   for (int t = 0; t < L; ++t) {
     // NB: the reference tests p_fac * delta_mass (sim1_solver.py:134), kept as is
     const double maxp = (p_fac * dm_[t] > p1_[t] + pm_[t]) ? p_fac * pm_[t] : p1_[t] + pm_[t];
-    dzn_[t] = -dm_[t] * RDGAS * pt_[t] * exp((ca_[t] - 1.0) * log(maxp));
+    dzn_[t] = -dm_[t] * RDGAS * pt_[t] * col_exp<CG>((ca_[t] - 1.0) * col_log<CG>(maxp));
     if (ON(t)) sdz = sdz + (CG ? dzn_[t] * GRAV : dzn_[t]);
   }
+  RIEM_STAMP(9);
   {
     // zh_km = zs, zh_k = zh_{k+1} - delz_k (riem_solver3.py:142-145); gz_km = hs, gz_k = gz_{k+1} - dz_k g (riem_solver_c.py:117-123)
-    double z = zs[c0] - excl_add_bwd(sdz, r);  // height of the interface below this block
+    double z = zs[OWN_COLUMN()] - excl_add_bwd(sdz, r);  // height of the interface below this block
     // (interface km is written by the lane whose block ends with level km - 1 or, if km is a multiple of L, by nobody else)
+    __syncthreads();  // (the movers have taken pk3 ... / everyone has read the inputs)
 #pragma unroll
     for (int t = L - 1; t >= 0; --t) {
       if (!ON(t)) continue;
-      if (LEV(t) == km - 1) zh[AT(km)] = z;
+      if (LEV(t) == km - 1) MINE(0, km) = z;
       z = z - (CG ? dzn_[t] * GRAV : dzn_[t]);
-      zh[AT(LEV(t))] = z;
+      MINE(0, LEV(t)) = z;
     }
   }
 #pragma unroll
   for (int t = 0; t < L; ++t) {
     if (!ON(t)) continue;
-    const long a = AT(LEV(t));
+    const int k = LEV(t);
     if (CG) {
       // finalize (riem_solver_c.py:91-116): pef = pe + pem below the top
-      ppe[a] = (LEV(t) == 0) ? ptop : pei_[t] + pem_[t];
-      if (LEV(t) == km - 1) ppe[AT(km)] = pei_[t + 1] + pem_[t + 1];
+      MINE(1, k) = (k == 0) ? ptop : pei_[t] + pem_[t];
+      if (k == km - 1) MINE(1, km) = pei_[t + 1] + pem_[t + 1];
     } else {
-      delz[a] = dzn_[t];
-      w[a] = wn_[t];
-      ppe[a] = pei_[t];
-      if (LEV(t) == km - 1) ppe[AT(km)] = pei_[t + 1];
+      MINE(1, k) = pei_[t];
+      if (k == km - 1) MINE(1, km) = pei_[t + 1];
+      MINE(2, k) = dzn_[t];
     }
   }
-#undef AT
+  __syncthreads();
+  MOVER();
+  STORE(0, zh, km + 1);
+  STORE(1, ppe, km + 1);
+  if (!CG) {
+    STORE(2, delz, km);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < L; ++t)
+      if (ON(t)) MINE(2, LEV(t)) = wn_[t];
+    __syncthreads();
+    STORE(2, w, km);
+  }
+  RIEM_STAMP(10);
+#undef MOVER
+#undef OWN_COLUMN
+#undef FETCH
+#undef PUT
+#undef STORE
+#undef MINE
 #undef LEV
 #undef ON
 #undef CL
@@ -532,7 +715,10 @@ static int launch_column(const Geo& g, int last_call, double dt, double ptop, do
 }
 
 // the column solvers accept up to 128 layers in this form (the thread-per-column kernels of k_riem3.hip serve beyond that)
-bool riem_column_supported(const Geo& g) { return g.nk >= 2 && g.nk <= 128; }
+bool riem_column_supported(const Geo& g) {
+  // (the movers of k_riem_column address a field with 32-bit byte offsets)
+  return g.nk >= 2 && g.nk <= 128 && (double)g.sk * (g.nk + 1) * sizeof(real) < 4.0e9;
+}
 
 int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const real* cappa, double ptop, const real* zs,
                                const real* wsd, real* delz, const real* q_con, const real* delp, const real* pt,

@@ -87,4 +87,4 @@ static inline T __shfl(T v, int src, int width = 64) {
 }
 
 using std::exp; using std::log; using std::sqrt; using std::fabs; using std::fmin; using std::fmax;
-using std::sin; using std::cos; using std::asin; using std::pow;
+using std::sin; using std::cos; using std::asin; using std::pow; using std::frexp; using std::ldexp; using std::rint; using std::fma;
