@@ -225,6 +225,58 @@ k_spline_to_interfaces_lds(Geo g, SplineK s, const real* __restrict__ q0, const 
 }
 
 
+// The same with the forward sweep's values in REGISTERS (km <= 80): the LDS form holds 48 KB per 64 columns -- three waves per
+// CU, each a serial chain of km divisions: 86 us at C192 x 79 for 205 MB moved.  160 registers of forward values leave two
+// waves per SIMD (eight per CU), and the levels are read sixteen at a time ahead of the chain.
+#define SPL_REGK 80
+__global__ void __launch_bounds__(64, 3)
+k_spline_to_interfaces_regs(Geo g, SplineK s, const real* __restrict__ q0, const real* __restrict__ q1,
+                            const real* __restrict__ q2, const real* __restrict__ q3, real* __restrict__ o0,
+                            real* __restrict__ o1, real* __restrict__ o2, real* __restrict__ o3) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i > g.ni - 2 || j > g.nj - 2) return;
+  const real* qc = (blockIdx.z == 0) ? q0 : (blockIdx.z == 1) ? q1 : (blockIdx.z == 2) ? q2 : q3;
+  real* qi = (blockIdx.z == 0) ? o0 : (blockIdx.z == 1) ? o1 : (blockIdx.z == 2) ? o2 : o3;
+  const long c0 = IDX2(g, i, j);
+  const long sk = g.sk;
+  const int km = g.nk;
+  constexpr int CHS = 16;
+  double sv[SPL_REGK];
+  double prev_c = qc[c0];
+  double v = (s.xt1_top * prev_c + qc[c0 + sk]) / s.beta[0];
+  sv[0] = v;
+  double c_last = prev_c, c_last2 = prev_c;  // qc[km-1], qc[km-2] for the bottom closure
+#pragma unroll
+  for (int k0 = 1; k0 < SPL_REGK; k0 += CHS) {
+    if (k0 < km) {
+      double c_[CHS];
+#pragma unroll
+      for (int t = 0; t < CHS; ++t) c_[t] = qc[c0 + (long)((k0 + t < km) ? k0 + t : km - 1) * sk];
+#pragma unroll
+      for (int t = 0; t < CHS; ++t) {
+        const int k = k0 + t;
+        if (k < SPL_REGK && k < km) {
+          v = (3.0 * (prev_c + s.gk[k] * c_[t]) - v) / s.beta[k];
+          sv[k] = v;
+          c_last2 = prev_c;
+          prev_c = c_[t];
+          c_last = c_[t];
+        }
+      }
+    }
+  }
+  v = (s.xt1_bot * c_last + c_last2 - s.a_bot * v) / s.xt2_bot;
+  qi[c0 + (long)km * sk] = v;
+#pragma unroll
+  for (int k = SPL_REGK - 1; k >= 0; --k) {
+    if (k < km) {
+      v = sv[k] - s.gamma[k] * v;
+      qi[c0 + (long)k * sk] = v;
+    }
+  }
+}
+
 // apply_height_fluxes (updatedzd.py:70-126) in two steps: the advective + diffusive update is a point function (all
 // levels in parallel, in place: a cell reads only its own zh); ws and the bottom-up monotonicity sweep are the only
 // column-sequential part and touch one field.
@@ -287,7 +339,10 @@ int launch_updatedzd(const Geo& g, const Met& m, void* ws_, const pace_updatedzd
   real *crx_i = p, *cry_i = p + field, *xfx_i = p + 2 * field, *yfx_i = p + 3 * field, *fx = p + 4 * field,
          *fy = p + 5 * field, *fx2 = p + 6 * field, *fy2 = p + 7 * field;
   SplineK s{kc->gk, kc->beta, kc->gamma, kc->xt1_top, kc->a_bot, kc->xt1_bot, kc->xt2_bot};
-  if (g.nk <= SPL_MAXK && g.nk >= 3)
+  if (g.nk <= SPL_REGK && g.nk >= 3)
+    hipLaunchKernelGGL(k_spline_to_interfaces_regs, dim3((g.ni - 1 + 63) / 64, g.nj - 1, 4), dim3(64), 0, st, g, s, crx, cry, xfx,
+                       yfx, crx_i, cry_i, xfx_i, yfx_i);
+  else if (g.nk <= SPL_MAXK && g.nk >= 3)
     hipLaunchKernelGGL(k_spline_to_interfaces_lds, dim3((g.ni - 1 + 63) / 64, g.nj - 1, 4), dim3(64), 0, st, g, s, crx, cry, xfx,
                        yfx, crx_i, cry_i, xfx_i, yfx_i);
   else
@@ -441,46 +496,64 @@ k_nh_set_top(Geo g, real* __restrict__ pp, real* __restrict__ pk3, double top_va
 // calc_u (nh_p_grad.py:29-69), calc_v (:72-112).  The B-grid values of gz, pk3, pp (and of delp: wk1) come from the
 // a2b_ord4 launches before it; with WRITE_BACK they are stored over the caller's gz / pk3 / pp here (a2b_ord4's replace = True,
 // a2b_ord4.py:505-506: the reference leaves the interpolated values in its arguments) instead of by three copy kernels.
+// A thread takes NH_CH consecutive levels of its corner: the interface values of level k + 1 are level k's of the next
+// turn and stay in registers (one thread per level read every interface of gz / pk3 / pp twice, from workgroups a whole plane
+// apart: 324 MB counted for 14 field passes of 23.6 MB).
+#define NH_CH 8
 template <bool WRITE_BACK>
 __global__ void __launch_bounds__(256)
 k_nh_uv(Geo g, Met m, real* __restrict__ u, real* __restrict__ v, const real* __restrict__ wk1,
         const real* __restrict__ gz, const real* __restrict__ pk3, const real* __restrict__ pp, double dt,
         real* __restrict__ gz_out, real* __restrict__ pk3_out, real* __restrict__ pp_out) {
-  PATCH_IJK(g);
+  const int i = (int)blockIdx.x * PATCH_W + (int)threadIdx.x;
+  const int j = (int)blockIdx.y * PATCH_H + (int)threadIdx.y;
+  const int k0 = (int)blockIdx.z * NH_CH;
+  if (j >= g.nj || i >= g.ni) return;
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
-  const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const long sk = g.sk;
   const int sj = g.sj;
-  const double pk_0 = pk3[c], pk_1 = pk3[c + sk], gz_0 = gz[c], gz_1 = gz[c + sk], pp_0 = pp[c], pp_1 = pp[c + sk];
-  const double wk0 = pk_1 - pk_0;
-  if (i <= g.ie) {
-    const double wkx = pk3[c + 1 + sk] - pk3[c + 1];
-    const double du = dt / (wk0 + wkx) *
-                      ((gz_1 - gz[c + 1]) * (pk3[c + 1 + sk] - pk_0) + (gz_0 - gz[c + 1 + sk]) * (pk_1 - pk3[c + 1]));
-    u[c] = (u[c] + du +
-            dt / (wk1[c] + wk1[c + 1]) *
-                ((gz_1 - gz[c + 1]) * (pp[c + 1 + sk] - pp_0) + (gz_0 - gz[c + 1 + sk]) * (pp_1 - pp[c + 1]))) *
-           m.rdx[c2];
-  }
-  if (j <= g.je) {
-    const double wky = pk3[c + sj + sk] - pk3[c + sj];
-    const double dv = dt / (wk0 + wky) *
-                      ((gz_1 - gz[c + sj]) * (pk3[c + sj + sk] - pk_0) + (gz_0 - gz[c + sj + sk]) * (pk_1 - pk3[c + sj]));
-    v[c] = (v[c] + dv +
-            dt / (wk1[c] + wk1[c + sj]) *
-                ((gz_1 - gz[c + sj]) * (pp[c + sj + sk] - pp_0) + (gz_0 - gz[c + sj + sk]) * (pp_1 - pp[c + sj]))) *
-           m.rdy[c2];
-  }
-  if (WRITE_BACK) {
-    gz_out[c] = gz_0;
-    pk3_out[c] = pk_0;
-    pp_out[c] = pp_0;
-    if (k == g.nk - 1) {
-      gz_out[c + sk] = gz_1;
-      pk3_out[c + sk] = pk_1;
-      pp_out[c + sk] = pp_1;
+  const bool do_u = i <= g.ie, do_v = j <= g.je;
+  const double rdx = do_u ? (double)m.rdx[c2] : 0.0, rdy = do_v ? (double)m.rdy[c2] : 0.0;
+  // (places a thread does not use -- beyond the last row / column of corners -- read its own corner again)
+  const long dxo = do_u ? 1 : 0, dyo = do_v ? sj : 0;
+  long c = IDX3(g, i, j, k0);
+  double pk_0 = pk3[c], gz_0 = gz[c], pp_0 = pp[c];
+  double pkx_0 = pk3[c + dxo], gzx_0 = gz[c + dxo], ppx_0 = pp[c + dxo];
+  double pky_0 = pk3[c + dyo], gzy_0 = gz[c + dyo], ppy_0 = pp[c + dyo];
+#pragma unroll
+  for (int t = 0; t < NH_CH; ++t) {
+    const int k = k0 + t;
+    if (k >= g.nk) break;
+    const double pk_1 = pk3[c + sk], gz_1 = gz[c + sk], pp_1 = pp[c + sk];
+    const double pkx_1 = pk3[c + dxo + sk], gzx_1 = gz[c + dxo + sk], ppx_1 = pp[c + dxo + sk];
+    const double pky_1 = pk3[c + dyo + sk], gzy_1 = gz[c + dyo + sk], ppy_1 = pp[c + dyo + sk];
+    const double wk0 = pk_1 - pk_0;
+    const double w0 = wk1[c];
+    if (do_u) {
+      const double wkx = pkx_1 - pkx_0;
+      const double du = dt / (wk0 + wkx) * ((gz_1 - gzx_0) * (pkx_1 - pk_0) + (gz_0 - gzx_1) * (pk_1 - pkx_0));
+      u[c] = (u[c] + du + dt / (w0 + wk1[c + 1]) * ((gz_1 - gzx_0) * (ppx_1 - pp_0) + (gz_0 - gzx_1) * (pp_1 - ppx_0))) * rdx;
     }
+    if (do_v) {
+      const double wky = pky_1 - pky_0;
+      const double dv = dt / (wk0 + wky) * ((gz_1 - gzy_0) * (pky_1 - pk_0) + (gz_0 - gzy_1) * (pk_1 - pky_0));
+      v[c] = (v[c] + dv + dt / (w0 + wk1[c + sj]) * ((gz_1 - gzy_0) * (ppy_1 - pp_0) + (gz_0 - gzy_1) * (pp_1 - ppy_0))) * rdy;
+    }
+    if (WRITE_BACK) {
+      gz_out[c] = gz_0;
+      pk3_out[c] = pk_0;
+      pp_out[c] = pp_0;
+      if (k == g.nk - 1) {
+        gz_out[c + sk] = gz_1;
+        pk3_out[c + sk] = pk_1;
+        pp_out[c + sk] = pp_1;
+      }
+    }
+    pk_0 = pk_1, gz_0 = gz_1, pp_0 = pp_1;
+    pkx_0 = pkx_1, gzx_0 = gzx_1, ppx_0 = ppx_1;
+    pky_0 = pky_1, gzy_0 = gzy_1, ppy_0 = ppy_1;
+    c += sk;
   }
 }
 
@@ -502,7 +575,7 @@ int launch_nh_p_grad(const Geo& g, const Met& m, void* ws_, real* u, real* v, re
   if (rc) return rc;
   const double top_value = pow(ptop, akap);
   hipLaunchKernelGGL(k_nh_set_top, plane_grid(g, 1), dim3(256), 0, st, g, pp_b, pk3_b, top_value);
-  hipLaunchKernelGGL(k_nh_uv<true>, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, u, v, wk1, gz_b, pk3_b, pp_b, dt, gz, pk3, pp);
+  hipLaunchKernelGGL(k_nh_uv<true>, patch_grid(g, (g.nk + NH_CH - 1) / NH_CH), PATCH_BLOCK, 0, st, g, m, u, v, wk1, gz_b, pk3_b, pp_b, dt, gz, pk3, pp);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

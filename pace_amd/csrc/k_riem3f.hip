@@ -214,19 +214,54 @@ __device__ __forceinline__ Mob excl_mob_fwd(Mob m, int r) {
 #define RIEM_LDG(p, off) (*(const real*)((const char*)(p) + (off)))
 #define RIEM_STG(p, off) (*(real*)((char*)(p) + (off)))
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// The columns lo .. hi of a row in windows of sixteen that are 128-byte lines of every level.  The partial windows at the two
+// ends (13 + 3 columns at C192, whose compute domain starts at i = 3) share workgroup 0 when they fit side by side -- each
+// column stays at its place in its line, x = column mod 16 -- so that 192 columns are twelve workgroups, not thirteen: 2 304
+// workgroups are exactly three rounds of the 768 the chip holds, 2 496 were a fourth round one quarter full.
+struct ColumnWindows {
+  int a0, nfull, head, tail;  // first line boundary >= lo; whole windows from there; columns before / after them
+  bool merged;
+  __host__ __device__ ColumnWindows(int lo, int hi) {
+    a0 = (lo + 15) & ~15;
+    head = a0 - lo;
+    if (hi + 1 < a0) {  // (the whole row inside one window)
+      nfull = 0, tail = 0, merged = false;
+    } else {
+      nfull = (hi + 1 - a0) / 16;
+      tail = (hi + 1 - a0) - 16 * nfull;
+      merged = head + tail <= 16;
+    }
+  }
+  __host__ __device__ int workgroups() const { return merged ? nfull + (head + tail > 0 ? 1 : 0) : nfull + (head > 0) + (tail > 0); }
+  // column of place x of workgroup b (any column of the row, nearest valid one, for places that hold none)
+  __host__ __device__ int column(int b, int x, int lo, int hi, bool& valid) const {
+    int c;
+    if (merged && head + tail > 0) {
+      if (b == 0) c = x < tail ? a0 + 16 * nfull + x : a0 - 16 + x;
+      else c = a0 + 16 * (b - 1) + x;
+      valid = b == 0 ? (x < tail || x >= 16 - head) : true;
+    } else {
+      c = a0 - (head > 0 ? 16 : 0) + 16 * b + x;
+      valid = c >= lo && c <= hi;
+    }
+    return c < lo ? lo : (c > hi ? hi : c);
+  }
+};
+__device__ __forceinline__ int own_column(const Geo& g, int cg, const ColumnWindows& cw, int bx, int x) {
+  bool valid;
+  return cw.column(bx, x, g.is - cg, g.ie + cg, valid);
+}
 template <int L>
 struct Mover {
   int xl, xc;        // level (of the first piece) and column within the window
   unsigned row, sk;  // element offset of (column, j) at level 0; level stride
   bool in;           // the column is in the domain
-  __device__ __forceinline__ Mover(const Geo& g, int cg, int first, int j) {
+  __device__ __forceinline__ Mover(const Geo& g, int cg, const ColumnWindows& cw, int bx, int j) {
     int tid = threadIdx.x;
     RIEM_OPAQUE(tid);
     xl = tid >> 4;
     xc = tid & 15;
-    const int iw = first + xc;
-    in = iw >= g.is - cg && iw <= g.ie + cg;
-    row = (unsigned)IDX2(g, clampi(iw, g.is - cg, g.ie + cg), j);
+    row = (unsigned)IDX2(g, cw.column(bx, xc, g.is - cg, g.ie + cg, in), j);
     sk = (unsigned)g.sk;
   }
   // byte offset of piece n in a field whose last level is `last` (pieces beyond it repeat it); 32 bits: riem_column_supported
@@ -255,15 +290,15 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
               real* __restrict__ pk3, real* __restrict__ pk, real* __restrict__ peln, real* __restrict__ w) {
   const int r = threadIdx.x & (ROW - 1);   // level block of this lane
   const int col = threadIdx.x >> 4;        // column within the workgroup
-  // A workgroup's sixteen columns are one 128-byte line of every level row it touches: the column window starts at a multiple of 16
-  // (the compute domain starts at i = 3: windows anchored there straddled two lines each, and the line shared with the neighbouring
-  // workgroup -- which runs on another XCD -- was fetched by both: measured 1.76 x the algorithmic reads).  The first and the
-  // last workgroup of a row hold a few columns outside the domain: they solve a copy of the nearest column and store nothing.
-  const int first = ((g.is - CG) & ~15) + blockIdx.x * 16;
+  // A workgroup's sixteen columns are one 128-byte line of every level row it touches (ColumnWindows; windows anchored at the
+  // start of the compute domain, i = 3, straddled two lines each, and the line shared with the neighbouring workgroup -- which
+  // runs on another XCD -- was fetched by both: measured 1.76 x the algorithmic reads).  Places of a window that hold no column
+  // of the domain solve a copy of the nearest one and store nothing.
+  const ColumnWindows cw(g.is - CG, g.ie + CG);
   const int j = g.js - CG + blockIdx.y;
   const int km = g.nk;
   // (this lane's own column, for the two surface fields)
-#define OWN_COLUMN() IDX2(g, clampi(first + col, g.is - CG, g.ie + CG), j)
+#define OWN_COLUMN() IDX2(g, own_column(g, CG, cw, blockIdx.x, col), j)
   // Fields move between memory and the lanes that solve through LDS.  In the solver's own arrangement (a lane = five levels of
   // one column) a wave's load touches sixteen lines for 32 bytes each, and the four waves of the workgroup ask for the same
   // lines at different times: the load and store stages were 60 % of a wave's 74 000 cycles (tools/riem_stage_times.py), and
@@ -275,7 +310,7 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
   __shared__ double xs_[3][NLV * LP];
   // (the movers' addresses are rebuilt from the lane number at each of the three places they are used -- RIEM_OPAQUE keeps the
   // compiler from holding them in registers across the solver, which sits at the 168-register limit of three waves per SIMD)
-#define MOVER() const Mover<L> M(g, CG, first, j)
+#define MOVER() const Mover<L> M(g, CG, cw, blockIdx.x, j)
   // fetch: the pieces of a field with nlev levels (16 L + 1 at most: the last one is the extra piece of the movers of level 0)
 #define FETCH(v, f, nlev)                                                                          \
   double v[L + 1];                                                                                 \
@@ -696,8 +731,7 @@ static int launch_column(const Geo& g, int last_call, double dt, double ptop, do
   const double peln1 = log(ptop);
   const double ptk = exp(KAPPA * peln1);
   const int ncol = g.n + 2 * CG;
-  const int first = (g.is - CG) & ~15;  // (the aligned window of the kernel)
-  const dim3 grid((g.ie + CG - first + 16) / 16, ncol), block(256);
+  const dim3 grid(ColumnWindows(g.is - CG, g.ie + CG).workgroups(), ncol), block(256);
 #define GO(L)                                                                                                                  \
   hipLaunchKernelGGL((k_riem_column<CG, L>), grid, block, 0, st, g, last_call, dt, ptop, p_fac, peln1, ptk, cappa, zs, ws, q_con, \
                      delp, pt, delz, zh, pe, ppe, pk3, pk, peln, w)
