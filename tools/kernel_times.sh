@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel average times of tools/exp_variants.py for the given libraries (rocprofv3 --kernel-trace --stats), on the GPU box:
-#   bash tools/kernel_times.sh name=path.so [name=path.so ...]
+#   [KT_N=96] bash tools/kernel_times.sh name=path.so [name=path.so ...]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
@@ -9,7 +9,7 @@ for spec in "$@"; do
   D=/tmp/kt_$name; rm -rf $D
   mkdir -p $D
   # (the measuring process itself under the profiler: the parent mode of exp_variants.py does no GPU work)
-  rocprofv3 --kernel-trace --stats -d $D -o t -- python3 $R/tools/exp_variants.py $spec --reps 10 --child $D/out > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $D -o t -- python3 $R/tools/exp_variants.py $spec --reps 10 --n ${KT_N:-192} --child $D/out > /dev/null 2>&1
   echo "== $name"
   python3 $R/tools/rocprof_summary.py $(find $D -name "*.db" | head -1) | python3 -c "
 import sys,csv,re
