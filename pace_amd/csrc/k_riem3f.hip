@@ -69,13 +69,13 @@ __device__ __forceinline__ double dn(double v, int d) {
 }
 #endif
 
-// ---- exp / log of the D-grid solver ----------------------------------------------------------------------------------------
-// riem_solver3 takes seven exp / log per level (riem_solver3.py:63-141, sim1_solver.py:118-141); the library's versions are ~65
-// instructions each with their special-case handling -- a third of this kernel's 6 300 instructions per wave, and the kernel is
-// bound by exactly that count (161 VGPRs = three waves per SIMD: ~12 cycles per instruction).  The arguments here are pressures
-// and pressure ratios -- positive, finite, far from the ends of the exponent range -- and the operator's bound is 5e-6
-// (overrides/standard.yaml:49-61), so: straight range reduction + polynomial, no special cases, ~1e-16 relative error
-// (tools/riem_check.py prints the errors against the numpy oracle).  The C-grid solver (bound 5e-14) keeps the library functions.
+// ---- exp / log of the column solvers ---------------------------------------------------------------------------------------
+// riem_solver3 takes seven exp / log per level (riem_solver3.py:63-141, sim1_solver.py:118-141), riem_solver_c four; the
+// library's versions are ~65 instructions each with their special-case handling.  The arguments here are pressures and
+// pressure ratios -- positive, finite, far from the ends of the exponent range -- so: straight range reduction + polynomial,
+// no special cases, ~1e-16 relative error.  Against the numpy oracle: riem_solver3 <= 1.1e-7 (bound 5e-6,
+// overrides/standard.yaml:49-61), riem_solver_c 3.3e-15 (bound 5e-14, translate_riem_solver_c.py:33; the library functions
+// gave 1.5e-15); tools/riem_check.py prints the errors per variable.
 __device__ __forceinline__ double lean_log(double x) {
   int e;
   double m = frexp(x, &e);  // [0.5, 1)
@@ -126,9 +126,9 @@ __device__ __forceinline__ double lean_exp(double x) {
   return ldexp(p, (int)k);
 }
 template <int CG>
-__device__ __forceinline__ double col_log(double x) { return CG ? log(x) : lean_log(x); }
+__device__ __forceinline__ double col_log(double x) { return lean_log(x); }  // (one place to switch a solver back to the library)
 template <int CG>
-__device__ __forceinline__ double col_exp(double x) { return CG ? exp(x) : lean_exp(x); }
+__device__ __forceinline__ double col_exp(double x) { return lean_exp(x); }
 
 // ---- scan of additions over the row: returns the sum of the values of the lanes BEFORE (fwd) / AFTER (bwd) this one ----
 __device__ __forceinline__ double excl_add_fwd(double v, int r) {

@@ -506,6 +506,52 @@ def test_other_level_counts_emulated_vs_oracle(emu_lib, nz):
         assert compare(b[k][window(n, 0, 0, nk)], got[k][window(n, 0, 0, nk)], near_zero=1e-9 * float(np.abs(b[k]).max())) < 5e-6, k
 
 
+@pytest.mark.parametrize("n", [13, 16, 40])
+def test_riem_column_windows_emulated_vs_oracle(emu_lib, n):
+    """The column solver's sixteen-column windows (k_riem3f.hip ColumnWindows) in each of their shapes: the whole row inside
+    one window with only a head (13), head and tail side by side in one workgroup (16: the shape of C48 / C96 / C192), head, a
+    whole window and a tail that do not fit together (40) -- riem_solver3 on the compute domain and riem_solver_c on
+    compute + 1 (other window bounds), against the oracle."""
+    from oracle import vertical
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils.riem_solver_c import NonhydrostaticVerticalSolverCGrid
+
+    nz = 33
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    env = Env(emu_lib, "cpu", metrics, n, nz)
+    g = oracle_grid(metrics, n, nz)
+    inp = {"cappa": s["cappa"], "zs": s["zs"], "ws": s["ws"], "delz": s["delz"], "q_con": s["q_con"], "delp": s["delp"],
+           "pt": s["pt"], "zh": s["zh"], "p": s["pe"], "ppe": s["ppe"], "pk3": s["pk3"], "pk": s["pk"],
+           "log_p_interface": s["peln"], "w": s["w"]}
+    got = run_riem3(env, inp, True, s["dt"], metrics["ptop"])
+    b = {k: v.copy() for k, v in inp.items()}
+    vertical.riem_solver3(g, True, s["dt"], b["cappa"], metrics["ptop"], b["zs"], b["ws"], b["delz"], b["q_con"], b["delp"], b["pt"],
+                          b["zh"], b["p"], b["ppe"], b["pk3"], b["pk"], b["log_p_interface"], b["w"], p_fac=0.05)
+    for k in ("delz", "zh", "ppe", "pk3", "w", "p", "pk", "log_p_interface"):
+        nk = nz if k in ("delz", "w") else nz + 1
+        assert compare(b[k][window(n, 0, 0, nk)], got[k][window(n, 0, 0, nk)], near_zero=1e-9 * float(np.abs(b[k]).max())) < 5e-6, k
+        # nothing outside the compute domain is written
+        outside = np.ones(b[k].shape, dtype=bool)
+        outside[window(n, 0, 0, nk)] = False
+        outside[:, :, nk:] = False
+        assert np.array_equal(got[k][outside], inp[k][outside]), k
+    # riem_solver_c: compute + 1
+    solver = NonhydrostaticVerticalSolverCGrid(env.stencil_factory, env.qf, 0.05)
+    a = {k: s[k].copy() for k in ("cappa", "pt", "q_con", "delp", "zh", "w")}
+    f = {k: env.q3(v) for k, v in a.items()}
+    hs = s["zs"] * 9.80665
+    ws3 = np.ascontiguousarray(s["ws"])
+    pef = env.q3(np.zeros_like(s["zh"]))
+    solver(0.5 * s["dt"], f["cappa"], float(metrics["ptop"]), env.q2(hs), env.q2(ws3), f["pt"], f["q_con"], f["delp"], f["zh"], pef, f["w"])
+    ref_pef = np.zeros_like(s["zh"])
+    vertical.riem_solver_c(g, 0.5 * s["dt"], a["cappa"], float(metrics["ptop"]), hs, ws3, a["pt"], a["q_con"], a["delp"], a["zh"], ref_pef,
+                           a["w"], p_fac=0.05)
+    W = (slice(2, 4 + n), slice(2, 4 + n), slice(0, nz + 1))
+    assert compare(ref_pef[W], pef.numpy()[W]) < 5e-14
+    assert compare(a["zh"][W], f["zh"].numpy()[W]) < 5e-14
+
+
 @pytest.mark.parametrize("order", [2, 4])
 def test_c2l_and_preamble_kernels_emulated_vs_oracle(emu_lib, order):
     """pace_c2l_ord (both orders), pace_fv_setup_pt and pace_omega_from_w against oracle/dycore_parts.py on a synthetic tile:
