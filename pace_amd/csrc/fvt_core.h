@@ -647,6 +647,9 @@ struct FvtTile {
 // DMODE: -1 transport only; 0 damping fluxes -> dp.fx2o / fy2o (+ dp.add2d, u / v update: the vorticity call of d_sw);
 // 1 damping fluxes added to the transport fluxes; 2 added mass-weighted; 3 damping of q -> dw / heat_s / diss_est only (w).
 // EPI 0: fluxes stored (or accumulated / turned into winds); 1: flux-form update of the cell stored.
+#ifndef FVT_STAMP
+#define FVT_STAMP(n)  // (tools/census/fvt_prof.hip: shader-clock stamps of one workgroup per level)
+#endif
 template <int MORD, int DMODE, int EPI, bool EX, bool EY>
 __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m, const real* __restrict__ q,
                                          const real* __restrict__ crx, const real* __restrict__ cry,
@@ -657,9 +660,11 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
   const long kb = (long)k * g.sk;
   const unsigned kb8 = T.kb8;
   const int sj8 = T.sj8;
+  FVT_STAMP(20);
   T.load_footprint(q + kb);
   if (DMODE >= 0) T.stage_damping_metrics();
   __syncthreads();
+  FVT_STAMP(21);
 
   double dvx[NF], dvy[NF];
   double damp = 0.0;
@@ -671,9 +676,11 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
     __syncthreads();  // the sweeps overwrite the damping planes
   }
   if (DMODE == 0 && dp.add2d) T.add_2d(dp.add2d);
+  FVT_STAMP(22);
 
   double si_y[NF], si_x[NF], cy[NF], cx[NF];
   T.inner(crx + kb, cry + kb, xfx + kb, yfx + kb, si_x, si_y, cx, cy);
+  FVT_STAMP(23);
 
   if (T.x_outer) {
     double v[NF], xu[NF], ms[NF + 1];
@@ -721,6 +728,7 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
       T.put_ax(v);
     }
   }
+  FVT_STAMP(24);
   if (T.y_outer) {
     double v[NF], yu[NF], ms[NF + 1];
 #pragma unroll
@@ -766,6 +774,7 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
       T.put_ay(v);
     }
   }
+  FVT_STAMP(25);
   if (EPI == 1) {
     // apply_fluxes (d_sw.py:122-145): q * mass + the flux increment, one cell per lane, lanes along i
     __syncthreads();
@@ -781,6 +790,7 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
 #pragma unroll
     for (int t = 0; t < NEC; ++t) STG(dp.qout, kb8 + c2[t]) = T.flux_form(jj[t], ii[t], am[t], ra[t]);
   }
+  FVT_STAMP(26);
 }
 
 // ---- the scalar phase of d_sw in one kernel -------------------------------------------------------------------------------
@@ -803,9 +813,6 @@ struct FvtScalars {
   double dt;
 };
 
-#ifndef FVT_STAMP
-#define FVT_STAMP(n)  // (tools/census/fvt_prof.hip: shader-clock stamps of one workgroup per level)
-#endif
 
 template <int MORD, bool EX, bool EY>
 __device__ __forceinline__ void fvt_scalars_tile(FvtLdsScalars& LS, const Geo& g, const FvMet& m, const FvtScalars& S, int bx, int by, int k) {

@@ -34,7 +34,7 @@ def main():
         lib.call("pace_d_sw_phases", mask, C.byref(dsw._geom), C.byref(dsw._met), C.byref(dsw._col), C.byref(dsw._cfg),
                  dsw._workspace.data_ptr(), *[dptr(f[k]) for k in DSW_ARGS], float(s["dt"]), None)
 
-    host = (C.c_longlong * (4 * 128 * 20))()
+    host = (C.c_longlong * (4 * 128 * 32))()
     rows = [[], [], [], []]
     for rep in range(6):
         f = copies[rep]
@@ -43,10 +43,27 @@ def main():
         phase(2, f)
         torch.cuda.synchronize()
         assert lib.cdll.pace_debug_fvt_prof(host) == 0
-        a = np.frombuffer(host, dtype=np.int64).reshape(4, 128, 20)[:, :nz, :17].astype(float)
+        a = np.frombuffer(host, dtype=np.int64).reshape(4, 128, 32)[:, :nz, :17].astype(float)
         if rep >= 1:
             for w in range(4):
                 rows[w].append(np.diff(a[w], axis=1))
+    # the single-scalar kernel as d_sw launches it: the vorticity transport (phases: flux preparation, ke / vorticity, damping + transport)
+    rows1 = [[], [], [], []]
+    for rep in range(6):
+        f = copies[rep]
+        for mask in (1, 64, 128):
+            phase(mask, f)
+            torch.cuda.synchronize()
+        assert lib.cdll.pace_debug_fvt_prof(host) == 0
+        a = np.frombuffer(host, dtype=np.int64).reshape(4, 128, 32)[:, :nz, 20:27].astype(float)
+        if rep >= 1:
+            for w in range(4):
+                rows1[w].append(np.diff(a[w], axis=1))
+    parts1 = ["footprint -> LDS", "damping, faces, + f", "inner sweeps (operand loads)", "outer x + u epilogue", "outer y + v epilogue", "tail"]
+    for w, label in enumerate(("interior", "corner", "west-edge", "south-edge")):
+        med = np.median(np.concatenate(rows1[w]), axis=0)
+        print(f"{label} workgroup of k_fvt<6,0,0> (vorticity transport): {med.sum():.0f} cycles | " +
+              "  ".join(f"{parts1[p]} {med[p]:.0f}" for p in range(6)))
     for w, label in enumerate(("interior", "corner", "west-edge", "south-edge")):
         d = np.concatenate(rows[w])
         med = np.median(d, axis=0)
