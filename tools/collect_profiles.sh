@@ -10,22 +10,23 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 export PACE_BENCH_CACHE=/tmp
 cd "$R"
-python bench.py > "$O/bench.json" 2> "$O/bench.err"
+timeout 900 python bench.py > "$O/bench.json" 2> "$O/bench.err"
 # (each size twice, the second line kept: the first run of a size on a fresh box pays for its set-up -- caches of the state, clocks)
-for n in 48 96 384; do python bench.py --tile-size $n --no-cpu-baseline --no-traffic > /dev/null 2>&1; python bench.py --tile-size $n --no-cpu-baseline --no-traffic 2>/dev/null | tail -1; done > "$O/bench_sizes.jsonl"
-python tools/acoustic_bench.py 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench.txt"
-python tools/acoustic_bench.py --n 96 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench_c96.txt"   # BASELINE configuration 3
+for n in 48 96 384; do timeout 300 python bench.py --tile-size $n --no-cpu-baseline --no-traffic > /dev/null 2>&1; timeout 300 python bench.py --tile-size $n --no-cpu-baseline --no-traffic 2>/dev/null | tail -1; done > "$O/bench_sizes.jsonl"
+timeout 300 python tools/acoustic_bench.py 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench.txt"
+timeout 300 python tools/acoustic_bench.py --n 96 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench_c96.txt"   # BASELINE configuration 3
 # stage times of the scalar-phase kernel's workgroups (interior / corner / edge tiles): tools/build_prof.sh builds the stamped library
-[ -f build/var/prof/libpace_hip.so ] && python tools/fvt_stage_times.py 2>/dev/null | grep -v amdgpu > "$O/scalar_phase_stage_times.txt"
-bash tools/kernel_times.sh prod=pace_amd/libpace_hip.so 2>/dev/null > "$O/kernel_times_single_stream.txt"
-bash tools/pmc_kernels.sh prod=pace_amd/libpace_hip.so 2>/dev/null > "$O/pmc_kernels.json"
+[ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/fvt_stage_times.py 2>/dev/null | grep -v amdgpu > "$O/scalar_phase_stage_times.txt"
+[ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/riem_stage_times.py 2>/dev/null | grep -v amdgpu > "$O/riem_stage_times.txt"
+timeout 400 bash tools/kernel_times.sh prod=$R/pace_amd/libpace_hip.so 2>/dev/null > "$O/kernel_times_single_stream.txt"
+timeout 600 bash tools/pmc_kernels.sh prod=$R/pace_amd/libpace_hip.so 2>/dev/null > "$O/pmc_kernels.json"
 python tools/step_table.py "$O/kernel_times_single_stream.txt" "$O/pmc_kernels.json" > "$O/step_table.json"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$O/trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-traffic > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
-rocprofv3 --kernel-trace --stats -d "$O/trace_loop" -o loop -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2> "$O/trace_loop.err"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-traffic > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace_loop" -o loop -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2> "$O/trace_loop.err"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-traffic > /dev/null 2>> "$O/pmc.err"
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_loop_$c" -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2>> "$O/pmc.err"
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-traffic > /dev/null 2>> "$O/pmc.err"
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_loop_$c" -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2>> "$O/pmc.err"
 done
 cd "$R"
 DB=$(find "$O/trace" -name '*.db' | head -1)
