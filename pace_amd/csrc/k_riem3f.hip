@@ -270,6 +270,10 @@ struct Mover {
     return (row + (unsigned)(lv < last ? lv : last) * sk) * (unsigned)sizeof(real);
   }
   __device__ __forceinline__ int slot(int n) const { return (xl + 16 * n) * RIEM_LP + xc; }
+  __device__ __forceinline__ int slot_upto(int n, int last) const {
+    const int lv = xl + 16 * n;
+    return (lv < last ? lv : last) * RIEM_LP + xc;
+  }
   __device__ __forceinline__ bool has(int n, int nlev) const { return in && xl + 16 * n < nlev; }
 };
 
@@ -322,11 +326,14 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
     if (16 * L < (nlev) && M.xl == 0) xs_[b][M.slot(L)] = v[L];                                    \
   } while (0)
   // store: the mover's pieces of the LDS copy b go to field f (levels 0 .. nlev-1, the columns of the domain)
+  // (one test -- of the column -- for all pieces: a piece beyond the field's last level stores that level's value to that level's
+  // place once more, the same bits its owner stores; a test per piece cost four scalar instructions and a branch each)
 #define STORE(b, f, nlev)                                                                          \
   do {                                                                                             \
-    _Pragma("unroll") for (int n = 0; n < L; ++n)                                                  \
-      if (M.has(n, nlev)) RIEM_STG(f, M.at(n, (nlev) - 1)) = xs_[b][M.slot(n)];                    \
-    if (16 * L < (nlev) && M.has(L, nlev)) RIEM_STG(f, M.at(L, (nlev) - 1)) = xs_[b][M.slot(L)];   \
+    if (M.in) {                                                                                    \
+      _Pragma("unroll") for (int n = 0; n < L; ++n) RIEM_STG(f, M.at(n, (nlev) - 1)) = xs_[b][M.slot_upto(n, (nlev) - 1)]; \
+      if (16 * L < (nlev) && M.xl == 0) RIEM_STG(f, M.at(L, (nlev) - 1)) = xs_[b][M.slot(L)];      \
+    }                                                                                              \
   } while (0)
 #define MINE(b, k) xs_[b][(k) * LP + col]
   const int k0 = r * L;
