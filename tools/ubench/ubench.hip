@@ -283,6 +283,42 @@ __global__ void __launch_bounds__(1024) k_gl_stream(const double* __restrict__ s
   }
   out[blockIdx.x * blockDim.x + tid] = acc;
 }
+// the SHAPE of a wave-load: 8 bytes per lane, G consecutive lanes share a 128-byte line (G * 8 bytes of it), the wave touches
+// 64 / G lines that are `line_stride` lines apart.  G = 16: four whole lines (k_gl_stream's shape); G = 4: sixteen lines for 32
+// bytes each (the column solver's shape before its movers, the x-runs' operands of the transport kernels); G = 1: 64 lines.
+// `share`: the waves of a workgroup ask for the SAME lines (different 8-byte pieces when G < 16 allows) -- the column solver's
+// four waves -- or for lines of their own.
+template <int NB, int G>
+__global__ void __launch_bounds__(1024) k_gl_shape(const double* __restrict__ src, double* out, Stamp* st, int iters, int nelem_mask,
+                                                   int line_stride) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  __syncthreads();
+  double acc = lds[0] * 0.0;
+  const int lane = tid & 63, wave = tid >> 6;
+  // element offset of this lane inside the wave's footprint: line (lane / G) * line_stride, piece lane % G (8 bytes each)
+  const unsigned in_wave = (unsigned)(lane / G) * 16u * (unsigned)line_stride + (unsigned)(lane % G);
+  const unsigned foot = (64u / G) * 16u * (unsigned)line_stride;  // elements a wave-load spans
+  unsigned base = (blockIdx.x * (blockDim.x >> 6) + wave) * foot + in_wave;
+  const unsigned round = gridDim.x * (blockDim.x >> 6) * foot;  // elements all waves of the launch touch per load: the next load starts behind them
+  const long long r0 = wall_clock64();
+  const long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+    double v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) v[u] = src[(base + (unsigned)(it * NB + u) * round) & (unsigned)nelem_mask];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) acc += v[u];
+  }
+  const long long t1 = clock64();
+  const long long r1 = wall_clock64();
+  if ((tid & 63) == 0) {
+    const int w = blockIdx.x * (blockDim.x / 64) + tid / 64;
+    st[w].cyc = t1 - t0;
+    st[w].real = r1 - r0;
+  }
+  out[blockIdx.x * blockDim.x + tid] = acc;
+}
 // the same through LDS-DMA (16 B per lane, 1 KiB per wave-instruction), NB in flight then vmcnt(0)
 template <int NB>
 __global__ void __launch_bounds__(1024) k_gl_lds_dma(const double* __restrict__ src, double* out, Stamp* st, int iters, int nelem_mask) {
@@ -439,6 +475,23 @@ int main(int argc, char** argv) {
   } while (0)
       DMA_TEST(1);
       DMA_TEST(4);
+#define SHAPE_TEST(G, STRIDE)                                                                                              \
+  do {                                                                                                                     \
+    CHECK(hipFuncSetAttribute((const void*)k_gl_shape<4, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    for (int w : {2, 4}) {                                                                                                 \
+      Result r = run([&](int nb, int th, int it) { hipLaunchKernelGGL((k_gl_shape<4, G>), dim3(nb), dim3(th), lds_bytes, 0, d_src, d_out, d_st, it, (int)(ne - 1), STRIDE); }, w, 400, 4, d_st, nblocks); \
+      const double bpc = 512.0 * w * 4 / r.cyc_per_instr_wave;                                                             \
+      printf("shape: %2d lines x %3d B per wave-load, lines %3d apart, buffer %5zu MB  waves/SIMD %d  cycles/load seen by a wave %7.1f  useful B/clk/CU %6.1f  chip %5.2f TB/s useful\n", \
+             64 / G, G * 8, STRIDE, ne * 8 >> 20, w, r.cyc_per_instr_wave, bpc, bpc * 256 * r.mhz * 1e6 / 1e12);          \
+    }                                                                                                                      \
+  } while (0)
+      SHAPE_TEST(16, 1);
+      SHAPE_TEST(8, 1);
+      SHAPE_TEST(4, 1);
+      SHAPE_TEST(2, 1);
+      SHAPE_TEST(1, 1);
+      SHAPE_TEST(4, 13);
+      SHAPE_TEST(16, 13);
     }
     CHECK(hipFree(d_src));
   }
