@@ -94,12 +94,15 @@ k_updatedzc_column(Geo g, const real* __restrict__ zs, const real* __restrict__ 
   double below = gz_new[c0 + (long)km * g.sk];
   gz[c0 + (long)km * g.sk] = below;
   ws[c0] = (zs[c0] - below) * rdt;
-  for (int k0 = km - 1; k0 >= 0; k0 -= 8) {  // eight levels' loads in flight (one latency per level otherwise)
-    double v[8];
+  // forty levels' loads in flight: the kernel is one wave per 64 columns and a handful of waves per CU -- its time is the number
+  // of load round trips of a column (one per level without the chunks, ten with chunks of eight: 24 us at C192 x 79)
+  constexpr int CHC = 40;
+  for (int k0 = km - 1; k0 >= 0; k0 -= CHC) {
+    double v[CHC];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = gz_new[c0 + (long)(k0 - t >= 0 ? k0 - t : 0) * g.sk];
+    for (int t = 0; t < CHC; ++t) v[t] = gz_new[c0 + (long)(k0 - t >= 0 ? k0 - t : 0) * g.sk];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < CHC; ++t)
       if (k0 - t >= 0) {
         const double lim = below + DZ_MIN;
         below = (v[t] > lim) ? v[t] : lim;
@@ -304,7 +307,7 @@ k_height_column(Geo g, const real* __restrict__ zs, const real* zin, real* zh, r
   if (i > g.ie || j > g.je) return;
   const long c0 = IDX2(g, i, j);
   const int km = g.nk;
-  constexpr int CHZ = 16;
+  constexpr int CHZ = 40;  // (levels' loads in flight: see k_updatedzc_column)
   double below = zin[c0 + (long)km * g.sk];
   zh[c0 + (long)km * g.sk] = below;
   ws[c0] = (zs[c0] - below) / dt;
@@ -599,9 +602,9 @@ __device__ __forceinline__ bool ring_cell(const Geo& g, int width, int t, int& i
   return false;
 }
 
-// (the level loop loads eight levels ahead of the running sum: a plain load - add - store loop exposes one memory latency per
+// (the level loop loads RING_CH levels ahead of the running sum: a plain load - add - store loop exposes one memory latency per
 // level, 79 of them per ring column: 44 us for PK3Halo's 1 552 columns at C192)
-#define RING_CH 8
+#define RING_CH 40
 __global__ void __launch_bounds__(64)
 k_edge_pe(Geo g, real* __restrict__ pe, const real* __restrict__ delp, double ptop) {
   int i, j;
@@ -694,17 +697,70 @@ __device__ __forceinline__ void ray_wind(const RayK& r, real* __restrict__ wind,
   }
 }
 
+// The sponge is a few levels deep (kmax ~ 10 at 79 levels): with all of a column's levels loaded at once (RAY_REG of them, in
+// registers) and the three fields in different workgroups (blockIdx.z), a column costs one load round trip per field instead
+// of two per level and field in a row -- the kernel is a few hundred waves, its time is the latency of one of them.
+#define RAY_REG 16
+__device__ __forceinline__ void ray_wind_regs(const RayK& r, real* __restrict__ wind, long c0, long sk) {
+  double wv[RAY_REG], s_[RAY_REG];
+#pragma unroll
+  for (int k = 0; k < RAY_REG; ++k)
+    if (k < r.kmax && (r.act[k] || r.nudge[k])) wv[k] = wind[c0 + (long)k * sk];
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < RAY_REG; ++k) {
+    if (k < r.kmax && r.act[k]) {
+      const double layer = (1.0 - r.rf[k]) * r.dp[k] * wv[k];
+      s = (k == 0) ? layer : s + layer;
+      wv[k] = wv[k] * r.rf[k];
+    }
+    s_[k] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < RAY_REG; ++k) {
+    if (k < r.kmax && (r.act[k] || r.nudge[k])) {
+      double out = wv[k];
+      if (r.nudge[k]) {
+        double src = 0.0;
+#pragma unroll
+        for (int q = 0; q < RAY_REG; ++q)
+          if (r.msrc[k] == q) src = s_[q];  // (block-uniform: a scalar branch per candidate)
+        out = out + src / r.p_ref[k];
+      }
+      wind[c0 + (long)k * sk] = out;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(64)
 k_ray_fast(Geo g, RayK r, real* __restrict__ u, real* __restrict__ v, real* __restrict__ w, int hydrostatic) {
   const int i = g.is + blockIdx.x * 64 + threadIdx.x;
   const int j = g.js + blockIdx.y;
   if (i > g.ie + 1 || j > g.je + 1) return;
   const long c0 = IDX2(g, i, j);
-  if (i <= g.ie) ray_wind(r, u, c0, g.sk);
-  if (j <= g.je) ray_wind(r, v, c0, g.sk);
-  if (!hydrostatic && i <= g.ie && j <= g.je) {
-    for (int k = 0; k < r.kmax; ++k)
-      if (r.act[k]) w[c0 + (long)k * g.sk] = w[c0 + (long)k * g.sk] * r.rf[k];
+  const int field = (int)blockIdx.z;  // 0: u, 1: v, 2: w
+  const bool regs = r.kmax <= RAY_REG;
+  if (field == 0 && i <= g.ie) {
+    if (regs) ray_wind_regs(r, u, c0, g.sk);
+    else ray_wind(r, u, c0, g.sk);
+  }
+  if (field == 1 && j <= g.je) {
+    if (regs) ray_wind_regs(r, v, c0, g.sk);
+    else ray_wind(r, v, c0, g.sk);
+  }
+  if (field == 2 && !hydrostatic && i <= g.ie && j <= g.je) {
+    if (regs) {
+      double wv[RAY_REG];
+#pragma unroll
+      for (int k = 0; k < RAY_REG; ++k)
+        if (k < r.kmax && r.act[k]) wv[k] = w[c0 + (long)k * g.sk];
+#pragma unroll
+      for (int k = 0; k < RAY_REG; ++k)
+        if (k < r.kmax && r.act[k]) w[c0 + (long)k * g.sk] = wv[k] * r.rf[k];
+    } else {
+      for (int k = 0; k < r.kmax; ++k)
+        if (r.act[k]) w[c0 + (long)k * g.sk] = w[c0 + (long)k * g.sk] * r.rf[k];
+    }
   }
 }
 
@@ -756,7 +812,7 @@ int launch_ray_fast(const Geo& g, real* u, real* v, real* w, const double* dp, c
       r.rf[k] = 1.0 / (1.0 + rffvals);
     }
   }
-  hipLaunchKernelGGL(k_ray_fast, dim3((g.n + 1 + 63) / 64, g.n + 1), dim3(64), 0, st, g, r, u, v, w, hydrostatic);
+  hipLaunchKernelGGL(k_ray_fast, dim3((g.n + 1 + 63) / 64, g.n + 1, 3), dim3(64), 0, st, g, r, u, v, w, hydrostatic);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
