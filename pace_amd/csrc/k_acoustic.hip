@@ -232,7 +232,7 @@ k_spline_to_interfaces_lds(Geo g, SplineK s, const real* __restrict__ q0, const 
 // CU, each a serial chain of km divisions: 86 us at C192 x 79 for 205 MB moved.  160 registers of forward values leave two
 // waves per SIMD (eight per CU), and the levels are read sixteen at a time ahead of the chain.
 #define SPL_REGK 80
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, 2)
 k_spline_to_interfaces_regs(Geo g, SplineK s, const real* __restrict__ q0, const real* __restrict__ q1,
                             const real* __restrict__ q2, const real* __restrict__ q3, real* __restrict__ o0,
                             real* __restrict__ o1, real* __restrict__ o2, real* __restrict__ o3) {
@@ -244,7 +244,7 @@ k_spline_to_interfaces_regs(Geo g, SplineK s, const real* __restrict__ q0, const
   const long c0 = IDX2(g, i, j);
   const long sk = g.sk;
   const int km = g.nk;
-  constexpr int CHS = 16;
+  constexpr int CHS = 32;
   double sv[SPL_REGK];
   double prev_c = qc[c0];
   double v = (s.xt1_top * prev_c + qc[c0 + sk]) / s.beta[0];
