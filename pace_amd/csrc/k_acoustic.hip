@@ -61,25 +61,67 @@ __device__ __forceinline__ double pavg(const real* __restrict__ f, long c, long 
   return (dp[k] * f[c - sk] + dp[k - 1] * f[c]) * int_ratio;
 }
 
+// A thread takes ZC_CH consecutive interfaces of its column: the winds of layer k are the "layer above" of interface k + 1 and
+// stay in registers (one thread per interface read every layer of ut / vt twice, from workgroups a whole plane apart).
+#define ZC_CH 8
 __global__ void __launch_bounds__(256)
 k_updatedzc_advect(Geo g, Met m, const real* __restrict__ dp_ref, const real* __restrict__ ut,
                    const real* __restrict__ vt, const real* __restrict__ gz, real* __restrict__ gz_new) {
-  PATCH_IJK(g);
+  const int i = (int)blockIdx.x * PATCH_W + (int)threadIdx.x;
+  const int j = (int)blockIdx.y * PATCH_H + (int)threadIdx.y;
+  const int k0 = (int)blockIdx.z * ZC_CH;
+  if (j >= g.nj || i >= g.ni) return;
   if (i < g.is - 1 || i > g.ie + 1 || j < g.js - 1 || j > g.je + 1) return;
-  const long kb = (long)k * g.sk;
   const long c2 = IDX2(g, i, j);
-  const long c = c2 + kb;
   const int km = g.nk;
-  double xfx[2], yfx[2], fx[2], fy[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    xfx[t] = pavg(ut, c + t, g.sk, k, km, dp_ref);
-    fx[t] = xfx[t] * ((xfx[t] > 0.0) ? gz[kb + zc_xfill(g, i + t - 1, j)] : gz[kb + zc_xfill(g, i + t, j)]);
-    yfx[t] = pavg(vt, c + (long)t * g.sj, g.sk, k, km, dp_ref);
-    fy[t] = yfx[t] * ((yfx[t] > 0.0) ? gz[kb + zc_yfill(g, i, j + t - 1)] : gz[kb + zc_yfill(g, i, j + t)]);
-  }
+  const long sk = g.sk;
   const double area = m.area[c2];
-  gz_new[c] = (gz[c] * area + fx[0] - fx[1] + fy[0] - fy[1]) / (area + xfx[0] - xfx[1] + yfx[0] - yfx[1]);
+  // (the four gz neighbours: the same places on every level)
+  const long zxm = zc_xfill(g, i - 1, j), zx0 = zc_xfill(g, i, j), zxp = zc_xfill(g, i + 1, j);
+  const long zym = zc_yfill(g, i, j - 1), zy0 = zc_yfill(g, i, j), zyp = zc_yfill(g, i, j + 1);
+  double up[2] = {0.0, 0.0}, vp[2] = {0.0, 0.0};  // ut at (i, i + 1), vt at (j, j + 1) of the layer above the interface
+  bool have = false;
+#pragma unroll
+  for (int t = 0; t < ZC_CH; ++t) {
+    const int k = k0 + t;
+    if (k > km) break;
+    const long kb = (long)k * sk;
+    const long c = c2 + kb;
+    double xfx[2], yfx[2], fx[2], fy[2];
+    if (k == 0 || k == km) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        xfx[q] = pavg(ut, c + q, sk, k, km, dp_ref);
+        yfx[q] = pavg(vt, c + (long)q * g.sj, sk, k, km, dp_ref);
+      }
+      have = false;
+    } else {
+      double un[2], vn[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (!have) {
+          up[q] = ut[c + q - sk];
+          vp[q] = vt[c + (long)q * g.sj - sk];
+        }
+        un[q] = ut[c + q];
+        vn[q] = vt[c + (long)q * g.sj];
+      }
+      const double int_ratio = 1.0 / (dp_ref[k - 1] + dp_ref[k]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        xfx[q] = (dp_ref[k] * up[q] + dp_ref[k - 1] * un[q]) * int_ratio;  // (pavg's interior expression)
+        yfx[q] = (dp_ref[k] * vp[q] + dp_ref[k - 1] * vn[q]) * int_ratio;
+        up[q] = un[q];
+        vp[q] = vn[q];
+      }
+      have = true;
+    }
+    fx[0] = xfx[0] * ((xfx[0] > 0.0) ? gz[kb + zxm] : gz[kb + zx0]);
+    fx[1] = xfx[1] * ((xfx[1] > 0.0) ? gz[kb + zx0] : gz[kb + zxp]);
+    fy[0] = yfx[0] * ((yfx[0] > 0.0) ? gz[kb + zym] : gz[kb + zy0]);
+    fy[1] = yfx[1] * ((yfx[1] > 0.0) ? gz[kb + zy0] : gz[kb + zyp]);
+    gz_new[c] = (gz[c] * area + fx[0] - fx[1] + fy[0] - fy[1]) / (area + xfx[0] - xfx[1] + yfx[0] - yfx[1]);
+  }
 }
 
 // ws and the monotonicity sweep (updatedzc.py:108-117), columns of compute +- 1
@@ -117,7 +159,7 @@ int launch_updatedzc(const Geo& g, const Met& m, void* ws_, const real* dp_ref, 
                      const real* vt, real* gz, real* ws, double dt, hipStream_t st) {
   if (g.nk < 3) return PACE_ERR_UNSUPPORTED;
   real* gz_new = (real*)ws_;
-  hipLaunchKernelGGL(k_updatedzc_advect, patch_grid(g, g.nk + 1), PATCH_BLOCK, 0, st, g, m, dp_ref, ut, vt, gz, gz_new);
+  hipLaunchKernelGGL(k_updatedzc_advect, patch_grid(g, (g.nk + 1 + ZC_CH - 1) / ZC_CH), PATCH_BLOCK, 0, st, g, m, dp_ref, ut, vt, gz, gz_new);
   hipLaunchKernelGGL(k_updatedzc_column, dim3((g.n + 2 + 63) / 64, g.n + 2), dim3(64), 0, st, g, zs, gz_new, gz, ws, 1.0 / dt);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
