@@ -489,20 +489,37 @@ k_scale_copy(Geo g, const real* __restrict__ src, real* __restrict__ dst, double
   dst[c] = scale ? src[c] * factor : src[c];
 }
 
-// p_grad_c_stencil (dyn_core.py:120-171), non-hydrostatic; compute + 1
+// p_grad_c_stencil (dyn_core.py:120-171), non-hydrostatic; compute + 1.  A thread takes PG_CH consecutive layers of its point:
+// the interface values below a layer are the ones above the next and stay in registers (k_nh_uv's arrangement).
+#define PG_CH 8
 __global__ void __launch_bounds__(256)
 k_p_grad_c(Geo g, Met m, real* __restrict__ uc, real* __restrict__ vc, const real* __restrict__ delpc,
            const real* __restrict__ pkc, const real* __restrict__ gz, double dt2) {
-  PATCH_IJK(g);
+  const int i = (int)blockIdx.x * PATCH_W + (int)threadIdx.x;
+  const int j = (int)blockIdx.y * PATCH_H + (int)threadIdx.y;
+  const int k0 = (int)blockIdx.z * PG_CH;
+  if (j >= g.nj || i >= g.ni) return;
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
-  const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const long sk = g.sk;
   const int sj = g.sj;
-  uc[c] = uc[c] + dt2 * m.rdxc[c2] / (delpc[c - 1] + delpc[c]) *
-                      ((gz[c - 1 + sk] - gz[c]) * (pkc[c + sk] - pkc[c - 1]) + (gz[c - 1] - gz[c + sk]) * (pkc[c - 1 + sk] - pkc[c]));
-  vc[c] = vc[c] + dt2 * m.rdyc[c2] / (delpc[c - sj] + delpc[c]) *
-                      ((gz[c - sj + sk] - gz[c]) * (pkc[c + sk] - pkc[c - sj]) + (gz[c - sj] - gz[c + sk]) * (pkc[c - sj + sk] - pkc[c]));
+  const double rdxc = m.rdxc[c2], rdyc = m.rdyc[c2];
+  long c = IDX3(g, i, j, k0);
+  // gz and pkc at (i, j), (i - 1, j), (i, j - 1) on the interface above the layer
+  double gz_0 = gz[c], gzx_0 = gz[c - 1], gzy_0 = gz[c - sj];
+  double pk_0 = pkc[c], pkx_0 = pkc[c - 1], pky_0 = pkc[c - sj];
+#pragma unroll
+  for (int t = 0; t < PG_CH; ++t) {
+    if (k0 + t >= g.nk) break;
+    const double gz_1 = gz[c + sk], gzx_1 = gz[c - 1 + sk], gzy_1 = gz[c - sj + sk];
+    const double pk_1 = pkc[c + sk], pkx_1 = pkc[c - 1 + sk], pky_1 = pkc[c - sj + sk];
+    const double d0 = delpc[c];
+    uc[c] = uc[c] + dt2 * rdxc / (delpc[c - 1] + d0) * ((gzx_1 - gz_0) * (pk_1 - pkx_0) + (gzx_0 - gz_1) * (pkx_1 - pk_0));
+    vc[c] = vc[c] + dt2 * rdyc / (delpc[c - sj] + d0) * ((gzy_1 - gz_0) * (pk_1 - pky_0) + (gzy_0 - gz_1) * (pky_1 - pk_0));
+    gz_0 = gz_1, gzx_0 = gzx_1, gzy_0 = gzy_1;
+    pk_0 = pk_1, pkx_0 = pkx_1, pky_0 = pky_1;
+    c += sk;
+  }
 }
 
 int launch_gz_from_surface(const Geo& g, const real* zs, const real* delz, real* gz, hipStream_t st) {
@@ -519,7 +536,7 @@ int launch_scale_copy(const Geo& g, const real* src, real* dst, double factor, i
 }
 int launch_p_grad_c(const Geo& g, const Met& m, real* uc, real* vc, const real* delpc, const real* pkc,
                     const real* gz, double dt2, hipStream_t st) {
-  hipLaunchKernelGGL(k_p_grad_c, patch_grid(g, g.nk), PATCH_BLOCK, 0, st, g, m, uc, vc, delpc, pkc, gz, dt2);
+  hipLaunchKernelGGL(k_p_grad_c, patch_grid(g, (g.nk + PG_CH - 1) / PG_CH), PATCH_BLOCK, 0, st, g, m, uc, vc, delpc, pkc, gz, dt2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
