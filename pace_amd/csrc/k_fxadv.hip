@@ -134,7 +134,9 @@ __device__ __forceinline__ void fx_vt_corners_point(const Geo& g, const Met& m, 
   vt[c] = val;
 }
 
-// fxadv_fluxes_stencil (:436-486)
+// fxadv_fluxes_stencil (:436-486).  A thread takes FX_CH consecutive levels of its point: the ten metric values a point needs
+// (rdxa, rdya, dx, dy and the sin_sg of either side) are the same on every level and are loaded once.
+#define FX_CH 8
 __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* __restrict__ ut,
                                                       const real* __restrict__ vt, real* __restrict__ crx,
                                                       real* __restrict__ cry, real* __restrict__ xfx,
@@ -142,35 +144,49 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
                                                       real* __restrict__ cx_acc, real* __restrict__ cy_acc, FxBox box) {
   // cx_acc / cy_acc (optional): the Courant-number half of d_sw's flux_capacitor (d_sw.py:33-60), cx += crx, cy += cry,
   // done where crx / cry are produced
-  PLANE_IJK(g);
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(p / g.sj);
+  const int i = (int)(p - (long)j * g.sj);
+  const int k0 = (int)blockIdx.y * FX_CH;
+  if (j >= g.nj || i >= g.ni) return;
   if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;
-  const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
-  if (i >= g.is && i <= g.ie + 1) {
-    const double u = ut[c];
-    double cr;
-    if (u > 0.0) {
-      cr = dt * u * m.rdxa[c2 - 1];
-      xfx[c] = m.dy[c2] * dt * u * m.sin_sg3[c2 - 1];
-    } else {
-      cr = dt * u * m.rdxa[c2];
-      xfx[c] = m.dy[c2] * dt * u * m.sin_sg1[c2];
+  const bool do_x = i >= g.is && i <= g.ie + 1, do_y = j >= g.js && j <= g.je + 1;
+  double rdxa_m = 0.0, rdxa_0 = 0.0, dy = 0.0, sg3_m = 0.0, sg1_0 = 0.0;
+  double rdya_m = 0.0, rdya_0 = 0.0, dx = 0.0, sg4_m = 0.0, sg2_0 = 0.0;
+  if (do_x) rdxa_m = m.rdxa[c2 - 1], rdxa_0 = m.rdxa[c2], dy = m.dy[c2], sg3_m = m.sin_sg3[c2 - 1], sg1_0 = m.sin_sg1[c2];
+  if (do_y) rdya_m = m.rdya[c2 - g.sj], rdya_0 = m.rdya[c2], dx = m.dx[c2], sg4_m = m.sin_sg4[c2 - g.sj], sg2_0 = m.sin_sg2[c2];
+#pragma unroll
+  for (int t = 0; t < FX_CH; ++t) {
+    const int k = k0 + t;
+    if (k >= g.nk) break;
+    const long c = c2 + (long)k * g.sk;
+    if (do_x) {
+      const double u = ut[c];
+      double cr;
+      if (u > 0.0) {
+        cr = dt * u * rdxa_m;
+        xfx[c] = dy * dt * u * sg3_m;
+      } else {
+        cr = dt * u * rdxa_0;
+        xfx[c] = dy * dt * u * sg1_0;
+      }
+      crx[c] = cr;
+      if (cx_acc) cx_acc[c] = cx_acc[c] + cr;
     }
-    crx[c] = cr;
-    if (cx_acc) cx_acc[c] = cx_acc[c] + cr;
-  }
-  if (j >= g.js && j <= g.je + 1) {
-    const double v = vt[c];
-    double cr;
-    if (v > 0.0) {
-      cr = dt * v * m.rdya[c2 - g.sj];
-      yfx[c] = m.dx[c2] * dt * v * m.sin_sg4[c2 - g.sj];
-    } else {
-      cr = dt * v * m.rdya[c2];
-      yfx[c] = m.dx[c2] * dt * v * m.sin_sg2[c2];
+    if (do_y) {
+      const double v = vt[c];
+      double cr;
+      if (v > 0.0) {
+        cr = dt * v * rdya_m;
+        yfx[c] = dx * dt * v * sg4_m;
+      } else {
+        cr = dt * v * rdya_0;
+        yfx[c] = dx * dt * v * sg2_0;
+      }
+      cry[c] = cr;
+      if (cy_acc) cy_acc[c] = cy_acc[c] + cr;
     }
-    cry[c] = cr;
-    if (cy_acc) cy_acc[c] = cy_acc[c] + cr;
   }
 }
 
@@ -237,7 +253,8 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
     add_region(S.d, g.is - 1, g.ie + 1, g.je, g.je);
     hipLaunchKernelGGL(k_fxadv_edges, dim3((unsigned)g.nk), dim3(1024), 0, st, g, m, uc, vc, ut, vt, S);
   }
-  hipLaunchKernelGGL(k_fxadv_fluxes, grid, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box);
+  const dim3 grid_fluxes(grid.x, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);
+  hipLaunchKernelGGL(k_fxadv_fluxes, grid_fluxes, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
