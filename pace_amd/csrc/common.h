@@ -382,6 +382,46 @@ static inline Regions bgrid_regions(const Geo& g, int d) {
     if (j > (R).je[reg__]) return;                                                             \
   }
 static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsigned)r.first[r.n], 1, (unsigned)nlev); }
+// The same with CH levels per thread in the interior patches and ONE in the frame strips (their edge forms are several times the
+// interior's cost per point: CH levels of them in a row would make the frame workgroups the last to finish), in one launch so
+// that the strips run beside the interior: a 1-D grid, first the interior patches of every chunk of levels, then the frame
+// blocks of every level (the other order measured slower: 99 against 91 us for k_d2a2c_b).  Sets i, j, `interior`, k0 (first level) and nk_here (levels this thread takes).
+static inline dim3 regions_grid_chunked(const Regions& r, int nlev, int ch) {
+  const int nbi = r.first[1], nfr = r.first[r.n] - r.first[1];
+  return dim3((unsigned)(nbi * ((nlev + ch - 1) / ch) + nfr * nlev), 1, 1);
+}
+#define REGION_POINT_CHUNKED(R, CH, NLEV)                                                      \
+  const int nbi__ = (R).first[1];                                                              \
+  const int ni__ = nbi__ * (((NLEV) + (CH)-1) / (CH));                                         \
+  int bx__, k0, nk_here;                                                                       \
+  if ((int)blockIdx.x < ni__) {                                                                \
+    const int ch__ = (int)blockIdx.x / nbi__;                                                  \
+    bx__ = (int)blockIdx.x - ch__ * nbi__;                                                     \
+    k0 = ch__ * (CH);                                                                          \
+    nk_here = (NLEV)-k0 < (CH) ? (NLEV)-k0 : (CH);                                             \
+  } else {                                                                                     \
+    const int f__ = (int)blockIdx.x - ni__, nfr__ = (R).first[(R).n] - nbi__;                  \
+    k0 = f__ / nfr__;                                                                          \
+    bx__ = nbi__ + (f__ - k0 * nfr__);                                                         \
+    nk_here = 1;                                                                               \
+  }                                                                                            \
+  int reg__ = 0;                                                                               \
+  while (reg__ + 1 < (R).n && bx__ >= (R).first[reg__ + 1]) ++reg__;                           \
+  const int b__ = bx__ - (R).first[reg__];                                                     \
+  const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
+  const bool interior = reg__ == 0;                                                            \
+  int i, j;                                                                                    \
+  if (interior) {                                                                              \
+    i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
+    j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
+    if (i > (R).ie[0] || j > (R).je[0]) return;                                                \
+  } else {                                                                                     \
+    const int w__ = (R).ie[reg__] - (R).ib[reg__] + 1;                                         \
+    const int p__ = b__ * 256 + t__;                                                           \
+    j = (R).jb[reg__] + p__ / w__;                                                             \
+    i = (R).ib[reg__] + p__ % w__;                                                             \
+    if (j > (R).je[reg__]) return;                                                             \
+  }
 // The same with the workgroups of a level on ONE XCD (workgroups are dealt to the eight XCDs round-robin in launch order; each
 // XCD has its own L2): for kernels whose points re-read rows of their j-neighbours -- with the plain order the patch above and
 // the patch below run on other XCDs and every XCD fetches its own copy of the shared rows.  XCD x works through levels x, x + 8,

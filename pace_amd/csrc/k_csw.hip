@@ -102,38 +102,16 @@ k_d2a2c_a(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, 
 
 // pass B: d2a2c_vect.py:362-527 (ut_main / east_west_edges / north_south_edges / vt_main), geoadjust_ut/vt
 // (c_sw.py:159-203) and divergence_corner (c_sw.py:31-156)
-__global__ void __launch_bounds__(256)
-k_d2a2c_b(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
-          const real* __restrict__ utmp, const real* __restrict__ vtmp, const real* __restrict__ ua,
-          const real* __restrict__ va, real* __restrict__ uc, real* __restrict__ vc, real* __restrict__ ut,
-          real* __restrict__ vt, real* __restrict__ divgd, double dt2, int do_divg, int geoadjust, Regions R) {
-  REGION_POINT(R);
+// (the points of the frame strips: the edge forms)
+__device__ __forceinline__ void d2a2c_b_frame_point(const Geo& g, const Met& m, const real* __restrict__ u, const real* __restrict__ v,
+                                                    const real* __restrict__ utmp, const real* __restrict__ vtmp,
+                                                    const real* __restrict__ ua, const real* __restrict__ va, real* __restrict__ uc,
+                                                    real* __restrict__ vc, real* __restrict__ ut, real* __restrict__ vt,
+                                                    real* __restrict__ divgd, double dt2, int do_divg, int geoadjust, int i, int j,
+                                                    int k) {
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;
-  if (interior) {
-    // is+2 <= i <= ie-1, js+2 <= j <= je-1: 4-point Lagrange everywhere, no edge wind, interior divergence
-    const double ucv = A2 * (utmp[c - 2] + utmp[c + 1]) + A1 * (utmp[c - 1] + utmp[c]);
-    double utv = contra2(ucv, v[c], m.cosa_u[c2], m.rsin_u[c2]);
-    uc[c] = ucv;
-    if (geoadjust) utv = (utv > 0.0) ? dt2 * utv * m.dy[c2] * m.sin_sg3[c2 - 1] : dt2 * utv * m.dy[c2] * m.sin_sg1[c2];
-    ut[c] = utv;
-    const double vcv = A2 * (vtmp[c - 2 * sj] + vtmp[c + sj]) + A1 * (vtmp[c - sj] + vtmp[c]);
-    double vtv = contra2(vcv, u[c], m.cosa_v[c2], m.rsin_v[c2]);
-    vc[c] = vcv;
-    if (geoadjust) vtv = (vtv > 0.0) ? dt2 * vtv * m.dx[c2] * m.sin_sg4[c2 - sj] : dt2 * vtv * m.dx[c2] * m.sin_sg2[c2];
-    vt[c] = vtv;
-    if (do_divg) {
-      const real* sg1 = m.sin_sg1; const real* sg2 = m.sin_sg2; const real* sg3 = m.sin_sg3; const real* sg4 = m.sin_sg4;
-      const real* cg1 = m.cos_sg1; const real* cg2 = m.cos_sg2; const real* cg3 = m.cos_sg3; const real* cg4 = m.cos_sg4;
-      const double uf = (u[c] - 0.25 * (va[c - sj] + va[c]) * (cg4[c2 - sj] + cg2[c2])) * m.dyc[c2] * 0.5 * (sg4[c2 - sj] + sg2[c2]);
-      const double uf1 = (u[c - 1] - 0.25 * (va[c - 1 - sj] + va[c - 1]) * (cg4[c2 - 1 - sj] + cg2[c2 - 1])) * m.dyc[c2 - 1] * 0.5 * (sg4[c2 - 1 - sj] + sg2[c2 - 1]);
-      const double vf = (v[c] - 0.25 * (ua[c - 1] + ua[c]) * (cg3[c2 - 1] + cg1[c2])) * m.dxc[c2] * 0.5 * (sg3[c2 - 1] + sg1[c2]);
-      const double vf1 = (v[c - sj] - 0.25 * (ua[c - 1 - sj] + ua[c - sj]) * (cg3[c2 - 1 - sj] + cg1[c2 - sj])) * m.dxc[c2 - sj] * 0.5 * (sg3[c2 - 1 - sj] + sg1[c2 - sj]);
-      divgd[c] = (vf1 - vf + uf1 - uf) * m.rarea_c[c2];
-    }
-    return;
-  }
   if (j <= g.je + 1) {  // uc, ut on i = is-1 .. ie+2, j = js-1 .. je+1
     double ucv, utv;
     if (i == g.is || i == g.ie + 1) {
@@ -201,6 +179,67 @@ k_d2a2c_b(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
     else d = (vf1 - vf + uf1 - uf) * m.rarea_c[c2];
     divgd[c] = d;
   }
+}
+
+// A thread takes D2B_CH consecutive levels of its point.  An interior point reads ~30 metric values (cosa / rsin of both winds,
+// dx, dy, the sin_sg and cos_sg of four neighbours, dxc, dyc, rarea_c) against 14 values of the 3-D fields: they -- and the sums
+// of them the divergence uses -- are formed once per point instead of once per level.
+#define D2B_CH 8
+__global__ void __launch_bounds__(256)
+k_d2a2c_b(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
+          const real* __restrict__ utmp, const real* __restrict__ vtmp, const real* __restrict__ ua,
+          const real* __restrict__ va, real* __restrict__ uc, real* __restrict__ vc, real* __restrict__ ut,
+          real* __restrict__ vt, real* __restrict__ divgd, double dt2, int do_divg, int geoadjust, Regions R) {
+  REGION_POINT_CHUNKED(R, D2B_CH, g.nk);  // (D2B_CH levels per thread in the interior, one in the frame strips)
+  const int sj = g.sj;
+  if (!interior) {
+    d2a2c_b_frame_point(g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2, do_divg, geoadjust, i, j, k0);
+    return;
+  }
+  // is+2 <= i <= ie-1, js+2 <= j <= je-1: 4-point Lagrange everywhere, no edge wind, interior divergence
+  const long c2 = IDX2(g, i, j);
+  const double cosa_u = m.cosa_u[c2], rsin_u = m.rsin_u[c2], cosa_v = m.cosa_v[c2], rsin_v = m.rsin_v[c2];
+  const double dy = m.dy[c2], dx = m.dx[c2];
+  const double sg3_m = m.sin_sg3[c2 - 1], sg1_0 = m.sin_sg1[c2], sg4_m = m.sin_sg4[c2 - sj], sg2_0 = m.sin_sg2[c2];
+  // divergence_corner: the sums of cos_sg / sin_sg on the four faces around the corner, dyc / dxc there, rarea_c
+  double cu = 0.0, su = 0.0, dyc0 = 0.0, cu1 = 0.0, su1 = 0.0, dyc1 = 0.0, cv = 0.0, sv = 0.0, dxc0 = 0.0, cv1 = 0.0, sv1 = 0.0,
+         dxc1 = 0.0, rarea_c = 0.0;
+  if (do_divg) {
+    cu = m.cos_sg4[c2 - sj] + m.cos_sg2[c2], su = sg4_m + sg2_0, dyc0 = m.dyc[c2];
+    cu1 = m.cos_sg4[c2 - 1 - sj] + m.cos_sg2[c2 - 1], su1 = m.sin_sg4[c2 - 1 - sj] + m.sin_sg2[c2 - 1], dyc1 = m.dyc[c2 - 1];
+    cv = m.cos_sg3[c2 - 1] + m.cos_sg1[c2], sv = sg3_m + sg1_0, dxc0 = m.dxc[c2];
+    cv1 = m.cos_sg3[c2 - 1 - sj] + m.cos_sg1[c2 - sj], sv1 = m.sin_sg3[c2 - 1 - sj] + m.sin_sg1[c2 - sj], dxc1 = m.dxc[c2 - sj];
+    rarea_c = m.rarea_c[c2];
+  }
+#pragma unroll
+  for (int t = 0; t < D2B_CH; ++t) {
+    if (t >= nk_here) break;
+    const long c = c2 + (long)(k0 + t) * g.sk;
+    const double ucv = A2 * (utmp[c - 2] + utmp[c + 1]) + A1 * (utmp[c - 1] + utmp[c]);
+    double utv = contra2(ucv, v[c], cosa_u, rsin_u);
+    uc[c] = ucv;
+    if (geoadjust) utv = (utv > 0.0) ? dt2 * utv * dy * sg3_m : dt2 * utv * dy * sg1_0;
+    ut[c] = utv;
+    const double vcv = A2 * (vtmp[c - 2 * sj] + vtmp[c + sj]) + A1 * (vtmp[c - sj] + vtmp[c]);
+    double vtv = contra2(vcv, u[c], cosa_v, rsin_v);
+    vc[c] = vcv;
+    if (geoadjust) vtv = (vtv > 0.0) ? dt2 * vtv * dx * sg4_m : dt2 * vtv * dx * sg2_0;
+    vt[c] = vtv;
+    if (do_divg) {
+      const double uf = (u[c] - 0.25 * (va[c - sj] + va[c]) * cu) * dyc0 * 0.5 * su;
+      const double uf1 = (u[c - 1] - 0.25 * (va[c - 1 - sj] + va[c - 1]) * cu1) * dyc1 * 0.5 * su1;
+      const double vf = (v[c] - 0.25 * (ua[c - 1] + ua[c]) * cv) * dxc0 * 0.5 * sv;
+      const double vf1 = (v[c - sj] - 0.25 * (ua[c - 1 - sj] + ua[c - sj]) * cv1) * dxc1 * 0.5 * sv1;
+      divgd[c] = (vf1 - vf + uf1 - uf) * rarea_c;
+    }
+  }
+}
+
+static void launch_d2a2c_b(const Geo& g, const Met& m, const real* u, const real* v, const real* utmp, const real* vtmp,
+                           const real* ua, const real* va, real* uc, real* vc, real* ut, real* vt, real* divgd, double dt2,
+                           int do_divg, int geoadjust, const Regions& rb, hipStream_t st) {
+  hipLaunchKernelGGL(k_d2a2c_b, regions_grid_chunked(rb, g.nk, D2B_CH), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut,
+                     vt, divgd, dt2, do_divg, geoadjust, rb);
 }
 
 // read-side forms of fill_corners_2cells_x / _y with unit multipliers on the transported scalars
@@ -359,8 +398,7 @@ int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, real* uc, real* vc, 
   const dim3 grid = plane_grid(g, g.nk), block(256);
   hipLaunchKernelGGL(k_d2a2c_a, grid, block, 0, st, g, m, u, v, utmp, vtmp, ua, va, SplitBox{0, 0, 0, 0, 0});
   const Regions rb = d2a2c_regions(g);
-  hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, utc, vtc,
-                     (real*)nullptr, 0.0, 0, 0, rb);
+  launch_d2a2c_b(g, m, u, v, utmp, vtmp, ua, va, uc, vc, utc, vtc, (real*)nullptr, 0.0, 0, 0, rb, st);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
@@ -384,8 +422,7 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, co
     return PACE_OK;
   }
   const Regions rb = d2a2c_regions(g);
-  hipLaunchKernelGGL(k_d2a2c_b, regions_grid(rb, g.nk), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2,
-                     nord > 0 ? 1 : 0, 1, rb);
+  launch_d2a2c_b(g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2, nord > 0 ? 1 : 0, 1, rb, st);
   Regions rt{};  // interior box + the width-2 frame of the domain [is-1, ie+1] x [js-1, je+1]
   add_region(rt, g.is + 1, g.ie - 1, g.js + 1, g.je - 1);
   add_region(rt, g.is - 1, g.is, g.js - 1, g.je + 1);
