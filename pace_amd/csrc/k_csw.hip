@@ -353,24 +353,39 @@ k_csw_transport(Geo g, Met m, const real* __restrict__ delp, const real* __restr
 }
 
 // pass D: update_y_velocity (c_sw.py:445-480), update_x_velocity (:411-442)
+#define UV_CH 8
 __global__ void __launch_bounds__(256)
 k_csw_update_uc_vc(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
                    const real* __restrict__ ke, const real* __restrict__ vort, real* __restrict__ uc,
                    real* __restrict__ vc, double dt2) {
-  PLANE_IJK(g);
+  // (UV_CH levels per thread: the six metric values of a point are loaded once)
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(p / g.sj);
+  const int i = (int)(p - (long)j * g.sj);
+  const int k0 = (int)blockIdx.y * UV_CH;
+  if (j >= g.nj || i >= g.ni) return;
   if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
-  const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;
-  if (i <= g.ie) {
-    const double tmp = (j == g.js || j == g.je + 1) ? dt2 * u[c] : dt2 * (u[c] - vc[c] * m.cosa_v[c2]) / m.sina_v[c2];
-    const double flux = (tmp > 0.0) ? vort[c] : vort[c + 1];
-    vc[c] = vc[c] - tmp * flux + m.rdyc[c2] * (ke[c - sj] - ke[c]);
-  }
-  if (j <= g.je) {
-    const double tmp = (i == g.is || i == g.ie + 1) ? dt2 * v[c] : dt2 * (v[c] - uc[c] * m.cosa_u[c2]) / m.sina_u[c2];
-    const double flux = (tmp > 0.0) ? vort[c] : vort[c + sj];
-    uc[c] = uc[c] + tmp * flux + m.rdxc[c2] * (ke[c - 1] - ke[c]);
+  const bool do_v = i <= g.ie, do_u = j <= g.je;
+  const bool v_edge = j == g.js || j == g.je + 1, u_edge = i == g.is || i == g.ie + 1;
+  double cosa_v = 0.0, sina_v = 1.0, rdyc = 0.0, cosa_u = 0.0, sina_u = 1.0, rdxc = 0.0;
+  if (do_v) cosa_v = m.cosa_v[c2], sina_v = m.sina_v[c2], rdyc = m.rdyc[c2];
+  if (do_u) cosa_u = m.cosa_u[c2], sina_u = m.sina_u[c2], rdxc = m.rdxc[c2];
+#pragma unroll
+  for (int t = 0; t < UV_CH; ++t) {
+    if (k0 + t >= g.nk) break;
+    const long c = c2 + (long)(k0 + t) * g.sk;
+    if (do_v) {
+      const double tmp = v_edge ? dt2 * u[c] : dt2 * (u[c] - vc[c] * cosa_v) / sina_v;
+      const double flux = (tmp > 0.0) ? vort[c] : vort[c + 1];
+      vc[c] = vc[c] - tmp * flux + rdyc * (ke[c - sj] - ke[c]);
+    }
+    if (do_u) {
+      const double tmp = u_edge ? dt2 * v[c] : dt2 * (v[c] - uc[c] * cosa_u) / sina_u;
+      const double flux = (tmp > 0.0) ? vort[c] : vort[c + sj];
+      uc[c] = uc[c] + tmp * flux + rdxc * (ke[c - 1] - ke[c]);
+    }
   }
 }
 
@@ -431,7 +446,7 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, co
   add_region(rt, g.is + 1, g.ie - 1, g.je, g.je + 1);
   hipLaunchKernelGGL(k_csw_transport, regions_grid(rt, g.nk), dim3(64, 4), 0, st, g, m, delp, pt, w, u, v, ua, va, uc, vc, ut, vt,
                      delpc, ptc, omga, ke, vort, dt2, rt);
-  hipLaunchKernelGGL(k_csw_update_uc_vc, grid, block, 0, st, g, m, u, v, ke, vort, uc, vc, dt2);
+  hipLaunchKernelGGL(k_csw_update_uc_vc, dim3(grid.x, (unsigned)((g.nk + UV_CH - 1) / UV_CH), 1), block, 0, st, g, m, u, v, ke, vort, uc, vc, dt2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
