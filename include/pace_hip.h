@@ -76,7 +76,18 @@ typedef struct {
   const double *fac_vt, *fac_t, *fac_vt_c, *fac_w_c;
 } pace_column_t;
 
+/* flags of pace_dsw_config_t */
+#define PACE_DSW_SKIP_DEAD_OUTPUTS 1 /* delpc, divgd, uc, vc are not brought to the state the reference leaves them in: they are
+                                      * work fields of DivergenceDamping (divergence_damping.py:561-600) that c_sw recomputes before
+                                      * anything reads them again (d_sw.py:1032-1033, dyn_core.py:720-852).  Their contents are
+                                      * unspecified after the call; every other argument is unaffected, bit for bit.  This is what
+                                      * the acoustic loop asks for; the default (0) is the reference's full contract. */
+
 typedef struct {
+  /* sizeof(pace_dsw_config_t) of the header the caller was built with: a mismatch is refused (PACE_ERR_ARG) instead of
+   * reading fields the caller never set.  Zero-initialise the struct, then fill it. */
+  int32_t struct_bytes;
+  int32_t flags; /* PACE_DSW_* */
   int32_t hord_dp, hord_tm, hord_vt, hord_mt;
   int32_t nord;
   int32_t do_skeb;

@@ -43,8 +43,12 @@ class Column(C.Structure):
     _fields_ = [(n, C.POINTER(C.c_double)) for n in COLUMN_FIELDS]
 
 
+DSW_SKIP_DEAD_OUTPUTS = 1  # include/pace_hip.h PACE_DSW_SKIP_DEAD_OUTPUTS
+
+
 class DswConfig(C.Structure):
     _fields_ = [
+        ("struct_bytes", C.c_int32), ("flags", C.c_int32),
         ("hord_dp", C.c_int32), ("hord_tm", C.c_int32), ("hord_vt", C.c_int32), ("hord_mt", C.c_int32),
         ("nord", C.c_int32), ("do_skeb", C.c_int32), ("dddmp", C.c_double), ("d4_bg", C.c_double), ("d_con", C.c_double),
         # optional separate outputs of the four transported scalars (include/pace_hip.h): all four or none

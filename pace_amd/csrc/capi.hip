@@ -165,10 +165,13 @@ static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t*
   NEED(geom && met && col && cfg && workspace);
   NEED(delpc && delp && pt && u && v && w && uc && vc && ua && va && divgd && mfx && mfy && cx && cy);
   NEED(crx && cry && xfx && yfx && q_con && heat_source && diss_est);
+  if (cfg->struct_bytes != (int32_t)sizeof(pace_dsw_config_t)) return PACE_ERR_ARG;  // built against another header
   {  // separate outputs: all four or none, none of them an input
     const int given = (cfg->delp_out != nullptr) + (cfg->pt_out != nullptr) + (cfg->w_out != nullptr) + (cfg->q_con_out != nullptr);
     if (given != 0 && given != 4) return PACE_ERR_ARG;
     if (given && (cfg->delp_out == delp || cfg->pt_out == pt || cfg->w_out == w || cfg->q_con_out == q_con)) return PACE_ERR_ARG;
+    if (given && ((((uintptr_t)cfg->delp_out | (uintptr_t)cfg->pt_out | (uintptr_t)cfg->w_out | (uintptr_t)cfg->q_con_out) & 15) != 0))
+      return PACE_ERR_ARG;  // (16-byte rows, as the header says)
   }
   return launch_d_sw(make_geo(geom), *met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy,
                      cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est, dt, phases, S(stream));

@@ -252,33 +252,39 @@ __device__ __forceinline__ void ppm_run8(const double* Q, const double* c, int p
 // the fluxes of a run from its F + 2 interface values (shared by the forms of ppm_run below)
 template <int MORD, int F>
 __device__ __forceinline__ void ppm_fluxes_from_al(const double* Q, const double* al, const double* c, double* out) {
-  double bl[F + 1], br[F + 1], b0[F + 1];
-  bool steep[F + 1];
-#pragma unroll
-  for (int x = 0; x < F + 1; ++x) {
+  // Cell x of the run (Q[x + 2], between al[x] and al[x + 1]): bl = al[x] - q, br = al[x + 1] - q, b0 = bl + br, and whether the
+  // parabola is steep (xppm.py:40-53).  The fluxes are formed in the order of the faces with only the two cells of a face live
+  // (round 5: all F + 1 reconstructions at once were 6 * (3 doubles + a flag) of register pressure at the kernel's peak).
+  auto cell = [&](int x, double& b0, bool& steep) {
     const double qx = Q[x + 2];
-    bl[x] = al[x] - qx;
-    br[x] = al[x + 1] - qx;
-    b0[x] = bl[x] + br[x];
-    steep[x] = (MORD == 5) ? (bl[x] * br[x] < 0) : ((3.0 * fabs(b0[x])) < fabs(bl[x] - br[x]));
-  }
+    const double bl = al[x] - qx;
+    const double br = al[x + 1] - qx;
+    b0 = bl + br;
+    steep = (MORD == 5) ? (bl * br < 0) : ((3.0 * fabs(b0)) < fabs(bl - br));
+  };
+  double b0_lo, b0_hi;
+  bool steep_lo, steep_hi;
+  cell(0, b0_lo, steep_lo);
 #pragma unroll
   for (int f = 0; f < F; ++f) {
-    const double mask = (steep[f] || steep[f + 1]) ? 1.0 : 0.0;
+    cell(f + 1, b0_hi, steep_hi);
+    const double mask = (steep_lo || steep_hi) ? 1.0 : 0.0;
     const double cc = c[f];
     // xppm.py:56-72: c > 0: q[i-1] + (1 - c) * (br[i-1] - c * b0[i-1]), else q[i] + (1 + c) * (bl[i] + c * b0[i]).  With a = |c|
     // both are Q + (1 - a) * (X - a * B) on the upwind cell's values -- the same bits (1 + c == 1 - |c| and bl + c * b0 ==
     // bl - |c| * b0 for c <= 0: a sign moved, no rounding) -- selected as values instead of as branches: a divergent branch per
     // face costs seven scalar instructions of exec-mask bookkeeping and both arms.
     // (X = br of the cell behind the face or bl of the cell in front of it: both are al[f + 1] - that cell's value, the very
-    // expressions of the cell loop above -- one select less)
+    // expressions of the cell function above -- one select less)
     const bool up = cc > 0.0;
     const double a = fabs(cc);
     const double Qs = up ? Q[f + 2] : Q[f + 3];
     const double X = al[f + 1] - Qs;
-    const double B = up ? b0[f] : b0[f + 1];
+    const double B = up ? b0_lo : b0_hi;
     const double fx1 = (1.0 - a) * (X - a * B);
     out[f] = Qs + fx1 * mask;
+    b0_lo = b0_hi;
+    steep_lo = steep_hi;
   }
 }
 
@@ -331,7 +337,7 @@ __device__ __forceinline__ void ppm_run(const double* Q, const double* c, int po
 // the points; 64 x 4 patches so rows stay coalesced) and up to four thin frame strips that run the general code (their
 // points are flattened over the 256 threads of a block so lanes stay busy whatever the strip's orientation) -- all in
 // ONE launch: blockIdx.x is split into per-region ranges, the branch on the region is block-uniform.
-#define MAX_REGIONS 5
+#define MAX_REGIONS 9
 struct Regions {
   int n;
   int ib[MAX_REGIONS], ie[MAX_REGIONS], jb[MAX_REGIONS], je[MAX_REGIONS];

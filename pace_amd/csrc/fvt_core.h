@@ -80,8 +80,16 @@ struct FvtLds {
 // order pin for the instruction scheduler (register pressure: operands that are only needed after a PPM run are loaded after it)
 #ifdef PACE_EMU
 #define FVT_FENCE()
+#define FVT_LAUNDER(x) (x)
 #else
 #define FVT_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the same value through an empty asm: what is derived from it is derived AGAIN, not kept in registers from the last time
+// (the thread places of the scalar-phase kernel, re-derived per scalar instead of living through the whole kernel)
+__device__ __forceinline__ int fvt_launder(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+#define FVT_LAUNDER(x) fvt_launder(x)
 #endif
 // ... of the scalar-phase kernel (two workgroups per CU: 80 KB each): the transport's arrays, the mass on the tile and one cell
 // around it (the mass-weighted damping of q_con and pt reads it at the faces, the cell update at the cells), and ten doubles
@@ -91,6 +99,7 @@ struct FvtLdsScalars {
   FvtLds t;
   double mass[(TJ + 2) * MP];
   double priv[2 * NF][256];
+  double newmass[TI * TJ];  // (512-thread form: the new delp of the tile's cells; the 256-thread form keeps it in registers)
 };
 
 #define LDG(p, off) (*(const real*)((const char*)(p) + (off)))
@@ -128,7 +137,7 @@ __device__ __forceinline__ void fvt_run(const double* Q, const double* c, bool l
 // footprint (after the first pass; two rings after the second) holds garbage that no tile face ever reads -- the reference
 // shrinks its compute domain by one cell per pass for the same reason -- so no cell is predicated and no index is clamped
 // (rows -1 and QH of a plane are the neighbouring arrays / pad rows of FvtLds).
-template <bool FIRST>
+template <bool FIRST, int RC = DN_RC>
 __device__ __forceinline__ void fvt_deln_run(const double* p, const double* pv, const double* pu, const double* ra, double d0, double* res) {
   auto val = [&](double x) { return FIRST ? d0 * x : x; };  // (d0 * x: the reference's first statement, d2 = damp * q)
   auto sgn = [&](double x) { return FIRST ? x : -x; };      // (later passes: fx2 = -fx2, delnflux.py:1232-1254)
@@ -156,18 +165,19 @@ __device__ __forceinline__ void fvt_deln_run(const double* p, const double* pv, 
       res[T0 + t] = (fw - fe + fy[t] - fy[t + 1]) * ra[T0 + t];
     }
   };
-  constexpr int H = (DN_RC + 1) / 2;
+  constexpr int H = (RC + 1) / 2;
   chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
 #ifndef PACE_EMU
   __builtin_amdgcn_sched_barrier(0);
 #endif
-  chunk(std::integral_constant<int, H>{}, std::integral_constant<int, DN_RC>{});
+  chunk(std::integral_constant<int, H>{}, std::integral_constant<int, RC>{});
 }
 
 // a footprint-sized plane of a field, 16 bytes per lane
-struct FvtPieces {
+template <int NT>
+struct FvtPiecesT {
   static constexpr int HW = QW / 2;             // 16-byte pieces per row
-  static constexpr int RPP = 256 / HW;          // rows per pass
+  static constexpr int RPP = NT / HW;           // rows per pass
   static constexpr int NP = (QH + RPP - 1) / RPP;
   int lc, lr0, row[NP];
   unsigned off[NP];
@@ -197,11 +207,21 @@ struct FvtPieces {
     }
   }
 };
+using FvtPieces = FvtPiecesT<256>;
 
 // The stages of one tile.  EX / EY: the tile holds a west or east / south or north edge of the cubed-sphere tile (block-uniform).
-template <int MORD, bool EX, bool EY>
+// NT = 256: every thread owns one y-run AND one x-run.  NT = 512 (the scalar-phase kernel): the first four waves own the x-runs,
+// the last four the y-runs -- half the persistent state per thread, twice the waves per SIMD.
+template <int MORD, bool EX, bool EY, int NT = 256>
 struct FvtTile {
   static constexpr bool RC = EX && EY;  // the footprint reaches a corner of the halo: the corner copies apply
+  static constexpr bool SPLIT = NT == 512;
+  static_assert(NT == 256 || NT == 512, "thread places of one or two roles");
+  static constexpr int DRC = SPLIT ? 3 : DN_RC;       // cells per column run of the damping
+  static constexpr int DNR = (QH + DRC - 1) / DRC;   // runs per column
+  static_assert(QW * DNR <= NT, "one column run per thread");
+  static constexpr int NCU = (TI * TJ + NT - 1) / NT;  // cells per thread in the cell update
+  using Pieces = FvtPiecesT<NT>;
   FvtLds& L;
   const Geo& g;
   const FvMet& m;
@@ -213,11 +233,11 @@ struct FvtTile {
   bool y_on, y_outer, x_on, x_outer;
   int ybase, xbase;     // sq / sqi / damping planes: element (row C*yg, column ycol); sq: element (row xrow, column C*xg)
   unsigned yoff, xoff;  // byte offsets in a level: the y-run's first interface (ilo + ycol, j0 + C*yg), the x-run's (i0 + C*xg, jlo + xrow)
-  FvtPieces pc;
-  // the thread's column run of the damping: column dc, rows dr0 .. dr0 + DN_RC - 1 of the footprint
+  Pieces pc;
+  // the thread's column run of the damping: column dc, rows dr0 .. dr0 + DRC - 1 of the footprint
   int dc, dr0, dbase;
   bool dn_on;
-  double dra[DN_RC];
+  double dra[DRC];
   // corner tiles: a cell whose damping stencil reaches into a corner region of the halo (delnflux_core.h deln_affected), one
   // candidate per thread of the first wave: its place in the plane (or -1) and the places its six operands come from once the
   // corner copies are applied -- X(i-1), X(i), X(i+1) with copy_corners_x, Y(j-1), Y(j), Y(j+1) with copy_corners_y
@@ -235,20 +255,22 @@ struct FvtTile {
     // which edges of the cubed-sphere tile this workgroup tile holds (one per axis at most: >= 2 tiles each way)
     west = EX && bx == 0, east = EX && !west;
     south = EY && by == 0, north = EY && !south;
-    y_on = true;
-    if (tid < NYO) {
-      yg = tid / TI;
-      ycol = 3 + (tid - yg * TI);
+    const bool xrole = !SPLIT || tid < 256, yrole = !SPLIT || tid >= 256;  // (wave-uniform)
+    const int tr = SPLIT ? (tid & 255) : tid;                               // the thread's number within its role
+    y_on = yrole;
+    if (tr < NYO) {
+      yg = tr / TI;
+      ycol = 3 + (tr - yg * TI);
     } else {
-      const int r = tid - NYO;
-      y_on = r < NYH;
+      const int r = tr - NYO;
+      y_on = yrole && r < NYH;
       yg = y_on ? r / 6 : 0;
       const int h = y_on ? r - yg * 6 : 0;
       ycol = h < 3 ? h : TI + h;
     }
-    y_outer = tid < NYO;
-    xr = tid / GXN, xg = tid - xr * GXN;
-    x_on = xr < QH, x_outer = xr < TJ;
+    y_outer = yrole && tr < NYO;
+    xr = tr / GXN, xg = tr - xr * GXN;
+    x_on = xrole && xr < QH, x_outer = xrole && xr < TJ;
     xrow = xr + 3;  // the tile's own rows first: footprint rows 3 .. TJ+2, then TJ+3 .. QH-1, then 0 .. 2
     if (xrow >= QH) xrow -= QH;
     if (!x_on) xrow = 0;
@@ -259,8 +281,8 @@ struct FvtTile {
     pc.init(tid, ilo, jlo, sj8);
     const int dr = tid / QW;
     dc = tid - dr * QW;
-    dn_on = dr < DN_NR;
-    dr0 = dn_on ? dr * DN_RC : 0;
+    dn_on = dr < DNR;
+    dr0 = dn_on ? dr * DRC : 0;
     dbase = dr0 * P + dc;
     plane = L.u.scratch;
     sdv = plane + QH * P;
@@ -308,11 +330,11 @@ struct FvtTile {
   // halo_out (edge tiles of the scalar phase): the footprint's cells outside the compute domain are copied there as they are, so
   // that the output buffer ends up with the halo the input has (the reference updates its fields in place).
   __device__ __forceinline__ void load_footprint(const real* __restrict__ q, real* __restrict__ halo_out = nullptr) {
-    D2 v[FvtPieces::NP];
+    D2 v[Pieces::NP];
     pc.load(q, v);
     if ((EX || EY) && halo_out) {
 #pragma unroll
-      for (int p = 0; p < FvtPieces::NP; ++p) {
+      for (int p = 0; p < Pieces::NP; ++p) {
         const int gj = jlo + pc.row[p];
         const bool rowout = gj < g.js || gj > g.je;
 #pragma unroll
@@ -326,7 +348,7 @@ struct FvtTile {
     if (RC) {  // corner tile: the corner block holds the values copy_corners_y puts there (corners.py:367-425); the thread that
                // stored a piece overwrites its corner cells (same thread, same address: program order)
 #pragma unroll
-      for (int p = 0; p < FvtPieces::NP; ++p) {
+      for (int p = 0; p < Pieces::NP; ++p) {
         const int gj = jlo + pc.row[p];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -352,7 +374,7 @@ struct FvtTile {
     load_damping_rarea();
   }
   __device__ __forceinline__ void stage_damping_planes() {
-    D2 mv[FvtPieces::NP], mu[FvtPieces::NP];
+    D2 mv[Pieces::NP], mu[Pieces::NP];
     pc.load(m.del6_v, mv);
     pc.load(m.del6_u, mu);
     pc.store(sdv, mv);
@@ -360,19 +382,19 @@ struct FvtTile {
   }
   __device__ __forceinline__ void load_damping_rarea() {
 #pragma unroll
-    for (int t = 0; t < DN_RC; ++t) {
+    for (int t = 0; t < DRC; ++t) {
       int row = dr0 + t;
-      if (QH % DN_RC != 0 && row >= QH) row = QH - 1;
+      if (QH % DRC != 0 && row >= QH) row = QH - 1;
       dra[t] = LDG(m.rarea, (unsigned)((jlo + row) * sj8 + (ilo + dc) * 8));
     }
   }
   // the transported scalar is q + add2d (absolute vorticity), the damped one was q: every thread adds to the pieces it loaded.
   // Ends with a barrier.
   __device__ __forceinline__ void add_2d(const real* __restrict__ add2d) {
-    D2 v[FvtPieces::NP];
+    D2 v[Pieces::NP];
     pc.load(add2d, v);
 #pragma unroll
-    for (int p = 0; p < FvtPieces::NP; ++p) {
+    for (int p = 0; p < Pieces::NP; ++p) {
       if (pc.own(p)) {  // (each piece once: the clamped repeats would add twice)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -407,11 +429,11 @@ struct FvtTile {
   __device__ __forceinline__ Damped damp(double d0, bool hi_order, int nmax) {
     const int iters = hi_order ? nmax : 0;
     for (int it = 0; it < iters; ++it) {
-      double res[DN_RC];
+      double res[DRC];
       double fix = 0.0;
       if (dn_on) {
-        if (it == 0) fvt_deln_run<true>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
-        else fvt_deln_run<false>(plane + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
+        if (it == 0) fvt_deln_run<true, DRC>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
+        else fvt_deln_run<false, DRC>(plane + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
       }
       if (RC && fx_at >= 0) {  // corner tile: the cells whose stencil reaches into a corner region, with the corner copies
         if (it == 0) fix = corner_fix<true>(L.sq, d0);
@@ -420,8 +442,8 @@ struct FvtTile {
       if (it > 0) __syncthreads();  // (in place: everyone has read the iterate)
       if (dn_on) {
 #pragma unroll
-        for (int t = 0; t < DN_RC; ++t)
-          if (QH % DN_RC == 0 || dr0 + t < QH) plane[dbase + t * P] = res[t];
+        for (int t = 0; t < DRC; ++t)
+          if (QH % DRC == 0 || dr0 + t < QH) plane[dbase + t * P] = res[t];
       }
       if (RC) {
         __syncthreads();  // (the runs have written those cells as if they were interior cells: overwrite)
@@ -451,12 +473,12 @@ struct FvtTile {
   __device__ __forceinline__ void heat_diss(const Damped& D, real* __restrict__ dw, real* __restrict__ heat_s,
                                             real* __restrict__ diss_est, bool on, double dd8) {
     if (!dn_on) return;
-    double res[DN_RC];
-    if (D.first) fvt_deln_run<true>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, D.d0, res);
-    else fvt_deln_run<false>(plane + dbase, sdv + dbase, sdu + dbase, dra, D.d0, res);
+    double res[DRC];
+    if (D.first) fvt_deln_run<true, DRC>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, D.d0, res);
+    else fvt_deln_run<false, DRC>(plane + dbase, sdv + dbase, sdu + dbase, dra, D.d0, res);
     if (dc >= 3 && dc < TI + 3) {
 #pragma unroll
-      for (int t = 0; t < DN_RC; ++t) {
+      for (int t = 0; t < DRC; ++t) {
         const int jj = dr0 + t;
         if (jj >= 3 && jj < TJ + 3) {
           const unsigned c = (unsigned)((jlo + jj) * sj8 + (ilo + dc) * 8);
@@ -623,8 +645,8 @@ struct FvtTile {
   // the cells of the cell update: NEC per thread, lanes along i
   __device__ __forceinline__ void cell_places(int* jj, int* ii, unsigned* c2) const {
 #pragma unroll
-    for (int t = 0; t < NEC; ++t) {
-      int e = tid + 256 * t;
+    for (int t = 0; t < NCU; ++t) {
+      int e = tid + NT * t;
       if (e >= TI * TJ) e = TI * TJ - 1;  // (spare lanes repeat the last cell)
       jj[t] = e / TI, ii[t] = e - jj[t] * TI;
       c2[t] = (unsigned)((j0 + jj[t]) * sj8 + (i0 + ii[t]) * 8);
@@ -966,6 +988,258 @@ __device__ __forceinline__ void fvt_scalars_tile(FvtLdsScalars& LS, const Geo& g
           val = dn[t];
         } else {
           val = T.flux_form(jj[t], ii[t], am, ra[t]) / dn[t];
+          if (is_w && w_on) val = val + dwv[t];  // adjust_w_and_qcon (d_sw.py:331-350)
+        }
+        STG(qout, c2[t]) = val;
+      }
+    }
+    if (s < 3) __syncthreads();  // (the cell update read sq / ax / ay)
+  }
+  FVT_STAMP(16);
+}
+
+
+// ---- the same with 512 threads: x-runs and y-runs owned by different waves ----------------------------------------------------
+// Round 5.  The 256-thread form holds the Courant numbers, area fluxes and mass fluxes of ten faces per thread (its y-run and
+// its x-run): ~250 VGPRs = two waves per SIMD, and the counters showed the issue slots two thirds empty (one wave issues at most
+// every ~8 cycles; 54 % of wave time in memory / LDS / barrier waits with nothing else to issue).  Here waves 0-3 own the x-runs
+// (inner sweep in x on q, outer sweep in x on q_i) and waves 4-7 the y-runs, so a thread carries the operands of FIVE faces:
+// <= 128 VGPRs = four waves per SIMD at the same LDS per workgroup, the same tile and the same arithmetic (same bits).  The
+// stages every thread shares (footprint, damping passes, cell update) are spread over twice the threads.
+template <int MORD, bool EX, bool EY>
+__device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const Geo& g, const FvMet& m, const FvtScalars& S, int bx, int by, int k) {
+  constexpr int NT = 512;
+  using Tile = FvtTile<MORD, EX, EY, NT>;
+  constexpr int NCU = Tile::NCU;
+  FvtLds& L = LS.t;
+  const int tid = (int)threadIdx.x;
+  const bool xrole = tid < 256;  // wave-uniform
+  const long kb = (long)k * g.sk;
+  const int sj8 = g.sj * 8;
+  const bool w_on = S.damp_w[k] > 1e-5;
+  double* const priv = &LS.priv[0][0];  // [NF][NT]: the damping fluxes of the thread's faces while the sweeps run
+  double c[NF], af[NF], mf[NF];    // Courant numbers, area fluxes, mass fluxes (unit fluxes of w, q_con, pt) of the run's faces
+  {
+    Tile T(L, g, m, bx, by, k, tid);
+    const unsigned roff = xrole ? T.xoff : T.yoff;
+  if (xrole) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      c[f] = LDG(S.crx + kb, roff + (unsigned)(f * 8));
+      af[f] = LDG(S.xfx + kb, roff + (unsigned)(f * 8));
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      c[f] = LDG(S.cry + kb, roff + (unsigned)(f * sj8));
+      af[f] = LDG(S.yfx + kb, roff + (unsigned)(f * sj8));
+    }
+  }
+  }
+
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {  // delp, w, q_con, pt
+    FVT_STAMP(4 * s);
+    const real* const q = S.q[s] + kb;
+    real* const qout = S.qout[s] + kb;
+    const bool is_delp = s == 0, is_w = s == 1;
+    const bool mass_weighted = s >= 2;  // DelnFlux with mass (q_con, pt); delp: plain DelnFlux; w: DelnFluxNoSG -> heat_diss
+    const double damp = S.fac[s][k];
+    // the thread's places, derived again for every scalar: only the operands above live through the whole kernel
+    Tile T(L, g, m, bx, by, k, FVT_LAUNDER(tid));
+    // the thread's run: its five faces in memory (first face, step), whether it takes part in the inner / the outer sweep
+    const unsigned roff = xrole ? T.xoff : T.yoff;
+    const bool run_outer = xrole ? T.x_outer : T.y_outer;
+    const bool lane_lo = xrole ? (T.west && T.xg == 0) : (T.south && T.yg == 0);
+    const bool lane_hi = xrole ? (T.east && T.xg == GXN - 1) : (T.north && T.yg == GYN - 1);
+    const bool last_face = lane_hi;  // the run that stores the face past the end of the tile (ie + 1 / je + 1)
+    // the one-sided forms' spacings (edge tiles), loaded by the runs that hold the edge where a sweep needs them
+    auto spacing = [&]() {
+      FvtSpacing sp;
+      if (EX && xrole) sp = fvt_spacing(m.dxa, (unsigned)((T.jlo + T.xrow) * sj8), 8, g.is, g.ie, lane_lo, lane_hi);
+      if (EY && !xrole) sp = fvt_spacing(m.dya, (unsigned)((T.ilo + T.ycol) * 8), sj8, g.js, g.je, lane_lo, lane_hi);
+      return sp;
+    };
+    T.load_footprint(q, qout);
+    T.stage_damping_metrics();
+    __syncthreads();
+    FVT_STAMP(4 * s + 1);
+    if (is_delp) {  // the mass on the tile and one cell around it, from the footprint while it is there
+      for (int e = tid; e < (TJ + 2) * (TI + 2); e += NT) {
+        const int r = e / (TI + 2), cc = e - r * (TI + 2);
+        LS.mass[r * MP + cc] = L.sq[(r + 2) * P + cc + 2];
+      }
+    }
+    {
+      const auto D = T.damp(mass_weighted ? 1.0 : damp, S.nord[s][k] > 0.0, S.nmax[s]);
+      if (is_w) {
+        T.heat_diss(D, S.dw + kb, S.heat_s + kb, S.diss_est + kb, w_on, S.ke_bg[k] * fabs(S.dt));
+      } else if (run_outer) {
+        if (xrole) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            priv[f * NT + tid] = Tile::face(D, T.sdv[T.xbase + f + 3], D.last[T.xbase + f + 2], D.last[T.xbase + f + 3]);
+        } else {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            priv[f * NT + tid] = Tile::face(D, T.sdu[T.ybase + (f + 3) * P], D.last[T.ybase + (f + 2) * P], D.last[T.ybase + (f + 3) * P]);
+        }
+      }
+      __syncthreads();  // the sweeps overwrite the damping planes
+    }
+    FVT_STAMP(4 * s + 2);
+    // stage I: the inner sweep of the thread's run on q, and the field advected along it (fvtp2d.py:34-77).  The inner fluxes of
+    // the runs that take part in the outer sweep wait in ax / ay, each run using the places of the C faces it opens (the places
+    // its final fluxes go to; the face it shares with the next run is that run's place) and a register for the last one,
+    // instead of ten registers across the barrier.
+    double si_last = 0.0;
+    double* const slot = xrole ? L.u.s.ax + T.xr * PJ + C * T.xg : L.u.s.ay + (C * T.yg) * TI + T.ycol - 3;  // of the run's first face
+    constexpr int XS = 1, YS = TI;  // from face to face in ax / ay
+    if (xrole) {
+      if (T.x_on) {
+        double Q[NF + 5], ar[C];
+#pragma unroll
+        for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[T.xbase + u];
+        if (Tile::RC) {  // halo rows of a corner tile: the three corner columns hold the x-direction copies
+          const bool halo_row = T.south ? T.xrow < 3 : T.xrow >= TJ + 3;
+          const int b = T.south ? T.xrow : T.xrow - (TJ + 3);
+          if (halo_row && T.west && T.xg == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Q[a] = L.sqc[b * 3 + a];
+          }
+          if (halo_row && T.east && T.xg == GXN - 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Q[NF + 2 + a] = L.sqc[b * 3 + a];
+          }
+        }
+        double si[NF];
+        fvt_run<MORD, EX>(Q, c, lane_lo, lane_hi, spacing(), si);
+        FVT_FENCE();
+#pragma unroll
+        for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, roff + (unsigned)(t * 8));
+        if (T.x_outer) {
+#pragma unroll
+          for (int f = 0; f < C; ++f) slot[f * XS] = si[f];
+          si_last = si[C];
+        }
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+          L.u.s.sqj[T.xrow * PJ + C * T.xg + t] = (Q[t + 3] * ar[t] + af[t] * si[t] - af[t + 1] * si[t + 1]) / (ar[t] + af[t] - af[t + 1]);
+      }
+    } else {
+      if (T.y_on) {
+        double Q[NF + 5], ar[C];
+#pragma unroll
+        for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[T.ybase + u * P];
+        double si[NF];
+        fvt_run<MORD, EY>(Q, c, lane_lo, lane_hi, spacing(), si);
+        FVT_FENCE();
+#pragma unroll
+        for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, roff + (unsigned)(t * sj8));
+        if (T.y_outer) {
+#pragma unroll
+          for (int f = 0; f < C; ++f) slot[f * YS] = si[f];
+          si_last = si[C];
+        }
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+          L.u.s.sqi[T.ybase + t * P] = (Q[t + 3] * ar[t] + af[t] * si[t] - af[t + 1] * si[t + 1]) / (ar[t] + af[t] - af[t + 1]);
+      }
+    }
+    __syncthreads();
+    FVT_STAMP(4 * s + 3);
+    // stage II: the outer sweep on the field advected across the run (fvtp2d.py:80-119), the fluxes through the run's faces
+    if (run_outer) {
+      double v[NF];
+      {
+        double Q[NF + 5], out[NF];
+        if (xrole) {
+#pragma unroll
+          for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqi[T.xr * P + C * T.xg + u];
+          fvt_run<MORD, EX>(Q, c, lane_lo, lane_hi, spacing(), out);
+        } else {
+#pragma unroll
+          for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqj[(C * T.yg + u) * PJ + T.ycol - 3];
+          fvt_run<MORD, EY>(Q, c, lane_lo, lane_hi, spacing(), out);
+        }
+        if (xrole) {
+#pragma unroll
+          for (int f = 0; f < C; ++f) v[f] = 0.5 * (out[f] + slot[f * XS]);
+        } else {
+#pragma unroll
+          for (int f = 0; f < C; ++f) v[f] = 0.5 * (out[f] + slot[f * YS]);
+        }
+        v[C] = 0.5 * (out[C] + si_last);
+      }
+      FVT_FENCE();
+      if (is_delp) {
+        double wa[NF];
+        if (xrole) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfx + kb, roff + (unsigned)(f * 8));
+        } else {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfy + kb, roff + (unsigned)(f * sj8));
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          mf[f] = v[f] * af[f] + priv[f * NT + tid];
+          v[f] = mf[f];
+          wa[f] = wa[f] + mf[f];  // flux_capacitor (d_sw.py:33-60)
+        }
+        if (xrole) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            if (f < C || last_face) STG(S.mfx + kb, roff + (unsigned)(f * 8)) = wa[f];
+        } else {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            if (f < C || last_face) STG(S.mfy + kb, roff + (unsigned)(f * sj8)) = wa[f];
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          v[f] = v[f] * mf[f];
+          if (mass_weighted) {  // the cells on either side of the face
+            const double* ms = xrole ? LS.mass + (T.xr + 1) * MP + C * T.xg + f : LS.mass + (C * T.yg + f) * MP + T.ycol - 2;
+            const double m1 = xrole ? ms[1] : ms[MP];
+            v[f] = v[f] + 0.5 * damp * (ms[0] + m1) * priv[f * NT + tid];
+          }
+        }
+      }
+      // a face's flux is put down by the run that opens it; the last face of the row / column by its last run
+      if (xrole) {
+#pragma unroll
+        for (int f = 0; f < C; ++f) slot[f * XS] = v[f];
+        if (T.xg == GXN - 1) slot[C * XS] = v[C];
+      } else {
+#pragma unroll
+        for (int f = 0; f < C; ++f) slot[f * YS] = v[f];
+        if (T.yg == GYN - 1) slot[C * YS] = v[C];
+      }
+    }
+    __syncthreads();
+    {
+      int jj[NCU], ii[NCU];
+      unsigned c2[NCU];
+      double ra[NCU], dwv[NCU];
+      T.cell_places(jj, ii, c2);
+#pragma unroll
+      for (int t = 0; t < NCU; ++t) ra[t] = LDG(m.rarea, c2[t]);
+      if (is_w && w_on) {
+#pragma unroll
+        for (int t = 0; t < NCU; ++t) dwv[t] = LDG(S.dw + kb, c2[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < NCU; ++t) {
+        const double am = LS.mass[(jj[t] + 1) * MP + ii[t] + 1];
+        double val;
+        if (is_delp) {
+          // the new delp (apply_pt_delp_fluxes, d_sw.py:148-201)
+          val = am + T.flux_increment(jj[t], ii[t], ra[t]);
+          LS.newmass[jj[t] * TI + ii[t]] = val;  // (read back by this same thread)
+        } else {
+          val = T.flux_form(jj[t], ii[t], am, ra[t]) / LS.newmass[jj[t] * TI + ii[t]];
           if (is_w && w_on) val = val + dwv[t];  // adjust_w_and_qcon (d_sw.py:331-350)
         }
         STG(qout, c2[t]) = val;

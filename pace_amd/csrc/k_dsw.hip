@@ -59,15 +59,28 @@ k_finish_scalars(Geo g, Met m, real* __restrict__ pt, real* __restrict__ delp, r
 // ------------------------------------------------------------------------------------------------
 // (wind_flux6 -- the 1-D advection of a wind component, xtp_u.py:9-91 -- lives in common.h: csrc/k_stencils.hip launches it as a
 // stencil of its own)
+// compute_vorticity (d_sw.py:301-328) at cell (i, j): the relative vorticity; the absolute one (+ fC_agrid, rel_vorticity_to_abs
+// :389-402) is formed where it is transported (launch_d_sw)
+__device__ __forceinline__ double rel_vorticity(const Geo& g, const Met& m, const real* __restrict__ u, const real* __restrict__ v,
+                                                long c, long c2) {
+  const double ra = m.rarea[c2], dx = m.dx[c2], dy = m.dy[c2];
+  return (u[c] - u[c + g.sj] * m.dx[c2 + g.sj] / dx) * (ra * dx) + (v[c + 1] * m.dy[c2 + 1] / dy - v[c]) * (ra * dy);
+}
+
+// ... with the relative vorticity of the same winds (round 5: it was a kernel of its own that read u and v once more): regions
+// [0, nke) are the B-grid points of the kinetic energy (each also a cell of the vorticity), the regions after them the rest of
+// the vorticity's domain (the halo cells around the B-grid domain), where only the vorticity is formed.  vort == nullptr: none.
 template <int MORD>
 __global__ void __launch_bounds__(256)
 k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
                  const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ut,
-                 const real* __restrict__ vt, real* __restrict__ ke, double dt, Regions R) {
+                 const real* __restrict__ vt, real* __restrict__ ke, double dt, Regions R, real* __restrict__ vort, int nke) {
   REGION_POINT_XCD(R);  // (six rows of v per point: the j-neighbouring patches share an L2 -- 255 -> 156 MB, round 3's x17)
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;
+  if (vort != nullptr) vort[c] = rel_vorticity(g, m, u, v, c, c2);  // (every point of every region is a cell of its domain)
+  if (reg__ >= nke) return;
   if (interior) {
     // is+3 <= i <= ie-2 and the same in j: no edge wind, no one-sided PPM interface, no zeroed reconstruction
     const double ub_cov = 0.5 * (uc[c - sj] + uc[c]);
@@ -141,9 +154,7 @@ k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
-  const double ra = m.rarea[c2], dx = m.dx[c2], dy = m.dy[c2];
-  const double val = (u[c] - u[c + g.sj] * m.dx[c2 + g.sj] / dx) * (ra * dx) + (v[c + 1] * m.dy[c2 + 1] / dy - v[c]) * (ra * dy);
-  vort[c] = val;  // the absolute vorticity (+ fC_agrid) is formed where it is transported (launch_d_sw)
+  vort[c] = rel_vorticity(g, m, u, v, c, c2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,7 +621,7 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
                                               const double* __restrict__ swk, const real* __restrict__ din,
                                               real* __restrict__ divg_d, real* __restrict__ vort_b, real* __restrict__ ke,
                                               real* __restrict__ uc_out, real* __restrict__ vc_out, double d2, double dddmp,
-                                              double dd8, double absdt, int tid, int i0, int j0, long kb) {
+                                              double dd8, double absdt, int tid, int i0, int j0, long kb, bool full) {
   constexpr int NB = T1 - T0;
   double dvm[NB], dv0[NB], dum[NB], du0[NB], ra[NB], dpc[NB], ke0[NB];
   bool on[NB];
@@ -645,8 +656,10 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
     double dfin = ucm - uc0 + vcm - vc0;
     dfin = dfin * ra[t];
     const long c = cc[t];
-    uc_out[c] = uc0;  // (own points here have j <= je and i <= ie)
-    vc_out[c] = vc0;
+    if (full) {
+      uc_out[c] = uc0;  // (own points here have j <= je and i <= ie)
+      vc_out[c] = vc0;
+    }
     double vb;
     if (dddmp < 1e-5) {
       vb = 0.0;
@@ -658,14 +671,16 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
     const double vort = damp * dpc[t] + dd8 * dfin;
     vort_b[c] = vort;
     ke[c] = ke0[t] + vort;
-    divg_d[c] = dfin;
+    if (full) divg_d[c] = dfin;
   }
 }
 
 __global__ void __launch_bounds__(256)
 k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
                 real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
-                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx) {
+                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int full_) {
+  // full_ == 0 (PACE_DSW_SKIP_DEAD_OUTPUTS): divg_d, uc_out, vc_out are not written -- din may then be divg_d itself
+  const bool full = full_ != 0;
   __shared__ double sbuf[2][DD_W * DD_H];
   const int tid = threadIdx.x;
   const int bx = (int)blockIdx.x % ntx, by = (int)blockIdx.x / ntx;
@@ -740,9 +755,9 @@ k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restric
   __syncthreads();
   const double d2 = d2_bg[kk];
   constexpr int P1 = (DD_NP + 1) / 2;
-  dd_tail_batch<0, P1>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb);
+  dd_tail_batch<0, P1>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb, full);
   if constexpr (DD_NP > P1)
-    dd_tail_batch<P1, DD_NP>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb);
+    dd_tail_batch<P1, DD_NP>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb, full);
   // The remaining own points: the frame of the tile domain, two points deep (corner regions, edge forms of the pass and of
   // a2b_ord4).  They are enumerated densely -- first the tile's frame columns over all of its rows, then its frame rows over
   // the other columns -- so that a wave that runs the long general code is full (left in place, two lanes of EVERY wave of
@@ -777,8 +792,8 @@ k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restric
     const double dpc = din[c];  // the divergence before the passes (= delpc)
     // The reference uses the caller's uc / vc as the work fields of the passes and its Translate tests compare what is left
     // in them after d_sw on the staggered compute windows (translate_d_sw.py:36-65): the values of the LAST pass.
-    if (j <= g.je) uc_out[c] = uc_here;
-    if (i <= g.ie) vc_out[c] = vc_here;
+    if (full && j <= g.je) uc_out[c] = uc_here;
+    if (full && i <= g.ie) vc_out[c] = vc_here;
     double vb;
     if (dddmp < 1e-5) {
       vb = 0.0;
@@ -791,7 +806,7 @@ k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restric
     const double vort = damp * dpc + dd8 * dfin;
     vort_b[c] = vort;
     ke[c] = ke[c] + vort;
-    divg_d[c] = dfin;  // the caller's divgd ends as the iterated divergence (redo_divg_d; compared by TranslateD_SW)
+    if (full) divg_d[c] = dfin;  // the caller's divgd ends as the iterated divergence (redo_divg_d; compared by TranslateD_SW)
   }
 }
 
@@ -1050,15 +1065,22 @@ int launch_a2b_ord4_tiled(const Geo& g, const Met& m, const real* qin, real* qou
 int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const real* v, const real* va, real* vort_b,
                               const real* ua, real* divg_d, real* vc, real* uc, real* delpc, real* ke,
                               const real* rel_vort_agrid, double dt, const real* d2_bg_dev, int kstart, int nonzero_nord,
-                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st) {
+                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead) {
   const int nk = g.nk;
   const int nhigh = nk - kstart;
   const bool fused = nhigh > 0 && !legacy_divergence_damping();
-  if (fused) {
+  skip_dead = skip_dead && fused;
+  if (fused && !skip_dead) {
     // sponge levels + delpc = divg_d below them (copy_computeplus :578; whole planes, so that the fused kernel can take its
     // footprint from delpc), one launch
     hipLaunchKernelGGL(k_divdamp_low_and_copy, plane_grid(g, nk), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
                        d2_bg_dev, dddmp, dt, divg_d, kstart);
+  } else if (fused) {
+    // the work fields are dead after d_sw (PACE_DSW_SKIP_DEAD_OUTPUTS): no copy -- the fused kernel reads the divergence where it
+    // is and writes neither it nor uc / vc -- and only the sponge levels here
+    if (kstart > 0)
+      hipLaunchKernelGGL(k_divdamp_low_and_copy, plane_grid(g, kstart), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
+                         d2_bg_dev, dddmp, dt, divg_d, kstart);
   } else if (kstart > 0) {
     hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
                        d2_bg_dev, dddmp, dt);
@@ -1067,7 +1089,8 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
     const double dd8 = pow(m.da_min_c * d4_bg, (double)(nonzero_nord + 1));
     const int ntx = (g.n + 1 + DD_TI - 1) / DD_TI, nty = (g.n + 1 + DD_TJ - 1) / DD_TJ;
     hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)nhigh), dim3(256), 0, st, g, m, rel_vort_agrid,
-                       delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart, nonzero_nord, ntx);
+                       skip_dead ? divg_d : delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart, nonzero_nord, ntx,
+                       skip_dead ? 0 : 1);
   } else if (nhigh > 0) {
     const real* src = divg_d;
     real* bufs[2] = {da, db};
@@ -1229,21 +1252,26 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   if (phases & (4 | 64)) {
   // winds A1: kinetic energy and relative vorticity (need only the flux preparation)
-  const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
+  Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
+  const int nke = rke.n;
+  // the rest of the vorticity's domain [0, ni-2] x [0, nj-2]: the halo cells around the B-grid points is .. ie+1
+  add_region(rke, 0, g.is - 1, 0, g.nj - 2);
+  add_region(rke, g.ie + 2, g.ni - 2, 0, g.nj - 2);
+  add_region(rke, g.is, g.ie + 1, 0, g.js - 1);
+  add_region(rke, g.is, g.ie + 1, g.je + 2, g.nj - 2);
   if (cfg->hord_mt == 5) {
-    hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke);
+    hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nke);
   } else if (cfg->hord_mt == 6) {
-    hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke);
+    hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nke);
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
   }
   if (phases & (4 | 128)) {
   // winds A2: divergence damping
   if (nonzero_nord < 0 || nonzero_nord > 3) return PACE_ERR_UNSUPPORTED;  // (as pace_divergence_damping: halo 3)
   if ((rc = launch_divergence_damping(g, m, u, v, va, W.vort_b, ua, divgd, vc, uc, delpc, W.ke, W.wk, dt, d_d2, kstart, nonzero_nord,
-                                      cfg->dddmp, cfg->d4_bg, W.da, W.db, st)))
+                                      cfg->dddmp, cfg->d4_bg, W.da, W.db, st, (cfg->flags & PACE_DSW_SKIP_DEAD_OUTPUTS) != 0)))
     return rc;
   // vorticity transport
   // vorticity: transport of the absolute vorticity (wk + fC_agrid) -> W.fy2, W.fyv (own flux buffers: the mass fluxes

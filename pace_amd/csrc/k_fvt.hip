@@ -24,19 +24,27 @@ __global__ void __launch_bounds__(256, FVT_WAVES) k_fvt(Geo g, FvMet m, const re
   else fvt_tile<MORD, DMODE, EPI, false, false>(L, g, m, q, crx, cry, xfx, yfx, fx, fy, xunit, yunit, dp, wg.bx, wg.by, wg.bz);
 }
 
-#ifndef FVT_SCALARS_WAVES
-#define FVT_SCALARS_WAVES 2  // workgroups per CU the register budget of the scalar-phase kernel is set for (fvt_core.h)
+#ifndef FVT_SCALARS_NT
+#define FVT_SCALARS_NT 512  // threads per workgroup of the scalar-phase kernel: 512 = x-runs and y-runs in different waves
 #endif
+// two workgroups per CU either way (LDS: 66 KB each); 512 threads -> four waves per SIMD at <= 128 VGPRs, 256 -> two at <= 256
 template <int MORD>
-__global__ void __launch_bounds__(256, FVT_SCALARS_WAVES) k_fvt_scalars(Geo g, FvMet m, FvtScalars S) {
+__global__ void __launch_bounds__(FVT_SCALARS_NT, 2) k_fvt_scalars(Geo g, FvMet m, FvtScalars S) {
   __shared__ FvtLdsScalars L;
   const FvTile wg = fv_tile_of_workgroup();
   const int gx = g.n / TI, gy = g.n / TJ;
   const bool ex = wg.bx == 0 || wg.bx == gx - 1, ey = wg.by == 0 || wg.by == gy - 1;
+#if FVT_SCALARS_NT == 512
+  if (ex && ey) fvt_scalars_tile_split<MORD, true, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else if (ex) fvt_scalars_tile_split<MORD, true, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else if (ey) fvt_scalars_tile_split<MORD, false, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else fvt_scalars_tile_split<MORD, false, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
+#else
   if (ex && ey) fvt_scalars_tile<MORD, true, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
   else if (ex) fvt_scalars_tile<MORD, true, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
   else if (ey) fvt_scalars_tile<MORD, false, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
   else fvt_scalars_tile<MORD, false, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
+#endif
 }
 
 template <int MORD>
@@ -117,8 +125,8 @@ int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const 
   S.damp_w = kc + 4 * K, S.ke_bg = kc + 8 * K;
   S.dt = dt;
   const dim3 grid(g.n / TI, g.n / TJ, g.nk);
-  if (hord == 5) hipLaunchKernelGGL(k_fvt_scalars<5>, grid, dim3(256), 0, st, g, fv_met(m), S);
-  else hipLaunchKernelGGL(k_fvt_scalars<6>, grid, dim3(256), 0, st, g, fv_met(m), S);
+  if (hord == 5) hipLaunchKernelGGL(k_fvt_scalars<5>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);
+  else hipLaunchKernelGGL(k_fvt_scalars<6>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 #else

@@ -74,7 +74,14 @@ class DGridShallowWaterLagrangianDynamics(Operator):
     the reference's 177 stencil launches."""
 
     def __init__(self, stencil_factory, quantity_factory, grid_data, damping_coefficients, column_namelist, nested: bool,
-                 stretched_grid: bool, config: DGridShallowWaterLagrangianDynamicsConfig):
+                 stretched_grid: bool, config: DGridShallowWaterLagrangianDynamicsConfig, *, swap_scalar_storage: bool = False):
+        """The keyword-only argument is an extension (default: the reference's contract, d_sw.py:726-1237).
+
+        swap_scalar_storage: delp, pt, w, q_con are written to spare buffers this object owns and swapped into the caller's
+        Quantities (``Quantity.swap_storage``): the Quantity objects look updated in place, but their STORAGE changes identity at
+        every call -- tensors taken from ``.data`` before the call, cached device pointers and captured HIP graphs go stale
+        (``Quantity.generation`` counts the swaps; holders of cached pointers check it).  Off: the library writes to its workspace
+        and copies back (+ one copy kernel).  AcousticDynamics, which owns its state between halo updates, turns it on."""
         super().__init__(stencil_factory, quantity_factory, grid_data)
         assert config.grid_type < 3, "ubke and vbke only implemented for grid_type < 3"
         assert not config.inline_q, "inline_q not yet implemented"
@@ -98,15 +105,16 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         self._col = _lib.Column()
         for k in _lib.COLUMN_FIELDS:
             setattr(self._col, k, self._col_host[k].ctypes.data_as(C.POINTER(C.c_double)))
-        self._cfg = _lib.DswConfig(config.hord_dp, config.hord_tm, config.hord_vt, config.hord_mt, config.nord,
-                                   int(config.do_skeb), config.dddmp, config.d4_bg, config.d_con)
+        self._cfg = _lib.DswConfig(C.sizeof(_lib.DswConfig), 0, config.hord_dp,
+                                   config.hord_tm, config.hord_vt, config.hord_mt, config.nord, int(config.do_skeb), config.dddmp,
+                                   config.d4_bg, config.d_con)
         nbytes = self.lib.cdll.pace_d_sw_workspace_bytes(C.byref(self._geom))
         self._workspace = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=quantity_factory.device)
         self.call("pace_d_sw_prepare", C.byref(self._col), self._workspace.data_ptr(), self.stream())
         # The four scalars d_sw transports are written to buffers of their own where the library supports it (the fused scalar
         # kernel of the production tilings, include/pace_hip.h pace_dsw_config_t) and swapped into the caller's Quantities.
-        self._pingpong = bool(self.lib.cdll.pace_d_sw_pingpong_supported(C.byref(self._geom), C.byref(self._cfg))) and not os.environ.get(
-            "PACE_DSW_INPLACE")
+        self._pingpong = bool(swap_scalar_storage) and not os.environ.get("PACE_DSW_INPLACE") and bool(
+            self.lib.cdll.pace_d_sw_pingpong_supported(C.byref(self._geom), C.byref(self._cfg)))
         self._quantity_factory = quantity_factory
         self._spares = None
 
@@ -152,14 +160,20 @@ class DGridShallowWaterLagrangianDynamics(Operator):
     _prep_started = False
 
     def __call__(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
-                 heat_source, diss_est, dt, overlap_winds: bool = False):
-        """overlap_winds=True (an extension; the default is the reference's behaviour): the wind update of d_sw, which
+                 heat_source, diss_est, dt, overlap_winds: bool = False, skip_dead_outputs: bool = False):
+        """skip_dead_outputs=True (an extension): delpc, divgd, uc, vc are left unspecified (include/pace_hip.h
+        PACE_DSW_SKIP_DEAD_OUTPUTS): they are work fields of the divergence damping that c_sw recomputes before anything reads
+        them again (dyn_core.py:720-852) -- AcousticDynamics asks for it in every substep but the last, whose leftovers in uc / vc
+        the reference's TranslateDynCore compares (translate_dyncore.py:84-85).
+
+        overlap_winds=True (an extension; the default is the reference's behaviour): the wind update of d_sw, which
         nothing before nh_p_grad reads, is launched on this object's side stream: after return it runs concurrently with the caller's next
         launches (halo exchange, updatedzd, riem_solver3).  The caller MUST call
         ``join()`` before touching u, v, uc, vc, heat_source, diss_est, delpc or divgd again."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                   heat_source, diss_est)
         spares = self._outputs_for(delp, pt, w, q_con)
+        self._cfg.flags = _lib.DSW_SKIP_DEAD_OUTPUTS if skip_dead_outputs else 0
         args = self._args(fields, dt)
         # flux preparation: everything (1), or only its frame (32) if start_flux_preparation did the interior box (16)
         prep = 32 if self._prep_started else 1

@@ -147,7 +147,8 @@ class AcousticDynamics(Operator):
                                                                        p_fac=config.p_fac)
         self.dgrid_shallow_water_lagrangian_dynamics = d_sw.DGridShallowWaterLagrangianDynamics(
             stencil_factory, quantity_factory=quantity_factory, grid_data=grid_data, damping_coefficients=damping_coefficients,
-            column_namelist=column_namelist, nested=nested, stretched_grid=stretched_grid, config=config.d_grid_shallow_water)
+            column_namelist=column_namelist, nested=nested, stretched_grid=stretched_grid, config=config.d_grid_shallow_water,
+            swap_scalar_storage=True)  # (this class owns the state between its halo updates: no stale aliases; d_sw.py docstring)
         self.cgrid_shallow_water_lagrangian_dynamics = CGridShallowWaterDynamics(
             stencil_factory, quantity_factory=quantity_factory, grid_data=grid_data, nested=nested, grid_type=config.grid_type,
             nord=config.nord)
@@ -283,7 +284,10 @@ class AcousticDynamics(Operator):
                 halo.divgd.wait()
             halo.uc__vc.wait()
             self._checkpoint_dsw_in(state)
-            self.dgrid_shallow_water_lagrangian_dynamics(*dsw_args, overlap_winds=True)
+            # delpc, divgd, uc, vc are work fields c_sw recomputes in the next substep: d_sw brings them to the reference's final
+            # state only where something can see it -- after the last substep (TranslateDynCore compares uc / vc) or a checkpointer
+            self.dgrid_shallow_water_lagrangian_dynamics(*dsw_args, overlap_winds=True,
+                                                         skip_dead_outputs=(it != n_split - 1 and not self.call_checkpointer))
             self._checkpoint_dsw_out(state)
             # dyn_core.py:854 updates the halos of delp / pt / q_con right here.  Nothing before pk3_halo reads them (updatedzd works
             # on zh and the Courant numbers, the column solver on the compute domain's columns), so without checkpoints the

@@ -262,12 +262,16 @@ class HaloUpdater:
         cube.lib.call("pace_halo_pack", C.byref(self._geom), pack, npack, cube.stream())
         req = cube.comm.exchange([(b, p) for p, b in self._msgs.sendbuf.items()], [(b, p) for p, b in self._msgs.recvbuf.items()],
                                  tag=self._tag)
-        self._inflight = (req, unpack, nunpack)
+        self._inflight = (req, unpack, nunpack, [(q, getattr(q, "generation", 0)) for q in qs])
 
     def wait(self):
         if self._inflight is None:
             raise RuntimeError('Halo update "wait" call before "start"')
-        req, unpack, nunpack = self._inflight
+        req, unpack, nunpack, started_on = self._inflight
+        for q, gen in started_on:  # the unpack table holds the addresses the fields had at start()
+            if getattr(q, "generation", 0) != gen:
+                raise RuntimeError("the storage of a Quantity was swapped (Quantity.swap_storage) between start() and wait() of its "
+                                   "halo update: the received halo would be written to the buffer it no longer owns")
         req.wait()
         self._cube.lib.call("pace_halo_unpack", C.byref(self._geom), unpack, nunpack, self._cube.stream())
         self._inflight = None

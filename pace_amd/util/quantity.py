@@ -115,6 +115,17 @@ class Quantity:
             raise ValueError("swap_storage needs two quantities of the same layout")
         self._data, other._data = other._data, self._data
         self._base, other._base = other._base, self._base
+        self._generation = self.generation + 1
+        other._generation = other.generation + 1
+
+    _generation = 0
+
+    @property
+    def generation(self) -> int:
+        """How often ``swap_storage`` has replaced this Quantity's storage.  Whoever keeps something derived from the storage
+        across calls (a device pointer, a tensor taken from ``data``, a captured graph) records the generation with it and
+        checks it before use: ``HaloUpdater.wait`` does, for the fields it was started on."""
+        return self._generation
 
     def transpose(self, target_dims: Sequence[str]) -> "Quantity":
         """quantity.py:518-560: the same storage seen with its dimensions in another order (a view; what the reference's

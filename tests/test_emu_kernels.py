@@ -136,17 +136,17 @@ def test_legacy_thread_per_column_solvers_emulated(precision):
         assert e < tol, (k, e, errs)
 
 
-def _dsw_child(gpu=False):
-    """(child process: PACE_DSW_INPLACE is read when the operator is built) d_sw on a C24 synthetic tile with the 8 x 8 tiling of
-    the emulation build `emu-canon` -- the tiling class the scalar-phase kernel takes -- (gpu: C96 x 12 with the product library),
-    all outputs pickled, plus whether the operator wrote to separate outputs."""
-    import pickle
-    import sys
-
+def dsw_contract_variants(gpu=False):
+    """d_sw called TWICE on a synthetic tile -- the halos of delp / pt / w / q_con rewritten between the calls, as a halo update
+    would -- by four operators: the reference's in-place contract; `swap_scalar_storage` (the scalar-phase kernel writes to
+    spare buffers that are swapped into the caller's Quantities: the second call's output buffers are the first call's inputs,
+    stale halos and all); the same with the wind half on the side stream; and `skip_dead_outputs`.  CPU: C24 with the 8 x 8
+    tiling of the emulation build `emu-canon` -- the tiling class the scalar-phase kernel takes; gpu: C96 x 12, product library.
+    Returns {variant: ({name: whole storage after the second call}, operator)}."""
     from helpers import build_emu_canon
     from pace_amd import _lib, synthetic
     from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
-    from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, column_namelist_arrays, get_column_namelist
+    from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, get_column_namelist
 
     n, nz = (96, 12) if gpu else (24, 5)
     lib = _lib.load() if gpu else _lib.Library(build_emu_canon())
@@ -154,36 +154,97 @@ def _dsw_child(gpu=False):
     s = synthetic.acoustic_state(m, n, nz)
     env = Env(lib, "cuda" if gpu else "cpu", m, n, nz)
     cfg = DGridShallowWaterLagrangianDynamicsConfig()
-    col = column_namelist_arrays(cfg, nz)
-    out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, float(s["dt"]))
-    op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, get_column_namelist(cfg, env.qf), False,
-                                            False, cfg)
-    pickle.dump(({k: np.ascontiguousarray(v) for k, v in out.items()}, bool(op._pingpong)), sys.stdout.buffer)
+    rng = np.random.default_rng(5)
+    halo_noise = {k: 1.0 + 1e-3 * rng.uniform(-1, 1, s[k].shape) for k in ("delp", "pt", "w", "q_con")}
+    out = {}
+    for name, ctor, call in (("in_place", {}, {}), ("swapped", dict(swap_scalar_storage=True), {}),
+                             ("swapped_overlapped", dict(swap_scalar_storage=True), dict(overlap_winds=True)),
+                             ("skip_dead", dict(swap_scalar_storage=True), dict(skip_dead_outputs=True))):
+        op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, get_column_namelist(cfg, env.qf),
+                                                False, False, cfg, **ctor)
+        f = {k: env.q3(s[k]) for k in DSW_ARGS}
+        for rep in range(2):
+            op(*[f[k] for k in DSW_ARGS], float(s["dt"]), **call)
+            op.join()
+            if rep == 0:
+                for k, noise in halo_noise.items():  # new halo values (the halo proper: 3 cells around the compute domain, the
+                    a = f[k].numpy()                  # model's levels); compute domain untouched
+                    b = a.copy()
+                    b[:n + 6, :n + 6, :nz] = (a * noise)[:n + 6, :n + 6, :nz]
+                    b[3:3 + n, 3:3 + n] = a[3:3 + n, 3:3 + n]
+                    f[k].set(b)
+                for k in ("delpc", "divgd", "uc", "vc"):  # (c_sw recomputes the work fields before every d_sw)
+                    f[k].set(s[k])
+        if gpu:
+            import torch
+
+            torch.cuda.synchronize()
+        out[name] = ({k: f[k].numpy() for k in DSW_ARGS}, op)
+    return out
+
+
+def check_dsw_contract_variants(res):
+    ref, op_ref = res["in_place"]
+    assert not op_ref._pingpong
+    for name in ("swapped", "swapped_overlapped"):
+        got, op = res[name]
+        assert op._pingpong, "the library must have taken the separate outputs here"
+        for k in ref:  # every output of d_sw bit for bit, whole storage (halos included)
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
+    got, _ = res["skip_dead"]
+    for k in ref:
+        if k not in ("delpc", "divgd", "uc", "vc"):  # (unspecified: include/pace_hip.h PACE_DSW_SKIP_DEAD_OUTPUTS)
+            assert np.array_equal(ref[k], got[k], equal_nan=True), ("skip_dead", k)
 
 
 def test_d_sw_separate_outputs_equal_in_place_emulated():
-    """The scalar phase of d_sw writes delp, pt, w, q_con to buffers of their own that the operator swaps in (the default where the
-    library supports it: include/pace_hip.h pace_dsw_config_t) against the library's in-place contract (PACE_DSW_INPLACE=1:
-    workspace outputs + copy back): every output of d_sw bit for bit, whole storage (halos included)."""
-    import pickle
-    import subprocess
-    import sys
+    check_dsw_contract_variants(dsw_contract_variants())
 
-    from helpers import ROOT
 
-    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); "
-            f"import test_emu_kernels as t; t._dsw_child()")
-    outs = []
-    for inplace in ("", "1"):
-        env = {k: v for k, v in os.environ.items() if k != "PACE_DSW_INPLACE"}
-        if inplace:
-            env["PACE_DSW_INPLACE"] = "1"
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=900, env=env)
-        assert p.returncode == 0, p.stderr[-3000:].decode()
-        outs.append(pickle.loads(p.stdout))
-    assert outs[0][1] and not outs[1][1], "the first run must have taken the separate outputs, the second not"
-    for k in outs[0][0]:
-        assert np.array_equal(outs[0][0][k], outs[1][0][k], equal_nan=True), k
+def test_swapped_storage_is_detectable():
+    """What holds something derived from a Quantity's storage across a d_sw call with `swap_scalar_storage` can tell that it went
+    stale: `Quantity.generation` counts the swaps, a tensor taken from `.data` before the call no longer aliases the Quantity,
+    and a halo update whose fields were swapped between start() and wait() refuses to unpack."""
+    import torch
+
+    from helpers import build_emu_canon
+    from pace_amd import _lib, synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, get_column_namelist
+
+    n, nz = 24, 3
+    lib = _lib.Library(build_emu_canon())
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, "cpu", m, n, nz)
+    cfg = DGridShallowWaterLagrangianDynamicsConfig()
+    col = get_column_namelist(cfg, env.qf)
+    f = {k: env.q3(s[k]) for k in DSW_ARGS}
+    # the reference's contract (the default): storage identity never changes
+    op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, False, False, cfg)
+    alias, ptr, view = f["delp"].data, f["delp"].ptr, f["delp"].transpose(["z", "y", "x"][::-1])
+    before = alias.clone()
+    op(*[f[k] for k in DSW_ARGS], float(s["dt"]))
+    assert f["delp"].generation == 0 and f["delp"].ptr == ptr and f["delp"].data.data_ptr() == alias.data_ptr()
+    assert not torch.equal(alias, before) and torch.equal(view.data, f["delp"].data)  # updated in place, aliases follow
+    # the extension: the storage is replaced, and that is visible
+    op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, False, False, cfg,
+                                            swap_scalar_storage=True)
+    alias, ptr = f["pt"].data, f["pt"].ptr
+    before = alias.clone()
+    op(*[f[k] for k in DSW_ARGS], float(s["dt"]))
+    assert f["pt"].generation == 1 and f["pt"].ptr != ptr
+    assert torch.equal(alias, before), "the old buffer keeps the old values: an alias taken before the call is stale"
+    # a halo update started on a field that is then swapped
+    from pace_amd.util import CubedSphereCommunicator, CubedSpherePartitioner, NullComm
+
+    cube = CubedSphereCommunicator(NullComm(rank=0, total_ranks=6), CubedSpherePartitioner(), device="cpu", lib=lib)
+    a, b = env.qf.zeros(["x", "y", "z"], ""), env.qf.zeros(["x", "y", "z"], "")
+    up = cube.get_scalar_halo_updater([env.qf.get_quantity_halo_spec(["x", "y", "z"])])
+    up.start([a])
+    a.swap_storage(b)
+    with pytest.raises(RuntimeError, match="swapped"):
+        up.wait()
 
 
 def test_fvtp2d_kernel_emulated(emu_lib):

@@ -688,25 +688,9 @@ def test_dynamical_core_step_from_generated_inputs_matches_reference_run(lib, tm
 
 
 def test_d_sw_separate_outputs_equal_in_place(lib):
-    """The GPU twin of test_d_sw_separate_outputs_equal_in_place_emulated at C96 x 12: the scalar-phase kernel writing to separate
-    outputs that the operator swaps in, against the library's in-place contract (workspace + copy back): every output of d_sw bit
-    for bit over the whole storage (halos included)."""
-    import os
-    import pickle
-    import subprocess
-    import sys
+    """The GPU twin of test_d_sw_separate_outputs_equal_in_place_emulated at C96 x 12: d_sw called twice with the halos rewritten
+    in between, the reference's in-place contract against `swap_scalar_storage` (one stream and with the wind half on the side
+    stream) -- every output bit for bit over the whole storage -- and against `skip_dead_outputs` on every live output."""
+    from test_emu_kernels import check_dsw_contract_variants, dsw_contract_variants
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (f"import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); "
-            f"import test_emu_kernels as t; t._dsw_child(True)")
-    outs = []
-    for inplace in ("", "1"):
-        env = {k: v for k, v in os.environ.items() if k != "PACE_DSW_INPLACE"}
-        if inplace:
-            env["PACE_DSW_INPLACE"] = "1"
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=900, env=env)
-        assert p.returncode == 0, p.stderr[-3000:].decode()
-        outs.append(pickle.loads(p.stdout))
-    assert outs[0][1] and not outs[1][1]
-    for k in outs[0][0]:
-        assert np.array_equal(outs[0][0][k], outs[1][0][k], equal_nan=True), k
+    check_dsw_contract_variants(dsw_contract_variants(gpu=True))

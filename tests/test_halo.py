@@ -454,3 +454,26 @@ def test_bench_full_loop_diagnosis_two_ranks_over_gloo(tmp_path):
         assert per[k]["calls_per_substep"] == 1.0, (k, per[k])
     for k in ("q_con__cappa", "delp__pt", "gz", "heat_source"):
         assert per[k]["calls_per_substep"] == 0.25, (k, per[k])
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher around it (the shape of the command the driver runs at N = 1): the flag
+    starts the two ranks as a child `torch.distributed.run`, relays the one JSON line and the exit code -- it does not silently
+    run one rank.  And a launcher whose rank count differs from --gpus is refused with a non-zero exit code."""
+    import json
+
+    build_emu()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tile-size", "12", "--nz", "8",
+           "--emulate", "--watchdog", "240"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["comm"]["world_size"] == 2
+    # WORLD_SIZE from a launcher that disagrees with --gpus: refused before anything runs
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--emulate", "--tile-size", "12", "--nz", "8"],
+                       capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=str(tmp_path))
+    assert p.returncode != 0 and "--gpus 4" in p.stderr

@@ -29,4 +29,14 @@ template __global__ void k_var_scalars<6, false, false>(Geo, FvMet, FvtScalars);
 template __global__ void k_var_scalars<6, true, false>(Geo, FvMet, FvtScalars);
 template __global__ void k_var_scalars<6, false, true>(Geo, FvMet, FvtScalars);
 template __global__ void k_var_scalars<6, true, true>(Geo, FvMet, FvtScalars);
+// the 512-thread form (x-runs and y-runs in different waves)
+template <int MORD, bool EX, bool EY>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_var_scalars_split(Geo g, FvMet m, FvtScalars S) {
+  __shared__ FvtLdsScalars L;
+  fvt_scalars_tile_split<MORD, EX, EY>(L, g, m, S, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template __global__ void k_var_scalars_split<6, false, false>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars_split<6, true, false>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars_split<6, false, true>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars_split<6, true, true>(Geo, FvMet, FvtScalars);
 #endif
