@@ -100,6 +100,12 @@ typedef struct {
    * buffers (pace_amd: Quantity.swap_storage).  Without them the library writes to its workspace and copies back.
    * Only where pace_d_sw_pingpong_supported() says so; otherwise PACE_ERR_UNSUPPORTED. */
   pace_real_t *delp_out, *pt_out, *w_out, *q_con_out;
+  /* Optional separate outputs of the D-grid winds, both or none, only together with the four above and only in calls that run
+   * the whole of d_sw (pace_d_sw, pace_d_sw_overlapped, pace_d_sw_phases with 2, 4 and 8 set): u and v are then left as they were
+   * and the updated winds (d_sw.py:406-477,582-608) are written to u_out / v_out, halo included -- the caller swaps the buffers.
+   * The winds are updated by the kernel that transports the scalars, tile by tile, and a tile reads the old wind on the face its
+   * neighbour writes.  Without them that kernel writes to the workspace and the winds are copied back. */
+  pace_real_t *u_out, *v_out;
 } pace_dsw_config_t;
 
 /* ---- FiniteVolumeFluxPrep.__call__ (fv3core/pace/fv3core/stencils/fxadv.py:565-661) ---- */
@@ -172,6 +178,11 @@ int pace_a2b_ord4(const pace_geom_t* geom, const pace_metrics_t* met, pace_real_
 int64_t pace_d_sw_workspace_bytes(const pace_geom_t* geom);
 /* 1 if pace_d_sw* accept separate outputs (pace_dsw_config_t::delp_out ...) for this geometry and these orders, else 0. */
 int pace_d_sw_pingpong_supported(const pace_geom_t* geom, const pace_dsw_config_t* cfg);
+/* 1 if whole-d_sw calls also accept separate outputs of the winds (pace_dsw_config_t::u_out, v_out) -- the library then updates
+ * the winds in the kernel that transports the scalars, and pace_d_sw_overlapped has nothing left for its side stream --, else 0.
+ * (The damping orders nord_v, nord_w, nord_t of the column namelist must be <= 2, as get_column_namelist makes them,
+ * d_sw.py:633-683; otherwise the call returns PACE_ERR_UNSUPPORTED.) */
+int pace_d_sw_wind_outputs_supported(const pace_geom_t* geom, const pace_dsw_config_t* cfg);
 /* Once per object, after zero-filling the workspace: uploads the column namelist (synchronises). */
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream);
 int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,

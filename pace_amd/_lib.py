@@ -53,6 +53,8 @@ class DswConfig(C.Structure):
         ("nord", C.c_int32), ("do_skeb", C.c_int32), ("dddmp", C.c_double), ("d4_bg", C.c_double), ("d_con", C.c_double),
         # optional separate outputs of the four transported scalars (include/pace_hip.h): all four or none
         ("delp_out", C.c_void_p), ("pt_out", C.c_void_p), ("w_out", C.c_void_p), ("q_con_out", C.c_void_p),
+        # ... and of the D-grid winds (both or none, with the four above, whole-d_sw calls only)
+        ("u_out", C.c_void_p), ("v_out", C.c_void_p),
     ]
 
 
@@ -92,6 +94,7 @@ _PROTOS = {
     "pace_d_sw_workspace_bytes": (C.c_int64, [_P(Geom)]),
     "pace_d_sw_prepare": (C.c_int, [_P(Geom), _P(Column), c_dp, C.c_void_p]),
     "pace_d_sw_pingpong_supported": (C.c_int, [_P(Geom), _P(DswConfig)]),
+    "pace_d_sw_wind_outputs_supported": (C.c_int, [_P(Geom), _P(DswConfig)]),
     "pace_d_sw": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_transport": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_winds": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),

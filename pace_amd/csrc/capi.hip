@@ -151,6 +151,9 @@ int64_t pace_d_sw_workspace_bytes(const pace_geom_t* geom) { return geom ? dsw_w
 int pace_d_sw_pingpong_supported(const pace_geom_t* geom, const pace_dsw_config_t* cfg) {
   return (geom && cfg && dsw_pingpong_supported(make_geo(geom), cfg)) ? 1 : 0;
 }
+int pace_d_sw_wind_outputs_supported(const pace_geom_t* geom, const pace_dsw_config_t* cfg) {
+  return (geom && cfg && dsw_winds_in_scalars(make_geo(geom), cfg)) ? 1 : 0;
+}
 
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream) {
   NEED(geom && col && workspace);
@@ -172,6 +175,10 @@ static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t*
     if (given && (cfg->delp_out == delp || cfg->pt_out == pt || cfg->w_out == w || cfg->q_con_out == q_con)) return PACE_ERR_ARG;
     if (given && ((((uintptr_t)cfg->delp_out | (uintptr_t)cfg->pt_out | (uintptr_t)cfg->w_out | (uintptr_t)cfg->q_con_out) & 15) != 0))
       return PACE_ERR_ARG;  // (16-byte rows, as the header says)
+    // ... of the winds: both or none, only with the four, only in a call that runs scalars and winds together
+    const int winds = (cfg->u_out != nullptr) + (cfg->v_out != nullptr);
+    if (winds == 1 || (winds && !given) || (winds && (cfg->u_out == u || cfg->v_out == v || cfg->u_out == cfg->v_out))) return PACE_ERR_ARG;
+    if (winds && !((phases & 2) && (phases & 4) && (phases & 8))) return PACE_ERR_ARG;
   }
   return launch_d_sw(make_geo(geom), *met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy,
                      cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est, dt, phases, S(stream));
@@ -211,6 +218,12 @@ int pace_d_sw_overlapped(int prep, DSW_PARAMS, void* side_stream, void* ev_prep,
   hipStream_t main_s = S(stream), side_s = S(side_stream);
   hipEvent_t e_prep = (hipEvent_t)ev_prep, e_scal = (hipEvent_t)ev_scalars, e_done = (hipEvent_t)ev_done;
   int rc;
+  if (geom && cfg && dsw_winds_in_scalars(make_geo(geom), cfg)) {
+    // the winds are the last pass of the kernel that transports the scalars: one stream, nothing left for the side stream
+    if ((rc = d_sw_entry(prep | 14, DSW_ARGS_))) return rc;
+    if (hipEventRecord(e_done, main_s) != hipSuccess) return PACE_ERR_LAUNCH;
+    return PACE_OK;
+  }
   if ((rc = d_sw_entry(prep, DSW_ARGS_))) return rc;  // flux preparation on the caller's stream
   if (hipEventRecord(e_prep, main_s) != hipSuccess || hipStreamWaitEvent(side_s, e_prep, 0) != hipSuccess) return PACE_ERR_LAUNCH;
   {

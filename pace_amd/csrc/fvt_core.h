@@ -100,7 +100,9 @@ struct FvtLdsScalars {
   double mass[(TJ + 2) * MP];
   double priv[2 * NF][256];
   double newmass[TI * TJ];  // (512-thread form: the new delp of the tile's cells; the 256-thread form keeps it in registers)
+  double heat[TI * TJ];     // (512-thread form with the winds: w's heating term, heat_diss -> the dissipative heating at the end)
 };
+static_assert(2 * sizeof(FvtLdsScalars) <= 160 * 1024, "two workgroups per CU");
 
 #define LDG(p, off) (*(const real*)((const char*)(p) + (off)))
 #define STG(p, off) (*(real*)((char*)(p) + (off)))
@@ -332,6 +334,13 @@ struct FvtTile {
   __device__ __forceinline__ void load_footprint(const real* __restrict__ q, real* __restrict__ halo_out = nullptr) {
     D2 v[Pieces::NP];
     pc.load(q, v);
+    place_footprint(q, v, halo_out);
+  }
+  // the two halves of it: the loads (the scalar-phase kernel issues those of all four scalars at its start: one memory latency
+  // per tile instead of one per scalar) ...
+  __device__ __forceinline__ void fetch_footprint(const real* __restrict__ q, D2* v) const { pc.load(q, v); }
+  // ... and the pieces' way into the LDS (+ the halo copy and the corner values, which read q again)
+  __device__ __forceinline__ void place_footprint(const real* __restrict__ q, const D2* v, real* __restrict__ halo_out = nullptr) {
     if ((EX || EY) && halo_out) {
 #pragma unroll
       for (int p = 0; p < Pieces::NP; ++p) {
@@ -470,8 +479,11 @@ struct FvtTile {
   // heat_diss (d_sw.py:63-103): dw = divergence of the damping fluxes / area -- one more divergence of the iterate on this thread's
   // column run (the same expression, in the same order, as the flux-difference form of the general kernel) --, heat_source and
   // diss_est from it; stored for the tile's cells of the run (level offsets applied by the caller)
+  // dw_tile / heat_tile: if given, dw / heat_s go to these LDS tiles ([TJ][TI]; read back by the caller after a barrier) instead
+  // of memory
   __device__ __forceinline__ void heat_diss(const Damped& D, real* __restrict__ dw, real* __restrict__ heat_s,
-                                            real* __restrict__ diss_est, bool on, double dd8) {
+                                            real* __restrict__ diss_est, bool on, double dd8, double* dw_tile = nullptr,
+                                            double* heat_tile = nullptr) {
     if (!dn_on) return;
     double res[DRC];
     if (D.first) fvt_deln_run<true, DRC>(L.sq + dbase, sdv + dbase, sdu + dbase, dra, D.d0, res);
@@ -486,10 +498,12 @@ struct FvtTile {
           if (on) {
             const double d = res[t];
             const double qv = L.sq[jj * P + dc];
-            STG(dw, c) = d;
+            if (dw_tile) dw_tile[(jj - 3) * TI + dc - 3] = d;
+            else STG(dw, c) = d;
             hs = dd8 - d * (qv + 0.5 * d);
           }
-          STG(heat_s, c) = hs;
+          if (heat_tile) heat_tile[(jj - 3) * TI + dc - 3] = hs;
+          else STG(heat_s, c) = hs;
           STG(diss_est, c) = hs;
         }
       }
@@ -821,18 +835,29 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
 // transport with the mass fluxes, flux-form update / new delp + dw (adjust_w_and_qcon, :331-350).  q_con, pt: transport with
 // the mass fluxes + mass-weighted damping, flux-form update / new delp.  All outputs to buffers of their own.
 struct FvtScalars {
-  // in the order delp, w, q_con, pt: input (never written), output, damping factor / order columns (device, dsw_prepare)
-  const real* q[4];
+  // in the order delp, w, q_con, pt (and, with the winds, the relative vorticity): input (never written), output, damping factor /
+  // order columns (device, dsw_prepare)
+  const real* q[5];
   real* qout[4];
-  const real* fac[4];
-  const real* nord[4];
-  int nmax[4];
+  const real* fac[5];
+  const real* nord[5];
+  int nmax[5];
   const real *crx, *cry, *xfx, *yfx;
   real *mfx, *mfy;  // accumulated mass fluxes
   real *dw;         // one workspace field
   real *heat_s, *diss_est;
   const real *damp_w, *ke_bg;
   double dt;
+  // ---- the winds (512-thread form only; winds != 0): the vorticity transport, u / v from it and the kinetic energy, the
+  // dissipative heating and the final winds as a fifth pass of the tile (d_sw.py:406-477,493-608) ----
+  int winds, do_skeb, copy_wind_halo;
+  double d_con;
+  const real *u, *v;         // the winds before d_sw (read at the tile's faces only)
+  real *u_out, *v_out;       // the winds after it: buffers of their own (a tile reads the old wind on the face its neighbour writes)
+  const real *ke, *vort_b;   // kinetic energy (+ divergence damping) and damped vorticity at the B-grid points
+  real* heat_source;         // += the dissipative heating
+  const real *damp_vt, *d_con_k;
+  const real *fC, *rdx, *rdy, *rsin2, *cosa_s;  // metric fields FvMet does not carry
 };
 
 
@@ -1019,8 +1044,12 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
   const bool w_on = S.damp_w[k] > 1e-5;
   double* const priv = &LS.priv[0][0];  // [NF][NT]: the damping fluxes of the thread's faces while the sweeps run
   double c[NF], af[NF], mf[NF];    // Courant numbers, area fluxes, mass fluxes (unit fluxes of w, q_con, pt) of the run's faces
+  D2 fp[5][Tile::Pieces::NP];      // the thread's pieces of the footprints: every load of the tile's inputs is in flight at once
   {
     Tile T(L, g, m, bx, by, k, tid);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) T.fetch_footprint(S.q[s] + kb, fp[s]);
+    if (S.winds) T.fetch_footprint(S.q[4] + kb, fp[4]);
     const unsigned roff = xrole ? T.xoff : T.yoff;
   if (xrole) {
 #pragma unroll
@@ -1037,13 +1066,15 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
   }
   }
 
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {  // delp, w, q_con, pt
+  // one pass of the tile: s = 0 .. 4 = delp, w, q_con, pt, (the winds:) relative vorticity -- a compile-time constant
+  auto pass = [&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr bool is_delp = s == 0, is_w = s == 1, is_vort = s == 4;
     FVT_STAMP(4 * s);
     const real* const q = S.q[s] + kb;
-    real* const qout = S.qout[s] + kb;
-    const bool is_delp = s == 0, is_w = s == 1;
-    const bool mass_weighted = s >= 2;  // DelnFlux with mass (q_con, pt); delp: plain DelnFlux; w: DelnFluxNoSG -> heat_diss
+    real* const qout = is_vort ? nullptr : S.qout[is_vort ? 0 : s] + kb;
+    // DelnFlux with mass (q_con, pt); delp: plain DelnFlux; w: DelnFluxNoSG -> heat_diss; vorticity: DelnFluxNoSG -> the winds
+    const bool mass_weighted = s == 2 || s == 3;
     const double damp = S.fac[s][k];
     // the thread's places, derived again for every scalar: only the operands above live through the whole kernel
     Tile T(L, g, m, bx, by, k, FVT_LAUNDER(tid));
@@ -1060,8 +1091,24 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
       if (EY && !xrole) sp = fvt_spacing(m.dya, (unsigned)((T.ilo + T.ycol) * 8), sj8, g.js, g.je, lane_lo, lane_hi);
       return sp;
     };
-    T.load_footprint(q, qout);
-    T.stage_damping_metrics();
+    T.stage_damping_planes();  // (its loads first: the metric planes are cache hits, the footprint may still be on its way)
+    T.load_damping_rarea();
+    T.place_footprint(q, fp[s], qout);
+    // the winds: the kinetic energy and the damped vorticity at the tile's (TI + 1) x (TJ + 1) B-grid points, on their way now,
+    // into the LDS after the inner sweeps (where q's footprint and the mass tile are dead)
+    constexpr int BW = TI + 1, NBP = (BW * (TJ + 1) + NT - 1) / NT;
+    double bke[NBP], bvb[NBP];
+    if (is_vort) {
+#pragma unroll
+      for (int t = 0; t < NBP; ++t) {
+        int e = tid + NT * t;
+        if (e >= BW * (TJ + 1)) e = BW * (TJ + 1) - 1;
+        const int r = e / BW, cc = e - r * BW;
+        const unsigned o = (unsigned)((T.j0 + r) * sj8 + (T.i0 + cc) * 8);
+        bke[t] = LDG(S.ke + kb, o);
+        bvb[t] = LDG(S.vort_b + kb, o);
+      }
+    }
     __syncthreads();
     FVT_STAMP(4 * s + 1);
     if (is_delp) {  // the mass on the tile and one cell around it, from the footprint while it is there
@@ -1073,7 +1120,8 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
     {
       const auto D = T.damp(mass_weighted ? 1.0 : damp, S.nord[s][k] > 0.0, S.nmax[s]);
       if (is_w) {
-        T.heat_diss(D, S.dw + kb, S.heat_s + kb, S.diss_est + kb, w_on, S.ke_bg[k] * fabs(S.dt));
+        // (w has no face values: priv is free for dw; with the winds its heating term stays in the LDS as well)
+        T.heat_diss(D, S.dw + kb, S.heat_s + kb, S.diss_est + kb, w_on, S.ke_bg[k] * fabs(S.dt), priv, S.winds ? LS.heat : nullptr);
       } else if (run_outer) {
         if (xrole) {
 #pragma unroll
@@ -1087,6 +1135,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
       }
       __syncthreads();  // the sweeps overwrite the damping planes
     }
+    if (is_vort) T.add_2d(S.fC);  // the damped scalar was the relative vorticity, the transported one is the absolute (d_sw.py:389-402)
     FVT_STAMP(4 * s + 2);
     // stage I: the inner sweep of the thread's run on q, and the field advected along it (fvtp2d.py:34-77).  The inner fluxes of
     // the runs that take part in the outer sweep wait in ax / ay, each run using the places of the C faces it opens (the places
@@ -1148,9 +1197,28 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
     }
     __syncthreads();
     FVT_STAMP(4 * s + 3);
+    double* const tke = L.sq;     // the winds: kinetic energy / damped vorticity at the tile's B-grid points, pitch BW
+    double* const tvb = LS.mass;
+    if (is_vort) {
+#pragma unroll
+      for (int t = 0; t < NBP; ++t) {
+        const int e = tid + NT * t;
+        if (e < BW * (TJ + 1)) tke[e] = bke[t], tvb[e] = bvb[t];
+      }
+    }
     // stage II: the outer sweep on the field advected across the run (fvtp2d.py:80-119), the fluxes through the run's faces
+    double v[NF];
+    double wind[NF];  // the winds: the old wind on the run's faces, on its way while the sweep runs
+    if (is_vort && run_outer) {
+      if (xrole) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wind[f] = LDG(S.v + kb, roff + (unsigned)(f * 8));
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wind[f] = LDG(S.u + kb, roff + (unsigned)(f * sj8));
+      }
+    }
     if (run_outer) {
-      double v[NF];
       {
         double Q[NF + 5], out[NF];
         if (xrole) {
@@ -1172,7 +1240,10 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         v[C] = 0.5 * (out[C] + si_last);
       }
       FVT_FENCE();
-      if (is_delp) {
+      if (is_vort) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f] = v[f] * af[f];  // (the unit fluxes of the vorticity are the area fluxes)
+      } else if (is_delp) {
         double wa[NF];
         if (xrole) {
 #pragma unroll
@@ -1208,7 +1279,9 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         }
       }
       // a face's flux is put down by the run that opens it; the last face of the row / column by its last run
-      if (xrole) {
+      if (is_vort) {
+        // (the winds take the fluxes from the registers below)
+      } else if (xrole) {
 #pragma unroll
         for (int f = 0; f < C; ++f) slot[f * XS] = v[f];
         if (T.xg == GXN - 1) slot[C * XS] = v[C];
@@ -1219,6 +1292,102 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
       }
     }
     __syncthreads();
+    if (is_vort) {
+      // ---- the winds.  On a face of the tile: u_and_v_from_ke (d_sw.py:406-477) with the vorticity flux through it, the
+      // vorticity-damping increment (vort_differencing :353-380, the damping flux from priv), the final wind (update_u_and_v
+      // :582-608) and the face's terms of heat_source_from_vorticity_damping (:493-577: ubt, fy / vbt, fx); then, per cell, the
+      // damping term from its four faces and the heating.  The face terms travel through the LDS arrays the sweeps are done
+      // with: vbt -> ax, fx -> sqj (rows x TI + 1 faces), ubt -> ay, fy -> sqi (TJ + 1 faces x columns).
+      const bool upd = S.damp_vt[k] > 1e-5;
+      const double dck = S.d_con_k[k];
+      const bool don = dck > 1e-5;
+      double* const avbt = L.u.s.ax;
+      double* const afx = L.u.s.sqj;
+      double* const aubt = L.u.s.ay;
+      double* const afy = L.u.s.sqi;
+      if (run_outer) {
+        if (xrole) {  // x-faces: v-points (i0 + C * xg + f, j0 + xr)
+          double dyv[NF], rdyv[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            dyv[f] = LDG(m.dy, roff + (unsigned)(f * 8));
+            rdyv[f] = LDG(S.rdy, roff + (unsigned)(f * 8));
+          }
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const int b = T.xr * BW + C * T.xg + f;
+            const double vmid = wind[f] * dyv[f] + tke[b] - tke[b + BW] - v[f];  // v_from_ke (d_sw.py:423-436)
+            const double ut2 = priv[f * NT + tid];
+            const double vyd = don ? tvb[b] - tvb[b + BW] : 0.0;
+            const double vbt = (vyd - ut2) * rdyv[f];
+            const double fxh = vmid * rdyv[f];
+            if (f < C || last_face) STG(S.v_out + kb, roff + (unsigned)(f * 8)) = upd ? vmid - ut2 : vmid;
+            if (f < C || T.xg == GXN - 1) avbt[T.xr * PJ + C * T.xg + f] = vbt, afx[T.xr * PJ + C * T.xg + f] = fxh;
+          }
+        } else {  // y-faces: u-points (i0 + ycol - 3, j0 + C * yg + f)
+          double dxv[NF], rdxv[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            dxv[f] = LDG(m.dx, roff + (unsigned)(f * sj8));
+            rdxv[f] = LDG(S.rdx, roff + (unsigned)(f * sj8));
+          }
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const int b = (C * T.yg + f) * BW + T.ycol - 3;
+            const double umid = wind[f] * dxv[f] + tke[b] - tke[b + 1] + v[f];  // u_from_ke (d_sw.py:406-420)
+            const double vt2 = priv[f * NT + tid];
+            const double vxd = don ? tvb[b] - tvb[b + 1] : 0.0;
+            const double ubt = (vxd + vt2) * rdxv[f];
+            const double fyh = umid * rdxv[f];
+            if (f < C || last_face) STG(S.u_out + kb, roff + (unsigned)(f * sj8)) = upd ? umid + vt2 : umid;
+            if (f < C || T.yg == GYN - 1) aubt[(C * T.yg + f) * TI + T.ycol - 3] = ubt, afy[(C * T.yg + f) * TI + T.ycol - 3] = fyh;
+          }
+        }
+      }
+      __syncthreads();
+      {
+        int jj[NCU], ii[NCU];
+        unsigned c2[NCU];
+        T.cell_places(jj, ii, c2);
+        const bool any = S.d_con > 1e-5 || S.do_skeb;
+#pragma unroll
+        for (int t = 0; t < NCU; ++t) {
+          if (NCU * NT > TI * TJ && tid + NT * t >= TI * TJ) continue;  // (no cell of its own: the spare lanes would add twice)
+          const double heat_s = LS.heat[jj[t] * TI + ii[t]];
+          if (don || S.do_skeb) {
+            const int ey = jj[t] * TI + ii[t], ex = jj[t] * PJ + ii[t];
+            const double ubt0 = aubt[ey], ubtj = aubt[ey + TI], fy0 = afy[ey], fyj = afy[ey + TI];
+            const double vbt0 = avbt[ex], vbti = avbt[ex + 1], fx0 = afx[ex], fxi = afx[ex + 1];
+            const double gy0 = fy0 * ubt0, gyj = fyj * ubtj, gx0 = fx0 * vbt0, gxi = fxi * vbti;
+            const double u2 = fy0 + fyj, du2 = ubt0 + ubtj, v2 = fx0 + fxi, dv2 = vbt0 + vbti;
+            const double dampterm = LDG(S.rsin2, c2[t]) * 0.25 *
+                                    ((ubt0 * ubt0 + ubtj * ubtj + vbt0 * vbt0 + vbti * vbti) + 2.0 * (gy0 + gyj + gx0 + gxi) -
+                                     LDG(S.cosa_s, c2[t]) * (u2 * dv2 + v2 * du2 + du2 * dv2));
+            const double hs = LS.newmass[jj[t] * TI + ii[t]] * (heat_s - dck * dampterm);
+            if (any) {
+              STG(S.heat_source + kb, c2[t]) = LDG(S.heat_source + kb, c2[t]) + hs;
+              if (S.do_skeb) STG(S.diss_est + kb, c2[t]) = LDG(S.diss_est + kb, c2[t]) - dampterm;
+            }
+          } else if (any) {
+            STG(S.heat_source + kb, c2[t]) = LDG(S.heat_source + kb, c2[t]) + heat_s;
+          }
+        }
+      }
+      if ((EX || EY) && S.copy_wind_halo) {
+        // the output buffers of the winds get the halo the inputs have (the caller swaps the buffers): this tile's share of the
+        // storage outside the faces the kernel writes -- u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je]
+        const int xa = T.west ? 0 : T.i0, xb = T.east ? g.ni : T.i0 + TI, ya = T.south ? 0 : T.j0, yb = T.north ? g.nj : T.j0 + TJ;
+        const int bw = xb - xa, nbox = bw * (yb - ya);
+        for (int e = tid; e < nbox; e += NT) {
+          const int r = e / bw, i = xa + (e - r * bw), j = ya + r;
+          const unsigned o = (unsigned)(j * sj8 + i * 8);
+          const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
+          if (!(in_i && (in_j || j == g.je + 1))) STG(S.u_out + kb, o) = LDG(S.u + kb, o);
+          if (!((in_i || i == g.ie + 1) && in_j)) STG(S.v_out + kb, o) = LDG(S.v + kb, o);
+        }
+      }
+      return;
+    }
     {
       int jj[NCU], ii[NCU];
       unsigned c2[NCU];
@@ -1228,7 +1397,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
       for (int t = 0; t < NCU; ++t) ra[t] = LDG(m.rarea, c2[t]);
       if (is_w && w_on) {
 #pragma unroll
-        for (int t = 0; t < NCU; ++t) dwv[t] = LDG(S.dw + kb, c2[t]);
+        for (int t = 0; t < NCU; ++t) dwv[t] = priv[jj[t] * TI + ii[t]];
       }
 #pragma unroll
       for (int t = 0; t < NCU; ++t) {
@@ -1245,8 +1414,13 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         STG(qout, c2[t]) = val;
       }
     }
-    if (s < 3) __syncthreads();  // (the cell update read sq / ax / ay)
-  }
+    if (s < 3 || S.winds) __syncthreads();  // (the cell update read sq / ax / ay)
+  };
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
+  pass(std::integral_constant<int, 2>{});
+  pass(std::integral_constant<int, 3>{});
+  if (S.winds) pass(std::integral_constant<int, 4>{});
   FVT_STAMP(16);
 }
 

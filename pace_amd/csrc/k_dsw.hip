@@ -31,8 +31,23 @@ k_copy_scalars(Geo g, real* __restrict__ delp, real* __restrict__ pt, real* __re
   q_con[c] = q_con_n[c];
 }
 
+// the final winds from their workspace fields back into the caller's u (faces [is, ie] x [js, je + 1]) and v ([is, ie + 1] x [js, je])
+__global__ void __launch_bounds__(256)
+k_copy_winds(Geo g, real* __restrict__ u, real* __restrict__ v, const real* __restrict__ u_n, const real* __restrict__ v_n) {
+  PATCH_IJK(g);
+  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  const long c = IDX3(g, i, j, k);
+  if (i <= g.ie) u[c] = u_n[c];
+  if (j <= g.je) v[c] = v_n[c];
+}
+
 bool dsw_pingpong_supported(const Geo& g, const pace_dsw_config_t* cfg) {
   return cfg->hord_dp == cfg->hord_vt && cfg->hord_dp == cfg->hord_tm && transport_lean_covers(g, cfg->hord_dp);
+}
+// whether a whole-d_sw call runs the winds as the fifth pass of the scalar-phase kernel (then nothing of d_sw is left to overlap
+// with what follows it, and the winds can have outputs of their own)
+bool dsw_winds_in_scalars(const Geo& g, const pace_dsw_config_t* cfg) {
+  return dsw_pingpong_supported(g, cfg) && dsw_scalars_take_winds() && getenv("PACE_DSW_SEPARATE_WINDS") == nullptr;
 }
 
 // apply_pt_delp_fluxes (d_sw.py:148-201) + adjust_w_and_qcon (:331-350), given the flux-form updates
@@ -1192,25 +1207,41 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     }
   }
   int rc;
+  // Where the scalar-phase kernel can take the winds (the production tilings, one order for all transports, the 512-thread form)
+  // and the call asks for scalars and winds together, the vorticity transport, the wind update and the dissipative heating are
+  // the FIFTH PASS of that kernel (fvt_core.h): k_fvt<.., 0, 0> and k_heat_source, and the fields between them, disappear.
+  // The kinetic energy, the vorticity and the divergence damping then have to run BEFORE the scalars.
+  static const bool separate_winds = getenv("PACE_DSW_SEPARATE_WINDS") != nullptr;  // (A/B measurements)
+  const bool lean_scalars = cfg->hord_dp == cfg->hord_vt && cfg->hord_dp == cfg->hord_tm && transport_lean_covers(g, cfg->hord_dp);
+  const bool winds_in_scalars = lean_scalars && (phases & 2) && (phases & 4) && (phases & 8) && dsw_scalars_take_winds() &&
+                                !separate_winds && nmax_v <= 2 && nmax_w <= 2 && nmax_t <= 2 && ((uintptr_t)W.wk & 15) == 0;
+  if ((cfg->u_out != nullptr) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;  // (separate wind outputs exist in that form only)
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
   } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
     if ((phases & 16) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 1))) return rc;
     if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2))) return rc;
   }
-  if (phases & 2) {
+  auto scalar_phase = [&]() -> int {
     // The production tilings with one order for all four: ONE kernel (k_fvt.hip launch_dsw_scalars_lean) takes a tile through
     // delp, w, q_con, pt and the division by the new delp; its results go to the caller's separate outputs, or to workspace
     // fields that are copied back (the in-place contract of pace_d_sw).
     bool fused = false;
-    if (cfg->hord_dp == cfg->hord_vt && cfg->hord_dp == cfg->hord_tm && transport_lean_covers(g, cfg->hord_dp)) {
+    if (lean_scalars) {
       real* ws_outs[4] = {W.gx, W.fx2, W.wtmp, W.gy};
+      DswWinds wd{};
+      if (winds_in_scalars) {
+        wd.rel_vort = W.wk, wd.u = u, wd.v = v, wd.ke = W.ke, wd.vort_b = W.vort_b, wd.heat_source = heat_source;
+        wd.u_out = cfg->u_out ? cfg->u_out : W.umid, wd.v_out = cfg->v_out ? cfg->v_out : W.vmid;
+        wd.copy_halo = cfg->u_out != nullptr, wd.do_skeb = cfg->do_skeb, wd.d_con = cfg->d_con;
+      }
       rc = launch_dsw_scalars_lean(g, m, delp, pt, w, q_con, pingpong ? scalar_outs : ws_outs, crx, cry, xfx, yfx, mfx, mfy, W.dw,
-                                   W.heat_s, diss_est, kc, cfg->hord_dp, nmax_v, nmax_w, nmax_t, dt, st);
+                                   W.heat_s, diss_est, kc, cfg->hord_dp, nmax_v, nmax_w, nmax_t, dt, st, winds_in_scalars ? &wd : nullptr);
       if (rc == PACE_OK) {
         fused = true;
         if (!pingpong) hipLaunchKernelGGL(k_copy_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, delp, pt, w, q_con, W.gx, W.fx2, W.wtmp, W.gy);
-      } else if (rc != PACE_ERR_UNSUPPORTED) {
+        if (winds_in_scalars && !cfg->u_out) hipLaunchKernelGGL(k_copy_winds, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, u, v, W.umid, W.vmid);
+      } else if (rc != PACE_ERR_UNSUPPORTED || winds_in_scalars) {
         return rc;
       }
     }
@@ -1249,23 +1280,23 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     }
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
     }
-  }
+    return PACE_OK;
+  };
+  if ((phases & 2) && !winds_in_scalars && (rc = scalar_phase())) return rc;
   if (phases & (4 | 64)) {
   // winds A1: kinetic energy and relative vorticity (need only the flux preparation)
-  Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
-  const int nke = rke.n;
-  // the rest of the vorticity's domain [0, ni-2] x [0, nj-2]: the halo cells around the B-grid points is .. ie+1
-  add_region(rke, 0, g.is - 1, 0, g.nj - 2);
-  add_region(rke, g.ie + 2, g.ni - 2, 0, g.nj - 2);
-  add_region(rke, g.is, g.ie + 1, 0, g.js - 1);
-  add_region(rke, g.is, g.ie + 1, g.je + 2, g.nj - 2);
+  const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
+  // (k_kinetic_energy can form the vorticity of the same winds as well -- its last two arguments -- but that measured no faster
+  // than the two kernels: 74.8 us against 51.3 + 20.6 at C192 x 79, the nine extra loads per point cost what the second pass over
+  // u and v did; profiles/r05_experiments)
   if (cfg->hord_mt == 5) {
-    hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nke);
+    hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);
   } else if (cfg->hord_mt == 6) {
-    hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nke);
+    hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
+  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
   }
   if (phases & (4 | 128)) {
   // winds A2: divergence damping
@@ -1277,7 +1308,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // vorticity: transport of the absolute vorticity (wk + fC_agrid) -> W.fy2, W.fyv (own flux buffers: the mass fluxes
   // in W.fx / W.fy may still be in use by phase 2 on another stream) and the del-n damping fluxes of the relative
   // vorticity -> ut2, vt2 (DelnFluxNoSG, d_sw.py:1187-1195), one kernel
-  {
+  if (!winds_in_scalars) {
     FvDamp dp{};
     dp.damp_k = d_dampfac_vt_c; dp.nord_k = d_nord_v; dp.nmax = nmax_v; dp.mass_given = 0;
     dp.fx2o = W.ut2; dp.fy2o = W.vt2; dp.add2d = m.fC_agrid;
@@ -1287,7 +1318,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     if ((rc = launch_transport(g, m, W.wk, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, 0, 0, dp, st))) return rc;
   }
   }
-  if (phases & 8) {
+  if (winds_in_scalars && (rc = scalar_phase())) return rc;  // scalars + winds, after the kinetic energy and the divergence damping
+  if ((phases & 8) && !winds_in_scalars) {
   hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, W.umid, W.vmid, W.vort_b, W.ut2, W.vt2, pingpong ? scalar_outs[0] : delp, W.heat_s, heat_source,
                      diss_est, d_dcon, cfg->d_con, cfg->do_skeb, u, v, d_damp_vt_c);
   }

@@ -27,9 +27,18 @@ __global__ void __launch_bounds__(256, FVT_WAVES) k_fvt(Geo g, FvMet m, const re
 #ifndef FVT_SCALARS_NT
 #define FVT_SCALARS_NT 512  // threads per workgroup of the scalar-phase kernel: 512 = x-runs and y-runs in different waves
 #endif
-// two workgroups per CU either way (LDS: 66 KB each); 512 threads -> four waves per SIMD at <= 128 VGPRs, 256 -> two at <= 256
+// two workgroups per CU either way (LDS: 78 KB each); 512 threads -> four waves per SIMD at <= 128 VGPRs, 256 -> two at <= 256.
+// (__launch_bounds__(512, 2) alone does not hold the compiler to 128 registers -- it took 134 once, which is ONE workgroup per
+// CU: 342 -> 447 us --, the waves-per-EU attribute does)
+#ifdef PACE_EMU
+#define FVT_SCALARS_ATTR
+#elif FVT_SCALARS_NT == 512
+#define FVT_SCALARS_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define FVT_SCALARS_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <int MORD>
-__global__ void __launch_bounds__(FVT_SCALARS_NT, 2) k_fvt_scalars(Geo g, FvMet m, FvtScalars S) {
+__global__ void __launch_bounds__(FVT_SCALARS_NT) FVT_SCALARS_ATTR k_fvt_scalars(Geo g, FvMet m, FvtScalars S) {
   __shared__ FvtLdsScalars L;
   const FvTile wg = fv_tile_of_workgroup();
   const int gx = g.n / TI, gy = g.n / TJ;
@@ -101,12 +110,22 @@ int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real*
 // The scalar phase of d_sw (delp, w, q_con, pt) in one launch; see fvt_core.h.  kc: the device column block of dsw_prepare
 // (NCOL arrays of nk + 1).  outs[4] = delp, pt, w, q_con outputs, distinct from the inputs.  PACE_ERR_UNSUPPORTED if the geometry /
 // orders are not covered (the caller then runs the scalars one by one).
+// whether the scalar-phase kernel can take the winds as its fifth pass (the 512-thread form)
+bool dsw_scalars_take_winds() {
+#if FVT_AVAILABLE && FVT_SCALARS_NT == 512
+  return true;
+#else
+  return false;
+#endif
+}
+
 int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,
                             real* const* outs, const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx,
                             real* mfy, real* dw, real* heat_s, real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w,
-                            int nmax_t, double dt, hipStream_t st) {
+                            int nmax_t, double dt, hipStream_t st, const DswWinds* winds) {
 #if FVT_AVAILABLE
   if (!transport_lean_covers(g, hord) || nmax_v > 2 || nmax_w > 2 || nmax_t > 2) return PACE_ERR_UNSUPPORTED;
+  if (winds && !dsw_scalars_take_winds()) return PACE_ERR_UNSUPPORTED;
   const real* ins[4] = {delp, pt, w, q_con};
   for (int n = 0; n < 4; ++n)
     if (((uintptr_t)ins[n] & 15) != 0 || outs[n] == nullptr || outs[n] == ins[n]) return PACE_ERR_UNSUPPORTED;
@@ -124,6 +143,16 @@ int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const 
   S.diss_est = diss_est;
   S.damp_w = kc + 4 * K, S.ke_bg = kc + 8 * K;
   S.dt = dt;
+  if (winds) {
+    // the relative vorticity: DelnFluxNoSG with nord_v and (damp_vt * da_min_c) ^ (nord_v + 1) (d_sw.py:1187-1195)
+    if (((uintptr_t)winds->rel_vort & 15) != 0 || winds->u_out == winds->u || winds->v_out == winds->v) return PACE_ERR_UNSUPPORTED;
+    S.winds = 1;
+    S.q[4] = winds->rel_vort, S.fac[4] = kc + 11 * K, S.nord[4] = nord_v, S.nmax[4] = nmax_v;
+    S.u = winds->u, S.v = winds->v, S.u_out = winds->u_out, S.v_out = winds->v_out, S.ke = winds->ke, S.vort_b = winds->vort_b;
+    S.heat_source = winds->heat_source, S.do_skeb = winds->do_skeb, S.d_con = winds->d_con, S.copy_wind_halo = winds->copy_halo;
+    S.damp_vt = kc + 3 * K, S.d_con_k = kc + 7 * K;
+    S.fC = m.fC_agrid, S.rdx = m.rdx, S.rdy = m.rdy, S.rsin2 = m.rsin2, S.cosa_s = m.cosa_s;
+  }
   const dim3 grid(g.n / TI, g.n / TJ, g.nk);
   if (hord == 5) hipLaunchKernelGGL(k_fvt_scalars<5>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);
   else hipLaunchKernelGGL(k_fvt_scalars<6>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);

@@ -58,10 +58,20 @@ int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real*
                           const real* yfx, real* fx, real* fy, const real* xu, const real* yu, int hord, int nlev, int dmode,
                           int epi, const FvDamp& dp, hipStream_t st);
 
+// the winds of d_sw as the fifth pass of the scalar-phase kernel (fvt_core.h): the vorticity transport (u_and_v_from_ke), the
+// vorticity damping, the dissipative heating and the final winds.  u_out / v_out: buffers of their own; copy_halo: they also get
+// the halo u / v have (the caller swaps the buffers).
+struct DswWinds {
+  const real *rel_vort, *u, *v, *ke, *vort_b;
+  real *u_out, *v_out, *heat_source;
+  int do_skeb, copy_halo;
+  double d_con;
+};
+bool dsw_scalars_take_winds();
 int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,
                             real* const* outs, const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx,
                             real* mfy, real* dw, real* heat_s, real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w,
-                            int nmax_t, double dt, hipStream_t st);
+                            int nmax_t, double dt, hipStream_t st, const DswWinds* winds = nullptr);
 // whether launch_transport_lean takes this geometry with this order (fp64 build, tiling, row alignment)
 bool transport_lean_covers(const Geo& g, int hord);
 
@@ -124,6 +134,7 @@ int launch_a2b_ord4_batch(const Geo& g, const Met& m, const real* const* qin, re
 int64_t dsw_workspace_bytes(const Geo& g);
 // whether launch_d_sw can write the four transported scalars to separate buffers (pace_dsw_config_t::delp_out ...)
 bool dsw_pingpong_supported(const Geo& g, const pace_dsw_config_t* cfg);
+bool dsw_winds_in_scalars(const Geo& g, const pace_dsw_config_t* cfg);
 int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st);
 int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace_dsw_config_t* cfg, void* ws,
                 real* delpc, real* delp, real* pt, real* u, real* v, real* w, real* uc, real* vc,

@@ -115,30 +115,37 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         # kernel of the production tilings, include/pace_hip.h pace_dsw_config_t) and swapped into the caller's Quantities.
         self._pingpong = bool(swap_scalar_storage) and not os.environ.get("PACE_DSW_INPLACE") and bool(
             self.lib.cdll.pace_d_sw_pingpong_supported(C.byref(self._geom), C.byref(self._cfg)))
+        # ... and the winds, where the library updates them in the kernel that transports the scalars
+        self._wind_outputs = self._pingpong and bool(self.lib.cdll.pace_d_sw_wind_outputs_supported(C.byref(self._geom), C.byref(self._cfg)))
         self._quantity_factory = quantity_factory
         self._spares = None
 
-    def _outputs_for(self, delp, pt, w, q_con):
+    def _outputs_for(self, fields, winds: bool):
         """Point the config at the spare buffers (allocated at the first call as copies of the fields, so that the storage line
-        beyond the halo, which no kernel writes, holds what the fields hold)."""
-        if not self._pingpong or not all(hasattr(f, "swap_storage") for f in (delp, pt, w, q_con)):
-            self._cfg.delp_out = self._cfg.pt_out = self._cfg.w_out = self._cfg.q_con_out = None
-            return None
+        beyond the halo, which no kernel writes, holds what the fields hold).  fields: delp, pt, w, q_con, u, v; `winds`: the call
+        runs the whole of d_sw (the winds have outputs of their own only then).  Returns the (field, spare) pairs to swap."""
+        cfg = self._cfg
+        cfg.delp_out = cfg.pt_out = cfg.w_out = cfg.q_con_out = cfg.u_out = cfg.v_out = None
+        if not self._pingpong or not all(hasattr(f, "swap_storage") for f in fields):
+            return []
         if self._spares is None:
             self._spares = []
-            for f in (delp, pt, w, q_con):
+            for f in fields:
                 sp = self._quantity_factory.empty(f.dims, f.units)
                 sp.data[...] = f.data
                 self._spares.append(sp)
         sp = self._spares
-        self._cfg.delp_out, self._cfg.pt_out, self._cfg.w_out, self._cfg.q_con_out = (dptr(x) for x in sp)
-        return sp
+        cfg.delp_out, cfg.pt_out, cfg.w_out, cfg.q_con_out = (dptr(x) for x in sp[:4])
+        pairs = list(zip(fields[:4], sp[:4]))
+        if winds and self._wind_outputs:
+            cfg.u_out, cfg.v_out = dptr(sp[4]), dptr(sp[5])
+            pairs += list(zip(fields[4:], sp[4:]))
+        return pairs
 
     @staticmethod
-    def _swap_in(fields, spares):
-        if spares is not None:
-            for f, sp in zip(fields, spares):
-                f.swap_storage(sp)
+    def _swap_in(pairs):
+        for f, sp in pairs:
+            f.swap_storage(sp)
 
     def _args(self, fields, dt):
         check_layout(self._geom, *fields)
@@ -153,7 +160,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         after the wait) then computes only the frame of the flux preparation before it goes on.  Same results bit for bit."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source,
                   diss_est)
-        self._cfg.delp_out = self._cfg.pt_out = self._cfg.w_out = self._cfg.q_con_out = None
+        self._cfg.delp_out = self._cfg.pt_out = self._cfg.w_out = self._cfg.q_con_out = self._cfg.u_out = self._cfg.v_out = None
         self.lib.call("pace_d_sw_phases", 16, C.byref(self._geom), *self._args(fields, dt), self.stream())
         self._prep_started = True
 
@@ -172,7 +179,8 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         ``join()`` before touching u, v, uc, vc, heat_source, diss_est, delpc or divgd again."""
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                   heat_source, diss_est)
-        spares = self._outputs_for(delp, pt, w, q_con)
+        late_winds = bool(overlap_winds and not self._emu and os.environ.get("PACE_DSW_LATE_WINDS"))  # (phases in separate calls)
+        pairs = self._outputs_for((delp, pt, w, q_con, u, v), winds=not late_winds)
         self._cfg.flags = _lib.DSW_SKIP_DEAD_OUTPUTS if skip_dead_outputs else 0
         args = self._args(fields, dt)
         # flux preparation: everything (1), or only its frame (32) if start_flux_preparation did the interior box (16)
@@ -187,7 +195,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
                 self.call("pace_d_sw", *args, self.stream())
             else:
                 phases(prep | 14, self.stream())
-            self._swap_in((delp, pt, w, q_con), spares)
+            self._swap_in(pairs)
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self._workspace.device)
@@ -215,7 +223,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
                 self._ev_handles = tuple(C.c_void_p(e.cuda_event) for e in (self._ev_prep, self._ev_scalars, self._done))
             self.lib.call("pace_d_sw_overlapped", prep, C.byref(self._geom), *args, self.stream(), side_ptr, *self._ev_handles)
             self._pending = True
-            self._swap_in((delp, pt, w, q_con), spares)
+            self._swap_in(pairs)
             return
         phases(prep | 2, self.stream())  # flux preparation + scalar transport on the calling stream
         self._ev_scalars.record(main)
@@ -223,7 +231,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         phases(12, side_ptr)            # the whole wind update on the side stream
         self._done.record(side)
         self._pending = True
-        self._swap_in((delp, pt, w, q_con), spares)
+        self._swap_in(pairs)
 
     _side = None
     _ev_handles = None
