@@ -757,19 +757,30 @@ def main():
 
         geom = dsw._geom
         fused = bool(getattr(dsw, "_pingpong", False))
+        winds_fused = fused and bool(getattr(dsw, "_wind_outputs", False))
         if fused:
-            roof_kernel = "k_fvt_scalars<6> (d_sw scalar phase: delp, w, q_con, pt in one kernel)"
             roof_names = ("k_fvt_scalars",)
-            # distinct 3-D fields once per direction: delp, w, q_con, pt, crx, cry, xfx, yfx, mfx, mfy in;
-            # delp, w, q_con, pt, mfx, mfy, diss_est and w's heating term out
-            algo_fields = 18
-            spare_sets = [[env.q3() for _ in range(4)] for _ in range(2)]
+            if winds_fused:
+                roof_kernel = ("k_fvt_scalars<6> with the winds (d_sw: delp, w, q_con, pt transported and updated, the vorticity transport, "
+                               "the wind update and the dissipative heating in one kernel)")
+                # distinct 3-D fields once per direction: delp, w, q_con, pt, crx, cry, xfx, yfx, mfx, mfy,
+                # relative vorticity, u, v, kinetic energy, damped vorticity, heat_source in; delp, w, q_con, pt, mfx, mfy,
+                # diss_est, u, v, heat_source out
+                algo_fields = 26
+            else:
+                roof_kernel = "k_fvt_scalars<6> (d_sw scalar phase: delp, w, q_con, pt in one kernel)"
+                # ... delp, w, q_con, pt, crx, cry, xfx, yfx, mfx, mfy in; delp, w, q_con, pt, mfx, mfy, diss_est, w's heating term out
+                algo_fields = 18
+            spare_sets = [[env.q3() for _ in range(6)] for _ in range(2)]
 
             def kernel(r):
                 b = batches[r % nbatch]  # a different state copy every launch: operands come from HBM, as inside a step
                 sp = spare_sets[r % 2]
-                dsw._cfg.delp_out, dsw._cfg.pt_out, dsw._cfg.w_out, dsw._cfg.q_con_out = (dptr(x) for x in sp)
-                lib.call("pace_d_sw_phases", 2, C.byref(geom), *dsw._args([b[k] for k in DSW_ARGS], dt), dsw.stream())
+                c_ = dsw._cfg
+                c_.delp_out, c_.pt_out, c_.w_out, c_.q_con_out = (dptr(x) for x in sp[:4])
+                c_.u_out, c_.v_out = (dptr(sp[4]), dptr(sp[5])) if winds_fused else (None, None)
+                # (256: the fused kernel alone, on the kinetic energy / vorticity / damped vorticity the last step left in the workspace)
+                lib.call("pace_d_sw_phases", 256 if winds_fused else 2, C.byref(geom), *dsw._args([b[k] for k in DSW_ARGS], dt), dsw.stream())
         else:
             roof_kernel = "k_fvtp2d<6, 2, 1> (transport + damping + flux-form update of one scalar)"
             roof_names = ("k_fvtp2d<6, 2, 1", "k_fvtp2dILi6ELi2ELi1E", "k_fvt<6, 2, 1", "k_fvtILi6ELi2ELi1E")

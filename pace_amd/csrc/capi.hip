@@ -178,7 +178,7 @@ static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t*
     // ... of the winds: both or none, only with the four, only in a call that runs scalars and winds together
     const int winds = (cfg->u_out != nullptr) + (cfg->v_out != nullptr);
     if (winds == 1 || (winds && !given) || (winds && (cfg->u_out == u || cfg->v_out == v || cfg->u_out == cfg->v_out))) return PACE_ERR_ARG;
-    if (winds && !((phases & 2) && (phases & 4) && (phases & 8))) return PACE_ERR_ARG;
+    if (winds && !(((phases & 2) && (phases & 4) && (phases & 8)) || phases == 256)) return PACE_ERR_ARG;
   }
   return launch_d_sw(make_geo(geom), *met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy,
                      cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est, dt, phases, S(stream));
@@ -198,8 +198,8 @@ int pace_d_sw(DSW_PARAMS) { return d_sw_entry(15, DSW_ARGS_); }
 int pace_d_sw_transport(DSW_PARAMS) { return d_sw_entry(3, DSW_ARGS_); }
 int pace_d_sw_winds(DSW_PARAMS) { return d_sw_entry(12, DSW_ARGS_); }
 int pace_d_sw_phases(int phases, DSW_PARAMS) {
-  if (phases < 1 || phases > 255 || ((phases & 1) && (phases & 48)) || ((phases & 4) && (phases & 192)))
-    return PACE_ERR_ARG;  // (1 and 16 / 32, 4 and 64 / 128 are alternatives)
+  if (phases < 1 || phases > 256 || ((phases & 1) && (phases & 48)) || ((phases & 4) && (phases & 192)))
+    return PACE_ERR_ARG;  // (1 and 16 / 32, 4 and 64 / 128 are alternatives; 256 stands alone)
   return d_sw_entry(phases, DSW_ARGS_);
 }
 

@@ -1213,7 +1213,9 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // The kinetic energy, the vorticity and the divergence damping then have to run BEFORE the scalars.
   static const bool separate_winds = getenv("PACE_DSW_SEPARATE_WINDS") != nullptr;  // (A/B measurements)
   const bool lean_scalars = cfg->hord_dp == cfg->hord_vt && cfg->hord_dp == cfg->hord_tm && transport_lean_covers(g, cfg->hord_dp);
-  const bool winds_in_scalars = lean_scalars && (phases & 2) && (phases & 4) && (phases & 8) && dsw_scalars_take_winds() &&
+  // (phases 256, a measurement aid: that kernel ALONE, on the kinetic energy / vorticity / damped vorticity a previous call left in
+  // the workspace)
+  const bool winds_in_scalars = lean_scalars && (((phases & 2) && (phases & 4) && (phases & 8)) || (phases & 256)) && dsw_scalars_take_winds() &&
                                 !separate_winds && nmax_v <= 2 && nmax_w <= 2 && nmax_t <= 2 && ((uintptr_t)W.wk & 15) == 0;
   if ((cfg->u_out != nullptr) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;  // (separate wind outputs exist in that form only)
   if (phases & 1) {
@@ -1318,6 +1320,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     if ((rc = launch_transport(g, m, W.wk, crx, cry, xfx, yfx, W.fy2, W.fyv, nullptr, nullptr, cfg->hord_vt, nk, 0, 0, dp, st))) return rc;
   }
   }
+  if ((phases & 256) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;
   if (winds_in_scalars && (rc = scalar_phase())) return rc;  // scalars + winds, after the kinetic energy and the divergence damping
   if ((phases & 8) && !winds_in_scalars) {
   hipLaunchKernelGGL(k_heat_source, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, W.umid, W.vmid, W.vort_b, W.ut2, W.vt2, pingpong ? scalar_outs[0] : delp, W.heat_s, heat_source,
