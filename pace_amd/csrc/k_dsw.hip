@@ -199,6 +199,32 @@ __device__ __forceinline__ double dd_v_contra_dxc(const Geo& g, const Met& m, co
   return vc_ * m.dxc[c2];
 }
 
+// one B-grid point of the sponge levels: delpc, the damped vorticity and ke += it (divergence_damping.py:30-158)
+__device__ __forceinline__ void divdamp_low_point(const Geo& g, const Met& m, const real* __restrict__ u, const real* __restrict__ v,
+                                                  const real* __restrict__ ua, const real* __restrict__ va, const real* __restrict__ uc,
+                                                  const real* __restrict__ vc, real* __restrict__ delpc, real* __restrict__ vort_b,
+                                                  real* __restrict__ ke, double d2, double dddmp, double dt, int i, int j, int k) {
+  const long c = IDX3(g, i, j, k);
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  // a = u_contra_dyc, b = v_contra_dxc (argument order at divergence_damping.py:561-566)
+  const double a0 = dd_u_contra_dyc(g, m, u, va, vc, c, c2, j);
+  const double am = dd_u_contra_dyc(g, m, u, va, vc, c - 1, c2 - 1, j);
+  const double b0 = dd_v_contra_dxc(g, m, v, ua, uc, c, c2, i);
+  const double bm = dd_v_contra_dxc(g, m, v, ua, uc, c - sj, c2 - sj, i);
+  double d = bm - b0 + am - a0;
+  const bool ic = (i == g.is || i == g.ie + 1);
+  if (ic && j == g.js) d = d - bm;
+  if (ic && j == g.je + 1) d = d + b0;
+  d = m.rarea_c[c2] * d;
+  delpc[c] = d;
+  const double delpcdt = d * dt;
+  const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(delpcdt)));
+  const double vort = damp * d;
+  vort_b[c] = vort;
+  ke[c] = ke[c] + vort;
+}
+
 __global__ void __launch_bounds__(256)
 k_divdamp_low(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
               const real* __restrict__ ua, const real* __restrict__ va, const real* __restrict__ uc,
@@ -557,6 +583,14 @@ k_divdamp_high_final(Geo g, Met m, const real* __restrict__ wk, const real* delp
 #define DD_NE ((DD_W * DD_H + 255) / 256)
 #define DD_NP ((DD_TI * DD_TJ + 255) / 256)
 
+// the operands of the sponge levels for k_divdamp_fused (first_block: the blockIdx.z they start at; > the grid's height: none)
+struct DdSponge {
+  const real *u, *v, *ua, *va, *uc, *vc;
+  real* delpc;
+  double dt;
+  int first_block;
+};
+
 template <class Plane>
 __device__ __forceinline__ void divdamp_point(const Geo& g, const Met& m, const Plane& src, int i, int j, bool fill, double& d,
                                               double& uc_here, double& vc_here) {
@@ -693,7 +727,8 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
 __global__ void __launch_bounds__(256)
 k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
                 real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
-                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int full_) {
+                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int full_,
+                DdSponge sp) {
   // full_ == 0 (PACE_DSW_SKIP_DEAD_OUTPUTS): divg_d, uc_out, vc_out are not written -- din may then be divg_d itself
   const bool full = full_ != 0;
   __shared__ double sbuf[2][DD_W * DD_H];
@@ -701,6 +736,18 @@ k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restric
   const int bx = (int)blockIdx.x % ntx, by = (int)blockIdx.x / ntx;
   const int i0 = g.is + bx * DD_TI, j0 = g.js + by * DD_TJ;
   const int ilo = i0 - 3, jlo = j0 - 3;
+  if ((int)blockIdx.z >= sp.first_block) {
+    // the sponge levels [0, k0) ride along as extra workgroups (they were a launch of their own: 10 us for two or three levels):
+    // second-order damping, a point function of the winds, on the tile's own points
+    const int kk = (int)blockIdx.z - sp.first_block;
+    for (int q = tid; q < DD_TI * DD_TJ; q += 256) {
+      const int jj = q / DD_TI, ii = q - jj * DD_TI;
+      const int i = i0 + ii, j = j0 + jj;
+      if (i <= g.ie + 1 && j <= g.je + 1)
+        divdamp_low_point(g, m, sp.u, sp.v, sp.ua, sp.va, sp.uc, sp.vc, sp.delpc, vort_b, ke, d2_bg[kk], dddmp, sp.dt, i, j, kk);
+    }
+    return;
+  }
   const int kk = (int)blockIdx.z + k0;
   const long kb = (long)kk * g.sk;
   // the divergence on the footprint, and (kept in registers until a plane is free) the relative vorticity under the tile
@@ -1092,10 +1139,7 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
                        d2_bg_dev, dddmp, dt, divg_d, kstart);
   } else if (fused) {
     // the work fields are dead after d_sw (PACE_DSW_SKIP_DEAD_OUTPUTS): no copy -- the fused kernel reads the divergence where it
-    // is and writes neither it nor uc / vc -- and only the sponge levels here
-    if (kstart > 0)
-      hipLaunchKernelGGL(k_divdamp_low_and_copy, plane_grid(g, kstart), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
-                         d2_bg_dev, dddmp, dt, divg_d, kstart);
+    // is and writes neither it nor uc / vc -- and the sponge levels are extra workgroups of the fused launch
   } else if (kstart > 0) {
     hipLaunchKernelGGL(k_divdamp_low, plane_grid(g, kstart), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
                        d2_bg_dev, dddmp, dt);
@@ -1103,9 +1147,10 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
   if (fused) {
     const double dd8 = pow(m.da_min_c * d4_bg, (double)(nonzero_nord + 1));
     const int ntx = (g.n + 1 + DD_TI - 1) / DD_TI, nty = (g.n + 1 + DD_TJ - 1) / DD_TJ;
-    hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)nhigh), dim3(256), 0, st, g, m, rel_vort_agrid,
-                       skip_dead ? divg_d : delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart, nonzero_nord, ntx,
-                       skip_dead ? 0 : 1);
+    const DdSponge sp{u, v, ua, va, uc, vc, delpc, dt, nhigh};
+    hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)(nhigh + (skip_dead ? kstart : 0))), dim3(256), 0, st, g, m,
+                       rel_vort_agrid, skip_dead ? divg_d : delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart,
+                       nonzero_nord, ntx, skip_dead ? 0 : 1, sp);
   } else if (nhigh > 0) {
     const real* src = divg_d;
     real* bufs[2] = {da, db};
@@ -1218,11 +1263,18 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   const bool winds_in_scalars = lean_scalars && (((phases & 2) && (phases & 4) && (phases & 8)) || (phases & 256)) && dsw_scalars_take_winds() &&
                                 !separate_winds && nmax_v <= 2 && nmax_w <= 2 && nmax_t <= 2 && ((uintptr_t)W.wk & 15) == 0;
   if ((cfg->u_out != nullptr) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;  // (separate wind outputs exist in that form only)
+  // The flux half of the flux preparation (Courant numbers, area fluxes, cx += crx, cy += cry) moves into that kernel as well --
+  // it forms them for its own faces from ut / vt and writes them for the operators after d_sw -- when the flux preparation is
+  // part of the same call, or when the caller says so for a flux preparation split over calls (512, with 16 and with 32: the call
+  // that completes d_sw must then run the scalars and the winds together).
+  static const bool fluxes_in_prep = getenv("PACE_DSW_FLUXES_IN_PREP") != nullptr;  // (A/B measurements)
+  const bool defer_fluxes = (((phases & 1) && winds_in_scalars) || (phases & 512)) && !fluxes_in_prep;
+  if ((phases & 512) && !(phases & 16) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;
   if (phases & 1) {
-  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
+  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 0, !defer_fluxes))) return rc;
   } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
-    if ((phases & 16) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 1))) return rc;
-    if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2))) return rc;
+    if ((phases & 16) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 1, !defer_fluxes))) return rc;
+    if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2, !defer_fluxes))) return rc;
   }
   auto scalar_phase = [&]() -> int {
     // The production tilings with one order for all four: ONE kernel (k_fvt.hip launch_dsw_scalars_lean) takes a tile through
@@ -1236,6 +1288,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
         wd.rel_vort = W.wk, wd.u = u, wd.v = v, wd.ke = W.ke, wd.vort_b = W.vort_b, wd.heat_source = heat_source;
         wd.u_out = cfg->u_out ? cfg->u_out : W.umid, wd.v_out = cfg->v_out ? cfg->v_out : W.vmid;
         wd.copy_halo = cfg->u_out != nullptr, wd.do_skeb = cfg->do_skeb, wd.d_con = cfg->d_con;
+        if (defer_fluxes) wd.ut = W.ut, wd.vt = W.vt, wd.cx = cx, wd.cy = cy;
       }
       rc = launch_dsw_scalars_lean(g, m, delp, pt, w, q_con, pingpong ? scalar_outs : ws_outs, crx, cry, xfx, yfx, mfx, mfy, W.dw,
                                    W.heat_s, diss_est, kc, cfg->hord_dp, nmax_v, nmax_w, nmax_t, dt, st, winds_in_scalars ? &wd : nullptr);
