@@ -198,9 +198,8 @@ int pace_d_sw(DSW_PARAMS) { return d_sw_entry(15, DSW_ARGS_); }
 int pace_d_sw_transport(DSW_PARAMS) { return d_sw_entry(3, DSW_ARGS_); }
 int pace_d_sw_winds(DSW_PARAMS) { return d_sw_entry(12, DSW_ARGS_); }
 int pace_d_sw_phases(int phases, DSW_PARAMS) {
-  if (phases < 1 || phases > 1023 || ((phases & 1) && (phases & 48)) || ((phases & 4) && (phases & 192)) || ((phases & 256) && phases != 256) ||
-      ((phases & 512) && !(phases & 48)))
-    return PACE_ERR_ARG;  // (1 and 16 / 32, 4 and 64 / 128 are alternatives; 256 stands alone; 512 qualifies 16 / 32)
+  if (phases < 1 || phases > 256 || ((phases & 1) && (phases & 48)) || ((phases & 4) && (phases & 192)))
+    return PACE_ERR_ARG;  // (1 and 16 / 32, 4 and 64 / 128 are alternatives; 256 stands alone)
   return d_sw_entry(phases, DSW_ARGS_);
 }
 
@@ -211,11 +210,11 @@ int pace_d_sw_phases(int phases, DSW_PARAMS) {
 int pace_d_sw_overlapped(int prep, DSW_PARAMS, void* side_stream, void* ev_prep, void* ev_scalars, void* ev_done) {
 #ifdef PACE_EMU
   (void)side_stream; (void)ev_prep; (void)ev_scalars; (void)ev_done;
-  if (prep != 1 && prep != 32 && prep != (32 | 512)) return PACE_ERR_ARG;
+  if (prep != 1 && prep != 32) return PACE_ERR_ARG;
   return d_sw_entry(prep | 14, DSW_ARGS_);
 #else
   NEED(side_stream && ev_prep && ev_scalars && ev_done);
-  if (prep != 1 && prep != 32 && prep != (32 | 512)) return PACE_ERR_ARG;
+  if (prep != 1 && prep != 32) return PACE_ERR_ARG;
   hipStream_t main_s = S(stream), side_s = S(side_stream);
   hipEvent_t e_prep = (hipEvent_t)ev_prep, e_scal = (hipEvent_t)ev_scalars, e_done = (hipEvent_t)ev_done;
   int rc;

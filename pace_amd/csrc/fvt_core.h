@@ -81,7 +81,6 @@ struct FvtLds {
 #ifdef PACE_EMU
 #define FVT_FENCE()
 #define FVT_LAUNDER(x) (x)
-
 #else
 #define FVT_FENCE() __builtin_amdgcn_sched_barrier(0)
 // the same value through an empty asm: what is derived from it is derived AGAIN, not kept in registers from the last time
@@ -859,12 +858,6 @@ struct FvtScalars {
   real* heat_source;         // += the dissipative heating
   const real *damp_vt, *d_con_k;
   const real *fC, *rdx, *rdy, *rsin2, *cosa_s;  // metric fields FvMet does not carry
-  // ---- the flux half of FiniteVolumeFluxPrep (fxadv.py:433-508, 565-661: Courant numbers and area fluxes from the contravariant
-  // winds; 512-thread form only; ut != nullptr): formed by the tile for its own faces from ut / vt instead of read from crx .. yfx,
-  // which the tile writes for the operators after d_sw (+ cx += crx, cy += cry: the Courant half of flux_capacitor, d_sw.py:33-60)
-  const real *ut, *vt;
-  real *crx_out, *cry_out, *xfx_out, *yfx_out, *cx, *cy;
-  const real *rdxa, *rdya, *sin_sg1, *sin_sg2, *sin_sg3, *sin_sg4;
 };
 
 
@@ -1054,94 +1047,11 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
   D2 fp[5][Tile::Pieces::NP];      // the thread's pieces of the footprints: every load of the tile's inputs is in flight at once
   {
     Tile T(L, g, m, bx, by, k, tid);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) T.fetch_footprint(S.q[s] + kb, fp[s]);
+    if (S.winds) T.fetch_footprint(S.q[4] + kb, fp[4]);
     const unsigned roff = xrole ? T.xoff : T.yoff;
-  if (S.ut != nullptr) {
-    // the Courant numbers and area fluxes of the run's faces from the contravariant wind through them (the expressions of
-    // k_fxadv_fluxes -> the same bits), stored by the run that owns the face in the domain crx .. yfx are defined on: the tile's
-    // rows / columns, and in the tiles along an edge the three halo rows / columns beside it
-    const double dt = S.dt;
-    if (xrole) {
-      const bool own = T.x_outer || (EY && T.x_on && (T.south ? T.xrow < 3 : T.xrow >= TJ + 3));
-      const bool last = T.east && T.xg == GXN - 1;
-      double w[NF], rm[NF + 1], dyv[NF], s3[NF], s1[NF];
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const unsigned o = roff + (unsigned)(f * 8);
-        w[f] = LDG(S.ut + kb, o);
-        rm[f] = LDG(S.rdxa, o - 8u);
-        dyv[f] = LDG(m.dy, o);
-        s3[f] = LDG(S.sin_sg3, o - 8u);
-        s1[f] = LDG(S.sin_sg1, o);
-      }
-      rm[NF] = LDG(S.rdxa, roff + (unsigned)((NF - 1) * 8));
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const double u = w[f];
-        if (u > 0.0) {
-          c[f] = dt * u * rm[f];
-          af[f] = dyv[f] * dt * u * s3[f];
-        } else {
-          c[f] = dt * u * rm[f + 1];
-          af[f] = dyv[f] * dt * u * s1[f];
-        }
-      }
-      FVT_FENCE();
-      if (own) {
-        double acc[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f] = LDG(S.cx + kb, roff + (unsigned)(f * 8));
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          if (f < C || last) {
-            const unsigned o = roff + (unsigned)(f * 8);
-            STG(S.crx_out + kb, o) = c[f];
-            STG(S.xfx_out + kb, o) = af[f];
-            STG(S.cx + kb, o) = acc[f] + c[f];
-          }
-        }
-      }
-    } else {
-      const bool own = T.y_outer || (EX && T.y_on && (T.west ? T.ycol < 3 : T.ycol >= TI + 3));
-      const bool last = T.north && T.yg == GYN - 1;
-      double w[NF], rm[NF + 1], dxv[NF], s4[NF], s2[NF];
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const unsigned o = roff + (unsigned)(f * sj8);
-        w[f] = LDG(S.vt + kb, o);
-        rm[f] = LDG(S.rdya, o - (unsigned)sj8);
-        dxv[f] = LDG(m.dx, o);
-        s4[f] = LDG(S.sin_sg4, o - (unsigned)sj8);
-        s2[f] = LDG(S.sin_sg2, o);
-      }
-      rm[NF] = LDG(S.rdya, roff + (unsigned)((NF - 1) * sj8));
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const double v = w[f];
-        if (v > 0.0) {
-          c[f] = dt * v * rm[f];
-          af[f] = dxv[f] * dt * v * s4[f];
-        } else {
-          c[f] = dt * v * rm[f + 1];
-          af[f] = dxv[f] * dt * v * s2[f];
-        }
-      }
-      FVT_FENCE();
-      if (own) {
-        double acc[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f] = LDG(S.cy + kb, roff + (unsigned)(f * sj8));
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          if (f < C || last) {
-            const unsigned o = roff + (unsigned)(f * sj8);
-            STG(S.cry_out + kb, o) = c[f];
-            STG(S.yfx_out + kb, o) = af[f];
-            STG(S.cy + kb, o) = acc[f] + c[f];
-          }
-        }
-      }
-    }
-  } else if (xrole) {
+  if (xrole) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       c[f] = LDG(S.crx + kb, roff + (unsigned)(f * 8));
@@ -1154,10 +1064,6 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
       af[f] = LDG(S.yfx + kb, roff + (unsigned)(f * sj8));
     }
   }
-    FVT_FENCE();  // (the footprints after the operands: both at once did not fit the registers)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) T.fetch_footprint(S.q[s] + kb, fp[s]);
-    if (S.winds) T.fetch_footprint(S.q[4] + kb, fp[4]);
   }
 
   // one pass of the tile: s = 0 .. 4 = delp, w, q_con, pt, (the winds:) relative vorticity -- a compile-time constant

@@ -1263,18 +1263,11 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   const bool winds_in_scalars = lean_scalars && (((phases & 2) && (phases & 4) && (phases & 8)) || (phases & 256)) && dsw_scalars_take_winds() &&
                                 !separate_winds && nmax_v <= 2 && nmax_w <= 2 && nmax_t <= 2 && ((uintptr_t)W.wk & 15) == 0;
   if ((cfg->u_out != nullptr) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;  // (separate wind outputs exist in that form only)
-  // The flux half of the flux preparation (Courant numbers, area fluxes, cx += crx, cy += cry) moves into that kernel as well --
-  // it forms them for its own faces from ut / vt and writes them for the operators after d_sw -- when the flux preparation is
-  // part of the same call, or when the caller says so for a flux preparation split over calls (512, with 16 and with 32: the call
-  // that completes d_sw must then run the scalars and the winds together).
-  static const bool fluxes_in_prep = getenv("PACE_DSW_FLUXES_IN_PREP") != nullptr;  // (A/B measurements)
-  const bool defer_fluxes = (((phases & 1) && winds_in_scalars) || (phases & 512)) && !fluxes_in_prep;
-  if ((phases & 512) && !(phases & 16) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;
   if (phases & 1) {
-  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 0, !defer_fluxes))) return rc;
+  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
   } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
-    if ((phases & 16) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 1, !defer_fluxes))) return rc;
-    if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2, !defer_fluxes))) return rc;
+    if ((phases & 16) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 1))) return rc;
+    if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2))) return rc;
   }
   auto scalar_phase = [&]() -> int {
     // The production tilings with one order for all four: ONE kernel (k_fvt.hip launch_dsw_scalars_lean) takes a tile through
@@ -1288,7 +1281,6 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
         wd.rel_vort = W.wk, wd.u = u, wd.v = v, wd.ke = W.ke, wd.vort_b = W.vort_b, wd.heat_source = heat_source;
         wd.u_out = cfg->u_out ? cfg->u_out : W.umid, wd.v_out = cfg->v_out ? cfg->v_out : W.vmid;
         wd.copy_halo = cfg->u_out != nullptr, wd.do_skeb = cfg->do_skeb, wd.d_con = cfg->d_con;
-        if (defer_fluxes) wd.ut = W.ut, wd.vt = W.vt, wd.cx = cx, wd.cy = cy;
       }
       rc = launch_dsw_scalars_lean(g, m, delp, pt, w, q_con, pingpong ? scalar_outs : ws_outs, crx, cry, xfx, yfx, mfx, mfy, W.dw,
                                    W.heat_s, diss_est, kc, cfg->hord_dp, nmax_v, nmax_w, nmax_t, dt, st, winds_in_scalars ? &wd : nullptr);

@@ -152,20 +152,10 @@ int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const 
     S.heat_source = winds->heat_source, S.do_skeb = winds->do_skeb, S.d_con = winds->d_con, S.copy_wind_halo = winds->copy_halo;
     S.damp_vt = kc + 3 * K, S.d_con_k = kc + 7 * K;
     S.fC = m.fC_agrid, S.rdx = m.rdx, S.rdy = m.rdy, S.rsin2 = m.rsin2, S.cosa_s = m.cosa_s;
-    if (winds->ut) {
-      S.ut = winds->ut, S.vt = winds->vt, S.cx = winds->cx, S.cy = winds->cy;
-      S.crx_out = const_cast<real*>(crx), S.cry_out = const_cast<real*>(cry), S.xfx_out = const_cast<real*>(xfx), S.yfx_out = const_cast<real*>(yfx);
-      S.rdxa = m.rdxa, S.rdya = m.rdya, S.sin_sg1 = m.sin_sg1, S.sin_sg2 = m.sin_sg2, S.sin_sg3 = m.sin_sg3, S.sin_sg4 = m.sin_sg4;
-    }
   }
   const dim3 grid(g.n / TI, g.n / TJ, g.nk);
-#ifdef PACE_EMU  // (the kernel accumulates cx / cy before its first barrier: no probe run of its first thread, tests/emu/hip_emu.h)
-#define FVT_SCALARS_LAUNCH hipLaunchKernelGGL_barriers
-#else
-#define FVT_SCALARS_LAUNCH hipLaunchKernelGGL
-#endif
-  if (hord == 5) FVT_SCALARS_LAUNCH(k_fvt_scalars<5>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);
-  else FVT_SCALARS_LAUNCH(k_fvt_scalars<6>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);
+  if (hord == 5) hipLaunchKernelGGL(k_fvt_scalars<5>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);
+  else hipLaunchKernelGGL(k_fvt_scalars<6>, grid, dim3(FVT_SCALARS_NT), 0, st, g, fv_met(m), S);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 #else

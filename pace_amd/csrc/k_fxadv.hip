@@ -232,9 +232,7 @@ __global__ void __launch_bounds__(1024) k_fxadv_edges(Geo g, Met m, const real* 
 
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
-                 hipStream_t st, int part, bool fluxes) {
-  // fluxes == false: only the contravariant winds ut / vt; the Courant numbers and area fluxes (and cx += crx, cy += cry) are then
-  // formed by the scalar-phase kernel of d_sw, tile by tile, where they are consumed (fvt_core.h)
+                 hipStream_t st, int part) {
   // part 0: everything; 1: the interior box only (needs no halo of uc / vc); 2: the rest, to be run after part 1
   const dim3 grid = plane_grid(g, g.nk), block(256);
   FxBox box{g.is + 2, g.ie - 1, g.js + 2, g.je - 1, part};
@@ -256,7 +254,7 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
     hipLaunchKernelGGL(k_fxadv_edges, dim3((unsigned)g.nk), dim3(1024), 0, st, g, m, uc, vc, ut, vt, S);
   }
   const dim3 grid_fluxes(grid.x, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);
-  if (fluxes) hipLaunchKernelGGL(k_fxadv_fluxes, grid_fluxes, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box);
+  hipLaunchKernelGGL(k_fxadv_fluxes, grid_fluxes, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

@@ -4,7 +4,7 @@
 
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
-                 hipStream_t st, int part = 0, bool fluxes = true);
+                 hipStream_t st, int part = 0);
 int launch_fvtp2d(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry,
                   const real* xfx, const real* yfx, real* fx, real* fy, const real* xmf,
                   const real* ymf, int hord, int nlev, hipStream_t st);
@@ -66,10 +66,6 @@ struct DswWinds {
   real *u_out, *v_out, *heat_source;
   int do_skeb, copy_halo;
   double d_con;
-  // if ut != nullptr: the kernel also forms the Courant numbers / area fluxes from the contravariant winds (the flux half of
-  // FiniteVolumeFluxPrep), writes them to crx .. yfx and accumulates cx, cy
-  const real *ut, *vt;
-  real *cx, *cy;
 };
 bool dsw_scalars_take_winds();
 int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,

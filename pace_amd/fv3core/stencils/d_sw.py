@@ -161,13 +161,10 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         fields = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source,
                   diss_est)
         self._cfg.delp_out = self._cfg.pt_out = self._cfg.w_out = self._cfg.q_con_out = self._cfg.u_out = self._cfg.v_out = None
-        # (512: where the library forms the Courant numbers / area fluxes in its scalar kernel, the early part leaves them alone)
-        self._prep_deferred = 512 if self._wind_outputs and not os.environ.get("PACE_DSW_LATE_WINDS") else 0
-        self.lib.call("pace_d_sw_phases", 16 | self._prep_deferred, C.byref(self._geom), *self._args(fields, dt), self.stream())
+        self.lib.call("pace_d_sw_phases", 16, C.byref(self._geom), *self._args(fields, dt), self.stream())
         self._prep_started = True
 
     _prep_started = False
-    _prep_deferred = 0
 
     def __call__(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh,
                  heat_source, diss_est, dt, overlap_winds: bool = False, skip_dead_outputs: bool = False):
@@ -187,7 +184,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         self._cfg.flags = _lib.DSW_SKIP_DEAD_OUTPUTS if skip_dead_outputs else 0
         args = self._args(fields, dt)
         # flux preparation: everything (1), or only its frame (32) if start_flux_preparation did the interior box (16)
-        prep = (32 | self._prep_deferred) if self._prep_started else 1
+        prep = 32 if self._prep_started else 1
         self._prep_started = False
 
         def phases(mask, stream_ptr):

@@ -48,8 +48,7 @@ inline void __threadfence_block() {}
 inline void __threadfence() {}
 // `mode` is per launch site: 0 = not known yet, 1 = the kernel never synchronises (threads run as plain calls),
 // 2 = it does (threads run as fibers).  A kernel that hits __syncthreads() in plain mode is restarted with fibers;
-// that is safe as long as nothing before a kernel's first barrier modifies global memory non-idempotently (plain stores are
-// fine; a kernel that accumulates in memory there is launched with hipLaunchKernelGGL_barriers below).
+// that is safe because nothing but LDS is written before a kernel's first barrier.
 // `name` is what the SIGSEGV reporter prints (PACE_EMU_GUARD=1: tests/guard.py puts every array against an inaccessible
 // page, so an out-of-bounds access of a kernel faults here instead of only on the GPU).
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode, const char* name);
@@ -57,14 +56,6 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* m
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                      \
   do {                                                                                    \
     static int emu_mode__ = 0;                                                            \
-    emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); }, &emu_mode__, #kernel);    \
-  } while (0)
-
-// For a kernel that is known to synchronise AND modifies global memory (read-modify-write) before its first barrier: no plain
-// probe run of its first thread, fibers from the start.
-#define hipLaunchKernelGGL_barriers(kernel, grid, block, shmem, stream, ...)             \
-  do {                                                                                    \
-    static int emu_mode__ = 2;                                                            \
     emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); }, &emu_mode__, #kernel);    \
   } while (0)
 
