@@ -812,8 +812,23 @@ def main():
         if not args.no_traffic and world == 1:
             torch.cuda.synchronize()
             traffic, traffic_detail = measure_traffic(roof_names, n, nz, args.precision)
-        # what this memory system sustains on a plain device-to-device copy (read + write of 1 GiB each way), next to the spec
-        # peak the fractions are priced against
+        # what this memory system sustains on plain streams, next to the spec peak the fractions are priced against (SURVEY.md
+        # section 8d): this repo's own read / write / copy kernels at 16 bytes per lane over 1 GiB buffers (tools/ubench/streams.hip,
+        # built by __graft_entry__.build() into build/ubench_streams and run here as a child process), and torch's copy_
+        streams = None
+        try:
+            import subprocess
+
+            exe = os.path.join(ROOT, "build", "ubench_streams")
+            if os.path.exists(exe):
+                torch.cuda.synchronize()
+                txt = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+                rows = {ln[:28].strip(): ln[28:].split() for ln in txt.splitlines() if ln[:5] in ("read ", "write", "copy ")}
+                streams = {"read_16B_per_lane": 1e3 * float(rows["read  16 B/lane"][0]), "write_16B_per_lane": 1e3 * float(rows["write 16 B/lane"][0]),
+                           "copy_16B_per_lane": 1e3 * float(rows["copy  16 B/lane"][0]), "read_8B_per_lane": 1e3 * float(rows["read   8 B/lane"][0]),
+                           "copy_8B_per_lane": 1e3 * float(rows["copy   8 B/lane"][0]), "unit": "GB/s, plain grid, median of 5"}
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench] stream micro-benchmark failed: {e!r}\n")
         try:
             src = torch.empty(1 << 27, dtype=torch.float64, device=dev).normal_()
             dst = torch.empty_like(src)
@@ -825,19 +840,23 @@ def main():
                 dst.copy_(src)
             c1.record()
             torch.cuda.synchronize()
-            copy_gbs = 10 * 2 * src.numel() * 8 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            torch_copy_gbs = 10 * 2 * src.numel() * 8 / (c0.elapsed_time(c1) * 1e-3) / 1e9
             del src, dst
         except Exception:  # noqa: BLE001
-            copy_gbs = None
+            torch_copy_gbs = None
+        copy_gbs = streams["copy_16B_per_lane"] if streams else torch_copy_gbs
         roof = {"kernel": roof_kernel, "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "measured_copy_GBs": copy_gbs,
+                "measured_copy_GBs": copy_gbs, "measured_streams": streams, "torch_copy_GBs": torch_copy_gbs,
                 "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                 "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo, "algorithmic_fields": algo_fields,
-                "where_in_the_step": ("the step's longest launch (a third of it); timed here exactly as the step launches it, alone" if fused else
+                "where_in_the_step": ("the step's longest launch (more than half of it); timed here alone, exactly as the step launches it "
+                                      "(pace_d_sw_phases 256: on the kinetic energy / vorticities the last step left in the workspace)" if winds_fused else
+                                      "the step's longest launch; timed here exactly as the step launches it, alone" if fused else
                                       "three of the step's launches are instances of this kernel; timed here alone, one scalar"),
-                "limited_by": ("instruction issue at two workgroups per CU (256 VGPRs: what keeps a tile's operands in registers across the "
-                               "four scalars) and the bytes it moves: its L2 misses are ~1.9 x the algorithmic bytes (footprint halos, "
-                               "face rows) -- DESIGN.md section 4" if fused else
+                "limited_by": ("its instruction stream: five transports + the wind update per tile are ~5 000 instructions per wave (45 % "
+                               "fp64, no FMA contraction: the results are bit-identical to the numpy oracle) on sixteen waves per CU -- the "
+                               "SIMDs' vector ports are ~75 % busy; its L2 misses (~1.5 x the algorithmic bytes) move at < 2 TB/s -- "
+                               "DESIGN.md section 4" if fused else
                                "the bytes it really moves (L2 misses ~1.5 x algorithmic at ~3.5 TB/s) -- DESIGN.md section 4")}
 
     if rank == 0:

@@ -103,7 +103,10 @@ __device__ __forceinline__ double lean_log(double x) {
   const double s_lo = fma(-s, d, f) * r;
   const double lm = fma(s * z, p, 2.0 * s_lo) + 2.0 * s;
   const double de = (double)e;
-  return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+  const double v = fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+  // a column that has gone bad (a negative pressure, dz >= 0 upstream) must not come back as a plausible finite number: what the
+  // library's log answers there -- NaN below zero, -inf at zero -- for one compare and one select (NaN and +inf pass through)
+  return x > 0.0 ? v : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
 }
 __device__ __forceinline__ double lean_exp(double x) {
   const double k = rint(x * 1.44269504088896338700e+00);
@@ -123,7 +126,9 @@ __device__ __forceinline__ double lean_exp(double x) {
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
+  // (k clamped: ldexp with an int from a huge or NaN k would be undefined; +-2000 saturates to inf / 0 like the library's exp)
+  const double kc = fmin(fmax(k, -2000.0), 2000.0);
+  return x != x ? x : ldexp(p, (int)kc);
 }
 template <int CG>
 __device__ __forceinline__ double col_log(double x) { return lean_log(x); }  // (one place to switch a solver back to the library)

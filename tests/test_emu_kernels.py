@@ -44,6 +44,19 @@ def test_riem_solver3_kernel_emulated(emu_lib, name):
         assert err < 5e-6, (k, err)  # overrides/standard.yaml:49-61
 
 
+def test_riem_solver3_bad_column_does_not_come_back_finite(emu_lib):
+    """the column solvers' own log / exp (k_riem3f.hip lean_log / lean_exp) answer what the library's do outside
+    their domain: a column whose pressure thickness has gone negative must come back non-finite, not as a plausible number that
+    the `finite` checks downstream would let through."""
+    fix = golden("riem_solver3_c12_tile0_call2.npz")
+    env = Env(emu_lib, "cpu", golden("grid_c12_tile0.npz"), 12, 79)
+    inp = expand_riem_fixture(fix)
+    inp["delp"][5, 5, :] = -np.abs(inp["delp"][5, 5, :])  # one bad column; its neighbours stay good
+    out = run_riem3(env, inp, bool(fix["last_call"]), float(fix["dt"]), float(fix["ptop"]))
+    assert not np.isfinite(out["ppe"][5, 5, :79]).all() or not np.isfinite(out["delz"][5, 5, :79]).all()
+    assert np.isfinite(out["ppe"][6, 5, :79]).all() and np.isfinite(out["delz"][6, 5, :79]).all()
+
+
 def test_in_checkpoints_hold_the_state_before_the_call(emu_lib):
     """AcousticDynamics overlaps the u / v and uc / vc halo exchanges with the interior of c_sw's first pass and
     of d_sw's flux preparation; with a checkpointer attached those early starts are skipped, so that "C_SW-In" / "D_SW-In" hold
