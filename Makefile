@@ -3,8 +3,8 @@
 # tests/emu/README.md).
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC := pace_amd/csrc
-SRCS := $(CSRC)/capi.hip $(CSRC)/k_fxadv.hip $(CSRC)/k_fvtp2d.hip $(CSRC)/k_fvt.hip $(CSRC)/k_delnflux.hip $(CSRC)/k_dsw.hip $(CSRC)/k_riem3.hip $(CSRC)/k_riem3f.hip $(CSRC)/k_sim1.hip $(CSRC)/k_ppm.hip $(CSRC)/k_csw.hip $(CSRC)/k_acoustic.hip $(CSRC)/k_halo.hip $(CSRC)/k_tracer.hip $(CSRC)/k_remap.hip $(CSRC)/k_l2e.hip $(CSRC)/k_dycore.hip $(CSRC)/k_stencils.hip
-HDRS := $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/delnflux_core.h $(CSRC)/fvt_core.h include/pace_hip.h
+SRCS := $(CSRC)/capi.hip $(CSRC)/k_fxadv.hip $(CSRC)/k_fvtp2d.hip $(CSRC)/k_fvt.hip $(CSRC)/k_fvt16.hip $(CSRC)/k_delnflux.hip $(CSRC)/k_dsw.hip $(CSRC)/k_riem3.hip $(CSRC)/k_riem3f.hip $(CSRC)/k_sim1.hip $(CSRC)/k_ppm.hip $(CSRC)/k_csw.hip $(CSRC)/k_acoustic.hip $(CSRC)/k_halo.hip $(CSRC)/k_tracer.hip $(CSRC)/k_remap.hip $(CSRC)/k_l2e.hip $(CSRC)/k_dycore.hip $(CSRC)/k_stencils.hip
+HDRS := $(CSRC)/k_fvt.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/delnflux_core.h $(CSRC)/fvt_core.h include/pace_hip.h
 # -ffp-contract=off: no FMA contraction, so horizontal stencils are bit-comparable with the numpy oracle.
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 OBJS := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))

@@ -41,8 +41,11 @@
 #define FVT_AVAILABLE 0
 #endif
 
+#ifndef FVT_NS
+#define FVT_NS fvt  // (k_fvt16.hip compiles the same source for a second tile shape in a namespace of its own)
+#endif
 #if FVT_AVAILABLE
-namespace fvt {
+namespace FVT_NS {
 
 constexpr int TI = FV_TI, TJ = FV_TJ;
 constexpr int C = 4;                       // cells per run
@@ -682,7 +685,8 @@ struct FvtTile {
 
 // DMODE: -1 transport only; 0 damping fluxes -> dp.fx2o / fy2o (+ dp.add2d, u / v update: the vorticity call of d_sw);
 // 1 damping fluxes added to the transport fluxes; 2 added mass-weighted; 3 damping of q -> dw / heat_s / diss_est only (w).
-// EPI 0: fluxes stored (or accumulated / turned into winds); 1: flux-form update of the cell stored.
+// EPI 0: fluxes stored (or accumulated / turned into winds); 1: flux-form update of the cell stored; 3 (with DMODE 0): the
+// height update of updatedzd stored (apply_height_fluxes, updatedzd.py:70-126).
 #ifndef FVT_STAMP
 #define FVT_STAMP(n)  // (tools/census/fvt_prof.hip: shader-clock stamps of one workgroup per level)
 #endif
@@ -811,6 +815,49 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
     }
   }
   FVT_STAMP(25);
+  if (EPI == 3) {
+    // apply_height_fluxes (updatedzd.py:70-126): the advected height from the transport's own fluxes over the area the cell has
+    // after the step, plus the damping increment -- to dp.qout (the neighbouring tiles still read the height field); the same
+    // expressions in the same order as k_fvtp2d.hip's epilogue.  The damping fluxes of the tile's faces go where the sweeps'
+    // inputs were (sqi as [TJ][PJ], sqj as [TJ + 1][TI]) once every sweep has read them.
+    static_assert(EPI != 3 || DMODE == 0, "the height epilogue takes the damping fluxes unmixed");
+    __syncthreads();
+    double* const ax2 = L.u.s.sqi;
+    double* const ay2 = L.u.s.sqj;
+    if (T.x_outer) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) ax2[T.xr * PJ + C * T.xg + f] = dvx[f];
+    }
+    if (T.y_outer) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) ay2[(C * T.yg + f) * TI + T.ycol - 3] = dvy[f];
+    }
+    __syncthreads();
+    int jj[NEC], ii[NEC];
+    unsigned c2[NEC];
+    double ar[NEC], x0[NEC], x1[NEC], y0[NEC], y1[NEC];
+    T.cell_places(jj, ii, c2);
+#pragma unroll
+    for (int t = 0; t < NEC; ++t) {
+      ar[t] = LDG(m.area, c2[t]);
+      x0[t] = LDG(xfx, kb8 + c2[t]);
+      x1[t] = LDG(xfx, kb8 + c2[t] + 8u);
+      y0[t] = LDG(yfx, kb8 + c2[t]);
+      y1[t] = LDG(yfx, kb8 + c2[t] + (unsigned)sj8);
+    }
+#pragma unroll
+    for (int t = 0; t < NEC; ++t) {
+      const double area = ar[t];
+      const double qv = L.sq[(jj[t] + 3) * P + ii[t] + 3];
+      const double* ax = L.u.s.ax + jj[t] * PJ + ii[t];
+      const double* ay = L.u.s.ay + jj[t] * TI + ii[t];
+      const double* bx = ax2 + jj[t] * PJ + ii[t];
+      const double* by = ay2 + jj[t] * TI + ii[t];
+      const double area_after = (area + x0[t] - x1[t]) + (area + y0[t] - y1[t]) - area;
+      const double adv = (qv * area + ax[0] - ax[1] + ay[0] - ay[TI]) / area_after;
+      STG(dp.qout, kb8 + c2[t]) = adv + (bx[0] - bx[1] + by[0] - by[TI]) / area;
+    }
+  }
   if (EPI == 1) {
     // apply_fluxes (d_sw.py:122-145): q * mass + the flux increment, one cell per lane, lanes along i
     __syncthreads();
@@ -1424,5 +1471,5 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
   FVT_STAMP(16);
 }
 
-}  // namespace fvt
+}  // namespace FVT_NS
 #endif  // FVT_AVAILABLE

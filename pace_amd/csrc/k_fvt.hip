@@ -1,9 +1,20 @@
 // FiniteVolumeTransport for the production tilings -- the lean form of k_fvtp2d.hip (same arithmetic, same bits).
 // (kernels and launchers; the device code and the design notes are in fvt_core.h)
+// This source is compiled twice: as itself for the 32 x 24 tile (C96, C192, C384: N a multiple of 32 and of 24) and through
+// k_fvt16.hip for a 16 x 24 tile (C48: N a multiple of 16 and of 24 only), each in a namespace of its own (the kernels' names
+// carry it); the functions the rest of the library calls (kernels.h) are defined here once and try the shapes in that order.
 #include "fvt_core.h"
 
+#ifndef FVT_SHAPE
+#define FVT_SHAPE 32
+#endif
+#define FVT_CAT_(a, b) a##b
+#define FVT_CAT(a, b) FVT_CAT_(a, b)
+#define FVT_FN(name) FVT_CAT(FVT_CAT(fvt, FVT_SHAPE), _##name)  // fvt32_covers, fvt16_launch_transport, ...
+
 #if FVT_AVAILABLE
-using namespace fvt;
+using namespace FVT_NS;
+namespace FVT_NS {
 
 #ifndef FVT_WAVES
 #define FVT_WAVES 3  // workgroups per CU the register budget of the single-scalar kernel is set for (168 VGPRs: at 128 the
@@ -56,8 +67,10 @@ __global__ void __launch_bounds__(FVT_SCALARS_NT) FVT_SCALARS_ATTR k_fvt_scalars
 #endif
 }
 
+}  // namespace FVT_NS
+
 template <int MORD>
-int fvt_launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g, const FvMet& m, const real* q, const real* crx,
+static int fvt_launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g, const FvMet& m, const real* q, const real* crx,
                     const real* cry, const real* xfx, const real* yfx, real* fx, real* fy, const real* xu, const real* yu,
                     const FvDamp& dp) {
 #define FVT_GO(D, E)                                                                                                         \
@@ -70,13 +83,14 @@ int fvt_launch_mode(int dmode, int epi, dim3 grid, hipStream_t st, const Geo& g,
   if (epi == 0 && dmode == 0) FVT_GO(0, 0);
   if (epi == 2 && dmode == 0) FVT_GO(3, 1);  // w: damping -> dw / heat_source / diss_est, plain transport -> cell update
   if (epi == 1 && dmode == 2) FVT_GO(2, 1);
+  if (epi == 3 && dmode == 0) FVT_GO(0, 3);  // updatedzd: transport + damping of the heights -> the height update
 #undef FVT_GO
   return PACE_ERR_UNSUPPORTED;
 }
 
 #endif  // FVT_AVAILABLE
 
-bool transport_lean_covers(const Geo& g, int hord) {
+bool FVT_FN(covers)(const Geo& g, int hord) {
 #if FVT_AVAILABLE
   return (hord == 5 || hord == 6) && g.n % TI == 0 && g.n % TJ == 0 && g.n >= 2 * TI && g.n >= 2 * TJ && (g.sj & 1) == 0 && (g.sk & 1) == 0;
 #else
@@ -87,11 +101,11 @@ bool transport_lean_covers(const Geo& g, int hord) {
 
 // Same contract as launch_transport (k_fvtp2d.hip), for the calls this kernel covers; PACE_ERR_UNSUPPORTED otherwise (the
 // caller then takes the general kernel).  xmf / ymf resolved by the caller: xu / yu are the unit fluxes.
-int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
-                          const real* yfx, real* fx, real* fy, const real* xu, const real* yu, int hord, int nlev, int dmode,
-                          int epi, const FvDamp& dp, hipStream_t st) {
+int FVT_FN(launch_transport)(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
+                             const real* yfx, real* fx, real* fy, const real* xu, const real* yu, int hord, int nlev, int dmode,
+                             int epi, const FvDamp& dp, hipStream_t st) {
 #if FVT_AVAILABLE
-  if (!transport_lean_covers(g, hord) || ((uintptr_t)q & 15) != 0) return PACE_ERR_UNSUPPORTED;  // (16-byte rows of the footprint)
+  if (!FVT_FN(covers)(g, hord) || ((uintptr_t)q & 15) != 0) return PACE_ERR_UNSUPPORTED;  // (16-byte rows of the footprint)
   if (dmode >= 0 && dp.nmax > 2) return PACE_ERR_UNSUPPORTED;
   const dim3 grid(g.n / TI, g.n / TJ, nlev);
   const FvMet fm = fv_met(m);
@@ -111,7 +125,7 @@ int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real*
 // (NCOL arrays of nk + 1).  outs[4] = delp, pt, w, q_con outputs, distinct from the inputs.  PACE_ERR_UNSUPPORTED if the geometry /
 // orders are not covered (the caller then runs the scalars one by one).
 // whether the scalar-phase kernel can take the winds as its fifth pass (the 512-thread form)
-bool dsw_scalars_take_winds() {
+bool FVT_FN(take_winds)() {
 #if FVT_AVAILABLE && FVT_SCALARS_NT == 512
   return true;
 #else
@@ -119,13 +133,13 @@ bool dsw_scalars_take_winds() {
 #endif
 }
 
-int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,
-                            real* const* outs, const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx,
-                            real* mfy, real* dw, real* heat_s, real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w,
-                            int nmax_t, double dt, hipStream_t st, const DswWinds* winds) {
+int FVT_FN(launch_scalars)(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,
+                           real* const* outs, const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx,
+                           real* mfy, real* dw, real* heat_s, real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w,
+                           int nmax_t, double dt, hipStream_t st, const DswWinds* winds) {
 #if FVT_AVAILABLE
-  if (!transport_lean_covers(g, hord) || nmax_v > 2 || nmax_w > 2 || nmax_t > 2) return PACE_ERR_UNSUPPORTED;
-  if (winds && !dsw_scalars_take_winds()) return PACE_ERR_UNSUPPORTED;
+  if (!FVT_FN(covers)(g, hord) || nmax_v > 2 || nmax_w > 2 || nmax_t > 2) return PACE_ERR_UNSUPPORTED;
+  if (winds && !FVT_FN(take_winds)()) return PACE_ERR_UNSUPPORTED;
   const real* ins[4] = {delp, pt, w, q_con};
   for (int n = 0; n < 4; ++n)
     if (((uintptr_t)ins[n] & 15) != 0 || outs[n] == nullptr || outs[n] == ins[n]) return PACE_ERR_UNSUPPORTED;
@@ -162,3 +176,35 @@ int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const 
   return PACE_ERR_UNSUPPORTED;
 #endif
 }
+
+#if FVT_SHAPE == 32
+// ---- what the rest of the library calls: the 32 x 24 tile where it tiles the domain, else the 16 x 24 one (k_fvt16.hip) ----
+bool fvt16_covers(const Geo& g, int hord);
+bool fvt16_take_winds();
+int fvt16_launch_transport(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx, const real* yfx,
+                           real* fx, real* fy, const real* xu, const real* yu, int hord, int nlev, int dmode, int epi, const FvDamp& dp,
+                           hipStream_t st);
+int fvt16_launch_scalars(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con, real* const* outs,
+                         const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx, real* mfy, real* dw, real* heat_s,
+                         real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w, int nmax_t, double dt, hipStream_t st,
+                         const DswWinds* winds);
+
+bool transport_lean_covers(const Geo& g, int hord) { return fvt32_covers(g, hord) || fvt16_covers(g, hord); }
+bool dsw_scalars_take_winds() { return fvt32_take_winds(); }  // (both shapes are compiled from the same source with the same form)
+int launch_transport_lean(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry, const real* xfx,
+                          const real* yfx, real* fx, real* fy, const real* xu, const real* yu, int hord, int nlev, int dmode,
+                          int epi, const FvDamp& dp, hipStream_t st) {
+  if (fvt32_covers(g, hord)) return fvt32_launch_transport(g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, hord, nlev, dmode, epi, dp, st);
+  return fvt16_launch_transport(g, m, q, crx, cry, xfx, yfx, fx, fy, xu, yu, hord, nlev, dmode, epi, dp, st);
+}
+int launch_dsw_scalars_lean(const Geo& g, const Met& m, const real* delp, const real* pt, const real* w, const real* q_con,
+                            real* const* outs, const real* crx, const real* cry, const real* xfx, const real* yfx, real* mfx,
+                            real* mfy, real* dw, real* heat_s, real* diss_est, const real* kc, int hord, int nmax_v, int nmax_w,
+                            int nmax_t, double dt, hipStream_t st, const DswWinds* winds) {
+  if (fvt32_covers(g, hord))
+    return fvt32_launch_scalars(g, m, delp, pt, w, q_con, outs, crx, cry, xfx, yfx, mfx, mfy, dw, heat_s, diss_est, kc, hord, nmax_v, nmax_w,
+                                nmax_t, dt, st, winds);
+  return fvt16_launch_scalars(g, m, delp, pt, w, q_con, outs, crx, cry, xfx, yfx, mfx, mfy, dw, heat_s, diss_est, kc, hord, nmax_v, nmax_w,
+                              nmax_t, dt, st, winds);
+}
+#endif

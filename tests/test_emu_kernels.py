@@ -369,6 +369,32 @@ def test_d_sw_canonical_edge_tiling_vs_oracle(cfg):
         assert np.array_equal(a[k][W], out[k][W]), (k, compare(a[k][W], out[k][W]))
 
 
+def test_d_sw_c48_takes_the_16_x_24_tile_shape_vs_oracle(emu_lib):
+    """C48 (BASELINE configuration 2) is a multiple of 16 and of 24 but not of 32: the lean transport / scalar-phase kernels are
+    compiled a second time for a 16 x 24 tile (csrc/k_fvt16.hip).  All of d_sw at C48 x 3 with the default emulation build (its
+    tile shapes are the product's), against the oracle, exactly; and the library really took the fused path."""
+    from helpers import DSW_CFG, oracle_grid
+    from oracle import dgrid_sw
+    from pace_amd import synthetic
+
+    n, nz = 48, 3
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    col = column_for_levels(np.arange(nz))
+    env = Env(emu_lib, "cpu", metrics, n, nz)
+    out, op = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"], cfg=DSW_CFG)
+    import ctypes as C
+
+    assert emu_lib.cdll.pace_d_sw_wind_outputs_supported(C.byref(op._geom), C.byref(op._cfg)) == 1
+    g = oracle_grid(metrics, n, nz)
+    a = {k: s[k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(g, col, DSW_CFG, dgrid_sw.DSWState(s["u"].shape), *[a[k] for k in DSW_ARGS], s["dt"])
+    for k in DSW_ARGS:
+        if k != "zh":
+            W = dsw_window(k, n, nz)
+            assert np.array_equal(a[k][W], out[k][W]), (k, compare(a[k][W], out[k][W]))
+
+
 @pytest.mark.parametrize("which", ["big", "small"])
 def test_ord8_transport_emulated_vs_oracle(emu_lib, emu_small_lib, which):
     """Monotone (ord 8) PPM transport against the oracle, bit for bit, with both tilings."""

@@ -49,7 +49,10 @@ def build_ops(n, nz):
     csw = CGridShallowWaterDynamics(sf, qf, gd, False, 0, 3)
     zc = UpdateGeopotentialHeightOnCGrid(sf, qf, gd.area, gd.dp_ref)
     rc = NonhydrostaticVerticalSolverCGrid(sf, qf, 0.05)
-    dsw = DGridShallowWaterLagrangianDynamics(sf, qf, gd, dc, col, False, False, DGridShallowWaterLagrangianDynamicsConfig())
+    # (as AcousticDynamics constructs and calls it: the transported scalars and the winds to spare buffers that are swapped in, the
+    # divergence damping's dead work fields skipped)
+    dsw = DGridShallowWaterLagrangianDynamics(sf, qf, gd, dc, col, False, False, DGridShallowWaterLagrangianDynamicsConfig(),
+                                              swap_scalar_storage=True)
     zd = UpdateHeightOnDGrid(sf, qf, dc, gd, 0, 6, col)
     r3 = NonhydrostaticVerticalSolver(sf, qf, RiemannConfig())
     nh = NonHydrostaticPressureGradient(sf, qf, gd, 0)
@@ -71,7 +74,7 @@ def build_ops(n, nz):
         ("updatedzc", lambda: zc(zs, ut, vt, gz, ws3, dt2)),
         ("riem_solver_c", lambda: rc(dt2, f["cappa"], ptop, phis, ws3, csw.ptc, f["q_con"], csw.delpc, gz, f["ppe"], omga)),
         ("p_grad_c", lambda: call("pace_p_grad_c", C.byref(csw._met), f["uc"].ptr, f["vc"].ptr, csw.delpc.ptr, f["ppe"].ptr, gz.ptr, dt2, st())),
-        ("d_sw", lambda: dsw(*[f[k] if k != "delpc" else vt for k in DSW_ARGS], dt)),
+        ("d_sw", lambda: dsw(*[f[k] if k != "delpc" else vt for k in DSW_ARGS], dt, skip_dead_outputs=True)),
         ("updatedzd", lambda: zd(zs, f["zh"], f["crx"], f["cry"], f["xfx"], f["yfx"], wsd, dt)),
         ("riem_solver3", lambda: r3(False, dt, f["cappa"], ptop, zs, wsd, f["delz"], f["q_con"], f["delp"], f["pt"], f["zh"], f["pe"],
                                     f["ppe"], f["pk3"], f["pk"], f["peln"], f["w"])),
@@ -120,15 +123,29 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[name].append(e0.elapsed_time(e1) * 1e3)
-    tot = 0.0
+    # distinct 3-D fields per operator, each once per direction (the convention of SURVEY.md section 8d; 2-D / K fields ~ 0):
+    #   c_sw: delp, pt, u, v, w -> delpc, ptc, uc, vc, ua, va, ut, vt, divgd, w3;  updatedzc: ut, vt, gz -> gz;
+    #   riem_solver_c: cappa, ptc, q_con, delpc, gz, w3 -> gz, pef;  p_grad_c: uc, vc, delpc, pkc, gz -> uc, vc;
+    #   d_sw: 16 -> 16;  updatedzd: zh, crx, cry, xfx, yfx -> zh;  riem_solver3: 7 -> 6;  nh_p_grad: u, v, pp, gz, pk3, delp -> u, v;
+    #   pk3_halo / ray_fast touch halo rows / sponge levels only (no figure)
+    fields = {"c_sw": 15, "copy zh->gz": 2, "updatedzc": 4, "riem_solver_c": 8, "p_grad_c": 7, "d_sw": 32, "updatedzd": 6, "riem_solver3": 13,
+              "compute_geopotential": 2, "nh_p_grad": 8}
+    item = 8 if PRECISION == 64 else 4
+    cells = n * n * nz
+    tot = tot_mb = 0.0
     print(f"single-tile acoustic substep, C{n} x {nz}  (NaN fraction in w after one pass: {nanfrac:.2e})")
-    print(f"{'operator':24s} {'us':>10s}")
+    print(f"{'operator':24s} {'us':>10s} {'algorithmic MB':>15s} {'GB/s':>8s} {'% of 8 TB/s':>12s}")
     for name, _ in ops:
         us = float(np.median(times[name]))
         tot += us
-        print(f"{name:24s} {us:10.1f}")
-    cells = n * n * nz
-    print(f"{'total':24s} {tot:10.1f}   -> {cells / tot * 1e6 / 1e9:.2f} G cell-updates/s for the whole loop body")
+        if name in fields:
+            mb = fields[name] * item * cells / 1e6
+            tot_mb += mb
+            print(f"{name:24s} {us:10.1f} {mb:15.1f} {mb / us * 1e3:8.0f} {100 * mb / us * 1e3 / 8000:11.1f}%")
+        else:
+            print(f"{name:24s} {us:10.1f}")
+    print(f"{'total':24s} {tot:10.1f} {tot_mb:15.1f} {tot_mb / tot * 1e3:8.0f} {100 * tot_mb / tot * 1e3 / 8000:11.1f}%   -> "
+          f"{cells / tot * 1e6 / 1e9:.2f} G cell-updates/s for the whole loop body")
 
 
 if __name__ == "__main__":
