@@ -34,7 +34,7 @@
 #endif
 #include "delnflux_core.h"
 
-#if !defined(PACE_REAL_FLOAT) && (FV_TI % 4 == 0) && (FV_TJ % 4 == 0) && (FV_TI >= 8) && (FV_TJ >= 8) && (DN_TI == FV_TI) && \
+#if (FV_TI % 4 == 0) && (FV_TJ % 4 == 0) && (FV_TI >= 8) && (FV_TJ >= 8) && (DN_TI == FV_TI) && \
     (DN_TJ == FV_TJ) && ((FV_TI + 6) * (FV_TJ / 4) <= 256) && ((FV_TJ + 6) * (FV_TI / 4) <= 256)
 #define FVT_AVAILABLE 1
 #else
@@ -60,8 +60,13 @@ constexpr int NEC = (TI * TJ + 255) / 256;  // cells per thread in the cell upda
 static_assert(DW == QW && DH == QH && DWP == P, "the damping core shares the footprint");
 static_assert(GXN >= 2 && GYN >= 2, "the first and the last run of a row / column must be different runs");
 
+constexpr int RB = (int)sizeof(real);  // bytes per stored element (8; 4 in the float32-storage build: arithmetic is double in both)
+
 struct alignas(16) D2 {
   double x, y;
+};
+struct alignas(2 * sizeof(real)) RealPair {  // two neighbouring elements as they are stored: one 16-byte (float32: 8-byte) load
+  real x, y;
 };
 
 struct FvtLds {
@@ -197,12 +202,15 @@ struct FvtPiecesT {
     for (int p = 0; p < NP; ++p) {
       row[p] = lr + RPP * p;
       if (row[p] >= QH) row[p] = QH - 1;
-      off[p] = (unsigned)((jlo + row[p]) * sj8 + (ilo + 2 * lc) * 8);
+      off[p] = (unsigned)((jlo + row[p]) * sj8 + (ilo + 2 * lc) * RB);
     }
   }
   __device__ __forceinline__ void load(const real* src, D2* v) const {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) v[p] = *(const D2*)((const char*)src + off[p]);
+    for (int p = 0; p < NP; ++p) {
+      const RealPair r = *(const RealPair*)((const char*)src + off[p]);
+      v[p].x = r.x, v[p].y = r.y;
+    }
   }
   __device__ __forceinline__ void store(double* plane, const D2* v) const {
 #pragma unroll
@@ -255,8 +263,8 @@ struct FvtTile {
     k = k_;
     i0 = g.is + bx * TI, j0 = g.js + by * TJ;
     ilo = i0 - 3, jlo = j0 - 3;
-    sj8 = g.sj * 8;
-    kb8 = (unsigned)((long)k * g.sk * 8);
+    sj8 = g.sj * RB;
+    kb8 = (unsigned)((long)k * g.sk * RB);
     // which edges of the cubed-sphere tile this workgroup tile holds (one per axis at most: >= 2 tiles each way)
     west = EX && bx == 0, east = EX && !west;
     south = EY && by == 0, north = EY && !south;
@@ -281,8 +289,8 @@ struct FvtTile {
     if (!x_on) xrow = 0;
     ybase = (C * yg) * P + ycol;
     xbase = xrow * P + C * xg;
-    yoff = (unsigned)((j0 + C * yg) * sj8 + (ilo + ycol) * 8);
-    xoff = (unsigned)((jlo + xrow) * sj8 + (i0 + C * xg) * 8);
+    yoff = (unsigned)((j0 + C * yg) * sj8 + (ilo + ycol) * RB);
+    xoff = (unsigned)((jlo + xrow) * sj8 + (i0 + C * xg) * RB);
     pc.init(tid, ilo, jlo, sj8);
     const int dr = tid / QW;
     dc = tid - dr * QW;
@@ -321,7 +329,7 @@ struct FvtTile {
   __device__ __forceinline__ double corner_fix(const double* src, double d0) const {
     auto rd = [&](int o) { return o >= 0 ? (FIRST ? d0 * src[o] : src[o]) : 0.0; };
     auto sgn = [&](double x) { return FIRST ? x : -x; };
-    const double ra = LDG(m.rarea, (unsigned)((jlo + fx_at / P) * sj8 + (ilo + fx_at % P) * 8));
+    const double ra = LDG(m.rarea, (unsigned)((jlo + fx_at / P) * sj8 + (ilo + fx_at % P) * RB));
     const double xm = rd(fx_src[0]), xc = rd(fx_src[1]), xp = rd(fx_src[2]), ym = rd(fx_src[3]), yc = rd(fx_src[4]), yp = rd(fx_src[5]);
     const double fw = sgn(sdv[fx_at] * (xm - xc));
     const double fe = sgn(sdv[fx_at + 1] * (xc - xp));
@@ -352,7 +360,7 @@ struct FvtTile {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int gi = ilo + 2 * pc.lc + e;
-          if (pc.own(p) && (rowout || gi < g.is || gi > g.ie)) STG(halo_out, pc.off[p] + (unsigned)(8 * e)) = e == 0 ? v[p].x : v[p].y;
+          if (pc.own(p) && (rowout || gi < g.is || gi > g.ie)) STG(halo_out, pc.off[p] + (unsigned)(RB * e)) = e == 0 ? v[p].x : v[p].y;
         }
       }
     }
@@ -368,7 +376,7 @@ struct FvtTile {
           if ((gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) {
             int ri = gi, rj = gj;
             remap_agrid_y(g, ri, rj);
-            L.sq[pc.row[p] * P + 2 * pc.lc + e] = LDG(q, (unsigned)(rj * sj8 + ri * 8));
+            L.sq[pc.row[p] * P + 2 * pc.lc + e] = LDG(q, (unsigned)(rj * sj8 + ri * RB));
           }
         }
       }
@@ -376,7 +384,7 @@ struct FvtTile {
         const int b = tid / 3, a = tid - b * 3;
         int ri = (west ? g.is - 3 : g.ie + 1) + a, rj = (south ? g.js - 3 : g.je + 1) + b;
         remap_agrid_x(g, ri, rj);
-        L.sqc[tid] = LDG(q, (unsigned)(rj * sj8 + ri * 8));
+        L.sqc[tid] = LDG(q, (unsigned)(rj * sj8 + ri * RB));
       }
     }
   }
@@ -397,7 +405,7 @@ struct FvtTile {
     for (int t = 0; t < DRC; ++t) {
       int row = dr0 + t;
       if (QH % DRC != 0 && row >= QH) row = QH - 1;
-      dra[t] = LDG(m.rarea, (unsigned)((jlo + row) * sj8 + (ilo + dc) * 8));
+      dra[t] = LDG(m.rarea, (unsigned)((jlo + row) * sj8 + (ilo + dc) * RB));
     }
   }
   // the transported scalar is q + add2d (absolute vorticity), the damped one was q: every thread adds to the pieces it loaded.
@@ -415,7 +423,7 @@ struct FvtTile {
             int gi = ilo + 2 * pc.lc + e, gj = jlo + pc.row[p];
             if ((gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) {
               remap_agrid_y(g, gi, gj);
-              add = LDG(add2d, (unsigned)(gj * sj8 + gi * 8));
+              add = LDG(add2d, (unsigned)(gj * sj8 + gi * RB));
             }
           }
           L.sq[pc.row[p] * P + 2 * pc.lc + e] = L.sq[pc.row[p] * P + 2 * pc.lc + e] + add;
@@ -426,7 +434,7 @@ struct FvtTile {
       const int b = tid / 3, a = tid - b * 3;
       int ri = (west ? g.is - 3 : g.ie + 1) + a, rj = (south ? g.js - 3 : g.je + 1) + b;
       remap_agrid_x(g, ri, rj);
-      L.sqc[tid] = L.sqc[tid] + LDG(add2d, (unsigned)(rj * sj8 + ri * 8));
+      L.sqc[tid] = L.sqc[tid] + LDG(add2d, (unsigned)(rj * sj8 + ri * RB));
     }
     __syncthreads();
   }
@@ -496,7 +504,7 @@ struct FvtTile {
       for (int t = 0; t < DRC; ++t) {
         const int jj = dr0 + t;
         if (jj >= 3 && jj < TJ + 3) {
-          const unsigned c = (unsigned)((jlo + jj) * sj8 + (ilo + dc) * 8);
+          const unsigned c = (unsigned)((jlo + jj) * sj8 + (ilo + dc) * RB);
           double hs = 0.0;
           if (on) {
             const double d = res[t];
@@ -523,7 +531,7 @@ struct FvtTile {
 #pragma unroll
       for (int f = 0; f < NF; ++f) cy[f] = LDG(cry, yoff + (unsigned)(f * sj8));
       FvtSpacing sp;
-      if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
+      if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * RB), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
       fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, si_y);
       FVT_FENCE();
 #pragma unroll
@@ -552,15 +560,15 @@ struct FvtTile {
         }
       }
 #pragma unroll
-      for (int f = 0; f < NF; ++f) cx[f] = LDG(crx, xoff + (unsigned)(f * 8));
+      for (int f = 0; f < NF; ++f) cx[f] = LDG(crx, xoff + (unsigned)(f * RB));
       FvtSpacing sp;
-      if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
+      if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), RB, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
       fvt_run<MORD, EX>(Q, cx, west && xg == 0, east && xg == GXN - 1, sp, si_x);
       FVT_FENCE();
 #pragma unroll
-      for (int f = 0; f < NF; ++f) xf[f] = LDG(xfx, xoff + (unsigned)(f * 8));
+      for (int f = 0; f < NF; ++f) xf[f] = LDG(xfx, xoff + (unsigned)(f * RB));
 #pragma unroll
-      for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, xoff + (unsigned)(t * 8));
+      for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, xoff + (unsigned)(t * RB));
 #pragma unroll
       for (int t = 0; t < C; ++t)
         L.u.s.sqj[xrow * PJ + C * xg + t] = (Q[t + 3] * ar[t] + xf[t] * si_x[t] - xf[t + 1] * si_x[t + 1]) / (ar[t] + xf[t] - xf[t + 1]);
@@ -579,13 +587,13 @@ struct FvtTile {
     for (int f = 0; f < NF; ++f) {
       o.cy[f] = LDG(cry, yoff + (unsigned)(f * sj8));
       o.yf[f] = LDG(yfx, yoff + (unsigned)(f * sj8));
-      o.cx[f] = LDG(crx, xoff + (unsigned)(f * 8));
-      o.xf[f] = LDG(xfx, xoff + (unsigned)(f * 8));
+      o.cx[f] = LDG(crx, xoff + (unsigned)(f * RB));
+      o.xf[f] = LDG(xfx, xoff + (unsigned)(f * RB));
     }
 #pragma unroll
     for (int t = 0; t < C; ++t) {
       o.ary[t] = LDG(m.area, yoff + (unsigned)(t * sj8));
-      o.arx[t] = LDG(m.area, xoff + (unsigned)(t * 8));
+      o.arx[t] = LDG(m.area, xoff + (unsigned)(t * RB));
     }
   }
   // stage I with the operands given.  Ends with a barrier.
@@ -596,7 +604,7 @@ struct FvtTile {
 #pragma unroll
       for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[ybase + u * P];
       FvtSpacing sp;
-      if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
+      if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * RB), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
       fvt_run<MORD, EY>(Q, o.cy, south && yg == 0, north && yg == GYN - 1, sp, si_y);
 #pragma unroll
       for (int t = 0; t < C; ++t)
@@ -619,7 +627,7 @@ struct FvtTile {
         }
       }
       FvtSpacing sp;
-      if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
+      if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), RB, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
       fvt_run<MORD, EX>(Q, o.cx, west && xg == 0, east && xg == GXN - 1, sp, si_x);
 #pragma unroll
       for (int t = 0; t < C; ++t)
@@ -635,7 +643,7 @@ struct FvtTile {
 #pragma unroll
     for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqi[xr * P + C * xg + u];
     FvtSpacing sp;
-    if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), 8, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
+    if (EX) sp = fvt_spacing(m.dxa, (unsigned)((jlo + xrow) * sj8), RB, g.is, g.ie, west && xg == 0, east && xg == GXN - 1);
     fvt_run<MORD, EX>(Q, cx, west && xg == 0, east && xg == GXN - 1, sp, out);
 #pragma unroll
     for (int f = 0; f < NF; ++f) mean[f] = 0.5 * (out[f] + si_x[f]);
@@ -646,7 +654,7 @@ struct FvtTile {
 #pragma unroll
     for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqj[(C * yg + u) * PJ + ycol - 3];
     FvtSpacing sp;
-    if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * 8), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
+    if (EY) sp = fvt_spacing(m.dya, (unsigned)((ilo + ycol) * RB), sj8, g.js, g.je, south && yg == 0, north && yg == GYN - 1);
     fvt_run<MORD, EY>(Q, cy, south && yg == 0, north && yg == GYN - 1, sp, out);
 #pragma unroll
     for (int f = 0; f < NF; ++f) mean[f] = 0.5 * (out[f] + si_y[f]);
@@ -666,7 +674,7 @@ struct FvtTile {
       int e = tid + NT * t;
       if (e >= TI * TJ) e = TI * TJ - 1;  // (spare lanes repeat the last cell)
       jj[t] = e / TI, ii[t] = e - jj[t] * TI;
-      c2[t] = (unsigned)((j0 + jj[t]) * sj8 + (i0 + ii[t]) * 8);
+      c2[t] = (unsigned)((j0 + jj[t]) * sj8 + (i0 + ii[t]) * RB);
     }
   }
   // q * mass + the flux increment (apply_fluxes, d_sw.py:122-145) of cell t from the fluxes in ax / ay
@@ -725,10 +733,10 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
   if (T.x_outer) {
     double v[NF], xu[NF], ms[NF + 1];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) xu[f] = LDG(xunit, kb8 + T.xoff + (unsigned)(f * 8));
+    for (int f = 0; f < NF; ++f) xu[f] = LDG(xunit, kb8 + T.xoff + (unsigned)(f * RB));
     if (DMODE == 2) {
 #pragma unroll
-      for (int t = 0; t <= NF; ++t) ms[t] = LDG(dp.mass, kb8 + T.xoff + (unsigned)((t - 1) * 8));
+      for (int t = 0; t <= NF; ++t) ms[t] = LDG(dp.mass, kb8 + T.xoff + (unsigned)((t - 1) * RB));
     }
     T.outer_x(cx, si_x, v);
 #pragma unroll
@@ -744,20 +752,20 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
       if (dp.v_upd) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          w0[f] = LDG(dp.v_upd, kb8 + T.xoff + (unsigned)(f * 8));
-          w1[f] = LDG(m.dy, T.xoff + (unsigned)(f * 8));
-          w2[f] = LDG(dp.ke, kb8 + T.xoff + (unsigned)(f * 8));
-          w3[f] = LDG(dp.ke, kb8 + T.xoff + (unsigned)(f * 8 + sj8));
+          w0[f] = LDG(dp.v_upd, kb8 + T.xoff + (unsigned)(f * RB));
+          w1[f] = LDG(m.dy, T.xoff + (unsigned)(f * RB));
+          w2[f] = LDG(dp.ke, kb8 + T.xoff + (unsigned)(f * RB));
+          w3[f] = LDG(dp.ke, kb8 + T.xoff + (unsigned)(f * RB + sj8));
         }
       }
       if (dp.accx) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) wa[f] = LDG(dp.accx, kb8 + T.xoff + (unsigned)(f * 8));
+        for (int f = 0; f < NF; ++f) wa[f] = LDG(dp.accx, kb8 + T.xoff + (unsigned)(f * RB));
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         if (f < C || last) {
-          const unsigned c = kb8 + T.xoff + (unsigned)(f * 8);
+          const unsigned c = kb8 + T.xoff + (unsigned)(f * RB);
           if (DMODE == 0) STG(dp.fx2o, c) = dvx[f];
           if (dp.v_upd) STG(dp.v_out ? dp.v_out : dp.v_upd, c) = w0[f] * w1[f] + w2[f] - w3[f] - v[f];  // v_from_ke (d_sw.py:423-436)
           else STG(fx, c) = v[f];
@@ -793,7 +801,7 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
           w0[f] = LDG(dp.u_upd, kb8 + T.yoff + (unsigned)(f * sj8));
           w1[f] = LDG(m.dx, T.yoff + (unsigned)(f * sj8));
           w2[f] = LDG(dp.ke, kb8 + T.yoff + (unsigned)(f * sj8));
-          w3[f] = LDG(dp.ke, kb8 + T.yoff + (unsigned)(f * sj8 + 8));
+          w3[f] = LDG(dp.ke, kb8 + T.yoff + (unsigned)(f * sj8 + RB));
         }
       }
       if (dp.accy) {
@@ -841,7 +849,7 @@ __device__ __forceinline__ void fvt_tile(FvtLds& L, const Geo& g, const FvMet& m
     for (int t = 0; t < NEC; ++t) {
       ar[t] = LDG(m.area, c2[t]);
       x0[t] = LDG(xfx, kb8 + c2[t]);
-      x1[t] = LDG(xfx, kb8 + c2[t] + 8u);
+      x1[t] = LDG(xfx, kb8 + c2[t] + (unsigned)RB);
       y0[t] = LDG(yfx, kb8 + c2[t]);
       y1[t] = LDG(yfx, kb8 + c2[t] + (unsigned)sj8);
     }
@@ -927,8 +935,8 @@ __device__ __forceinline__ void fvt_scalars_tile(FvtLdsScalars& LS, const Geo& g
   for (int f = 0; f < NF; ++f) {
     cy[f] = LDG(S.cry + kb, T.yoff + (unsigned)(f * sj8));
     yf[f] = LDG(S.yfx + kb, T.yoff + (unsigned)(f * sj8));
-    cx[f] = LDG(S.crx + kb, T.xoff + (unsigned)(f * 8));
-    xf[f] = LDG(S.xfx + kb, T.xoff + (unsigned)(f * 8));
+    cx[f] = LDG(S.crx + kb, T.xoff + (unsigned)(f * RB));
+    xf[f] = LDG(S.xfx + kb, T.xoff + (unsigned)(f * RB));
   }
   double mfx[NF], mfy[NF];  // the mass fluxes through them (unit fluxes of w, q_con, pt)
   double dn[NEC];           // the new mass of the thread's cells
@@ -978,7 +986,7 @@ __device__ __forceinline__ void fvt_scalars_tile(FvtLdsScalars& LS, const Geo& g
 #pragma unroll
       for (int t = 0; t < C; ++t) {
         O.ary[t] = LDG(m.area, T.yoff + (unsigned)(t * sj8));
-        O.arx[t] = LDG(m.area, T.xoff + (unsigned)(t * 8));
+        O.arx[t] = LDG(m.area, T.xoff + (unsigned)(t * RB));
       }
       T.inner_with(O, si_x, si_y);
     }
@@ -991,12 +999,12 @@ __device__ __forceinline__ void fvt_scalars_tile(FvtLdsScalars& LS, const Geo& g
         double wa[NF];
         const bool last = T.east && T.xg == GXN - 1;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfx + kb, T.xoff + (unsigned)(f * 8));
+        for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfx + kb, T.xoff + (unsigned)(f * RB));
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           mfx[f] = v[f] * xf[f] + LS.priv[f][tid];
           v[f] = mfx[f];
-          if (f < C || last) STG(S.mfx + kb, T.xoff + (unsigned)(f * 8)) = wa[f] + mfx[f];  // flux_capacitor (d_sw.py:33-60)
+          if (f < C || last) STG(S.mfx + kb, T.xoff + (unsigned)(f * RB)) = wa[f] + mfx[f];  // flux_capacitor (d_sw.py:33-60)
         }
       } else {
 #pragma unroll
@@ -1087,7 +1095,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
   const int tid = (int)threadIdx.x;
   const bool xrole = tid < 256;  // wave-uniform
   const long kb = (long)k * g.sk;
-  const int sj8 = g.sj * 8;
+  const int sj8 = g.sj * RB;
   const bool w_on = S.damp_w[k] > 1e-5;
   double* const priv = &LS.priv[0][0];  // [NF][NT]: the damping fluxes of the thread's faces while the sweeps run
   double c[NF], af[NF], mf[NF];    // Courant numbers, area fluxes, mass fluxes (unit fluxes of w, q_con, pt) of the run's faces
@@ -1101,8 +1109,8 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
   if (xrole) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      c[f] = LDG(S.crx + kb, roff + (unsigned)(f * 8));
-      af[f] = LDG(S.xfx + kb, roff + (unsigned)(f * 8));
+      c[f] = LDG(S.crx + kb, roff + (unsigned)(f * RB));
+      af[f] = LDG(S.xfx + kb, roff + (unsigned)(f * RB));
     }
   } else {
 #pragma unroll
@@ -1134,8 +1142,8 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
     // the one-sided forms' spacings (edge tiles), loaded by the runs that hold the edge where a sweep needs them
     auto spacing = [&]() {
       FvtSpacing sp;
-      if (EX && xrole) sp = fvt_spacing(m.dxa, (unsigned)((T.jlo + T.xrow) * sj8), 8, g.is, g.ie, lane_lo, lane_hi);
-      if (EY && !xrole) sp = fvt_spacing(m.dya, (unsigned)((T.ilo + T.ycol) * 8), sj8, g.js, g.je, lane_lo, lane_hi);
+      if (EX && xrole) sp = fvt_spacing(m.dxa, (unsigned)((T.jlo + T.xrow) * sj8), RB, g.is, g.ie, lane_lo, lane_hi);
+      if (EY && !xrole) sp = fvt_spacing(m.dya, (unsigned)((T.ilo + T.ycol) * RB), sj8, g.js, g.je, lane_lo, lane_hi);
       return sp;
     };
     T.stage_damping_planes();  // (its loads first: the metric planes are cache hits, the footprint may still be on its way)
@@ -1151,7 +1159,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         int e = tid + NT * t;
         if (e >= BW * (TJ + 1)) e = BW * (TJ + 1) - 1;
         const int r = e / BW, cc = e - r * BW;
-        const unsigned o = (unsigned)((T.j0 + r) * sj8 + (T.i0 + cc) * 8);
+        const unsigned o = (unsigned)((T.j0 + r) * sj8 + (T.i0 + cc) * RB);
         bke[t] = LDG(S.ke + kb, o);
         bvb[t] = LDG(S.vort_b + kb, o);
       }
@@ -1212,7 +1220,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         fvt_run<MORD, EX>(Q, c, lane_lo, lane_hi, spacing(), si);
         FVT_FENCE();
 #pragma unroll
-        for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, roff + (unsigned)(t * 8));
+        for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, roff + (unsigned)(t * RB));
         if (T.x_outer) {
 #pragma unroll
           for (int f = 0; f < C; ++f) slot[f * XS] = si[f];
@@ -1259,7 +1267,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
     if (is_vort && run_outer) {
       if (xrole) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) wind[f] = LDG(S.v + kb, roff + (unsigned)(f * 8));
+        for (int f = 0; f < NF; ++f) wind[f] = LDG(S.v + kb, roff + (unsigned)(f * RB));
       } else {
 #pragma unroll
         for (int f = 0; f < NF; ++f) wind[f] = LDG(S.u + kb, roff + (unsigned)(f * sj8));
@@ -1294,7 +1302,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         double wa[NF];
         if (xrole) {
 #pragma unroll
-          for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfx + kb, roff + (unsigned)(f * 8));
+          for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfx + kb, roff + (unsigned)(f * RB));
         } else {
 #pragma unroll
           for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfy + kb, roff + (unsigned)(f * sj8));
@@ -1308,7 +1316,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         if (xrole) {
 #pragma unroll
           for (int f = 0; f < NF; ++f)
-            if (f < C || last_face) STG(S.mfx + kb, roff + (unsigned)(f * 8)) = wa[f];
+            if (f < C || last_face) STG(S.mfx + kb, roff + (unsigned)(f * RB)) = wa[f];
         } else {
 #pragma unroll
           for (int f = 0; f < NF; ++f)
@@ -1357,8 +1365,8 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
           double dyv[NF], rdyv[NF];
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
-            dyv[f] = LDG(m.dy, roff + (unsigned)(f * 8));
-            rdyv[f] = LDG(S.rdy, roff + (unsigned)(f * 8));
+            dyv[f] = LDG(m.dy, roff + (unsigned)(f * RB));
+            rdyv[f] = LDG(S.rdy, roff + (unsigned)(f * RB));
           }
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
@@ -1368,7 +1376,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
             const double vyd = don ? tvb[b] - tvb[b + BW] : 0.0;
             const double vbt = (vyd - ut2) * rdyv[f];
             const double fxh = vmid * rdyv[f];
-            if (f < C || last_face) STG(S.v_out + kb, roff + (unsigned)(f * 8)) = upd ? vmid - ut2 : vmid;
+            if (f < C || last_face) STG(S.v_out + kb, roff + (unsigned)(f * RB)) = upd ? vmid - ut2 : vmid;
             if (f < C || T.xg == GXN - 1) avbt[T.xr * PJ + C * T.xg + f] = vbt, afx[T.xr * PJ + C * T.xg + f] = fxh;
           }
         } else {  // y-faces: u-points (i0 + ycol - 3, j0 + C * yg + f)
@@ -1427,7 +1435,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         const int bw = xb - xa, nbox = bw * (yb - ya);
         for (int e = tid; e < nbox; e += NT) {
           const int r = e / bw, i = xa + (e - r * bw), j = ya + r;
-          const unsigned o = (unsigned)(j * sj8 + i * 8);
+          const unsigned o = (unsigned)(j * sj8 + i * RB);
           const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
           if (!(in_i && (in_j || j == g.je + 1))) STG(S.u_out + kb, o) = LDG(S.u + kb, o);
           if (!((in_i || i == g.ie + 1) && in_j)) STG(S.v_out + kb, o) = LDG(S.v + kb, o);

@@ -72,6 +72,34 @@ def test_f32_dynamical_core_step_emulated(emu_f32):
     check_step(fixes, outs)
 
 
+def test_f32_lean_kernels_c48_against_f64_emulated(emu_f32):
+    """The fused scalar + wind kernel (csrc/fvt_core.h) with float32 fields -- BASELINE configuration 5's storage type; it was a
+    float64-only kernel until round 5 -- at a size its tilings cover (C48: the 16 x 24 tile shape), all of d_sw against the SAME
+    kernels of the float64 emulation build on the same synthetic state, to float32 storage accuracy."""
+    import ctypes as C
+
+    from helpers import DSW_CFG, build_emu
+    from pace_amd import _lib, synthetic
+
+    n, nz = 48, 2
+    metrics = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(metrics, n, nz)
+    col = {k: np.ascontiguousarray(v[:nz]) for k, v in golden("column_namelist_c12.npz").items()}
+    outs = {}
+    for name, lib in (("f64", _lib.Library(build_emu())), ("f32", emu_f32)):
+        env = Env(lib, "cpu", metrics, n, nz)
+        outs[name], op = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"], cfg=DSW_CFG)
+        assert lib.cdll.pace_d_sw_wind_outputs_supported(C.byref(op._geom), C.byref(op._cfg)) == 1, name  # the fused path is the one that ran
+    for k in DSW_ARGS:
+        if k == "zh":
+            continue
+        W = dsw_window(k, n, nz)
+        a, b = outs["f64"][k][W], outs["f32"][k][W]
+        e = float(np.abs(a - b).max() / (np.abs(a).max() + 1e-300))
+        # (the divergence damping's work fields are gradients of a divergence: differences of nearly equal numbers)
+        assert e < (5e-3 if k in ("heat_source", "diss_est") else 2e-4 if k in ("uc", "vc", "divgd", "delpc") else 5e-5), (k, e)
+
+
 def test_storage_type_mismatch_is_refused(emu_f32):
     """float64 fields handed to the float32 library (or the reverse) are an error, not a reinterpretation."""
     import torch
