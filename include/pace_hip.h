@@ -219,7 +219,11 @@ int pace_d_sw_winds(const pace_geom_t* geom, const pace_metrics_t* met, const pa
  * 4.  pace_d_sw_transport == phases 3, pace_d_sw_winds == phases 12, pace_d_sw == 15.  Instead of 1: 16 = the part of the flux
  * preparation that reads no halo value of uc / vc (the box [is+2, ie-1] x [js+2, je-1]) -- it may run while the uc / vc halo
  * exchange is in flight (dyn_core.py:817-820) --, 32 = the rest of it, after the exchange.  Instead of 4: 64 = kinetic energy and
- * relative vorticity (they need only the flux preparation), 128 = the rest of winds A. */
+ * relative vorticity (they need only the flux preparation), 128 = the rest of winds A.
+ * Where pace_d_sw_wind_outputs_supported() and the call runs 2, 4 and 8 together, the library orders the work differently: kinetic
+ * energy, vorticity and divergence damping first, then ONE kernel that transports the scalars and the vorticity, updates the
+ * winds and forms the dissipative heating.  256 (alone; a measurement aid): only that kernel, on the kinetic energy /
+ * vorticities a previous call left in the workspace. */
 int pace_d_sw_phases(int phases, const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,
                      const pace_dsw_config_t* cfg, void* workspace, pace_real_t* delpc, pace_real_t* delp,
                      pace_real_t* pt, pace_real_t* u, pace_real_t* v, pace_real_t* w, pace_real_t* uc,

@@ -178,7 +178,8 @@ static int d_sw_entry(int phases, const pace_geom_t* geom, const pace_metrics_t*
     // ... of the winds: both or none, only with the four, only in a call that runs scalars and winds together
     const int winds = (cfg->u_out != nullptr) + (cfg->v_out != nullptr);
     if (winds == 1 || (winds && !given) || (winds && (cfg->u_out == u || cfg->v_out == v || cfg->u_out == cfg->v_out))) return PACE_ERR_ARG;
-    if (winds && !(((phases & 2) && (phases & 4) && (phases & 8)) || phases == 256)) return PACE_ERR_ARG;
+    // (they are written by the kernel of phases 2 + 4 + 8 / 256; a call without 2 and 8 does not touch the winds' outputs)
+    if (winds && ((phases & 2) || (phases & 8)) && !((phases & 2) && (phases & 4) && (phases & 8))) return PACE_ERR_ARG;
   }
   return launch_d_sw(make_geo(geom), *met, col, cfg, workspace, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy,
                      cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est, dt, phases, S(stream));
@@ -198,7 +199,7 @@ int pace_d_sw(DSW_PARAMS) { return d_sw_entry(15, DSW_ARGS_); }
 int pace_d_sw_transport(DSW_PARAMS) { return d_sw_entry(3, DSW_ARGS_); }
 int pace_d_sw_winds(DSW_PARAMS) { return d_sw_entry(12, DSW_ARGS_); }
 int pace_d_sw_phases(int phases, DSW_PARAMS) {
-  if (phases < 1 || phases > 256 || ((phases & 1) && (phases & 48)) || ((phases & 4) && (phases & 192)))
+  if (phases < 1 || phases > 256 || ((phases & 1) && (phases & 48)) || ((phases & 4) && (phases & 192)) || ((phases & 256) && phases != 256))
     return PACE_ERR_ARG;  // (1 and 16 / 32, 4 and 64 / 128 are alternatives; 256 stands alone)
   return d_sw_entry(phases, DSW_ARGS_);
 }
@@ -219,7 +220,8 @@ int pace_d_sw_overlapped(int prep, DSW_PARAMS, void* side_stream, void* ev_prep,
   hipEvent_t e_prep = (hipEvent_t)ev_prep, e_scal = (hipEvent_t)ev_scalars, e_done = (hipEvent_t)ev_done;
   int rc;
   if (geom && cfg && dsw_winds_in_scalars(make_geo(geom), cfg)) {
-    // the winds are the last pass of the kernel that transports the scalars: one stream, nothing left for the side stream
+    // the winds are the last pass of the kernel that transports the scalars: one stream, nothing left for the side stream (the
+    // kinetic energy there next to vorticity + divergence damping measured slower: profiles/r05_experiments x05)
     if ((rc = d_sw_entry(prep | 14, DSW_ARGS_))) return rc;
     if (hipEventRecord(e_done, main_s) != hipSuccess) return PACE_ERR_LAUNCH;
     return PACE_OK;

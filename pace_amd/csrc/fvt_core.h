@@ -906,6 +906,7 @@ struct FvtScalars {
   // ---- the winds (512-thread form only; winds != 0): the vorticity transport, u / v from it and the kinetic energy, the
   // dissipative heating and the final winds as a fifth pass of the tile (d_sw.py:406-477,493-608) ----
   int winds, do_skeb, copy_wind_halo;
+  int ke_plus_vort;          // ke is the plain kinetic energy: ke + vort_b (the divergence damping's increment) is formed here
   double d_con;
   const real *u, *v;         // the winds before d_sw (read at the tile's faces only)
   real *u_out, *v_out;       // the winds after it: buffers of their own (a tile reads the old wind on the face its neighbour writes)
@@ -1258,7 +1259,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
 #pragma unroll
       for (int t = 0; t < NBP; ++t) {
         const int e = tid + NT * t;
-        if (e < BW * (TJ + 1)) tke[e] = bke[t], tvb[e] = bvb[t];
+        if (e < BW * (TJ + 1)) tke[e] = S.ke_plus_vort ? bke[t] + bvb[t] : bke[t], tvb[e] = bvb[t];
       }
     }
     // stage II: the outer sweep on the field advected across the run (fvtp2d.py:80-119), the fluxes through the run's faces

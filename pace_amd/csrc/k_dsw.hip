@@ -86,16 +86,15 @@ __device__ __forceinline__ double rel_vorticity(const Geo& g, const Met& m, cons
 // [0, nke) are the B-grid points of the kinetic energy (each also a cell of the vorticity), the regions after them the rest of
 // the vorticity's domain (the halo cells around the B-grid domain), where only the vorticity is formed.  vort == nullptr: none.
 template <int MORD>
-__global__ void __launch_bounds__(256)
-k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
-                 const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ut,
-                 const real* __restrict__ vt, real* __restrict__ ke, double dt, Regions R, real* __restrict__ vort, int nke) {
-  REGION_POINT_XCD(R);  // (six rows of v per point: the j-neighbouring patches share an L2 -- 255 -> 156 MB, round 3's x17)
+__device__ __forceinline__ void
+kinetic_energy_point(const Geo& g, const Met& m, const real* __restrict__ uc, const real* __restrict__ vc, const real* __restrict__ u,
+                     const real* __restrict__ v, const real* __restrict__ ut, const real* __restrict__ vt, real* __restrict__ ke, double dt,
+                     real* __restrict__ vort, int i, int j, int k, bool interior, bool ke_region) {
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;
   if (vort != nullptr) vort[c] = rel_vorticity(g, m, u, v, c, c2);  // (every point of every region is a cell of its domain)
-  if (reg__ >= nke) return;
+  if (!ke_region) return;
   if (interior) {
     // is+3 <= i <= ie-2 and the same in j: no edge wind, no one-sided PPM interface, no zeroed reconstruction
     const double ub_cov = 0.5 * (uc[c - sj] + uc[c]);
@@ -162,6 +161,15 @@ k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restri
   ke[c] = kev;
 }
 
+template <int MORD>
+__global__ void __launch_bounds__(256)
+k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
+                 const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ut,
+                 const real* __restrict__ vt, real* __restrict__ ke, double dt, Regions R, real* __restrict__ vort, int nke) {
+  REGION_POINT_XCD(R);  // (six rows of v per point: the j-neighbouring patches share an L2 -- 255 -> 156 MB, round 3's x17)
+  kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, vort, i, j, k, interior, reg__ < nke);
+}
+
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
 __global__ void __launch_bounds__(256)
 k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ vort) {
@@ -222,7 +230,7 @@ __device__ __forceinline__ void divdamp_low_point(const Geo& g, const Met& m, co
   const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(delpcdt)));
   const double vort = damp * d;
   vort_b[c] = vort;
-  ke[c] = ke[c] + vort;
+  if (ke != nullptr) ke[c] = ke[c] + vort;  // (nullptr: the consumer adds the damped vorticity to the kinetic energy itself)
 }
 
 __global__ void __launch_bounds__(256)
@@ -689,7 +697,7 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
     du0[t] = m.divg_u[c2];
     ra[t] = m.rarea_c[c2];
     dpc[t] = din[cc[t]];
-    ke0[t] = ke[cc[t]];
+    ke0[t] = ke != nullptr ? ke[cc[t]] : 0.0;
   }
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
@@ -719,27 +727,27 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
     const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(vb)));
     const double vort = damp * dpc[t] + dd8 * dfin;
     vort_b[c] = vort;
-    ke[c] = ke0[t] + vort;
+    if (ke != nullptr) ke[c] = ke0[t] + vort;
     if (full) divg_d[c] = dfin;
   }
 }
 
-__global__ void __launch_bounds__(256)
-k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
-                real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
-                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int full_,
-                DdSponge sp) {
+// (the body of k_divdamp_fused as a function of the workgroup's tile and level index, so that k_divdamp_and_ke can run it too)
+__device__ __forceinline__ void
+divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo& g, const Met& m, const real* __restrict__ wk,
+                    const real* __restrict__ din, real* __restrict__ divg_d, real* __restrict__ vort_b, real* __restrict__ ke,
+                    real* __restrict__ uc_out, real* __restrict__ vc_out, const real* __restrict__ d2_bg, double dddmp, double dd8,
+                    double absdt, int k0, int nord, int ntx, int full_, const DdSponge& sp) {
   // full_ == 0 (PACE_DSW_SKIP_DEAD_OUTPUTS): divg_d, uc_out, vc_out are not written -- din may then be divg_d itself
   const bool full = full_ != 0;
-  __shared__ double sbuf[2][DD_W * DD_H];
   const int tid = threadIdx.x;
-  const int bx = (int)blockIdx.x % ntx, by = (int)blockIdx.x / ntx;
+  const int bx = tile % ntx, by = tile / ntx;
   const int i0 = g.is + bx * DD_TI, j0 = g.js + by * DD_TJ;
   const int ilo = i0 - 3, jlo = j0 - 3;
-  if ((int)blockIdx.z >= sp.first_block) {
+  if (zblock >= sp.first_block) {
     // the sponge levels [0, k0) ride along as extra workgroups (they were a launch of their own: 10 us for two or three levels):
     // second-order damping, a point function of the winds, on the tile's own points
-    const int kk = (int)blockIdx.z - sp.first_block;
+    const int kk = zblock - sp.first_block;
     for (int q = tid; q < DD_TI * DD_TJ; q += 256) {
       const int jj = q / DD_TI, ii = q - jj * DD_TI;
       const int i = i0 + ii, j = j0 + jj;
@@ -748,7 +756,7 @@ k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restric
     }
     return;
   }
-  const int kk = (int)blockIdx.z + k0;
+  const int kk = zblock + k0;
   const long kb = (long)kk * g.sk;
   // the divergence on the footprint, and (kept in registers until a plane is free) the relative vorticity under the tile
   double wreg[DD_NW];
@@ -867,9 +875,19 @@ k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restric
     const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(vb)));
     const double vort = damp * dpc + dd8 * dfin;
     vort_b[c] = vort;
-    ke[c] = ke[c] + vort;
+    if (ke != nullptr) ke[c] = ke[c] + vort;
     if (full) divg_d[c] = dfin;  // the caller's divgd ends as the iterated divergence (redo_divg_d; compared by TranslateD_SW)
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
+                real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
+                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int full_,
+                DdSponge sp) {
+  __shared__ double sbuf[2][DD_W * DD_H];
+  divdamp_fused_block(sbuf, (int)blockIdx.x, (int)blockIdx.z, g, m, wk, din, divg_d, vort_b, ke, uc_out, vc_out, d2_bg, dddmp, dd8, absdt,
+                      k0, nord, ntx, full_, sp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1127,11 +1145,15 @@ int launch_a2b_ord4_tiled(const Geo& g, const Met& m, const real* qin, real* qou
 int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const real* v, const real* va, real* vort_b,
                               const real* ua, real* divg_d, real* vc, real* uc, real* delpc, real* ke,
                               const real* rel_vort_agrid, double dt, const real* d2_bg_dev, int kstart, int nonzero_nord,
-                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead) {
+                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead, bool ke_by_consumer) {
+  // ke_by_consumer (with skip_dead only): `ke += damped vorticity` is left to the kernel that reads both (the fused scalar + wind
+  // kernel forms ke + vort_b, the same single addition): this operator then neither reads nor writes ke
   const int nk = g.nk;
   const int nhigh = nk - kstart;
   const bool fused = nhigh > 0 && !legacy_divergence_damping();
   skip_dead = skip_dead && fused;
+  if (ke_by_consumer && !skip_dead) return PACE_ERR_ARG;
+  if (ke_by_consumer) ke = nullptr;
   if (fused && !skip_dead) {
     // sponge levels + delpc = divg_d below them (copy_computeplus :578; whole planes, so that the fused kernel can take its
     // footprint from delpc), one launch
@@ -1262,7 +1284,13 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // the workspace)
   const bool winds_in_scalars = lean_scalars && (((phases & 2) && (phases & 4) && (phases & 8)) || (phases & 256)) && dsw_scalars_take_winds() &&
                                 !separate_winds && nmax_v <= 2 && nmax_w <= 2 && nmax_t <= 2 && ((uintptr_t)W.wk & 15) == 0;
-  if ((cfg->u_out != nullptr) && !winds_in_scalars) return PACE_ERR_UNSUPPORTED;  // (separate wind outputs exist in that form only)
+  // (separate wind outputs exist in that form only; a call that runs neither the scalars nor the heating does not touch them)
+  if ((cfg->u_out != nullptr) && !winds_in_scalars && (phases & (2 | 8))) return PACE_ERR_UNSUPPORTED;
+  const bool skip_dead = (cfg->flags & PACE_DSW_SKIP_DEAD_OUTPUTS) != 0;
+  // ... and where the work fields are not asked for either, the divergence damping leaves `ke += damped vorticity` to that kernel
+  // (it holds both at the tile's B-grid points): the damping then does not touch ke, 47 MB less, and it no longer depends on the
+  // kinetic-energy kernel
+  const bool ke_by_consumer = winds_in_scalars && skip_dead && nk - kstart > 0;
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
   } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
@@ -1281,6 +1309,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
         wd.rel_vort = W.wk, wd.u = u, wd.v = v, wd.ke = W.ke, wd.vort_b = W.vort_b, wd.heat_source = heat_source;
         wd.u_out = cfg->u_out ? cfg->u_out : W.umid, wd.v_out = cfg->v_out ? cfg->v_out : W.vmid;
         wd.copy_halo = cfg->u_out != nullptr, wd.do_skeb = cfg->do_skeb, wd.d_con = cfg->d_con;
+        wd.ke_plus_vort = ke_by_consumer;
       }
       rc = launch_dsw_scalars_lean(g, m, delp, pt, w, q_con, pingpong ? scalar_outs : ws_outs, crx, cry, xfx, yfx, mfx, mfy, W.dw,
                                    W.heat_s, diss_est, kc, cfg->hord_dp, nmax_v, nmax_w, nmax_t, dt, st, winds_in_scalars ? &wd : nullptr);
@@ -1349,7 +1378,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // winds A2: divergence damping
   if (nonzero_nord < 0 || nonzero_nord > 3) return PACE_ERR_UNSUPPORTED;  // (as pace_divergence_damping: halo 3)
   if ((rc = launch_divergence_damping(g, m, u, v, va, W.vort_b, ua, divgd, vc, uc, delpc, W.ke, W.wk, dt, d_d2, kstart, nonzero_nord,
-                                      cfg->dddmp, cfg->d4_bg, W.da, W.db, st, (cfg->flags & PACE_DSW_SKIP_DEAD_OUTPUTS) != 0)))
+                                      cfg->dddmp, cfg->d4_bg, W.da, W.db, st, skip_dead, ke_by_consumer)))
     return rc;
   // vorticity transport
   // vorticity: transport of the absolute vorticity (wk + fC_agrid) -> W.fy2, W.fyv (own flux buffers: the mass fluxes

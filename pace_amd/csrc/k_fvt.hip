@@ -164,6 +164,7 @@ int FVT_FN(launch_scalars)(const Geo& g, const Met& m, const real* delp, const r
     S.q[4] = winds->rel_vort, S.fac[4] = kc + 11 * K, S.nord[4] = nord_v, S.nmax[4] = nmax_v;
     S.u = winds->u, S.v = winds->v, S.u_out = winds->u_out, S.v_out = winds->v_out, S.ke = winds->ke, S.vort_b = winds->vort_b;
     S.heat_source = winds->heat_source, S.do_skeb = winds->do_skeb, S.d_con = winds->d_con, S.copy_wind_halo = winds->copy_halo;
+    S.ke_plus_vort = winds->ke_plus_vort;
     S.damp_vt = kc + 3 * K, S.d_con_k = kc + 7 * K;
     S.fC = m.fC_agrid, S.rdx = m.rdx, S.rdy = m.rdy, S.rsin2 = m.rsin2, S.cosa_s = m.cosa_s;
   }

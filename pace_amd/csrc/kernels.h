@@ -65,6 +65,7 @@ struct DswWinds {
   const real *rel_vort, *u, *v, *ke, *vort_b;
   real *u_out, *v_out, *heat_source;
   int do_skeb, copy_halo;
+  int ke_plus_vort;  // `ke` is the plain kinetic energy: the kernel adds the damped vorticity to it (divergence_damping.py:161-185)
   double d_con;
 };
 bool dsw_scalars_take_winds();
@@ -153,7 +154,8 @@ int launch_ppm1d(const Geo& g, const Met& m, int axis, int iord, const real* q, 
 int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const real* v, const real* va, real* vort_b,
                               const real* ua, real* divg_d, real* vc, real* uc, real* delpc, real* ke,
                               const real* rel_vort_agrid, double dt, const real* d2_bg_dev, int kstart, int nonzero_nord,
-                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead = false);
+                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead = false,
+                              bool ke_by_consumer = false);
 // k_riem3f.hip: both column solvers as one k-cooperative kernel (16 lanes per column), no workspace
 bool riem_column_supported(const Geo& g);
 int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const real* cappa, double ptop, const real* zs,

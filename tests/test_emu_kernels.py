@@ -172,7 +172,10 @@ def dsw_contract_variants(gpu=False):
     out = {}
     for name, ctor, call in (("in_place", {}, {}), ("swapped", dict(swap_scalar_storage=True), {}),
                              ("swapped_overlapped", dict(swap_scalar_storage=True), dict(overlap_winds=True)),
-                             ("skip_dead", dict(swap_scalar_storage=True), dict(skip_dead_outputs=True))):
+                             ("skip_dead", dict(swap_scalar_storage=True), dict(skip_dead_outputs=True)),
+                             # (on the GPU: the kinetic energy on the side stream next to vorticity + divergence damping, `ke +=
+                             # damped vorticity` left to the fused kernel -- pace_d_sw_overlapped)
+                             ("skip_dead_overlapped", dict(swap_scalar_storage=True), dict(skip_dead_outputs=True, overlap_winds=True))):
         op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, get_column_namelist(cfg, env.qf),
                                                 False, False, cfg, **ctor)
         f = {k: env.q3(s[k]) for k in DSW_ARGS}
@@ -204,10 +207,11 @@ def check_dsw_contract_variants(res):
         assert op._pingpong, "the library must have taken the separate outputs here"
         for k in ref:  # every output of d_sw bit for bit, whole storage (halos included)
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
-    got, _ = res["skip_dead"]
-    for k in ref:
-        if k not in ("delpc", "divgd", "uc", "vc"):  # (unspecified: include/pace_hip.h PACE_DSW_SKIP_DEAD_OUTPUTS)
-            assert np.array_equal(ref[k], got[k], equal_nan=True), ("skip_dead", k)
+    for name in ("skip_dead", "skip_dead_overlapped"):
+        got, _ = res[name]
+        for k in ref:
+            if k not in ("delpc", "divgd", "uc", "vc"):  # (unspecified: include/pace_hip.h PACE_DSW_SKIP_DEAD_OUTPUTS)
+                assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
 
 
 def test_d_sw_separate_outputs_equal_in_place_emulated():
