@@ -1477,7 +1477,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
   pass(std::integral_constant<int, 2>{});
   pass(std::integral_constant<int, 3>{});
   if (S.winds) pass(std::integral_constant<int, 4>{});
-  FVT_STAMP(16);
+  FVT_STAMP(S.winds ? 20 : 16);
 }
 
 }  // namespace FVT_NS

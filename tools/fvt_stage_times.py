@@ -16,7 +16,7 @@ from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, 
 from pace_amd.tile import DSW_ARGS, Env  # noqa: E402
 
 PARTS = ["footprint + metrics -> LDS", "damping + face values", "inner sweeps, q_i / q_j", "outer sweeps, fluxes, cell update"]
-SCALARS = ["delp", "w", "q_con", "pt"]
+SCALARS = ["delp", "w", "q_con", "pt", "winds"]
 
 
 def main():
@@ -27,8 +27,11 @@ def main():
     env = Env(lib, "cuda", m, n, nz)
     cfg = DGridShallowWaterLagrangianDynamicsConfig()
     col = get_column_namelist(cfg, env.qf)
-    dsw = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, False, False, cfg)
+    dsw = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, False, False, cfg,
+                                              swap_scalar_storage=True)
+    dsw._cfg.flags = _lib.DSW_SKIP_DEAD_OUTPUTS
     copies = [{k: env.q3(s[k]) for k in DSW_ARGS} for _ in range(6)]
+    fused = bool(dsw._wind_outputs)  # the winds are the fifth pass of the scalar-phase kernel
 
     def phase(mask, f):
         lib.call("pace_d_sw_phases", mask, C.byref(dsw._geom), C.byref(dsw._met), C.byref(dsw._col), C.byref(dsw._cfg),
@@ -36,14 +39,22 @@ def main():
 
     host = (C.c_longlong * (4 * 128 * 32))()
     rows = [[], [], [], []]
+    nstamp = 21 if fused else 17
     for rep in range(6):
         f = copies[rep]
         phase(1, f)
-        torch.cuda.synchronize()
-        phase(2, f)
+        if fused:  # the kernel alone (256), on the kinetic energy / vorticities of phase 4, with outputs of its own
+            phase(4, f)
+            torch.cuda.synchronize()
+            dsw._outputs_for(tuple(f[k] for k in ("delp", "pt", "w", "q_con", "u", "v")), winds=True)
+            phase(256, f)
+            dsw._cfg.delp_out = dsw._cfg.pt_out = dsw._cfg.w_out = dsw._cfg.q_con_out = dsw._cfg.u_out = dsw._cfg.v_out = None
+        else:
+            torch.cuda.synchronize()
+            phase(2, f)
         torch.cuda.synchronize()
         assert lib.cdll.pace_debug_fvt_prof(host) == 0
-        a = np.frombuffer(host, dtype=np.int64).reshape(4, 128, 32)[:, :nz, :17].astype(float)
+        a = np.frombuffer(host, dtype=np.int64).reshape(4, 128, 32)[:, :nz, :nstamp].astype(float)
         if rep >= 1:
             for w in range(4):
                 rows[w].append(np.diff(a[w], axis=1))
@@ -68,7 +79,7 @@ def main():
         d = np.concatenate(rows[w])
         med = np.median(d, axis=0)
         print(f"{label} workgroup of k_fvt_scalars: {med.sum():.0f} cycles")
-        for sc in range(4):
+        for sc in range(5 if fused else 4):
             line = "  ".join(f"{PARTS[p][:24]:24s} {med[4 * sc + p]:7.0f}" for p in range(4))
             print(f"   {SCALARS[sc]:6s} {med[4 * sc:4 * sc + 4].sum():7.0f} | {line}")
 
