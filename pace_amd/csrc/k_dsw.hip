@@ -170,89 +170,6 @@ k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restri
   kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, vort, i, j, k, interior, reg__ < nke);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Kinetic energy AND relative vorticity from LDS tiles of u and v (round 5).  As point kernels the two are bound by their load
-// instructions -- 22 and 9 per point, each ~12 cycles of the CU's address unit -- not by bytes (4 x 23 MB at 2.3 - 3.4 TB/s).
-// Here a workgroup = a 64 x 4 patch of points over KV_CH levels: per level it stages u (rows j0 .. j0+4, columns i0-3 .. i0+65)
-// and v (rows j0-3 .. j0+5, columns i0 .. i0+64) -- 3.6 loads per thread -- and every point reads its six + six + four values
-// from there; its eleven 2-D metric values are loaded once for all levels.  The patches cover the vorticity's whole domain
-// [0, ni-2] x [0, nj-2]; a point that is also a B-grid point of the kinetic energy gets it here -- from the tiles where the
-// plain forms apply ([is+3, ie-2] in both directions), through the general point function (global loads, edge and corner forms)
-// in the frame.  Same expressions in the same order as k_kinetic_energy / k_vorticity: same bits.
-// ------------------------------------------------------------------------------------------------
-#define KV_TI 64
-#define KV_TJ 4
-#ifndef KV_CH
-#define KV_CH 4
-#endif
-#define KV_UW (KV_TI + 6)
-#define KV_UH (KV_TJ + 1)
-#define KV_VW (KV_TI + 1)
-#define KV_VH (KV_TJ + 6)
-template <int MORD>
-__global__ void __launch_bounds__(256)
-k_ke_vort_tiled(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc, const real* __restrict__ u,
-                const real* __restrict__ v, const real* __restrict__ ut, const real* __restrict__ vt, real* __restrict__ ke,
-                real* __restrict__ vort, double dt) {
-  __shared__ double su[KV_UH * KV_UW];
-  __shared__ double sv[KV_VH * KV_VW];
-  const int tid = (int)threadIdx.x;
-  const int tx = tid & (KV_TI - 1), ty = tid / KV_TI;
-  const int i0 = (int)blockIdx.x * KV_TI, j0 = (int)blockIdx.y * KV_TJ;
-  const int i = i0 + tx, j = j0 + ty;
-  const int k0 = (int)blockIdx.z * KV_CH;
-  const int sj = g.sj;
-  const bool cell = i <= g.ni - 2 && j <= g.nj - 2;                                          // a cell of the vorticity's domain
-  const bool bpt = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1;                  // a B-grid point of the kinetic energy
-  const bool plain = g.n >= 8 && i >= g.is + 3 && i <= g.ie - 2 && j >= g.js + 3 && j <= g.je - 2;  // ... with the plain forms
-  const long c2 = cell ? IDX2(g, i, j) : IDX2(g, 0, 0);
-  // the point's 2-D metric values, once for all levels
-  double cosa = 0, rsina = 0, rdy_m = 0, rdy_0 = 0, rdx_m = 0, rdx_0 = 0, ra = 0, dx0 = 0, dxj = 0, dy0 = 0, dyi = 0;
-  if (cell) ra = m.rarea[c2], dx0 = m.dx[c2], dxj = m.dx[c2 + sj], dy0 = m.dy[c2], dyi = m.dy[c2 + 1];
-  if (plain) cosa = m.cosa[c2], rsina = m.rsina[c2], rdy_m = m.rdy[c2 - sj], rdy_0 = m.rdy[c2], rdx_m = m.rdx[c2 - 1], rdx_0 = m.rdx[c2];
-  for (int kk = 0; kk < KV_CH; ++kk) {
-    const int k = k0 + kk;
-    if (k >= g.nk) break;  // (block-uniform)
-    const long kb = (long)k * g.sk;
-    // the tiles (zero outside the storage: those values reach no result)
-    for (int e = tid; e < KV_UH * KV_UW; e += 256) {
-      const int r = e / KV_UW, cc = e - r * KV_UW;
-      const int gi = i0 - 3 + cc, gj = j0 + r;
-      su[e] = (gi >= 0 && gi < g.ni && gj < g.nj) ? (double)u[kb + IDX2(g, gi, gj)] : 0.0;
-    }
-    for (int e = tid; e < KV_VH * KV_VW; e += 256) {
-      const int r = e / KV_VW, cc = e - r * KV_VW;
-      const int gi = i0 + cc, gj = j0 - 3 + r;
-      sv[e] = (gi < g.ni && gj >= 0 && gj < g.nj) ? (double)v[kb + IDX2(g, gi, gj)] : 0.0;
-    }
-    __syncthreads();
-    const double* pu = su + ty * KV_UW + tx + 3;        // u(i, j)
-    const double* pv = sv + (ty + 3) * KV_VW + tx;      // v(i, j)
-    if (cell)  // compute_vorticity (d_sw.py:301-328): the expression of rel_vorticity()
-      vort[kb + c2] = (pu[0] - pu[KV_UW] * dxj / dx0) * (ra * dx0) + (pv[1] * dyi / dy0 - pv[0]) * (ra * dy0);
-    if (plain) {
-      const long c = kb + c2;
-      const double ub_cov = 0.5 * (uc[c - sj] + uc[c]);
-      const double vb_cov = 0.5 * (vc[c - 1] + vc[c]);
-      const double ub = (ub_cov - vb_cov * cosa) * rsina;
-      const double vb = (vb_cov - ub_cov * cosa) * rsina;
-      double q6[6];
-#pragma unroll
-      for (int t = 0; t < 6; ++t) q6[t] = pv[(t - 3) * KV_VW];
-      double cfl = (vb > 0.0) ? vb * dt * rdy_m : vb * dt * rdy_0;
-      const double adv_v = wind_flux6<MORD, false>(q6, vb, cfl, j, g.js, g.je, [](int) { return 0.0; }, false, false);
-#pragma unroll
-      for (int t = 0; t < 6; ++t) q6[t] = pu[t - 3];
-      cfl = (ub > 0.0) ? ub * dt * rdx_m : ub * dt * rdx_0;
-      const double adv_u = wind_flux6<MORD, false>(q6, ub, cfl, i, g.is, g.ie, [](int) { return 0.0; }, false, false);
-      ke[c] = 0.5 * dt * (ub * adv_u + vb * adv_v);
-    } else if (bpt) {
-      kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, (real*)nullptr, i, j, k, false, true);
-    }
-    __syncthreads();
-  }
-}
-
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
 __global__ void __launch_bounds__(256)
 k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ vort) {
@@ -1444,23 +1361,17 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   if ((phases & 2) && !winds_in_scalars && (rc = scalar_phase())) return rc;
   if (phases & (4 | 64)) {
   // winds A1: kinetic energy and relative vorticity (need only the flux preparation)
-  // kinetic energy and relative vorticity of the same winds from LDS tiles of u and v, one launch (k_ke_vort_tiled); the point
-  // kernels k_kinetic_energy / k_vorticity remain for PACE_DSW_POINT_KE=1 (A/B) and the stencil-level entry points
-  static const bool point_ke = getenv("PACE_DSW_POINT_KE") != nullptr;
-  if (cfg->hord_mt != 5 && cfg->hord_mt != 6) return PACE_ERR_UNSUPPORTED;
-  if (!point_ke) {
-    const dim3 grid((unsigned)((g.ni - 1 + KV_TI - 1) / KV_TI), (unsigned)((g.nj - 1 + KV_TJ - 1) / KV_TJ), (unsigned)((nk + KV_CH - 1) / KV_CH));
-    if (cfg->hord_mt == 5) hipLaunchKernelGGL(k_ke_vort_tiled<5>, grid, dim3(256), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, W.wk, dt);
-    else hipLaunchKernelGGL(k_ke_vort_tiled<6>, grid, dim3(256), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, W.wk, dt);
-  } else {
+  // (two point kernels.  The vorticity inside the kinetic-energy kernel: no faster, x02; both from LDS tiles of u and v: twice as
+  // slow, x06 -- profiles/r05_experiments)
   const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
   if (cfg->hord_mt == 5) {
     hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);
-  } else {
+  } else if (cfg->hord_mt == 6) {
     hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);
+  } else {
+    return PACE_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
-  }
   }
   if (phases & (4 | 128)) {
   // winds A2: divergence damping
