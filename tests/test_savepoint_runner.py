@@ -46,6 +46,34 @@ def _write_pairs(d):
     dgrid_sw.d_sw(g, col, DSW_CFG, dgrid_sw.DSWState(s["u"].shape), *[a[k] for k in DSW_ARGS], s["dt"])
     np.savez(os.path.join(d, "D_SW-In.npz"), **ins)
     np.savez(os.path.join(d, "D_SW-Out.npz"), **{k + "d": _sp(a[k][win.get(k, full)]) for k in DSW_ARGS if k != "zh"})
+    # ---- Riem_Solver3: pe on [is-1, ie+1] with the k axis in the middle, peln on the compute domain likewise, wsd on the compute domain
+    fullk = np.s_[:N + 6, :N + 6, :NZ + 1]
+    r = {k: s[k].copy() for k in ("cappa", "delz", "q_con", "delp", "pt", "zh", "pe", "ppe", "pk3", "pk", "peln", "w")}
+    zs, ws = s["zs"].copy(), s["ws"].copy()
+
+    def riem_vars(x):
+        return {"cappa": _sp(x["cappa"][full]), "zs": _sp(zs[:N + 6, :N + 6]), "w": _sp(x["w"][full]), "delz": _sp(x["delz"][full]),
+                "q_con": _sp(x["q_con"][full]), "delp": _sp(x["delp"][full]), "pt": _sp(x["pt"][full]), "zh": _sp(x["zh"][fullk]),
+                "pe": _sp(np.moveaxis(x["pe"][2:N + 4, 2:N + 4, :NZ + 1], 2, 1)), "ppe": _sp(x["ppe"][fullk]), "pk3": _sp(x["pk3"][fullk]),
+                "pk": _sp(x["pk"][3:N + 3, 3:N + 3, :NZ + 1] if x is not r0 else x["pk"][fullk]),
+                "peln": _sp(np.moveaxis(x["peln"][3:N + 3, 3:N + 3, :NZ + 1], 2, 1)), "wsd": _sp(ws[3:N + 3, 3:N + 3])}
+
+    r0 = {k: v.copy() for k, v in r.items()}
+    ins = riem_vars(r0)
+    ins.update(dt=_sp(np.array(s["dt"])), ptop=_sp(np.array(float(m["ptop"]))), last_call=_sp(np.array(1.0)))
+    vertical.riem_solver3(g, True, s["dt"], r["cappa"], float(m["ptop"]), zs, ws, r["delz"], r["q_con"], r["delp"], r["pt"], r["zh"], r["pe"],
+                          r["ppe"], r["pk3"], r["pk"], r["peln"], r["w"], p_fac=0.05)
+    np.savez(os.path.join(d, "Riem_Solver3-In.npz"), **ins)
+    np.savez(os.path.join(d, "Riem_Solver3-Out.npz"), **riem_vars(r))
+    # ---- FxAdv: uc_contra / vc_contra compared on the compute domain + 2 (translate_fxadv.py:49-72)
+    f0 = {k: s[k].copy() for k in ("uc", "vc", "crx", "cry", "xfx", "yfx")}
+    ut, vt = np.zeros_like(s["uc"]), np.zeros_like(s["uc"])
+    dgrid_sw.fxadv(g, f0["uc"], f0["vc"], f0["crx"], f0["cry"], f0["xfx"], f0["yfx"], ut, vt, s["dt"])
+    np.savez(os.path.join(d, "FxAdv-In.npz"), uc=_sp(s["uc"][fx]), vc=_sp(s["vc"][fy]), ut=_sp(np.zeros_like(s["uc"])[fx]),
+             vt=_sp(np.zeros_like(s["uc"])[fy]), xfx_adv=_sp(s["xfx"][cx_]), crx_adv=_sp(s["crx"][cx_]), yfx_adv=_sp(s["yfx"][cy_]),
+             cry_adv=_sp(s["cry"][cy_]), dt=_sp(np.array(s["dt"])))
+    np.savez(os.path.join(d, "FxAdv-Out.npz"), ut=_sp(ut[1:N + 6, 1:N + 5, :NZ]), vt=_sp(vt[1:N + 5, 1:N + 6, :NZ]), xfx_adv=_sp(f0["xfx"][cx_]),
+             crx_adv=_sp(f0["crx"][cx_]), yfx_adv=_sp(f0["yfx"][cy_]), cry_adv=_sp(f0["cry"][cy_]))
     return m, s
 
 
@@ -89,6 +117,25 @@ def test_d_sw_savepoint_pair_through_the_runner(tmp_path):
     np.savez(os.path.join(str(tmp_path), "D_SW-Out.npz"), **bad)
     _, _, _, ok_inner, inner = rs.run_one("D_SW", rs.read_pair(str(tmp_path), "D_SW"), args, lib)
     assert not ok_inner and inner["pt"] > 3.2e-10
+
+
+def test_riem_solver3_and_fxadv_pairs_through_the_runner(tmp_path):
+    """The variables with a twist: `pe` / `peln` serialised with the k axis in the middle on windows of their own, `wsd` on the
+    compute domain (placed by shape), uc_contra / vc_contra compared on the compute domain + 2."""
+    import argparse
+
+    import run_savepoints as rs
+    from pace_amd import _lib
+
+    _write_pairs(str(tmp_path))
+    lib = _lib.Library(build_emu())
+    args = argparse.Namespace(device="cpu", metrics=os.path.join(str(tmp_path), "metrics.npz"), rank_tile=False, namelist={})
+    ok, bound, worst, _, _ = rs.run_one("Riem_Solver3", rs.read_pair(str(tmp_path), "Riem_Solver3"), args, lib)
+    assert bound == 5e-6 and set(worst) == {"zh", "w", "p", "log_p_interface", "ppe", "delz", "pk", "pk3"}
+    assert ok, worst
+    ok, bound, worst, _, _ = rs.run_one("FxAdv", rs.read_pair(str(tmp_path), "FxAdv"), args, lib)
+    assert set(worst) == {"uc_contra", "vc_contra", "x_area_flux", "crx", "y_area_flux", "cry"}
+    assert ok and max(worst.values()) == 0.0, worst
 
 
 def test_unreadable_netcdf_says_what_to_do(tmp_path):

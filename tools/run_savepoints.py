@@ -275,7 +275,56 @@ def spec_fvtp2d(g):  # translate_fvtp2d.py:8-70
     return Spec(iv, ["hord"], ov, 1e-14, run)
 
 
-SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": spec_fvtp2d}
+def spec_riem_solver_c(g):  # translate_riem_solver_c.py:8-34
+    iv = {k: {} for k in ("cappa", "hs", "w3", "ptc", "q_con", "delpc", "gz", "pef", "ws")}
+    ov = {"pef": {"kend": g.npz}, "gz": {"kend": g.npz}}
+
+    def run(env, f, p):
+        from pace_amd.fv3core.stencils.riem_solver_c import NonhydrostaticVerticalSolverCGrid
+
+        op = NonhydrostaticVerticalSolverCGrid(env.stencil_factory, env.qf, p_fac=env.namelist.get("riemann", {}).get("p_fac", 0.05))
+        op(p["dt2"], f["cappa"], p["ptop"], f["hs"], f["ws"], f["ptc"], f["q_con"], f["delpc"], f["gz"], f["pef"], f["w3"])
+        return f
+
+    return Spec(iv, ["dt2", "ptop"], ov, 5e-14, run)
+
+
+def spec_nh_p_grad(g):  # translate_nh_p_grad.py:8-46
+    iv = {k: {} for k in ("u", "v", "pp", "gz", "pk3", "delp")}
+    ov = {"u": g.y3d_domain_dict(), "v": g.x3d_domain_dict(), "pp": {"kend": g.npz + 1}, "gz": {"kend": g.npz + 1}, "pk3": {"kend": g.npz + 1},
+          "delp": {}}
+
+    def run(env, f, p):
+        from pace_amd.fv3core.stencils.nh_p_grad import NonHydrostaticPressureGradient
+
+        op = NonHydrostaticPressureGradient(env.stencil_factory, env.qf, env.grid_data, 0)
+        op(f["u"], f["v"], f["pp"], f["gz"], f["pk3"], f["delp"], p["dt"], p["ptop"], p["akap"])
+        return f
+
+    return Spec(iv, ["dt", "ptop", "akap"], ov, 5e-10, run)
+
+
+def spec_fxadv(g):  # translate_fxadv.py:8-72 (uc_contra / vc_contra are compared on the compute domain + 2: `_subset`)
+    ut, vt = _named(g.x3d_domain_dict(), "ut"), _named(g.y3d_domain_dict(), "vt")
+    iv = {"uc": {}, "vc": {}, "uc_contra": ut, "vc_contra": vt, "x_area_flux": _named(g.x3d_compute_domain_y_dict(), "xfx_adv"),
+          "crx": _named(g.x3d_compute_domain_y_dict(), "crx_adv"), "y_area_flux": _named(g.y3d_compute_domain_x_dict(), "yfx_adv"),
+          "cry": _named(g.y3d_compute_domain_x_dict(), "cry_adv")}
+    sub = {"istart": g.is_ - 2, "iend": g.ie + 2, "jstart": g.js - 2, "jend": g.je + 2}
+    ov = {"uc_contra": dict(ut, **dict(sub, iend=g.ie + 3)), "vc_contra": dict(vt, **dict(sub, jend=g.je + 3)),
+          "x_area_flux": iv["x_area_flux"], "crx": iv["crx"], "y_area_flux": iv["y_area_flux"], "cry": iv["cry"]}
+
+    def run(env, f, p):
+        from pace_amd.fv3core.stencils.fxadv import FiniteVolumeFluxPrep
+
+        FiniteVolumeFluxPrep(env.stencil_factory, env.grid_data, quantity_factory=env.qf)(
+            f["uc"], f["vc"], f["crx"], f["cry"], f["x_area_flux"], f["y_area_flux"], f["uc_contra"], f["vc_contra"], p["dt"])
+        return f
+
+    return Spec(iv, ["dt"], ov, 1e-14, run)
+
+
+SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": spec_fvtp2d, "Riem_Solver_C": spec_riem_solver_c,
+              "NH_P_Grad": spec_nh_p_grad, "FxAdv": spec_fxadv}
 # KNOWN DEVIATIONS from the windows of the reference's Translate classes (TranslateD_SW compares every variable over the FULL
 # domain, halo included, translate_d_sw.py:36-65): (a) the reference's transport rewrites the 3 x 3 corner blocks of the halo of
 # delp, pt, w, q_con in place (copy_corners_x / _y, fvtp2d.py:262-345) and leaves the last copy there; the HIP kernels apply the
@@ -283,9 +332,9 @@ SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": sp
 # divergence damping's work fields uc, vc, divgd, delpc are brought to the reference's final state on the compute domain
 # (+ staggering) only, not in the halo rows its shrinking iteration domains touch.  Neither is read by anything before it is
 # overwritten (halo update / c_sw).  The runner therefore reports both verdicts.
-# Not in the table yet (their Translate classes: translate_{xppm,yppm,delnflux,fxadv,c_sw,updatedzc,updatedzd,riem_solver_c,
-# nh_p_grad}.py, translate_dyncore.py): XPPM, YPPM, DelnFlux, FxAdv, C_SW, UpdateDzC, UpdateDzD, Riem_Solver_C, NH_P_Grad, DynCore
-# -- same machinery, one `spec_*` function each.
+# Not in the table yet (their Translate classes: translate_{xppm,yppm,delnflux,c_sw,updatedzc,updatedzd}.py, translate_dyncore.py):
+# XPPM, YPPM, DelnFlux, C_SW, UpdateDzC, UpdateDzD, DynCore -- same machinery, one `spec_*` function each (XPPM / YPPM take their
+# row window from the savepoint's jfirst / jlast; UpdateDzC / UpdateDzD compare a compute-domain subset and the 2-D ws).
 
 
 def metrics_for(n, npz, tile, path=None):
