@@ -480,13 +480,33 @@ int launch_interface_pressure(const Geo& g, const real* delp, real* pem, double 
 
 // dst = src * factor on the window [i0, i1] x [j0, j1], nlev levels: copy_defn (basic_operations.py:7, factor 1)
 // and compute_geopotential (dyn_core.py:115-117, factor GRAV)
+// (two neighbouring elements per thread: one 16-byte load and store per lane -- this repo's stream kernels move 6.2 TB/s that way
+// against 5.2 with 8 bytes per lane, profiles/r05_ubench_streams.txt; the rows are 16-byte aligned: sj is even)
+struct alignas(2 * sizeof(real)) ScPair {
+  real x, y;
+};
 __global__ void __launch_bounds__(256)
 k_scale_copy(Geo g, const real* __restrict__ src, real* __restrict__ dst, double factor, int scale, int i0, int i1,
              int j0, int j1) {
-  PLANE_IJK(g);
-  if (i < i0 || i > i1 || j < j0 || j > j1) return;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;  // pair index in the plane
+  const int half = g.sj / 2;
+  const int j = (int)(p / half);
+  const int i = 2 * (int)(p - (long)j * half);
+  const int k = (int)blockIdx.y;
+  if (j >= g.nj || j < j0 || j > j1 || i + 1 < i0 || i > i1) return;
   const long c = IDX3(g, i, j, k);
-  dst[c] = scale ? src[c] * factor : src[c];
+  const bool lo = i >= i0, hi = i + 1 <= i1;
+  if (lo && hi && (((uintptr_t)src | (uintptr_t)dst) & (2 * sizeof(real) - 1)) == 0) {
+    ScPair v = *(const ScPair*)(src + c);
+    if (scale) v.x = (real)(v.x * factor), v.y = (real)(v.y * factor);
+    *(ScPair*)(dst + c) = v;
+  } else {
+    if (lo) dst[c] = scale ? src[c] * factor : src[c];
+    if (hi) dst[c + 1] = scale ? src[c + 1] * factor : src[c + 1];
+  }
+}
+static inline dim3 pair_grid(const Geo& g, int nlev) {
+  return dim3((unsigned)(((long)(g.sj / 2) * g.nj + 255) / 256), (unsigned)nlev, 1);
 }
 
 // p_grad_c_stencil (dyn_core.py:120-171), non-hydrostatic; compute + 1.  A thread takes PG_CH consecutive layers of its point:
@@ -529,7 +549,7 @@ int launch_gz_from_surface(const Geo& g, const real* zs, const real* delz, real*
 }
 int launch_scale_copy(const Geo& g, const real* src, real* dst, double factor, int scale, int halo, int nlev,
                       hipStream_t st) {
-  hipLaunchKernelGGL(k_scale_copy, plane_grid(g, nlev), dim3(256), 0, st, g, src, dst, factor, scale, g.is - halo, g.ie + halo,
+  hipLaunchKernelGGL(k_scale_copy, pair_grid(g, nlev), dim3(256), 0, st, g, src, dst, factor, scale, g.is - halo, g.ie + halo,
                      g.js - halo, g.je + halo);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
@@ -936,7 +956,7 @@ int launch_del2cubed(const Geo& g, const Met& m, void* ws_, real* qdel, double c
     src = dst;
     dst = t;
   }
-  if (src != qdel) hipLaunchKernelGGL(k_scale_copy, grid, block, 0, st, g, src, qdel, 1.0, 0, 0, g.ni - 2, 0, g.nj - 2);
+  if (src != qdel) hipLaunchKernelGGL(k_scale_copy, pair_grid(g, (int)grid.y), block, 0, st, g, src, qdel, 1.0, 0, 0, g.ni - 2, 0, g.nj - 2);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

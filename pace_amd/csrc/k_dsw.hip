@@ -588,8 +588,11 @@ k_divdamp_high_final(Geo g, Met m, const real* __restrict__ wk, const real* delp
 #endif
 #define DD_W (DD_TI + 6)
 #define DD_H (DD_TJ + 6)
-#define DD_NE ((DD_W * DD_H + 255) / 256)
-#define DD_NP ((DD_TI * DD_TJ + 255) / 256)
+#ifndef DD_NT
+#define DD_NT 256  // threads per workgroup of k_divdamp_fused
+#endif
+#define DD_NE ((DD_W * DD_H + DD_NT - 1) / DD_NT)
+#define DD_NP ((DD_TI * DD_TJ + DD_NT - 1) / DD_NT)
 
 // the operands of the sponge levels for k_divdamp_fused (first_block: the blockIdx.z they start at; > the grid's height: none)
 struct DdSponge {
@@ -629,7 +632,7 @@ __device__ __forceinline__ void divdamp_point(const Geo& g, const Met& m, const 
 
 #define DD_WKW (DD_TI + 3)  // relative vorticity (A-grid cells) under the tile's B-grid points: [i0-2, i0+TI] x [j0-2, j0+TJ]
 #define DD_WKH (DD_TJ + 3)
-#define DD_NW ((DD_WKW * DD_WKH + 255) / 256)
+#define DD_NW ((DD_WKW * DD_WKH + DD_NT - 1) / DD_NT)
 static_assert(DD_WKW * DD_WKH <= DD_W * DD_H, "the vorticity tile reuses a divergence plane");
 
 // One pass at the footprint points T0 <= t < T1 of this thread that lie in columns is+1 .. ie (no corner region involved):
@@ -644,7 +647,7 @@ __device__ __forceinline__ void dd_pass_batch(const Geo& g, const Met& m, const 
   const int fa = ia > g.is + 1 ? ia : g.is + 1, fb = ib < g.ie ? ib : g.ie;
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
-    const int e = tid + 256 * (T0 + t);
+    const int e = tid + DD_NT * (T0 + t);
     const int jj = e / DD_W, ii = e - jj * DD_W;
     const int gi = ilo + ii, gj = jlo + jj;
     on[t] = e < DD_W * DD_H && gi >= fa && gi <= fb && gj >= ja && gj <= jb;
@@ -657,7 +660,7 @@ __device__ __forceinline__ void dd_pass_batch(const Geo& g, const Met& m, const 
   }
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
-    const int e = tid + 256 * (T0 + t);
+    const int e = tid + DD_NT * (T0 + t);
     if (on[t]) {
       const double d0 = src[e];
       const double ucm = (d0 - src[e - DD_W]) * dvm[t];
@@ -685,7 +688,7 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
   long cc[NB];
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
-    const int q = tid + 256 * (T0 + t);
+    const int q = tid + DD_NT * (T0 + t);
     const int jj = q / DD_TI, ii = q - jj * DD_TI;
     const int i = i0 + ii, j = j0 + jj;
     on[t] = q < DD_TI * DD_TJ && g.n >= 8 && i >= g.is + 2 && i <= g.ie - 1 && j >= g.js + 2 && j <= g.je - 1;
@@ -702,7 +705,7 @@ __device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const 
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
     if (!on[t]) continue;
-    const int q = tid + 256 * (T0 + t);
+    const int q = tid + DD_NT * (T0 + t);
     const int jj = q / DD_TI, ii = q - jj * DD_TI;
     const int e = (jj + 3) * DD_W + ii + 3;
     const double d0 = src[e];
@@ -748,7 +751,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
     // the sponge levels [0, k0) ride along as extra workgroups (they were a launch of their own: 10 us for two or three levels):
     // second-order damping, a point function of the winds, on the tile's own points
     const int kk = zblock - sp.first_block;
-    for (int q = tid; q < DD_TI * DD_TJ; q += 256) {
+    for (int q = tid; q < DD_TI * DD_TJ; q += DD_NT) {
       const int jj = q / DD_TI, ii = q - jj * DD_TI;
       const int i = i0 + ii, j = j0 + jj;
       if (i <= g.ie + 1 && j <= g.je + 1)
@@ -764,7 +767,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
     double dreg[DD_NE];
 #pragma unroll
     for (int t = 0; t < DD_NE; ++t) {
-      const int e = tid + 256 * t;
+      const int e = tid + DD_NT * t;
       const int jj = e / DD_W, ii = e - jj * DD_W;
       const int gi = ilo + ii, gj = jlo + jj;
       const bool ok = e < DD_W * DD_H && gi < g.ni && gj < g.nj;
@@ -773,7 +776,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
     }
 #pragma unroll
     for (int t = 0; t < DD_NW; ++t) {
-      const int e = tid + 256 * t;
+      const int e = tid + DD_NT * t;
       const int jj = e / DD_WKW, ii = e - jj * DD_WKW;
       const int gi = i0 - 2 + ii, gj = j0 - 2 + jj;
       const bool ok = e < DD_WKW * DD_WKH && gi < g.ni && gj < g.nj;
@@ -782,7 +785,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
     }
 #pragma unroll
     for (int t = 0; t < DD_NE; ++t) {
-      const int e = tid + 256 * t;
+      const int e = tid + DD_NT * t;
       if (e < DD_W * DD_H) sbuf[0][e] = dreg[t];
     }
   }
@@ -804,7 +807,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
       const int ncl = ia <= g.is ? g.is - ia + 1 : 0, ncr = ib > g.ie ? ib - g.ie : 0;
       const int ncol = ncl + ncr, total = ncol * (jb - ja + 1);
       const PlaneInLds plane{src, ilo, jlo, DD_W};
-      for (int p = tid; p < total; p += 256) {
+      for (int p = tid; p < total; p += DD_NT) {
         const int r = p / ncol, cx = p - r * ncol;
         const int gi = cx < ncl ? ia + cx : g.ie + 1 + (cx - ncl), gj = ja + r;
         double d, u_, v_;
@@ -819,7 +822,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
   double* swk = sbuf[cur ^ 1];
 #pragma unroll
   for (int t = 0; t < DD_NW; ++t) {
-    const int e = tid + 256 * t;
+    const int e = tid + DD_NT * t;
     if (e < DD_WKW * DD_WKH) swk[e] = wreg[t];
   }
   __syncthreads();
@@ -844,7 +847,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
   const int ncol = (fl - i0) + (i1 - fr), nrow_all = j1 - j0 + 1;
   const int nmid = fr - fl + 1, nrow = (fb - j0) + (j1 - ft);
   const int n_a = ncol * nrow_all, n_b = nmid > 0 ? nmid * nrow : 0;
-  for (int p = tid; p < n_a + n_b; p += 256) {
+  for (int p = tid; p < n_a + n_b; p += DD_NT) {
     int i, j;
     if (p < n_a) {
       const int r = p / ncol, cx = p - r * ncol;
@@ -880,7 +883,7 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(DD_NT)
 k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
                 real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
                 const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int full_,
@@ -1052,15 +1055,29 @@ struct A2BBatch {  // up to four fields in one launch (blockIdx.y): nh_p_grad in
 };
 
 __global__ void __launch_bounds__(256)
-k_a2b_interior_tiled(Geo g, A2BBatch job, int kmin, int ntx) {
+k_a2b_interior_tiled(Geo g, Met m, A2BBatch job, int kmin, int ntx, Regions R) {
+  // One launch for the interior tiles AND the frame (blocks [0, R.first[R.n]): every region of the frame through the general point
+  // function -- long, divergent code on few points; as a launch of its own it took 32 us after the 46 us of the tiles, here it
+  // runs beside them, first in launch order).  Launch with dim3(64, 4) threads.
   __shared__ double sq[AB_W * AB_H];
   const int f = (int)blockIdx.y;
+  const int nfr = R.first[R.n];
+  if ((int)blockIdx.x < nfr) {
+    REGION_POINT(R);
+    (void)interior;
+    const int kf = k + kmin;
+    if (kf < job.k0[f] || kf >= job.k1[f]) return;
+    A2B a{g, m, job.in[f] + (long)kf * g.sk};
+    job.out[f][IDX3(g, i, j, kf)] = a.point(i, j);
+    return;
+  }
   const int kk = (int)blockIdx.z + kmin;
   if (kk < job.k0[f] || kk >= job.k1[f]) return;  // block-uniform
   const real* __restrict__ qin = job.in[f];
   real* __restrict__ qout = job.out[f];
-  const int tid = threadIdx.x;
-  const int bx = (int)blockIdx.x % ntx, by = (int)blockIdx.x / ntx;
+  const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+  const int tile = (int)blockIdx.x - nfr;
+  const int bx = tile % ntx, by = tile / ntx;
   const int i0 = g.is + 2 + bx * AB_TI, j0 = g.js + 2 + by * AB_TJ;  // first B-grid point of the tile
   const long kb = (long)kk * g.sk;
   double v[AB_NE];
@@ -1088,19 +1105,6 @@ k_a2b_interior_tiled(Geo g, A2BBatch job, int kmin, int ntx) {
   }
 }
 
-// the frame: every region of a2b_regions but the interior box (long, divergent code on few points: all fields in one launch
-// so that there is something to hide its latency behind)
-__global__ void __launch_bounds__(256)
-k_a2b_frame(Geo g, Met m, A2BBatch job, int kmin, Regions R) {
-  const int f = (int)blockIdx.y;
-  REGION_POINT(R);
-  (void)interior;
-  const int kk = k + kmin;
-  if (kk < job.k0[f] || kk >= job.k1[f]) return;
-  A2B a{g, m, job.in[f] + (long)kk * g.sk};
-  job.out[f][IDX3(g, i, j, kk)] = a.point(i, j);
-}
-
 int launch_a2b_ord4_batch(const Geo& g, const Met& m, const real* const* qin, real* const* qout, const int* k0, const int* k1,
                           int nfields, hipStream_t st) {
   if (nfields < 1 || nfields > 4) return PACE_ERR_ARG;
@@ -1121,15 +1125,13 @@ int launch_a2b_ord4_batch(const Geo& g, const Met& m, const real* const* qin, re
   const int nlev = kmax - kmin;
   const int nbox = g.n - 3;  // points is+2 .. ie-1
   const int ntx = (nbox + AB_TI - 1) / AB_TI, nty = (nbox + AB_TJ - 1) / AB_TJ;
-  hipLaunchKernelGGL(k_a2b_interior_tiled, dim3((unsigned)(ntx * nty), (unsigned)nfields, (unsigned)nlev), dim3(256), 0, st, g, job,
-                     kmin, ntx);
-  Regions r{};  // (region 0 is enumerated in 64 x 4 patches: a row strip suits that, a column strip would not)
+  Regions r{};  // the frame (region 0 is enumerated in 64 x 4 patches: a row strip suits that, a column strip would not)
   add_region(r, g.is + 2, g.ie - 1, g.js, g.js + 1);
   add_region(r, g.is + 2, g.ie - 1, g.je, g.je + 1);
   add_region(r, g.is, g.is + 1, g.js, g.je + 1);
   add_region(r, g.ie, g.ie + 1, g.js, g.je + 1);
-  hipLaunchKernelGGL(k_a2b_frame, dim3((unsigned)r.first[r.n], (unsigned)nfields, (unsigned)nlev), dim3(64, 4), 0, st, g, m, job,
-                     kmin, r);
+  hipLaunchKernelGGL(k_a2b_interior_tiled, dim3((unsigned)(r.first[r.n] + ntx * nty), (unsigned)nfields, (unsigned)nlev), dim3(64, 4), 0, st,
+                     g, m, job, kmin, ntx, r);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
@@ -1170,7 +1172,7 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
     const double dd8 = pow(m.da_min_c * d4_bg, (double)(nonzero_nord + 1));
     const int ntx = (g.n + 1 + DD_TI - 1) / DD_TI, nty = (g.n + 1 + DD_TJ - 1) / DD_TJ;
     const DdSponge sp{u, v, ua, va, uc, vc, delpc, dt, nhigh};
-    hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)(nhigh + (skip_dead ? kstart : 0))), dim3(256), 0, st, g, m,
+    hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)(nhigh + (skip_dead ? kstart : 0))), dim3(DD_NT), 0, st, g, m,
                        rel_vort_agrid, skip_dead ? divg_d : delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart,
                        nonzero_nord, ntx, skip_dead ? 0 : 1, sp);
   } else if (nhigh > 0) {
