@@ -114,6 +114,16 @@ static_assert(2 * sizeof(FvtLdsScalars) <= 160 * 1024, "two workgroups per CU");
 
 #define LDG(p, off) (*(const real*)((const char*)(p) + (off)))
 #define STG(p, off) (*(real*)((char*)(p) + (off)))
+// *p += v for an accumulator that exactly one thread of the launch touches: the hardware's fp64 atomic add without a return value
+// -- one instruction, nothing to wait for -- instead of load, add, store (one rounding either way: the same bits).  float32
+// storage: the sum is formed in double and rounded once, as the load-add-store form does.
+__device__ __forceinline__ void fvt_accumulate(real* p, double v) {
+#if defined(PACE_EMU) || defined(PACE_REAL_FLOAT)
+  *p = (real)((double)*p + v);
+#else
+  (void)unsafeAtomicAdd(p, v);
+#endif
+}
 
 // A-grid spacings of the one-sided PPM forms (the provider interface of common.h ppm_patch_edge): four values along the sweep
 // axis, at the start OR at the end of the tile -- a workgroup tile holds at most one edge per axis.  `fixed` is the byte offset of
@@ -1300,28 +1310,22 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
 #pragma unroll
         for (int f = 0; f < NF; ++f) v[f] = v[f] * af[f];  // (the unit fluxes of the vorticity are the area fluxes)
       } else if (is_delp) {
-        double wa[NF];
-        if (xrole) {
-#pragma unroll
-          for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfx + kb, roff + (unsigned)(f * RB));
-        } else {
-#pragma unroll
-          for (int f = 0; f < NF; ++f) wa[f] = LDG(S.mfy + kb, roff + (unsigned)(f * sj8));
-        }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           mf[f] = v[f] * af[f] + priv[f * NT + tid];
           v[f] = mf[f];
-          wa[f] = wa[f] + mf[f];  // flux_capacitor (d_sw.py:33-60)
         }
+        // flux_capacitor (d_sw.py:33-60): mfx += fx, mfy += fy, each face by the run that opens it.  (As load - add - store the
+        // accumulators' loads sat between the sweep and the stores with a memory latency to wait for: 7.6 k cycles for delp's
+        // last stage against 4.5 k for pt's.)
         if (xrole) {
 #pragma unroll
           for (int f = 0; f < NF; ++f)
-            if (f < C || last_face) STG(S.mfx + kb, roff + (unsigned)(f * RB)) = wa[f];
+            if (f < C || last_face) fvt_accumulate((real*)((char*)(S.mfx + kb) + roff + (unsigned)(f * RB)), mf[f]);
         } else {
 #pragma unroll
           for (int f = 0; f < NF; ++f)
-            if (f < C || last_face) STG(S.mfy + kb, roff + (unsigned)(f * sj8)) = wa[f];
+            if (f < C || last_face) fvt_accumulate((real*)((char*)(S.mfy + kb) + roff + (unsigned)(f * sj8)), mf[f]);
         }
       } else {
 #pragma unroll
@@ -1421,11 +1425,11 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
                                      LDG(S.cosa_s, c2[t]) * (u2 * dv2 + v2 * du2 + du2 * dv2));
             const double hs = LS.newmass[jj[t] * TI + ii[t]] * (heat_s - dck * dampterm);
             if (any) {
-              STG(S.heat_source + kb, c2[t]) = LDG(S.heat_source + kb, c2[t]) + hs;
+              fvt_accumulate((real*)((char*)(S.heat_source + kb) + c2[t]), hs);
               if (S.do_skeb) STG(S.diss_est + kb, c2[t]) = LDG(S.diss_est + kb, c2[t]) - dampterm;
             }
           } else if (any) {
-            STG(S.heat_source + kb, c2[t]) = LDG(S.heat_source + kb, c2[t]) + heat_s;
+            fvt_accumulate((real*)((char*)(S.heat_source + kb) + c2[t]), heat_s);
           }
         }
       }
