@@ -61,7 +61,7 @@ const char* pace_version(void) {
 int pace_fxadv(const pace_geom_t* geom, const pace_metrics_t* met, const real* uc, const real* vc, real* crx,
                real* cry, real* xfx, real* yfx, real* ut, real* vt, double dt, void* stream) {
   NEED(geom && met && uc && vc && crx && cry && xfx && yfx && ut && vt);
-  return launch_fxadv(make_geo(geom), *met, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, nullptr, nullptr, S(stream));
+  return launch_fxadv(make_geo(geom), *met, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, nullptr, nullptr, S(stream), 0, 1);
 }
 
 int pace_fvtp2d(const pace_geom_t* geom, const pace_metrics_t* met, const real* q, const real* crx,

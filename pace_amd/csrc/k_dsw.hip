@@ -414,13 +414,29 @@ __device__ __forceinline__ double a2b_interior_point(const Plane& Q, int i, int 
   return 0.5 * (qxx + qyy);
 }
 
-struct A2B {
+// where a2b_ord4's general forms take the field and the cell widths from: memory, or planes of a tile's footprint staged in LDS
+// (the edge forms are chains of a dozen dependent reads: from memory, one round trip each)
+struct A2BInMemory {
+  const real* q;  // level base applied
+  __device__ __forceinline__ double Q(const Geo& g, const Met&, int i, int j) const { return q[IDX2(g, i, j)]; }
+  __device__ __forceinline__ double DXA(const Geo& g, const Met& m, int i, int j) const { return m.dxa[IDX2(g, i, j)]; }
+  __device__ __forceinline__ double DYA(const Geo& g, const Met& m, int i, int j) const { return m.dya[IDX2(g, i, j)]; }
+};
+struct A2BInLds {
+  const double *q, *xa, *ya;
+  int ilo, jlo, pitch;
+  __device__ __forceinline__ double Q(const Geo&, const Met&, int i, int j) const { return q[(j - jlo) * pitch + (i - ilo)]; }
+  __device__ __forceinline__ double DXA(const Geo&, const Met&, int i, int j) const { return xa[(j - jlo) * pitch + (i - ilo)]; }
+  __device__ __forceinline__ double DYA(const Geo&, const Met&, int i, int j) const { return ya[(j - jlo) * pitch + (i - ilo)]; }
+};
+template <class Src>
+struct A2BT {
   const Geo& g;
   const Met& m;
-  const real* q;  // level base applied
-  __device__ __forceinline__ double Q(int i, int j) const { return q[IDX2(g, i, j)]; }
-  __device__ __forceinline__ double DXA(int i, int j) const { return m.dxa[IDX2(g, i, j)]; }
-  __device__ __forceinline__ double DYA(int i, int j) const { return m.dya[IDX2(g, i, j)]; }
+  Src src;
+  __device__ __forceinline__ double Q(int i, int j) const { return src.Q(g, m, i, j); }
+  __device__ __forceinline__ double DXA(int i, int j) const { return src.DXA(g, m, i, j); }
+  __device__ __forceinline__ double DYA(int i, int j) const { return src.DYA(g, m, i, j); }
   __device__ double qx(int i, int j) const {  // ppm_volume_mean_x :429-450
     const double b1 = 7.0 / 12.0, b2 = -1.0 / 12.0;
     if (i == g.is) {
@@ -497,7 +513,7 @@ struct A2B {
     }
     return (ec[0] + ec[1] + ec[2]) * (1.0 / 3.0);
   }
-  __device__ __forceinline__ double point_interior(int i, int j) const { return a2b_interior_point(PlaneInMemory{q, g.sj}, i, j); }
+  __device__ __forceinline__ double point_interior(int i, int j) const { return a2b_interior_point(PlaneInMemory{src.q, g.sj}, i, j); }
   __device__ double point(int i, int j) const {  // value of qout at B-grid point (i, j), is <= i,j <= ie+1
     const double a1 = 9.0 / 16.0, a2 = -1.0 / 16.0, c1 = 2.0 / 3.0, c2 = -1.0 / 6.0;
     const bool iw = (i == g.is), ie_ = (i == g.ie + 1), js_ = (j == g.js), jn = (j == g.je + 1);
@@ -529,12 +545,13 @@ struct A2B {
     return 0.5 * (qxx + qyy);
   }
 };
+typedef A2BT<A2BInMemory> A2B;
 
 __global__ void __launch_bounds__(256)
 k_a2b_ord4(Geo g, Met m, const real* __restrict__ qin, real* __restrict__ qout, int k0, Regions R) {
   REGION_POINT(R);
   const int kk = k + k0;
-  A2B a{g, m, qin + (long)kk * g.sk};
+  A2B a{g, m, {qin + (long)kk * g.sk}};
   qout[IDX3(g, i, j, kk)] = interior ? a.point_interior(i, j) : a.point(i, j);
 }
 
@@ -561,7 +578,7 @@ k_divdamp_high_final(Geo g, Met m, const real* __restrict__ wk, const real* delp
   if (dddmp < 1e-5) {
     vb = 0.0;
   } else {
-    A2B a{g, m, wk + (long)kk * g.sk};
+    A2B a{g, m, {wk + (long)kk * g.sk}};
     const double qb = interior ? a.point_interior(i, j) : a.point(i, j);
     vb = absdt * sqrt(dpc * dpc + qb * qb);
   }
@@ -584,22 +601,39 @@ k_divdamp_high_final(Geo g, Met m, const real* __restrict__ wk, const real* delp
 // ------------------------------------------------------------------------------------------------
 #ifndef DD_TI
 #define DD_TI 65  // 193 = 3 * 65 - 2 B-grid points per row at C192
-#define DD_TJ 25  // 193 = 8 * 25 - 7
+#define DD_TJ 17  // 193 = 12 * 17 - 11
+#endif
+#ifndef DD_STAMP
+#define DD_STAMP(n)  // (tools/census/dsw_prof.hip: wall-clock stamps of every workgroup of k_divdamp_fused)
+#endif
+#ifdef PACE_EMU
+#define DD_ATTR
+#elif !defined(DD_ATTR)
+#define DD_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))  // three workgroups per compute unit (168 registers)
 #endif
 #define DD_W (DD_TI + 6)
 #define DD_H (DD_TJ + 6)
 #ifndef DD_NT
 #define DD_NT 256  // threads per workgroup of k_divdamp_fused
 #endif
-#define DD_NE ((DD_W * DD_H + DD_NT - 1) / DD_NT)
-#define DD_NP ((DD_TI * DD_TJ + DD_NT - 1) / DD_NT)
+#define DD_STRIP (DD_W * DD_H / 8 - 6 < 96 ? DD_W * DD_H / 8 - 6 : 96)  // longest strip of the frame (own points along the edge) per workgroup
+// an LDS plane: a tile's footprint, or a strip's and, behind it, the cell widths (dxa, dya) on that footprint
+#define DD_PLANE (DD_W * DD_H > 2 * (DD_STRIP + 6) * 8 ? DD_W * DD_H : 2 * (DD_STRIP + 6) * 8)
 
-// the operands of the sponge levels for k_divdamp_fused (first_block: the blockIdx.z they start at; > the grid's height: none)
+// The launch of k_divdamp_fused is a 1-D grid of three kinds of workgroups, in this order: the sponge levels (second-order
+// damping, a point function of the winds: 256 points each), the strips (the frame of the B-grid domain, two points deep, of a level
+// with nord > 0: the tail through the general point functions), the tiles (DD_TI x DD_TJ points of such a level, the plain
+// forms of the tail only).  The first two are few, long-running workgroups: first in launch order, they run beside the tiles.  (Round 4 had
+// the sponge levels last and the frame inside the edge tiles, 18 of the 24 tiles of a C192 level: 85 us, of which 12 us the
+// frame alone.)
 struct DdSponge {
   const real *u, *v, *ua, *va, *uc, *vc;
   real* delpc;
   double dt;
-  int first_block;
+  int nlev;      // sponge levels [0, nlev) taken by this launch (0: none)
+  int nblocks;   // their workgroups: nlev * ceil((n + 1)^2 / DD_NT)
+  int nstrips;   // strip workgroups: strips per level * levels (0: the tiles take their frame themselves)
+  int nch_row, len_row, nch_col, len_col;  // chunks per edge and their length, rows (south / north) and columns (west / east)
 };
 
 template <class Plane>
@@ -630,249 +664,163 @@ __device__ __forceinline__ void divdamp_point(const Geo& g, const Met& m, const 
   d = d * m.rarea_c[c2];
 }
 
-#define DD_WKW (DD_TI + 3)  // relative vorticity (A-grid cells) under the tile's B-grid points: [i0-2, i0+TI] x [j0-2, j0+TJ]
-#define DD_WKH (DD_TJ + 3)
-#define DD_NW ((DD_WKW * DD_WKH + DD_NT - 1) / DD_NT)
-static_assert(DD_WKW * DD_WKH <= DD_W * DD_H, "the vorticity tile reuses a divergence plane");
-
-// One pass at the footprint points T0 <= t < T1 of this thread that lie in columns is+1 .. ie (no corner region involved):
-// all metric loads first, then the arithmetic (a loop that loads, computes and stores point by point exposes one L2 latency
-// per point -- measured on the transport kernel, and again on the first version of this kernel: 229 us instead of 70).
-template <int T0, int T1>
-__device__ __forceinline__ void dd_pass_batch(const Geo& g, const Met& m, const double* __restrict__ src, double* __restrict__ dst,
-                                              int tid, int ilo, int jlo, int ia, int ib, int ja, int jb) {
-  constexpr int NB = T1 - T0;
-  double dvm[NB], dv0[NB], dum[NB], du0[NB], ra[NB];
-  bool on[NB];
-  const int fa = ia > g.is + 1 ? ia : g.is + 1, fb = ib < g.ie ? ib : g.ie;
-#pragma unroll
-  for (int t = 0; t < NB; ++t) {
-    const int e = tid + DD_NT * (T0 + t);
-    const int jj = e / DD_W, ii = e - jj * DD_W;
-    const int gi = ilo + ii, gj = jlo + jj;
-    on[t] = e < DD_W * DD_H && gi >= fa && gi <= fb && gj >= ja && gj <= jb;
-    const long c2 = on[t] ? IDX2(g, gi, gj) : IDX2(g, g.is + 1, g.js);
-    dvm[t] = m.divg_v[c2 - g.sj];
-    dv0[t] = m.divg_v[c2];
-    dum[t] = m.divg_u[c2 - 1];
-    du0[t] = m.divg_u[c2];
-    ra[t] = m.rarea_c[c2];
-  }
-#pragma unroll
-  for (int t = 0; t < NB; ++t) {
-    const int e = tid + DD_NT * (T0 + t);
-    if (on[t]) {
-      const double d0 = src[e];
-      const double ucm = (d0 - src[e - DD_W]) * dvm[t];
-      const double uc0 = (src[e + DD_W] - d0) * dv0[t];
-      const double vcm = (d0 - src[e - 1]) * dum[t];
-      const double vc0 = (src[e + 1] - d0) * du0[t];
-      double d = ucm - uc0 + vcm - vc0;
-      d = d * ra[t];
-      dst[e] = d;
-    }
-  }
-}
-
-// The tail at the own points T0 <= t < T1 of this thread that are plain in every respect (pass: columns is+1 .. ie; a2b_ord4:
-// the 16-point mean): loads first, then arithmetic.
-template <int T0, int T1>
-__device__ __forceinline__ void dd_tail_batch(const Geo& g, const Met& m, const double* __restrict__ src,
-                                              const double* __restrict__ swk, const real* __restrict__ din,
-                                              real* __restrict__ divg_d, real* __restrict__ vort_b, real* __restrict__ ke,
-                                              real* __restrict__ uc_out, real* __restrict__ vc_out, double d2, double dddmp,
-                                              double dd8, double absdt, int tid, int i0, int j0, long kb, bool full) {
-  constexpr int NB = T1 - T0;
-  double dvm[NB], dv0[NB], dum[NB], du0[NB], ra[NB], dpc[NB], ke0[NB];
-  bool on[NB];
-  long cc[NB];
-#pragma unroll
-  for (int t = 0; t < NB; ++t) {
-    const int q = tid + DD_NT * (T0 + t);
-    const int jj = q / DD_TI, ii = q - jj * DD_TI;
-    const int i = i0 + ii, j = j0 + jj;
-    on[t] = q < DD_TI * DD_TJ && g.n >= 8 && i >= g.is + 2 && i <= g.ie - 1 && j >= g.js + 2 && j <= g.je - 1;
-    const long c2 = on[t] ? IDX2(g, i, j) : IDX2(g, g.is + 1, g.js);
-    cc[t] = kb + c2;
-    dvm[t] = m.divg_v[c2 - g.sj];
-    dv0[t] = m.divg_v[c2];
-    dum[t] = m.divg_u[c2 - 1];
-    du0[t] = m.divg_u[c2];
-    ra[t] = m.rarea_c[c2];
-    dpc[t] = din[cc[t]];
-    ke0[t] = ke != nullptr ? ke[cc[t]] : 0.0;
-  }
-#pragma unroll
-  for (int t = 0; t < NB; ++t) {
-    if (!on[t]) continue;
-    const int q = tid + DD_NT * (T0 + t);
-    const int jj = q / DD_TI, ii = q - jj * DD_TI;
-    const int e = (jj + 3) * DD_W + ii + 3;
-    const double d0 = src[e];
-    const double ucm = (d0 - src[e - DD_W]) * dvm[t];
-    const double uc0 = (src[e + DD_W] - d0) * dv0[t];
-    const double vcm = (d0 - src[e - 1]) * dum[t];
-    const double vc0 = (src[e + 1] - d0) * du0[t];
-    double dfin = ucm - uc0 + vcm - vc0;
-    dfin = dfin * ra[t];
-    const long c = cc[t];
-    if (full) {
-      uc_out[c] = uc0;  // (own points here have j <= je and i <= ie)
-      vc_out[c] = vc0;
-    }
-    double vb;
-    if (dddmp < 1e-5) {
-      vb = 0.0;
-    } else {
-      const double qb = a2b_interior_point(PlaneInLds{swk, i0 - 2, j0 - 2, DD_WKW}, i0 + ii, j0 + jj);
-      vb = absdt * sqrt(dpc[t] * dpc[t] + qb * qb);
-    }
-    const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(vb)));
-    const double vort = damp * dpc[t] + dd8 * dfin;
-    vort_b[c] = vort;
-    if (ke != nullptr) ke[c] = ke0[t] + vort;
-    if (full) divg_d[c] = dfin;
-  }
-}
-
-// (the body of k_divdamp_fused as a function of the workgroup's tile and level index, so that k_divdamp_and_ke can run it too)
+// One workgroup of k_divdamp_fused on the own points [i0, i1] x [j0, j1] (at most TI x TJ) of level kk.  Every operand comes from
+// memory ONCE, at the start and in one go -- the divergence and the relative vorticity on the footprint, the five metric values
+// of every footprint point (the same in every pass and in the tail), for a strip the cell widths a2b_ord4's edge forms divide
+// by; everything after the first barrier reads registers and LDS.  (Round 4's version fetched the metric values pass by pass
+// and batch by batch and spent 16 of a workgroup's 18.5 us waiting for seven such round trips one after the other; a strip whose
+// a2b_ord4 read memory took 25 us -- tools/dd_stage_times.py.)
+// The plain form of a pass applies wherever no operand lies in a corner region and no corner adjustment applies: columns
+// is+1 .. ie (any row) or rows js+1 .. je (any column); only the points near a tile corner take the general form.
+// MODE 0: a tile -- the tail at the own points where a2b_ord4 is the 16-point mean (the rest of them belong to the strips);
+// 2: a strip of the frame -- the tail at every own point, a2b_ord4's general forms on LDS planes; 1: the same from memory (a
+// tile too small to have an interior: its footprint leaves no room for the planes of the cell widths).
+template <int TI, int TJ, int MODE>
 __device__ __forceinline__ void
-divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo& g, const Met& m, const real* __restrict__ wk,
-                    const real* __restrict__ din, real* __restrict__ divg_d, real* __restrict__ vort_b, real* __restrict__ ke,
-                    real* __restrict__ uc_out, real* __restrict__ vc_out, const real* __restrict__ d2_bg, double dddmp, double dd8,
-                    double absdt, int k0, int nord, int ntx, int full_, const DdSponge& sp) {
-  // full_ == 0 (PACE_DSW_SKIP_DEAD_OUTPUTS): divg_d, uc_out, vc_out are not written -- din may then be divg_d itself
-  const bool full = full_ != 0;
+divdamp_tile(double (*sbuf)[DD_PLANE], int i0, int i1, int j0, int j1, int kk, const Geo& g, const Met& m,
+             const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d, real* __restrict__ vort_b,
+             real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out, const real* __restrict__ d2_bg, double dddmp,
+             double dd8, double absdt, int nord, bool full) {
+  // full == false (PACE_DSW_SKIP_DEAD_OUTPUTS): divg_d, uc_out, vc_out are not written -- din may then be divg_d itself
+  constexpr int W = TI + 6, H = TJ + 6, NE = (W * H + DD_NT - 1) / DD_NT;
+  static_assert((MODE == 2 ? 2 : 1) * W * H <= DD_PLANE, "the footprint (a strip's: twice) fits an LDS plane");
+  static_assert(NE <= 32, "one bit per footprint point of a thread");
   const int tid = threadIdx.x;
-  const int bx = tile % ntx, by = tile / ntx;
-  const int i0 = g.is + bx * DD_TI, j0 = g.js + by * DD_TJ;
-  const int ilo = i0 - 3, jlo = j0 - 3;
-  if (zblock >= sp.first_block) {
-    // the sponge levels [0, k0) ride along as extra workgroups (they were a launch of their own: 10 us for two or three levels):
-    // second-order damping, a point function of the winds, on the tile's own points
-    const int kk = zblock - sp.first_block;
-    for (int q = tid; q < DD_TI * DD_TJ; q += DD_NT) {
-      const int jj = q / DD_TI, ii = q - jj * DD_TI;
-      const int i = i0 + ii, j = j0 + jj;
-      if (i <= g.ie + 1 && j <= g.je + 1)
-        divdamp_low_point(g, m, sp.u, sp.v, sp.ua, sp.va, sp.uc, sp.vc, sp.delpc, vort_b, ke, d2_bg[kk], dddmp, sp.dt, i, j, kk);
-    }
-    return;
-  }
-  const int kk = zblock + k0;
+  const int ilo = i0 - 3, jlo = j0 - 3, sj = g.sj;
   const long kb = (long)kk * g.sk;
-  // the divergence on the footprint, and (kept in registers until a plane is free) the relative vorticity under the tile
-  double wreg[DD_NW];
+  double dreg[NE], gvm[NE], gv0[NE], gum[NE], gu0[NE], ra[NE];
+  unsigned plain = 0;  // bit t: this thread's footprint point t takes the plain form of the passes
+#pragma unroll
+  for (int t = 0; t < NE; ++t) {
+    const int e = tid + DD_NT * t;
+    const int jj = e / W, ii = e - jj * W;
+    const int gi = ilo + ii, gj = jlo + jj;
+    const bool ok = e < W * H && gi < g.ni && gj < g.nj;
+    const long c2 = ok ? IDX2(g, gi, gj) : 0;
+    dreg[t] = din[kb + c2];
+    if (!ok) dreg[t] = 0.0;
+    // (the widest pass reaches two points beyond the own points: nord <= 3)
+    const bool pl = ok && gi >= i0 - 2 && gi <= i1 + 2 && gj >= j0 - 2 && gj <= j1 + 2 &&
+                    ((gi > g.is && gi <= g.ie) || (gj > g.js && gj <= g.je));
+    plain |= (pl ? 1u : 0u) << t;
+    const long cm = pl ? c2 : IDX2(g, g.is + 1, g.js + 1);
+    gvm[t] = m.divg_v[cm - sj];
+    gv0[t] = m.divg_v[cm];
+    gum[t] = m.divg_u[cm - 1];
+    gu0[t] = m.divg_u[cm];
+    ra[t] = m.rarea_c[cm];
+  }
   {
-    double dreg[DD_NE];
+    // the relative vorticity under the tile to a plane of its own, a strip's cell widths behind its planes of the passes
+    double wreg[NE], xreg[MODE == 2 ? NE : 1], yreg[MODE == 2 ? NE : 1];
 #pragma unroll
-    for (int t = 0; t < DD_NE; ++t) {
+    for (int t = 0; t < NE; ++t) {
       const int e = tid + DD_NT * t;
-      const int jj = e / DD_W, ii = e - jj * DD_W;
-      const int gi = ilo + ii, gj = jlo + jj;
-      const bool ok = e < DD_W * DD_H && gi < g.ni && gj < g.nj;
-      dreg[t] = din[kb + (ok ? IDX2(g, gi, gj) : 0)];
-      if (!ok) dreg[t] = 0.0;
+      const int jj = e / W, ii = e - jj * W;
+      const bool ok = e < W * H && ilo + ii < g.ni && jlo + jj < g.nj;
+      const long c2 = ok ? IDX2(g, ilo + ii, jlo + jj) : 0;
+      wreg[t] = wk[kb + c2];
+      if (MODE == 2) xreg[t] = m.dxa[c2], yreg[t] = m.dya[c2];
     }
 #pragma unroll
-    for (int t = 0; t < DD_NW; ++t) {
+    for (int t = 0; t < NE; ++t) {
       const int e = tid + DD_NT * t;
-      const int jj = e / DD_WKW, ii = e - jj * DD_WKW;
-      const int gi = i0 - 2 + ii, gj = j0 - 2 + jj;
-      const bool ok = e < DD_WKW * DD_WKH && gi < g.ni && gj < g.nj;
-      wreg[t] = wk[kb + (ok ? IDX2(g, gi, gj) : 0)];
-      if (!ok) wreg[t] = 0.0;
-    }
-#pragma unroll
-    for (int t = 0; t < DD_NE; ++t) {
-      const int e = tid + DD_NT * t;
-      if (e < DD_W * DD_H) sbuf[0][e] = dreg[t];
+      if (e < W * H) {
+        sbuf[0][e] = dreg[t];
+        sbuf[2][e] = wreg[t];
+        if (MODE == 2) sbuf[0][W * H + e] = xreg[t], sbuf[1][W * H + e] = yreg[t];
+      }
     }
   }
   __syncthreads();
+  DD_STAMP(1);
   int cur = 0;
-  // two batches per pass (25 / 20 metric loads in flight; 146 VGPRs = three workgroups per CU.  Three batches at a forced
-  // 128 registers -- four workgroups -- measured 5 % slower)
-  constexpr int E1 = (DD_NE + 1) / 2;
   for (int n = 1; n < nord; ++n) {
     const int nt = nord - n;
-    const int ia = i0 - nt, ja = j0 - nt;  // (i0 >= is, j0 >= js)
-    const int ib = (g.ie + 1 < i0 + DD_TI - 1 ? g.ie + 1 : i0 + DD_TI - 1) + nt;
-    const int jb = (g.je + 1 < j0 + DD_TJ - 1 ? g.je + 1 : j0 + DD_TJ - 1) + nt;
+    const int ia = i0 - nt, ib = i1 + nt, ja = j0 - nt, jb = j1 + nt;
     const double* src = sbuf[cur];
     double* dst = sbuf[cur ^ 1];
-    dd_pass_batch<0, E1>(g, m, src, dst, tid, ilo, jlo, ia, ib, ja, jb);
-    if constexpr (DD_NE > E1) dd_pass_batch<E1, DD_NE>(g, m, src, dst, tid, ilo, jlo, ia, ib, ja, jb);
-    if (ia <= g.is || ib > g.ie) {  // block-uniform: the tile touches the west / east edge columns (corner regions, edge forms)
-      const int ncl = ia <= g.is ? g.is - ia + 1 : 0, ncr = ib > g.ie ? ib - g.ie : 0;
-      const int ncol = ncl + ncr, total = ncol * (jb - ja + 1);
-      const PlaneInLds plane{src, ilo, jlo, DD_W};
+#pragma unroll
+    for (int t = 0; t < NE; ++t) {
+      const int e = tid + DD_NT * t;
+      const int jj = e / W, ii = e - jj * W;
+      const int gi = ilo + ii, gj = jlo + jj;
+      if (((plain >> t) & 1u) && gi >= ia && gi <= ib && gj >= ja && gj <= jb) {
+        const double d0 = src[e];
+        const double ucm = (d0 - src[e - W]) * gvm[t];
+        const double uc0 = (src[e + W] - d0) * gv0[t];
+        const double vcm = (d0 - src[e - 1]) * gum[t];
+        const double vc0 = (src[e + 1] - d0) * gu0[t];
+        double d = ucm - uc0 + vcm - vc0;
+        d = d * ra[t];
+        dst[e] = d;
+      }
+    }
+    // the rest of the pass's domain: columns <= is or > ie in rows <= js or > je (a corner region among the operands, the corner
+    // adjustment of redo_divg_d) -- a handful of points of the corner tiles, enumerated densely
+    const int cl1 = g.is < ib ? g.is : ib, cr0 = g.ie + 1 > ia ? g.ie + 1 : ia;
+    const int rb1 = g.js < jb ? g.js : jb, rt0 = g.je + 1 > ja ? g.je + 1 : ja;
+    const int ncl = cl1 >= ia ? cl1 - ia + 1 : 0, ncr = ib >= cr0 ? ib - cr0 + 1 : 0;
+    const int nrb = rb1 >= ja ? rb1 - ja + 1 : 0, nrt = jb >= rt0 ? jb - rt0 + 1 : 0;
+    const int ncol = ncl + ncr, total = ncol * (nrb + nrt);
+    if (total > 0) {  // block-uniform
+      const PlaneInLds plane{src, ilo, jlo, W};
       for (int p = tid; p < total; p += DD_NT) {
         const int r = p / ncol, cx = p - r * ncol;
-        const int gi = cx < ncl ? ia + cx : g.ie + 1 + (cx - ncl), gj = ja + r;
+        const int gi = cx < ncl ? ia + cx : cr0 + (cx - ncl), gj = r < nrb ? ja + r : rt0 + (r - nrb);
         double d, u_, v_;
         divdamp_point(g, m, plane, gi, gj, true, d, u_, v_);
-        dst[(gj - jlo) * DD_W + (gi - ilo)] = d;
+        dst[(gj - jlo) * W + (gi - ilo)] = d;
       }
     }
     __syncthreads();
     cur ^= 1;
   }
-  // the free plane takes the relative vorticity
-  double* swk = sbuf[cur ^ 1];
-#pragma unroll
-  for (int t = 0; t < DD_NW; ++t) {
-    const int e = tid + DD_NT * t;
-    if (e < DD_WKW * DD_WKH) swk[e] = wreg[t];
-  }
-  __syncthreads();
+  DD_STAMP(2);
   const double d2 = d2_bg[kk];
-  constexpr int P1 = (DD_NP + 1) / 2;
-  dd_tail_batch<0, P1>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb, full);
-  if constexpr (DD_NP > P1)
-    dd_tail_batch<P1, DD_NP>(g, m, sbuf[cur], swk, din, divg_d, vort_b, ke, uc_out, vc_out, d2, dddmp, dd8, absdt, tid, i0, j0, kb, full);
-  // The remaining own points: the frame of the tile domain, two points deep (corner regions, edge forms of the pass and of
-  // a2b_ord4).  They are enumerated densely -- first the tile's frame columns over all of its rows, then its frame rows over
-  // the other columns -- so that a wave that runs the long general code is full (left in place, two lanes of EVERY wave of
-  // an edge tile took that path: 110 of 190 us).
-  const PlaneInLds src{sbuf[cur], ilo, jlo, DD_W};
-  const int i1 = (i0 + DD_TI - 1 < g.ie + 1) ? i0 + DD_TI - 1 : g.ie + 1;  // own points: i0 .. i1, j0 .. j1
-  const int j1 = (j0 + DD_TJ - 1 < g.je + 1) ? j0 + DD_TJ - 1 : g.je + 1;
-  const bool all_frame = g.n < 8;
-  // frame columns [i0, fl) and (fr, i1]; frame rows [j0, fb) and (ft, j1]
-  const int fl = all_frame ? i1 + 1 : (i0 < g.is + 2 ? (g.is + 2 < i1 + 1 ? g.is + 2 : i1 + 1) : i0);
-  const int fr = all_frame ? i1 : (i1 > g.ie - 1 ? (g.ie - 1 > fl - 1 ? g.ie - 1 : fl - 1) : i1);
-  const int fb = all_frame ? j1 + 1 : (j0 < g.js + 2 ? (g.js + 2 < j1 + 1 ? g.js + 2 : j1 + 1) : j0);
-  const int ft = all_frame ? j1 : (j1 > g.je - 1 ? (g.je - 1 > fb - 1 ? g.je - 1 : fb - 1) : j1);
-  const int ncol = (fl - i0) + (i1 - fr), nrow_all = j1 - j0 + 1;
-  const int nmid = fr - fl + 1, nrow = (fb - j0) + (j1 - ft);
-  const int n_a = ncol * nrow_all, n_b = nmid > 0 ? nmid * nrow : 0;
-  for (int p = tid; p < n_a + n_b; p += DD_NT) {
-    int i, j;
-    if (p < n_a) {
-      const int r = p / ncol, cx = p - r * ncol;
-      i = cx < fl - i0 ? i0 + cx : fr + 1 + (cx - (fl - i0));
-      j = j0 + r;
+  const double* src = sbuf[cur];
+  const double* swk = sbuf[2];
+#pragma unroll
+  for (int t = 0; t < NE; ++t) {
+    const int e = tid + DD_NT * t;
+    const int jj = e / W, ii = e - jj * W;
+    const int i = ilo + ii, j = jlo + jj;
+    bool on = e < W * H && i >= i0 && i <= i1 && j >= j0 && j <= j1;
+    // a tile: the own points where a2b_ord4 is the 16-point mean (there the pass is plain, too)
+    if (MODE == 0) on = on && i >= g.is + 2 && i <= g.ie - 1 && j >= g.js + 2 && j <= g.je - 1;
+    if (!on) continue;
+    double dfin, uc0, vc0;
+    if (MODE == 0 || ((plain >> t) & 1u)) {
+      const double d0 = src[e];
+      const double ucm = (d0 - src[e - W]) * gvm[t];
+      uc0 = (src[e + W] - d0) * gv0[t];
+      const double vcm = (d0 - src[e - 1]) * gum[t];
+      vc0 = (src[e + 1] - d0) * gu0[t];
+      dfin = ucm - uc0 + vcm - vc0;
+      dfin = dfin * ra[t];
     } else {
-      const int pp = p - n_a;
-      const int r = pp / nmid, cx = pp - r * nmid;
-      i = fl + cx;
-      j = r < fb - j0 ? j0 + r : ft + 1 + (r - (fb - j0));
+      divdamp_point(g, m, PlaneInLds{src, ilo, jlo, W}, i, j, false, dfin, uc0, vc0);
     }
-    double dfin, uc_here, vc_here;
-    divdamp_point(g, m, src, i, j, false, dfin, uc_here, vc_here);
     const long c = kb + IDX2(g, i, j);
-    const double dpc = din[c];  // the divergence before the passes (= delpc)
     // The reference uses the caller's uc / vc as the work fields of the passes and its Translate tests compare what is left
     // in them after d_sw on the staggered compute windows (translate_d_sw.py:36-65): the values of the LAST pass.
-    if (full && j <= g.je) uc_out[c] = uc_here;
-    if (full && i <= g.ie) vc_out[c] = vc_here;
+    if (full && j <= g.je) uc_out[c] = uc0;
+    if (full && i <= g.ie) vc_out[c] = vc0;
+    const double dpc = dreg[t];  // the divergence before the passes (= delpc)
     double vb;
     if (dddmp < 1e-5) {
       vb = 0.0;
     } else {
-      A2B a{g, m, wk + kb};
-      const double qb = a.point(i, j);
+      double qb;
+      if (MODE == 0) {
+        qb = a2b_interior_point(PlaneInLds{swk, ilo, jlo, W}, i, j);
+      } else if (MODE == 2) {
+        A2BT<A2BInLds> a{g, m, A2BInLds{swk, sbuf[0] + W * H, sbuf[1] + W * H, ilo, jlo, W}};
+        qb = a.point(i, j);
+      } else {
+        A2B a{g, m, {wk + kb}};
+        qb = a.point(i, j);
+      }
       vb = absdt * sqrt(dpc * dpc + qb * qb);
     }
     const double damp = m.da_min_c * fmax(d2, fmin(0.2, dddmp * fabs(vb)));
@@ -881,16 +829,64 @@ divdamp_fused_block(double (*sbuf)[DD_W * DD_H], int tile, int zblock, const Geo
     if (ke != nullptr) ke[c] = ke[c] + vort;
     if (full) divg_d[c] = dfin;  // the caller's divgd ends as the iterated divergence (redo_divg_d; compared by TranslateD_SW)
   }
+  DD_STAMP(3);
 }
 
-__global__ void __launch_bounds__(DD_NT)
+__global__ void __launch_bounds__(DD_NT) DD_ATTR
 k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
                 real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
-                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int full_,
+                const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int ntiles, int full_,
                 DdSponge sp) {
-  __shared__ double sbuf[2][DD_W * DD_H];
-  divdamp_fused_block(sbuf, (int)blockIdx.x, (int)blockIdx.z, g, m, wk, din, divg_d, vort_b, ke, uc_out, vc_out, d2_bg, dddmp, dd8, absdt,
-                      k0, nord, ntx, full_, sp);
+  __shared__ double sbuf[3][DD_PLANE];  // two planes of the passes, one of the relative vorticity
+  int b = (int)blockIdx.x;
+  const bool full = full_ != 0;
+  DD_STAMP(0);
+  if (b < sp.nblocks) {
+    // a sponge level: 256 B-grid points of it
+    const int per = sp.nblocks / sp.nlev, kk = b / per, w = g.n + 1;
+    const int q = (b - kk * per) * DD_NT + (int)threadIdx.x;
+    if (q < w * w) {
+      const int jj = q / w;
+      divdamp_low_point(g, m, sp.u, sp.v, sp.ua, sp.va, sp.uc, sp.vc, sp.delpc, vort_b, ke, d2_bg[kk], dddmp, sp.dt, g.is + (q - jj * w),
+                        g.js + jj, kk);
+    }
+    DD_STAMP(7);
+    return;
+  }
+  b -= sp.nblocks;
+  if (b < sp.nstrips) {
+    const int per = 2 * (sp.nch_row + sp.nch_col);
+    const int lev = b / per, id = b - lev * per;
+    if (id < 2 * sp.nch_row) {  // south, north rows: the full width
+      const int side = id / sp.nch_row, ch = id - side * sp.nch_row;
+      const int i0 = g.is + ch * sp.len_row, j0 = side == 0 ? g.js : g.je;
+      const int i1 = i0 + sp.len_row - 1 < g.ie + 1 ? i0 + sp.len_row - 1 : g.ie + 1;
+      divdamp_tile<DD_STRIP, 2, 2>(sbuf, i0, i1, j0, j0 + 1, lev + k0, g, m, wk, din, divg_d, vort_b, ke, uc_out, vc_out, d2_bg, dddmp, dd8,
+                                      absdt, nord, full);
+    } else {  // west, east columns between them
+      const int id2 = id - 2 * sp.nch_row;
+      const int side = id2 / sp.nch_col, ch = id2 - side * sp.nch_col;
+      const int j0 = g.js + 2 + ch * sp.len_col, i0 = side == 0 ? g.is : g.ie;
+      const int j1 = j0 + sp.len_col - 1 < g.je - 1 ? j0 + sp.len_col - 1 : g.je - 1;
+      divdamp_tile<2, DD_STRIP, 2>(sbuf, i0, i0 + 1, j0, j1, lev + k0, g, m, wk, din, divg_d, vort_b, ke, uc_out, vc_out, d2_bg, dddmp, dd8,
+                                      absdt, nord, full);
+    }
+    DD_STAMP(7);
+    return;
+  }
+  b -= sp.nstrips;
+  const int zblock = b / ntiles, tile = b - zblock * ntiles;
+  const int by = tile / ntx, bx = tile - by * ntx;
+  const int i0 = g.is + bx * DD_TI, j0 = g.js + by * DD_TJ;
+  const int i1 = i0 + DD_TI - 1 < g.ie + 1 ? i0 + DD_TI - 1 : g.ie + 1;
+  const int j1 = j0 + DD_TJ - 1 < g.je + 1 ? j0 + DD_TJ - 1 : g.je + 1;
+  if (sp.nstrips > 0)
+    divdamp_tile<DD_TI, DD_TJ, 0>(sbuf, i0, i1, j0, j1, zblock + k0, g, m, wk, din, divg_d, vort_b, ke, uc_out, vc_out, d2_bg, dddmp, dd8,
+                                      absdt, nord, full);
+  else  // a tile too small for a frame and an interior
+    divdamp_tile<DD_TI, DD_TJ, 1>(sbuf, i0, i1, j0, j1, zblock + k0, g, m, wk, din, divg_d, vort_b, ke, uc_out, vc_out, d2_bg, dddmp, dd8,
+                                     absdt, nord, full);
+  DD_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1067,7 +1063,7 @@ k_a2b_interior_tiled(Geo g, Met m, A2BBatch job, int kmin, int ntx, Regions R) {
     (void)interior;
     const int kf = k + kmin;
     if (kf < job.k0[f] || kf >= job.k1[f]) return;
-    A2B a{g, m, job.in[f] + (long)kf * g.sk};
+    A2B a{g, m, {job.in[f] + (long)kf * g.sk}};
     job.out[f][IDX3(g, i, j, kf)] = a.point(i, j);
     return;
   }
@@ -1171,10 +1167,23 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
   if (fused) {
     const double dd8 = pow(m.da_min_c * d4_bg, (double)(nonzero_nord + 1));
     const int ntx = (g.n + 1 + DD_TI - 1) / DD_TI, nty = (g.n + 1 + DD_TJ - 1) / DD_TJ;
-    const DdSponge sp{u, v, ua, va, uc, vc, delpc, dt, nhigh};
-    hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(ntx * nty), 1, (unsigned)(nhigh + (skip_dead ? kstart : 0))), dim3(DD_NT), 0, st, g, m,
+    DdSponge sp{u, v, ua, va, uc, vc, delpc, dt, 0, 0, 0, 1, 1, 1, 1};
+    if (skip_dead && kstart > 0) {
+      sp.nlev = kstart;
+      sp.nblocks = kstart * (((g.n + 1) * (g.n + 1) + DD_NT - 1) / DD_NT);
+    }
+    if (g.n >= 8) {
+      // chunks of at most DD_STRIP points along the edge (footprint (len + 6) x 8 <= a tile's: the strips share its two LDS planes)
+      const int nrow = g.n + 1, ncol = g.n - 3;
+      sp.nch_row = (nrow + DD_STRIP - 1) / DD_STRIP;
+      sp.len_row = (nrow + sp.nch_row - 1) / sp.nch_row;
+      sp.nch_col = (ncol + DD_STRIP - 1) / DD_STRIP;
+      sp.len_col = (ncol + sp.nch_col - 1) / sp.nch_col;
+      sp.nstrips = 2 * (sp.nch_row + sp.nch_col) * nhigh;
+    }
+    hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(sp.nblocks + sp.nstrips + ntx * nty * nhigh)), dim3(DD_NT), 0, st, g, m,
                        rel_vort_agrid, skip_dead ? divg_d : delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart,
-                       nonzero_nord, ntx, skip_dead ? 0 : 1, sp);
+                       nonzero_nord, ntx, ntx * nty, skip_dead ? 0 : 1, sp);
   } else if (nhigh > 0) {
     const real* src = divg_d;
     real* bufs[2] = {da, db};

@@ -1,12 +1,12 @@
 // FiniteVolumeFluxPrep (Fortran fxadv) -- contravariant C-grid winds, Courant numbers and area
 // fluxes.  Reference: fv3core/pace/fv3core/stencils/fxadv.py:10-661 (8 stencils, each a full
-// pass over two to four 3-D fields).  Here: one streaming pass for the interior formula and the
-// west/east edge rule, three thin passes that only touch the O(N) edge/corner points, and one
-// streaming pass for the fluxes.  HBM-bound: 2 reads + 6 writes of 3-D fields are algorithmic.
+// pass over two to four 3-D fields).  Here: one thin launch for the frame of the plane (the interior formula there, then the
+// edge and corner rules, which only touch O(N) points), and one streaming pass that forms the interior's contravariant winds
+// in registers and writes the fluxes.  HBM-bound: 2 reads + 4 writes (+ cx, cy read-modify-write in d_sw) are algorithmic.
 #include "common.h"
 #include "kernels.h"
 
-// Interior / frame split (launch_fxadv `part`): the points of the box [is+2, ie-1] x [js+2, je-1] read no halo value of uc / vc
+// Interior / frame split (launch_fxadv `part`): the points of the box [is+2, ie-2] x [js+2, je-2] read no halo value of uc / vc
 // and are touched by none of the edge / corner stages, so their share of stage A and of the fluxes can run while the uc / vc
 // halo exchange is in flight (dyn_core.py:817-820); the frame (everything else, incl. the whole halo region) runs after it.
 typedef SplitBox FxBox;
@@ -16,11 +16,9 @@ __device__ __forceinline__ double contra(double v1, double v2, double cosa, doub
 }
 
 // stage A: main_uc_vc_contra (fxadv.py:10-48) + uc_contra_y_edge (:51-77)
-__global__ void __launch_bounds__(256) k_fxadv_main(Geo g, Met m, const real* __restrict__ uc,
-                                                    const real* __restrict__ vc, real* __restrict__ ut,
-                                                    real* __restrict__ vt, FxBox box) {
-  PLANE_IJK(g);
-  if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;  // domain_full = N+6 points
+__device__ __forceinline__ void fx_main_point(const Geo& g, const Met& m, const real* __restrict__ uc, const real* __restrict__ vc,
+                                              real* __restrict__ ut, real* __restrict__ vt, int i, int j, int k) {
+  if (i > g.ni - 2 || j > g.nj - 2) return;  // domain_full = N+6 points
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
   if (i == g.is || i == g.ie + 1) {
@@ -134,16 +132,21 @@ __device__ __forceinline__ void fx_vt_corners_point(const Geo& g, const Met& m, 
   vt[c] = val;
 }
 
-// fxadv_fluxes_stencil (:436-486).  A thread takes FX_CH consecutive levels of its point: the ten metric values a point needs
-// (rdxa, rdya, dx, dy and the sin_sg of either side) are the same on every level and are loaded once.
+// fxadv_fluxes_stencil (:436-486).  A thread takes FX_CH consecutive levels of its point: the metric values a point needs
+// (rdxa, rdya, dx, dy, the sin_sg of either side, cosa / rsin of its two faces) are the same on every level and are loaded once.
+// Round 5: a point of the interior box forms its contravariant winds here, from uc and vc (stage A's interior formula, the only
+// one that applies there), instead of reading them back from ut / vt: the two 3-D fields ut and vt are no longer written and
+// read on 90 % of the plane (4 of 12 field passes of fxadv).  Frame points read the ut / vt the edge kernel below left there.
+// contra_out: also store the winds formed here (the stand-alone entry pace_fxadv returns ut and vt whole).
 #define FX_CH 8
-__global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* __restrict__ ut,
-                                                      const real* __restrict__ vt, real* __restrict__ crx,
+__global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
+                                                      real* __restrict__ ut, real* __restrict__ vt, real* __restrict__ crx,
                                                       real* __restrict__ cry, real* __restrict__ xfx,
                                                       real* __restrict__ yfx, double dt,
-                                                      real* __restrict__ cx_acc, real* __restrict__ cy_acc, FxBox box) {
+                                                      real* __restrict__ cx_acc, real* __restrict__ cy_acc, FxBox box, int contra_out) {
   // cx_acc / cy_acc (optional): the Courant-number half of d_sw's flux_capacitor (d_sw.py:33-60), cx += crx, cy += cry,
   // done where crx / cry are produced
+  // (flattened rows; 64 x 4 patches, which halve the re-reads of the rows above and below, measured 64 us against 61)
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   const int j = (int)(p / g.sj);
   const int i = (int)(p - (long)j * g.sj);
@@ -151,18 +154,33 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
   if (j >= g.nj || i >= g.ni) return;
   if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;
   const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  const bool inner = i >= box.i0 && i <= box.i1 && j >= box.j0 && j <= box.j1;  // then do_x and do_y both hold
   const bool do_x = i >= g.is && i <= g.ie + 1, do_y = j >= g.js && j <= g.je + 1;
   double rdxa_m = 0.0, rdxa_0 = 0.0, dy = 0.0, sg3_m = 0.0, sg1_0 = 0.0;
   double rdya_m = 0.0, rdya_0 = 0.0, dx = 0.0, sg4_m = 0.0, sg2_0 = 0.0;
+  double cosa_u = 0.0, rsin_u = 0.0, cosa_v = 0.0, rsin_v = 0.0;
   if (do_x) rdxa_m = m.rdxa[c2 - 1], rdxa_0 = m.rdxa[c2], dy = m.dy[c2], sg3_m = m.sin_sg3[c2 - 1], sg1_0 = m.sin_sg1[c2];
-  if (do_y) rdya_m = m.rdya[c2 - g.sj], rdya_0 = m.rdya[c2], dx = m.dx[c2], sg4_m = m.sin_sg4[c2 - g.sj], sg2_0 = m.sin_sg2[c2];
+  if (do_y) rdya_m = m.rdya[c2 - sj], rdya_0 = m.rdya[c2], dx = m.dx[c2], sg4_m = m.sin_sg4[c2 - sj], sg2_0 = m.sin_sg2[c2];
+  if (inner) cosa_u = m.cosa_u[c2], rsin_u = m.rsin_u[c2], cosa_v = m.cosa_v[c2], rsin_v = m.rsin_v[c2];
 #pragma unroll
   for (int t = 0; t < FX_CH; ++t) {
     const int k = k0 + t;
     if (k >= g.nk) break;
     const long c = c2 + (long)k * g.sk;
+    double u = 0.0, v = 0.0;
+    if (inner) {
+      const double uc0 = uc[c], vc0 = vc[c];
+      const double vb = 0.25 * (vc[c - 1] + vc0 + vc[c - 1 + sj] + vc[c + sj]);
+      const double ub = 0.25 * (uc[c - sj] + uc[c + 1 - sj] + uc0 + uc[c + 1]);
+      u = contra(uc0, vb, cosa_u, rsin_u);
+      v = contra(vc0, ub, cosa_v, rsin_v);
+      if (contra_out) ut[c] = u, vt[c] = v;
+    } else {
+      if (do_x) u = ut[c];
+      if (do_y) v = vt[c];
+    }
     if (do_x) {
-      const double u = ut[c];
       double cr;
       if (u > 0.0) {
         cr = dt * u * rdxa_m;
@@ -175,7 +193,6 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
       if (cx_acc) cx_acc[c] = cx_acc[c] + cr;
     }
     if (do_y) {
-      const double v = vt[c];
       double cr;
       if (v > 0.0) {
         cr = dt * v * rdya_m;
@@ -190,9 +207,21 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
   }
 }
 
-// Stages B, C, D in ONE launch: a workgroup of 1024 threads per level walks the strips of each stage (one or two points per thread); a stage reads what the previous one
-// wrote at other points of the same level, so the stages are separated by a workgroup barrier (writes to global memory made
-// visible to the workgroup by the fence).  Three launches of ~5 us each (their cost is launch latency) become one.
+// Stage A on the frame: a launch over its four rectangles.  (As a first stage of the one-workgroup-per-level kernel below it
+// cost 15 us: four rounds of dependent loads on 79 compute units.)
+__global__ void __launch_bounds__(256) k_fxadv_frame(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
+                                                    real* __restrict__ ut, real* __restrict__ vt, Regions R) {
+  REGION_POINT(R);
+  (void)interior;
+  fx_main_point(g, m, uc, vc, ut, vt, i, j, k);
+}
+
+// Stages B, C, D in ONE launch: a workgroup of 1024 threads per level walks the strips of each stage (one or two points per
+// thread); a stage reads what the previous one wrote at other points of the same level, so the stages are separated by a workgroup
+// barrier (writes to global memory made visible to the workgroup by the fence).  The frame is everything outside the interior
+// box [is+2, ie-2] x [js+2, je-2] (11 % of the plane at C192): every point a stage B, C or D formula reads or writes lies in it,
+// and so does every ut / vt d_sw's kinetic energy reads at the tile edges (rows js-2 .. js+1 and je-1 .. je+2 of ut, the same
+// columns of vt: k_dsw.hip kinetic_energy_point).
 struct FxStrips {
   Regions b, c, d;
 };
@@ -232,13 +261,24 @@ __global__ void __launch_bounds__(1024) k_fxadv_edges(Geo g, Met m, const real* 
 
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
-                 hipStream_t st, int part) {
-  // part 0: everything; 1: the interior box only (needs no halo of uc / vc); 2: the rest, to be run after part 1
-  const dim3 grid = plane_grid(g, g.nk), block(256);
-  FxBox box{g.is + 2, g.ie - 1, g.js + 2, g.je - 1, part};
-  if (part == 1 && (box.i1 < box.i0 || box.j1 < box.j0)) return PACE_OK;
-  hipLaunchKernelGGL(k_fxadv_main, grid, block, 0, st, g, m, uc, vc, ut, vt, box);
+                 hipStream_t st, int part, int contra_out) {
+  // part 0: everything; 1: the interior box only (needs no halo of uc / vc, and neither ut nor vt); 2: the rest, after part 1
+  FxBox box{g.is + 2, g.ie - 2, g.js + 2, g.je - 2, part};
+  const bool has_box = box.i1 >= box.i0 && box.j1 >= box.j0;
+  if (!has_box) box.i1 = box.i0 - 1, box.j1 = box.j0 - 1;  // nothing is inside
+  if (part == 1 && !has_box) return PACE_OK;
   if (part != 1) {
+    Regions A{};
+    // stage A: the frame -- whole rows below js+2 and above je-2, the columns left of is+2 and right of ie-2 between them
+    if (has_box) {
+      add_region(A, 0, g.ni - 2, 0, g.js + 1);
+      add_region(A, 0, g.ni - 2, g.je - 1, g.nj - 2);
+      add_region(A, 0, g.is + 1, g.js + 2, g.je - 2);
+      add_region(A, g.ie - 1, g.ni - 2, g.js + 2, g.je - 2);
+    } else {
+      add_region(A, 0, g.ni - 2, 0, g.nj - 2);
+    }
+    hipLaunchKernelGGL(k_fxadv_frame, regions_grid(A, g.nk), dim3(64, 4), 0, st, g, m, uc, vc, ut, vt, A);
     FxStrips S{};
     // stage B: rows js, je+1 over the whole width; columns is-1, is, ie, ie+1 between them
     add_region(S.b, 0, g.ni - 2, g.js, g.js);
@@ -253,8 +293,9 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
     add_region(S.d, g.is - 1, g.ie + 1, g.je, g.je);
     hipLaunchKernelGGL(k_fxadv_edges, dim3((unsigned)g.nk), dim3(1024), 0, st, g, m, uc, vc, ut, vt, S);
   }
-  const dim3 grid_fluxes(grid.x, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);
-  hipLaunchKernelGGL(k_fxadv_fluxes, grid_fluxes, block, 0, st, g, m, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box);
+  const dim3 grid_fluxes(plane_grid(g, 1).x, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);
+  hipLaunchKernelGGL(k_fxadv_fluxes, grid_fluxes, dim3(256), 0, st, g, m, uc, vc, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box,
+                     contra_out);
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

@@ -4,7 +4,7 @@
 
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
-                 hipStream_t st, int part = 0);
+                 hipStream_t st, int part = 0, int contra_out = 0);
 int launch_fvtp2d(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry,
                   const real* xfx, const real* yfx, real* fx, real* fy, const real* xmf,
                   const real* ymf, int hord, int nlev, hipStream_t st);

@@ -187,6 +187,43 @@ def test_c384x91_f32_d_sw_level_slab_matches_oracle():
         assert e < (5e-3 if k in ("heat_source", "diss_est") else 2e-5), (k, e)
 
 
+def test_c384x91_f32_d_sw_on_a_generated_sphere_tile_matches_oracle():
+    """The same on the cubed sphere: the metric terms of one C384 tile from pace_amd's own generator (gnomonic grid, every edge
+    and corner form with its real metrics; checked against the reference's MetricTerms at C12 in tests/test_gridgen.py), the
+    state built on them, all of d_sw in float32 storage -- the fused scalar + wind kernel, 12 x 16 tiles of 32 x 24 -- against
+    the float64 oracle on a slab of levels x the full plane."""
+    from oracle import dgrid_sw
+    from pace_amd import _lib, synthetic
+    from pace_amd.util import gridgen
+
+    n, nz = C384["n"], C384["nz"]
+    metrics = gridgen.tiles(n, nz)[2]
+    with np.errstate(all="ignore"):
+        s = synthetic.acoustic_state(metrics, n, nz)
+    s = {k: (np.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0) if isinstance(v, np.ndarray) else v) for k, v in s.items()}
+    lib32 = _lib.load(32)
+    env = Env(lib32, "cuda", metrics, n, nz)
+    col = {k: np.concatenate([v[:79], np.repeat(v[78:79], nz - 79 + 1)])[:nz] for k, v in golden("column_namelist_c12.npz").items()}
+    out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"])
+    assert out["delp"].dtype == np.float32
+    k_sel = np.array([0, 2, 46, 90])
+    nk = len(k_sel)
+    r32 = lambda a_: a_.astype(np.float32).astype(np.float64)  # noqa: E731
+    g = oracle_grid({k: (r32(v) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in metrics.items()}, n, nk)
+    colk = {k: np.concatenate([v[k_sel], v[k_sel][-1:]]) for k, v in col.items()}
+    pick = lambda a_: np.ascontiguousarray(np.concatenate([a_[:, :, k_sel], a_[:, :, k_sel[-1:]]], axis=2))  # noqa: E731
+    a = {k: r32(pick(s[k])) for k in DSW_ARGS}  # the oracle sees what the device saw: float32-rounded inputs and metrics
+    dgrid_sw.d_sw(g, colk, DSW_CFG, dgrid_sw.DSWState(a["u"].shape), *[a[k] for k in DSW_ARGS], s["dt"])
+    for k in DSW_ARGS:
+        if k == "zh":
+            continue
+        W = dsw_window(k, n, nk)
+        ref, got = a[k][W], out[k][:, :, k_sel][W[0], W[1]]
+        assert np.isfinite(got).all(), k
+        e = _rel(ref, got)
+        assert e < (5e-3 if k in ("heat_source", "diss_est") else 2e-4 if k in ("uc", "vc", "divgd", "delpc") else 5e-5), (k, e)
+
+
 def test_c384x91_f32_riem_solver3_sampled_columns_match_oracle():
     """riem_solver3 of the float32 library at C384 x 91 -- the six-levels-per-lane instance of the 16-lanes-per-column kernel
     (91 levels; 79 use five) -- on the whole tile; the float64 oracle on 12 x 12 blocks of columns (corners, an edge, the centre)
