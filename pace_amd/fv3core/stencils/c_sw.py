@@ -45,3 +45,4 @@ class CGridShallowWaterDynamics(Operator):
             self.lib.call("pace_c_sw_part", 2, C.byref(self._geom), *args)
         else:
             self.call("pace_c_sw", *args)
+        return self.delpc, self.ptc  # (c_sw.py:766: the reference returns its two internal fields)

@@ -104,35 +104,37 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* m
   gridDim = grid;
   blockDim = block;
   g_body = &body;
-  if (*mode != 2) {
-    g_plain = true;
-    try {
-      for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-          for (unsigned bx = 0; bx < grid.x; ++bx) {
-            blockIdx = {bx, by, bz};
+  const size_t nthreads = (size_t)block.x * block.y * block.z;
+  const size_t stack_bytes = 256 * 1024;
+  std::vector<Fiber> fibers;
+  // Block by block: the threads run as plain calls until one of them reaches a barrier, then THAT block is run again with
+  // fibers (nothing but LDS is written before a block's first barrier: its first thread is the one that gets there).  A launch
+  // may mix workgroups that synchronise with workgroups that do not (k_divdamp_fused: point-function workgroups first, then the
+  // tiles) -- restarting the whole launch would run the former twice, read-modify-writes included.
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = {bx, by, bz};
+        bool need_fibers = *mode == 2;
+        if (!need_fibers) {
+          g_plain = true;
+          try {
             for (unsigned tz = 0; tz < block.z; ++tz)
               for (unsigned ty = 0; ty < block.y; ++ty)
                 for (unsigned tx = 0; tx < block.x; ++tx) {
                   threadIdx = {tx, ty, tz};
                   body();
                 }
+          } catch (const NeedsFibers&) {
+            need_fibers = true;
           }
-      g_plain = false;
-      *mode = 1;
-      return;
-    } catch (const NeedsFibers&) {
-      g_plain = false;
-      *mode = 2;
-    }
-  }
-  const size_t nthreads = (size_t)block.x * block.y * block.z;
-  const size_t stack_bytes = 256 * 1024;
-  std::vector<Fiber> fibers(nthreads);
-  for (auto& f : fibers) f.stack.resize(stack_bytes);
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
+          g_plain = false;
+        }
+        if (!need_fibers) continue;
+        if (fibers.empty()) {
+          fibers.resize(nthreads);
+          for (auto& f : fibers) f.stack.resize(stack_bytes);
+        }
         size_t t = 0;
         for (unsigned tz = 0; tz < block.z; ++tz)
           for (unsigned ty = 0; ty < block.y; ++ty)
@@ -158,4 +160,5 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* m
           }
         }
       }
+  (void)mode;
 }

@@ -46,11 +46,9 @@ inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 void __syncthreads();
 inline void __threadfence_block() {}
 inline void __threadfence() {}
-// `mode` is per launch site: 0 = not known yet, 1 = the kernel never synchronises (threads run as plain calls),
-// 2 = it does (threads run as fibers).  A kernel that hits __syncthreads() in plain mode is restarted with fibers;
-// that is safe because nothing but LDS is written before a kernel's first barrier.
-// `name` is what the SIGSEGV reporter prints (PACE_EMU_GUARD=1: tests/guard.py puts every array against an inaccessible
-// page, so an out-of-bounds access of a kernel faults here instead of only on the GPU).
+// Per workgroup: its threads run as plain calls until one reaches __syncthreads(), then that workgroup is run again with
+// fibers; that is safe because nothing but LDS is written before a workgroup's first barrier.  (`mode`: unused, kept for the
+// launch macro.)
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body, int* mode, const char* name);
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                      \

@@ -138,6 +138,59 @@ def test_riem_solver3_and_fxadv_pairs_through_the_runner(tmp_path):
     assert ok and max(worst.values()) == 0.0, worst
 
 
+def test_c_sw_updatedzc_updatedzd_pairs_through_the_runner(tmp_path):
+    """The three operators of the acoustic loop next to the headline pair (translate_c_sw.py:73-113, translate_updatedzc.py:10-70,
+    translate_updatedzd.py:12-87): pairs in the serialised extents of their Translate classes -- staggered full-domain winds, the
+    2-D `ws` / `wsd`, `zh` with npz + 1 levels -- written from the oracle's walk through the loop body (tests/opchain.py)."""
+    import argparse
+
+    import opchain
+    import run_savepoints as rs
+    from pace_amd import _lib
+    from pace_amd.tile import DSW_CFG
+
+    d = str(tmp_path)
+    ch = opchain.Chain(N, NZ)
+    np.savez(os.path.join(d, "metrics.npz"), **ch.metrics)
+    cases = {c.name: c for c in ch.cases(only=("c_sw", "updatedzc", "updatedzd"))}
+    full, fx, fy, fxy = np.s_[:N + 6, :N + 6, :NZ], np.s_[:N + 7, :N + 6, :NZ], np.s_[:N + 6, :N + 7, :NZ], np.s_[:N + 7, :N + 7, :NZ]
+    fullk = np.s_[:N + 6, :N + 6, :NZ + 1]
+    cx_, cy_ = np.s_[3:N + 4, :N + 6, :NZ], np.s_[:N + 6, 3:N + 4, :NZ]
+    # ---- C_SW: every argument over the full domain (+ staggering), delpc / ptc as outputs
+    win = {"u": fy, "v": fx, "uc": fx, "vc": fy, "divgd": fxy}
+    names = ("delp", "pt", "u", "v", "w", "uc", "vc", "ua", "va", "ut", "vt", "omga", "divgd")
+    c = cases["c_sw"]
+    ins = {k + "d": _sp(c.before[k][win.get(k, full)]) for k in names}
+    ins["dt2"] = _sp(np.array(0.5 * ch.dt))
+    outs = {k + "d": _sp(c.after[k][win.get(k, full)]) for k in names}
+    outs.update(delpcd=_sp(c.after["delpc"][full]), ptcd=_sp(c.after["ptc"][full]))
+    np.savez(os.path.join(d, "C_SW-In.npz"), **ins)
+    np.savez(os.path.join(d, "C_SW-Out.npz"), **outs)
+    # ---- UpdateDzC: gz with npz + 1 levels over the full domain, ws 2-D; compared on the compute domain
+    c = cases["updatedzc"]
+    np.savez(os.path.join(d, "UpdateDzC-In.npz"), zs=_sp(c.before["zs"][:N + 6, :N + 6]), utc=_sp(c.before["ut"][full]), vtc=_sp(c.before["vt"][full]),
+             gz=_sp(c.before["gz"][fullk]), ws=_sp(c.before["ws3"][:N + 6, :N + 6]), dt2=_sp(np.array(0.5 * ch.dt)))
+    np.savez(os.path.join(d, "UpdateDzC-Out.npz"), gz=_sp(c.after["gz"][3:N + 3, 3:N + 3, :NZ + 1]), ws=_sp(c.after["ws3"][3:N + 3, 3:N + 3]))
+    # ---- UpdateDzD: zh with npz + 1 levels, the Courant numbers / area fluxes on their staggered windows, wsd on the compute domain
+    c = cases["updatedzd"]
+    uin = {"zs": _sp(c.before["zs"][:N + 6, :N + 6]), "zh": _sp(c.before["zh"][fullk]), "crx": _sp(c.before["crx"][cx_]), "cry": _sp(c.before["cry"][cy_]),
+           "xfx": _sp(c.before["xfx"][cx_]), "yfx": _sp(c.before["yfx"][cy_]), "wsd": _sp(c.before["wsd"][3:N + 3, 3:N + 3]), "dt": _sp(np.array(ch.dt))}
+    uout = {"zh": _sp(c.after["zh"][3:N + 3, 3:N + 3, :NZ + 1]), "crx": _sp(c.after["crx"][cx_]), "cry": _sp(c.after["cry"][cy_]),
+            "xfx": _sp(c.after["xfx"][cx_]), "yfx": _sp(c.after["yfx"][cy_]), "wsd": _sp(c.after["wsd"][3:N + 3, 3:N + 3])}
+    np.savez(os.path.join(d, "UpdateDzD-In.npz"), **uin)
+    np.savez(os.path.join(d, "UpdateDzD-Out.npz"), **uout)
+
+    lib = _lib.Library(build_emu())
+    args = argparse.Namespace(device="cpu", metrics=os.path.join(d, "metrics.npz"), rank_tile=False, namelist={"d_sw": DSW_CFG, "hord_tm": opchain.HORD_TM})
+    ok, bound, worst, ok_inner, inner = rs.run_one("C_SW", rs.read_pair(d, "C_SW"), args, lib)
+    assert bound == 2e-10 and set(worst) == {"delp", "pt", "u", "v", "w", "uc", "vc", "ua", "va", "ut", "vt", "omga", "divgd", "delpcd", "ptcd"}
+    assert ok_inner, inner
+    ok, bound, worst, _, _ = rs.run_one("UpdateDzC", rs.read_pair(d, "UpdateDzC"), args, lib)
+    assert bound == 1e-14 and set(worst) == {"gz", "ws"} and ok, worst
+    ok, bound, worst, _, _ = rs.run_one("UpdateDzD", rs.read_pair(d, "UpdateDzD"), args, lib)
+    assert set(worst) == {"height", "courant_number_x", "courant_number_y", "x_area_flux", "y_area_flux", "ws"} and ok, worst
+
+
 def test_unreadable_netcdf_says_what_to_do(tmp_path):
     import run_savepoints as rs
 

@@ -323,8 +323,65 @@ def spec_fxadv(g):  # translate_fxadv.py:8-72 (uc_contra / vc_contra are compare
     return Spec(iv, ["dt"], ov, 1e-14, run)
 
 
+def spec_c_sw(g):  # translate_c_sw.py:73-113
+    iv = {"delp": {}, "pt": {}, "u": {"jend": g.jed + 1}, "v": {"iend": g.ied + 1}, "w": {}, "uc": {"iend": g.ied + 1}, "vc": {"jend": g.jed + 1},
+          "ua": {}, "va": {}, "ut": {}, "vt": {}, "omga": {}, "divgd": {"iend": g.ied + 1, "jend": g.jed + 1}}
+    iv = {k: _named(v, k + "d") for k, v in iv.items()}
+    ov = dict(iv)
+    ov["delpcd"], ov["ptcd"] = {}, {}
+
+    def run(env, f, p):
+        from pace_amd.fv3core.stencils.c_sw import CGridShallowWaterDynamics
+
+        nord = int(env.namelist.get("d_sw", {}).get("nord", env.namelist.get("nord", 3)))
+        op = CGridShallowWaterDynamics(env.stencil_factory, env.qf, env.grid_data, nested=False, grid_type=0, nord=nord)
+        f["delpcd"], f["ptcd"] = op(f["delp"], f["pt"], f["u"], f["v"], f["w"], f["uc"], f["vc"], f["ua"], f["va"], f["ut"], f["vt"], f["divgd"],
+                                    f["omga"], p["dt2"])
+        return f
+
+    return Spec(iv, ["dt2"], ov, 2e-10, run)
+
+
+def spec_updatedzc(g):  # translate_updatedzc.py:10-70 (gz and ws are compared on the compute domain: `_subset`)
+    iv = {"zs": {}, "ut": {"serialname": "utc"}, "vt": {"serialname": "vtc"}, "gz": {}, "ws": {}}
+    cd = g.compute_dict()
+    ov = {"gz": dict(cd, kend=g.npz), "ws": {k: v for k, v in cd.items() if k[0] != "k"}}
+
+    def run(env, f, p):
+        from pace_amd.fv3core.stencils.updatedzc import UpdateGeopotentialHeightOnCGrid
+
+        op = UpdateGeopotentialHeightOnCGrid(env.stencil_factory, env.qf, area=env.grid_data.area, dp_ref=env.grid_data.dp_ref,
+                                             grid_data=env.grid_data)
+        op(f["zs"], f["ut"], f["vt"], f["gz"], f["ws"], p["dt2"])
+        return f
+
+    return Spec(iv, ["dt2"], ov, 1e-14, run)
+
+
+def spec_updatedzd(g):  # translate_updatedzd.py:12-87 (height compared on the compute domain, `ws` = wsd there; near-zero values ignored)
+    iv = {"surface_height": {"serialname": "zs"}, "height": {"kend": g.npz + 1, "serialname": "zh"},
+          "courant_number_x": _named(g.x3d_compute_domain_y_dict(), "crx"), "courant_number_y": _named(g.y3d_compute_domain_x_dict(), "cry"),
+          "x_area_flux": _named(g.x3d_compute_domain_y_dict(), "xfx"), "y_area_flux": _named(g.y3d_compute_domain_x_dict(), "yfx"),
+          "ws": _named({k: v for k, v in g.compute_dict().items() if k[0] != "k"}, "wsd")}
+    ov = {k: iv[k] for k in ("courant_number_x", "courant_number_y", "x_area_flux", "y_area_flux", "ws")}
+    ov["height"] = dict(g.compute_dict(), kend=g.npz, serialname="zh")
+
+    def run(env, f, p):
+        from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+        from pace_amd.fv3core.stencils.d_sw import get_column_namelist
+        from pace_amd.fv3core.stencils.updatedzd import UpdateHeightOnDGrid
+
+        cfg = DGridShallowWaterLagrangianDynamicsConfig(**env.namelist.get("d_sw", {}))
+        op = UpdateHeightOnDGrid(env.stencil_factory, env.qf, env.damping, env.grid_data, 0, int(env.namelist.get("hord_tm", cfg.hord_tm)),
+                                 column_namelist=get_column_namelist(cfg, env.qf))
+        op(f["surface_height"], f["height"], f["courant_number_x"], f["courant_number_y"], f["x_area_flux"], f["y_area_flux"], f["ws"], p["dt"])
+        return f
+
+    return Spec(iv, ["dt"], ov, 1e-14, run, ignore_near_zero={"height": 1e-30, "ws": 1e-30})
+
+
 SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": spec_fvtp2d, "Riem_Solver_C": spec_riem_solver_c,
-              "NH_P_Grad": spec_nh_p_grad, "FxAdv": spec_fxadv}
+              "NH_P_Grad": spec_nh_p_grad, "FxAdv": spec_fxadv, "C_SW": spec_c_sw, "UpdateDzC": spec_updatedzc, "UpdateDzD": spec_updatedzd}
 # KNOWN DEVIATIONS from the windows of the reference's Translate classes (TranslateD_SW compares every variable over the FULL
 # domain, halo included, translate_d_sw.py:36-65): (a) the reference's transport rewrites the 3 x 3 corner blocks of the halo of
 # delp, pt, w, q_con in place (copy_corners_x / _y, fvtp2d.py:262-345) and leaves the last copy there; the HIP kernels apply the
@@ -332,9 +389,8 @@ SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": sp
 # divergence damping's work fields uc, vc, divgd, delpc are brought to the reference's final state on the compute domain
 # (+ staggering) only, not in the halo rows its shrinking iteration domains touch.  Neither is read by anything before it is
 # overwritten (halo update / c_sw).  The runner therefore reports both verdicts.
-# Not in the table yet (their Translate classes: translate_{xppm,yppm,delnflux,c_sw,updatedzc,updatedzd}.py, translate_dyncore.py):
-# XPPM, YPPM, DelnFlux, C_SW, UpdateDzC, UpdateDzD, DynCore -- same machinery, one `spec_*` function each (XPPM / YPPM take their
-# row window from the savepoint's jfirst / jlast; UpdateDzC / UpdateDzD compare a compute-domain subset and the 2-D ws).
+# Not in the table yet (their Translate classes: translate_{xppm,yppm,delnflux}.py, translate_dyncore.py): XPPM, YPPM, DelnFlux,
+# DynCore -- same machinery, one `spec_*` function each (XPPM / YPPM take their row window from the savepoint's jfirst / jlast).
 
 
 def metrics_for(n, npz, tile, path=None):

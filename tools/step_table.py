@@ -12,9 +12,9 @@ import sys
 
 # distinct 3-D fields per launch (in + out), by kernel-name fragment; the edge-strip kernel touches a few rows only
 FIELDS = [
-    ("k_fxadv_main", 4, "uc, vc -> ut, vt"),
+    ("k_fxadv_frame", 0.45, "uc, vc -> ut, vt on the frame of the plane (11 % of it)"),
     ("k_fxadv_edges", 0.2, "edge strips of ut, vt"),
-    ("k_fxadv_fluxes", 10, "ut, vt, cx, cy -> crx, cry, xfx, yfx, cx, cy"),
+    ("k_fxadv_fluxes", 10, "uc, vc (ut, vt on the frame), cx, cy -> crx, cry, xfx, yfx, cx, cy"),
     ("k_fvt_scalars", 26, "delp, w, q_con, pt, crx, cry, xfx, yfx, mfx, mfy, vorticity, u, v, ke, damped vorticity, heat_source -> delp, w, "
                           "q_con, pt, mfx, mfy, diss_est, u, v, heat_source"),
     ("k_kinetic_energy", 5, "uc, vc, u, v -> ke"),
