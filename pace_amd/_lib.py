@@ -225,5 +225,8 @@ def load(precision: int = 64):
     if precision not in (64, 32):
         raise ValueError("precision is 64 or 32")
     if precision not in _default:
-        _default[precision] = Library(DEFAULT_LIB if precision == 64 else DEFAULT_LIB_F32)
+        path = DEFAULT_LIB if precision == 64 else DEFAULT_LIB_F32
+        if precision == 64 and os.environ.get("PACE_HIP_LIB"):  # another build of the same sources (tools/, experiments)
+            path = os.environ["PACE_HIP_LIB"]
+        _default[precision] = Library(path)
     return _default[precision]

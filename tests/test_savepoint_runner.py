@@ -191,6 +191,49 @@ def test_c_sw_updatedzc_updatedzd_pairs_through_the_runner(tmp_path):
     assert set(worst) == {"height", "courant_number_x", "courant_number_y", "x_area_flux", "y_area_flux", "ws"} and ok, worst
 
 
+def test_d2a2c_vect_and_divergence_damping_pairs_through_the_runner(tmp_path):
+    """Two of d_sw's / c_sw's parts the reference tests on their own (translate_d2a2c_vect.py:8-47, translate_divergencedamping.py:11-76:
+    K-only inputs `nord_col` and `d2_bg` next to the 3-D ones, `vort` / `wk` under their serialised names)."""
+    import argparse
+
+    import opchain
+    import run_savepoints as rs
+    from oracle import damping
+    from pace_amd import _lib
+    from pace_amd.tile import DSW_CFG
+
+    d = str(tmp_path)
+    ch = opchain.Chain(N, NZ)
+    np.savez(os.path.join(d, "metrics.npz"), **ch.metrics)
+    full, fx, fy, fxy = np.s_[:N + 6, :N + 6, :NZ], np.s_[:N + 7, :N + 6, :NZ], np.s_[:N + 6, :N + 7, :NZ], np.s_[:N + 7, :N + 7, :NZ]
+    c = next(iter(ch.cases(only=("d2a2c_vect",))))
+    names = ("uc", "vc", "u", "v", "ua", "va", "utc", "vtc")
+    np.savez(os.path.join(d, "D2A2C_Vect-In.npz"), **{k: _sp(c.before[k][full]) for k in names})
+    np.savez(os.path.join(d, "D2A2C_Vect-Out.npz"), uc=_sp(c.after["uc"][fx]), vc=_sp(c.after["vc"][fy]),
+             **{k: _sp(c.after[k][full]) for k in ("ua", "va", "utc", "vtc")})
+    # DivergenceDamping on the synthetic winds (as tests/opchain.py check_standalone_operators)
+    s, col = c.before, ch.col
+    f = {k: s[k].copy() for k in ("u", "v", "va", "ua", "divgd", "vc", "uc")}
+    f["vort_b"], f["delpc"] = np.zeros_like(s["pt"]), np.zeros_like(s["pt"])
+    f["ke"] = 0.5 * (s["u"] ** 2 + s["v"] ** 2)
+    f["wk"] = 1.0e-5 * s["pt"] * np.cos(s["u"] * 0.1)
+    ser = {"u": "u", "v": "v", "va": "va", "vort": "vort_b", "ua": "ua", "divg_d": "divgd", "vc": "vc", "uc": "uc", "delpc": "delpc", "ke": "ke",
+           "wk": "wk"}
+    ins = {sn: _sp(f[k][full].copy()) for sn, k in ser.items()}  # (copies: the oracle works in place)
+    ins.update(nord_col=_sp(np.asarray(col["nord"], dtype=float)[:NZ]), d2_bg=_sp(np.asarray(col["d2_divg"], dtype=float)[:NZ]), dt=_sp(np.array(ch.dt)))
+    damping.divergence_damping(ch.g, f["u"], f["v"], f["va"], f["vort_b"], f["ua"], f["divgd"], f["vc"], f["uc"], f["delpc"], f["ke"], f["wk"],
+                               ch.dt, nord_k=col["nord"], d2_bg_k=col["d2_divg"], dddmp=DSW_CFG["dddmp"], d4_bg=DSW_CFG["d4_bg"], nord=DSW_CFG["nord"])
+    np.savez(os.path.join(d, "DivergenceDamping-In.npz"), **ins)
+    np.savez(os.path.join(d, "DivergenceDamping-Out.npz"), ke=_sp(f["ke"][fxy]), delpc=_sp(f["delpc"][full]))
+
+    lib = _lib.Library(build_emu())
+    args = argparse.Namespace(device="cpu", metrics=os.path.join(d, "metrics.npz"), rank_tile=False, namelist={"d_sw": DSW_CFG})
+    ok, bound, worst, ok_inner, inner = rs.run_one("D2A2C_Vect", rs.read_pair(d, "D2A2C_Vect"), args, lib)
+    assert bound == 2e-10 and set(worst) == {"uc", "vc", "ua", "va", "utc", "vtc"} and ok_inner, (worst, inner)
+    ok, bound, worst, ok_inner, inner = rs.run_one("DivergenceDamping", rs.read_pair(d, "DivergenceDamping"), args, lib)
+    assert bound == 1.4e-10 and set(worst) == {"ke", "delpc"} and ok_inner, (worst, inner)
+
+
 def test_unreadable_netcdf_says_what_to_do(tmp_path):
     import run_savepoints as rs
 

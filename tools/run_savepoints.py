@@ -380,8 +380,43 @@ def spec_updatedzd(g):  # translate_updatedzd.py:12-87 (height compared on the c
     return Spec(iv, ["dt"], ov, 1e-14, run, ignore_near_zero={"height": 1e-30, "ws": 1e-30})
 
 
+def spec_d2a2c_vect(g):  # translate_d2a2c_vect.py:8-47
+    iv = {k: {} for k in ("uc", "vc", "u", "v", "ua", "va", "utc", "vtc")}
+    ov = {"uc": g.x3d_domain_dict(), "vc": g.y3d_domain_dict(), "ua": {}, "va": {}, "utc": {}, "vtc": {}}
+
+    def run(env, f, p):
+        from pace_amd.fv3core.stencils.d2a2c_vect import DGrid2AGrid2CGridVectors
+
+        DGrid2AGrid2CGridVectors(env.stencil_factory, env.qf, env.grid_data, False, 0, True)(
+            f["uc"], f["vc"], f["u"], f["v"], f["ua"], f["va"], f["utc"], f["vtc"])
+        return f
+
+    return Spec(iv, [], ov, 2e-10, run)
+
+
+def spec_divergence_damping(g):  # translate_divergencedamping.py:11-76 (ke on the B-grid domain, delpc)
+    iv = {"u": {}, "v": {}, "va": {}, "damped_rel_vort_bgrid": {"serialname": "vort"}, "ua": {}, "divg_d": {}, "vc": {}, "uc": {}, "delpc": {},
+          "ke": {}, "rel_vort_agrid": {"serialname": "wk"}, "nord_col": {}, "d2_bg": {}}
+    ov = {"ke": {"iend": g.ied + 1, "jend": g.jed + 1}, "delpc": {}}
+
+    def run(env, f, p):
+        from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+        from pace_amd.fv3core.stencils.divergence_damping import DivergenceDamping
+
+        cfg = DGridShallowWaterLagrangianDynamicsConfig(**env.namelist.get("d_sw", {}))
+        nord_col, d2_bg = env.kq(np.asarray(f.pop("nord_col_host"))), env.kq(np.asarray(f.pop("d2_bg_host")))
+        op = DivergenceDamping(env.stencil_factory, env.qf, env.grid_data, env.damping, False, False, cfg.dddmp, cfg.d4_bg, cfg.nord, 0, nord_col,
+                               d2_bg)
+        op(f["u"], f["v"], f["va"], f["damped_rel_vort_bgrid"], f["ua"], f["divg_d"], f["vc"], f["uc"], f["delpc"], f["ke"], f["rel_vort_agrid"],
+           p["dt"])
+        return f
+
+    return Spec(iv, ["dt"], ov, 1.4e-10, run)
+
+
 SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": spec_fvtp2d, "Riem_Solver_C": spec_riem_solver_c,
-              "NH_P_Grad": spec_nh_p_grad, "FxAdv": spec_fxadv, "C_SW": spec_c_sw, "UpdateDzC": spec_updatedzc, "UpdateDzD": spec_updatedzd}
+              "NH_P_Grad": spec_nh_p_grad, "FxAdv": spec_fxadv, "C_SW": spec_c_sw, "UpdateDzC": spec_updatedzc, "UpdateDzD": spec_updatedzd,
+              "D2A2C_Vect": spec_d2a2c_vect, "DivergenceDamping": spec_divergence_damping}
 # KNOWN DEVIATIONS from the windows of the reference's Translate classes (TranslateD_SW compares every variable over the FULL
 # domain, halo included, translate_d_sw.py:36-65): (a) the reference's transport rewrites the 3 x 3 corner blocks of the halo of
 # delp, pt, w, q_con in place (copy_corners_x / _y, fvtp2d.py:262-345) and leaves the last copy there; the HIP kernels apply the
