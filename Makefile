@@ -54,7 +54,7 @@ tests/emu/libpace_emu_f32.so: $(EMUF32OBJS) build/emu/hip_emu.o
 
 # the same, with 4 x 4 transport / damping tiles and runs of 2 interfaces: at C12 this gives workgroups that touch no tile
 # edge, so the straight-line interior code paths and every tile seam are exercised by the CPU test-suite as well
-SMALLFLAGS := $(EMUFLAGS) -DFV_TI=4 -DFV_TJ=4 -DDN_TI=4 -DDN_TJ=4 -DFV_RF=2 -DDD_TI=5 -DDD_TJ=4 -DAB_TI=6 -DAB_TJ=3
+SMALLFLAGS := $(EMUFLAGS) -DFV_TI=4 -DFV_TJ=4 -DDN_TI=4 -DDN_TJ=4 -DFV_RF=2 -DDD_TI=5 -DDD_TJ=4 -DAB_TI=6 -DAB_TJ=3 -DCSW_TI=4 -DCSW_TJ=3
 SMALLOBJS := $(patsubst $(CSRC)/%.hip,build/emu_small/%.o,$(SRCS))
 build/emu_small/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
 	@mkdir -p build/emu_small

@@ -343,6 +343,7 @@ struct Regions {
   int ib[MAX_REGIONS], ie[MAX_REGIONS], jb[MAX_REGIONS], je[MAX_REGIONS];
   int first[MAX_REGIONS + 1];  // first block of each region; first[n] = total
   int nbx0;                    // 64-wide patches per row of region 0
+  int nplain;                  // regions [0, nplain) are "interior" (their points take a kernel's plain forms); set by add_region: 1
 };
 static inline void add_region(Regions& r, int ib, int ie, int jb, int je) {
   if (ie < ib || je < jb) return;
@@ -350,6 +351,7 @@ static inline void add_region(Regions& r, int ib, int ie, int jb, int je) {
   r.ib[q] = ib; r.ie[q] = ie; r.jb[q] = jb; r.je[q] = je;
   int nb;
   if (q == 0) {
+    r.nplain = 1;
     r.nbx0 = (ie - ib + 64) / 64;
     nb = r.nbx0 * ((je - jb + 4) / 4);
   } else {
@@ -373,10 +375,10 @@ static inline Regions bgrid_regions(const Geo& g, int d) {
   while (reg__ + 1 < (R).n && (int)blockIdx.x >= (R).first[reg__ + 1]) ++reg__;               \
   const int b__ = (int)blockIdx.x - (R).first[reg__];                                          \
   const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
-  const bool interior = reg__ == 0;                                                            \
+  const bool interior = reg__ < (R).nplain;                                                         \
   int i, j;                                                                                    \
   const int k = (int)blockIdx.z;                                                               \
-  if (interior) {                                                                              \
+  if (reg__ == 0) {                                                                            \
     i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
     j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
     if (i > (R).ie[0] || j > (R).je[0]) return;                                                \
@@ -393,11 +395,11 @@ static inline dim3 regions_grid(const Regions& r, int nlev) { return dim3((unsig
 // that the strips run beside the interior: a 1-D grid, first the interior patches of every chunk of levels, then the frame
 // blocks of every level (the other order measured slower: 99 against 91 us for k_d2a2c_b).  Sets i, j, `interior`, k0 (first level) and nk_here (levels this thread takes).
 static inline dim3 regions_grid_chunked(const Regions& r, int nlev, int ch) {
-  const int nbi = r.first[1], nfr = r.first[r.n] - r.first[1];
+  const int nbi = r.first[r.nplain > 0 ? r.nplain : 1], nfr = r.first[r.n] - nbi;
   return dim3((unsigned)(nbi * ((nlev + ch - 1) / ch) + nfr * nlev), 1, 1);
 }
 #define REGION_POINT_CHUNKED(R, CH, NLEV)                                                      \
-  const int nbi__ = (R).first[1];                                                              \
+  const int nbi__ = (R).first[(R).nplain > 0 ? (R).nplain : 1];                                \
   const int ni__ = nbi__ * (((NLEV) + (CH)-1) / (CH));                                         \
   int bx__, k0, nk_here;                                                                       \
   if ((int)blockIdx.x < ni__) {                                                                \
@@ -415,9 +417,9 @@ static inline dim3 regions_grid_chunked(const Regions& r, int nlev, int ch) {
   while (reg__ + 1 < (R).n && bx__ >= (R).first[reg__ + 1]) ++reg__;                           \
   const int b__ = bx__ - (R).first[reg__];                                                     \
   const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
-  const bool interior = reg__ == 0;                                                            \
+  const bool interior = reg__ < (R).nplain;                                                         \
   int i, j;                                                                                    \
-  if (interior) {                                                                              \
+  if (reg__ == 0) {                                                                            \
     i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
     j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
     if (i > (R).ie[0] || j > (R).je[0]) return;                                                \
@@ -454,10 +456,10 @@ static inline dim3 regions_grid_chunked(const Regions& r, int nlev, int ch) {
   while (reg__ + 1 < (R).n && bx__ >= (R).first[reg__ + 1]) ++reg__;                           \
   const int b__ = bx__ - (R).first[reg__];                                                     \
   const int t__ = (int)threadIdx.y * 64 + (int)threadIdx.x;                                    \
-  const bool interior = reg__ == 0;                                                            \
+  const bool interior = reg__ < (R).nplain;                                                         \
   int i, j;                                                                                    \
   const int k = bz__;                                                                          \
-  if (interior) {                                                                              \
+  if (reg__ == 0) {                                                                            \
     i = (R).ib[0] + (b__ % (R).nbx0) * 64 + (int)threadIdx.x;                                   \
     j = (R).jb[0] + (b__ / (R).nbx0) * 4 + (int)threadIdx.y;                                    \
     if (i > (R).ie[0] || j > (R).je[0]) return;                                                \

@@ -57,6 +57,45 @@ def test_riem_solver3_bad_column_does_not_come_back_finite(emu_lib):
     assert np.isfinite(out["ppe"][6, 5, :79]).all() and np.isfinite(out["delz"][6, 5, :79]).all()
 
 
+@pytest.mark.parametrize("n,nz,which", [(24, 5, "small"), (48, 2, "big")])
+def test_c_sw_interior_tiles_equal_the_four_passes(emu_lib, emu_small_lib, n, nz, which):
+    """c_sw's interior goes through k_csw_tile (one workgroup = all of c_sw for a tile of cells of one level, every intermediate
+    in LDS), the band near the edges through the four passes.  With PACE_CSW_NO_TILES the four passes take the whole plane: the
+    same bits in every output array, whole storage (4 x 3 tiles at C24: twelve tiles and every seam between them and the band;
+    the product's 30 x 18 at C48) -- and the same again when the call is split around the halo exchange (start / finish)."""
+    from pace_amd import synthetic
+    from pace_amd.fv3core.stencils.c_sw import CGridShallowWaterDynamics
+
+    lib = emu_small_lib if which == "small" else emu_lib
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, "cpu", m, n, nz)
+    names = ("delp", "pt", "u", "v", "w", "uc", "vc", "ua", "va", "ut", "vt", "divgd", "omga")
+
+    def run(split):
+        f = {k: env.q3(s[k] if k in s else np.zeros_like(s["pt"])) for k in names}
+        op = CGridShallowWaterDynamics(env.stencil_factory, env.qf, env.grid_data, nested=False, grid_type=0, nord=3)
+        args = [f[k] for k in names] + [0.5 * s["dt"]]
+        if split:
+            op.start_interior(*args)
+        delpc, ptc = op(*args)
+        out = {k: f[k].numpy().copy() for k in names}
+        out.update(delpc=delpc.numpy().copy(), ptc=ptc.numpy().copy())
+        return out
+
+    os.environ["PACE_CSW_NO_TILES"] = "1"
+    try:
+        ref = run(False)
+    finally:
+        del os.environ["PACE_CSW_NO_TILES"]
+    for split in (False, True):
+        got = run(split)
+        for k in ref:
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (k, split, float(np.nanmax(np.abs(ref[k] - got[k]))))
+    # (and the tiles did run: the interior of the caller's uc differs from what pass B alone leaves there)
+    assert not np.array_equal(ref["uc"][10:n - 4, 10:n - 4, :nz], s["uc"][10:n - 4, 10:n - 4, :nz])
+
+
 def test_in_checkpoints_hold_the_state_before_the_call(emu_lib):
     """AcousticDynamics overlaps the u / v and uc / vc halo exchanges with the interior of c_sw's first pass and
     of d_sw's flux preparation; with a checkpointer attached those early starts are skipped, so that "C_SW-In" / "D_SW-In" hold

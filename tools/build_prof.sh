@@ -7,6 +7,7 @@ CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract
 $CC "$@" -c tools/census/fvt_prof.hip -o $D/k_fvt.o
 $CC "$@" -c tools/census/riem_prof.hip -o $D/k_riem3f.o
 $CC "$@" -c tools/census/dsw_prof.hip -o $D/k_dsw.o
+$CC "$@" -c tools/census/csw_prof.hip -o $D/k_csw.o
 OBJS=""
 for f in build/hip/*.o; do s=$(basename $f .o); if [ -f $D/$s.o ]; then OBJS="$OBJS $D/$s.o"; else OBJS="$OBJS $f"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $D/libpace_hip.so
