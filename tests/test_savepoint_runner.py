@@ -226,12 +226,27 @@ def test_d2a2c_vect_and_divergence_damping_pairs_through_the_runner(tmp_path):
     np.savez(os.path.join(d, "DivergenceDamping-In.npz"), **ins)
     np.savez(os.path.join(d, "DivergenceDamping-Out.npz"), ke=_sp(f["ke"][fxy]), delpc=_sp(f["delpc"][full]))
 
+    # DelnFlux: q with its mass, the fluxes on their staggered compute windows, K-only damp_c / nord_column (translate_delnflux.py:15-26)
+    from oracle import ppm_transport
+
+    s2 = c.before
+    q, mass = s2["pt"].copy(), s2["delp"].copy()
+    fxd, fyd = 1.0e-3 * s2["xfx"].copy() + 1.0, 1.0e-3 * s2["yfx"].copy() + 2.0
+    mx_, my_ = np.s_[3:N + 4, 3:N + 3, :NZ], np.s_[3:N + 3, 3:N + 4, :NZ]
+    nord_c, damp_c = np.asarray(col["nord_v"], dtype=float)[:NZ], np.asarray(col["damp_vt"], dtype=float)[:NZ]
+    np.savez(os.path.join(d, "DelnFlux-In.npz"), q=_sp(q[full].copy()), mass=_sp(mass[full].copy()), fx=_sp(fxd[mx_].copy()), fy=_sp(fyd[my_].copy()),
+             damp_c=_sp(damp_c), nord_column=_sp(nord_c))
+    ppm_transport.delnflux(ch.g, q, fxd, fyd, col["nord_v"], col["damp_vt"], float(ch.metrics["da_min"]), mass=mass)
+    np.savez(os.path.join(d, "DelnFlux-Out.npz"), fx=_sp(fxd[mx_]), fy=_sp(fyd[my_]))
+
     lib = _lib.Library(build_emu())
     args = argparse.Namespace(device="cpu", metrics=os.path.join(d, "metrics.npz"), rank_tile=False, namelist={"d_sw": DSW_CFG})
     ok, bound, worst, ok_inner, inner = rs.run_one("D2A2C_Vect", rs.read_pair(d, "D2A2C_Vect"), args, lib)
     assert bound == 2e-10 and set(worst) == {"uc", "vc", "ua", "va", "utc", "vtc"} and ok_inner, (worst, inner)
     ok, bound, worst, ok_inner, inner = rs.run_one("DivergenceDamping", rs.read_pair(d, "DivergenceDamping"), args, lib)
     assert bound == 1.4e-10 and set(worst) == {"ke", "delpc"} and ok_inner, (worst, inner)
+    ok, bound, worst, _, _ = rs.run_one("DelnFlux", rs.read_pair(d, "DelnFlux"), args, lib)
+    assert bound == 1e-14 and set(worst) == {"fx", "fy"} and ok, worst
 
 
 def test_unreadable_netcdf_says_what_to_do(tmp_path):

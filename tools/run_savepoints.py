@@ -414,9 +414,24 @@ def spec_divergence_damping(g):  # translate_divergencedamping.py:11-76 (ke on t
     return Spec(iv, ["dt"], ov, 1.4e-10, run)
 
 
+def spec_delnflux(g):  # translate_delnflux.py:8-47 (DelnFlux_2: the same without `mass`)
+    iv = {"q": {}, "fx": g.x3d_compute_dict(), "fy": g.y3d_compute_dict(), "damp_c": {}, "nord_column": {}, "mass": {}}
+    ov = {"fx": g.x3d_compute_dict(), "fy": g.y3d_compute_dict()}
+
+    def run(env, f, p):
+        from pace_amd.fv3core.stencils.delnflux import DelnFlux
+
+        nord, damp = env.kq(np.asarray(f.pop("nord_column_host"))), env.kq(np.asarray(f.pop("damp_c_host")))
+        op = DelnFlux(env.stencil_factory, env.qf, env.damping, env.grid_data.rarea, nord, damp, grid_data=env.grid_data)
+        op(f["q"], f["fx"], f["fy"], mass=f.get("mass"))
+        return f
+
+    return Spec(iv, [], ov, 1e-14, run)
+
+
 SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": spec_fvtp2d, "Riem_Solver_C": spec_riem_solver_c,
               "NH_P_Grad": spec_nh_p_grad, "FxAdv": spec_fxadv, "C_SW": spec_c_sw, "UpdateDzC": spec_updatedzc, "UpdateDzD": spec_updatedzd,
-              "D2A2C_Vect": spec_d2a2c_vect, "DivergenceDamping": spec_divergence_damping}
+              "D2A2C_Vect": spec_d2a2c_vect, "DivergenceDamping": spec_divergence_damping, "DelnFlux": spec_delnflux}
 # KNOWN DEVIATIONS from the windows of the reference's Translate classes (TranslateD_SW compares every variable over the FULL
 # domain, halo included, translate_d_sw.py:36-65): (a) the reference's transport rewrites the 3 x 3 corner blocks of the halo of
 # delp, pt, w, q_con in place (copy_corners_x / _y, fvtp2d.py:262-345) and leaves the last copy there; the HIP kernels apply the
@@ -424,8 +439,8 @@ SAVEPOINTS = {"D_SW": spec_d_sw, "Riem_Solver3": spec_riem_solver3, "FvTp2d": sp
 # divergence damping's work fields uc, vc, divgd, delpc are brought to the reference's final state on the compute domain
 # (+ staggering) only, not in the halo rows its shrinking iteration domains touch.  Neither is read by anything before it is
 # overwritten (halo update / c_sw).  The runner therefore reports both verdicts.
-# Not in the table yet (their Translate classes: translate_{xppm,yppm,delnflux}.py, translate_dyncore.py): XPPM, YPPM, DelnFlux,
-# DynCore -- same machinery, one `spec_*` function each (XPPM / YPPM take their row window from the savepoint's jfirst / jlast).
+# Not in the table yet (their Translate classes: translate_{xppm,yppm}.py, translate_dyncore.py): XPPM, YPPM, DynCore -- same
+# machinery, one `spec_*` function each (XPPM / YPPM take their row window from the savepoint's jfirst / jlast).
 
 
 def metrics_for(n, npz, tile, path=None):
