@@ -21,6 +21,7 @@ timeout 300 python tools/acoustic_bench.py --n 96 2>/dev/null | grep -v amdgpu >
 # stage times of the scalar-phase kernel's workgroups (interior / corner / edge tiles): tools/build_prof.sh builds the stamped library
 [ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/fvt_stage_times.py 2>/dev/null | grep -v amdgpu > "$O/scalar_phase_stage_times.txt"
 [ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/dd_stage_times.py 2>/dev/null | grep -v amdgpu | tail -9 > "$O/divdamp_workgroup_timeline.txt"
+[ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/csw_stage_times.py 2>/dev/null | grep -v amdgpu | tail -3 > "$O/csw_tile_workgroup_timeline.txt"
 [ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/riem_stage_times.py 2>/dev/null | grep -v amdgpu > "$O/riem_stage_times.txt"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-traffic > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
