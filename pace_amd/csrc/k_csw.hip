@@ -205,12 +205,14 @@ __device__ __forceinline__ void d2a2c_b_frame_point(const Geo& g, const Met& m, 
 // dx, dy, the sin_sg and cos_sg of four neighbours, dxc, dyc, rarea_c) against 14 values of the 3-D fields: they -- and the sums
 // of them the divergence uses -- are formed once per point instead of once per level.
 #define D2B_CH 8
+// (CH = 2 when only the band of the plane is left to this pass: few points, so levels side by side instead of one after the other)
+template <int CH>
 __global__ void __launch_bounds__(256)
 k_d2a2c_b(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
           const real* __restrict__ utmp, const real* __restrict__ vtmp, const real* __restrict__ ua,
           const real* __restrict__ va, real* __restrict__ uc, real* __restrict__ vc, real* __restrict__ ut,
           real* __restrict__ vt, real* __restrict__ divgd, double dt2, int do_divg, int geoadjust, Regions R) {
-  REGION_POINT_CHUNKED(R, D2B_CH, g.nk);  // (D2B_CH levels per thread in the interior, one in the frame strips)
+  REGION_POINT_CHUNKED(R, CH, g.nk);  // (CH levels per thread in the interior, one in the frame strips)
   const int sj = g.sj;
   if (!interior) {
     d2a2c_b_frame_point(g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut, vt, divgd, dt2, do_divg, geoadjust, i, j, k0);
@@ -232,7 +234,7 @@ k_d2a2c_b(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
     rarea_c = m.rarea_c[c2];
   }
 #pragma unroll
-  for (int t = 0; t < D2B_CH; ++t) {
+  for (int t = 0; t < CH; ++t) {
     if (t >= nk_here) break;
     const long c = c2 + (long)(k0 + t) * g.sk;
     const double ucv = A2 * (utmp[c - 2] + utmp[c + 1]) + A1 * (utmp[c - 1] + utmp[c]);
@@ -258,8 +260,12 @@ k_d2a2c_b(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
 static void launch_d2a2c_b(const Geo& g, const Met& m, const real* u, const real* v, const real* utmp, const real* vtmp,
                            const real* ua, const real* va, real* uc, real* vc, real* ut, real* vt, real* divgd, double dt2,
                            int do_divg, int geoadjust, const Regions& rb, hipStream_t st) {
-  hipLaunchKernelGGL(k_d2a2c_b, regions_grid_chunked(rb, g.nk, D2B_CH), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut,
-                     vt, divgd, dt2, do_divg, geoadjust, rb);
+  if (rb.nplain > 1)  // (a band: the plain region has a hole)
+    hipLaunchKernelGGL(k_d2a2c_b<2>, regions_grid_chunked(rb, g.nk, 2), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut,
+                       vt, divgd, dt2, do_divg, geoadjust, rb);
+  else
+    hipLaunchKernelGGL(k_d2a2c_b<D2B_CH>, regions_grid_chunked(rb, g.nk, D2B_CH), dim3(64, 4), 0, st, g, m, u, v, utmp, vtmp, ua, va, uc, vc, ut,
+                       vt, divgd, dt2, do_divg, geoadjust, rb);
 }
 
 // read-side forms of fill_corners_2cells_x / _y with unit multipliers on the transported scalars
@@ -374,6 +380,7 @@ k_csw_transport(Geo g, Met m, const real* __restrict__ delp, const real* __restr
 
 // pass D: update_y_velocity (c_sw.py:445-480), update_x_velocity (:411-442)
 #define UV_CH 8
+template <int CH>
 __device__ __forceinline__ void csw_update_point(const Geo& g, const Met& m, const real* __restrict__ u, const real* __restrict__ v,
                                                  const real* __restrict__ ke, const real* __restrict__ vort,
                                                  const real* __restrict__ ucw, const real* __restrict__ vcw, real* __restrict__ uc,
@@ -392,7 +399,7 @@ __device__ __forceinline__ void csw_update_point(const Geo& g, const Met& m, con
   if (do_v) cosa_v = m.cosa_v[c2], sina_v = m.sina_v[c2], rdyc = m.rdyc[c2];
   if (do_u) cosa_u = m.cosa_u[c2], sina_u = m.sina_u[c2], rdxc = m.rdxc[c2];
 #pragma unroll
-  for (int t = 0; t < UV_CH; ++t) {
+  for (int t = 0; t < CH; ++t) {
     if (k0 + t >= g.nk) break;
     const long c = c2 + (long)(k0 + t) * g.sk;
     if (do_v) {
@@ -419,16 +426,17 @@ k_csw_update_uc_vc(Geo g, Met m, const real* __restrict__ u, const real* __restr
   const int j = (int)(p / g.sj);
   const int i = (int)(p - (long)j * g.sj);
   if (j >= g.nj || i >= g.ni) return;
-  csw_update_point(g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2, i, j, (int)blockIdx.y * UV_CH);
+  csw_update_point<UV_CH>(g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2, i, j, (int)blockIdx.y * UV_CH);
 }
-// ... on the rectangles of the band (blockIdx.z: the chunk of UV_CH levels)
+// ... on the rectangles of the band (blockIdx.z: the chunk of UV_CH_BAND levels: few points, so levels side by side)
+#define UV_CH_BAND 2
 __global__ void __launch_bounds__(256)
 k_csw_update_uc_vc_band(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v,
                         const real* __restrict__ ke, const real* __restrict__ vort, const real* __restrict__ ucw,
                         const real* __restrict__ vcw, real* __restrict__ uc, real* __restrict__ vc, double dt2, Regions R) {
   REGION_POINT(R);
   (void)interior;
-  csw_update_point(g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2, i, j, k * UV_CH);
+  csw_update_point<UV_CH_BAND>(g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2, i, j, k * UV_CH_BAND);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -756,9 +764,10 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, co
                        delpc, ptc, omga, ke, vort, dt2, rt);
     const int nchunk = (g.nk + UV_CH - 1) / UV_CH;
     if (tiles.any()) {
+      const int nchunk_band = (g.nk + UV_CH_BAND - 1) / UV_CH_BAND;
       Regions rd{};  // pass D's domain [is-1, ie+2]^2 without the tiles
       add_plain_with_hole(rd, g.is - 1, g.ie + 2, tiles.hole(0));
-      hipLaunchKernelGGL(k_csw_update_uc_vc_band, regions_grid(rd, nchunk), dim3(64, 4), 0, sb, g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2, rd);
+      hipLaunchKernelGGL(k_csw_update_uc_vc_band, regions_grid(rd, nchunk_band), dim3(64, 4), 0, sb, g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2, rd);
     } else {
       hipLaunchKernelGGL(k_csw_update_uc_vc, dim3(grid.x, (unsigned)nchunk, 1), block, 0, sb, g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2);
     }
