@@ -493,6 +493,35 @@ extern int g_pace_sync_launches;
     }                                                              \
   } while (0)
 
+#ifndef PACE_EMU
+// A stream of the calling thread's own (high priority) with the two events of a fork / join around it, for launchers that put a
+// short chain of latency-bound kernels (edge forms: few points, dependent reads) BESIDE a streaming or tile kernel on the caller's
+// stream instead of in front of it.  Created on first use; nullptr if the runtime refuses.
+struct PaceSideStream {
+  hipStream_t s;
+  hipEvent_t in, out;
+  // side waits for everything queued on `main` so far
+  bool fork(hipStream_t main) const { return hipEventRecord(in, main) == hipSuccess && hipStreamWaitEvent(s, in, 0) == hipSuccess; }
+  // `main` waits for everything queued on the side stream so far
+  bool join(hipStream_t main) const { return hipEventRecord(out, s) == hipSuccess && hipStreamWaitEvent(main, out, 0) == hipSuccess; }
+};
+static inline const PaceSideStream* pace_side_stream() {
+  static thread_local PaceSideStream side{nullptr, nullptr, nullptr};
+  static thread_local bool failed = false;
+  if (side.s == nullptr && !failed) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&side.s, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&side.in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&side.out, hipEventDisableTiming) != hipSuccess) {
+      failed = true;
+      side.s = nullptr;
+    }
+  }
+  return side.s != nullptr ? &side : nullptr;
+}
+#endif
+
 // Interior / frame split of a plane launch around a halo exchange: mode 0 = every point, 1 = the points inside the box,
 // 2 = the points outside it (launched after mode 1; together they cover the plane exactly once).
 struct SplitBox {

@@ -777,22 +777,13 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, co
   // points there are) and need no LDS and few registers; the tile kernel is bound by what it issues and by its LDS.  Neither reads
   // what the other writes (pass B's winds go to the workspace; where both write -- the rim of the tiled area -- they write the same
   // values): the band runs on a stream of this thread's own, beside the tiles.
-  if (part == 0 && tiles.any() && !getenv("PACE_CSW_ONE_STREAM")) {
-    static thread_local hipStream_t side = nullptr;
-    static thread_local hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    if (side == nullptr) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess)
-        return PACE_ERR_LAUNCH;
-    }
-    if (hipEventRecord(ev_in, st) != hipSuccess || hipStreamWaitEvent(side, ev_in, 0) != hipSuccess) return PACE_ERR_LAUNCH;
-    pass_a(side);
-    passes_bcd(side);
+  const PaceSideStream* side = (part == 0 && tiles.any() && !getenv("PACE_CSW_ONE_STREAM")) ? pace_side_stream() : nullptr;
+  if (side != nullptr) {
+    if (!side->fork(st)) return PACE_ERR_LAUNCH;
+    pass_a(side->s);
+    passes_bcd(side->s);
     tile_kernel(st);
-    if (hipEventRecord(ev_out, side) != hipSuccess || hipStreamWaitEvent(st, ev_out, 0) != hipSuccess) return PACE_ERR_LAUNCH;
+    if (!side->join(st)) return PACE_ERR_LAUNCH;
     PACE_CHECK_LAUNCH();
     return PACE_OK;
   }
