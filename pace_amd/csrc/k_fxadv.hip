@@ -147,10 +147,24 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
   // cx_acc / cy_acc (optional): the Courant-number half of d_sw's flux_capacitor (d_sw.py:33-60), cx += crx, cy += cry,
   // done where crx / cry are produced
   // (flattened rows; 64 x 4 patches, which halve the re-reads of the rows above and below, measured 64 us against 61)
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+#ifdef PACE_EMU
+  const int bxp = (int)blockIdx.x, chunk = (int)blockIdx.y;
+#else
+  // Workgroups are dealt to the eight XCDs round-robin in launch order, and a point reads the rows above and below its own: with
+  // the plain order those rows belong to workgroups on OTHER XCDs and every XCD's L2 fetches its own copy (counted 324 MB for 233
+  // algorithmic).  Here XCD x takes the x-th eighth of the plane's blocks (contiguous rows) of every chunk of levels: workgroup
+  // 8 q + x of a chunk is block x S + q, S = ceil(blocks / 8); only the seams between the eighths are fetched twice.
+  const int nbx = (int)gridDim.x, seg = (nbx + 7) / 8;
+  const int lin = (int)blockIdx.x + nbx * (int)blockIdx.y;
+  const int per_chunk = 8 * seg;  // (the grid is launched with 8 * seg blocks per chunk: see launch_fxadv)
+  const int chunk = lin / per_chunk, r = lin - chunk * per_chunk;
+  const int bxp = (r & 7) * seg + (r >> 3);
+  if (bxp >= (int)((((long)g.sj * g.nj) + 255) / 256)) return;
+#endif
+  const long p = (long)bxp * 256 + threadIdx.x;
   const int j = (int)(p / g.sj);
   const int i = (int)(p - (long)j * g.sj);
-  const int k0 = (int)blockIdx.y * FX_CH;
+  const int k0 = chunk * FX_CH;
   if (j >= g.nj || i >= g.ni) return;
   if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;
   const long c2 = IDX2(g, i, j);
@@ -293,7 +307,11 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
     add_region(S.d, g.is - 1, g.ie + 1, g.je, g.je);
     hipLaunchKernelGGL(k_fxadv_edges, dim3((unsigned)g.nk), dim3(1024), 0, st, g, m, uc, vc, ut, vt, S);
   }
+#ifdef PACE_EMU
   const dim3 grid_fluxes(plane_grid(g, 1).x, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);
+#else
+  const dim3 grid_fluxes((plane_grid(g, 1).x + 7) / 8 * 8, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);  // (eight equal segments: k_fxadv_fluxes)
+#endif
   hipLaunchKernelGGL(k_fxadv_fluxes, grid_fluxes, dim3(256), 0, st, g, m, uc, vc, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box,
                      contra_out);
   PACE_CHECK_LAUNCH();
