@@ -249,6 +249,44 @@ def test_d2a2c_vect_and_divergence_damping_pairs_through_the_runner(tmp_path):
     assert bound == 1e-14 and set(worst) == {"fx", "fy"} and ok, worst
 
 
+def test_xppm_yppm_pairs_through_the_runner(tmp_path):
+    """XPPM / YPPM (translate_xppm.py:8-58, translate_yppm.py:8-60): the row / column window comes as Fortran indices of the model grid
+    in the savepoint's parameters (jfirst / jlast, ifirst / ilast: + 2 = the local index), `q` and the flux are serialised on it."""
+    import argparse
+
+    import run_savepoints as rs
+    from oracle import dgrid_sw
+    from oracle import ppm_transport as tr
+    from pace_amd import _lib, synthetic
+
+    d = str(tmp_path)
+    m = synthetic.tile_metrics(N, NZ)
+    s = synthetic.acoustic_state(m, N, NZ)
+    np.savez(os.path.join(d, "metrics.npz"), **m)
+    g = oracle_grid(m, N, NZ)
+    for k in ("crx", "cry", "xfx", "yfx"):
+        s[k] = np.zeros_like(s["pt"])
+    dgrid_sw.fxadv(g, s["uc"], s["vc"], s["crx"], s["cry"], s["xfx"], s["yfx"], np.zeros_like(s["pt"]), np.zeros_like(s["pt"]), s["dt"])
+    # the inner sweeps of fvtp2d: x on the rows 0 .. N+5 (Fortran jfirst = -2), y on the columns 0 .. N+5
+    first_f, last_f = -2, N + 3
+    for axis, name, order, c_name, metric in ((0, "XPPM", "iord", "crx", "dxa"), (1, "YPPM", "jord", "cry", "dya")):
+        origin = (3, 0, 0) if axis == 0 else (0, 3, 0)
+        domain = (N + 1, N + 6, NZ) if axis == 0 else (N + 6, N + 1, NZ)
+        ref = np.zeros_like(s["pt"])
+        tr.ppm_flux(s["pt"], s[c_name], m[metric], g, axis, 6, ref, origin, domain)
+        W = tuple(slice(o, o + dd) for o, dd in zip(origin, domain))
+        ins = {("qx" if axis == 0 else "q"): _sp(s["pt"][:N + 6, :N + 6, :NZ]), ("cx" if axis == 0 else "c"): _sp(s[c_name][W]),
+               order: _sp(np.array(6.0)), ("jfirst" if axis == 0 else "ifirst"): _sp(np.array(float(first_f))),
+               ("jlast" if axis == 0 else "ilast"): _sp(np.array(float(last_f)))}
+        np.savez(os.path.join(d, f"{name}-In.npz"), **ins)
+        np.savez(os.path.join(d, f"{name}-Out.npz"), **{("xflux" if axis == 0 else "flux"): _sp(ref[W])})
+    lib = _lib.Library(build_emu())
+    args = argparse.Namespace(device="cpu", metrics=os.path.join(d, "metrics.npz"), rank_tile=False, namelist={})
+    for name, out in (("XPPM", "xflux"), ("YPPM", "flux")):
+        ok, bound, worst, _, _ = rs.run_one(name, rs.read_pair(d, name), args, lib)
+        assert bound == 1e-14 and set(worst) == {out} and ok and worst[out] == 0.0, (name, worst)
+
+
 def test_unreadable_netcdf_says_what_to_do(tmp_path):
     import run_savepoints as rs
 
