@@ -138,7 +138,9 @@ __device__ __forceinline__ void fx_vt_corners_point(const Geo& g, const Met& m, 
 // one that applies there), instead of reading them back from ut / vt: the two 3-D fields ut and vt are no longer written and
 // read on 90 % of the plane (4 of 12 field passes of fxadv).  Frame points read the ut / vt the edge kernel below left there.
 // contra_out: also store the winds formed here (the stand-alone entry pace_fxadv returns ut and vt whole).
+#ifndef FX_CH
 #define FX_CH 8
+#endif
 __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
                                                       real* __restrict__ ut, real* __restrict__ vt, real* __restrict__ crx,
                                                       real* __restrict__ cry, real* __restrict__ xfx,
