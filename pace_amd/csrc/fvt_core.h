@@ -705,6 +705,9 @@ struct FvtTile {
 // 1 damping fluxes added to the transport fluxes; 2 added mass-weighted; 3 damping of q -> dw / heat_s / diss_est only (w).
 // EPI 0: fluxes stored (or accumulated / turned into winds); 1: flux-form update of the cell stored; 3 (with DMODE 0): the
 // height update of updatedzd stored (apply_height_fluxes, updatedzd.py:70-126).
+#ifndef FVT_ARRIVE
+#define FVT_ARRIVE(n)  // (tools/census/fvt_prof.hip: when the first x-run wave and the first y-run wave reach barrier n of a pass)
+#endif
 #ifndef FVT_STAMP
 #define FVT_STAMP(n)  // (tools/census/fvt_prof.hip: shader-clock stamps of one workgroup per level)
 #endif
@@ -1175,6 +1178,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         bvb[t] = LDG(S.vort_b + kb, o);
       }
     }
+    FVT_ARRIVE(4 * s);
     __syncthreads();
     FVT_STAMP(4 * s + 1);
     if (is_delp) {  // the mass on the tile and one cell around it, from the footprint while it is there
@@ -1199,6 +1203,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
             priv[f * NT + tid] = Tile::face(D, T.sdu[T.ybase + (f + 3) * P], D.last[T.ybase + (f + 2) * P], D.last[T.ybase + (f + 3) * P]);
         }
       }
+      FVT_ARRIVE(4 * s + 1);
       __syncthreads();  // the sweeps overwrite the damping planes
     }
     if (is_vort) T.add_2d(S.fC);  // the damped scalar was the relative vorticity, the transported one is the absolute (d_sw.py:389-402)
@@ -1261,6 +1266,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
           L.u.s.sqi[T.ybase + t * P] = (Q[t + 3] * ar[t] + af[t] * si[t] - af[t + 1] * si[t + 1]) / (ar[t] + af[t] - af[t + 1]);
       }
     }
+    FVT_ARRIVE(4 * s + 2);
     __syncthreads();
     FVT_STAMP(4 * s + 3);
     double* const tke = L.sq;     // the winds: kinetic energy / damped vorticity at the tile's B-grid points, pitch BW
@@ -1474,6 +1480,7 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         STG(qout, c2[t]) = val;
       }
     }
+    FVT_ARRIVE(4 * s + 3);
     if (s < 3 || S.winds) __syncthreads();  // (the cell update read sq / ax / ay)
   };
   pass(std::integral_constant<int, 0>{});

@@ -38,6 +38,8 @@ def main():
                  dsw._workspace.data_ptr(), *[dptr(f[k]) for k in DSW_ARGS], float(s["dt"]), None)
 
     host = (C.c_longlong * (4 * 128 * 32))()
+    host_arr = (C.c_longlong * (4 * 128 * 64))()
+    arrive = [[], [], [], []]
     rows = [[], [], [], []]
     nstamp = 21 if fused else 17
     for rep in range(6):
@@ -58,6 +60,11 @@ def main():
         if rep >= 1:
             for w in range(4):
                 rows[w].append(np.diff(a[w], axis=1))
+            if hasattr(lib.cdll, "pace_debug_fvt_arrive") and lib.cdll.pace_debug_fvt_arrive(host_arr) == 0:
+                b = np.frombuffer(host_arr, dtype=np.int64).reshape(4, 128, 32, 2)[:, :nz].astype(float)
+                for w in range(4):
+                    # arrival at barrier q of pass s_, both roles, relative to the stamp that opens the stage (4 s_ + q)
+                    arrive[w].append(b[w][:, :nstamp - 1, :] - a[w][:, :nstamp - 1, None])
     # the single-scalar kernel as d_sw launches it: the vorticity transport (phases: flux preparation, ke / vorticity, damping + transport)
     rows1 = [[], [], [], []]
     for rep in range(6):
@@ -82,6 +89,13 @@ def main():
         for sc in range(5 if fused else 4):
             line = "  ".join(f"{PARTS[p][:24]:24s} {med[4 * sc + p]:7.0f}" for p in range(4))
             print(f"   {SCALARS[sc]:6s} {med[4 * sc:4 * sc + 4].sum():7.0f} | {line}")
+        if arrive[w]:
+            am = np.median(np.concatenate(arrive[w]), axis=0)  # [stage, role]
+            print("   when the first x-run wave / the first y-run wave reach the barrier that ends a stage (cycles after the stage opened):")
+            for sc in range(5 if fused else 4):
+                print(f"   {SCALARS[sc]:6s} " + "  ".join(
+                    f"{PARTS[p_][:18]:18s} " + (f"x {am[4 * sc + p_, 0]:6.0f} y {am[4 * sc + p_, 1]:6.0f}" if abs(am[4 * sc + p_, 0]) < 1e9 else "(no barrier)     ")
+                    for p_ in range(4)))
 
 
 if __name__ == "__main__":
