@@ -292,7 +292,17 @@ struct FvtTile {
       ycol = h < 3 ? h : TI + h;
     }
     y_outer = yrole && tr < NYO;
-    xr = tr / GXN, xg = tr - xr * GXN;
+    if (GXN == 8) {
+      // Sixteen lanes that the LDS serves together take 4 rows x 4 runs, not 2 rows x 8 runs: a run starts every C = 4 values, so
+      // runs g and g + 4 of a row are 16 values apart -- the same pair of banks for 8-byte accesses (two-way conflicts on every
+      // read of the x-runs: 30 M conflict cycles per launch, a third of the LDS's busy time; SQ_LDS_BANK_CONFLICT).  With the
+      // pitches of these planes (41, 33, 35: odd and != 1 mod 4 apart) four consecutive rows shift by distinct amounts mod 16.
+      const int l = tr & 63, w = tr >> 6;
+      xr = (w << 3) + ((l >> 5) << 2) + ((l & 15) >> 2);
+      xg = (((l >> 4) & 1) << 2) + (l & 3);
+    } else {
+      xr = tr / GXN, xg = tr - xr * GXN;
+    }
     x_on = xrole && xr < QH, x_outer = xrole && xr < TJ;
     xrow = xr + 3;  // the tile's own rows first: footprint rows 3 .. TJ+2, then TJ+3 .. QH-1, then 0 .. 2
     if (xrow >= QH) xrow -= QH;
