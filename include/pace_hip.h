@@ -183,6 +183,10 @@ int pace_d_sw_pingpong_supported(const pace_geom_t* geom, const pace_dsw_config_
  * (The damping orders nord_v, nord_w, nord_t of the column namelist must be <= 2, as get_column_namelist makes them,
  * d_sw.py:633-683; otherwise the call returns PACE_ERR_UNSUPPORTED.) */
 int pace_d_sw_wind_outputs_supported(const pace_geom_t* geom, const pace_dsw_config_t* cfg);
+/* The two queries above AND the condition on the column namelist in one call (what pace_d_sw* really accepts for this object):
+ * 0 = no separate outputs, 1 = the four scalars', 3 = the scalars' and the winds'.  col: the HOST arrays given to pace_d_sw_prepare
+ * (get_column_namelist, d_sw.py:633-683). */
+int pace_d_sw_outputs_supported(const pace_geom_t* geom, const pace_column_t* col, const pace_dsw_config_t* cfg);
 /* Once per object, after zero-filling the workspace: uploads the column namelist (synchronises). */
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream);
 int pace_d_sw(const pace_geom_t* geom, const pace_metrics_t* met, const pace_column_t* col,

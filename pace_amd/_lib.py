@@ -95,6 +95,7 @@ _PROTOS = {
     "pace_d_sw_prepare": (C.c_int, [_P(Geom), _P(Column), c_dp, C.c_void_p]),
     "pace_d_sw_pingpong_supported": (C.c_int, [_P(Geom), _P(DswConfig)]),
     "pace_d_sw_wind_outputs_supported": (C.c_int, [_P(Geom), _P(DswConfig)]),
+    "pace_d_sw_outputs_supported": (C.c_int, [_P(Geom), _P(Column), _P(DswConfig)]),
     "pace_d_sw": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_transport": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),
     "pace_d_sw_winds": (C.c_int, [_P(Geom), _P(Metrics), _P(Column), _P(DswConfig), c_dp] + [c_dp] * 23 + [C.c_double, C.c_void_p]),

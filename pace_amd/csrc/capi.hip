@@ -155,6 +155,16 @@ int pace_d_sw_wind_outputs_supported(const pace_geom_t* geom, const pace_dsw_con
   return (geom && cfg && dsw_winds_in_scalars(make_geo(geom), cfg)) ? 1 : 0;
 }
 
+int pace_d_sw_outputs_supported(const pace_geom_t* geom, const pace_column_t* col, const pace_dsw_config_t* cfg) {
+  // the ONE predicate of what launch_d_sw accepts: the two queries above plus the condition on the column namelist they cannot see
+  if (!geom || !col || !cfg || !col->nord_v || !col->nord_w || !col->nord_t) return 0;
+  const Geo g = make_geo(geom);
+  for (int k = 0; k < g.nk; ++k)
+    if (col->nord_v[k] > 2 || col->nord_w[k] > 2 || col->nord_t[k] > 2) return 0;
+  if (!dsw_pingpong_supported(g, cfg)) return 0;
+  return dsw_winds_in_scalars(g, cfg) ? 3 : 1;
+}
+
 int pace_d_sw_prepare(const pace_geom_t* geom, const pace_column_t* col, void* workspace, void* stream) {
   NEED(geom && col && workspace);
   return dsw_prepare(make_geo(geom), col, workspace, S(stream));

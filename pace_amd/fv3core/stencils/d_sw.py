@@ -113,10 +113,11 @@ class DGridShallowWaterLagrangianDynamics(Operator):
         self.call("pace_d_sw_prepare", C.byref(self._col), self._workspace.data_ptr(), self.stream())
         # The four scalars d_sw transports are written to buffers of their own where the library supports it (the fused scalar
         # kernel of the production tilings, include/pace_hip.h pace_dsw_config_t) and swapped into the caller's Quantities.
-        self._pingpong = bool(swap_scalar_storage) and not os.environ.get("PACE_DSW_INPLACE") and bool(
-            self.lib.cdll.pace_d_sw_pingpong_supported(C.byref(self._geom), C.byref(self._cfg)))
+        # (pace_d_sw_outputs_supported: the one predicate of what the launcher accepts, the column namelist's damping orders included)
+        accepts = int(self.lib.cdll.pace_d_sw_outputs_supported(C.byref(self._geom), C.byref(self._col), C.byref(self._cfg)))
+        self._pingpong = bool(swap_scalar_storage) and not os.environ.get("PACE_DSW_INPLACE") and bool(accepts & 1)
         # ... and the winds, where the library updates them in the kernel that transports the scalars
-        self._wind_outputs = self._pingpong and bool(self.lib.cdll.pace_d_sw_wind_outputs_supported(C.byref(self._geom), C.byref(self._cfg)))
+        self._wind_outputs = self._pingpong and bool(accepts & 2)
         self._quantity_factory = quantity_factory
         self._spares = None
 

@@ -96,6 +96,38 @@ def test_c_sw_interior_tiles_equal_the_four_passes(emu_lib, emu_small_lib, n, nz
     assert not np.array_equal(ref["uc"][10:n - 4, 10:n - 4, :nz], s["uc"][10:n - 4, 10:n - 4, :nz])
 
 
+def test_d_sw_outputs_supported_is_what_the_launcher_accepts(emu_lib):
+    """the query and the launcher must agree.  pace_d_sw_outputs_supported sees the column namelist: damping orders
+    nord_v / nord_w / nord_t above 2 (get_column_namelist never makes them: d_sw.py:633-683) mean no separate outputs, and the
+    operator built on such a namelist runs in place -- the launcher is never handed outputs it would refuse."""
+    import ctypes as C
+
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, get_column_namelist
+
+    n, nz = 24, 4
+    from pace_amd import synthetic
+
+    m = synthetic.tile_metrics(n, nz)
+    from helpers import build_emu_canon
+    from pace_amd import _lib
+
+    env = Env(_lib.Library(build_emu_canon()), "cpu", m, n, nz)
+    cfg = DGridShallowWaterLagrangianDynamicsConfig()
+    col = get_column_namelist(cfg, env.qf)
+    op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, col, False, False, cfg, swap_scalar_storage=True)
+    lib = op.lib
+    assert lib.cdll.pace_d_sw_outputs_supported(C.byref(op._geom), C.byref(op._col), C.byref(op._cfg)) == 3 and op._pingpong and op._wind_outputs
+    col3 = {k: (v.numpy().copy() if hasattr(v, "numpy") else np.array(v, dtype=float)) for k, v in col.items()}
+    col3["nord_v"] = np.full_like(col3["nord_v"], 3.0)
+    op3 = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, {k: env.kq(v) for k, v in col3.items()}, False, False, cfg,
+                                              swap_scalar_storage=True)
+    assert lib.cdll.pace_d_sw_outputs_supported(C.byref(op3._geom), C.byref(op3._col), C.byref(op3._cfg)) == 0
+    assert not op3._pingpong and not op3._wind_outputs
+    # the older, column-blind queries still say what they said
+    assert lib.cdll.pace_d_sw_pingpong_supported(C.byref(op3._geom), C.byref(op3._cfg)) == 1
+
+
 def test_in_checkpoints_hold_the_state_before_the_call(emu_lib):
     """AcousticDynamics overlaps the u / v and uc / vc halo exchanges with the interior of c_sw's first pass and
     of d_sw's flux preparation; with a checkpointer attached those early starts are skipped, so that "C_SW-In" / "D_SW-In" hold
