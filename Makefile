@@ -8,6 +8,8 @@ HDRS := $(CSRC)/k_fvt.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/delnflux_co
 # -ffp-contract=off: no FMA contraction, so horizontal stencils are bit-comparable with the numpy oracle.
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 OBJS := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
+# the C ABI (pace_*) is all a library exports: $(CSRC)/exports.map
+EXPORTS := -Wl,--version-script=$(CSRC)/exports.map
 
 all: pace_amd/libpace_hip.so pace_amd/libpace_hip_f32.so
 
@@ -17,19 +19,21 @@ build/hip_f32/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip_f32
 	$(HIPCC) $(HIPFLAGS) -DPACE_REAL_FLOAT -c $< -o $@
 f32: pace_amd/libpace_hip_f32.so
-pace_amd/libpace_hip_f32.so: $(F32OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(F32OBJS) -o $@
+pace_amd/libpace_hip_f32.so: $(F32OBJS) $(CSRC)/exports.map
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(EXPORTS) $(F32OBJS) -o $@
 
 build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-pace_amd/libpace_hip.so: $(OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OBJS) -o $@
+pace_amd/libpace_hip.so: $(OBJS) $(CSRC)/exports.map
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(EXPORTS) $(OBJS) -o $@
 
 EMU_TI ?= 64
 EMU_TJ ?= 16
-EMUFLAGS := -O2 -g -std=c++17 -fPIC -ffp-contract=off -DPACE_EMU -Itests/emu -x c++ $(EMU_EXTRA)
+# -fno-gnu-unique: the emulated __shared__ statics of template kernels must NOT be unified process-wide (STB_GNU_UNIQUE symbols
+# are, even under RTLD_LOCAL): two emulation libraries with different tile constants would share LDS arrays of different sizes
+EMUFLAGS := -O2 -g -std=c++17 -fPIC -fno-gnu-unique -ffp-contract=off -DPACE_EMU -Itests/emu -x c++ $(EMU_EXTRA)
 EMUOBJS := $(patsubst $(CSRC)/%.hip,build/emu/%.o,$(SRCS))
 
 build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
@@ -38,11 +42,11 @@ build/emu/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
 
 build/emu/hip_emu.o: tests/emu/hip_emu.cpp tests/emu/hip_emu.h
 	@mkdir -p build/emu
-	g++ -O2 -g -std=c++17 -fPIC -Itests/emu -c $< -o $@
+	g++ -O2 -g -std=c++17 -fPIC -fno-gnu-unique -Itests/emu -c $< -o $@
 
 emu: tests/emu/libpace_emu.so
 tests/emu/libpace_emu.so: $(EMUOBJS) build/emu/hip_emu.o
-	g++ -shared -fPIC $(EMUOBJS) build/emu/hip_emu.o -o $@
+	g++ -shared -fPIC $(EXPORTS) $(EMUOBJS) build/emu/hip_emu.o -o $@
 
 EMUF32OBJS := $(patsubst $(CSRC)/%.hip,build/emu_f32/%.o,$(SRCS))
 build/emu_f32/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
@@ -50,7 +54,7 @@ build/emu_f32/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
 	g++ $(EMUFLAGS) -DPACE_REAL_FLOAT -c $< -o $@
 emu-f32: tests/emu/libpace_emu_f32.so
 tests/emu/libpace_emu_f32.so: $(EMUF32OBJS) build/emu/hip_emu.o
-	g++ -shared -fPIC $(EMUF32OBJS) build/emu/hip_emu.o -o $@
+	g++ -shared -fPIC $(EXPORTS) $(EMUF32OBJS) build/emu/hip_emu.o -o $@
 
 # the same, with 4 x 4 transport / damping tiles and runs of 2 interfaces: at C12 this gives workgroups that touch no tile
 # edge, so the straight-line interior code paths and every tile seam are exercised by the CPU test-suite as well
@@ -61,7 +65,7 @@ build/emu_small/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
 	g++ $(SMALLFLAGS) -c $< -o $@
 emu-small: tests/emu/libpace_emu_small.so
 tests/emu/libpace_emu_small.so: $(SMALLOBJS) build/emu/hip_emu.o
-	g++ -shared -fPIC $(SMALLOBJS) build/emu/hip_emu.o -o $@
+	g++ -shared -fPIC $(EXPORTS) $(SMALLOBJS) build/emu/hip_emu.o -o $@
 
 # the same, with 8 x 8 transport tiles and runs of 3 interfaces: at C16 / C24 every tile edge coincides with a tile boundary of
 # the workgroup tiling AND the run geometry satisfies ppm_run_canon's conditions (AHI = 2), so the CPU test-suite exercises the
@@ -73,7 +77,7 @@ build/emu_canon/%.o: $(CSRC)/%.hip $(HDRS) tests/emu/hip_emu.h
 	g++ $(CANONFLAGS) -c $< -o $@
 emu-canon: tests/emu/libpace_emu_canon.so
 tests/emu/libpace_emu_canon.so: $(CANONOBJS) build/emu/hip_emu.o
-	g++ -shared -fPIC $(CANONOBJS) build/emu/hip_emu.o -o $@
+	g++ -shared -fPIC $(EXPORTS) $(CANONOBJS) build/emu/hip_emu.o -o $@
 
 clean:
 	rm -rf build pace_amd/libpace_hip.so pace_amd/libpace_hip_f32.so tests/emu/libpace_emu.so tests/emu/libpace_emu_small.so tests/emu/libpace_emu_f32.so tests/emu/libpace_emu_canon.so
