@@ -31,7 +31,7 @@ TRANSPORT_FIELDS = 9  # fused transport kernel: q, crx, cry, xfx, yfx, x/y mass 
 
 def parse():
     p = argparse.ArgumentParser()
-    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--gpus", type=int, default=None)  # (None: one, or what a launcher's WORLD_SIZE says)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--n", "--tile-size", dest="n", type=int, default=192)  # (--n alone is ambiguous to torch.distributed.run)
@@ -150,6 +150,10 @@ def _cpu_omp_job(args):
     path, n, nz, reps, threads = args
     import time as _t
 
+    # threads pinned to cores, next to each other (set before the OpenMP runtime starts in this fresh process); the operands and the
+    # workspace are first touched BY THE TEAM, level by level as the loop nests walk them (oracle/omp_port.py team_copy)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import omp_port
     from oracle._np import Grid
     from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
@@ -186,9 +190,11 @@ def _cpu_omp_job(args):
         tried[t] = _t.perf_counter() - t0
         if best is None or tried[t] < best:
             best, best_t = tried[t], t
-        if tried[t] > 1.25 * best or t >= threads:
+        if tried[t] > 1.5 * best or t >= threads:
             break
         t = min(2 * t, threads)
+        dsw.work = omp_port._fresh(dsw.src)  # (first touch by the NEW team)
+        dsw.fp = omp_port._ptrs(dsw.work)
     omp_port.set_threads(best_t)
     secs = []
     for _ in range(reps):
@@ -297,7 +303,7 @@ def verify_against_oracle(got, ref, n, nz, skip=()):
     """One timed batch's device outputs against the oracle's outputs on the same operands, in the reference's metric with the
     bounds of its Translate tests: d_sw 3.2e-10 (translate_d_sw.py:19), riem_solver3 5e-6 (overrides/standard.yaml:49-61).
     `skip`: outputs the run did not ask for (DEAD_AFTER_DSW unless --full-outputs).  Returns (ok, {variable: error})."""
-    from pace_amd.tile import DSW_ARGS, compare, dsw_window, window
+    from pace_amd.tile import DSW_ARGS, compare, dsw_live_window, dsw_window, window
 
     errs, ok = {}, True
     for k in DSW_ARGS:
@@ -307,7 +313,9 @@ def verify_against_oracle(got, ref, n, nz, skip=()):
             continue
         if k == "w":  # overwritten by riem_solver3 afterwards: compared below
             continue
-        W = dsw_window(k, n, nz)
+        # --full-outputs: TranslateD_SW's own windows (the whole storage for the centred fields, translate_d_sw.py:36-65); with the
+        # dead work fields skipped the scalars' corner blocks are not specified either (pace_amd/tile.py dsw_live_window)
+        W = dsw_live_window(k, n, nz) if skip else dsw_window(k, n, nz)
         scale = float(np.abs(ref[k][W]).max())
         e = compare(ref[k][W], got[k][W], near_zero=1e-12 * max(scale, 1e-300))
         errs["d_sw." + k] = e
@@ -474,6 +482,8 @@ def launch_ranks(args):
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:  # left at its default: a launcher's world is adopted; only an EXPLICIT mismatch is refused
+        args.gpus = int(env_world) if env_world is not None else 1
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args))
     if env_world is not None and int(env_world) != args.gpus:
@@ -744,6 +754,32 @@ def main():
         torch.cuda.synchronize()
         got_last = {k: batches[-1][k].numpy().astype(np.float64) for k in list(DSW_ARGS) + ["delz", "ppe", "pk3"]}
 
+    # The OTHER output contract of d_sw, timed right here in the same way (not part of `value`): the line quotes the substep that
+    # skips the divergence damping's dead work fields (7 of 8 substeps of a remapping step); the reference's full contract --
+    # every argument as TranslateD_SW compares it, the halo of the work fields and the scalars' corner blocks included -- is the
+    # eighth.  (--full-outputs swaps the two.)  The state copies have been stepped once already: a second step of the same
+    # arithmetic, same bytes.
+    other_contract = None
+    if world == 1 and not use_graph:
+        nb = min(10, len(batches))
+
+        def step_other(b):
+            dsw(*[b[k] for k in DSW_ARGS], dt, overlap_winds=overlap, skip_dead_outputs=not skip_dead)
+            riem(False, dt, b["cappa"], ptop, zs, ws, b["delz"], b["q_con"], b["delp"], b["pt"], b["zh"], b["pe"], b["ppe"], b["pk3"],
+                 b["pk"], b["peln"], b["w"])
+            dsw.join()
+
+        for i in range(min(3, nb)):
+            step_other(batches[i])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nb):
+            step_other(batches[-1 - i])
+        torch.cuda.synchronize()
+        other_contract = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / nb, "steps": nb,
+                          "d_sw_outputs": "dead work fields skipped" if args.full_outputs else
+                          "the reference's full contract (flags = 0): all 21 arguments over TranslateD_SW's windows"}
+
     # The dominant kernel OF THE STEP, timed live with events on the launch stream, alone, on HBM-resident operands that change
     # from launch to launch.  Production tilings: k_fvt_scalars -- the scalar phase of d_sw (delp, w, q_con, pt transported, damped
     # and updated in one kernel; pace_amd/csrc/fvt_core.h), launched exactly as the step launches it (pace_d_sw_phases, mask 2,
@@ -820,7 +856,9 @@ def main():
             import subprocess
 
             exe = os.path.join(ROOT, "build", "ubench_streams")
-            if os.path.exists(exe):
+            # (not under --no-traffic: that is what the profiled children of measure_traffic / collect_*.sh run with, and a
+            # child process would inherit the profiler's preload and stream 1 GiB buffers under counter collection)
+            if os.path.exists(exe) and not args.no_traffic:
                 torch.cuda.synchronize()
                 txt = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
                 rows = {ln[:28].strip(): ln[28:].split() for ln in txt.splitlines() if ln[:5] in ("read ", "write", "copy ")}
@@ -830,6 +868,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f"[bench] stream micro-benchmark failed: {e!r}\n")
         try:
+            if args.no_traffic:
+                raise RuntimeError("skipped")
             src = torch.empty(1 << 27, dtype=torch.float64, device=dev).normal_()
             dst = torch.empty_like(src)
             for _ in range(2):
@@ -888,6 +928,7 @@ def main():
                                              "--full-outputs measures the other)")},
             "step_hbm_frac": BYTES_PER_CELL_UPDATE * (item / 8.0) * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": roof,
+            "other_contract": other_contract,
         }
         if world > 1:
             import torch.distributed as dist

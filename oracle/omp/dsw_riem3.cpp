@@ -50,10 +50,11 @@ inline double contra(double v1, double v2, double cosa, double rsin2) { return (
 
 // -------------------------------------------------------------------------------------------------------- workspace
 struct Work {
-  std::vector<double> buf;
+  double* buf = nullptr;  // (malloc'ed and zeroed BY THE TEAM, level by level as the loop nests walk it: first touch puts a level's
+  long size = 0;          //  pages on the memory of the core that will work on it)
   long n3 = 0;
   int used = 0;
-  double* take() { return buf.data() + (long)(used++) * n3; }
+  double* take() { return buf + (long)(used++) * n3; }
 };
 
 // -------------------------------------------------------------------------------------------------------- fxadv
@@ -1157,9 +1158,17 @@ namespace {
 Work& work_for(const Grid& g, int fields) {
   static Work W;
   const long n3 = g.sk * (g.nk + 1);
-  if (W.n3 != n3 || (long)W.buf.size() < n3 * fields) {
+  if (W.n3 != n3 || W.size < n3 * fields) {
+    free(W.buf);
     W.n3 = n3;
-    W.buf.assign((size_t)n3 * fields, 0.0);
+    W.size = n3 * fields;
+    W.buf = (double*)malloc(sizeof(double) * (size_t)W.size);
+    for (int f = 0; f < fields; ++f) {
+      double* p = W.buf + (long)f * n3;
+#pragma omp parallel for schedule(static)
+      for (int k = 0; k <= g.nk; ++k)
+        for (long e = 0; e < g.sk; ++e) p[(long)k * g.sk + e] = 0.0;
+    }
   }
   W.used = 0;
   return W;
@@ -1177,6 +1186,12 @@ Grid make_grid(const int* dims, const double* const* m, const double* sc) {
 extern "C" {
 int omp_port_threads() { return omp_get_max_threads(); }
 void omp_port_set_threads(int n) { omp_set_num_threads(n); }
+// dst = src for a field of nlev levels of n2 elements, by the team with the loop nests' schedule (a level's pages are first
+// touched by the thread that will work on that level)
+void omp_port_copy_levels(double* dst, const double* src, long nlev, long n2) {
+#pragma omp parallel for schedule(static)
+  for (long k = 0; k < nlev; ++k) memcpy(dst + k * n2, src + k * n2, sizeof(double) * (size_t)n2);
+}
 
 void omp_port_d_sw(const int* dims, const double* const* metrics, const double* scalars, const double* const* col, const int* icfg,
                    const double* dcfg, double* const* f, double dt) {

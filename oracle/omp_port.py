@@ -60,6 +60,23 @@ def from_kji(dst, src):
     dst[...] = src.T
 
 
+def team_copy(dst, src):
+    """dst[...] = src through the library's team, level by level (3-D [k][j][i] arrays): the pages of a level are first touched
+    by the thread that works on it.  Anything else: a plain copy."""
+    if dst.ndim == 3 and dst.flags.c_contiguous and src.flags.c_contiguous and dst.shape == src.shape:
+        load().omp_port_copy_levels(C.c_void_p(dst.ctypes.data), C.c_void_p(src.ctypes.data), C.c_long(dst.shape[0]), C.c_long(dst.shape[1] * dst.shape[2]))
+    else:
+        dst[...] = src
+
+
+def _fresh(src):
+    """Untouched arrays of the shapes of `src`, filled by the team."""
+    out = [np.empty_like(a) for a in src]
+    for w, s in zip(out, src):
+        team_copy(w, s)
+    return out
+
+
 def _ptrs(arrs):
     return (C.c_void_p * len(arrs))(*[a.ctypes.data if a is not None else None for a in arrs])
 
@@ -98,12 +115,12 @@ class DswCall:
         self.icfg = (C.c_int * 6)(cfg["hord_dp"], cfg["hord_tm"], cfg["hord_vt"], cfg["hord_mt"], cfg["nord"], int(cfg.get("do_skeb", False)))
         self.dcfg = (C.c_double * 3)(cfg["dddmp"], cfg["d4_bg"], cfg["d_con"])
         self.src = [to_kji(ut), to_kji(vt)] + [to_kji(fields[k]) for k in DSW_FIELDS]
-        self.work = [a.copy() for a in self.src]
+        self.work = _fresh(self.src)
         self.fp = _ptrs(self.work)
 
     def reset(self):
         for w, s in zip(self.work, self.src):
-            w[...] = s
+            team_copy(w, s)
 
     def run(self):
         load().omp_port_d_sw(self.tile.dims(), self.tile.mp, self.tile.sc, self.colp, self.icfg, self.dcfg, self.fp, C.c_double(self.dt))
@@ -131,12 +148,12 @@ class RiemCall:
         self.tile = tile
         self.args = (int(bool(last_call)), C.c_double(dt), C.c_double(ptop), C.c_double(p_fac), C.c_double(beta), int(bool(use_logp)))
         self.src = [to_kji(fields[k]) for k in RIEM_FIELDS]
-        self.work = [a.copy() for a in self.src]
+        self.work = _fresh(self.src)
         self.fp = _ptrs(self.work)
 
     def reset(self):
         for w, s in zip(self.work, self.src):
-            w[...] = s
+            team_copy(w, s)
 
     def run(self):
         load().omp_port_riem3(self.tile.dims(), self.tile.mp, self.tile.sc, self.fp, *self.args)

@@ -489,14 +489,15 @@ __global__ void __launch_bounds__(256)
 k_scale_copy(Geo g, const real* __restrict__ src, real* __restrict__ dst, double factor, int scale, int i0, int i1,
              int j0, int j1) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;  // pair index in the plane
-  const int half = g.sj / 2;
+  const int half = (g.sj + 1) / 2;  // (an odd row stride: the last pair of a row is its last element alone)
   const int j = (int)(p / half);
   const int i = 2 * (int)(p - (long)j * half);
   const int k = (int)blockIdx.y;
   if (j >= g.nj || j < j0 || j > j1 || i + 1 < i0 || i > i1) return;
   const long c = IDX3(g, i, j, k);
-  const bool lo = i >= i0, hi = i + 1 <= i1;
-  if (lo && hi && (((uintptr_t)src | (uintptr_t)dst) & (2 * sizeof(real) - 1)) == 0) {
+  const bool lo = i >= i0, hi = i + 1 <= i1 && i + 1 < g.sj;
+  // the pair form needs the ELEMENT aligned, not only the bases: even row and level strides (the C ABI accepts odd ones)
+  if (lo && hi && (((uintptr_t)src | (uintptr_t)dst) & (2 * sizeof(real) - 1)) == 0 && ((g.sj | g.sk) & 1) == 0) {
     ScPair v = *(const ScPair*)(src + c);
     if (scale) v.x = (real)(v.x * factor), v.y = (real)(v.y * factor);
     *(ScPair*)(dst + c) = v;
@@ -506,7 +507,7 @@ k_scale_copy(Geo g, const real* __restrict__ src, real* __restrict__ dst, double
   }
 }
 static inline dim3 pair_grid(const Geo& g, int nlev) {
-  return dim3((unsigned)(((long)(g.sj / 2) * g.nj + 255) / 256), (unsigned)nlev, 1);
+  return dim3((unsigned)(((long)((g.sj + 1) / 2) * g.nj + 255) / 256), (unsigned)nlev, 1);
 }
 
 // p_grad_c_stencil (dyn_core.py:120-171), non-hydrostatic; compute + 1.  A thread takes PG_CH consecutive layers of its point:

@@ -41,6 +41,24 @@ k_copy_winds(Geo g, real* __restrict__ u, real* __restrict__ v, const real* __re
   if (j <= g.je) v[c] = v_n[c];
 }
 
+// What the reference LEAVES in the 3 x 3 corner blocks of the halo of a transported scalar (full contract only):
+// FiniteVolumeTransport copies the corners in y, then in x, IN PLACE on q (fvtp2d.py:262-345; corners.py:307-425), the del-n
+// damping works on a copy, and nothing of d_sw writes the blocks afterwards -- so delp, pt, w, q_con end with copy_corners_x of
+// what they held, which TranslateD_SW compares (translate_d_sw.py:36-65: the whole storage).  The kernels apply the corner
+// copies as index maps on reads; this writes the blocks once, at the end: every source lies in an edge halo, which d_sw never
+// writes.  One workgroup per level, 4 fields x 4 corners x 9 cells.
+__global__ void __launch_bounds__(256)
+k_corner_blocks_x(Geo g, real* __restrict__ f0, real* __restrict__ f1, real* __restrict__ f2, real* __restrict__ f3) {
+  const int t = (int)threadIdx.x;
+  if (t >= 144) return;
+  const int f = t / 36, e = t - f * 36, q = e / 9, a = (e % 9) % 3, b = (e % 9) / 3;
+  real* const p = (f == 0 ? f0 : f == 1 ? f1 : f == 2 ? f2 : f3) + (long)blockIdx.x * g.sk;
+  const int i = (q & 1) ? g.ie + 1 + a : g.is - 1 - a, j = (q & 2) ? g.je + 1 + b : g.js - 1 - b;
+  int si = i, sj_ = j;
+  remap_agrid_x(g, si, sj_);
+  p[IDX2(g, i, j)] = p[IDX2(g, si, sj_)];
+}
+
 bool dsw_pingpong_supported(const Geo& g, const pace_dsw_config_t* cfg) {
   return cfg->hord_dp == cfg->hord_vt && cfg->hord_dp == cfg->hord_tm && transport_lean_covers(g, cfg->hord_dp);
 }
@@ -595,8 +613,8 @@ k_divdamp_high_final(Geo g, Met m, const real* __restrict__ wk, const real* delp
 // of the divergence run in LDS on the tile's footprint (halo `nord` <= 3, shrinking by one per pass like the reference's
 // domains, divergence_damping.py:579-600), the last pass at the tile's own points with its uc / vc kept for the caller,
 // then the tail (a2b_ord4 of the relative vorticity, Smagorinsky term, damped vorticity, ke += ...).  `din` holds the
-// divergence c_sw left (the caller copies it to delpc first -- copy_computeplus, :578 -- so din == delpc and this kernel
-// may overwrite divg_d while neighbouring tiles still read their halo from delpc).
+// divergence c_sw left (full contract: a copy of it on the whole plane in a scratch field, so that this kernel may overwrite
+// divg_d while neighbouring tiles still read their halo; PACE_DSW_SKIP_DEAD_OUTPUTS: divg_d itself, which is then not written).
 // Replaces 3 x k_divdamp_iter + k_divdamp_high_final: 10 field passes instead of 16.
 // ------------------------------------------------------------------------------------------------
 #ifndef DD_TI
@@ -995,14 +1013,20 @@ __global__ void __launch_bounds__(256)
 k_divdamp_low_and_copy(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ua,
                        const real* __restrict__ va, const real* __restrict__ uc, const real* __restrict__ vc,
                        real* __restrict__ delpc, real* __restrict__ vort_b, real* __restrict__ ke, const real* __restrict__ d2_bg,
-                       double dddmp, double dt, const real* __restrict__ divg_d, int kstart) {
+                       double dddmp, double dt, const real* __restrict__ divg_d, int kstart, real* __restrict__ dcopy) {
   PLANE_IJK(g);
   const long c = IDX3(g, i, j, k);
+  const bool own = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1;
   if (k >= kstart) {
-    delpc[c] = divg_d[c];
+    // copy_computeplus (divergence_damping.py:578): delpc = divg_d on the B-grid points of the tile -- delpc's halo stays what c_sw
+    // left there (TranslateD_SW compares it on the whole storage); the whole plane, halo included, goes to the scratch field the
+    // fused kernel takes its footprints from (it overwrites divg_d while neighbouring tiles still read theirs)
+    const double d = divg_d[c];
+    if (own) delpc[c] = d;
+    dcopy[c] = d;
     return;
   }
-  if (i < g.is || i > g.ie + 1 || j < g.js || j > g.je + 1) return;
+  if (!own) return;
   const long c2 = IDX2(g, i, j);
   const int sj = g.sj;
   const double a0 = dd_u_contra_dyc(g, m, u, va, vc, c, c2, j);
@@ -1136,6 +1160,139 @@ int launch_a2b_ord4_tiled(const Geo& g, const Met& m, const real* qin, real* qou
   return launch_a2b_ord4_batch(g, m, &qin, &qout, &k0, &k1, 1, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// What the reference LEAVES in the halo of its work fields (full contract only: pace_dsw_config_t.flags without
+// PACE_DSW_SKIP_DEAD_OUTPUTS).  DivergenceDamping iterates in place on the caller's divg_d, uc, vc over domains that reach
+// nt = nord - 1, ..., 0 points into the halo and fills the corner points of all three between the steps
+// (divergence_damping.py:579-600; corners.py:591-712, 987-1151), and TranslateD_SW compares uc, vc, divgd over the whole
+// storage (translate_d_sw.py:36-65).  The fused kernel above produces the tile's own points only; this kernel -- one workgroup
+// per level with nord > 0 -- replays the iteration LITERALLY on a band around the tile's edges (the whole halo and DDH_M points
+// inside: what the halo's final values depend on lies within two points of the edge), in the reference's order:
+//   A  vc on its domain from the divergence with corners filled in x, uc on its domain with corners filled in y
+//   B  fill_corners_dgrid(vc, uc, -1) -- and the y fill is what stays in the divergence's corner points
+//   C  the divergence on its domain from uc, vc (redo_divg_d)
+// with a barrier after each.  uc / vc are the caller's arrays, written OUTSIDE their compute windows only (inside, the fused
+// kernel has put the last pass's values, and a value needed there is formed again from the divergence: the window lies inside
+// every pass's domain and touches no corner point); the divergence ping-pongs between two scratch planes, `d0` holding the
+// divergence before the passes on the whole plane.  The band's innermost points go wrong by one point per pass (they read past
+// the band); nothing the halo depends on reaches them.  ~5 k points per level.
+// ------------------------------------------------------------------------------------------------
+#define DDH_M 4
+#define DDH_NT 1024
+__global__ void __launch_bounds__(DDH_NT)
+k_divdamp_halo_state(Geo g, Met m, real* __restrict__ d0, real* __restrict__ d1, real* __restrict__ divg_d, real* __restrict__ uc,
+                     real* __restrict__ vc, int k0, int nord) {
+  const int kk = (int)blockIdx.x + k0;
+  const long kb = (long)kk * g.sk;
+  const int tid = (int)threadIdx.x;
+  // the band as four rectangles: south rows, north rows, west and east columns between them
+  int lo = g.is + DDH_M, hi = g.ie + 1 - DDH_M;
+  const bool all = hi - lo < 1;  // a tile too small to have an inside: the whole plane
+  const int nsouth = all ? g.nj : lo, nnorth = all ? 0 : g.nj - 1 - hi, nmid = all ? 0 : hi - lo + 1;
+  const int nwest = all ? 0 : lo, neast = all ? 0 : g.ni - 1 - hi;
+  const int total = (nsouth + nnorth) * g.ni + nmid * (nwest + neast);
+  auto point = [&](int p, int& i, int& j) {
+    if (p < nsouth * g.ni) {
+      j = p / g.ni, i = p - j * g.ni;
+    } else if (p < (nsouth + nnorth) * g.ni) {
+      p -= nsouth * g.ni;
+      const int r = p / g.ni;
+      j = hi + 1 + r, i = p - r * g.ni;
+    } else {
+      p -= (nsouth + nnorth) * g.ni;
+      const int w = nwest + neast, r = p / w, c = p - r * w;
+      j = lo + r, i = c < nwest ? c : hi + 1 + (c - nwest);
+    }
+  };
+  real* U = uc + kb;
+  real* V = vc + kb;
+  const real* S = d0 + kb;
+  real* T = d1 + kb;
+  auto in_uwin = [&](int i, int j) { return i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je; };
+  auto in_vwin = [&](int i, int j) { return i >= g.is && i <= g.ie && j >= g.js && j <= g.je + 1; };
+  for (int it = 0; it < nord; ++it) {
+    const int nt = nord - (it + 1);
+    const bool fillc = it + 1 != nord;
+    auto at = [&](int i, int j) -> double { return S[IDX2(g, i, j)]; };
+    auto sx = [&](int i, int j) -> double {
+      if (fillc) remap_bgrid_x(g, i, j);
+      return at(i, j);
+    };
+    auto sy = [&](int i, int j) -> double {
+      if (fillc) remap_bgrid_y(g, i, j);
+      return at(i, j);
+    };
+    // ---- A: vc_from_divg on [is-nt-1, ie+nt+1] x [js-nt, je+nt+1], uc_from_divg on [is-nt, ie+nt+1] x [js-nt-1, je+nt+1]
+    for (int p = tid; p < total; p += DDH_NT) {
+      int i, j;
+      point(p, i, j);
+      const long c2 = IDX2(g, i, j);
+      if (i >= g.is - nt - 1 && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1 && !in_vwin(i, j))
+        V[c2] = (real)((sx(i + 1, j) - sx(i, j)) * m.divg_u[c2]);
+      if (i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt - 1 && j <= g.je + nt + 1 && !in_uwin(i, j))
+        U[c2] = (real)((sy(i, j + 1) - sy(i, j)) * m.divg_v[c2]);
+    }
+    __syncthreads();
+    // ---- B: fill_corners_dgrid(x = vc, y = uc, mysign = -1): every source lies outside the corner blocks (and outside the windows)
+    if (fillc && tid < 72) {
+      const int e = tid % 36, q = e / 9, a = 1 + (e % 9) % 3, b = 1 + (e % 9) / 3;
+      int di, dj, si, sj_;
+      double sgn;
+      if (tid < 36) {  // vc <- +-uc
+        if (q == 0) di = g.is - a, dj = g.js - b, sgn = -1.0, si = g.is - b, sj_ = g.js + a - 1;                   // SW
+        else if (q == 1) di = g.ie + a, dj = g.je + 1 + b, sgn = -1.0, si = g.ie + 1 + b, sj_ = g.je + 1 - a;      // NE
+        else if (q == 2) di = g.is - a, dj = g.je + 1 + b, sgn = 1.0, si = g.is - b, sj_ = g.je + 1 - a;           // NW
+        else di = g.ie + a, dj = g.js - b, sgn = 1.0, si = g.ie + 1 + b, sj_ = g.js + a - 1;                       // SE
+        V[IDX2(g, di, dj)] = (real)(sgn * (double)U[IDX2(g, si, sj_)]);
+      } else {  // uc <- +-vc
+        if (q == 0) di = g.is - a, dj = g.js - b, sgn = -1.0, si = g.is + b - 1, sj_ = g.js - a;                   // SW
+        else if (q == 1) di = g.ie + 1 + a, dj = g.je + b, sgn = -1.0, si = g.ie + 1 - b, sj_ = g.je + 1 + a;      // NE
+        else if (q == 2) di = g.is - a, dj = g.je + b, sgn = 1.0, si = g.is + b - 1, sj_ = g.je + 1 + a;           // NW
+        else di = g.ie + 1 + a, dj = g.js - b, sgn = 1.0, si = g.ie + 1 - b, sj_ = g.js - a;                       // SE
+        U[IDX2(g, di, dj)] = (real)(sgn * (double)V[IDX2(g, si, sj_)]);
+      }
+    }
+    __syncthreads();
+    // ---- C: redo_divg_d on [is-nt, ie+nt+1]^2; elsewhere the plane carries the state on (corner points: the y fill)
+    auto uval = [&](int i, int j) -> double {
+      const long c2 = IDX2(g, i, j);
+      return in_uwin(i, j) ? (at(i, j + 1) - at(i, j)) * m.divg_v[c2] : (double)U[c2];
+    };
+    auto vval = [&](int i, int j) -> double {
+      const long c2 = IDX2(g, i, j);
+      return in_vwin(i, j) ? (at(i + 1, j) - at(i, j)) * m.divg_u[c2] : (double)V[c2];
+    };
+    for (int p = tid; p < total; p += DDH_NT) {
+      int i, j;
+      point(p, i, j);
+      const long c2 = IDX2(g, i, j);
+      double d;
+      if (i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) {
+        const double ucm = uval(i, j - 1), uc0 = uval(i, j), vcm = vval(i - 1, j), vc0 = vval(i, j);
+        d = ucm - uc0 + vcm - vc0;
+        const bool ic = (i == g.is || i == g.ie + 1);
+        if (ic && j == g.js) d = d - ucm;
+        if (ic && j == g.je + 1) d = d + uc0;
+        d = d * m.rarea_c[c2];
+      } else {
+        d = sy(i, j);
+      }
+      T[c2] = (real)d;
+    }
+    __syncthreads();
+    const real* t = S;
+    S = T;
+    T = const_cast<real*>(t);
+  }
+  // the halo of the caller's divergence
+  for (int p = tid; p < total; p += DDH_NT) {
+    int i, j;
+    point(p, i, j);
+    if (i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1) continue;
+    divg_d[kb + IDX2(g, i, j)] = S[IDX2(g, i, j)];
+  }
+}
+
 // DivergenceDamping.__call__ (divergence_damping.py:482-632): second-order damping on the levels above `kstart` (the sponge
 // layers, nord = 0 there), `nonzero_nord` iterations of the divergence of the gradient of the divergence below, then
 // a2b_ord4 of the relative vorticity, the Smagorinsky term and the damped vorticity; ke += damping.  uc, vc and divg_d end as
@@ -1156,7 +1313,7 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
     // sponge levels + delpc = divg_d below them (copy_computeplus :578; whole planes, so that the fused kernel can take its
     // footprint from delpc), one launch
     hipLaunchKernelGGL(k_divdamp_low_and_copy, plane_grid(g, nk), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
-                       d2_bg_dev, dddmp, dt, divg_d, kstart);
+                       d2_bg_dev, dddmp, dt, divg_d, kstart, da);
   } else if (fused) {
     // the work fields are dead after d_sw (PACE_DSW_SKIP_DEAD_OUTPUTS): no copy -- the fused kernel reads the divergence where it
     // is and writes neither it nor uc / vc -- and the sponge levels are extra workgroups of the fused launch
@@ -1182,8 +1339,11 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
       sp.nstrips = 2 * (sp.nch_row + sp.nch_col) * nhigh;
     }
     hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(sp.nblocks + sp.nstrips + ntx * nty * nhigh)), dim3(DD_NT), 0, st, g, m,
-                       rel_vort_agrid, skip_dead ? divg_d : delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart,
+                       rel_vort_agrid, skip_dead ? divg_d : da, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart,
                        nonzero_nord, ntx, ntx * nty, skip_dead ? 0 : 1, sp);
+    // the full contract: the halo of divg_d, uc, vc as the reference's in-place passes leave it
+    if (!skip_dead && nonzero_nord > 0)
+      hipLaunchKernelGGL(k_divdamp_halo_state, dim3((unsigned)nhigh), dim3(DDH_NT), 0, st, g, m, da, db, divg_d, uc, vc, kstart, nonzero_nord);
   } else if (nhigh > 0) {
     const real* src = divg_d;
     real* bufs[2] = {da, db};
@@ -1301,7 +1461,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // ... and where the work fields are not asked for either, the divergence damping leaves `ke += damped vorticity` to that kernel
   // (it holds both at the tile's B-grid points): the damping then does not touch ke, 47 MB less, and it no longer depends on the
   // kinetic-energy kernel
-  const bool ke_by_consumer = winds_in_scalars && skip_dead && nk - kstart > 0;
+  // (the same predicate as launch_divergence_damping's `fused`: with the legacy A/B switch the damping adds to ke itself)
+  const bool ke_by_consumer = winds_in_scalars && skip_dead && nk - kstart > 0 && !legacy_divergence_damping();
   if (phases & 1) {
   if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
   } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
@@ -1366,6 +1527,11 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
       if ((rc = launch_transport(g, m, pt, crx, cry, xfx, yfx, nullptr, nullptr, W.fx, W.fy, cfg->hord_tm, nl, 2, 1, dp2, st))) return rc;
     }
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
+    }
+    // the full contract: the corner blocks of the four scalars as the transport's in-place corner copies leave them
+    if (!skip_dead) {
+      if (pingpong) hipLaunchKernelGGL(k_corner_blocks_x, dim3((unsigned)nk), dim3(256), 0, st, g, scalar_outs[0], scalar_outs[1], scalar_outs[2], scalar_outs[3]);
+      else hipLaunchKernelGGL(k_corner_blocks_x, dim3((unsigned)nk), dim3(256), 0, st, g, delp, pt, w, q_con);
     }
     return PACE_OK;
   };

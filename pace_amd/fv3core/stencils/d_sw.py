@@ -131,7 +131,7 @@ class DGridShallowWaterLagrangianDynamics(Operator):
             return []
         if self._spares is None:
             self._spares = []
-            for f in fields:
+            for f in fields[:4] + (tuple(fields[4:]) if self._wind_outputs else ()):  # (the winds' spares only where they are taken)
                 sp = self._quantity_factory.empty(f.dims, f.units)
                 sp.data[...] = f.data
                 self._spares.append(sp)

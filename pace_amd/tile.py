@@ -31,10 +31,39 @@ def window(n, di=0, dj=0, nk=None):
 
 
 def dsw_window(name, n, nk):
-    """Output windows of translate_d_sw.py:36-65 (x-interface / y-interface / centred variables)."""
-    di = 1 if name in ("mfx", "cx", "crx", "xfx", "v", "delpc", "uc", "divgd") else 0
-    dj = 1 if name in ("mfy", "cy", "cry", "yfx", "u", "delpc", "vc", "divgd") else 0
-    return window(n, di, dj, nk)
+    """The output windows of TranslateD_SW, exactly (translate_d_sw.py:36-65 with the dictionaries of
+    stencils/pace/stencils/testing/grid.py:288-382): `{}` = the whole domain, halo included ([isd, ied]^2 = N + 6 points each
+    way): delpc, delp, pt, w, q_con, ua, va, heat_source, diss_est; x3d / y3d_domain_dict (one more point along the staggered axis):
+    uc, v / vc, u; x3d_compute_domain_y / y3d_compute_domain_x: the Courant numbers and area fluxes; x3d / y3d_compute_dict: the mass
+    fluxes; default_dict_buffer_2d: divgd.  This is the window of the FULL contract (pace_dsw_config_t.flags == 0)."""
+    full = n + 6
+    if name in ("uc", "v"):
+        return (slice(0, full + 1), slice(0, full), slice(0, nk))
+    if name in ("vc", "u"):
+        return (slice(0, full), slice(0, full + 1), slice(0, nk))
+    if name in ("xfx", "crx", "cx"):
+        return (slice(3, 3 + n + 1), slice(0, full), slice(0, nk))
+    if name in ("yfx", "cry", "cy"):
+        return (slice(0, full), slice(3, 3 + n + 1), slice(0, nk))
+    if name == "mfx":
+        return window(n, 1, 0, nk)
+    if name == "mfy":
+        return window(n, 0, 1, nk)
+    if name == "divgd":
+        return (slice(0, full + 1), slice(0, full + 1), slice(0, nk))
+    return (slice(0, full), slice(0, full), slice(0, nk))
+
+
+DSW_DEAD = ("delpc", "divgd", "uc", "vc")  # unspecified under PACE_DSW_SKIP_DEAD_OUTPUTS (include/pace_hip.h)
+
+
+def dsw_live_window(name, n, nk):
+    """What a call with PACE_DSW_SKIP_DEAD_OUTPUTS specifies: as dsw_window, but the four transported scalars without the 3 x 3
+    corner blocks of the halo (the in-place corner copies of the reference's transport are not replayed: the halo update that
+    follows d_sw in AcousticDynamics overwrites them) -- their compute domain; DSW_DEAD not at all."""
+    if name in ("delp", "pt", "w", "q_con"):
+        return window(n, 0, 0, nk)
+    return dsw_window(name, n, nk)
 
 
 class Env:

@@ -11,7 +11,7 @@ import sys
 
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from pace_amd.tile import (DSW_ARGS, DSW_CFG, RIEM_ARGS, Env, compare, dsw_window, run_d_sw, run_riem3,  # noqa: E402,F401
+from pace_amd.tile import (DSW_ARGS, DSW_CFG, DSW_DEAD, RIEM_ARGS, Env, compare, dsw_live_window, dsw_window, run_d_sw, run_riem3,  # noqa: E402,F401
                            window)
 
 

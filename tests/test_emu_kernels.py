@@ -278,11 +278,21 @@ def check_dsw_contract_variants(res):
         assert op._pingpong, "the library must have taken the separate outputs here"
         for k in ref:  # every output of d_sw bit for bit, whole storage (halos included)
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
+    n = ref["delp"].shape[0] - 7
     for name in ("skip_dead", "skip_dead_overlapped"):
         got, _ = res[name]
         for k in ref:
-            if k not in ("delpc", "divgd", "uc", "vc"):  # (unspecified: include/pace_hip.h PACE_DSW_SKIP_DEAD_OUTPUTS)
-                assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
+            if k in ("delpc", "divgd", "uc", "vc"):  # (unspecified: include/pace_hip.h PACE_DSW_SKIP_DEAD_OUTPUTS)
+                continue
+            a, b = ref[k].copy(), got[k].copy()
+            if k in ("delp", "pt", "w", "q_con"):
+                # ... as are the 3 x 3 corner blocks of the scalars' halo: the full contract leaves the transport's in-place corner
+                # copy there (fvtp2d.py:262-345), this one the values that came in
+                for x in (a, b):
+                    for ci in (slice(0, 3), slice(n + 3, n + 6)):
+                        for cj in (slice(0, 3), slice(n + 3, n + 6)):
+                            x[ci, cj] = 0.0
+            assert np.array_equal(a, b, equal_nan=True), (name, k)
 
 
 def test_d_sw_separate_outputs_equal_in_place_emulated():
@@ -937,3 +947,44 @@ def test_dynamical_core_step_from_generated_inputs_emulated(emu_lib):
 
     fixes, outs = run_dycore_six_tiles(emu_lib, "cpu", generated="all")
     check_dycore_generated(fixes, outs)
+
+
+def test_two_emulation_libraries_in_one_process_do_not_share_symbols():
+    """the emulation libraries used to export their kernels' emulated `__shared__` statics as STB_GNU_UNIQUE
+    symbols, which the loader unifies process-wide even under RTLD_LOCAL -- `libpace_emu_canon.so` (8 x 8 tiles) and
+    `libpace_emu.so` (64 x 16) then shared LDS arrays of different sizes, and a test that ran after another library had been
+    loaded failed.  Now: `-fno-gnu-unique` and a version script that exports the C ABI only (pace_amd/csrc/exports.map).  Load
+    the canonical-tiling library FIRST, then the default one, and run DelnFlux (whose kernel `k_delnflux<...>` keeps its tile in
+    such a static) through both, in both orders of use: each equals the oracle bit for bit."""
+    import subprocess
+
+    from helpers import build_emu_canon
+    from oracle import ppm_transport
+    from pace_amd import _lib, synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import column_namelist_arrays
+    from pace_amd.fv3core.stencils.delnflux import DelnFlux
+
+    paths = [build_emu_canon(), build_emu()]
+    for p in paths:  # nothing but the C ABI is exported, nothing is GNU-unique
+        syms = subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True, check=True).stdout.split("\n")
+        kinds = {ln.split()[1] for ln in syms if len(ln.split()) == 3}
+        names = [ln.split()[2] for ln in syms if len(ln.split()) == 3]
+        assert "u" not in kinds and all(nm.startswith("pace_") for nm in names), p
+    libs = [_lib.Library(p) for p in paths]
+    n, nz = 24, 3
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    g = oracle_grid(m, n, nz)
+    col = column_namelist_arrays(DGridShallowWaterLagrangianDynamicsConfig(), nz)
+    fx0, fy0 = s["xfx"] * 0.5, s["yfx"] * 0.5
+    ref_fx, ref_fy = fx0.copy(), fy0.copy()
+    ppm_transport.delnflux(g, s["pt"].copy(), ref_fx, ref_fy, col["nord_v"], col["damp_vt"], float(m["da_min"]), mass=s["delp"])
+    for lib in libs + libs[::-1]:
+        env = Env(lib, "cpu", m, n, nz)
+        q, fx, fy, mass = env.q3(s["pt"]), env.q3(fx0), env.q3(fy0), env.q3(s["delp"])
+        op = DelnFlux(env.stencil_factory, env.qf, env.damping, env.grid_data.rarea, env.kq(col["nord_v"]), env.kq(col["damp_vt"]),
+                      grid_data=env.grid_data)
+        op(q, fx, fy, mass=mass)
+        assert np.array_equal(fx.numpy()[window(n, 1, 0, nz)], ref_fx[window(n, 1, 0, nz)]), lib.path
+        assert np.array_equal(fy.numpy()[window(n, 0, 1, nz)], ref_fy[window(n, 0, 1, nz)]), lib.path
