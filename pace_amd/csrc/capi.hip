@@ -34,14 +34,13 @@ static inline int geom_check(const pace_geom_t* g) {
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 // PACE_LEGACY_COLUMN_SOLVERS=1 selects the round-1 thread-per-column kernels of k_riem3.hip (kept for more than 128 layers and
-// for A/B measurements); read once.
+// for A/B measurements, and the form that walks a column's levels IN THE REFERENCE'S ORDER: the whole acoustic loop then agrees with
+// the oracle to w 6e-9 / diss_estd 1e-7 where the scans' re-association gives 4e-7 / 2e-6 -- tests/helpers.py ACOUSTIC_TOL).
 #include <cstdlib>
 static bool legacy_column_solvers() {
-  static const bool on = [] {
-    const char* e = getenv("PACE_LEGACY_COLUMN_SOLVERS");
-    return e != nullptr && e[0] == '1';
-  }();
-  return on;
+  // (read at every call: tests switch between the two forms within one process)
+  const char* e = getenv("PACE_LEGACY_COLUMN_SOLVERS");
+  return e != nullptr && e[0] == '1';
 }
 
 extern "C" {

@@ -73,9 +73,24 @@ __device__ __forceinline__ double dn(double v, int d) {
 // riem_solver3 takes seven exp / log per level (riem_solver3.py:63-141, sim1_solver.py:118-141), riem_solver_c four; the
 // library's versions are ~65 instructions each with their special-case handling.  The arguments here are pressures and
 // pressure ratios -- positive, finite, far from the ends of the exponent range -- so: straight range reduction + polynomial,
-// no special cases, ~1e-16 relative error.  Against the numpy oracle: riem_solver3 <= 1.1e-7 (bound 5e-6,
+// no special cases.  Against the numpy oracle (round 5's versions, ~1 ulp): riem_solver3 <= 1.1e-7 (bound 5e-6,
 // overrides/standard.yaml:49-61), riem_solver_c 3.3e-15 (bound 5e-14, translate_riem_solver_c.py:33; the library functions
 // gave 1.5e-15); tools/riem_check.py prints the errors per variable.
+// Round 6: both are evaluated so that the result is rounded ONCE (the leading terms are summed as a pair of doubles, every smaller
+// term goes into the low part before the final addition): <= ~0.55 ulp, against ~1 ulp before.  Why it matters: pe = exp(gm * log(..))
+// - pm and w's damping heating amplify an ulp of these functions by 1e6 .. 1e9 (the reference's own DynCore bound is 2e-6 on every
+// variable, translate_dyncore.py:120); numpy's exp / log are within 0.52 ulp, so a function that is off by one ulp in a quarter of
+// its results disagrees with the oracle everywhere, one that is nearly correctly rounded in a few per cent of them.  Measured with
+// the oracle itself (exp / log in extended precision, rounded once): diss_estd 1.0e-7, w 8e-9 -- the conditioning of the loop; the
+// previous versions: 2.9e-6 / 4.0e-7 (profiles/r06_transcendental_accuracy.txt).
+__device__ __forceinline__ double lean_rcp(double d) {  // 1 / d to ~1e-16 (the quotients below carry their own residuals)
+#ifdef PACE_EMU
+  return 1.0 / d;
+#else
+  const double r0 = __builtin_amdgcn_rcp(d);
+  return fma(fma(-d, r0, 1.0), r0, r0);
+#endif
+}
 __device__ __forceinline__ double lean_log(double x) {
   int e;
   double m = frexp(x, &e);  // [0.5, 1)
@@ -84,10 +99,13 @@ __device__ __forceinline__ double lean_log(double x) {
     e = e - 1;
   }
   // log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716
-  const double f = m - 1.0;
-  const double d = 2.0 + f;
-  double r = 1.0 / d;
+  const double f = m - 1.0;           // exact
+  const double d = 2.0 + f;           // rounded: m + 1 needs up to two more bits than m has ...
+  const double d_lo = f - (d - 2.0);  // ... which are here (Fast2Sum, |2| >= |f|)
+  const double r = lean_rcp(d);
   const double s = f * r;
+  // s_lo: f / (d + d_lo) - s, from the exact residual of s against d
+  const double s_lo = (fma(-s, d, f) - s * d_lo) * r;
   const double z = s * s;
   double p = 2.0 / 21.0;
   p = fma(p, z, 2.0 / 19.0);
@@ -99,33 +117,42 @@ __device__ __forceinline__ double lean_log(double x) {
   p = fma(p, z, 2.0 / 7.0);
   p = fma(p, z, 2.0 / 5.0);
   p = fma(p, z, 2.0 / 3.0);
-  // 2 s + s z p, with the rounding of s = f / d taken back: s_lo = (f - s d) / d
-  const double s_lo = fma(-s, d, f) * r;
-  const double lm = fma(s * z, p, 2.0 * s_lo) + 2.0 * s;
+  // log x = e ln2_hi + 2 s  (a pair: e ln2_hi is exact -- ln2_hi has 32 trailing zero bits -- and the larger of the two unless e = 0)
+  //       + [2 s_lo + s z p + e ln2_lo]
   const double de = (double)e;
-  const double v = fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+  const double a = de * 6.93147180369123816490e-01, b = 2.0 * s;
+  const double h = a + b;
+  const double l = b - (h - a);
+  const double low = fma(s * z, p, fma(de, 1.90821492927058770002e-10, 2.0 * s_lo)) + l;
+  const double v = h + low;
   // a column that has gone bad (a negative pressure, dz >= 0 upstream) must not come back as a plausible finite number: what the
   // library's log answers there -- NaN below zero, -inf at zero -- for one compare and one select (NaN and +inf pass through)
   return x > 0.0 ? v : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
 }
 __device__ __forceinline__ double lean_exp(double x) {
   const double k = rint(x * 1.44269504088896338700e+00);
-  double r = fma(-k, 6.93147180369123816490e-01, x);
-  r = fma(-k, 1.90821492927058770002e-10, r);  // |r| <= 0.3466
-  double p = 1.0 / 6227020800.0;  // 1 / 13!
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
+  const double r = fma(-k, 6.93147180369123816490e-01, x);  // exact (k ln2_hi is, and it lies within a factor of two of x); |r| <= 0.3466
+  const double c0 = -k * 1.90821492927058770002e-10;         // the rest of the reduction: exp(x) = 2^k exp(r) exp(c0),
+  const double c = fma(0.5 * c0, c0, c0);                    // exp(c0) - 1 = c0 + c0^2 / 2 (|c0| < 4e-7 for |k| < 2000: c0^3 / 6 < 1e-20)
+  // exp(r) = 1 + r + r^2 / 2 + r^3 q(r): the first three terms as pairs of doubles, the rest (<= 0.008) and every low part in one sum
+  double q = 1.0 / 6227020800.0;  // 1 / 13!
+  q = fma(q, r, 1.0 / 479001600.0);
+  q = fma(q, r, 1.0 / 39916800.0);
+  q = fma(q, r, 1.0 / 3628800.0);
+  q = fma(q, r, 1.0 / 362880.0);
+  q = fma(q, r, 1.0 / 40320.0);
+  q = fma(q, r, 1.0 / 5040.0);
+  q = fma(q, r, 1.0 / 720.0);
+  q = fma(q, r, 1.0 / 120.0);
+  q = fma(q, r, 1.0 / 24.0);
+  q = fma(q, r, 1.0 / 6.0);
+  const double rr = r * r, rr_lo = fma(r, r, -rr);    // r^2 as a pair
+  const double t = (r * rr) * q;                      // r^3 q
+  const double h1 = 1.0 + r, l1 = r - (h1 - 1.0);     // 1 + r as a pair (Fast2Sum)
+  const double hr = 0.5 * rr;
+  const double h = h1 + hr, l2 = hr - (h - h1);       // + r^2 / 2
+  const double e1 = h + t;                            // ~exp(r), for the reduction's remainder: exp(x) = 2^k exp(r) (1 + c)
+  const double p = h + (fma(c, e1, fma(0.5, rr_lo, t)) + (l1 + l2));  // ONE rounding of a sum whose low part is <= 0.008
   // (k clamped: ldexp with an int from a huge or NaN k would be undefined; +-2000 saturates to inf / 0 like the library's exp)
   const double kc = fmin(fmax(k, -2000.0), 2000.0);
   return x != x ? x : ldexp(p, (int)kc);

@@ -107,12 +107,19 @@ def acoustic_fixture(t):
     return fix
 
 
-# Per-variable bounds of the whole-AcousticDynamics comparisons (GPU and emulation; reference metric, bands above).  Measured on
-# the GPU (profiles/r02_acoustic_c12_gpu_errors.json): masses / temperatures / pressures <= 1.1e-15, the A-grid winds 1.4e-11,
-# the mass and Courant accumulators 1e-12, delz 4e-13, heat_source 3e-9, u / v 1.5e-8, omga 8e-8, vc 1.5e-7, w 4e-7,
-# diss_estd 2.3e-6.  What the vertical solvers feed gets the reference's own Riem_Solver3 bound (5e-6,
-# overrides/standard.yaml:49-61); the rest is held two to three orders above what is measured.
-ACOUSTIC_TOL = {"w": 5e-6, "omga": 5e-6, "diss_estd": 5e-6, "uc": 5e-6, "vc": 5e-6, "u": 1e-6, "v": 1e-6, "heat_source": 1e-6,
+# Bounds of the whole-AcousticDynamics comparisons (GPU and emulation; reference metric, bands above): the reference's own DynCore
+# bound, 2e-6 for EVERY variable (translate_dyncore.py:120) is the ceiling; what is measured far below it is held two to three
+# orders above the measurement (GPU, profiles/r06_acoustic_c12_gpu_errors.json: masses / temperatures / pressures <= 1.1e-15, the
+# A-grid winds 1.4e-11, the accumulators 1e-12, delz 4e-13, heat_source 3e-9, u / v 1.5e-8, omga 8e-8, vc 1.3e-7, w 4e-7).
+# The ONE variable not held to 2e-6 is diss_estd (measured 2.2e-6 .. 2.9e-6): w's damping heating of THIS fixture amplifies an ulp of
+# the column solver's operands by ~1e10.  That is a property of the loop, not of the kernels: the numpy oracle ITSELF moves by
+# diss_estd 1.35e-6 / w 1.7e-7 when only its two column sums of the interface pressures are formed in another order (extended
+# precision, rounded once per level: <= 1 ulp away; tests/test_oracle_golden.py::test_loop_conditioning_of_diss_estd), and the
+# device forms those sums AND the two tridiagonal sweeps as parallel scans over sixteen lanes (k_riem3f.hip).  With the sequential
+# legacy solvers (PACE_LEGACY_COLUMN_SOLVERS=1, bit-identical arithmetic order) the same test measures diss_estd 1.0e-7, w 5.6e-9 --
+# exactly what the oracle gives with exp / log evaluated in extended precision.  Round 6 took the solvers' own exp / log from
+# ~1 ulp to <= 0.55 ulp (2.9e-6 -> 2.2e-6); the rest is re-association, which no parallel column solver avoids.
+ACOUSTIC_TOL = {"w": 2e-6, "omga": 2e-6, "diss_estd": 3e-6, "uc": 2e-6, "vc": 2e-6, "u": 1e-6, "v": 1e-6, "heat_source": 1e-6,
                 "ua": 1e-8, "va": 1e-8, "delz": 1e-10, "mfxd": 1e-9, "mfyd": 1e-9, "cxd": 1e-9, "cyd": 1e-9}
 ACOUSTIC_TOL_DEFAULT = 1e-12  # delp, pt, pe, pk, peln, q_con
 
@@ -656,13 +663,13 @@ def dycore_errors(fix, out, n=12):
 
 # (measured on the GPU, profiles/r02_dycore_c12_gpu_errors.json: pressures 1e-15, delp / pt / pkz / tracers <= 1.5e-13, delz 4e-13,
 # accumulators 5e-10, u / v / va 1e-8, w 3e-7, omga 8e-7; default bound of check_dycore for everything not listed: 1e-9 -> 1e-11)
-DYCORE_TOL = {"w": 5e-6, "omga": 5e-6, "u": 1e-6, "v": 1e-6, "ua": 1e-6, "va": 1e-6, "delz": 1e-10, "mfxd": 1e-7, "mfyd": 1e-7,
+DYCORE_TOL = {"w": 2e-6, "omga": 2e-6, "u": 1e-6, "v": 1e-6, "ua": 1e-6, "va": 1e-6, "delz": 1e-10, "mfxd": 1e-7, "mfyd": 1e-7,
               "cxd": 1e-7, "cyd": 1e-7}
 
 
 def check_dycore(fixes, outs, default=1e-11):
-    """Tolerances: the acoustic loop's (5e-6 = the reference's own Riem_Solver3 bound for what the vertical solver feeds, see
-    test_acoustic_dynamics_six_tiles_emulated) carried through tracer advection, remapping (reference bound 2e-8) and the
+    """Tolerances: the acoustic loop's (2e-6 = the reference's own DynCore bound, translate_dyncore.py:120, see ACOUSTIC_TOL)
+    carried through tracer advection, remapping (reference bound 2e-8) and the
     final adjustments; `default` for everything else (masses, temperatures, tracers, pressures): 1e-11 after one remapping step
     (measured <= 1.5e-13), 1e-9 for the k_split = 2 run (two remapping steps: the condensates reach 3e-10)."""
     worst = {}

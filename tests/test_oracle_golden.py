@@ -343,3 +343,49 @@ def test_lagrangian_to_eulerian_order_10_oracle_against_reference_run():
         else:
             kk = km + 1 if name in ("pe", "peln", "pk") else km
             assert np.array_equal(got[win][:, :, :kk], d[key][win][:, :, :kk]), name
+
+
+def test_loop_conditioning_of_diss_estd():
+    """Why helpers.ACOUSTIC_TOL holds diss_estd to 3e-6 and not to the reference's DynCore bound of 2e-6 (translate_dyncore.py:120):
+    the ORACLE ITSELF, on the reference run's inputs, moves by more than 1e-6 in diss_estd when nothing but the ORDER of two
+    additions per level changes -- the column sums of the interface pressures (riem_solver3.py:63-81) accumulated in extended
+    precision and rounded once per level, which leaves every pressure within an ulp of the sequential double sum.  Any column
+    solver that does not walk the 79 levels one after the other (the device's scans over sixteen lanes) re-associates exactly
+    these sums.  Everything else stays far inside 2e-6 (w 1.7e-7, omga 5.6e-8, vc 8e-8)."""
+    import inspect
+
+    from helpers import DSW_CFG, acoustic_errors, acoustic_fixture, golden, oracle_grid
+
+    import oracle.vertical as V
+    from oracle import dyn_core
+
+    src = inspect.getsource(V.riem_solver3)
+    old_g = "            pg[W + (k,)] = pg[W + (k - 1,)] + dm[W + (k - 1,)] * (1.0 - q_con[W + (k - 1,)])\n"
+    old_p = "            p_int[W + (k,)] = p_int[W + (k - 1,)] + dm[W + (k - 1,)]\n"
+    loop = "        for k in range(1, K):\n"
+    assert old_g in src and old_p in src and loop in src
+    src = src.replace(old_g, "            _g = _g + (dm[W + (k - 1,)] * (1.0 - q_con[W + (k - 1,)])).astype(np.longdouble)\n"
+                             "            pg[W + (k,)] = _g.astype(np.float64)\n")
+    src = src.replace(old_p, "            _p = _p + dm[W + (k - 1,)].astype(np.longdouble)\n            p_int[W + (k,)] = _p.astype(np.float64)\n")
+    src = src.replace(loop, "        _g = np.full(pg[W + (0,)].shape, ptop, dtype=np.longdouble)\n        _p = _g.copy()\n" + loop, 1)
+    original = V.riem_solver3
+    try:
+        exec(src, V.__dict__)  # (oracle.dyn_core calls vertical.riem_solver3 through the module)
+        n, nz = 12, 79
+        fixes = [acoustic_fixture(t) for t in range(6)]
+        grids = [oracle_grid({k[5:]: v for k, v in fx.items() if k.startswith("grid_")}, n, nz) for fx in fixes]
+        states = [{k[3:]: v.copy() for k, v in fx.items() if k.startswith("in_") and k != "in_cappa"} for fx in fixes]
+        cappas = [fx["in_cappa"].copy() for fx in fixes]
+        col = {k: v for k, v in golden("column_namelist_c12.npz").items()}
+        cfg = dict(DSW_CFG, p_fac=0.05, rf_cutoff=3000.0, tau=10.0, delt_max=0.002, hord_tm=6)
+        tmp = dyn_core.acoustic_dynamics(grids, col, cfg, states, cappas, float(fixes[0]["timestep"]), int(fixes[0]["n_split"]), n, nz)
+    finally:
+        V.riem_solver3 = original
+    worst = {}
+    for t in range(6):
+        out = dict(states[t])
+        out["heat_source"] = tmp[t].heat_source
+        for k, e in acoustic_errors(fixes[t], out).items():
+            worst[k] = max(worst.get(k, 0.0), e)
+    assert worst["diss_estd"] > 1e-6, worst  # the oracle against itself: at the reference's bound already
+    assert all(e < 2e-6 for k, e in worst.items() if k != "diss_estd") and worst["delp"] < 1e-15, worst
