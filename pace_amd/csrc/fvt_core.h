@@ -380,7 +380,9 @@ struct FvtTile {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int gi = ilo + 2 * pc.lc + e;
-          if (pc.own(p) && (rowout || gi < g.is || gi > g.ie)) STG(halo_out, pc.off[p] + (unsigned)(RB * e)) = e == 0 ? v[p].x : v[p].y;
+          // (a corner tile's 3 x 3 corner block is written below: what the transport's in-place corner copies leave there)
+          const bool corner_cell = RC && rowout && (gi < g.is || gi > g.ie);
+          if (pc.own(p) && (rowout || gi < g.is || gi > g.ie) && !corner_cell) STG(halo_out, pc.off[p] + (unsigned)(RB * e)) = e == 0 ? v[p].x : v[p].y;
         }
       }
     }
@@ -402,9 +404,14 @@ struct FvtTile {
       }
       if (tid < 9) {  // ... and what copy_corners_x puts there, for the x sweeps
         const int b = tid / 3, a = tid - b * 3;
-        int ri = (west ? g.is - 3 : g.ie + 1) + a, rj = (south ? g.js - 3 : g.je + 1) + b;
+        const int di = (west ? g.is - 3 : g.ie + 1) + a, dj = (south ? g.js - 3 : g.je + 1) + b;
+        int ri = di, rj = dj;
         remap_agrid_x(g, ri, rj);
-        L.sqc[tid] = LDG(q, (unsigned)(rj * sj8 + ri * RB));
+        const real cv = LDG(q, (unsigned)(rj * sj8 + ri * RB));
+        L.sqc[tid] = cv;
+        // ... which is also what the reference LEAVES in q's corner block: the y copy, then the x copy, in place (fvtp2d.py:262-345),
+        // nothing after it -- TranslateD_SW compares the scalars over the whole storage (translate_d_sw.py:36-65)
+        if (halo_out) STG(halo_out, (unsigned)(dj * sj8 + di * RB)) = cv;
       }
     }
   }

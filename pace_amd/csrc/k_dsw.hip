@@ -696,10 +696,13 @@ __device__ __forceinline__ void divdamp_point(const Geo& g, const Met& m, const 
 template <int TI, int TJ, int MODE>
 __device__ __forceinline__ void
 divdamp_tile(double (*sbuf)[DD_PLANE], int i0, int i1, int j0, int j1, int kk, const Geo& g, const Met& m,
-             const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d, real* __restrict__ vort_b,
+             const real* __restrict__ wk, const real* din, real* divg_d, real* __restrict__ vort_b,
              real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out, const real* __restrict__ d2_bg, double dddmp,
              double dd8, double absdt, int nord, bool full) {
-  // full == false (PACE_DSW_SKIP_DEAD_OUTPUTS): divg_d, uc_out, vc_out are not written -- din may then be divg_d itself
+  // The divergence before the passes: `din` at the tile's own B-grid points [is, ie+1]^2, divg_d in the halo.  full (the
+  // reference's contract): din = delpc, which the caller has set to the divergence there (copy_computeplus), and divg_d is
+  // WRITTEN at the tile's points only -- no workgroup reads what another one writes.  full == false
+  // (PACE_DSW_SKIP_DEAD_OUTPUTS): divg_d, uc_out, vc_out are not written; din is divg_d itself.
   constexpr int W = TI + 6, H = TJ + 6, NE = (W * H + DD_NT - 1) / DD_NT;
   static_assert((MODE == 2 ? 2 : 1) * W * H <= DD_PLANE, "the footprint (a strip's: twice) fits an LDS plane");
   static_assert(NE <= 32, "one bit per footprint point of a thread");
@@ -715,7 +718,8 @@ divdamp_tile(double (*sbuf)[DD_PLANE], int i0, int i1, int j0, int j1, int kk, c
     const int gi = ilo + ii, gj = jlo + jj;
     const bool ok = e < W * H && gi < g.ni && gj < g.nj;
     const long c2 = ok ? IDX2(g, gi, gj) : 0;
-    dreg[t] = din[kb + c2];
+    const bool own_pt = gi >= g.is && gi <= g.ie + 1 && gj >= g.js && gj <= g.je + 1;
+    dreg[t] = (own_pt ? din : (const real*)divg_d)[kb + c2];
     if (!ok) dreg[t] = 0.0;
     // (the widest pass reaches two points beyond the own points: nord <= 3)
     const bool pl = ok && gi >= i0 - 2 && gi <= i1 + 2 && gj >= j0 - 2 && gj <= j1 + 2 &&
@@ -851,7 +855,7 @@ divdamp_tile(double (*sbuf)[DD_PLANE], int i0, int i1, int j0, int j1, int kk, c
 }
 
 __global__ void __launch_bounds__(DD_NT) DD_ATTR
-k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* __restrict__ din, real* __restrict__ divg_d,
+k_divdamp_fused(Geo g, Met m, const real* __restrict__ wk, const real* din, real* divg_d,
                 real* __restrict__ vort_b, real* __restrict__ ke, real* __restrict__ uc_out, real* __restrict__ vc_out,
                 const real* __restrict__ d2_bg, double dddmp, double dd8, double absdt, int k0, int nord, int ntx, int ntiles, int full_,
                 DdSponge sp) {
@@ -1013,17 +1017,16 @@ __global__ void __launch_bounds__(256)
 k_divdamp_low_and_copy(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ ua,
                        const real* __restrict__ va, const real* __restrict__ uc, const real* __restrict__ vc,
                        real* __restrict__ delpc, real* __restrict__ vort_b, real* __restrict__ ke, const real* __restrict__ d2_bg,
-                       double dddmp, double dt, const real* __restrict__ divg_d, int kstart, real* __restrict__ dcopy) {
+                       double dddmp, double dt, const real* __restrict__ divg_d, int kstart) {
   PLANE_IJK(g);
   const long c = IDX3(g, i, j, k);
   const bool own = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1;
   if (k >= kstart) {
     // copy_computeplus (divergence_damping.py:578): delpc = divg_d on the B-grid points of the tile -- delpc's halo stays what c_sw
-    // left there (TranslateD_SW compares it on the whole storage); the whole plane, halo included, goes to the scratch field the
-    // fused kernel takes its footprints from (it overwrites divg_d while neighbouring tiles still read theirs)
-    const double d = divg_d[c];
-    if (own) delpc[c] = d;
-    dcopy[c] = d;
+    // left there (TranslateD_SW compares it on the whole storage).  The fused kernel then takes the divergence before the passes from
+    // delpc at the tile's points and from divg_d in the halo: it writes divg_d at the tile's points only, so nobody reads what
+    // another workgroup writes
+    if (own) delpc[c] = divg_d[c];
     return;
   }
   if (!own) return;
@@ -1177,55 +1180,241 @@ int launch_a2b_ord4_tiled(const Geo& g, const Met& m, const real* qin, real* qou
 // divergence before the passes on the whole plane.  The band's innermost points go wrong by one point per pass (they read past
 // the band); nothing the halo depends on reaches them.  ~5 k points per level.
 // ------------------------------------------------------------------------------------------------
-#define DDH_M 4
+// Two forms.  LDS (tiles up to C200): the band's divergence (two planes) and uc / vc live in LDS for the whole kernel; a thread owns
+// at most four band points and keeps, per point, the LDS places of its neighbours -- plain and with the corner fills applied as
+// index maps --, its five metric values and a word of flags (which pass's domains it lies in, which windows) in registers, so a
+// step is straight-line code on LDS: ~12 us at C192 x 76 levels (the first version, a literal walk through memory: 68 us).
+// Memory form (larger tiles; PACE_DDH_MEM=1): the planes are the two scratch fields, uc / vc the caller's arrays.
+#define DDH_M 2                     // band depth inside the tile's edge, LDS form (the memory form keeps 4)
+#define DDH_MM 4
 #define DDH_NT 1024
-__global__ void __launch_bounds__(DDH_NT)
-k_divdamp_halo_state(Geo g, Met m, real* __restrict__ d0, real* __restrict__ d1, real* __restrict__ divg_d, real* __restrict__ uc,
-                     real* __restrict__ vc, int k0, int nord) {
-  const int kk = (int)blockIdx.x + k0;
-  const long kb = (long)kk * g.sk;
-  const int tid = (int)threadIdx.x;
-  // the band as four rectangles: south rows, north rows, west and east columns between them
-  int lo = g.is + DDH_M, hi = g.ie + 1 - DDH_M;
-  const bool all = hi - lo < 1;  // a tile too small to have an inside: the whole plane
-  const int nsouth = all ? g.nj : lo, nnorth = all ? 0 : g.nj - 1 - hi, nmid = all ? 0 : hi - lo + 1;
-  const int nwest = all ? 0 : lo, neast = all ? 0 : g.ni - 1 - hi;
-  const int total = (nsouth + nnorth) * g.ni + nmid * (nwest + neast);
-  auto point = [&](int p, int& i, int& j) {
-    if (p < nsouth * g.ni) {
-      j = p / g.ni, i = p - j * g.ni;
-    } else if (p < (nsouth + nnorth) * g.ni) {
-      p -= nsouth * g.ni;
-      const int r = p / g.ni;
-      j = hi + 1 + r, i = p - r * g.ni;
+#define DDH_PP 4                    // points per thread (LDS form)
+#define DDH_SLOTS (DDH_PP * DDH_NT)
+struct DdhBand {  // the band as four rectangles: south rows, north rows, west and east columns between them
+  int ni, nj, lo, hi, nsouth, nnorth, nmid, nwest, neast, total;
+  __host__ __device__ DdhBand(const Geo& g, int depth) {
+    ni = g.ni, nj = g.nj;
+    lo = g.is + depth, hi = g.ie + 1 - depth;
+    const bool all = hi - lo < 1;  // a tile too small to have an inside: the whole plane
+    nsouth = all ? g.nj : lo, nnorth = all ? 0 : g.nj - 1 - hi, nmid = all ? 0 : hi - lo + 1;
+    nwest = all ? 0 : lo, neast = all ? 0 : g.ni - 1 - hi;
+    total = (nsouth + nnorth) * g.ni + nmid * (nwest + neast);
+  }
+  __device__ __forceinline__ void point(int p, int& i, int& j) const {
+    if (p < nsouth * ni) {
+      j = p / ni, i = p - j * ni;
+    } else if (p < (nsouth + nnorth) * ni) {
+      p -= nsouth * ni;
+      const int r = p / ni;
+      j = hi + 1 + r, i = p - r * ni;
     } else {
-      p -= (nsouth + nnorth) * g.ni;
+      p -= (nsouth + nnorth) * ni;
       const int w = nwest + neast, r = p / w, c = p - r * w;
       j = lo + r, i = c < nwest ? c : hi + 1 + (c - nwest);
     }
-  };
+  }
+  // the slot of (i, j); `none` outside the band (or the storage)
+  __device__ __forceinline__ int slot(int i, int j, int none) const {
+    if (i < 0 || i >= ni || j < 0 || j >= nj) return none;
+    if (j < nsouth) return j * ni + i;
+    if (j > hi) return (nsouth + (j - hi - 1)) * ni + i;
+    if (i < nwest) return (nsouth + nnorth) * ni + (j - lo) * (nwest + neast) + i;
+    if (i > hi) return (nsouth + nnorth) * ni + (j - lo) * (nwest + neast) + nwest + (i - hi - 1);
+    return none;
+  }
+};
+// fill_corners_dgrid(x = vc, y = uc, mysign = -1), entry e of 72 (corners.py:987-1151; oracle/corner_ops.py): destination, source, sign;
+// e < 36: vc <- sgn * uc, else uc <- sgn * vc.  Every source lies outside the corner blocks and outside the windows.
+__device__ __forceinline__ void ddh_dgrid_entry(const Geo& g, int e72, int& di, int& dj, int& si, int& sj_, double& sgn) {
+  const int e = e72 % 36, q = e / 9, a = 1 + (e % 9) % 3, b = 1 + (e % 9) / 3;
+  if (e72 < 36) {
+    if (q == 0) di = g.is - a, dj = g.js - b, sgn = -1.0, si = g.is - b, sj_ = g.js + a - 1;                   // SW
+    else if (q == 1) di = g.ie + a, dj = g.je + 1 + b, sgn = -1.0, si = g.ie + 1 + b, sj_ = g.je + 1 - a;      // NE
+    else if (q == 2) di = g.is - a, dj = g.je + 1 + b, sgn = 1.0, si = g.is - b, sj_ = g.je + 1 - a;           // NW
+    else di = g.ie + a, dj = g.js - b, sgn = 1.0, si = g.ie + 1 + b, sj_ = g.js + a - 1;                       // SE
+  } else {
+    if (q == 0) di = g.is - a, dj = g.js - b, sgn = -1.0, si = g.is + b - 1, sj_ = g.js - a;                   // SW
+    else if (q == 1) di = g.ie + 1 + a, dj = g.je + b, sgn = -1.0, si = g.ie + 1 - b, sj_ = g.je + 1 + a;      // NE
+    else if (q == 2) di = g.is - a, dj = g.je + b, sgn = 1.0, si = g.is + b - 1, sj_ = g.je + 1 + a;           // NW
+    else di = g.ie + 1 + a, dj = g.js - b, sgn = 1.0, si = g.ie + 1 - b, sj_ = g.js - a;                       // SE
+  }
+}
+
+__global__ void __launch_bounds__(DDH_NT)
+k_divdamp_halo_state_lds(Geo g, Met m, const real* __restrict__ delpc, real* divg_d, real* __restrict__ uc, real* __restrict__ vc, int k0,
+                         int nord) {
+  __shared__ double sda[DDH_SLOTS + 1], sdb[DDH_SLOTS + 1], su[DDH_SLOTS + 1], sv[DDH_SLOTS + 1];  // (+ 1: the place of "no such point")
+  constexpr int NONE = DDH_SLOTS;
+  const int kk = (int)blockIdx.x + k0;
+  const long kb = (long)kk * g.sk;
+  const int tid = (int)threadIdx.x;
+  const DdhBand band(g, DDH_M);
+  const int total = band.total;
+  // what is stored in a field is rounded to the field's type (float32 build), as the passes through memory do
+  auto stored = [](double x) { return (double)(real)x; };
+  enum { F_VD = 0, F_UD = 3, F_DD = 6, F_VW = 9, F_VWM = 10, F_UW = 11, F_UWM = 12, F_CS = 13, F_CN = 14, F_OK = 15, F_OWN = 16 };
+  int c2_[DDH_PP], sE_[DDH_PP], sW_[DDH_PP], sN_[DDH_PP], sS_[DDH_PP], xE_[DDH_PP], xC_[DDH_PP], yN_[DDH_PP], yC_[DDH_PP];
+  unsigned fl_[DDH_PP];
+  double gu0_[DDH_PP], gum_[DDH_PP], gv0_[DDH_PP], gvm_[DDH_PP], ra_[DDH_PP];
+  if (tid == 0) sda[NONE] = sdb[NONE] = su[NONE] = sv[NONE] = 0.0;
+#pragma unroll
+  for (int t = 0; t < DDH_PP; ++t) {
+    const int p = tid + DDH_NT * t;
+    int i = 0, j = 0;
+    const bool ok = p < total;
+    if (ok) band.point(p, i, j);
+    const int c2 = (int)IDX2(g, i, j);
+    c2_[t] = c2;
+    sE_[t] = band.slot(i + 1, j, NONE), sW_[t] = band.slot(i - 1, j, NONE), sN_[t] = band.slot(i, j + 1, NONE), sS_[t] = band.slot(i, j - 1, NONE);
+    {
+      int a = i + 1, b = j;
+      remap_bgrid_x(g, a, b);
+      xE_[t] = band.slot(a, b, NONE);
+      a = i, b = j;
+      remap_bgrid_x(g, a, b);
+      xC_[t] = band.slot(a, b, NONE);
+      a = i, b = j + 1;
+      remap_bgrid_y(g, a, b);
+      yN_[t] = band.slot(a, b, NONE);
+      a = i, b = j;
+      remap_bgrid_y(g, a, b);
+      yC_[t] = band.slot(a, b, NONE);
+    }
+    auto in_uwin = [&](int a, int b) { return a >= g.is && a <= g.ie + 1 && b >= g.js && b <= g.je; };
+    auto in_vwin = [&](int a, int b) { return a >= g.is && a <= g.ie && b >= g.js && b <= g.je + 1; };
+    unsigned f = 0;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      f |= (unsigned)(i >= g.is - nt - 1 && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) << (F_VD + nt);
+      f |= (unsigned)(i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt - 1 && j <= g.je + nt + 1) << (F_UD + nt);
+      f |= (unsigned)(i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) << (F_DD + nt);
+    }
+    const bool ic = (i == g.is || i == g.ie + 1);
+    const bool own = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1;
+    f |= (unsigned)in_vwin(i, j) << F_VW | (unsigned)in_vwin(i - 1, j) << F_VWM | (unsigned)in_uwin(i, j) << F_UW | (unsigned)in_uwin(i, j - 1) << F_UWM;
+    f |= (unsigned)(ic && j == g.js) << F_CS | (unsigned)(ic && j == g.je + 1) << F_CN | (unsigned)ok << F_OK | (unsigned)own << F_OWN;
+    fl_[t] = f;
+    gu0_[t] = m.divg_u[c2], gv0_[t] = m.divg_v[c2], ra_[t] = m.rarea_c[c2];
+    gum_[t] = m.divg_u[i > 0 ? c2 - 1 : c2], gvm_[t] = m.divg_v[j > 0 ? c2 - g.sj : c2];
+    if (ok) {
+      // the divergence before the passes: delpc at the tile's points (copy_computeplus), the caller's divg_d in the halo (written by
+      // this kernel at its very end only); uc / vc: what the arrays hold (inside the windows: never read from here)
+      sda[p] = (double)(own ? delpc : (const real*)divg_d)[kb + c2];
+      su[p] = (double)uc[kb + c2];
+      sv[p] = (double)vc[kb + c2];
+    }
+  }
+  __syncthreads();
+  double* src = sda;
+  double* dst = sdb;
+  for (int it = 0; it < nord; ++it) {
+    const int nt = nord - (it + 1);
+    const bool fillc = it + 1 != nord;
+    // ---- A: vc_from_divg (corners filled in x), uc_from_divg (corners filled in y), outside the windows
+#pragma unroll
+    for (int t = 0; t < DDH_PP; ++t) {
+      const unsigned f = fl_[t];
+      const int p = tid + DDH_NT * t;
+      if (!((f >> F_OK) & 1u)) continue;
+      if (((f >> (F_VD + nt)) & 1u) && !((f >> F_VW) & 1u)) sv[p] = stored((src[fillc ? xE_[t] : sE_[t]] - src[fillc ? xC_[t] : p]) * gu0_[t]);
+      if (((f >> (F_UD + nt)) & 1u) && !((f >> F_UW) & 1u)) su[p] = stored((src[fillc ? yN_[t] : sN_[t]] - src[fillc ? yC_[t] : p]) * gv0_[t]);
+    }
+    __syncthreads();
+    // ---- B: fill_corners_dgrid
+    if (fillc) {
+      if (tid < 72) {
+        int di, dj, si, sj_;
+        double sgn;
+        ddh_dgrid_entry(g, tid, di, dj, si, sj_, sgn);
+        const int d_ = band.slot(di, dj, NONE), s_ = band.slot(si, sj_, NONE);
+        if (tid < 36) sv[d_] = sgn * su[s_];
+        else su[d_] = sgn * sv[s_];
+      }
+      __syncthreads();
+    }
+    // ---- C: redo_divg_d on its domain; elsewhere the plane carries the state on (corner points: the y fill)
+#pragma unroll
+    for (int t = 0; t < DDH_PP; ++t) {
+      const unsigned f = fl_[t];
+      const int p = tid + DDH_NT * t;
+      if (!((f >> F_OK) & 1u)) continue;
+      double d;
+      if ((f >> (F_DD + nt)) & 1u) {
+        const double dc = src[p];
+        // (the band's innermost points read one point past it: in the first pass that is the divergence before the passes -- delpc,
+        // a point of the tile --, afterwards nothing the halo depends on)
+        auto nb = [&](int sl, int off) -> double { return (it == 0 && sl == NONE) ? (double)delpc[kb + c2_[t] + off] : src[sl]; };
+        const double dS = nb(sS_[t], -g.sj), dN = nb(sN_[t], g.sj), dW = nb(sW_[t], -1), dE = nb(sE_[t], 1);
+        const double ucm = ((f >> F_UWM) & 1u) ? (dc - dS) * gvm_[t] : su[sS_[t]];
+        const double uc0 = ((f >> F_UW) & 1u) ? (dN - dc) * gv0_[t] : su[p];
+        const double vcm = ((f >> F_VWM) & 1u) ? (dc - dW) * gum_[t] : sv[sW_[t]];
+        const double vc0 = ((f >> F_VW) & 1u) ? (dE - dc) * gu0_[t] : sv[p];
+        d = ucm - uc0 + vcm - vc0;
+        if ((f >> F_CS) & 1u) d = d - ucm;
+        if ((f >> F_CN) & 1u) d = d + uc0;
+        d = d * ra_[t];
+      } else {
+        d = src[fillc ? yC_[t] : p];
+      }
+      dst[p] = stored(d);
+    }
+    __syncthreads();
+    double* const tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  // the halo of the caller's divergence, uc and vc
+#pragma unroll
+  for (int t = 0; t < DDH_PP; ++t) {
+    const unsigned f = fl_[t];
+    const int p = tid + DDH_NT * t;
+    if (!((f >> F_OK) & 1u)) continue;
+    if (!((f >> F_OWN) & 1u)) divg_d[kb + c2_[t]] = (real)src[p];
+    if (!((f >> F_UW) & 1u)) uc[kb + c2_[t]] = (real)su[p];
+    if (!((f >> F_VW) & 1u)) vc[kb + c2_[t]] = (real)sv[p];
+  }
+}
+
+__global__ void __launch_bounds__(DDH_NT)
+k_divdamp_halo_state_mem(Geo g, Met m, const real* __restrict__ delpc, real* __restrict__ d0, real* __restrict__ d1, real* divg_d,
+                         real* __restrict__ uc, real* __restrict__ vc, int k0, int nord) {
+  const int kk = (int)blockIdx.x + k0;
+  const long kb = (long)kk * g.sk;
+  const int tid = (int)threadIdx.x;
+  const DdhBand band(g, DDH_MM);
+  const int total = band.total;
   real* U = uc + kb;
   real* V = vc + kb;
-  const real* S = d0 + kb;
-  real* T = d1 + kb;
+  // the divergence before the passes: delpc at the tile's points (copy_computeplus), the caller's divg_d in the halo -- which this
+  // kernel writes at its very end only
+  auto orig = [&](int i, int j) -> double {
+    const bool own = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1;
+    return (double)(own ? delpc : (const real*)divg_d)[kb + IDX2(g, i, j)];
+  };
+  // the two planes of the passes: plane `cur` holds the state before a pass (first pass: the original), the other takes the state
+  // after it.  The band's innermost points go wrong by one point per pass (they read past the band); nothing the halo depends on
+  // reaches them.
+  real* Gm[2] = {d0 + kb, d1 + kb};
+  int cur = 0;
+  bool first = true;
+  auto rd = [&](int i, int j) -> double { return first ? orig(i, j) : (double)Gm[cur][IDX2(g, i, j)]; };
   auto in_uwin = [&](int i, int j) { return i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je; };
   auto in_vwin = [&](int i, int j) { return i >= g.is && i <= g.ie && j >= g.js && j <= g.je + 1; };
   for (int it = 0; it < nord; ++it) {
     const int nt = nord - (it + 1);
     const bool fillc = it + 1 != nord;
-    auto at = [&](int i, int j) -> double { return S[IDX2(g, i, j)]; };
     auto sx = [&](int i, int j) -> double {
       if (fillc) remap_bgrid_x(g, i, j);
-      return at(i, j);
+      return rd(i, j);
     };
     auto sy = [&](int i, int j) -> double {
       if (fillc) remap_bgrid_y(g, i, j);
-      return at(i, j);
+      return rd(i, j);
     };
     // ---- A: vc_from_divg on [is-nt-1, ie+nt+1] x [js-nt, je+nt+1], uc_from_divg on [is-nt, ie+nt+1] x [js-nt-1, je+nt+1]
     for (int p = tid; p < total; p += DDH_NT) {
       int i, j;
-      point(p, i, j);
+      band.point(p, i, j);
       const long c2 = IDX2(g, i, j);
       if (i >= g.is - nt - 1 && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1 && !in_vwin(i, j))
         V[c2] = (real)((sx(i + 1, j) - sx(i, j)) * m.divg_u[c2]);
@@ -1233,42 +1422,27 @@ k_divdamp_halo_state(Geo g, Met m, real* __restrict__ d0, real* __restrict__ d1,
         U[c2] = (real)((sy(i, j + 1) - sy(i, j)) * m.divg_v[c2]);
     }
     __syncthreads();
-    // ---- B: fill_corners_dgrid(x = vc, y = uc, mysign = -1): every source lies outside the corner blocks (and outside the windows)
+    // ---- B: fill_corners_dgrid(x = vc, y = uc, mysign = -1)
     if (fillc && tid < 72) {
-      const int e = tid % 36, q = e / 9, a = 1 + (e % 9) % 3, b = 1 + (e % 9) / 3;
       int di, dj, si, sj_;
       double sgn;
-      if (tid < 36) {  // vc <- +-uc
-        if (q == 0) di = g.is - a, dj = g.js - b, sgn = -1.0, si = g.is - b, sj_ = g.js + a - 1;                   // SW
-        else if (q == 1) di = g.ie + a, dj = g.je + 1 + b, sgn = -1.0, si = g.ie + 1 + b, sj_ = g.je + 1 - a;      // NE
-        else if (q == 2) di = g.is - a, dj = g.je + 1 + b, sgn = 1.0, si = g.is - b, sj_ = g.je + 1 - a;           // NW
-        else di = g.ie + a, dj = g.js - b, sgn = 1.0, si = g.ie + 1 + b, sj_ = g.js + a - 1;                       // SE
-        V[IDX2(g, di, dj)] = (real)(sgn * (double)U[IDX2(g, si, sj_)]);
-      } else {  // uc <- +-vc
-        if (q == 0) di = g.is - a, dj = g.js - b, sgn = -1.0, si = g.is + b - 1, sj_ = g.js - a;                   // SW
-        else if (q == 1) di = g.ie + 1 + a, dj = g.je + b, sgn = -1.0, si = g.ie + 1 - b, sj_ = g.je + 1 + a;      // NE
-        else if (q == 2) di = g.is - a, dj = g.je + b, sgn = 1.0, si = g.is + b - 1, sj_ = g.je + 1 + a;           // NW
-        else di = g.ie + 1 + a, dj = g.js - b, sgn = 1.0, si = g.ie + 1 - b, sj_ = g.js - a;                       // SE
-        U[IDX2(g, di, dj)] = (real)(sgn * (double)V[IDX2(g, si, sj_)]);
-      }
+      ddh_dgrid_entry(g, tid, di, dj, si, sj_, sgn);
+      if (tid < 36) V[IDX2(g, di, dj)] = (real)(sgn * (double)U[IDX2(g, si, sj_)]);
+      else U[IDX2(g, di, dj)] = (real)(sgn * (double)V[IDX2(g, si, sj_)]);
     }
     __syncthreads();
     // ---- C: redo_divg_d on [is-nt, ie+nt+1]^2; elsewhere the plane carries the state on (corner points: the y fill)
-    auto uval = [&](int i, int j) -> double {
-      const long c2 = IDX2(g, i, j);
-      return in_uwin(i, j) ? (at(i, j + 1) - at(i, j)) * m.divg_v[c2] : (double)U[c2];
-    };
-    auto vval = [&](int i, int j) -> double {
-      const long c2 = IDX2(g, i, j);
-      return in_vwin(i, j) ? (at(i + 1, j) - at(i, j)) * m.divg_u[c2] : (double)V[c2];
-    };
     for (int p = tid; p < total; p += DDH_NT) {
       int i, j;
-      point(p, i, j);
+      band.point(p, i, j);
       const long c2 = IDX2(g, i, j);
       double d;
       if (i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) {
-        const double ucm = uval(i, j - 1), uc0 = uval(i, j), vcm = vval(i - 1, j), vc0 = vval(i, j);
+        const double dc = rd(i, j);
+        const double ucm = in_uwin(i, j - 1) ? (dc - rd(i, j - 1)) * m.divg_v[c2 - g.sj] : (double)U[c2 - g.sj];
+        const double uc0 = in_uwin(i, j) ? (rd(i, j + 1) - dc) * m.divg_v[c2] : (double)U[c2];
+        const double vcm = in_vwin(i - 1, j) ? (dc - rd(i - 1, j)) * m.divg_u[c2 - 1] : (double)V[c2 - 1];
+        const double vc0 = in_vwin(i, j) ? (rd(i + 1, j) - dc) * m.divg_u[c2] : (double)V[c2];
         d = ucm - uc0 + vcm - vc0;
         const bool ic = (i == g.is || i == g.ie + 1);
         if (ic && j == g.js) d = d - ucm;
@@ -1277,19 +1451,18 @@ k_divdamp_halo_state(Geo g, Met m, real* __restrict__ d0, real* __restrict__ d1,
       } else {
         d = sy(i, j);
       }
-      T[c2] = (real)d;
+      Gm[cur ^ 1][c2] = (real)d;
     }
     __syncthreads();
-    const real* t = S;
-    S = T;
-    T = const_cast<real*>(t);
+    cur ^= 1;
+    first = false;
   }
   // the halo of the caller's divergence
   for (int p = tid; p < total; p += DDH_NT) {
     int i, j;
-    point(p, i, j);
+    band.point(p, i, j);
     if (i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1) continue;
-    divg_d[kb + IDX2(g, i, j)] = S[IDX2(g, i, j)];
+    divg_d[kb + IDX2(g, i, j)] = Gm[cur][IDX2(g, i, j)];
   }
 }
 
@@ -1313,7 +1486,7 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
     // sponge levels + delpc = divg_d below them (copy_computeplus :578; whole planes, so that the fused kernel can take its
     // footprint from delpc), one launch
     hipLaunchKernelGGL(k_divdamp_low_and_copy, plane_grid(g, nk), dim3(256), 0, st, g, m, u, v, ua, va, uc, vc, delpc, vort_b, ke,
-                       d2_bg_dev, dddmp, dt, divg_d, kstart, da);
+                       d2_bg_dev, dddmp, dt, divg_d, kstart);
   } else if (fused) {
     // the work fields are dead after d_sw (PACE_DSW_SKIP_DEAD_OUTPUTS): no copy -- the fused kernel reads the divergence where it
     // is and writes neither it nor uc / vc -- and the sponge levels are extra workgroups of the fused launch
@@ -1339,11 +1512,17 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
       sp.nstrips = 2 * (sp.nch_row + sp.nch_col) * nhigh;
     }
     hipLaunchKernelGGL(k_divdamp_fused, dim3((unsigned)(sp.nblocks + sp.nstrips + ntx * nty * nhigh)), dim3(DD_NT), 0, st, g, m,
-                       rel_vort_agrid, skip_dead ? divg_d : da, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart,
+                       rel_vort_agrid, skip_dead ? divg_d : delpc, divg_d, vort_b, ke, uc, vc, d2_bg_dev, dddmp, dd8, fabs(dt), kstart,
                        nonzero_nord, ntx, ntx * nty, skip_dead ? 0 : 1, sp);
     // the full contract: the halo of divg_d, uc, vc as the reference's in-place passes leave it
-    if (!skip_dead && nonzero_nord > 0)
-      hipLaunchKernelGGL(k_divdamp_halo_state, dim3((unsigned)nhigh), dim3(DDH_NT), 0, st, g, m, da, db, divg_d, uc, vc, kstart, nonzero_nord);
+    if (!skip_dead && nonzero_nord > 0) {
+      const bool mem = getenv("PACE_DDH_MEM") != nullptr;  // (tests: the memory form on a small tile; read at every call)
+      if (DdhBand(g, DDH_M).total <= DDH_SLOTS && !mem)
+        hipLaunchKernelGGL(k_divdamp_halo_state_lds, dim3((unsigned)nhigh), dim3(DDH_NT), 0, st, g, m, delpc, divg_d, uc, vc, kstart, nonzero_nord);
+      else
+        hipLaunchKernelGGL(k_divdamp_halo_state_mem, dim3((unsigned)nhigh), dim3(DDH_NT), 0, st, g, m, delpc, da, db, divg_d, uc, vc, kstart,
+                           nonzero_nord);
+    }
   } else if (nhigh > 0) {
     const real* src = divg_d;
     real* bufs[2] = {da, db};
@@ -1529,10 +1708,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
     hipLaunchKernelGGL(k_finish_scalars, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, pt, delp, w, q_con, W.fx2, W.gx, W.gy, W.fx, W.fy, W.dw, d_damp_w_c);
     }
     // the full contract: the corner blocks of the four scalars as the transport's in-place corner copies leave them
-    if (!skip_dead) {
-      if (pingpong) hipLaunchKernelGGL(k_corner_blocks_x, dim3((unsigned)nk), dim3(256), 0, st, g, scalar_outs[0], scalar_outs[1], scalar_outs[2], scalar_outs[3]);
-      else hipLaunchKernelGGL(k_corner_blocks_x, dim3((unsigned)nk), dim3(256), 0, st, g, delp, pt, w, q_con);
-    }
+    // (separate outputs: the scalar-phase kernel's corner tiles have written them with the halo, fvt_core.h place_footprint)
+    if (!skip_dead && !pingpong) hipLaunchKernelGGL(k_corner_blocks_x, dim3((unsigned)nk), dim3(256), 0, st, g, delp, pt, w, q_con);
     return PACE_OK;
   };
   if ((phases & 2) && !winds_in_scalars && (rc = scalar_phase())) return rc;

@@ -988,3 +988,31 @@ def test_two_emulation_libraries_in_one_process_do_not_share_symbols():
         op(q, fx, fy, mass=mass)
         assert np.array_equal(fx.numpy()[window(n, 1, 0, nz)], ref_fx[window(n, 1, 0, nz)]), lib.path
         assert np.array_equal(fy.numpy()[window(n, 0, 1, nz)], ref_fy[window(n, 0, 1, nz)]), lib.path
+
+
+def test_d_sw_halo_state_memory_form_equals_lds_form():
+    """k_divdamp_halo_state (the halo of divgd / uc / vc as the reference's in-place divergence damping leaves it: TranslateD_SW's
+    whole-storage windows) has two forms: the band's divergence planes in LDS (tiles up to C320), or in two scratch fields (larger
+    tiles; PACE_DDH_MEM=1 forces it).  C24: a band with an inside.  Both against the oracle, whole storage, bit for bit."""
+    from helpers import DSW_CFG
+    from oracle import dgrid_sw
+    from pace_amd import _lib, synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import column_namelist_arrays
+
+    n, nz = 24, 5
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    col = column_namelist_arrays(DGridShallowWaterLagrangianDynamicsConfig(), nz)
+    a = {k: s[k].copy() for k in DSW_ARGS}
+    dgrid_sw.d_sw(oracle_grid(m, n, nz), col, DSW_CFG, dgrid_sw.DSWState(s["u"].shape), *[a[k] for k in DSW_ARGS], s["dt"])
+    env = Env(_lib.Library(build_emu()), "cpu", m, n, nz)
+    for mem in (False, True):
+        if mem:
+            os.environ["PACE_DDH_MEM"] = "1"
+        try:
+            out, _ = run_d_sw(env, col, {k: s[k] for k in DSW_ARGS}, s["dt"])
+        finally:
+            os.environ.pop("PACE_DDH_MEM", None)
+        for k in ("divgd", "uc", "vc", "delpc", "delp", "pt", "w", "q_con"):
+            assert np.array_equal(a[k][dsw_window(k, n, nz)], out[k][dsw_window(k, n, nz)]), (mem, k)
