@@ -21,6 +21,8 @@
 // 331-350: no k_finish_scalars pass, no flux-form intermediates), results go to buffers of their own (the neighbouring tiles
 // still read the old values).  Other tilings, ord 8 and the float32 build take k_fvtp2d.hip.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -82,6 +84,29 @@ struct FvtLds {
     double scratch[3 * QH * P];  // damping: iterate, del6_v, del6_u
   } u;
   double pad1[P];
+  double sqc[9];  // the tile's corner block with corners copied in x (corner tiles)
+};
+
+// The layout of the scalar-phase kernel since round 6: the damping's iterate and its two metric planes have places of their own
+// instead of aliasing the sweeps' arrays.  del6_v / del6_u are then staged ONCE per tile (they used to be fetched again at the start
+// of every pass -- 0.35 GB of a launch's 1.06 GB, L2 misses every time: 50 us of 420, experiment x25 of round 5), and the iterate
+// lives until the outer sweep has formed its fluxes, so the damping's face values are read from it where they are used (no
+// per-thread store of them: 20 KB) and the damping's passes share barrier intervals with the sweeps, which read q only.
+struct FvtLdsRes {
+  double pad0[P];          // (the damping runs read one row above / below a plane without clamping)
+  double sq[QH * P];       // q on the footprint, corners copied in y; never modified
+  double it[QH * P];       // the damping's iterate
+  double sdv[QH * P];      // del6_v, del6_u on the footprint
+  double sdu[QH * P];
+  double pad1[P];
+  struct {
+    struct {
+      double sqi[TJ * P];        // q advected in y, tile rows x footprint columns (w: dw on the tile; the winds: fy)
+      double sqj[QH * PJ];       // q advected in x, footprint rows x tile columns (w: its heating term; the winds: fx)
+      double ax[TJ * PJ];        // inner, then final x-face fluxes
+      double ay[(TJ + 1) * TI];  // ... y-face fluxes
+    } s;
+  } u;
   double sqc[9];  // the tile's corner block with corners copied in x (corner tiles)
 };
 
@@ -235,8 +260,9 @@ using FvtPieces = FvtPiecesT<256>;
 // The stages of one tile.  EX / EY: the tile holds a west or east / south or north edge of the cubed-sphere tile (block-uniform).
 // NT = 256: every thread owns one y-run AND one x-run.  NT = 512 (the scalar-phase kernel): the first four waves own the x-runs,
 // the last four the y-runs -- half the persistent state per thread, twice the waves per SIMD.
-template <int MORD, bool EX, bool EY, int NT = 256>
+template <int MORD, bool EX, bool EY, int NT = 256, class LT = FvtLds>
 struct FvtTile {
+  static constexpr bool RES = std::is_same<LT, FvtLdsRes>::value;  // the damping's planes have places of their own
   static constexpr bool RC = EX && EY;  // the footprint reaches a corner of the halo: the corner copies apply
   static constexpr bool SPLIT = NT == 512;
   static_assert(NT == 256 || NT == 512, "thread places of one or two roles");
@@ -245,7 +271,7 @@ struct FvtTile {
   static_assert(QW * DNR <= NT, "one column run per thread");
   static constexpr int NCU = (TI * TJ + NT - 1) / NT;  // cells per thread in the cell update
   using Pieces = FvtPiecesT<NT>;
-  FvtLds& L;
+  LT& L;
   const Geo& g;
   const FvMet& m;
   int tid, i0, j0, ilo, jlo, sj8, k;
@@ -268,7 +294,7 @@ struct FvtTile {
   int fx_at, fx_src[6];
   double *plane, *sdv, *sdu;
 
-  __device__ __forceinline__ FvtTile(FvtLds& L_, const Geo& g_, const FvMet& m_, int bx, int by, int k_, int tid_) : L(L_), g(g_), m(m_) {
+  __device__ __forceinline__ FvtTile(LT& L_, const Geo& g_, const FvMet& m_, int bx, int by, int k_, int tid_) : L(L_), g(g_), m(m_) {
     tid = tid_;
     k = k_;
     i0 = g.is + bx * TI, j0 = g.js + by * TJ;
@@ -317,9 +343,13 @@ struct FvtTile {
     dn_on = dr < DNR;
     dr0 = dn_on ? dr * DRC : 0;
     dbase = dr0 * P + dc;
-    plane = L.u.scratch;
-    sdv = plane + QH * P;
-    sdu = sdv + QH * P;
+    if constexpr (RES) {
+      plane = L.it, sdv = L.sdv, sdu = L.sdu;
+    } else {
+      plane = L.u.scratch;
+      sdv = plane + QH * P;
+      sdu = sdv + QH * P;
+    }
     fx_at = -1;
     if (RC && tid < 64) {
       const int q = tid >> 4, a = tid & 3, b = (tid >> 2) & 3;
@@ -512,6 +542,27 @@ struct FvtTile {
     if (y_outer) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) dvy[f] = face(D, sdu[ybase + (f + 3) * P], D.last[ybase + (f + 2) * P], D.last[ybase + (f + 3) * P]);
+    }
+  }
+  // ---- the same damping in pieces, for a caller that runs other stages between its barriers (the resident layout) ----
+  // one pass on the thread's column run (and a corner tile's fixed cell), result in registers: from q (FIRST) or from the iterate
+  template <bool FIRST>
+  __device__ __forceinline__ void deln_compute(double d0, double* res, double& fix) const {
+    fix = 0.0;
+    if (dn_on) fvt_deln_run<FIRST, DRC>((FIRST ? L.sq : plane) + dbase, sdv + dbase, sdu + dbase, dra, d0, res);
+    if (RC && fx_at >= 0) fix = FIRST ? corner_fix<true>(L.sq, d0) : corner_fix<false>(plane, d0);
+  }
+  // ... put down into the iterate (the caller has passed a barrier since the last read of it).  On a corner tile the cells whose
+  // stencil reaches a corner region are overwritten behind a barrier; the caller's next barrier publishes everything.
+  __device__ __forceinline__ void deln_store(const double* res, double fix) {
+    if (dn_on) {
+#pragma unroll
+      for (int t = 0; t < DRC; ++t)
+        if (QH % DRC == 0 || dr0 + t < QH) plane[dbase + t * P] = res[t];
+    }
+    if (RC) {
+      __syncthreads();
+      if (fx_at >= 0) plane[fx_at] = fix;
     }
   }
   // heat_diss (d_sw.py:63-103): dw = divergence of the damping fluxes / area -- one more divergence of the iterate on this thread's
@@ -1493,6 +1544,436 @@ __device__ __forceinline__ void fvt_scalars_tile_split(FvtLdsScalars& LS, const 
         } else {
           val = T.flux_form(jj[t], ii[t], am, ra[t]) / LS.newmass[jj[t] * TI + ii[t]];
           if (is_w && w_on) val = val + dwv[t];  // adjust_w_and_qcon (d_sw.py:331-350)
+        }
+        STG(qout, c2[t]) = val;
+      }
+    }
+    FVT_ARRIVE(4 * s + 3);
+    if (s < 3 || S.winds) __syncthreads();  // (the cell update read sq / ax / ay)
+  };
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
+  pass(std::integral_constant<int, 2>{});
+  pass(std::integral_constant<int, 3>{});
+  if (S.winds) pass(std::integral_constant<int, 4>{});
+  FVT_STAMP(S.winds ? 20 : 16);
+}
+
+
+// ---- round 6: the 512-thread form on the resident layout (FvtLdsRes) --------------------------------------------------------------
+// What changes against fvt_scalars_tile_split (same stages, same expressions, same bits):
+//  * del6_v / del6_u are staged once per tile; the iterate has a plane of its own; no store of face values (see FvtLdsRes).
+//  * The barrier intervals of a pass -- each now holds a piece of the damping AND a piece of the transport, which read different
+//    arrays:   [footprint] | [damping pass 1: q -> iterate; inner sweep: q -> q_i / q_j] | [outer sweep -> registers; damping pass 2
+//    read] | [pass 2 written] | [face values from the iterate -> fluxes] | [cell update]      -- six barriers where there were eight,
+//    and none of them closes an interval of a dozen instructions.
+//  * The new mass and w's heating term of a thread's cells stay in its registers (the thread that forms them is the thread that
+//    uses them; the footprint pieces prefetched at kernel start have been released by then): 12 KB of LDS less.  73.6 KB per workgroup.
+struct FvtLdsScalarsRes {
+  FvtLdsRes t;
+  double mass[(TJ + 2) * MP];  // the mass on the tile and one cell around it (the winds: the damped vorticity at the B-grid points)
+};
+static_assert(2 * sizeof(FvtLdsScalarsRes) <= 160 * 1024, "two workgroups per CU");
+
+template <int MORD, bool EX, bool EY>
+__device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const Geo& g, const FvMet& m, const FvtScalars& S, int bx, int by, int k) {
+  constexpr int NT = 512;
+  using Tile = FvtTile<MORD, EX, EY, NT, FvtLdsRes>;
+  constexpr int NCU = Tile::NCU, DRC = Tile::DRC;
+  FvtLdsRes& L = LS.t;
+  const int tid = (int)threadIdx.x;
+  const bool xrole = tid < 256;  // wave-uniform
+  const long kb = (long)k * g.sk;
+  const int sj8 = g.sj * RB;
+  const bool w_on = S.damp_w[k] > 1e-5;
+  double c[NF], af[NF], mf[NF];    // Courant numbers, area fluxes, mass fluxes (unit fluxes of w, q_con, pt) of the run's faces
+  double nm[NCU], heat_r[NCU];     // the new mass and w's heating term of the thread's cells
+  D2 fp[5][Tile::Pieces::NP];      // the thread's pieces of the footprints: every load of the tile's inputs is in flight at once
+#ifndef FVT_RA_REGS
+#define FVT_RA_REGS 0  // 1: rarea of the thread's damping run loaded once per tile and kept in registers (0: once per pass)
+#endif
+  double ra_keep[DRC];
+#pragma unroll
+  for (int t = 0; t < NCU; ++t) nm[t] = 1.0, heat_r[t] = 0.0;
+  {
+    Tile T(L, g, m, bx, by, k, tid);
+    if (FVT_RA_REGS) {
+      T.load_damping_rarea();
+#pragma unroll
+      for (int t = 0; t < DRC; ++t) ra_keep[t] = T.dra[t];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) T.fetch_footprint(S.q[s] + kb, fp[s]);
+    if (S.winds) T.fetch_footprint(S.q[4] + kb, fp[4]);
+    T.stage_damping_planes();  // once per tile
+    const unsigned roff = xrole ? T.xoff : T.yoff;
+    if (xrole) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        c[f] = LDG(S.crx + kb, roff + (unsigned)(f * RB));
+        af[f] = LDG(S.xfx + kb, roff + (unsigned)(f * RB));
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        c[f] = LDG(S.cry + kb, roff + (unsigned)(f * sj8));
+        af[f] = LDG(S.yfx + kb, roff + (unsigned)(f * sj8));
+      }
+    }
+  }
+
+  // one pass of the tile: s = 0 .. 4 = delp, w, q_con, pt, (the winds:) relative vorticity -- a compile-time constant
+  auto pass = [&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr bool is_delp = s == 0, is_w = s == 1, is_vort = s == 4;
+    FVT_STAMP(4 * s);
+    const real* const q = S.q[s] + kb;
+    real* const qout = is_vort ? nullptr : S.qout[is_vort ? 0 : s] + kb;
+    // DelnFlux with mass (q_con, pt); delp: plain DelnFlux; w: DelnFluxNoSG -> heat_diss; vorticity: DelnFluxNoSG -> the winds
+    const bool mass_weighted = s == 2 || s == 3;
+    const double damp = S.fac[s][k];
+    const double d0 = mass_weighted ? 1.0 : damp;
+    const int iters = (S.nord[s][k] > 0.0) ? S.nmax[s] : 0;  // passes of the damping before its fluxes: 0, 1 or 2 (block-uniform)
+    // the thread's places, derived again for every scalar: only the operands above live through the whole kernel
+    Tile T(L, g, m, bx, by, k, FVT_LAUNDER(tid));
+    const unsigned roff = xrole ? T.xoff : T.yoff;
+    const bool run_outer = xrole ? T.x_outer : T.y_outer;
+    const bool lane_lo = xrole ? (T.west && T.xg == 0) : (T.south && T.yg == 0);
+    const bool lane_hi = xrole ? (T.east && T.xg == GXN - 1) : (T.north && T.yg == GYN - 1);
+    const bool last_face = lane_hi;  // the run that stores the face past the end of the tile (ie + 1 / je + 1)
+    auto spacing = [&]() {
+      FvtSpacing sp;
+      if (EX && xrole) sp = fvt_spacing(m.dxa, (unsigned)((T.jlo + T.xrow) * sj8), RB, g.is, g.ie, lane_lo, lane_hi);
+      if (EY && !xrole) sp = fvt_spacing(m.dya, (unsigned)((T.ilo + T.ycol) * RB), sj8, g.js, g.je, lane_lo, lane_hi);
+      return sp;
+    };
+    // the damping flux through face f of the thread's run, from the last iterate (q itself if no pass ran)
+    const typename Tile::Damped D{iters == 0 ? L.sq : T.plane, d0, iters == 0};
+    auto dface = [&](int f) -> double {
+      return xrole ? Tile::face(D, T.sdv[T.xbase + f + 3], D.last[T.xbase + f + 2], D.last[T.xbase + f + 3])
+                   : Tile::face(D, T.sdu[T.ybase + (f + 3) * P], D.last[T.ybase + (f + 2) * P], D.last[T.ybase + (f + 3) * P]);
+    };
+
+    // ---- interval 0: the footprint
+    if (FVT_RA_REGS) {
+#pragma unroll
+      for (int t = 0; t < DRC; ++t) T.dra[t] = ra_keep[t];
+    } else {
+      T.load_damping_rarea();
+    }
+    T.place_footprint(q, fp[s], qout);
+    constexpr int BW = TI + 1, NBP = (BW * (TJ + 1) + NT - 1) / NT;
+    double bke[NBP], bvb[NBP];  // the winds: kinetic energy and damped vorticity at the tile's B-grid points, on their way
+    if (is_vort) {
+#pragma unroll
+      for (int t = 0; t < NBP; ++t) {
+        int e = tid + NT * t;
+        if (e >= BW * (TJ + 1)) e = BW * (TJ + 1) - 1;
+        const int r = e / BW, cc = e - r * BW;
+        const unsigned o = (unsigned)((T.j0 + r) * sj8 + (T.i0 + cc) * RB);
+        bke[t] = LDG(S.ke + kb, o);
+        bvb[t] = LDG(S.vort_b + kb, o);
+      }
+    }
+    FVT_ARRIVE(4 * s);
+    __syncthreads();
+    FVT_STAMP(4 * s + 1);
+
+    // ---- interval 1: damping pass 1 (q -> iterate) and the inner sweep (q -> q_i / q_j, its fluxes to the faces' places)
+    if (is_delp) {  // the mass on the tile and one cell around it, from the footprint while it is there
+      for (int e = tid; e < (TJ + 2) * (TI + 2); e += NT) {
+        const int r = e / (TI + 2), cc = e - r * (TI + 2);
+        LS.mass[r * MP + cc] = L.sq[(r + 2) * P + cc + 2];
+      }
+    }
+    double fv0[NF];  // (the winds without a damping pass: the face values of the RELATIVE vorticity, before f is added to q)
+    if (is_vort && iters == 0 && run_outer) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) fv0[f] = dface(f);
+    }
+    if (iters >= 1) {
+      double res[DRC], fix;
+      T.template deln_compute<true>(d0, res, fix);
+      T.deln_store(res, fix);
+    }
+    if (is_vort) {
+      __syncthreads();      // (the pass above has read the relative vorticity)
+      T.add_2d(S.fC);       // ... the transported scalar is the absolute one (d_sw.py:389-402); ends with a barrier
+    }
+    double si_last = 0.0;
+    double* const slot = xrole ? L.u.s.ax + T.xr * PJ + C * T.xg : L.u.s.ay + (C * T.yg) * TI + T.ycol - 3;  // of the run's first face
+    constexpr int XS = 1, YS = TI;  // from face to face in ax / ay
+    if (xrole) {
+      if (T.x_on) {
+        double Q[NF + 5], ar[C];
+#pragma unroll
+        for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[T.xbase + u];
+        if (Tile::RC) {  // halo rows of a corner tile: the three corner columns hold the x-direction copies
+          const bool halo_row = T.south ? T.xrow < 3 : T.xrow >= TJ + 3;
+          const int b = T.south ? T.xrow : T.xrow - (TJ + 3);
+          if (halo_row && T.west && T.xg == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Q[a] = L.sqc[b * 3 + a];
+          }
+          if (halo_row && T.east && T.xg == GXN - 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Q[NF + 2 + a] = L.sqc[b * 3 + a];
+          }
+        }
+        double si[NF];
+        fvt_run<MORD, EX>(Q, c, lane_lo, lane_hi, spacing(), si);
+        FVT_FENCE();
+#pragma unroll
+        for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, roff + (unsigned)(t * RB));
+        if (T.x_outer) {
+#pragma unroll
+          for (int f = 0; f < C; ++f) slot[f * XS] = si[f];
+          si_last = si[C];
+        }
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+          L.u.s.sqj[T.xrow * PJ + C * T.xg + t] = (Q[t + 3] * ar[t] + af[t] * si[t] - af[t + 1] * si[t + 1]) / (ar[t] + af[t] - af[t + 1]);
+      }
+    } else {
+      if (T.y_on) {
+        double Q[NF + 5], ar[C];
+#pragma unroll
+        for (int u = 0; u < NF + 5; ++u) Q[u] = L.sq[T.ybase + u * P];
+        double si[NF];
+        fvt_run<MORD, EY>(Q, c, lane_lo, lane_hi, spacing(), si);
+        FVT_FENCE();
+#pragma unroll
+        for (int t = 0; t < C; ++t) ar[t] = LDG(m.area, roff + (unsigned)(t * sj8));
+        if (T.y_outer) {
+#pragma unroll
+          for (int f = 0; f < C; ++f) slot[f * YS] = si[f];
+          si_last = si[C];
+        }
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+          L.u.s.sqi[T.ybase + t * P] = (Q[t + 3] * ar[t] + af[t] * si[t] - af[t + 1] * si[t + 1]) / (ar[t] + af[t] - af[t + 1]);
+      }
+    }
+    FVT_ARRIVE(4 * s + 1);
+    __syncthreads();
+    FVT_STAMP(4 * s + 2);
+
+    // ---- interval 2: the outer sweep on the field advected across the run (fvtp2d.py:80-119) -> the mean advected values through
+    // the run's faces, in registers; then damping pass 2's read of the iterate
+    double* const tke = L.sq;     // the winds: kinetic energy / damped vorticity at the tile's B-grid points, pitch BW
+    double* const tvb = LS.mass;
+    if (is_vort) {  // (q's footprint and the mass tile are dead)
+#pragma unroll
+      for (int t = 0; t < NBP; ++t) {
+        const int e = tid + NT * t;
+        if (e < BW * (TJ + 1)) tke[e] = S.ke_plus_vort ? bke[t] + bvb[t] : bke[t], tvb[e] = bvb[t];
+      }
+    }
+    double v[NF];
+    double wind[NF];  // the winds: the old wind on the run's faces, on its way while the sweep runs
+    if (is_vort && run_outer) {
+      if (xrole) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wind[f] = LDG(S.v + kb, roff + (unsigned)(f * RB));
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wind[f] = LDG(S.u + kb, roff + (unsigned)(f * sj8));
+      }
+    }
+    if (run_outer) {
+      double Q[NF + 5], out[NF];
+      if (xrole) {
+#pragma unroll
+        for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqi[T.xr * P + C * T.xg + u];
+        fvt_run<MORD, EX>(Q, c, lane_lo, lane_hi, spacing(), out);
+#pragma unroll
+        for (int f = 0; f < C; ++f) v[f] = 0.5 * (out[f] + slot[f * XS]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NF + 5; ++u) Q[u] = L.u.s.sqj[(C * T.yg + u) * PJ + T.ycol - 3];
+        fvt_run<MORD, EY>(Q, c, lane_lo, lane_hi, spacing(), out);
+#pragma unroll
+        for (int f = 0; f < C; ++f) v[f] = 0.5 * (out[f] + slot[f * YS]);
+      }
+      v[C] = 0.5 * (out[C] + si_last);
+      FVT_FENCE();
+      if (is_w) {  // (no damping fluxes in w's transport: its fluxes are final here)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f] = v[f] * mf[f];
+#pragma unroll
+        for (int f = 0; f < C; ++f) slot[f * (xrole ? XS : YS)] = v[f];
+        if (xrole ? T.xg == GXN - 1 : T.yg == GYN - 1) slot[C * (xrole ? XS : YS)] = v[C];
+      }
+    }
+    FVT_FENCE();
+    double res2[DRC], fix2 = 0.0;
+    if (iters >= 2) T.template deln_compute<false>(d0, res2, fix2);
+    if (iters >= 2) {
+      FVT_ARRIVE(4 * s + 2);
+      __syncthreads();  // (everyone has read the iterate)
+      // ---- interval 3: damping pass 2 put down
+      T.deln_store(res2, fix2);
+    }
+    __syncthreads();  // (the iterate is final; the sweeps' inputs have been read)
+    FVT_STAMP(4 * s + 3);
+
+    // ---- interval 4: the damping's face fluxes from the iterate, the fluxes through the run's faces
+    if (is_w) {
+      // heat_diss: dw and the heating term on the tile, where the sweeps' inputs were (w has no face values)
+      T.heat_diss(D, S.dw + kb, S.heat_s + kb, S.diss_est + kb, w_on, S.ke_bg[k] * fabs(S.dt), L.u.s.sqi, S.winds ? L.u.s.sqj : nullptr);
+    } else if (run_outer && !is_vort) {
+      if (is_delp) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          mf[f] = v[f] * af[f] + dface(f);
+          v[f] = mf[f];
+        }
+        // flux_capacitor (d_sw.py:33-60): mfx += fx, mfy += fy, each face by the run that opens it
+        if (xrole) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            if (f < C || last_face) fvt_accumulate((real*)((char*)(S.mfx + kb) + roff + (unsigned)(f * RB)), mf[f]);
+        } else {
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            if (f < C || last_face) fvt_accumulate((real*)((char*)(S.mfy + kb) + roff + (unsigned)(f * sj8)), mf[f]);
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          v[f] = v[f] * mf[f];
+          // the cells on either side of the face
+          const double* ms = xrole ? LS.mass + (T.xr + 1) * MP + C * T.xg + f : LS.mass + (C * T.yg + f) * MP + T.ycol - 2;
+          const double m1 = xrole ? ms[1] : ms[MP];
+          v[f] = v[f] + 0.5 * damp * (ms[0] + m1) * dface(f);
+        }
+      }
+      // a face's flux is put down by the run that opens it; the last face of the row / column by its last run
+#pragma unroll
+      for (int f = 0; f < C; ++f) slot[f * (xrole ? XS : YS)] = v[f];
+      if (xrole ? T.xg == GXN - 1 : T.yg == GYN - 1) slot[C * (xrole ? XS : YS)] = v[C];
+    }
+    if (is_vort) {
+      // ---- the winds.  On a face of the tile: u_and_v_from_ke (d_sw.py:406-477) with the vorticity flux through it, the
+      // vorticity-damping increment (vort_differencing :353-380: the damping flux from the iterate), the final wind (update_u_and_v
+      // :582-608) and the face's terms of heat_source_from_vorticity_damping (:493-577: ubt, fy / vbt, fx); then, per cell, the
+      // damping term from its four faces and the heating.  The face terms travel through the LDS arrays the sweeps are done
+      // with: vbt -> ax, fx -> sqj (rows x TI + 1 faces), ubt -> ay, fy -> sqi (TJ + 1 faces x columns).
+      const bool upd = S.damp_vt[k] > 1e-5;
+      const double dck = S.d_con_k[k];
+      const bool don = dck > 1e-5;
+      double* const avbt = L.u.s.ax;
+      double* const afx = L.u.s.sqj;
+      double* const aubt = L.u.s.ay;
+      double* const afy = L.u.s.sqi;
+      if (run_outer) {
+        if (xrole) {  // x-faces: v-points (i0 + C * xg + f, j0 + xr)
+          double dyv[NF], rdyv[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            dyv[f] = LDG(m.dy, roff + (unsigned)(f * RB));
+            rdyv[f] = LDG(S.rdy, roff + (unsigned)(f * RB));
+          }
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const int b = T.xr * BW + C * T.xg + f;
+            const double vf = v[f] * af[f];  // (the unit fluxes of the vorticity are the area fluxes)
+            const double vmid = wind[f] * dyv[f] + tke[b] - tke[b + BW] - vf;  // v_from_ke (d_sw.py:423-436)
+            const double ut2 = iters == 0 ? fv0[f] : dface(f);
+            const double vyd = don ? tvb[b] - tvb[b + BW] : 0.0;
+            const double vbt = (vyd - ut2) * rdyv[f];
+            const double fxh = vmid * rdyv[f];
+            if (f < C || last_face) STG(S.v_out + kb, roff + (unsigned)(f * RB)) = upd ? vmid - ut2 : vmid;
+            if (f < C || T.xg == GXN - 1) avbt[T.xr * PJ + C * T.xg + f] = vbt, afx[T.xr * PJ + C * T.xg + f] = fxh;
+          }
+        } else {  // y-faces: u-points (i0 + ycol - 3, j0 + C * yg + f)
+          double dxv[NF], rdxv[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            dxv[f] = LDG(m.dx, roff + (unsigned)(f * sj8));
+            rdxv[f] = LDG(S.rdx, roff + (unsigned)(f * sj8));
+          }
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const int b = (C * T.yg + f) * BW + T.ycol - 3;
+            const double vf = v[f] * af[f];
+            const double umid = wind[f] * dxv[f] + tke[b] - tke[b + 1] + vf;  // u_from_ke (d_sw.py:406-420)
+            const double vt2 = iters == 0 ? fv0[f] : dface(f);
+            const double vxd = don ? tvb[b] - tvb[b + 1] : 0.0;
+            const double ubt = (vxd + vt2) * rdxv[f];
+            const double fyh = umid * rdxv[f];
+            if (f < C || last_face) STG(S.u_out + kb, roff + (unsigned)(f * sj8)) = upd ? umid + vt2 : umid;
+            if (f < C || T.yg == GYN - 1) aubt[(C * T.yg + f) * TI + T.ycol - 3] = ubt, afy[(C * T.yg + f) * TI + T.ycol - 3] = fyh;
+          }
+        }
+      }
+      __syncthreads();
+      {
+        int jj[NCU], ii[NCU];
+        unsigned c2[NCU];
+        T.cell_places(jj, ii, c2);
+        const bool any = S.d_con > 1e-5 || S.do_skeb;
+#pragma unroll
+        for (int t = 0; t < NCU; ++t) {
+          if (NCU * NT > TI * TJ && tid + NT * t >= TI * TJ) continue;  // (no cell of its own: the spare lanes would add twice)
+          const double heat_s = heat_r[t];
+          if (don || S.do_skeb) {
+            const int ey = jj[t] * TI + ii[t], ex = jj[t] * PJ + ii[t];
+            const double ubt0 = aubt[ey], ubtj = aubt[ey + TI], fy0 = afy[ey], fyj = afy[ey + TI];
+            const double vbt0 = avbt[ex], vbti = avbt[ex + 1], fx0 = afx[ex], fxi = afx[ex + 1];
+            const double gy0 = fy0 * ubt0, gyj = fyj * ubtj, gx0 = fx0 * vbt0, gxi = fxi * vbti;
+            const double u2 = fy0 + fyj, du2 = ubt0 + ubtj, v2 = fx0 + fxi, dv2 = vbt0 + vbti;
+            const double dampterm = LDG(S.rsin2, c2[t]) * 0.25 *
+                                    ((ubt0 * ubt0 + ubtj * ubtj + vbt0 * vbt0 + vbti * vbti) + 2.0 * (gy0 + gyj + gx0 + gxi) -
+                                     LDG(S.cosa_s, c2[t]) * (u2 * dv2 + v2 * du2 + du2 * dv2));
+            const double hs = nm[t] * (heat_s - dck * dampterm);
+            if (any) {
+              fvt_accumulate((real*)((char*)(S.heat_source + kb) + c2[t]), hs);
+              if (S.do_skeb) STG(S.diss_est + kb, c2[t]) = LDG(S.diss_est + kb, c2[t]) - dampterm;
+            }
+          } else if (any) {
+            fvt_accumulate((real*)((char*)(S.heat_source + kb) + c2[t]), heat_s);
+          }
+        }
+      }
+      if ((EX || EY) && S.copy_wind_halo) {
+        // the output buffers of the winds get the halo the inputs have (the caller swaps the buffers): this tile's share of the
+        // storage outside the faces the kernel writes -- u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je]
+        const int xa = T.west ? 0 : T.i0, xb = T.east ? g.ni : T.i0 + TI, ya = T.south ? 0 : T.j0, yb = T.north ? g.nj : T.j0 + TJ;
+        const int bw = xb - xa, nbox = bw * (yb - ya);
+        for (int e = tid; e < nbox; e += NT) {
+          const int r = e / bw, i = xa + (e - r * bw), j = ya + r;
+          const unsigned o = (unsigned)(j * sj8 + i * RB);
+          const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
+          if (!(in_i && (in_j || j == g.je + 1))) STG(S.u_out + kb, o) = LDG(S.u + kb, o);
+          if (!((in_i || i == g.ie + 1) && in_j)) STG(S.v_out + kb, o) = LDG(S.v + kb, o);
+        }
+      }
+      return;
+    }
+    __syncthreads();
+
+    // ---- interval 5: the cell update (apply_fluxes / apply_pt_delp_fluxes / adjust_w_and_qcon, d_sw.py:122-201,331-350)
+    {
+      int jj[NCU], ii[NCU];
+      unsigned c2[NCU];
+      double ra[NCU];
+      T.cell_places(jj, ii, c2);
+#pragma unroll
+      for (int t = 0; t < NCU; ++t) ra[t] = LDG(m.rarea, c2[t]);
+#pragma unroll
+      for (int t = 0; t < NCU; ++t) {
+        const double am = LS.mass[(jj[t] + 1) * MP + ii[t] + 1];
+        double val;
+        if (is_delp) {
+          val = am + T.flux_increment(jj[t], ii[t], ra[t]);  // the new delp (apply_pt_delp_fluxes, d_sw.py:148-201)
+          nm[t] = val;
+        } else {
+          val = T.flux_form(jj[t], ii[t], am, ra[t]) / nm[t];
+          if (is_w) {
+            if (w_on) val = val + L.u.s.sqi[jj[t] * TI + ii[t]];  // adjust_w_and_qcon (d_sw.py:331-350): + dw
+            if (S.winds) heat_r[t] = L.u.s.sqj[jj[t] * TI + ii[t]];
+          }
         }
         STG(qout, c2[t]) = val;
       }

@@ -48,13 +48,25 @@ __global__ void __launch_bounds__(256, FVT_WAVES) k_fvt(Geo g, FvMet m, const re
 #else
 #define FVT_SCALARS_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
+#ifndef FVT_RESIDENT
+#define FVT_RESIDENT 1  // the 512-thread form on the layout with the damping's planes resident (round 6; 0: round 5's, for A/B builds)
+#endif
 template <int MORD>
 __global__ void __launch_bounds__(FVT_SCALARS_NT) FVT_SCALARS_ATTR k_fvt_scalars(Geo g, FvMet m, FvtScalars S) {
+#if FVT_SCALARS_NT == 512 && FVT_RESIDENT
+  __shared__ FvtLdsScalarsRes L;
+#else
   __shared__ FvtLdsScalars L;
+#endif
   const FvTile wg = fv_tile_of_workgroup();
   const int gx = g.n / TI, gy = g.n / TJ;
   const bool ex = wg.bx == 0 || wg.bx == gx - 1, ey = wg.by == 0 || wg.by == gy - 1;
-#if FVT_SCALARS_NT == 512
+#if FVT_SCALARS_NT == 512 && FVT_RESIDENT
+  if (ex && ey) fvt_scalars_tile_res<MORD, true, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else if (ex) fvt_scalars_tile_res<MORD, true, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else if (ey) fvt_scalars_tile_res<MORD, false, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
+  else fvt_scalars_tile_res<MORD, false, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
+#elif FVT_SCALARS_NT == 512
   if (ex && ey) fvt_scalars_tile_split<MORD, true, true>(L, g, m, S, wg.bx, wg.by, wg.bz);
   else if (ex) fvt_scalars_tile_split<MORD, true, false>(L, g, m, S, wg.bx, wg.by, wg.bz);
   else if (ey) fvt_scalars_tile_split<MORD, false, true>(L, g, m, S, wg.bx, wg.by, wg.bz);

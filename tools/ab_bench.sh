@@ -1,0 +1,17 @@
+#!/bin/bash
+# A/B of two builds on ONE box, alternating: bash tools/ab_bench.sh <tag> <libA> <libB> [rounds] [bench args]
+# (libX: a path, or "default" for pace_amd/libpace_hip.so)  -> gpurun_out/<tag>/ab.txt
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=$1; A=$2; B=$3; N=${4:-3}; shift 4 || shift $#
+O=$R/gpurun_out/$TAG; mkdir -p "$O"
+cd "$R"
+for r in $(seq 1 $N); do
+  for L in "$A" "$B"; do
+    if [ "$L" = default ]; then unset PACE_HIP_LIB; else export PACE_HIP_LIB=$R/$L; fi
+    python bench.py --no-cpu-baseline --no-traffic "$@" 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}
+print('$L', 'ms_per_step %.4f' % d['ms_per_step'], 'kernel_us %.1f' % (r.get('us_per_launch') or 0), 'other %.4f' % ((d.get('other_contract') or {}).get('ms_per_step') or 0))
+" | tee -a "$O/ab.txt"
+  done
+done

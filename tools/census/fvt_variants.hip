@@ -40,3 +40,15 @@ template __global__ void k_var_scalars_split<6, true, false>(Geo, FvMet, FvtScal
 template __global__ void k_var_scalars_split<6, false, true>(Geo, FvMet, FvtScalars);
 template __global__ void k_var_scalars_split<6, true, true>(Geo, FvMet, FvtScalars);
 #endif
+#if FVT_AVAILABLE
+// the resident-layout form (round 6)
+template <int MORD, bool EX, bool EY>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_var_scalars_res(Geo g, FvMet m, FvtScalars S) {
+  __shared__ FvtLdsScalarsRes L;
+  fvt_scalars_tile_res<MORD, EX, EY>(L, g, m, S, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template __global__ void k_var_scalars_res<6, false, false>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars_res<6, true, false>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars_res<6, false, true>(Geo, FvMet, FvtScalars);
+template __global__ void k_var_scalars_res<6, true, true>(Geo, FvMet, FvtScalars);
+#endif

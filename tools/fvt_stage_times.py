@@ -15,7 +15,7 @@ from pace_amd.fv3core.stencils._common import dptr  # noqa: E402
 from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, get_column_namelist  # noqa: E402
 from pace_amd.tile import DSW_ARGS, Env  # noqa: E402
 
-PARTS = ["footprint + metrics -> LDS", "damping + face values", "inner sweeps, q_i / q_j", "outer sweeps, fluxes, cell update"]
+PARTS = ["footprint -> LDS", "damping pass 1 + inner sweep", "outer sweep + damping pass 2", "face fluxes + cell update"]  # (the resident layout, round 6)
 SCALARS = ["delp", "w", "q_con", "pt", "winds"]
 
 
