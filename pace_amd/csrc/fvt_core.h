@@ -108,6 +108,10 @@ struct FvtLdsRes {
     } s;
   } u;
   double sqc[9];  // the tile's corner block with corners copied in x (corner tiles)
+  // edge tiles: the four A-grid spacings of the one-sided PPM forms along the tile's edge, per footprint row (x sweeps) and column
+  // (y sweeps): staged once per tile -- every sweep of every pass used to load them from memory right in front of its arithmetic
+  double spx[QH * 4], spy[QW * 4];
+  int fxs[64 * 7];  // corner tiles: the places of the damping's corner cells (FvtTile fx_at, fx_src), derived once per tile
 };
 
 // order pin for the instruction scheduler (register pressure: operands that are only needed after a PPM run are loaded after it)
@@ -294,7 +298,9 @@ struct FvtTile {
   int fx_at, fx_src[6];
   double *plane, *sdv, *sdu;
 
-  __device__ __forceinline__ FvtTile(LT& L_, const Geo& g_, const FvMet& m_, int bx, int by, int k_, int tid_) : L(L_), g(g_), m(m_) {
+  // fx_cached (resident form, corner tiles): the corner cells' places are read from L.fxs (put there by publish_corner_places)
+  __device__ __forceinline__ FvtTile(LT& L_, const Geo& g_, const FvMet& m_, int bx, int by, int k_, int tid_, bool fx_cached = false)
+      : L(L_), g(g_), m(m_) {
     tid = tid_;
     k = k_;
     i0 = g.is + bx * TI, j0 = g.js + by * TJ;
@@ -351,7 +357,13 @@ struct FvtTile {
       sdu = sdv + QH * P;
     }
     fx_at = -1;
-    if (RC && tid < 64) {
+    if (RC && tid < 64 && fx_cached) {
+      if constexpr (RES) {
+        fx_at = L.fxs[tid * 7];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) fx_src[d] = L.fxs[tid * 7 + 1 + d];
+      }
+    } else if (RC && tid < 64) {
       const int q = tid >> 4, a = tid & 3, b = (tid >> 2) & 3;
       const int gi = (q & 1) ? g.ie + a : g.is - 3 + a;
       const int gj = (q & 2) ? g.je + b : g.js - 3 + b;
@@ -401,6 +413,10 @@ struct FvtTile {
   // per tile instead of one per scalar) ...
   __device__ __forceinline__ void fetch_footprint(const real* __restrict__ q, D2* v) const { pc.load(q, v); }
   // ... and the pieces' way into the LDS (+ the halo copy and the corner values, which read q again)
+  // DEFER (corner tiles of the resident form): the corner block's cells are filled by corners_from_lds() behind the caller's next
+  // barrier, from the footprint itself -- every source of a corner copy lies in the tile's own footprint -- instead of by dependent
+  // global loads here (a corner tile's footprint stage took 10 k cycles per pass against 1.3 k of an interior one)
+  template <bool DEFER = false>
   __device__ __forceinline__ void place_footprint(const real* __restrict__ q, const D2* v, real* __restrict__ halo_out = nullptr) {
     if ((EX || EY) && halo_out) {
 #pragma unroll
@@ -417,7 +433,7 @@ struct FvtTile {
       }
     }
     pc.store(L.sq, v);
-    if (RC) {  // corner tile: the corner block holds the values copy_corners_y puts there (corners.py:367-425); the thread that
+    if (RC && !DEFER) {  // corner tile: the corner block holds the values copy_corners_y puts there (corners.py:367-425); the thread that
                // stored a piece overwrites its corner cells (same thread, same address: program order)
 #pragma unroll
       for (int p = 0; p < Pieces::NP; ++p) {
@@ -492,6 +508,73 @@ struct FvtTile {
       int ri = (west ? g.is - 3 : g.ie + 1) + a, rj = (south ? g.js - 3 : g.je + 1) + b;
       remap_agrid_x(g, ri, rj);
       L.sqc[tid] = L.sqc[tid] + LDG(add2d, (unsigned)(rj * sj8 + ri * RB));
+    }
+    __syncthreads();
+  }
+
+  __device__ __forceinline__ void publish_corner_places() {
+    if constexpr (RES) {
+      if (RC && tid < 64) {
+        L.fxs[tid * 7] = fx_at;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) L.fxs[tid * 7 + 1 + d] = fx_src[d];
+      }
+    }
+  }
+  // edge tiles of the resident form: the spacings of the one-sided PPM forms into L.spx / L.spy (the caller's next barrier publishes)
+  __device__ __forceinline__ void stage_spacings() {
+    if constexpr (RES) {
+      if (EX && tid < QH) {
+        const int first = west ? g.is - 2 : g.ie - 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) L.spx[tid * 4 + t] = LDG(m.dxa, (unsigned)((jlo + tid) * sj8 + (first + t) * RB));
+      }
+      if (EY && tid >= 64 && tid < 64 + QW) {
+        const int cidx = tid - 64, first = south ? g.js - 2 : g.je - 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) L.spy[cidx * 4 + t] = LDG(m.dya, (unsigned)((first + t) * sj8 + (ilo + cidx) * RB));
+      }
+    }
+  }
+  // Corner tile, after the barrier that publishes the footprint: the corner block <- what copy_corners_y puts there, sqc <- what
+  // copy_corners_x puts there (and, if given, to the output buffer's corner block: what the reference leaves in q), all from the
+  // footprint in LDS.  The caller passes a barrier before anything reads the block.
+  __device__ __forceinline__ void corners_from_lds(real* __restrict__ halo_out) {
+    if (!RC) return;
+    const int t = tid < 9 ? tid : tid - 16;
+    if (t < 0 || t >= 9) return;
+    const int b = t / 3, a = t - b * 3;
+    const int di = (west ? g.is - 3 : g.ie + 1) + a, dj = (south ? g.js - 3 : g.je + 1) + b;
+    int ri = di, rj = dj;
+    if (tid < 9) {
+      remap_agrid_y(g, ri, rj);
+      L.sq[(dj - jlo) * P + (di - ilo)] = L.sq[(rj - jlo) * P + (ri - ilo)];
+    } else {
+      remap_agrid_x(g, ri, rj);
+      const double cv = L.sq[(rj - jlo) * P + (ri - ilo)];
+      L.sqc[t] = cv;
+      if (halo_out) STG(halo_out, (unsigned)(dj * sj8 + di * RB)) = (real)cv;
+    }
+  }
+  // add_2d for the resident form: every thread adds to the pieces it loaded, a corner tile's corner cells are copied again from
+  // their (now absolute) sources -- the same sums, formed once.  Ends with a barrier.
+  __device__ __forceinline__ void add_2d_lds(const real* __restrict__ add2d) {
+    D2 v[Pieces::NP];
+    pc.load(add2d, v);
+#pragma unroll
+    for (int p = 0; p < Pieces::NP; ++p) {
+      if (pc.own(p)) {  // (each piece once: the clamped repeats would add twice)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int gi = ilo + 2 * pc.lc + e, gj = jlo + pc.row[p];
+          if (RC && (gi < g.is || gi > g.ie) && (gj < g.js || gj > g.je)) continue;
+          L.sq[pc.row[p] * P + 2 * pc.lc + e] = L.sq[pc.row[p] * P + 2 * pc.lc + e] + (e == 0 ? v[p].x : v[p].y);
+        }
+      }
+    }
+    if (RC) {
+      __syncthreads();
+      corners_from_lds(nullptr);
     }
     __syncthreads();
   }
@@ -1606,6 +1689,8 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
     for (int s = 0; s < 4; ++s) T.fetch_footprint(S.q[s] + kb, fp[s]);
     if (S.winds) T.fetch_footprint(S.q[4] + kb, fp[4]);
     T.stage_damping_planes();  // once per tile
+    T.stage_spacings();
+    T.publish_corner_places();
     const unsigned roff = xrole ? T.xoff : T.yoff;
     if (xrole) {
 #pragma unroll
@@ -1635,16 +1720,25 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
     const double d0 = mass_weighted ? 1.0 : damp;
     const int iters = (S.nord[s][k] > 0.0) ? S.nmax[s] : 0;  // passes of the damping before its fluxes: 0, 1 or 2 (block-uniform)
     // the thread's places, derived again for every scalar: only the operands above live through the whole kernel
-    Tile T(L, g, m, bx, by, k, FVT_LAUNDER(tid));
+    Tile T(L, g, m, bx, by, k, FVT_LAUNDER(tid), s > 0);  // (pass 0's barrier has published the corner cells' places)
     const unsigned roff = xrole ? T.xoff : T.yoff;
     const bool run_outer = xrole ? T.x_outer : T.y_outer;
     const bool lane_lo = xrole ? (T.west && T.xg == 0) : (T.south && T.yg == 0);
     const bool lane_hi = xrole ? (T.east && T.xg == GXN - 1) : (T.north && T.yg == GYN - 1);
     const bool last_face = lane_hi;  // the run that stores the face past the end of the tile (ie + 1 / je + 1)
+    // the one-sided forms' spacings, from the tile's LDS table (the same values fvt_spacing loads)
     auto spacing = [&]() {
       FvtSpacing sp;
-      if (EX && xrole) sp = fvt_spacing(m.dxa, (unsigned)((T.jlo + T.xrow) * sj8), RB, g.is, g.ie, lane_lo, lane_hi);
-      if (EY && !xrole) sp = fvt_spacing(m.dya, (unsigned)((T.ilo + T.ycol) * RB), sj8, g.js, g.je, lane_lo, lane_hi);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sp.d[t] = 0.0;
+      if (EX && xrole && (lane_lo || lane_hi)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sp.d[t] = L.spx[T.xrow * 4 + t];
+      }
+      if (EY && !xrole && (lane_lo || lane_hi)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sp.d[t] = L.spy[T.ycol * 4 + t];
+      }
       return sp;
     };
     // the damping flux through face f of the thread's run, from the last iterate (q itself if no pass ran)
@@ -1661,7 +1755,7 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
     } else {
       T.load_damping_rarea();
     }
-    T.place_footprint(q, fp[s], qout);
+    T.template place_footprint<true>(q, fp[s], qout);
     constexpr int BW = TI + 1, NBP = (BW * (TJ + 1) + NT - 1) / NT;
     double bke[NBP], bvb[NBP];  // the winds: kinetic energy and damped vorticity at the tile's B-grid points, on their way
     if (is_vort) {
@@ -1675,8 +1769,26 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
         bvb[t] = LDG(S.vort_b + kb, o);
       }
     }
+    if (is_vort && (EX || EY) && S.copy_wind_halo) {
+      // the output buffers of the winds get the halo the inputs have (the caller swaps the buffers): this tile's share of the
+      // storage outside the faces the kernel writes -- u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je].  Here, at the top of
+      // the pass, the copy travels under the pass (at its end it was 4.5 k cycles of an edge tile's 110 k with nothing beside it).
+      const int xa = T.west ? 0 : T.i0, xb = T.east ? g.ni : T.i0 + TI, ya = T.south ? 0 : T.j0, yb = T.north ? g.nj : T.j0 + TJ;
+      const int bw = xb - xa, nbox = bw * (yb - ya);
+      for (int e = tid; e < nbox; e += NT) {
+        const int r = e / bw, i = xa + (e - r * bw), j = ya + r;
+        const unsigned o = (unsigned)(j * sj8 + i * RB);
+        const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
+        if (!(in_i && (in_j || j == g.je + 1))) STG(S.u_out + kb, o) = LDG(S.u + kb, o);
+        if (!((in_i || i == g.ie + 1) && in_j)) STG(S.v_out + kb, o) = LDG(S.v + kb, o);
+      }
+    }
     FVT_ARRIVE(4 * s);
     __syncthreads();
+    if (Tile::RC) {  // a corner tile: its corner block from the footprint (copy_corners_y; copy_corners_x to sqc and to the output)
+      T.corners_from_lds(qout);
+      __syncthreads();
+    }
     FVT_STAMP(4 * s + 1);
 
     // ---- interval 1: damping pass 1 (q -> iterate) and the inner sweep (q -> q_i / q_j, its fluxes to the faces' places)
@@ -1698,7 +1810,7 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
     }
     if (is_vort) {
       __syncthreads();      // (the pass above has read the relative vorticity)
-      T.add_2d(S.fC);       // ... the transported scalar is the absolute one (d_sw.py:389-402); ends with a barrier
+      T.add_2d_lds(S.fC);   // ... the transported scalar is the absolute one (d_sw.py:389-402); ends with a barrier
     }
     double si_last = 0.0;
     double* const slot = xrole ? L.u.s.ax + T.xr * PJ + C * T.xg : L.u.s.ay + (C * T.yg) * TI + T.ycol - 3;  // of the run's first face
@@ -1934,19 +2046,6 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
           } else if (any) {
             fvt_accumulate((real*)((char*)(S.heat_source + kb) + c2[t]), heat_s);
           }
-        }
-      }
-      if ((EX || EY) && S.copy_wind_halo) {
-        // the output buffers of the winds get the halo the inputs have (the caller swaps the buffers): this tile's share of the
-        // storage outside the faces the kernel writes -- u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je]
-        const int xa = T.west ? 0 : T.i0, xb = T.east ? g.ni : T.i0 + TI, ya = T.south ? 0 : T.j0, yb = T.north ? g.nj : T.j0 + TJ;
-        const int bw = xb - xa, nbox = bw * (yb - ya);
-        for (int e = tid; e < nbox; e += NT) {
-          const int r = e / bw, i = xa + (e - r * bw), j = ya + r;
-          const unsigned o = (unsigned)(j * sj8 + i * RB);
-          const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
-          if (!(in_i && (in_j || j == g.je + 1))) STG(S.u_out + kb, o) = LDG(S.u + kb, o);
-          if (!((in_i || i == g.ie + 1) && in_j)) STG(S.v_out + kb, o) = LDG(S.v + kb, o);
         }
       }
       return;

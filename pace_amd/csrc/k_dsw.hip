@@ -190,8 +190,18 @@ k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restri
 
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
 __global__ void __launch_bounds__(256)
-k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ vort) {
+k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ vort, real* __restrict__ u_halo,
+            real* __restrict__ v_halo) {
   PATCH_IJK(g);
+  // u_halo / v_halo (separate outputs of the winds, which the caller swaps in): the output buffers get the halo the inputs have --
+  // the storage outside the faces d_sw writes, u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je].  Here the copy rides on a
+  // kernel that reads u and v at every point anyway (inside the scalar-phase kernel it cost an edge tile 4.5 - 8 k cycles).
+  if (u_halo != nullptr) {
+    const long ch = IDX3(g, i, j, k);
+    const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
+    if (!(in_i && (in_j || j == g.je + 1))) u_halo[ch] = u[ch];
+    if (!((in_i || i == g.ie + 1) && in_j)) v_halo[ch] = v[ch];
+  }
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -1659,7 +1669,9 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
       if (winds_in_scalars) {
         wd.rel_vort = W.wk, wd.u = u, wd.v = v, wd.ke = W.ke, wd.vort_b = W.vort_b, wd.heat_source = heat_source;
         wd.u_out = cfg->u_out ? cfg->u_out : W.umid, wd.v_out = cfg->v_out ? cfg->v_out : W.vmid;
-        wd.copy_halo = cfg->u_out != nullptr, wd.do_skeb = cfg->do_skeb, wd.d_con = cfg->d_con;
+        // (the halo of separate wind outputs: copied by k_vorticity when this call runs it, by the kernel's edge tiles when the
+        // kernel is launched alone -- phases 256, a measurement aid)
+        wd.copy_halo = cfg->u_out != nullptr && !(phases & (4 | 64)), wd.do_skeb = cfg->do_skeb, wd.d_con = cfg->d_con;
         wd.ke_plus_vort = ke_by_consumer;
       }
       rc = launch_dsw_scalars_lean(g, m, delp, pt, w, q_con, pingpong ? scalar_outs : ws_outs, crx, cry, xfx, yfx, mfx, mfy, W.dw,
@@ -1725,7 +1737,10 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
+  // (with separate wind outputs the halo of the output buffers is copied here: see k_vorticity)
+  const bool halo_here = winds_in_scalars && cfg->u_out != nullptr;
+  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk, halo_here ? cfg->u_out : (real*)nullptr,
+                     halo_here ? cfg->v_out : (real*)nullptr);
   }
   if (phases & (4 | 128)) {
   // winds A2: divergence damping
