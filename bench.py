@@ -945,7 +945,15 @@ def main():
 
             # what the collective library saw (RCCL is reached through torch.distributed's "nccl" backend)
             line["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                            "phase_ms_max_over_ranks_synchronised": phase_ms}
+                            "exchanges_per_step": {"uc,vc (vector, before d_sw)": exchange_winds.message_bytes(),
+                                                   "delp,pt,q_con (after d_sw, under riem_solver3)": exchange.message_bytes()},
+                            "exchanges_note": "bytes of the one message per neighbour and update, rank 0; AcousticDynamics has seven such "
+                                              "groups per substep (dyn_core.py:720-942), this step the two that surround d_sw",
+                            "phase_ms_max_over_ranks_synchronised": phase_ms,
+                            "phase_note": "the step once more with the device synchronised after every phase (diagnosis, not the timed "
+                                          "region): what overlaps in the timed loop -- the interior of the flux preparation with the uc / vc "
+                                          "exchange, riem_solver3 with the delp / pt / q_con exchange -- is serial here, so "
+                                          "sum(phases) - ms_per_step is what the overlap hides"}
             if full_loop is not None:
                 line["comm"]["full_loop"] = full_loop
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only

@@ -249,6 +249,11 @@ class HaloUpdater:
     def force_finalize_on_wait(self):
         pass
 
+    def message_bytes(self):
+        """{peer rank: bytes of the ONE message this updater sends to it per update} (each of the up to four neighbours gets its
+        strips of all the group's fields in one buffer: halo_updater.py:217-303 sends one per field and edge)."""
+        return {int(peer): int(sum(s.size for s in strips) * self._msgs.itemsize) for peer, strips in self._msgs.send.items()}
+
     def start(self, quantities_x: List, quantities_y: Optional[List] = None):
         if self._inflight is not None:
             raise RuntimeError("Previous exchange hasn't been properly finished."

@@ -626,13 +626,14 @@ def _loop_child(n, nz, n_split, out_path, geometry="synthetic", timestep=None):
         pickle.dump(got, f)
 
 
-@pytest.mark.parametrize("geometry", ["synthetic", "sphere"])
-def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path, geometry):
-    """BASELINE configuration 3: the FULL acoustic loop (c_sw, updatedzc, riem_solver_c, p_grad_c, d_sw, updatedzd,
-    riem_solver3, pe / pk3 halo, nh_p_grad, ray_fast, del2cubed, heating; every halo-update group) at C96 x 79, six tiles
-    resident on the device and joined by the cubed-sphere exchange, every operator running on its predecessor's output,
-    against oracle/dyn_core.py.  Tolerances: what the vertical solvers feed (device exp / log) 5e-6 = the reference's
-    Riem_Solver3 bound; masses, temperatures, pressures, mass fluxes 1e-9 (the reference's DynCore bound is 2e-6)."""
+@pytest.mark.parametrize("n,geometry", [(96, "synthetic"), (96, "sphere"), (192, "sphere")], ids=["c96-synthetic", "c96-sphere", "c192-sphere"])
+def test_full_acoustic_loop_six_tiles_matches_oracle(lib, tmp_path, n, geometry):
+    """BASELINE configurations 3 and 4 (minus the wire): the FULL acoustic loop (c_sw, updatedzc, riem_solver_c, p_grad_c, d_sw,
+    updatedzd, riem_solver3, pe / pk3 halo, nh_p_grad, ray_fast, del2cubed, heating; every halo-update group) at C96 x 79 and at
+    C192 x 79, six tiles resident on ONE device and joined by the cubed-sphere exchange (the seven grouped exchanges per substep
+    of halo_updater.py:217-303 / dyn_core.py:720-942 between tiles of the same device: what six GPUs do over RCCL), every operator
+    running on its predecessor's output, against oracle/dyn_core.py.  Tolerances: the reference's DynCore bound, 2e-6, for what the
+    vertical solvers feed; masses, temperatures, pressures 1e-12."""
     import json
     import os
     import pickle
@@ -641,10 +642,10 @@ def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path, geometry
 
     import opchain
 
-    n, nz, n_split = 96, 79, 1
+    nz, n_split = 79, 1
     # synthetic: six copies of pace_amd/synthetic.py's tile (dt from its own Courant number); sphere: the gnomonic cubed sphere
     # with the baroclinic case's state (tests/opchain.py six_tile_inputs_sphere) and the C96 namelist's acoustic substep
-    timestep = 3.571 * n_split if geometry == "synthetic" else 112.5 * n_split
+    timestep = 3.571 * n_split if geometry == "synthetic" else (112.5 if n <= 96 else 56.25) * n_split  # (the C96 / C192 namelists' acoustic substeps)
     out = os.path.join(str(tmp_path), "loop.pkl")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (f"import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); "
@@ -659,7 +660,7 @@ def test_full_acoustic_loop_c96_six_tiles_matches_oracle(lib, tmp_path, geometry
     errs = opchain.loop_errors(ref, got, n, nz, detail=detail, geometry=geometry)
     out_dir = os.path.join(root, "gpurun_out")
     if os.path.isdir(out_dir):
-        json.dump(detail, open(os.path.join(out_dir, f"acoustic_loop_c96_{geometry}_gpu_errors.json"), "w"), indent=1)
+        json.dump(detail, open(os.path.join(out_dir, f"acoustic_loop_c{n}_{geometry}_gpu_errors.json"), "w"), indent=1)
     for k, e in errs.items():
         assert e < opchain.LOOP_TOL.get(k, 1e-9), (k, e)
         # the ABSOLUTE error, as a fraction of the field's magnitude, is bounded on both geometries: the floors of the relative

@@ -423,6 +423,9 @@ def test_bench_six_ranks_dry_run_over_gloo(tmp_path):
     assert out["value"] > 0 and "EMULATION" in out["data"]
     # what a first real 6-GPU run needs for its diagnosis: the collective library's view and the per-phase times
     assert out["comm"]["world_size"] == 6 and out["comm"]["backend"] == "gloo"
+    # the bytes per neighbour of the two exchanges of the step: four neighbours each; scalars: 3 fields x 3 halo rows x n x nz
+    ex = out["comm"]["exchanges_per_step"]
+    assert len(ex) == 2 and all(len(v) == 4 and min(v.values()) > 0 for v in ex.values()), ex
     ph = out["comm"]["phase_ms_max_over_ranks_synchronised"]
     assert set(ph) == {"uc_vc_start(pack+post)", "flux_prep_interior", "uc_vc_wait(+unpack)", "d_sw_rest", "delp_pt_qcon_start(pack+post)",
                        "delp_pt_qcon_wait(+unpack)", "riem_solver3"}
