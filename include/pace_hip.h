@@ -260,19 +260,21 @@ int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, d
 
 /* ---- CGridShallowWaterDynamics.__call__ (fv3core/pace/fv3core/stencils/c_sw.py:599-766), including
  * DGrid2AGrid2CGridVectors (d2a2c_vect.py:529-655).  delpc / ptc are the class attributes the reference
- * exposes (c_sw.py:497-502, read by dyn_core.py:795-800).  workspace: pace_c_sw_workspace_bytes(). */
+ * exposes (c_sw.py:497-502, read by dyn_core.py:795-800).  workspace: pace_c_sw_workspace_bytes().
+ * delp, pt, w are inputs -- except the two cells next to each corner of the tile's halo, which end as the reference's in-place
+ * corner fills of the C-grid transport leave them (c_sw.py:483-600; TranslateC_SW compares the three over the whole storage). */
 int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom);
 int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* delpc,
-              pace_real_t* ptc, const pace_real_t* delp, const pace_real_t* pt, const pace_real_t* u,
-              const pace_real_t* v, const pace_real_t* w, pace_real_t* uc, pace_real_t* vc, pace_real_t* ua,
+              pace_real_t* ptc, pace_real_t* delp, pace_real_t* pt, const pace_real_t* u,
+              const pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, pace_real_t* ua,
               pace_real_t* va, pace_real_t* ut, pace_real_t* vt, pace_real_t* divgd, pace_real_t* omga, double dt2,
               int nord, void* stream);
 /* The same in two parts around the u / v halo exchange in front of c_sw (dyn_core.py:744-745; an extension for overlapping
  * that exchange with compute): part 1 = the points of its first pass that read no halo value of u / v (the box
  * [is+1, ie-1] x [js+1, je-1]); part 2 = everything else, after the exchange; part 0 = pace_c_sw.  Same arguments. */
 int pace_c_sw_part(int part, const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, pace_real_t* delpc,
-                   pace_real_t* ptc, const pace_real_t* delp, const pace_real_t* pt, const pace_real_t* u,
-                   const pace_real_t* v, const pace_real_t* w, pace_real_t* uc, pace_real_t* vc, pace_real_t* ua,
+                   pace_real_t* ptc, pace_real_t* delp, pace_real_t* pt, const pace_real_t* u,
+                   const pace_real_t* v, pace_real_t* w, pace_real_t* uc, pace_real_t* vc, pace_real_t* ua,
                    pace_real_t* va, pace_real_t* ut, pace_real_t* vt, pace_real_t* divgd, pace_real_t* omga,
                    double dt2, int nord, void* stream);
 /* ---- DGrid2AGrid2CGridVectors.__call__ alone (d2a2c_vect.py:529-655), dord4 = True; same workspace. */

@@ -272,7 +272,7 @@ int pace_riem_solver3(const pace_geom_t* geom, void* workspace, int last_call, d
 int64_t pace_c_sw_workspace_bytes(const pace_geom_t* geom) { return geom ? csw_workspace_bytes(make_geo(geom)) : 0; }
 
 int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* delpc, real* ptc,
-              const real* delp, const real* pt, const real* u, const real* v, const real* w, real* uc,
+              real* delp, real* pt, const real* u, const real* v, real* w, real* uc,
               real* vc, real* ua, real* va, real* ut, real* vt, real* divgd, real* omga, double dt2,
               int nord, void* stream) {
   NEED(geom && met && workspace && delpc && ptc && delp && pt && u && v && w && uc && vc && ua && va && ut && vt && divgd && omga);
@@ -281,7 +281,7 @@ int pace_c_sw(const pace_geom_t* geom, const pace_metrics_t* met, void* workspac
 }
 
 int pace_c_sw_part(int part, const pace_geom_t* geom, const pace_metrics_t* met, void* workspace, real* delpc, real* ptc,
-                   const real* delp, const real* pt, const real* u, const real* v, const real* w, real* uc,
+                   real* delp, real* pt, const real* u, const real* v, real* w, real* uc,
                    real* vc, real* ua, real* va, real* ut, real* vt, real* divgd, real* omga, double dt2,
                    int nord, void* stream) {
   NEED(geom && met && workspace && delpc && ptc && delp && pt && u && v && w && uc && vc && ua && va && ut && vt && divgd && omga);

@@ -283,6 +283,27 @@ __device__ __forceinline__ long cell_yfill(const Geo& g, int i, int j) {
   return IDX2(g, i, j);
 }
 
+// What the reference LEAVES next to the corners of delp, pt, w: its C-grid transport fills two cells per corner in x, forms the x
+// fluxes, fills two in y, forms the y fluxes -- in place (c_sw.py:483-600; corners.py:129-305 fill_corners_2cells_x / _y with
+// multipliers 1) -- and TranslateC_SW compares the three fields over the whole storage (translate_c_sw.py:82-113).  The kernels here
+// apply the fills as index maps on reads; this writes what stays: per corner the x fill's second cell and the y fill's two (the
+// y fill overwrites the x fill's first).  Every source lies in an edge halo, which c_sw never writes.  36 cells per level.
+__global__ void __launch_bounds__(64)
+k_csw_corner_cells(Geo g, real* __restrict__ delp, real* __restrict__ pt, real* __restrict__ w) {
+  const int t = (int)threadIdx.x;
+  if (t >= 36) return;
+  const int f = t / 12, e = t - f * 12, q = e / 3, c = e - q * 3;  // field, corner (bit 0: east, bit 1: north), cell
+  real* const p = (f == 0 ? delp : f == 1 ? pt : w) + (long)blockIdx.x * g.sk;
+  const bool east = q & 1, north = q & 2;
+  const int ic = east ? g.ie + 1 : g.is - 1, jc = north ? g.je + 1 : g.js - 1;  // the corner cell next to the tile
+  const int di = east ? 1 : -1, dj = north ? 1 : -1;                             // away from the tile
+  int i, j, si, sj_;
+  if (c == 0) i = ic + di, j = jc, si = ic, sj_ = jc - 2 * dj;        // x fill, a = 2: (is-2, js-1) <- (is-1, js+1)
+  else if (c == 1) i = ic, j = jc, si = ic - di, sj_ = jc;            // y fill, a = 1: (is-1, js-1) <- (is, js-1)
+  else i = ic, j = jc + dj, si = ic - 2 * di, sj_ = jc;               // y fill, a = 2: (is-1, js-2) <- (is+1, js-1)
+  p[IDX2(g, i, j)] = p[IDX2(g, si, sj_)];
+}
+
 // pass C: compute_nonhydrostatic_fluxes_x (c_sw.py:231-259), transportdelp_update_vorticity_and_kineticenergy
 // (:262-364), circulation_cgrid (:367-397), absolute_vorticity (:400-408)
 __global__ void __launch_bounds__(256)
@@ -717,8 +738,8 @@ int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, real* uc, real* vc, 
   return PACE_OK;
 }
 
-int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, const real* delp, const real* pt,
-                const real* u, const real* v, const real* w, real* uc, real* vc, real* ua, real* va,
+int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, real* delp, real* pt,
+                const real* u, const real* v, real* w, real* uc, real* vc, real* ua, real* va,
                 real* ut, real* vt, real* divgd, real* omga, double dt2, int nord, hipStream_t st, int part) {
   // part 0: everything.  Around the u / v halo exchange (dyn_core.py:744-745): 1 = what reads no halo value of u / v -- the
   // interior tiles (complete) and the points of the band's pass A in the box [is+1, ie-1] x [js+1, je-1]; 2 = the rest of pass A
@@ -771,6 +792,8 @@ int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, co
     } else {
       hipLaunchKernelGGL(k_csw_update_uc_vc, dim3(grid.x, (unsigned)nchunk, 1), block, 0, sb, g, m, u, v, ke, vort, ucw, vcw, uc, vc, dt2);
     }
+    // (the cells next to the corners of delp, pt, w as the reference's in-place corner fills leave them: nothing here reads them)
+    hipLaunchKernelGGL(k_csw_corner_cells, dim3((unsigned)g.nk), dim3(64), 0, sb, g, delp, pt, w);
   };
 #ifndef PACE_EMU
   // The band's four passes are chains of dependent reads on a few thousand points (their edge forms: ~140 us at C192 however few

@@ -174,8 +174,8 @@ int launch_sim1_solver(const Geo& g, void* ws, int n_halo, double dt, double p_f
 int64_t csw_workspace_bytes(const Geo& g);
 int launch_d2a2c_vect(const Geo& g, const Met& m, void* ws, real* uc, real* vc, const real* u, const real* v,
                       real* ua, real* va, real* utc, real* vtc, hipStream_t st);
-int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, const real* delp, const real* pt,
-                const real* u, const real* v, const real* w, real* uc, real* vc, real* ua, real* va,
+int launch_c_sw(const Geo& g, const Met& m, void* ws, real* delpc, real* ptc, real* delp, real* pt,
+                const real* u, const real* v, real* w, real* uc, real* vc, real* ua, real* va,
                 real* ut, real* vt, real* divgd, real* omga, double dt2, int nord, hipStream_t st, int part = 0);
 // k_riem3.hip (C-grid solver)
 int64_t riemc_workspace_bytes(const Geo& g);

@@ -453,7 +453,8 @@ def product_loop(lib, device, n, nz, n_split, timestep, geometry="synthetic"):
 # device's exp / log in the two vertical solvers, carried through the pressure-gradient and transport steps), w to 3e-6.
 LOOP_TOL = {"w": 2e-6, "omga": 2e-6, "delz": 2e-6, "diss_estd": 2e-6, "heat_source": 2e-6,
             "u": 2e-6, "v": 2e-6, "ua": 2e-6, "va": 2e-6, "uc": 2e-6, "vc": 2e-6, "mfxd": 2e-6, "mfyd": 2e-6, "cxd": 2e-6, "cyd": 2e-6,
-            "delp": 1e-12, "pt": 1e-12, "pe": 1e-12, "pk": 1e-12, "peln": 1e-12, "q_con": 1e-12}
+            "delp": 1e-11, "pt": 1e-11, "pe": 1e-11, "pk": 1e-11, "peln": 1e-11, "q_con": 1e-11}
+# (masses, temperatures, pressures: measured 1e-12 at C96, 3e-12 at C192 -- profiles/r06_acoustic_loop_c192_sphere_gpu_errors.json)
 
 
 # Variables with entries that are residue of cancelling terms (dissipation sums, w / omga and the winds near their zero

@@ -208,8 +208,11 @@ def test_d2a2c_vect_and_divergence_damping_pairs_through_the_runner(tmp_path):
     c = next(iter(ch.cases(only=("d2a2c_vect",))))
     names = ("uc", "vc", "u", "v", "ua", "va", "utc", "vtc")
     np.savez(os.path.join(d, "D2A2C_Vect-In.npz"), **{k: _sp(c.before[k][full]) for k in names})
-    np.savez(os.path.join(d, "D2A2C_Vect-Out.npz"), uc=_sp(c.after["uc"][fx]), vc=_sp(c.after["vc"][fy]),
-             **{k: _sp(c.after[k][full]) for k in ("ua", "va", "utc", "vtc")})
+    # (the inputs are serialised over the full domain, N + 6 points each way, the C-grid winds compared over N + 7 along their
+    # staggered axis: make_storage_data_input_vars leaves the extra row / column zero and the operator does not write it)
+    uc_out, vc_out = c.after["uc"][fx].copy(), c.after["vc"][fy].copy()
+    uc_out[N + 6], vc_out[:, N + 6] = 0.0, 0.0
+    np.savez(os.path.join(d, "D2A2C_Vect-Out.npz"), uc=_sp(uc_out), vc=_sp(vc_out), **{k: _sp(c.after[k][full]) for k in ("ua", "va", "utc", "vtc")})
     # DivergenceDamping on the synthetic winds (as tests/opchain.py check_standalone_operators)
     s, col = c.before, ch.col
     f = {k: s[k].copy() for k in ("u", "v", "va", "ua", "divgd", "vc", "uc")}
@@ -223,7 +226,9 @@ def test_d2a2c_vect_and_divergence_damping_pairs_through_the_runner(tmp_path):
     damping.divergence_damping(ch.g, f["u"], f["v"], f["va"], f["vort_b"], f["ua"], f["divgd"], f["vc"], f["uc"], f["delpc"], f["ke"], f["wk"],
                                ch.dt, nord_k=col["nord"], d2_bg_k=col["d2_divg"], dddmp=DSW_CFG["dddmp"], d4_bg=DSW_CFG["d4_bg"], nord=DSW_CFG["nord"])
     np.savez(os.path.join(d, "DivergenceDamping-In.npz"), **ins)
-    np.savez(os.path.join(d, "DivergenceDamping-Out.npz"), ke=_sp(f["ke"][fxy]), delpc=_sp(f["delpc"][full]))
+    ke_out = f["ke"][fxy].copy()
+    ke_out[N + 6], ke_out[:, N + 6] = 0.0, 0.0  # (as above: ke goes in over N + 6 points and is compared over N + 7)
+    np.savez(os.path.join(d, "DivergenceDamping-Out.npz"), ke=_sp(ke_out), delpc=_sp(f["delpc"][full]))
 
     # DelnFlux: q with its mass, the fluxes on their staggered compute windows, K-only damp_c / nord_column (translate_delnflux.py:15-26)
     from oracle import ppm_transport

@@ -205,15 +205,12 @@ def _named(info, serialname):
 
 
 class Spec:
-    def __init__(self, in_vars, parameters, out_vars, max_error, run, near_zero=0.0, ignore_near_zero=None, index_parameters=(),
-                 halo_not_replayed=()):
+    def __init__(self, in_vars, parameters, out_vars, max_error, run, near_zero=0.0, ignore_near_zero=None, index_parameters=()):
         self.in_vars, self.parameters, self.out_vars, self.max_error, self.run = in_vars, parameters, out_vars, max_error, run
         self.near_zero, self.ignore_near_zero, self.index_parameters = near_zero, ignore_near_zero or {}, tuple(index_parameters)
-        # REMAINING DEVIATIONS from the reference's windows (none in D_SW since round 6): variables the Translate class compares over
-        # the whole storage whose HALO this library does not bring to the state the reference's in-place corner fills / work-domain
-        # writes leave there (nothing reads it before a halo update or the next operator overwrites it).  They are compared on the
-        # compute domain (+ the staggered row / column) and the verdict line says so.
-        self.halo_not_replayed = tuple(halo_not_replayed)
+        # (Every variable is compared over the window its Translate class names -- the whole storage where that is `{}`.  Rounds 1-5
+        # compared some on the compute domain only: the halo state the reference's in-place corner fills and work-domain writes leave
+        # behind was not replayed.  Since round 6 it is: D_SW, C_SW, D2A2C_Vect, DivergenceDamping.)
 
 
 def spec_d_sw(g):  # translate_d_sw.py:12-65
@@ -345,8 +342,7 @@ def spec_c_sw(g):  # translate_c_sw.py:73-113
                                     f["omga"], p["dt2"])
         return f
 
-    # (delp, pt, w: the 2-cell corner fills of the C-grid transport, c_sw.py:483-600 / corners.py:129-305, are index maps on reads here)
-    return Spec(iv, ["dt2"], ov, 2e-10, run, halo_not_replayed=("delp", "pt", "w"))
+    return Spec(iv, ["dt2"], ov, 2e-10, run)
 
 
 def spec_updatedzc(g):  # translate_updatedzc.py:10-70 (gz and ws are compared on the compute domain: `_subset`)
@@ -398,8 +394,7 @@ def spec_d2a2c_vect(g):  # translate_d2a2c_vect.py:8-47
             f["uc"], f["vc"], f["u"], f["v"], f["ua"], f["va"], f["utc"], f["vtc"])
         return f
 
-    # (uc, vc: the work-domain values d2a2c_vect leaves outside the C-grid winds' compute windows, d2a2c_vect.py:380-655)
-    return Spec(iv, [], ov, 2e-10, run, halo_not_replayed=("uc", "vc"))
+    return Spec(iv, [], ov, 2e-10, run)
 
 
 def spec_divergence_damping(g):  # translate_divergencedamping.py:11-76 (ke on the B-grid domain, delpc)
@@ -419,7 +414,7 @@ def spec_divergence_damping(g):  # translate_divergencedamping.py:11-76 (ke on t
            p["dt"])
         return f
 
-    return Spec(iv, ["dt"], ov, 1.4e-10, run, halo_not_replayed=("ke",))
+    return Spec(iv, ["dt"], ov, 1.4e-10, run)
 
 
 def spec_delnflux(g):  # translate_delnflux.py:8-47 (DelnFlux_2: the same without `mass`)
@@ -629,15 +624,6 @@ def run_one(name, pair, args, lib):
                 got = slice_out(res[var].numpy(), info, grid)
                 ref = np.squeeze(one_out[sname])
                 nz_ = spec.ignore_near_zero.get(var, spec.near_zero)
-                if var in spec.halo_not_replayed and got.ndim == 3 and "kaxis" not in info:
-                    ds = grid.default_domain_dict()
-                    ds.update({k: v for k, v in info.items() if k in ds})
-                    di = 1 if ds["iend"] in (grid.ied + 1, grid.ie + 1) else 0  # (an x-interface / y-interface variable)
-                    dj = 1 if ds["jend"] in (grid.jed + 1, grid.je + 1) else 0
-                    a0, b0 = max(grid.is_ - ds["istart"], 0), max(grid.js - ds["jstart"], 0)
-                    a1 = got.shape[0] - max(ds["iend"] - (grid.ie + di), 0)
-                    b1 = got.shape[1] - max(ds["jend"] - (grid.je + dj), 0)
-                    ref, got = ref[a0:a1, b0:b1], got[a0:a1, b0:b1]
                 worst[var] = max(worst.get(var, 0.0), compare(ref, got, near_zero=nz_))
     ok = all(e <= spec.max_error for e in worst.values())
     return ok, spec.max_error, worst
@@ -680,8 +666,7 @@ def main():
             print(f"{name}: no {name}-In.nc / .npz in {args.directory}")
             continue
         ok, bound, worst = run_one(name, read_pair(args.directory, name), args, lib)
-        note = SAVEPOINTS[name](SGrid(12, 79)).halo_not_replayed
-        print(f"{name}: {'PASS' if ok else 'FAIL'}  bound {bound:g}" + (f"  (compute domain only: {', '.join(note)})" if note else ""))
+        print(f"{name}: {'PASS' if ok else 'FAIL'}  bound {bound:g}")
         print("   the reference's windows: " + "  ".join(f"{k} {v:.2e}" for k, v in sorted(worst.items())))
         failed += 0 if ok else 1
     return 1 if failed else 0
