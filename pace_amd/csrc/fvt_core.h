@@ -1882,7 +1882,21 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
       }
     }
     double v[NF];
-    double wind[NF];  // the winds: the old wind on the run's faces, on its way while the sweep runs
+    // the winds: the old wind on the run's faces and the faces' grid spacings (dy, 1 / dy at the x-faces; dx, 1 / dx at the y-faces),
+    // on their way while the sweep runs (at the top of the face stage they were a round trip to memory with nothing beside it)
+    double wind[NF], dsp[NF], rdsp[NF];
+#ifndef FVT_HOIST_WIND
+#define FVT_HOIST_WIND 2  // the faces' spacings of the winds pass: 0 loaded where they are used, 1 before the outer sweep, 2 behind it
+#endif
+    auto load_spacings = [&]() {
+      if (xrole) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dsp[f] = LDG(m.dy, roff + (unsigned)(f * RB)), rdsp[f] = LDG(S.rdy, roff + (unsigned)(f * RB));
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dsp[f] = LDG(m.dx, roff + (unsigned)(f * sj8)), rdsp[f] = LDG(S.rdx, roff + (unsigned)(f * sj8));
+      }
+    };
     if (is_vort && run_outer) {
       if (xrole) {
 #pragma unroll
@@ -1891,6 +1905,7 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
 #pragma unroll
         for (int f = 0; f < NF; ++f) wind[f] = LDG(S.u + kb, roff + (unsigned)(f * sj8));
       }
+      if (FVT_HOIST_WIND == 1) load_spacings();
     }
     if (run_outer) {
       double Q[NF + 5], out[NF];
@@ -1918,6 +1933,7 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
       }
     }
     FVT_FENCE();
+    if (is_vort && run_outer && FVT_HOIST_WIND == 2) load_spacings();  // (behind the sweep: they travel under the damping's pass 2)
     double res2[DRC], fix2 = 0.0;
     if (iters >= 2) T.template deln_compute<false>(d0, res2, fix2);
     if (iters >= 2) {
@@ -1979,51 +1995,43 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
       double* const aubt = L.u.s.ay;
       double* const afy = L.u.s.sqi;
       if (run_outer) {
+        if (FVT_HOIST_WIND == 0) load_spacings();
         if (xrole) {  // x-faces: v-points (i0 + C * xg + f, j0 + xr)
-          double dyv[NF], rdyv[NF];
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            dyv[f] = LDG(m.dy, roff + (unsigned)(f * RB));
-            rdyv[f] = LDG(S.rdy, roff + (unsigned)(f * RB));
-          }
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
             const int b = T.xr * BW + C * T.xg + f;
             const double vf = v[f] * af[f];  // (the unit fluxes of the vorticity are the area fluxes)
-            const double vmid = wind[f] * dyv[f] + tke[b] - tke[b + BW] - vf;  // v_from_ke (d_sw.py:423-436)
+            const double vmid = wind[f] * dsp[f] + tke[b] - tke[b + BW] - vf;  // v_from_ke (d_sw.py:423-436)
             const double ut2 = iters == 0 ? fv0[f] : dface(f);
             const double vyd = don ? tvb[b] - tvb[b + BW] : 0.0;
-            const double vbt = (vyd - ut2) * rdyv[f];
-            const double fxh = vmid * rdyv[f];
+            const double vbt = (vyd - ut2) * rdsp[f];
+            const double fxh = vmid * rdsp[f];
             if (f < C || last_face) STG(S.v_out + kb, roff + (unsigned)(f * RB)) = upd ? vmid - ut2 : vmid;
             if (f < C || T.xg == GXN - 1) avbt[T.xr * PJ + C * T.xg + f] = vbt, afx[T.xr * PJ + C * T.xg + f] = fxh;
           }
         } else {  // y-faces: u-points (i0 + ycol - 3, j0 + C * yg + f)
-          double dxv[NF], rdxv[NF];
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            dxv[f] = LDG(m.dx, roff + (unsigned)(f * sj8));
-            rdxv[f] = LDG(S.rdx, roff + (unsigned)(f * sj8));
-          }
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
             const int b = (C * T.yg + f) * BW + T.ycol - 3;
             const double vf = v[f] * af[f];
-            const double umid = wind[f] * dxv[f] + tke[b] - tke[b + 1] + vf;  // u_from_ke (d_sw.py:406-420)
+            const double umid = wind[f] * dsp[f] + tke[b] - tke[b + 1] + vf;  // u_from_ke (d_sw.py:406-420)
             const double vt2 = iters == 0 ? fv0[f] : dface(f);
             const double vxd = don ? tvb[b] - tvb[b + 1] : 0.0;
-            const double ubt = (vxd + vt2) * rdxv[f];
-            const double fyh = umid * rdxv[f];
+            const double ubt = (vxd + vt2) * rdsp[f];
+            const double fyh = umid * rdsp[f];
             if (f < C || last_face) STG(S.u_out + kb, roff + (unsigned)(f * sj8)) = upd ? umid + vt2 : umid;
             if (f < C || T.yg == GYN - 1) aubt[(C * T.yg + f) * TI + T.ycol - 3] = ubt, afy[(C * T.yg + f) * TI + T.ycol - 3] = fyh;
           }
         }
       }
+      int jj[NCU], ii[NCU];
+      unsigned c2[NCU];
+      double rs2[NCU], csa[NCU];  // (loaded before the barrier: they travel while the last waves finish their faces)
+      T.cell_places(jj, ii, c2);
+#pragma unroll
+      for (int t = 0; t < NCU; ++t) rs2[t] = LDG(S.rsin2, c2[t]), csa[t] = LDG(S.cosa_s, c2[t]);
       __syncthreads();
       {
-        int jj[NCU], ii[NCU];
-        unsigned c2[NCU];
-        T.cell_places(jj, ii, c2);
         const bool any = S.d_con > 1e-5 || S.do_skeb;
 #pragma unroll
         for (int t = 0; t < NCU; ++t) {
@@ -2035,9 +2043,9 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
             const double vbt0 = avbt[ex], vbti = avbt[ex + 1], fx0 = afx[ex], fxi = afx[ex + 1];
             const double gy0 = fy0 * ubt0, gyj = fyj * ubtj, gx0 = fx0 * vbt0, gxi = fxi * vbti;
             const double u2 = fy0 + fyj, du2 = ubt0 + ubtj, v2 = fx0 + fxi, dv2 = vbt0 + vbti;
-            const double dampterm = LDG(S.rsin2, c2[t]) * 0.25 *
+            const double dampterm = rs2[t] * 0.25 *
                                     ((ubt0 * ubt0 + ubtj * ubtj + vbt0 * vbt0 + vbti * vbti) + 2.0 * (gy0 + gyj + gx0 + gxi) -
-                                     LDG(S.cosa_s, c2[t]) * (u2 * dv2 + v2 * du2 + du2 * dv2));
+                                     csa[t] * (u2 * dv2 + v2 * du2 + du2 * dv2));
             const double hs = nm[t] * (heat_s - dck * dampterm);
             if (any) {
               fvt_accumulate((real*)((char*)(S.heat_source + kb) + c2[t]), hs);
@@ -2050,16 +2058,16 @@ __device__ __forceinline__ void fvt_scalars_tile_res(FvtLdsScalarsRes& LS, const
       }
       return;
     }
+    int jj[NCU], ii[NCU];
+    unsigned c2[NCU];
+    double ra[NCU];  // (loaded before the barrier, like the winds' cell stage)
+    T.cell_places(jj, ii, c2);
+#pragma unroll
+    for (int t = 0; t < NCU; ++t) ra[t] = LDG(m.rarea, c2[t]);
     __syncthreads();
 
     // ---- interval 5: the cell update (apply_fluxes / apply_pt_delp_fluxes / adjust_w_and_qcon, d_sw.py:122-201,331-350)
     {
-      int jj[NCU], ii[NCU];
-      unsigned c2[NCU];
-      double ra[NCU];
-      T.cell_places(jj, ii, c2);
-#pragma unroll
-      for (int t = 0; t < NCU; ++t) ra[t] = LDG(m.rarea, c2[t]);
 #pragma unroll
       for (int t = 0; t < NCU; ++t) {
         const double am = LS.mass[(jj[t] + 1) * MP + ii[t] + 1];
