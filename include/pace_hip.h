@@ -80,8 +80,14 @@ typedef struct {
 #define PACE_DSW_SKIP_DEAD_OUTPUTS 1 /* delpc, divgd, uc, vc are not brought to the state the reference leaves them in: they are
                                       * work fields of DivergenceDamping (divergence_damping.py:561-600) that c_sw recomputes before
                                       * anything reads them again (d_sw.py:1032-1033, dyn_core.py:720-852).  Their contents are
-                                      * unspecified after the call; every other argument is unaffected, bit for bit.  This is what
-                                      * the acoustic loop asks for; the default (0) is the reference's full contract. */
+                                      * unspecified after the call, and so are the 3 x 3 corner blocks of the halo of delp, pt, w,
+                                      * q_con (which the next halo update overwrites); every other value of every other argument
+                                      * is unaffected, bit for bit.  This is what the acoustic loop asks for.
+                                      * The default (0) is the reference's FULL contract: every argument over the whole storage as
+                                      * TranslateD_SW compares it (translate_d_sw.py:36-65) -- the halo of divgd / uc / vc in the
+                                      * state the damping's in-place passes and corner fills leave it (divergence_damping.py:579-600),
+                                      * delpc's halo untouched, the corner blocks of the four scalars as FiniteVolumeTransport's
+                                      * in-place corner copies leave them (fvtp2d.py:262-345). */
 
 typedef struct {
   /* sizeof(pace_dsw_config_t) of the header the caller was built with: a mismatch is refused (PACE_ERR_ARG) instead of

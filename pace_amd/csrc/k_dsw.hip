@@ -196,7 +196,8 @@ k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v
   // u_halo / v_halo (separate outputs of the winds, which the caller swaps in): the output buffers get the halo the inputs have --
   // the storage outside the faces d_sw writes, u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je].  Here the copy rides on a
   // kernel that reads u and v at every point anyway (inside the scalar-phase kernel it cost an edge tile 4.5 - 8 k cycles).
-  if (u_halo != nullptr) {
+  // (one unsigned compare per axis decides for a whole interior wave that there is nothing to copy)
+  if (u_halo != nullptr && ((unsigned)(i - g.is) > (unsigned)(g.ie - g.is) || (unsigned)(j - g.js) > (unsigned)(g.je - g.js))) {
     const long ch = IDX3(g, i, j, k);
     const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
     if (!(in_i && (in_j || j == g.je + 1))) u_halo[ch] = u[ch];

@@ -3,7 +3,7 @@
 # profiles/).  Run from the repo root:  /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 # rocprofv3: the program itself after `--`, counters in their own passes, no tracing domain besides the kernel trace.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 export PACE_BENCH_CACHE=/tmp
 cd "$R"
 timeout 900 python bench.py > "$O/bench.json" 2> "$O/bench.err"
+timeout 600 python bench.py --full-outputs --no-cpu-baseline --no-traffic 2>/dev/null | tail -1 > "$O/bench_full_outputs.json"
 # (each size twice, the second line kept: the first run of a size on a fresh box pays for its set-up -- caches of the state, clocks)
 [ -x build/ubench_streams ] && ./build/ubench_streams > "$O/ubench_streams.txt" 2>&1
 timeout 600 python bench.py --precision 32 --tile-size 384 --nz 91 --no-cpu-baseline --state synthetic 2>/dev/null | tail -1 > "$O/f32_bench.jsonl"

@@ -1,7 +1,7 @@
 # SQ counters of the step's kernels (bench.py, C192 x 79), one group of counters per pass (MI355X_MICROARCH.md: counters in their
 # own runs, kernel trace only):  gpurun -- 'bash tools/collect_sq_counters.sh [tag]'  ->  gpurun_out/<tag>/sq_counters.json
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp PACE_BENCH_CACHE=/tmp
 python3 $R/bench.py --no-traffic --no-cpu-baseline --steps 2 > /dev/null 2>&1
 i=0
