@@ -188,21 +188,35 @@ k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restri
   kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, vort, i, j, k, interior, reg__ < nke);
 }
 
+// Separate outputs of the winds (which the caller swaps in): the output buffers get the halo the inputs have -- the storage outside
+// the faces d_sw writes, u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je].  The frame of the plane as four strips, one thread
+// per point: south rows [0, js), north rows (je, nj), and between them the west columns [0, is) and the east columns (ie, ni).
+// (Inside the scalar-phase kernel the copy cost an edge tile 4.5 - 8 k cycles; riding on k_vorticity it cost that kernel 7 us.)
+__global__ void __launch_bounds__(256)
+k_copy_wind_halo(Geo g, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ u_out, real* __restrict__ v_out) {
+  const int nsouth = g.js, nnorth = g.nj - 1 - g.je, nmid = g.je - g.js + 1, nwest = g.is, neast = g.ni - 1 - g.ie;
+  const int rows = (nsouth + nnorth) * g.ni, total = rows + nmid * (nwest + neast);
+  int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (p >= total) return;
+  int i, j;
+  if (p < rows) {
+    const int r = p / g.ni;
+    i = p - r * g.ni, j = r < nsouth ? r : g.je + 1 + (r - nsouth);
+  } else {
+    p -= rows;
+    const int w = nwest + neast, r = p / w, c = p - r * w;
+    j = g.js + r, i = c < nwest ? c : g.ie + 1 + (c - nwest);
+  }
+  const long ch = IDX3(g, i, j, (int)blockIdx.y);
+  const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
+  if (!(in_i && (in_j || j == g.je + 1))) u_out[ch] = u[ch];
+  if (!((in_i || i == g.ie + 1) && in_j)) v_out[ch] = v[ch];
+}
+
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
 __global__ void __launch_bounds__(256)
-k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ vort, real* __restrict__ u_halo,
-            real* __restrict__ v_halo) {
+k_vorticity(Geo g, Met m, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ vort) {
   PATCH_IJK(g);
-  // u_halo / v_halo (separate outputs of the winds, which the caller swaps in): the output buffers get the halo the inputs have --
-  // the storage outside the faces d_sw writes, u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je].  Here the copy rides on a
-  // kernel that reads u and v at every point anyway (inside the scalar-phase kernel it cost an edge tile 4.5 - 8 k cycles).
-  // (one unsigned compare per axis decides for a whole interior wave that there is nothing to copy)
-  if (u_halo != nullptr && ((unsigned)(i - g.is) > (unsigned)(g.ie - g.is) || (unsigned)(j - g.js) > (unsigned)(g.je - g.js))) {
-    const long ch = IDX3(g, i, j, k);
-    const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
-    if (!(in_i && (in_j || j == g.je + 1))) u_halo[ch] = u[ch];
-    if (!((in_i || i == g.ie + 1) && in_j)) v_halo[ch] = v[ch];
-  }
   if (i > g.ni - 2 || j > g.nj - 2) return;
   const long c = IDX3(g, i, j, k);
   const long c2 = IDX2(g, i, j);
@@ -1670,7 +1684,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
       if (winds_in_scalars) {
         wd.rel_vort = W.wk, wd.u = u, wd.v = v, wd.ke = W.ke, wd.vort_b = W.vort_b, wd.heat_source = heat_source;
         wd.u_out = cfg->u_out ? cfg->u_out : W.umid, wd.v_out = cfg->v_out ? cfg->v_out : W.vmid;
-        // (the halo of separate wind outputs: copied by k_vorticity when this call runs it, by the kernel's edge tiles when the
+        // (the halo of separate wind outputs: copied by k_copy_wind_halo when this call runs the wind phase, by the kernel's edge tiles when the
         // kernel is launched alone -- phases 256, a measurement aid)
         wd.copy_halo = cfg->u_out != nullptr && !(phases & (4 | 64)), wd.do_skeb = cfg->do_skeb, wd.d_con = cfg->d_con;
         wd.ke_plus_vort = ke_by_consumer;
@@ -1738,10 +1752,12 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   } else {
     return PACE_ERR_UNSUPPORTED;
   }
-  // (with separate wind outputs the halo of the output buffers is copied here: see k_vorticity)
-  const bool halo_here = winds_in_scalars && cfg->u_out != nullptr;
-  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk, halo_here ? cfg->u_out : (real*)nullptr,
-                     halo_here ? cfg->v_out : (real*)nullptr);
+  hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
+  // (with separate wind outputs the halo of the output buffers is copied here, by a launch of its own over the frame of the plane)
+  if (winds_in_scalars && cfg->u_out != nullptr) {
+    const int frame = (g.js + g.nj - 1 - g.je) * g.ni + (g.je - g.js + 1) * (g.is + g.ni - 1 - g.ie);
+    hipLaunchKernelGGL(k_copy_wind_halo, dim3((unsigned)((frame + 255) / 256), (unsigned)nk), dim3(256), 0, st, g, u, v, cfg->u_out, cfg->v_out);
+  }
   }
   if (phases & (4 | 128)) {
   // winds A2: divergence damping
