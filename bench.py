@@ -186,8 +186,10 @@ def _cpu_omp_job(args):
     while True:
         omp_port.set_threads(t)
         dsw.reset()
+        riem.reset()
         t0 = _t.perf_counter()
         dsw.run()
+        riem.run()  # (both operators: on a shared host the column solver's best team is not d_sw's)
         tried[t] = _t.perf_counter() - t0
         if best is None or tried[t] < best:
             best, best_t = tried[t], t
@@ -196,6 +198,8 @@ def _cpu_omp_job(args):
         t = min(2 * t, threads)
         dsw.work = omp_port._fresh(dsw.src)  # (first touch by the NEW team)
         dsw.fp = omp_port._ptrs(dsw.work)
+        riem.work = omp_port._fresh(riem.src)
+        riem.fp = omp_port._ptrs(riem.work)
     omp_port.set_threads(best_t)
     secs = []
     for _ in range(reps):
@@ -297,7 +301,7 @@ def cpu_baseline(n, nz, metrics, s, dt, ptop, reps=10, numpy_reps=3):
             port_err = max(port_err, float(np.abs(a_ - b_).max() / max(np.abs(a_).max(), 1e-300)))
     rec = {"value": n * n * nz / owall, "unit": "cell-updates/s", "cores": omp_threads, "kind": "port",
            "detail": "restatement, reference granularity: C++ / OpenMP, one parallel loop nest per reference stencil, i first, "
-                     f"OMP_NUM_THREADS = {omp_threads}, the fastest team size on this host (seconds of one d_sw per team size: {omp_tried}; "
+                     f"OMP_NUM_THREADS = {omp_threads}, the fastest team size on this host (seconds of one substep per team size: {omp_tried}; "
                      f"{ncpu} logical cores reported), threads {'pinned to cores (OMP_PROC_BIND=close)' if omp_bound else 'not pinned'} "
                      f"(the other way: {omp_other}), operands and workspace first touched by the team (oracle/omp/dsw_riem3.cpp)",
            "sample": f"{reps} substeps (d_sw + riem_solver3) at C{n}x{nz}L after 1 warm-up, the operands the GPU was timed on, median "

@@ -1163,8 +1163,14 @@ Work& work_for(const Grid& g, int fields) {
     W.n3 = n3;
     W.size = n3 * fields;
     W.buf = (double*)malloc(sizeof(double) * (size_t)W.size);
+    // (OMP_PORT_MASTER_TOUCH=1: zeroed by the calling thread, as rounds 1-5 did -- bench.py measures both)
+    const bool master = getenv("OMP_PORT_MASTER_TOUCH") != nullptr;
     for (int f = 0; f < fields; ++f) {
       double* p = W.buf + (long)f * n3;
+      if (master) {
+        memset(p, 0, sizeof(double) * (size_t)n3);
+        continue;
+      }
 #pragma omp parallel for schedule(static)
       for (int k = 0; k <= g.nk; ++k)
         for (long e = 0; e < g.sk; ++e) p[(long)k * g.sk + e] = 0.0;

@@ -63,7 +63,9 @@ def from_kji(dst, src):
 def team_copy(dst, src):
     """dst[...] = src through the library's team, level by level (3-D [k][j][i] arrays): the pages of a level are first touched
     by the thread that works on it.  Anything else: a plain copy."""
-    if dst.ndim == 3 and dst.flags.c_contiguous and src.flags.c_contiguous and dst.shape == src.shape:
+    if os.environ.get("OMP_PORT_MASTER_TOUCH"):  # (as rounds 1-5 did: the calling thread copies; bench.py measures both)
+        dst[...] = src
+    elif dst.ndim == 3 and dst.flags.c_contiguous and src.flags.c_contiguous and dst.shape == src.shape:
         load().omp_port_copy_levels(C.c_void_p(dst.ctypes.data), C.c_void_p(src.ctypes.data), C.c_long(dst.shape[0]), C.c_long(dst.shape[1] * dst.shape[2]))
     else:
         dst[...] = src
