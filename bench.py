@@ -49,6 +49,9 @@ def parse():
                         "the last substep of a remapping step does (default: skipped, as in every other substep of AcousticDynamics)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
+    p.add_argument("--no-other-contract", action="store_true",
+                   help="skip the timing of the substep under d_sw's other output contract (profiled runs: its launches would be averaged "
+                        "into the step's kernels)")
     p.add_argument("--watchdog", type=float, default=900.0, help="multi-rank runs: seconds after which a stuck run exits")
     p.add_argument("--exchange", choices=("on", "off"), default="on",
                    help="multi-rank runs: keep the delp/pt/q_con halo exchange inside the measured step (default) or run the tiles independently")
@@ -367,7 +370,7 @@ def measure_traffic(kernel_substring, n, nz, precision=64):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--steps", "3",
-                   "--warmup", "1", "--n", str(n), "--nz", str(nz), "--precision", str(precision), "--no-cpu-baseline", "--no-traffic"]
+                   "--warmup", "1", "--n", str(n), "--nz", str(nz), "--precision", str(precision), "--no-cpu-baseline", "--no-traffic", "--no-other-contract"]
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             if p.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-300:]}"
@@ -774,7 +777,7 @@ def main():
     # eighth.  (--full-outputs swaps the two.)  The state copies have been stepped once already: a second step of the same
     # arithmetic, same bytes.
     other_contract = None
-    if world == 1 and not use_graph:
+    if world == 1 and not use_graph and not args.no_other_contract:
         nb = min(10, len(batches))
 
         def step_other(b):

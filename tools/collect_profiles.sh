@@ -25,10 +25,10 @@ timeout 300 python tools/acoustic_bench.py --n 96 2>/dev/null | grep -v amdgpu >
 [ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/csw_stage_times.py 2>/dev/null | grep -v amdgpu | tail -3 > "$O/csw_tile_workgroup_timeline.txt"
 [ -f build/var/prof/libpace_hip.so ] && timeout 300 python tools/riem_stage_times.py 2>/dev/null | grep -v amdgpu > "$O/riem_stage_times.txt"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-traffic > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-other-contract --no-traffic > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace_loop" -o loop -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2> "$O/trace_loop.err"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-traffic > /dev/null 2>> "$O/pmc.err"
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-other-contract --no-traffic > /dev/null 2>> "$O/pmc.err"
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_loop_$c" -- python3 "$R/tools/acoustic_bench.py" --reps 3 > /dev/null 2>> "$O/pmc.err"
 done
 cd "$R"

@@ -9,7 +9,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VA
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/sqp$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic > /dev/null 2>> $O/sq_err.txt
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/sqp$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-contract --no-traffic > /dev/null 2>> $O/sq_err.txt
 done
 cd $R
 python tools/pmc_summary.py $O/sqp1 $O/sqp2 $O/sqp3 $O/sqp4 $O/sqp5 > $O/sq_counters_raw.json

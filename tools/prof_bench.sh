@@ -8,7 +8,7 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 cd /tmp
 D=/tmp/prof_$TAG; rm -rf $D; mkdir -p $D
-rocprofv3 --kernel-trace --stats -d $D -o t -- python3 $R/bench.py --no-cpu-baseline --no-traffic "$@" > "$O/bench.json" 2> "$O/trace.err"
+rocprofv3 --kernel-trace --stats -d $D -o t -- python3 $R/bench.py --no-cpu-baseline --no-other-contract --no-traffic "$@" > "$O/bench.json" 2> "$O/trace.err"
 DB=$(find $D -name '*.db' | head -1)
 cd "$R"
 [ -n "$DB" ] && python3 tools/rocprof_summary.py "$DB" > "$O/kernel_stats.csv"
