@@ -309,6 +309,61 @@ struct Mover {
   __device__ __forceinline__ bool has(int n, int nlev) const { return in && xl + 16 * n < nlev; }
 };
 
+// The same with SIXTEEN bytes per lane (round 6, experiment x31; -DRIEM_PAIR=1): a lane takes two neighbouring columns of one level, a
+// wave eight whole lines.  This chip's stream rates are 5.2 TB/s for 8-byte and 6.6 TB/s for 16-byte accesses
+// (profiles/r05_ubench_streams.txt), and the solver's load and store phases run at the former -- but the kernel is NOT faster with
+// pairs (104.5 against 100.1 us in the step, alternating builds on one box): its load phase waits for the first line to arrive, not
+// for the lines to stream.  Pairs that are not two neighbouring columns at an even place (the merged head / tail window when the
+// tail is odd, clamped places of a partial window) move as two single elements.  Off.
+#ifndef RIEM_PAIR
+#define RIEM_PAIR 0
+#endif
+struct alignas(2 * sizeof(real)) RiemPair {
+  real x, y;
+};
+template <int L>
+struct PairMover {
+  static constexpr int NP = (16 * L + 1 + 31) / 32;  // pieces per lane: levels xl + 32 n
+  int xl, x0;               // level (of the first piece), first of the lane's two places in the window
+  unsigned row0, row1, sk;  // element offsets of the two columns at level 0; level stride
+  bool in0, in1, contig;
+  __device__ __forceinline__ PairMover(const Geo& g, int cg, const ColumnWindows& cw, int bx, int j) {
+    int tid = threadIdx.x;
+    RIEM_OPAQUE(tid);
+    xl = tid >> 3;
+    x0 = 2 * (tid & 7);
+    const int c0 = cw.column(bx, x0, g.is - cg, g.ie + cg, in0), c1 = cw.column(bx, x0 + 1, g.is - cg, g.ie + cg, in1);
+    row0 = (unsigned)IDX2(g, c0, j), row1 = (unsigned)IDX2(g, c1, j);
+    sk = (unsigned)g.sk;
+    contig = c1 == c0 + 1 && (row0 & 1u) == 0 && (sk & 1u) == 0;
+  }
+  __device__ __forceinline__ int level(int n, int last) const {
+    const int lv = xl + 32 * n;
+    return lv < last ? lv : last;
+  }
+  __device__ __forceinline__ void load(const real* f, int n, int last, double& a, double& b) const {
+    const unsigned lo = (unsigned)level(n, last) * sk;
+    if (contig && ((uintptr_t)f & (2 * sizeof(real) - 1)) == 0) {
+      const RiemPair r = *(const RiemPair*)((const char*)f + (size_t)(row0 + lo) * sizeof(real));
+      a = r.x, b = r.y;
+    } else {
+      a = RIEM_LDG(f, (row0 + lo) * (unsigned)sizeof(real));
+      b = RIEM_LDG(f, (row1 + lo) * (unsigned)sizeof(real));
+    }
+  }
+  __device__ __forceinline__ void store(real* f, int n, int last, double a, double b) const {
+    const unsigned lo = (unsigned)level(n, last) * sk;
+    if (contig && in0 && in1 && ((uintptr_t)f & (2 * sizeof(real) - 1)) == 0) {
+      RiemPair r;
+      r.x = (real)a, r.y = (real)b;
+      *(RiemPair*)((char*)f + (size_t)(row0 + lo) * sizeof(real)) = r;
+    } else {
+      if (in0) RIEM_STG(f, (row0 + lo) * (unsigned)sizeof(real)) = (real)a;
+      if (in1) RIEM_STG(f, (row1 + lo) * (unsigned)sizeof(real)) = (real)b;
+    }
+  }
+};
+
 #ifndef RIEM_STAMP
 #define RIEM_STAMP(n)  // (tools/census/riem_prof.hip compiles shader-clock stamps in here)
 #endif
@@ -346,6 +401,30 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
   __shared__ double xs_[3][NLV * LP];
   // (the movers' addresses are rebuilt from the lane number at each of the three places they are used -- RIEM_OPAQUE keeps the
   // compiler from holding them in registers across the solver, which sits at the 168-register limit of three waves per SIMD)
+#if RIEM_PAIR
+#define MOVER() const PairMover<L> M(g, CG, cw, blockIdx.x, j)
+  constexpr int NPP = PairMover<L>::NP;
+  // fetch: the lane's pieces of a field with nlev levels (pieces beyond the last level repeat it)
+#define FETCH(v, f, nlev)                                                                          \
+  double v[NPP][2];                                                                                \
+  _Pragma("unroll") for (int n = 0; n < NPP; ++n) M.load(f, n, (nlev) - 1, v[n][0], v[n][1])
+#define PUT(b, v, nlev)                                                                            \
+  do {                                                                                             \
+    _Pragma("unroll") for (int n = 0; n < NPP; ++n) {                                              \
+      const int lv_ = M.xl + 32 * n;                                                               \
+      if (lv_ < NLV) xs_[b][lv_ * LP + M.x0] = v[n][0], xs_[b][lv_ * LP + M.x0 + 1] = v[n][1];     \
+    }                                                                                              \
+  } while (0)
+  // store: the lane's pieces of the LDS copy b go to field f (levels 0 .. nlev-1, the columns of the domain); a piece beyond the
+  // field's last level stores that level's value to that level's place once more, the same bits its owner stores
+#define STORE(b, f, nlev)                                                                          \
+  do {                                                                                             \
+    _Pragma("unroll") for (int n = 0; n < NPP; ++n) {                                              \
+      const int lv_ = M.level(n, (nlev) - 1);                                                      \
+      M.store(f, n, (nlev) - 1, xs_[b][lv_ * LP + M.x0], xs_[b][lv_ * LP + M.x0 + 1]);             \
+    }                                                                                              \
+  } while (0)
+#else
 #define MOVER() const Mover<L> M(g, CG, cw, blockIdx.x, j)
   // fetch: the pieces of a field with nlev levels (16 L + 1 at most: the last one is the extra piece of the movers of level 0)
 #define FETCH(v, f, nlev)                                                                          \
@@ -367,6 +446,7 @@ k_riem_column(Geo g, int last_call, double dt, double ptop, double p_fac, double
       if (16 * L < (nlev) && M.xl == 0) RIEM_STG(f, M.at(L, (nlev) - 1)) = xs_[b][M.slot(L)];      \
     }                                                                                              \
   } while (0)
+#endif  // RIEM_PAIR
 #define MINE(b, k) xs_[b][(k) * LP + col]
   const int k0 = r * L;
   const double t1g = 2.0 * dt * dt, rdt = 1.0 / dt;
