@@ -17,6 +17,7 @@ timeout 600 python bench.py --full-outputs --no-cpu-baseline --no-traffic 2>/dev
 timeout 600 python bench.py --precision 32 --tile-size 384 --nz 91 --no-cpu-baseline --state synthetic 2>/dev/null | tail -1 > "$O/f32_bench.jsonl"
 timeout 300 python tools/acoustic_bench.py --n 48 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench_c48.txt"
 for n in 48 96 384; do timeout 300 python bench.py --tile-size $n --no-cpu-baseline --no-traffic > /dev/null 2>&1; timeout 300 python bench.py --tile-size $n --no-cpu-baseline --no-traffic 2>/dev/null | tail -1; done > "$O/bench_sizes.jsonl"
+for n in 48 96; do timeout 300 python bench.py --tile-size $n --graph on --no-cpu-baseline --no-traffic 2>/dev/null | tail -1; done > "$O/bench_sizes_graph.jsonl"
 timeout 300 python tools/acoustic_bench.py 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench.txt"
 timeout 300 python tools/acoustic_bench.py --n 96 2>/dev/null | grep -v amdgpu > "$O/acoustic_bench_c96.txt"   # BASELINE configuration 3
 # stage times of the scalar-phase kernel's workgroups (interior / corner / edge tiles): tools/build_prof.sh builds the stamped library
@@ -36,6 +37,13 @@ DB=$(find "$O/trace" -name '*.db' | head -1)
 DBL=$(find "$O/trace_loop" -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" > "$O/kernel_stats.csv" && python tools/rocprof_timeline.py "$DB" > "$O/timeline.txt"
 [ -n "$DB" ] && python tools/rocprof_isolated.py "$DB" k_fvt_scalars > "$O/dominant_kernel_alone.txt"
+# the C48 step's timeline (launch- and round-trip-bound: where the gaps are)
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d "$O/trace48" -o b48 -- python3 "$R/bench.py" --tile-size 48 --no-cpu-baseline --no-other-contract --no-traffic > /dev/null 2>> "$O/trace.err"
+cd "$R"
+DB48=$(find "$O/trace48" -name '*.db' | head -1)
+[ -n "$DB48" ] && python tools/rocprof_timeline.py "$DB48" > "$O/timeline_c48.txt"
+rm -rf "$O/trace48"
 [ -n "$DBL" ] && python tools/rocprof_summary.py "$DBL" > "$O/whole_loop_kernel_stats.csv"
 python tools/pmc_summary.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" > "$O/pmc_traffic.json"
 python tools/step_table.py "$O/kernel_stats.csv" "$O/pmc_traffic.json" > "$O/step_table.json"
