@@ -1265,19 +1265,73 @@ __device__ __forceinline__ void ddh_dgrid_entry(const Geo& g, int e72, int& di, 
   }
 }
 
+// what a thread of k_divdamp_halo_state_lds knows of a band point -- the same at every level and in every call on a geometry:
+// [0] its offset in a plane, [1..4] the LDS places of its east / west / north / south neighbours, [5..8] those of the operands of
+// vc_from_divg / uc_from_divg with the corner fills applied as index maps (x fill: east, centre; y fill: north, centre), [9] flags
+enum { DDH_F_VD = 0, DDH_F_UD = 3, DDH_F_DD = 6, DDH_F_VW = 9, DDH_F_VWM = 10, DDH_F_UW = 11, DDH_F_UWM = 12, DDH_F_CS = 13, DDH_F_CN = 14,
+       DDH_F_OK = 15, DDH_F_OWN = 16 };
+#define DDH_TAB 10
+__device__ __forceinline__ void ddh_point_table(const Geo& g, const DdhBand& band, int p, int* t) {
+  constexpr int NONE = DDH_SLOTS;
+  int i = 0, j = 0;
+  const bool ok = p < band.total;
+  if (ok) band.point(p, i, j);
+  t[0] = (int)IDX2(g, i, j);
+  t[1] = band.slot(i + 1, j, NONE), t[2] = band.slot(i - 1, j, NONE), t[3] = band.slot(i, j + 1, NONE), t[4] = band.slot(i, j - 1, NONE);
+  int a = i + 1, b = j;
+  remap_bgrid_x(g, a, b);
+  t[5] = band.slot(a, b, NONE);
+  a = i, b = j;
+  remap_bgrid_x(g, a, b);
+  t[6] = band.slot(a, b, NONE);
+  a = i, b = j + 1;
+  remap_bgrid_y(g, a, b);
+  t[7] = band.slot(a, b, NONE);
+  a = i, b = j;
+  remap_bgrid_y(g, a, b);
+  t[8] = band.slot(a, b, NONE);
+  auto in_uwin = [&](int x, int y) { return x >= g.is && x <= g.ie + 1 && y >= g.js && y <= g.je; };
+  auto in_vwin = [&](int x, int y) { return x >= g.is && x <= g.ie && y >= g.js && y <= g.je + 1; };
+  unsigned f = 0;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    f |= (unsigned)(i >= g.is - nt - 1 && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) << (DDH_F_VD + nt);
+    f |= (unsigned)(i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt - 1 && j <= g.je + nt + 1) << (DDH_F_UD + nt);
+    f |= (unsigned)(i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) << (DDH_F_DD + nt);
+  }
+  const bool ic = (i == g.is || i == g.ie + 1);
+  const bool own = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1;
+  f |= (unsigned)in_vwin(i, j) << DDH_F_VW | (unsigned)in_vwin(i - 1, j) << DDH_F_VWM | (unsigned)in_uwin(i, j) << DDH_F_UW |
+       (unsigned)in_uwin(i, j - 1) << DDH_F_UWM;
+  f |= (unsigned)(ic && j == g.js) << DDH_F_CS | (unsigned)(ic && j == g.je + 1) << DDH_F_CN | (unsigned)ok << DDH_F_OK | (unsigned)own << DDH_F_OWN;
+  t[9] = (int)f;
+}
+// the tables of a geometry, [DDH_TAB][DDH_SLOTS] ints, built once per object (dsw_prepare) into the caller's workspace: the kernel
+// below then loads a thread's 4 x 10 words instead of deriving them at every level (~60 % of its 37 us)
+__global__ void __launch_bounds__(DDH_NT) k_ddh_tables(Geo g, int* __restrict__ tab) {
+  const DdhBand band(g, DDH_M);
+  for (int q = 0; q < DDH_PP; ++q) {
+    const int p = (int)threadIdx.x + DDH_NT * q;
+    int t[DDH_TAB];
+    ddh_point_table(g, band, p, t);
+#pragma unroll
+    for (int w = 0; w < DDH_TAB; ++w) tab[w * DDH_SLOTS + p] = t[w];
+  }
+}
+
 __global__ void __launch_bounds__(DDH_NT)
 k_divdamp_halo_state_lds(Geo g, Met m, const real* __restrict__ delpc, real* divg_d, real* __restrict__ uc, real* __restrict__ vc, int k0,
-                         int nord) {
+                         int nord, const int* __restrict__ tab) {
   __shared__ double sda[DDH_SLOTS + 1], sdb[DDH_SLOTS + 1], su[DDH_SLOTS + 1], sv[DDH_SLOTS + 1];  // (+ 1: the place of "no such point")
   constexpr int NONE = DDH_SLOTS;
   const int kk = (int)blockIdx.x + k0;
   const long kb = (long)kk * g.sk;
   const int tid = (int)threadIdx.x;
   const DdhBand band(g, DDH_M);
-  const int total = band.total;
   // what is stored in a field is rounded to the field's type (float32 build), as the passes through memory do
   auto stored = [](double x) { return (double)(real)x; };
-  enum { F_VD = 0, F_UD = 3, F_DD = 6, F_VW = 9, F_VWM = 10, F_UW = 11, F_UWM = 12, F_CS = 13, F_CN = 14, F_OK = 15, F_OWN = 16 };
+  enum { F_VD = DDH_F_VD, F_UD = DDH_F_UD, F_DD = DDH_F_DD, F_VW = DDH_F_VW, F_VWM = DDH_F_VWM, F_UW = DDH_F_UW, F_UWM = DDH_F_UWM,
+         F_CS = DDH_F_CS, F_CN = DDH_F_CN, F_OK = DDH_F_OK, F_OWN = DDH_F_OWN };
   int c2_[DDH_PP], sE_[DDH_PP], sW_[DDH_PP], sN_[DDH_PP], sS_[DDH_PP], xE_[DDH_PP], xC_[DDH_PP], yN_[DDH_PP], yC_[DDH_PP];
   unsigned fl_[DDH_PP];
   double gu0_[DDH_PP], gum_[DDH_PP], gv0_[DDH_PP], gvm_[DDH_PP], ra_[DDH_PP];
@@ -1285,42 +1339,21 @@ k_divdamp_halo_state_lds(Geo g, Met m, const real* __restrict__ delpc, real* div
 #pragma unroll
   for (int t = 0; t < DDH_PP; ++t) {
     const int p = tid + DDH_NT * t;
-    int i = 0, j = 0;
-    const bool ok = p < total;
-    if (ok) band.point(p, i, j);
-    const int c2 = (int)IDX2(g, i, j);
-    c2_[t] = c2;
-    sE_[t] = band.slot(i + 1, j, NONE), sW_[t] = band.slot(i - 1, j, NONE), sN_[t] = band.slot(i, j + 1, NONE), sS_[t] = band.slot(i, j - 1, NONE);
-    {
-      int a = i + 1, b = j;
-      remap_bgrid_x(g, a, b);
-      xE_[t] = band.slot(a, b, NONE);
-      a = i, b = j;
-      remap_bgrid_x(g, a, b);
-      xC_[t] = band.slot(a, b, NONE);
-      a = i, b = j + 1;
-      remap_bgrid_y(g, a, b);
-      yN_[t] = band.slot(a, b, NONE);
-      a = i, b = j;
-      remap_bgrid_y(g, a, b);
-      yC_[t] = band.slot(a, b, NONE);
-    }
-    auto in_uwin = [&](int a, int b) { return a >= g.is && a <= g.ie + 1 && b >= g.js && b <= g.je; };
-    auto in_vwin = [&](int a, int b) { return a >= g.is && a <= g.ie && b >= g.js && b <= g.je + 1; };
-    unsigned f = 0;
+    int w[DDH_TAB];
+    if (tab != nullptr) {  // (block-uniform)
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-      f |= (unsigned)(i >= g.is - nt - 1 && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) << (F_VD + nt);
-      f |= (unsigned)(i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt - 1 && j <= g.je + nt + 1) << (F_UD + nt);
-      f |= (unsigned)(i >= g.is - nt && i <= g.ie + nt + 1 && j >= g.js - nt && j <= g.je + nt + 1) << (F_DD + nt);
+      for (int q = 0; q < DDH_TAB; ++q) w[q] = tab[q * DDH_SLOTS + p];
+    } else {
+      ddh_point_table(g, band, p, w);
     }
-    const bool ic = (i == g.is || i == g.ie + 1);
-    const bool own = i >= g.is && i <= g.ie + 1 && j >= g.js && j <= g.je + 1;
-    f |= (unsigned)in_vwin(i, j) << F_VW | (unsigned)in_vwin(i - 1, j) << F_VWM | (unsigned)in_uwin(i, j) << F_UW | (unsigned)in_uwin(i, j - 1) << F_UWM;
-    f |= (unsigned)(ic && j == g.js) << F_CS | (unsigned)(ic && j == g.je + 1) << F_CN | (unsigned)ok << F_OK | (unsigned)own << F_OWN;
+    const int c2 = w[0];
+    c2_[t] = c2, sE_[t] = w[1], sW_[t] = w[2], sN_[t] = w[3], sS_[t] = w[4], xE_[t] = w[5], xC_[t] = w[6], yN_[t] = w[7], yC_[t] = w[8];
+    const unsigned f = (unsigned)w[9];
     fl_[t] = f;
+    const bool ok = (f >> F_OK) & 1u, own = (f >> F_OWN) & 1u;
     gu0_[t] = m.divg_u[c2], gv0_[t] = m.divg_v[c2], ra_[t] = m.rarea_c[c2];
-    gum_[t] = m.divg_u[i > 0 ? c2 - 1 : c2], gvm_[t] = m.divg_v[j > 0 ? c2 - g.sj : c2];
+    // (the neighbours' values: used only where the flags say the neighbour lies in a window; any valid address otherwise)
+    gum_[t] = m.divg_u[c2 > 0 ? c2 - 1 : c2], gvm_[t] = m.divg_v[c2 >= g.sj ? c2 - g.sj : c2];
     if (ok) {
       // the divergence before the passes: delpc at the tile's points (copy_computeplus), the caller's divg_d in the halo (written by
       // this kernel at its very end only); uc / vc: what the arrays hold (inside the windows: never read from here)
@@ -1498,7 +1531,8 @@ k_divdamp_halo_state_mem(Geo g, Met m, const real* __restrict__ delpc, real* __r
 int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const real* v, const real* va, real* vort_b,
                               const real* ua, real* divg_d, real* vc, real* uc, real* delpc, real* ke,
                               const real* rel_vort_agrid, double dt, const real* d2_bg_dev, int kstart, int nonzero_nord,
-                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead, bool ke_by_consumer) {
+                              double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead, bool ke_by_consumer,
+                              const int* ddh_tab) {
   // ke_by_consumer (with skip_dead only): `ke += damped vorticity` is left to the kernel that reads both (the fused scalar + wind
   // kernel forms ke + vort_b, the same single addition): this operator then neither reads nor writes ke
   const int nk = g.nk;
@@ -1543,7 +1577,8 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
     if (!skip_dead && nonzero_nord > 0) {
       const bool mem = getenv("PACE_DDH_MEM") != nullptr;  // (tests: the memory form on a small tile; read at every call)
       if (DdhBand(g, DDH_M).total <= DDH_SLOTS && !mem)
-        hipLaunchKernelGGL(k_divdamp_halo_state_lds, dim3((unsigned)nhigh), dim3(DDH_NT), 0, st, g, m, delpc, divg_d, uc, vc, kstart, nonzero_nord);
+        hipLaunchKernelGGL(k_divdamp_halo_state_lds, dim3((unsigned)nhigh), dim3(DDH_NT), 0, st, g, m, delpc, divg_d, uc, vc, kstart, nonzero_nord,
+                           ddh_tab);
       else
         hipLaunchKernelGGL(k_divdamp_halo_state_mem, dim3((unsigned)nhigh), dim3(DDH_NT), 0, st, g, m, delpc, da, db, divg_d, uc, vc, kstart,
                            nonzero_nord);
@@ -1571,12 +1606,13 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
 struct DswWork {
   real *ut, *vt, *fx, *fy, *gx, *gy, *fx2, *fy2, *dw, *heat_s, *ke, *wk, *abs_vort, *vort_b, *ut2, *vt2, *da, *db, *fyv, *umid, *vmid, *wtmp;
   real* kcol;  // device copy of the column namelist: 12 arrays of (nk+1)
+  int* ddh;    // the halo-state kernel's tables of this geometry (k_ddh_tables), or null where its LDS form does not apply
 };
 #define DSW_NFIELDS 22
 
 int64_t dsw_workspace_bytes(const Geo& g) {
   const int64_t field = (int64_t)g.sk * (g.nk + 1) * (int64_t)sizeof(real);
-  return field * DSW_NFIELDS + 16 * (int64_t)(g.nk + 1) * (int64_t)sizeof(real) + 256;
+  return field * DSW_NFIELDS + 16 * (int64_t)(g.nk + 1) * (int64_t)sizeof(real) + 256 + (int64_t)sizeof(int) * DDH_TAB * DDH_SLOTS;
 }
 
 static DswWork carve(const Geo& g, void* ws) {
@@ -1586,6 +1622,10 @@ static DswWork carve(const Geo& g, void* ws) {
   real** f = &w.ut;
   for (int n = 0; n < DSW_NFIELDS; ++n) f[n] = p + (long)n * field;
   w.kcol = p + (long)DSW_NFIELDS * field;
+  // (behind the column block: 16 (nk + 1) elements + padding to 256 bytes)
+  char* after = (char*)(w.kcol + 16 * (long)(g.nk + 1));
+  after += (256 - ((uintptr_t)after & 255)) & 255;
+  w.ddh = (DdhBand(g, DDH_M).total <= DDH_SLOTS) ? (int*)after : nullptr;
   return w;
 }
 
@@ -1610,6 +1650,8 @@ int dsw_prepare(const Geo& g, const pace_column_t* col, void* ws, hipStream_t st
   for (int a = 0; a < NCOL; ++a)
     for (int k = 0; k < g.nk; ++k) h[(size_t)a * K + k] = (real)src[a][k];
   upload(W.kcol, h.data(), h.size(), st);
+  if (W.ddh != nullptr) hipLaunchKernelGGL(k_ddh_tables, dim3(1), dim3(DDH_NT), 0, st, g, W.ddh);
+  PACE_CHECK_LAUNCH();
   return PACE_OK;
 }
 
@@ -1763,7 +1805,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // winds A2: divergence damping
   if (nonzero_nord < 0 || nonzero_nord > 3) return PACE_ERR_UNSUPPORTED;  // (as pace_divergence_damping: halo 3)
   if ((rc = launch_divergence_damping(g, m, u, v, va, W.vort_b, ua, divgd, vc, uc, delpc, W.ke, W.wk, dt, d_d2, kstart, nonzero_nord,
-                                      cfg->dddmp, cfg->d4_bg, W.da, W.db, st, skip_dead, ke_by_consumer)))
+                                      cfg->dddmp, cfg->d4_bg, W.da, W.db, st, skip_dead, ke_by_consumer, W.ddh)))
     return rc;
   // vorticity transport
   // vorticity: transport of the absolute vorticity (wk + fC_agrid) -> W.fy2, W.fyv (own flux buffers: the mass fluxes

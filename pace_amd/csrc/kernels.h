@@ -155,7 +155,7 @@ int launch_divergence_damping(const Geo& g, const Met& m, const real* u, const r
                               const real* ua, real* divg_d, real* vc, real* uc, real* delpc, real* ke,
                               const real* rel_vort_agrid, double dt, const real* d2_bg_dev, int kstart, int nonzero_nord,
                               double dddmp, double d4_bg, real* da, real* db, hipStream_t st, bool skip_dead = false,
-                              bool ke_by_consumer = false);
+                              bool ke_by_consumer = false, const int* ddh_tab = nullptr);
 // k_riem3f.hip: both column solvers as one k-cooperative kernel (16 lanes per column), no workspace
 bool riem_column_supported(const Geo& g);
 int launch_riem_solver3_column(const Geo& g, int last_call, double dt, const real* cappa, double ptop, const real* zs,
