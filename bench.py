@@ -910,12 +910,13 @@ def main():
                                       "(pace_d_sw_phases 256: on the kinetic energy / vorticities the last step left in the workspace)" if winds_fused else
                                       "the step's longest launch; timed here exactly as the step launches it, alone" if fused else
                                       "three of the step's launches are instances of this kernel; timed here alone, one scalar"),
-                "limited_by": ("its instruction stream and the waits in it: five transports + the wind update per tile are ~5 300 instructions "
-                               "per wave (3 969 vector, 46 % of them fp64; no FMA contraction: the results are bit-identical to the numpy "
-                               "oracle) on sixteen waves per CU; hardware counters (profiles/r05_sq_counters.json): the vector ports issue "
-                               "46 % of the kernel's cycles, a wave waits on its memory / LDS counters 55 % of its cycles (a barrier after "
-                               "every stage, two workgroups per CU to interleave); its L2 misses (~1.8 x the algorithmic bytes) move at "
-                               "2.5 TB/s -- DESIGN.md section 4" if fused else
+                "limited_by": ("its instruction stream and the waits in it: five transports + the wind update per tile are ~5 400 instructions "
+                               "per wave (4 077 vector, 45 % of them fp64; no FMA contraction: the results are bit-identical to the numpy "
+                               "oracle) on sixteen waves per CU (128 registers, 77.5 KB of LDS per workgroup); hardware counters "
+                               "(profiles/r06_sq_counters.json): vector issue alone is ~200 us of the kernel's ~390, a wave waits on its "
+                               "memory / LDS counters 54 % of its cycles (31 barriers per tile, two workgroups per CU to interleave); its L2 "
+                               "misses (~1.9 x the algorithmic bytes: halo rows of neighbouring tiles and the operands of the five passes) "
+                               "move at 2.9 TB/s -- DESIGN.md section 4" if fused else
                                "the bytes it really moves (L2 misses ~1.5 x algorithmic at ~3.5 TB/s) -- DESIGN.md section 4")}
 
     if rank == 0:

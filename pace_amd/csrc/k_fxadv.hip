@@ -138,9 +138,16 @@ __device__ __forceinline__ void fx_vt_corners_point(const Geo& g, const Met& m, 
 // one that applies there), instead of reading them back from ut / vt: the two 3-D fields ut and vt are no longer written and
 // read on 90 % of the plane (4 of 12 field passes of fxadv).  Frame points read the ut / vt the edge kernel below left there.
 // contra_out: also store the winds formed here (the stand-alone entry pace_fxadv returns ut and vt whole).
+// FX_CH levels per thread where that still leaves the chip several workgroups per compute unit (C192: 149 blocks x 10 chunks), FX_CH_SMALL
+// on small tiles (C48 at eight levels per thread: 120 workgroups on 256 compute units, each walking its levels one dependent load round
+// after the other -- 21.6 us for 15 MB).
 #ifndef FX_CH
 #define FX_CH 8
 #endif
+#ifndef FX_CH_SMALL
+#define FX_CH_SMALL 2
+#endif
+template <int FXC>
 __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc,
                                                       real* __restrict__ ut, real* __restrict__ vt, real* __restrict__ crx,
                                                       real* __restrict__ cry, real* __restrict__ xfx,
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
   const long p = (long)bxp * 256 + threadIdx.x;
   const int j = (int)(p / g.sj);
   const int i = (int)(p - (long)j * g.sj);
-  const int k0 = chunk * FX_CH;
+  const int k0 = chunk * FXC;
   if (j >= g.nj || i >= g.ni) return;
   if (i > g.ni - 2 || j > g.nj - 2 || box.skip(i, j)) return;
   const long c2 = IDX2(g, i, j);
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(256) k_fxadv_fluxes(Geo g, Met m, const real* 
   if (do_y) rdya_m = m.rdya[c2 - sj], rdya_0 = m.rdya[c2], dx = m.dx[c2], sg4_m = m.sin_sg4[c2 - sj], sg2_0 = m.sin_sg2[c2];
   if (inner) cosa_u = m.cosa_u[c2], rsin_u = m.rsin_u[c2], cosa_v = m.cosa_v[c2], rsin_v = m.rsin_v[c2];
 #pragma unroll
-  for (int t = 0; t < FX_CH; ++t) {
+  for (int t = 0; t < FXC; ++t) {
     const int k = k0 + t;
     if (k >= g.nk) break;
     const long c = c2 + (long)k * g.sk;
@@ -310,12 +317,18 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
     hipLaunchKernelGGL(k_fxadv_edges, dim3((unsigned)g.nk), dim3(1024), 0, st, g, m, uc, vc, ut, vt, S);
   }
 #ifdef PACE_EMU
-  const dim3 grid_fluxes(plane_grid(g, 1).x, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);
+  const unsigned nbx = plane_grid(g, 1).x;
 #else
-  const dim3 grid_fluxes((plane_grid(g, 1).x + 7) / 8 * 8, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1);  // (eight equal segments: k_fxadv_fluxes)
+  const unsigned nbx = (plane_grid(g, 1).x + 7) / 8 * 8;  // (eight equal segments: k_fxadv_fluxes)
 #endif
-  hipLaunchKernelGGL(k_fxadv_fluxes, grid_fluxes, dim3(256), 0, st, g, m, uc, vc, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box,
-                     contra_out);
+  const bool small = nbx * (unsigned)((g.nk + FX_CH - 1) / FX_CH) < 1024u;  // fewer than four workgroups per compute unit
+  if (small) {
+    hipLaunchKernelGGL(k_fxadv_fluxes<FX_CH_SMALL>, dim3(nbx, (unsigned)((g.nk + FX_CH_SMALL - 1) / FX_CH_SMALL), 1), dim3(256), 0, st, g, m, uc,
+                       vc, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, cy_acc, box, contra_out);
+  } else {
+    hipLaunchKernelGGL(k_fxadv_fluxes<FX_CH>, dim3(nbx, (unsigned)((g.nk + FX_CH - 1) / FX_CH), 1), dim3(256), 0, st, g, m, uc, vc, ut, vt, crx,
+                       cry, xfx, yfx, dt, cx_acc, cy_acc, box, contra_out);
+  }
   PACE_CHECK_LAUNCH();
   return PACE_OK;
 }

@@ -10,7 +10,7 @@ for r in $(seq 1 $N); do
     python bench.py --no-cpu-baseline --no-traffic 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}
-print('$L', 'ms_per_step %.4f' % d['ms_per_step'], 'kernel_us %.1f' % (r.get('us_per_launch') or 0), 'other %.4f' % ((d.get('other_contract') or {}).get('ms_per_step') or 0))
+print('$L', 'ms_per_step %.4f' % d['ms_per_step'], 'kernel_us %.1f' % (r.get('us_per_launch') or 0), 'other %.4f' % ((d.get('other_contract') or {}).get('ms_per_step') or 0), 'verified', d.get('verified'))
 " | tee -a "$O/ab.txt"
   done
 done
