@@ -282,6 +282,243 @@ __global__ void __launch_bounds__(1024) k_fxadv_edges(Geo g, Met m, const real* 
     if (strip_point(S.d, p, i, j)) fx_vt_corners_point(g, m, uc, vc, ut, vt, i, j, k);
 }
 
+// Stage A and the fluxes of the frame inside ONE workgroup per level (k_fxadv_fused): a thread has several points of the frame, and a
+// point's formula is a round trip to memory.  Load everything a batch of points needs first, then compute and store: one round trip per
+// batch instead of one per point (the workgroup's stages are the launch's critical path at C192: 85 us one point after the other).
+struct FxFramePointA {
+  long c;
+  bool xedge, umain, vmain;
+  double u0, u_s, u1_s, u1, v0, v_1, v_1s, vs, s3, s1, cu, ru, cv, rv;
+  __device__ __forceinline__ void load(const Geo& g, const Met& m, const real* __restrict__ uc, const real* __restrict__ vc, bool on, int i,
+                                       int j, int k) {
+    // (fx_main_point's cases, loads only)
+    const long c2 = IDX2(g, i, j);
+    c = IDX3(g, i, j, k);
+    const int sj = g.sj;
+    xedge = on && (i == g.is || i == g.ie + 1);
+    umain = on && !xedge && i >= g.is - 1 && i <= g.ie + 2 && !(j == g.js - 1 || j == g.js || j == g.je || j == g.je + 1);
+    vmain = on && j >= g.js - 1 && j <= g.je + 2;
+    u0 = u_s = u1_s = u1 = v0 = v_1 = v_1s = vs = s3 = s1 = cu = ru = cv = rv = 0.0;
+    if (xedge || umain || vmain) u0 = uc[c];
+    if (umain || vmain) v0 = vc[c];
+    if (xedge) s3 = m.sin_sg3[c2 - 1], s1 = m.sin_sg1[c2];
+    if (umain) v_1 = vc[c - 1], v_1s = vc[c - 1 + sj], vs = vc[c + sj], cu = m.cosa_u[c2], ru = m.rsin_u[c2];
+    if (vmain) u_s = uc[c - sj], u1_s = uc[c + 1 - sj], u1 = uc[c + 1], cv = m.cosa_v[c2], rv = m.rsin_v[c2];
+  }
+  __device__ __forceinline__ void finish(real* ut, real* vt) const {
+    if (xedge) {
+      ut[c] = (u0 > 0.0) ? (u0 / s3) : (u0 / s1);
+    } else if (umain) {
+      const double vb = 0.25 * (v_1 + v0 + v_1s + vs);
+      ut[c] = contra(u0, vb, cu, ru);
+    }
+    if (vmain) {
+      const double ub = 0.25 * (u_s + u1_s + u0 + u1);
+      vt[c] = contra(v0, ub, cv, rv);
+    }
+  }
+};
+struct FxFramePointF {
+  long c;
+  bool do_x, do_y;
+  double u, v, rdxa_m, rdxa_0, dy, sg3_m, sg1_0, rdya_m, rdya_0, dx, sg4_m, sg2_0, cxa, cya;
+  __device__ __forceinline__ void load(const Geo& g, const Met& m, const real* ut, const real* vt, const real* cx_acc, const real* cy_acc,
+                                       bool on, int i, int j, int k) {
+    const long c2 = IDX2(g, i, j);
+    c = c2 + (long)k * g.sk;
+    const int sj = g.sj;
+    do_x = on && i >= g.is && i <= g.ie + 1, do_y = on && j >= g.js && j <= g.je + 1;
+    u = v = rdxa_m = rdxa_0 = dy = sg3_m = sg1_0 = rdya_m = rdya_0 = dx = sg4_m = sg2_0 = cxa = cya = 0.0;
+    if (do_x) {
+      u = ut[c], rdxa_m = m.rdxa[c2 - 1], rdxa_0 = m.rdxa[c2], dy = m.dy[c2], sg3_m = m.sin_sg3[c2 - 1], sg1_0 = m.sin_sg1[c2];
+      if (cx_acc) cxa = cx_acc[c];
+    }
+    if (do_y) {
+      v = vt[c], rdya_m = m.rdya[c2 - sj], rdya_0 = m.rdya[c2], dx = m.dx[c2], sg4_m = m.sin_sg4[c2 - sj], sg2_0 = m.sin_sg2[c2];
+      if (cy_acc) cya = cy_acc[c];
+    }
+  }
+  __device__ __forceinline__ void finish(double dt, real* crx, real* cry, real* xfx, real* yfx, real* cx_acc, real* cy_acc) const {
+    if (do_x) {
+      double cr;
+      if (u > 0.0) {
+        cr = dt * u * rdxa_m;
+        xfx[c] = dy * dt * u * sg3_m;
+      } else {
+        cr = dt * u * rdxa_0;
+        xfx[c] = dy * dt * u * sg1_0;
+      }
+      crx[c] = cr;
+      if (cx_acc) cx_acc[c] = cxa + cr;
+    }
+    if (do_y) {
+      double cr;
+      if (v > 0.0) {
+        cr = dt * v * rdya_m;
+        yfx[c] = dx * dt * v * sg4_m;
+      } else {
+        cr = dt * v * rdya_0;
+        yfx[c] = dx * dt * v * sg2_0;
+      }
+      cry[c] = cr;
+      if (cy_acc) cy_acc[c] = cya + cr;
+    }
+  }
+};
+#ifndef FX_NB
+#define FX_NB 1  // points of the frame a thread takes through a stage together.  (2 - 4, loads first: no faster -- 128 registers at 4 leave an
+                 // interior workgroup no room beside a frame one; 2 under a 64-register cap spills; the frame's chain waits for round trips
+                 // that are slow BECAUSE the interior's stream runs beside it: profiles/r06_experiments/x34)
+#endif
+
+// ---- ONE launch for all of it (round 6) -------------------------------------------------------------------------------------
+// Two kinds of workgroups, in this order: (1) one per level for the FRAME of the plane -- stage A on the frame, the edge / corner stages
+// B, C, D, then the fluxes of the frame's points, one after the other behind workgroup barriers (the three launches above and the frame's
+// share of the fourth: ~25 us of dependent round trips on a handful of points); (2) the interior box's blocks, which depend on nothing
+// the frame kind writes (a point of the box forms its winds from uc / vc).  The few long frame workgroups are first in launch order and
+// run beside the interior's stream instead of in front of it.
+#ifndef FX_NT
+#define FX_NT 1024
+#endif
+#ifndef FX_MIN_WGS
+#define FX_MIN_WGS (512 * 1024 / FX_NT)  // interior blocks the launch should have at least (two workgroups of 1024 threads per compute unit)
+#endif
+#ifndef FX_ATTR
+#define FX_ATTR  // (55 registers as it stands: two workgroups of 1024 threads per compute unit, a frame one and an interior one)
+#endif
+template <int FXC>
+__global__ void __launch_bounds__(FX_NT) FX_ATTR k_fxadv_fused(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc, real* ut, real* vt,
+                                                      real* __restrict__ crx, real* __restrict__ cry, real* __restrict__ xfx,
+                                                      real* __restrict__ yfx, double dt, real* __restrict__ cx_acc,
+                                                      real* __restrict__ cy_acc, FxBox box, int contra_out, Regions A, FxStrips S,
+                                                      int nframe, int nbx) {
+  const int tid = (int)threadIdx.x;
+  int b = (int)blockIdx.x;
+  if (b < nframe) {
+    const int k = b;
+    int i, j;
+    const int na = strip_count(A);
+    for (int p0 = tid; p0 < na; p0 += FX_NT * FX_NB) {
+      FxFramePointA P[FX_NB];
+#pragma unroll
+      for (int q = 0; q < FX_NB; ++q) {
+        int pi = 0, pj = 0;
+        const bool on = strip_point(A, p0 + q * FX_NT, pi, pj) && pi <= g.ni - 2 && pj <= g.nj - 2;
+        P[q].load(g, m, uc, vc, on, on ? pi : 1, on ? pj : 1, k);
+      }
+#pragma unroll
+      for (int q = 0; q < FX_NB; ++q) P[q].finish(ut, vt);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int p = tid, n = strip_count(S.b); p < n; p += FX_NT)
+      if (strip_point(S.b, p, i, j)) fx_vt_edges_point(g, m, vc, ut, vt, i, j, k);
+    __threadfence_block();
+    __syncthreads();
+    for (int p = tid, n = strip_count(S.c); p < n; p += FX_NT)
+      if (strip_point(S.c, p, i, j)) fx_ut_edges_corners_point(g, m, uc, vc, ut, vt, i, j, k);
+    __threadfence_block();
+    __syncthreads();
+    for (int p = tid, n = strip_count(S.d); p < n; p += FX_NT)
+      if (strip_point(S.d, p, i, j)) fx_vt_corners_point(g, m, uc, vc, ut, vt, i, j, k);
+    __threadfence_block();
+    __syncthreads();
+    // the frame's fluxes (fxadv_fluxes_stencil :436-486 at the points outside the interior box)
+    for (int p0 = tid; p0 < na; p0 += FX_NT * FX_NB) {
+      FxFramePointF P[FX_NB];
+#pragma unroll
+      for (int q = 0; q < FX_NB; ++q) {
+        int pi = 0, pj = 0;
+        const bool on = strip_point(A, p0 + q * FX_NT, pi, pj);
+        P[q].load(g, m, ut, vt, cx_acc, cy_acc, on, on ? pi : 1, on ? pj : 1, k);
+      }
+#pragma unroll
+      for (int q = 0; q < FX_NB; ++q) P[q].finish(dt, crx, cry, xfx, yfx, cx_acc, cy_acc);
+    }
+    return;
+  }
+  b -= nframe;
+  // ---- the interior box: FXC levels of a point per thread (the metric values of the point loaded once) ----
+#ifdef PACE_EMU
+  const int chunk = b / nbx, bxp = b - chunk * nbx;
+#else
+  // (XCD x takes the x-th eighth of the plane's blocks of every chunk of levels: see k_fxadv_fluxes)
+  const int seg = nbx / 8;
+  const int chunk = b / nbx, r = b - chunk * nbx;
+  const int bxp = (r & 7) * seg + (r >> 3);
+#endif
+  const long p = (long)bxp * FX_NT + tid;
+  const int j = (int)(p / g.sj);
+  const int i = (int)(p - (long)j * g.sj);
+  if (i < box.i0 || i > box.i1 || j < box.j0 || j > box.j1) return;
+  const int k0 = chunk * FXC;
+  const long c2 = IDX2(g, i, j);
+  const int sj = g.sj;
+  const double rdxa_m = m.rdxa[c2 - 1], rdxa_0 = m.rdxa[c2], dy = m.dy[c2], sg3_m = m.sin_sg3[c2 - 1], sg1_0 = m.sin_sg1[c2];
+  const double rdya_m = m.rdya[c2 - sj], rdya_0 = m.rdya[c2], dx = m.dx[c2], sg4_m = m.sin_sg4[c2 - sj], sg2_0 = m.sin_sg2[c2];
+  const double cosa_u = m.cosa_u[c2], rsin_u = m.rsin_u[c2], cosa_v = m.cosa_v[c2], rsin_v = m.rsin_v[c2];
+#pragma unroll
+  for (int t = 0; t < FXC; ++t) {
+    const int k = k0 + t;
+    if (k >= g.nk) break;
+    const long c = c2 + (long)k * g.sk;
+    const double uc0 = uc[c], vc0 = vc[c];
+    const double vb = 0.25 * (vc[c - 1] + vc0 + vc[c - 1 + sj] + vc[c + sj]);
+    const double ub = 0.25 * (uc[c - sj] + uc[c + 1 - sj] + uc0 + uc[c + 1]);
+    const double u = contra(uc0, vb, cosa_u, rsin_u);
+    const double v = contra(vc0, ub, cosa_v, rsin_v);
+    if (contra_out) ut[c] = u, vt[c] = v;
+    double cr;
+    if (u > 0.0) {
+      cr = dt * u * rdxa_m;
+      xfx[c] = dy * dt * u * sg3_m;
+    } else {
+      cr = dt * u * rdxa_0;
+      xfx[c] = dy * dt * u * sg1_0;
+    }
+    crx[c] = cr;
+    if (cx_acc) cx_acc[c] = cx_acc[c] + cr;
+    if (v > 0.0) {
+      cr = dt * v * rdya_m;
+      yfx[c] = dx * dt * v * sg4_m;
+    } else {
+      cr = dt * v * rdya_0;
+      yfx[c] = dx * dt * v * sg2_0;
+    }
+    cry[c] = cr;
+    if (cy_acc) cy_acc[c] = cy_acc[c] + cr;
+  }
+}
+
+// the frame of the plane (stage A's regions) and the strips of stages B, C, D
+static void fxadv_frame_regions(const Geo& g, bool has_box, Regions& A, FxStrips& S) {
+  // stage A: the frame -- whole rows below js+2 and above je-2, the columns left of is+2 and right of ie-2 between them
+  if (has_box) {
+    add_region(A, 0, g.ni - 2, 0, g.js + 1);
+    add_region(A, 0, g.ni - 2, g.je - 1, g.nj - 2);
+    add_region(A, 0, g.is + 1, g.js + 2, g.je - 2);
+    add_region(A, g.ie - 1, g.ni - 2, g.js + 2, g.je - 2);
+  } else {
+    add_region(A, 0, g.ni - 2, 0, g.nj - 2);
+  }
+  // stage B: rows js, je+1 over the whole width; columns is-1, is, ie, ie+1 between them
+  add_region(S.b, 0, g.ni - 2, g.js, g.js);
+  add_region(S.b, 0, g.ni - 2, g.je + 1, g.je + 1);
+  add_region(S.b, g.is - 1, g.is, g.js + 2, g.je - 1);
+  add_region(S.b, g.ie, g.ie + 1, g.js + 2, g.je - 1);
+  // stage C: rows js-1, js, je, je+1, columns is+1 .. ie
+  add_region(S.c, g.is + 1, g.ie, g.js - 1, g.js);
+  add_region(S.c, g.is + 1, g.ie, g.je, g.je + 1);
+  // stage D: the eight points (is-1, is, ie, ie+1) x (js+1, je)
+  add_region(S.d, g.is - 1, g.ie + 1, g.js + 1, g.js + 1);
+  add_region(S.d, g.is - 1, g.ie + 1, g.je, g.je);
+}
+
+static bool fxadv_split_launches() {
+  const char* e = getenv("PACE_FXADV_SPLIT");  // (read per call: an A/B switch)
+  return e != nullptr && e[0] == '1';
+}
+
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
                  hipStream_t st, int part, int contra_out) {
@@ -290,30 +527,38 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
   const bool has_box = box.i1 >= box.i0 && box.j1 >= box.j0;
   if (!has_box) box.i1 = box.i0 - 1, box.j1 = box.j0 - 1;  // nothing is inside
   if (part == 1 && !has_box) return PACE_OK;
+  if (!fxadv_split_launches()) {
+    Regions A{};
+    FxStrips S{};
+    if (part != 1) fxadv_frame_regions(g, has_box, A, S);
+    const int nframe = (part != 1) ? g.nk : 0;
+    // the interior's blocks: the whole plane's flattened rows (a block whose points all lie outside the box returns at once)
+    unsigned nbx = (unsigned)(((long)g.sj * g.nj + FX_NT - 1) / FX_NT);
+#ifndef PACE_EMU
+    nbx = (nbx + 7) / 8 * 8;
+#endif
+    const bool interior = has_box && part != 2;
+    // levels per thread of the interior's blocks: as many as still leave two workgroups (of 1024 threads) per compute unit
+    int ch = 8;
+    while (ch > 1 && nbx * (unsigned)((g.nk + ch - 1) / ch) < (unsigned)FX_MIN_WGS) ch >>= 1;
+    const unsigned nint = interior ? nbx * (unsigned)((g.nk + ch - 1) / ch) : 0u;
+    if (nframe + nint == 0) return PACE_OK;
+#define FX_GO(CH)                                                                                                                            \
+  hipLaunchKernelGGL(k_fxadv_fused<CH>, dim3((unsigned)nframe + nint), dim3(FX_NT), 0, st, g, m, uc, vc, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, \
+                     cy_acc, box, contra_out, A, S, nframe, (int)nbx)
+    if (ch == 8) FX_GO(8);
+    else if (ch == 4) FX_GO(4);
+    else if (ch == 2) FX_GO(2);
+    else FX_GO(1);
+#undef FX_GO
+    PACE_CHECK_LAUNCH();
+    return PACE_OK;
+  }
   if (part != 1) {
     Regions A{};
-    // stage A: the frame -- whole rows below js+2 and above je-2, the columns left of is+2 and right of ie-2 between them
-    if (has_box) {
-      add_region(A, 0, g.ni - 2, 0, g.js + 1);
-      add_region(A, 0, g.ni - 2, g.je - 1, g.nj - 2);
-      add_region(A, 0, g.is + 1, g.js + 2, g.je - 2);
-      add_region(A, g.ie - 1, g.ni - 2, g.js + 2, g.je - 2);
-    } else {
-      add_region(A, 0, g.ni - 2, 0, g.nj - 2);
-    }
-    hipLaunchKernelGGL(k_fxadv_frame, regions_grid(A, g.nk), dim3(64, 4), 0, st, g, m, uc, vc, ut, vt, A);
     FxStrips S{};
-    // stage B: rows js, je+1 over the whole width; columns is-1, is, ie, ie+1 between them
-    add_region(S.b, 0, g.ni - 2, g.js, g.js);
-    add_region(S.b, 0, g.ni - 2, g.je + 1, g.je + 1);
-    add_region(S.b, g.is - 1, g.is, g.js + 2, g.je - 1);
-    add_region(S.b, g.ie, g.ie + 1, g.js + 2, g.je - 1);
-    // stage C: rows js-1, js, je, je+1, columns is+1 .. ie
-    add_region(S.c, g.is + 1, g.ie, g.js - 1, g.js);
-    add_region(S.c, g.is + 1, g.ie, g.je, g.je + 1);
-    // stage D: the eight points (is-1, is, ie, ie+1) x (js+1, je)
-    add_region(S.d, g.is - 1, g.ie + 1, g.js + 1, g.js + 1);
-    add_region(S.d, g.is - 1, g.ie + 1, g.je, g.je);
+    fxadv_frame_regions(g, has_box, A, S);
+    hipLaunchKernelGGL(k_fxadv_frame, regions_grid(A, g.nk), dim3(64, 4), 0, st, g, m, uc, vc, ut, vt, A);
     hipLaunchKernelGGL(k_fxadv_edges, dim3((unsigned)g.nk), dim3(1024), 0, st, g, m, uc, vc, ut, vt, S);
   }
 #ifdef PACE_EMU

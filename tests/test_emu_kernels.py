@@ -1016,3 +1016,35 @@ def test_d_sw_halo_state_memory_form_equals_lds_form():
             os.environ.pop("PACE_DDH_MEM", None)
         for k in ("divgd", "uc", "vc", "delpc", "delp", "pt", "w", "q_con"):
             assert np.array_equal(a[k][dsw_window(k, n, nz)], out[k][dsw_window(k, n, nz)]), (mem, k)
+
+
+def test_fxadv_one_launch_equals_the_four_launches_and_the_oracle():
+    """FiniteVolumeFluxPrep as ONE launch (the frame's stages and fluxes in one workgroup per level beside the interior's blocks;
+    k_fxadv_fused) and as round 5's four launches (PACE_FXADV_SPLIT=1): both against the oracle, bit for bit, on the windows
+    TranslateFxAdv compares (translate_fxadv.py:49-72) and on the fluxes' whole domains.  C12 and C24 (levels per thread 1 .. 8)."""
+    from oracle import dgrid_sw
+    from pace_amd import _lib, synthetic
+    from pace_amd.fv3core.stencils.fxadv import FiniteVolumeFluxPrep
+
+    for n, nz in ((12, 3), (24, 9)):
+        m = synthetic.tile_metrics(n, nz)
+        s = synthetic.acoustic_state(m, n, nz)
+        ref = {k: np.zeros_like(s["pt"]) for k in ("crx", "cry", "xfx", "yfx", "ut", "vt")}
+        dgrid_sw.fxadv(oracle_grid(m, n, nz), s["uc"], s["vc"], ref["crx"], ref["cry"], ref["xfx"], ref["yfx"], ref["ut"], ref["vt"], s["dt"])
+        env = Env(_lib.Library(build_emu()), "cpu", m, n, nz)
+        prep = FiniteVolumeFluxPrep(env.stencil_factory, env.grid_data)
+        for split in (False, True):
+            if split:
+                os.environ["PACE_FXADV_SPLIT"] = "1"
+            try:
+                uc, vc = env.q3(s["uc"]), env.q3(s["vc"])
+                out = {k: env.q3() for k in ref}
+                prep(uc, vc, out["crx"], out["cry"], out["xfx"], out["yfx"], out["ut"], out["vt"], s["dt"])
+            finally:
+                os.environ.pop("PACE_FXADV_SPLIT", None)
+            wins = {"crx": (slice(3, n + 4), slice(0, n + 6)), "xfx": (slice(3, n + 4), slice(0, n + 6)),
+                    "cry": (slice(0, n + 6), slice(3, n + 4)), "yfx": (slice(0, n + 6), slice(3, n + 4)),
+                    "ut": (slice(1, n + 6), slice(1, n + 5)), "vt": (slice(1, n + 5), slice(1, n + 6))}
+            for k, (wi, wj) in wins.items():
+                a, b = ref[k][wi, wj, :nz], out[k].numpy()[wi, wj, :nz]
+                assert np.array_equal(a, b), (n, split, k, float(np.abs(a - b).max()))

@@ -14,7 +14,8 @@ def main(path, back=2):
     q = f"""select s.kernel_name, d.start, d.end, {qcol or 0} from rocpd_kernel_dispatch d
             join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start"""
     rows = [(n.split("(")[0], a, b, qq) for n, a, b, qq in cur.execute(q)]
-    starts = [i for i, r in enumerate(rows) if "k_fxadv_frame" in r[0]]  # first kernel of a d_sw
+    # first kernel of a d_sw: the flux preparation (one launch, k_fxadv_fused; PACE_FXADV_SPLIT=1: k_fxadv_frame is its first)
+    starts = [i for i, r in enumerate(rows) if "k_fxadv_frame" in r[0] or "k_fxadv_fused" in r[0]]
     i0 = starts[-back]
     i1 = starts[-back + 1] if back > 1 else len(rows)
     t0 = rows[i0][1]

@@ -12,6 +12,7 @@ import sys
 
 # distinct 3-D fields per launch (in + out), by kernel-name fragment; the edge-strip kernel touches a few rows only
 FIELDS = [
+    ("k_fxadv_fused", 10.65, "uc, vc, cx, cy -> crx, cry, xfx, yfx, cx, cy (ut, vt on the frame of the plane, 11 % of it): the frame's stages and the interior's stream in one launch"),
     ("k_fxadv_frame", 0.45, "uc, vc -> ut, vt on the frame of the plane (11 % of it)"),
     ("k_fxadv_edges", 0.2, "edge strips of ut, vt"),
     ("k_fxadv_fluxes", 10, "uc, vc (ut, vt on the frame), cx, cy -> crx, cry, xfx, yfx, cx, cy"),
