@@ -852,13 +852,16 @@ def main():
         reps = max(10, args.steps)
         for r in range(3):
             kernel(r)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for r in range(reps):
+        # a pair of events around EVERY launch, the median of them: one stall of the host thread between two launches (a shared
+        # host: 50 ms were seen once) would otherwise be averaged into every launch of the batch
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for r, (e0, e1) in enumerate(evs):
+            e0.record()
             kernel(3 + r)
-        e1.record()
+            e1.record()
         torch.cuda.synchronize()
-        t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
+        per_launch = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in evs)
+        t_kernel = float(np.median(per_launch))
         algo = algo_fields * item * n * n * nz
         # HBM bytes per launch: measured live by two child passes under rocprofv3 --pmc (see measure_traffic), null otherwise
         traffic, traffic_detail = (None, "skipped (--no-traffic)")
@@ -905,7 +908,8 @@ def main():
         roof = {"kernel": roof_kernel, "bound": "hbm", "achieved": algo / t_kernel / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "measured_copy_GBs": copy_gbs, "measured_streams": streams, "torch_copy_GBs": torch_copy_gbs,
                 "frac": algo / t_kernel / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
-                "us_per_launch": t_kernel * 1e6, "algorithmic_bytes_per_launch": algo, "algorithmic_fields": algo_fields,
+                "us_per_launch": t_kernel * 1e6, "us_per_launch_min_max": [per_launch[0] * 1e6, per_launch[-1] * 1e6],
+                "launches_timed": reps, "algorithmic_bytes_per_launch": algo, "algorithmic_fields": algo_fields,
                 "where_in_the_step": ("the step's longest launch (more than half of it); timed here alone, exactly as the step launches it "
                                       "(pace_d_sw_phases 256: on the kinetic energy / vorticities the last step left in the workspace)" if winds_fused else
                                       "the step's longest launch; timed here exactly as the step launches it, alone" if fused else

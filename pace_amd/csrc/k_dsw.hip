@@ -194,23 +194,9 @@ k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restri
 // (Inside the scalar-phase kernel the copy cost an edge tile 4.5 - 8 k cycles; riding on k_vorticity it cost that kernel 7 us.)
 __global__ void __launch_bounds__(256)
 k_copy_wind_halo(Geo g, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ u_out, real* __restrict__ v_out) {
-  const int nsouth = g.js, nnorth = g.nj - 1 - g.je, nmid = g.je - g.js + 1, nwest = g.is, neast = g.ni - 1 - g.ie;
-  const int rows = (nsouth + nnorth) * g.ni, total = rows + nmid * (nwest + neast);
-  int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  if (p >= total) return;
-  int i, j;
-  if (p < rows) {
-    const int r = p / g.ni;
-    i = p - r * g.ni, j = r < nsouth ? r : g.je + 1 + (r - nsouth);
-  } else {
-    p -= rows;
-    const int w = nwest + neast, r = p / w, c = p - r * w;
-    j = g.js + r, i = c < nwest ? c : g.ie + 1 + (c - nwest);
-  }
-  const long ch = IDX3(g, i, j, (int)blockIdx.y);
-  const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
-  if (!(in_i && (in_j || j == g.je + 1))) u_out[ch] = u[ch];
-  if (!((in_i || i == g.ie + 1) && in_j)) v_out[ch] = v[ch];
+  const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (p >= wind_halo_points(g)) return;
+  wind_halo_copy_point(g, p, (int)blockIdx.y, u, v, u_out, v_out);
 }
 
 // compute_vorticity (d_sw.py:301-328) + rel_vorticity_to_abs (:389-402), compute domain + halo 3
@@ -1709,11 +1695,15 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // kinetic-energy kernel
   // (the same predicate as launch_divergence_damping's `fused`: with the legacy A/B switch the damping adds to ke itself)
   const bool ke_by_consumer = winds_in_scalars && skip_dead && nk - kstart > 0 && !legacy_divergence_damping();
+  // (separate wind outputs: the halo of the output buffers is a copy of the inputs' -- taken along by the flux preparation's frame
+  // workgroups when this call also runs the wind phase, else by a launch of its own below)
+  FxWindHalo wind_halo{u, v, cfg->u_out, cfg->v_out, false};
+  FxWindHalo* const wh = (winds_in_scalars && cfg->u_out != nullptr && (phases & (4 | 64))) ? &wind_halo : nullptr;
   if (phases & 1) {
-  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st))) return rc;
+  if ((rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 0, 0, wh))) return rc;
   } else {  // the same in two parts around a halo exchange: 16 = interior box, 32 = the rest
     if ((phases & 16) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 1))) return rc;
-    if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2))) return rc;
+    if ((phases & 32) && (rc = launch_fxadv(g, m, uc, vc, crx, cry, xfx, yfx, W.ut, W.vt, dt, cx, cy, st, 2, 0, wh))) return rc;
   }
   auto scalar_phase = [&]() -> int {
     // The production tilings with one order for all four: ONE kernel (k_fvt.hip launch_dsw_scalars_lean) takes a tile through
@@ -1796,8 +1786,8 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   }
   hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
   // (with separate wind outputs the halo of the output buffers is copied here, by a launch of its own over the frame of the plane)
-  if (winds_in_scalars && cfg->u_out != nullptr) {
-    const int frame = (g.js + g.nj - 1 - g.je) * g.ni + (g.je - g.js + 1) * (g.is + g.ni - 1 - g.ie);
+  if (winds_in_scalars && cfg->u_out != nullptr && !wind_halo.done) {
+    const int frame = wind_halo_points(g);
     hipLaunchKernelGGL(k_copy_wind_halo, dim3((unsigned)((frame + 255) / 256), (unsigned)nk), dim3(256), 0, st, g, u, v, cfg->u_out, cfg->v_out);
   }
   }

@@ -391,13 +391,16 @@ __global__ void __launch_bounds__(FX_NT) FX_ATTR k_fxadv_fused(Geo g, Met m, con
                                                       real* __restrict__ crx, real* __restrict__ cry, real* __restrict__ xfx,
                                                       real* __restrict__ yfx, double dt, real* __restrict__ cx_acc,
                                                       real* __restrict__ cy_acc, FxBox box, int contra_out, Regions A, FxStrips S,
-                                                      int nframe, int nbx) {
+                                                      int nframe, int nbx, FxWindHalo wh) {
   const int tid = (int)threadIdx.x;
   int b = (int)blockIdx.x;
   if (b < nframe) {
     const int k = b;
     int i, j;
     const int na = strip_count(A);
+    // (d_sw's separate wind outputs: the halo of this level, copied here -- nothing below depends on it)
+    if (wh.u_out != nullptr)
+      for (int p = tid, n = wind_halo_points(g); p < n; p += FX_NT) wind_halo_copy_point(g, p, k, wh.u, wh.v, wh.u_out, wh.v_out);
     for (int p0 = tid; p0 < na; p0 += FX_NT * FX_NB) {
       FxFramePointA P[FX_NB];
 #pragma unroll
@@ -521,7 +524,7 @@ static bool fxadv_split_launches() {
 
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
-                 hipStream_t st, int part, int contra_out) {
+                 hipStream_t st, int part, int contra_out, FxWindHalo* wind_halo) {
   // part 0: everything; 1: the interior box only (needs no halo of uc / vc, and neither ut nor vt); 2: the rest, after part 1
   FxBox box{g.is + 2, g.ie - 2, g.js + 2, g.je - 2, part};
   const bool has_box = box.i1 >= box.i0 && box.j1 >= box.j0;
@@ -543,9 +546,11 @@ int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, rea
     while (ch > 1 && nbx * (unsigned)((g.nk + ch - 1) / ch) < (unsigned)FX_MIN_WGS) ch >>= 1;
     const unsigned nint = interior ? nbx * (unsigned)((g.nk + ch - 1) / ch) : 0u;
     if (nframe + nint == 0) return PACE_OK;
+    FxWindHalo wcopy{nullptr, nullptr, nullptr, nullptr, false};
+    if (wind_halo != nullptr && nframe > 0) wcopy = *wind_halo, wind_halo->done = true;
 #define FX_GO(CH)                                                                                                                            \
   hipLaunchKernelGGL(k_fxadv_fused<CH>, dim3((unsigned)nframe + nint), dim3(FX_NT), 0, st, g, m, uc, vc, ut, vt, crx, cry, xfx, yfx, dt, cx_acc, \
-                     cy_acc, box, contra_out, A, S, nframe, (int)nbx)
+                     cy_acc, box, contra_out, A, S, nframe, (int)nbx, wcopy)
     if (ch == 8) FX_GO(8);
     else if (ch == 4) FX_GO(4);
     else if (ch == 2) FX_GO(2);

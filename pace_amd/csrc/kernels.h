@@ -2,9 +2,39 @@
 #pragma once
 #include "common.h"
 
+// d_sw's separate wind outputs get the halo of the inputs (k_dsw.hip k_copy_wind_halo): a copy the frame workgroups of the one-launch
+// form take along (their stage A waits for a round trip anyway); `done` tells the caller whether this launch took it
+struct FxWindHalo {
+  const real *u, *v;
+  real *u_out, *v_out;
+  bool done;
+};
 int launch_fxadv(const Geo& g, const Met& m, const real* uc, const real* vc, real* crx, real* cry,
                  real* xfx, real* yfx, real* ut, real* vt, double dt, real* cx_acc, real* cy_acc,
-                 hipStream_t st, int part = 0, int contra_out = 0);
+                 hipStream_t st, int part = 0, int contra_out = 0, FxWindHalo* wind_halo = nullptr);
+// the frame of the plane outside the faces d_sw's winds are written on, point p of its level (k_copy_wind_halo's enumeration)
+__device__ __forceinline__ void wind_halo_copy_point(const Geo& g, int p, int k, const real* __restrict__ u, const real* __restrict__ v,
+                                                     real* __restrict__ u_out, real* __restrict__ v_out) {
+  const int nsouth = g.js, nnorth = g.nj - 1 - g.je, nmid = g.je - g.js + 1, nwest = g.is, neast = g.ni - 1 - g.ie;
+  const int rows = (nsouth + nnorth) * g.ni;
+  int i, j;
+  if (p < rows) {
+    const int r = p / g.ni;
+    i = p - r * g.ni, j = r < nsouth ? r : g.je + 1 + (r - nsouth);
+  } else {
+    p -= rows;
+    const int w = nwest + neast, r = p / w, c = p - r * w;
+    if (r >= nmid) return;
+    j = g.js + r, i = c < nwest ? c : g.ie + 1 + (c - nwest);
+  }
+  const long ch = IDX3(g, i, j, k);
+  const bool in_i = i >= g.is && i <= g.ie, in_j = j >= g.js && j <= g.je;
+  if (!(in_i && (in_j || j == g.je + 1))) u_out[ch] = u[ch];
+  if (!((in_i || i == g.ie + 1) && in_j)) v_out[ch] = v[ch];
+}
+__host__ __device__ __forceinline__ int wind_halo_points(const Geo& g) {
+  return (g.js + g.nj - 1 - g.je) * g.ni + (g.je - g.js + 1) * (g.is + g.ni - 1 - g.ie);
+}
 int launch_fvtp2d(const Geo& g, const Met& m, const real* q, const real* crx, const real* cry,
                   const real* xfx, const real* yfx, real* fx, real* fy, const real* xmf,
                   const real* ymf, int hord, int nlev, hipStream_t st);
