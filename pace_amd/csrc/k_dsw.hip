@@ -188,6 +188,62 @@ k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restri
   kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, vort, i, j, k, interior, reg__ < nke);
 }
 
+// The kinetic energy and the relative vorticity in ONE launch, as two kinds of workgroups (round 6): a level's kinetic-energy blocks and,
+// behind them in the same level's share of the launch, the 64 x 4 patches of its vorticity.  Nothing is shared per point (x02: the
+// vorticity inside the kinetic-energy point function was slower); what is shared is the launch -- no drain / fill between the two -- and
+// the XCD: a level's blocks of both kinds run on one XCD, where the vorticity finds the rows of u and v the kinetic energy just read.
+template <int MORD>
+__global__ void __launch_bounds__(256)
+k_ke_vorticity(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc, const real* __restrict__ u,
+               const real* __restrict__ v, const real* __restrict__ ut, const real* __restrict__ vt, real* __restrict__ ke, double dt,
+               Regions R, real* __restrict__ vort, int nbr) {
+  int bx__, bz__;
+#ifdef PACE_EMU
+  bx__ = (int)blockIdx.x, bz__ = (int)blockIdx.z;
+#else
+  {  // (REGION_POINT_XCD's map: XCD x works through levels x, x + 8, ...)
+    const int nbx__ = (int)gridDim.x, nlev__ = (int)gridDim.z;
+    const int lin__ = (int)blockIdx.x + nbx__ * (int)blockIdx.z;
+    const int full__ = (nlev__ / 8) * 8;
+    if (lin__ < full__ * nbx__) {
+      const int slot__ = lin__ >> 3;
+      bz__ = (slot__ / nbx__) * 8 + (lin__ & 7);
+      bx__ = slot__ - (slot__ / nbx__) * nbx__;
+    } else {
+      bz__ = lin__ / nbx__;
+      bx__ = lin__ - bz__ * nbx__;
+    }
+  }
+#endif
+  const int k = bz__;
+  if (bx__ >= nbr) {
+    // a patch of the vorticity (k_vorticity's enumeration)
+    const int pb = bx__ - nbr, npx = (g.ni + PATCH_W - 1) / PATCH_W;
+    const int i = (pb % npx) * PATCH_W + (int)threadIdx.x, j = (pb / npx) * PATCH_H + (int)threadIdx.y;
+    if (i > g.ni - 2 || j > g.nj - 2) return;
+    const long c = IDX3(g, i, j, k);
+    vort[c] = rel_vorticity(g, m, u, v, c, IDX2(g, i, j));
+    return;
+  }
+  int reg__ = 0;
+  while (reg__ + 1 < R.n && bx__ >= R.first[reg__ + 1]) ++reg__;
+  const int b__ = bx__ - R.first[reg__];
+  const bool interior = reg__ < R.nplain;
+  int i, j;
+  if (reg__ == 0) {
+    i = R.ib[0] + (b__ % R.nbx0) * 64 + (int)threadIdx.x;
+    j = R.jb[0] + (b__ / R.nbx0) * 4 + (int)threadIdx.y;
+    if (i > R.ie[0] || j > R.je[0]) return;
+  } else {
+    const int w__ = R.ie[reg__] - R.ib[reg__] + 1;
+    const int p__ = b__ * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;
+    j = R.jb[reg__] + p__ / w__;
+    i = R.ib[reg__] + p__ % w__;
+    if (j > R.je[reg__]) return;
+  }
+  kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, (real*)nullptr, i, j, k, interior, true);
+}
+
 // Separate outputs of the winds (which the caller swaps in): the output buffers get the halo the inputs have -- the storage outside
 // the faces d_sw writes, u: [is, ie] x [js, je + 1], v: [is, ie + 1] x [js, je].  The frame of the plane as four strips, one thread
 // per point: south rows [0, js), north rows (je, nj), and between them the west columns [0, is) and the east columns (ie, ni).
@@ -1777,14 +1833,25 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // (two point kernels.  The vorticity inside the kinetic-energy kernel: no faster, x02; both from LDS tiles of u and v: twice as
   // slow, x06 -- profiles/r05_experiments)
   const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
+  if (cfg->hord_mt != 5 && cfg->hord_mt != 6) return PACE_ERR_UNSUPPORTED;
+  static const bool two_launches = getenv("PACE_KE_VORT_SPLIT") != nullptr;  // (A/B measurements: round 5's two launches)
+  if (!two_launches && PATCH_W == 64) {
+    const int nbr = rke.first[rke.n];
+    const dim3 pg = patch_grid(g, 1);
+    const dim3 grid((unsigned)nbr + pg.x * pg.y, 1, (unsigned)nk);
+    if (cfg->hord_mt == 5) {
+      hipLaunchKernelGGL(k_ke_vorticity<5>, grid, dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nbr);
+    } else {
+      hipLaunchKernelGGL(k_ke_vorticity<6>, grid, dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nbr);
+    }
+  } else {
   if (cfg->hord_mt == 5) {
     hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);
-  } else if (cfg->hord_mt == 6) {
-    hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);
   } else {
-    return PACE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_kinetic_energy<6>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);
   }
   hipLaunchKernelGGL(k_vorticity, patch_grid(g, nk), PATCH_BLOCK, 0, st, g, m, u, v, W.wk);
+  }
   // (with separate wind outputs the halo of the output buffers is copied here, by a launch of its own over the frame of the plane)
   if (winds_in_scalars && cfg->u_out != nullptr && !wind_halo.done) {
     const int frame = wind_halo_points(g);

@@ -18,6 +18,7 @@ FIELDS = [
     ("k_fxadv_fluxes", 10, "uc, vc (ut, vt on the frame), cx, cy -> crx, cry, xfx, yfx, cx, cy"),
     ("k_fvt_scalars", 26, "delp, w, q_con, pt, crx, cry, xfx, yfx, mfx, mfy, vorticity, u, v, ke, damped vorticity, heat_source -> delp, w, "
                           "q_con, pt, mfx, mfy, diss_est, u, v, heat_source"),
+    ("k_ke_vorticity", 6, "uc, vc, u, v -> ke, rel. vorticity (two kinds of workgroups of one launch)"),
     ("k_kinetic_energy", 5, "uc, vc, u, v -> ke"),
     ("k_vorticity", 3, "u, v -> rel. vorticity"),
     ("k_divdamp_fused", 3, "divgd, vorticity -> damped vorticity (+ the sponge levels: u, v, ua, va, uc, vc on two or three levels)"),
