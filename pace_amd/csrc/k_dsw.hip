@@ -1834,7 +1834,7 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   // slow, x06 -- profiles/r05_experiments)
   const Regions rke = (g.n >= 8) ? bgrid_regions(g, 3) : a2b_regions(g);
   if (cfg->hord_mt != 5 && cfg->hord_mt != 6) return PACE_ERR_UNSUPPORTED;
-  static const bool two_launches = getenv("PACE_KE_VORT_SPLIT") != nullptr;  // (A/B measurements: round 5's two launches)
+  const bool two_launches = getenv("PACE_KE_VORT_SPLIT") != nullptr;  // (read per call; A/B measurements, tests: round 5's two launches)
   if (!two_launches && PATCH_W == 64) {
     const int nbr = rke.first[rke.n];
     const dim3 pg = patch_grid(g, 1);

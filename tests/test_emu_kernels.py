@@ -299,6 +299,51 @@ def test_d_sw_separate_outputs_equal_in_place_emulated():
     check_dsw_contract_variants(dsw_contract_variants())
 
 
+def dsw_launch_structure_switches(gpu=False):
+    """The launch structure of d_sw is switchable for A/B measurements: the flux preparation as one launch
+    or three (+ the wind halo copy as a launch of its own), the kinetic energy and the vorticity as one launch or two.  Every
+    combination must leave the same bits in every argument over the whole storage (the separate-outputs contract, so that the
+    wind halo copy -- which moves between launches with the switches -- is compared too)."""
+    from pace_amd import _lib, synthetic
+    from pace_amd.fv3core import DGridShallowWaterLagrangianDynamicsConfig
+    from pace_amd.fv3core.stencils.d_sw import DGridShallowWaterLagrangianDynamics, get_column_namelist
+    from helpers import build_emu_canon
+
+    n, nz = (48, 7) if gpu else (24, 4)
+    lib = _lib.load() if gpu else _lib.Library(build_emu_canon())
+    m = synthetic.tile_metrics(n, nz)
+    s = synthetic.acoustic_state(m, n, nz)
+    env = Env(lib, "cuda" if gpu else "cpu", m, n, nz)
+    cfg = DGridShallowWaterLagrangianDynamicsConfig()
+    res = {}
+    for sw in ((), ("PACE_FXADV_SPLIT",), ("PACE_KE_VORT_SPLIT",), ("PACE_FXADV_SPLIT", "PACE_KE_VORT_SPLIT")):
+        for k in sw:
+            os.environ[k] = "1"
+        try:
+            op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, get_column_namelist(cfg, env.qf),
+                                                    False, False, cfg, swap_scalar_storage=True)
+            f = {k: env.q3(s[k]) for k in DSW_ARGS}
+            op(*[f[k] for k in DSW_ARGS], float(s["dt"]))
+            op.join()
+            if gpu:
+                import torch
+
+                torch.cuda.synchronize()
+            assert op._pingpong
+            res[sw] = {k: f[k].numpy().copy() for k in DSW_ARGS}
+        finally:
+            for k in sw:
+                os.environ.pop(k, None)
+    ref = res[()]
+    for sw, got in res.items():
+        for k in ref:
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (sw, k)
+
+
+def test_d_sw_launch_structure_switches_are_bit_identical_emulated():
+    dsw_launch_structure_switches()
+
+
 def test_swapped_storage_is_detectable():
     """What holds something derived from a Quantity's storage across a d_sw call with `swap_scalar_storage` can tell that it went
     stale: `Quantity.generation` counts the swaps, a tensor taken from `.data` before the call no longer aliases the Quantity,

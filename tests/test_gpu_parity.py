@@ -698,6 +698,15 @@ def test_d_sw_separate_outputs_equal_in_place(lib):
 
 
 @pytest.mark.gpu
+def test_d_sw_launch_structure_switches_are_bit_identical(lib):
+    """The GPU twin of ..._emulated at C48 x 7: FiniteVolumeFluxPrep as one launch or three, the wind halo copy inside it or as a launch of
+    its own, kinetic energy + vorticity as one launch or two -- every argument of d_sw bit for bit over the whole storage."""
+    from test_emu_kernels import dsw_launch_structure_switches
+
+    dsw_launch_structure_switches(gpu=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,nz", [(192, 8), (96, 79)])
 def test_c_sw_interior_tiles_equal_the_four_passes_on_the_device(n, nz):
     """c_sw on the device: k_csw_tile on the interior tiles (6 x 12 of them at C192) + the four passes on the band, beside each other
