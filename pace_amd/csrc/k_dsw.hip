@@ -192,7 +192,12 @@ k_kinetic_energy(Geo g, Met m, const real* __restrict__ uc, const real* __restri
 // behind them in the same level's share of the launch, the 64 x 4 patches of its vorticity.  Nothing is shared per point (x02: the
 // vorticity inside the kinetic-energy point function was slower); what is shared is the launch -- no drain / fill between the two -- and
 // the XCD: a level's blocks of both kinds run on one XCD, where the vorticity finds the rows of u and v the kinetic energy just read.
-template <int MORD>
+// KE_CH levels per thread: 2 where the launch still has many workgroups per compute unit (the metric values of a point are loaded once
+// for both levels: -7 us at C192), 1 on small tiles (C48: 12 against 15 us); 4 is no better than 1 at C192 (experiment x40).
+#ifndef KE_CH2_MIN_WGS
+#define KE_CH2_MIN_WGS 16384u  // workgroups the one-level launch must have for two levels per thread to pay (C192: 27 k; C96: 7.9 k)
+#endif
+template <int MORD, int KE_CH>
 __global__ void __launch_bounds__(256)
 k_ke_vorticity(Geo g, Met m, const real* __restrict__ uc, const real* __restrict__ vc, const real* __restrict__ u,
                const real* __restrict__ v, const real* __restrict__ ut, const real* __restrict__ vt, real* __restrict__ ke, double dt,
@@ -215,14 +220,19 @@ k_ke_vorticity(Geo g, Met m, const real* __restrict__ uc, const real* __restrict
     }
   }
 #endif
-  const int k = bz__;
+  const int k0 = bz__ * KE_CH;
   if (bx__ >= nbr) {
     // a patch of the vorticity (k_vorticity's enumeration)
     const int pb = bx__ - nbr, npx = (g.ni + PATCH_W - 1) / PATCH_W;
     const int i = (pb % npx) * PATCH_W + (int)threadIdx.x, j = (pb / npx) * PATCH_H + (int)threadIdx.y;
     if (i > g.ni - 2 || j > g.nj - 2) return;
-    const long c = IDX3(g, i, j, k);
-    vort[c] = rel_vorticity(g, m, u, v, c, IDX2(g, i, j));
+#pragma unroll
+    for (int t = 0; t < KE_CH; ++t) {
+      const int k = k0 + t;
+      if (k >= g.nk) break;
+      const long c = IDX3(g, i, j, k);
+      vort[c] = rel_vorticity(g, m, u, v, c, IDX2(g, i, j));
+    }
     return;
   }
   int reg__ = 0;
@@ -241,7 +251,12 @@ k_ke_vorticity(Geo g, Met m, const real* __restrict__ uc, const real* __restrict
     i = R.ib[reg__] + p__ % w__;
     if (j > R.je[reg__]) return;
   }
-  kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, (real*)nullptr, i, j, k, interior, true);
+#pragma unroll
+  for (int t = 0; t < KE_CH; ++t) {
+    const int k = k0 + t;
+    if (k >= g.nk) break;
+    kinetic_energy_point<MORD>(g, m, uc, vc, u, v, ut, vt, ke, dt, (real*)nullptr, i, j, k, interior, true);
+  }
 }
 
 // Separate outputs of the winds (which the caller swaps in): the output buffers get the halo the inputs have -- the storage outside
@@ -1838,12 +1853,18 @@ int launch_d_sw(const Geo& g, const Met& m, const pace_column_t* col, const pace
   if (!two_launches && PATCH_W == 64) {
     const int nbr = rke.first[rke.n];
     const dim3 pg = patch_grid(g, 1);
-    const dim3 grid((unsigned)nbr + pg.x * pg.y, 1, (unsigned)nk);
+    const unsigned nbl = (unsigned)nbr + pg.x * pg.y;
+    const char* ke_ch_env = getenv("PACE_KE_LEVELS");  // (read per call; A/B measurements, tests: 1 or 2)
+    const int ke_ch = ke_ch_env ? (ke_ch_env[0] == '2' ? 2 : 1) : (nbl * (unsigned)nk >= KE_CH2_MIN_WGS ? 2 : 1);
+#define KE_GO(MORD, CH)                                                                                                                   \
+  hipLaunchKernelGGL((k_ke_vorticity<MORD, CH>), dim3(nbl, 1, (unsigned)((nk + CH - 1) / CH)), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, \
+                     W.ke, dt, rke, W.wk, nbr)
     if (cfg->hord_mt == 5) {
-      hipLaunchKernelGGL(k_ke_vorticity<5>, grid, dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nbr);
+      if (ke_ch == 2) KE_GO(5, 2); else KE_GO(5, 1);
     } else {
-      hipLaunchKernelGGL(k_ke_vorticity<6>, grid, dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, W.wk, nbr);
+      if (ke_ch == 2) KE_GO(6, 2); else KE_GO(6, 1);
     }
+#undef KE_GO
   } else {
   if (cfg->hord_mt == 5) {
     hipLaunchKernelGGL(k_kinetic_energy<5>, regions_grid(rke, nk), dim3(64, 4), 0, st, g, m, uc, vc, u, v, W.ut, W.vt, W.ke, dt, rke, (real*)nullptr, rke.n);

@@ -316,9 +316,10 @@ def dsw_launch_structure_switches(gpu=False):
     env = Env(lib, "cuda" if gpu else "cpu", m, n, nz)
     cfg = DGridShallowWaterLagrangianDynamicsConfig()
     res = {}
-    for sw in ((), ("PACE_FXADV_SPLIT",), ("PACE_KE_VORT_SPLIT",), ("PACE_FXADV_SPLIT", "PACE_KE_VORT_SPLIT")):
+    # (PACE_KE_LEVELS: levels per thread of the kinetic energy / vorticity launch -- 2 on large tiles, 1 on small ones by itself)
+    for sw in ((), ("PACE_FXADV_SPLIT",), ("PACE_KE_VORT_SPLIT",), ("PACE_FXADV_SPLIT", "PACE_KE_VORT_SPLIT"), ("PACE_KE_LEVELS",)):
         for k in sw:
-            os.environ[k] = "1"
+            os.environ[k] = "2" if k == "PACE_KE_LEVELS" else "1"
         try:
             op = DGridShallowWaterLagrangianDynamics(env.stencil_factory, env.qf, env.grid_data, env.damping, get_column_namelist(cfg, env.qf),
                                                     False, False, cfg, swap_scalar_storage=True)
